@@ -1,0 +1,297 @@
+"""Packed rigid-body model ("LHWM v1") shared by the HIP stepper and the CPU oracle.
+
+The reference keeps its model in a MuJoCo ``mjModel`` built by
+``MjSpec.from_file(...).compile()`` (reference envs/common/mujoco_env.py:24-25).
+Here the same information (the subset the hot path reads)
+is flattened into two blobs -- one int32, one float64 -- whose layout is fixed
+by ``FIELDS`` below.  ``include/lhw_model_fields.h`` is generated from this
+table (``python -m learninghumanoidwalking_amd.model``) so the C side and the
+Python side can never disagree.
+
+Field names follow MuJoCo's ``mjModel`` names on purpose: a maintainer with a
+real ``mujoco.MjModel`` can fill the blobs with ``pack_from_mjmodel`` instead of
+using our MJCF-subset compiler.
+"""
+
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+
+import numpy as np
+
+MAGIC = 0x4C48574D  # "LHWM"
+VERSION = 1
+
+# joint types / geom types use MuJoCo's enum values (mjtJoint, mjtGeom)
+JNT_FREE, JNT_BALL, JNT_SLIDE, JNT_HINGE = 0, 1, 2, 3
+GEOM_PLANE, GEOM_HFIELD, GEOM_SPHERE, GEOM_CAPSULE, GEOM_ELLIPSOID, GEOM_CYLINDER, GEOM_BOX = 0, 1, 2, 3, 4, 5, 6
+
+# scalar header (int32 blob, fixed positions)
+I_HEADER = [
+    "magic", "version", "nq", "nv", "nu", "nbody", "njnt", "ngeom", "npair", "nsite",
+    "iterations", "ls_iterations", "cone", "disableflags", "n_ifields", "n_dfields",
+]
+# scalar header (float64 blob, fixed positions)
+D_HEADER = [
+    "timestep", "gravity_x", "gravity_y", "gravity_z", "tolerance", "ls_tolerance",
+    "impratio", "meaninertia", "totalmass", "o_margin",
+]
+
+# (name, blob, width, count-symbol)
+FIELDS = [
+    # bodies
+    ("body_parentid", "i", 1, "nbody"),
+    ("body_rootid", "i", 1, "nbody"),
+    ("body_weldid", "i", 1, "nbody"),
+    ("body_jntadr", "i", 1, "nbody"),
+    ("body_jntnum", "i", 1, "nbody"),
+    ("body_dofadr", "i", 1, "nbody"),
+    ("body_dofnum", "i", 1, "nbody"),
+    ("body_pos", "d", 3, "nbody"),
+    ("body_quat", "d", 4, "nbody"),
+    ("body_ipos", "d", 3, "nbody"),
+    ("body_iquat", "d", 4, "nbody"),
+    ("body_mass", "d", 1, "nbody"),
+    ("body_inertia", "d", 3, "nbody"),
+    ("body_invweight0", "d", 2, "nbody"),
+    # joints
+    ("jnt_type", "i", 1, "njnt"),
+    ("jnt_bodyid", "i", 1, "njnt"),
+    ("jnt_qposadr", "i", 1, "njnt"),
+    ("jnt_dofadr", "i", 1, "njnt"),
+    ("jnt_limited", "i", 1, "njnt"),
+    ("jnt_pos", "d", 3, "njnt"),
+    ("jnt_axis", "d", 3, "njnt"),
+    ("jnt_range", "d", 2, "njnt"),
+    ("jnt_solref", "d", 2, "njnt"),
+    ("jnt_solimp", "d", 5, "njnt"),
+    ("jnt_margin", "d", 1, "njnt"),
+    # dofs
+    ("dof_bodyid", "i", 1, "nv"),
+    ("dof_jntid", "i", 1, "nv"),
+    ("dof_parentid", "i", 1, "nv"),
+    ("dof_armature", "d", 1, "nv"),
+    ("dof_damping", "d", 1, "nv"),
+    ("dof_frictionloss", "d", 1, "nv"),
+    ("dof_invweight0", "d", 1, "nv"),
+    ("dof_solref", "d", 2, "nv"),
+    ("dof_solimp", "d", 5, "nv"),
+    ("qpos0", "d", 1, "nq"),
+    # geoms
+    ("geom_type", "i", 1, "ngeom"),
+    ("geom_bodyid", "i", 1, "ngeom"),
+    ("geom_contype", "i", 1, "ngeom"),
+    ("geom_conaffinity", "i", 1, "ngeom"),
+    ("geom_condim", "i", 1, "ngeom"),
+    ("geom_priority", "i", 1, "ngeom"),
+    ("geom_pos", "d", 3, "ngeom"),
+    ("geom_quat", "d", 4, "ngeom"),
+    ("geom_size", "d", 3, "ngeom"),
+    ("geom_friction", "d", 3, "ngeom"),
+    ("geom_solmix", "d", 1, "ngeom"),
+    ("geom_solref", "d", 2, "ngeom"),
+    ("geom_solimp", "d", 5, "ngeom"),
+    ("geom_margin", "d", 1, "ngeom"),
+    ("geom_gap", "d", 1, "ngeom"),
+    # statically filtered collision candidates, in MuJoCo's body-pair order
+    ("pair_geom1", "i", 1, "npair"),
+    ("pair_geom2", "i", 1, "npair"),
+    # actuators (motors on a joint transmission only)
+    ("actuator_trnid", "i", 1, "nu"),
+    ("actuator_ctrllimited", "i", 1, "nu"),
+    ("actuator_forcelimited", "i", 1, "nu"),
+    ("actuator_gear", "d", 1, "nu"),
+    ("actuator_ctrlrange", "d", 2, "nu"),
+    ("actuator_forcerange", "d", 2, "nu"),
+    # sites
+    ("site_bodyid", "i", 1, "nsite"),
+    ("site_pos", "d", 3, "nsite"),
+    ("site_quat", "d", 4, "nsite"),
+]
+
+I_FIELDS = [f for f in FIELDS if f[1] == "i"]
+D_FIELDS = [f for f in FIELDS if f[1] == "d"]
+
+# mjtDisableBit subset
+DSBL_ACTUATION = 1 << 10  # informational: actuation is disabled per call, not in the model
+DSBL_REFSAFE = 1 << 11
+DSBL_EULERDAMP = 1 << 14
+DSBL_WARMSTART = 1 << 7
+
+
+@dataclass
+class Model:
+    """Compiled model: scalars + one numpy array per FIELDS entry + name tables."""
+
+    nq: int = 0
+    nv: int = 0
+    nu: int = 0
+    nbody: int = 0
+    njnt: int = 0
+    ngeom: int = 0
+    npair: int = 0
+    nsite: int = 0
+    iterations: int = 100
+    ls_iterations: int = 50
+    cone: int = 0  # 0 = pyramidal (MuJoCo default)
+    disableflags: int = 0
+    timestep: float = 0.002
+    gravity: tuple = (0.0, 0.0, -9.81)
+    tolerance: float = 1e-8
+    ls_tolerance: float = 0.01
+    impratio: float = 1.0
+    meaninertia: float = 1.0
+    totalmass: float = 0.0
+    o_margin: float = 0.0
+    arrays: dict = field(default_factory=dict)
+    body_names: list = field(default_factory=list)
+    jnt_names: list = field(default_factory=list)
+    geom_names: list = field(default_factory=list)
+    actuator_names: list = field(default_factory=list)
+    site_names: list = field(default_factory=list)
+
+    def __getattr__(self, name):
+        arrays = self.__dict__.get("arrays", {})
+        if name in arrays:
+            return arrays[name]
+        raise AttributeError(name)
+
+    # -- name lookups (same spirit as mjModel.body(name).id) --------------------------
+    def body_id(self, name: str) -> int:
+        return self.body_names.index(name)
+
+    def jnt_id(self, name: str) -> int:
+        return self.jnt_names.index(name)
+
+    def geom_id(self, name: str) -> int:
+        return self.geom_names.index(name)
+
+    def site_id(self, name: str) -> int:
+        return self.site_names.index(name)
+
+    def count(self, sym: str) -> int:
+        return int(getattr(self, sym))
+
+    def copy(self) -> "Model":
+        m = Model(**{k: v for k, v in self.__dict__.items() if k != "arrays"})
+        m.arrays = {k: v.copy() for k, v in self.arrays.items()}
+        for k in ("body_names", "jnt_names", "geom_names", "actuator_names", "site_names"):
+            setattr(m, k, list(getattr(self, k)))
+        return m
+
+    # -- packing ------------------------------------------------------------------
+    def pack(self) -> tuple[np.ndarray, np.ndarray]:
+        """Return (int32 blob, float64 blob) in the LHWM v1 layout."""
+        ihead = np.zeros(len(I_HEADER), dtype=np.int32)
+        vals = dict(
+            magic=MAGIC, version=VERSION, nq=self.nq, nv=self.nv, nu=self.nu, nbody=self.nbody,
+            njnt=self.njnt, ngeom=self.ngeom, npair=self.npair, nsite=self.nsite,
+            iterations=self.iterations, ls_iterations=self.ls_iterations, cone=self.cone,
+            disableflags=self.disableflags, n_ifields=len(I_FIELDS), n_dfields=len(D_FIELDS),
+        )
+        for k, name in enumerate(I_HEADER):
+            ihead[k] = np.int32(np.uint32(vals[name]).astype(np.int32)) if name == "magic" else vals[name]
+        dhead = np.array(
+            [self.timestep, *self.gravity, self.tolerance, self.ls_tolerance, self.impratio,
+             self.meaninertia, self.totalmass, self.o_margin], dtype=np.float64)
+        assert len(dhead) == len(D_HEADER)
+
+        # offset tables follow the headers; both index into their own blob
+        ioff = np.zeros(len(I_FIELDS), dtype=np.int32)
+        doff = np.zeros(len(D_FIELDS), dtype=np.int32)
+        ichunks, dchunks = [], []
+        ipos = len(I_HEADER) + len(I_FIELDS) + len(D_FIELDS)
+        dpos = len(D_HEADER)
+        for k, (name, _, width, sym) in enumerate(I_FIELDS):
+            arr = np.ascontiguousarray(self.arrays[name], dtype=np.int32).reshape(-1)
+            assert arr.size == width * self.count(sym), (name, arr.size, width, self.count(sym))
+            ioff[k] = ipos
+            ichunks.append(arr)
+            ipos += arr.size
+        for k, (name, _, width, sym) in enumerate(D_FIELDS):
+            arr = np.ascontiguousarray(self.arrays[name], dtype=np.float64).reshape(-1)
+            assert arr.size == width * self.count(sym), (name, arr.size, width, self.count(sym))
+            doff[k] = dpos
+            dchunks.append(arr)
+            dpos += arr.size
+        iblob = np.concatenate([ihead, ioff, doff] + ichunks).astype(np.int32)
+        dblob = np.concatenate([dhead] + dchunks).astype(np.float64)
+        return iblob, dblob
+
+
+def generate_header() -> str:
+    """C header with the blob layout (written to include/lhw_model_fields.h)."""
+    out = [
+        "/* GENERATED by `python -m learninghumanoidwalking_amd.model` -- do not edit.",
+        " * Layout of the packed model blobs (LHWM v1) consumed by lhw_create().",
+        " * Field names mirror MuJoCo's mjModel (the reference's model container,",
+        " * reference envs/common/mujoco_env.py:24-25). */",
+        "#ifndef LHW_MODEL_FIELDS_H",
+        "#define LHW_MODEL_FIELDS_H",
+        f"#define LHW_MODEL_MAGIC 0x{MAGIC:08X}",
+        f"#define LHW_MODEL_VERSION {VERSION}",
+        "/* int32 blob: scalar header */",
+        "enum LhwIHeader {",
+    ]
+    out += [f"  LHW_IH_{n.upper()} = {k}," for k, n in enumerate(I_HEADER)]
+    out += [f"  LHW_IH_COUNT = {len(I_HEADER)}", "};", "/* float64 blob: scalar header */", "enum LhwDHeader {"]
+    out += [f"  LHW_DH_{n.upper()} = {k}," for k, n in enumerate(D_HEADER)]
+    out += [f"  LHW_DH_COUNT = {len(D_HEADER)}", "};"]
+    out += ["/* int32 fields: offset of field k (into the int32 blob) is iblob[LHW_IH_COUNT + k] */", "enum LhwIField {"]
+    out += [f"  LHW_IF_{n.upper()} = {k},  /* width {w}, count {s} */" for k, (n, _, w, s) in enumerate(I_FIELDS)]
+    out += [f"  LHW_IF_COUNT = {len(I_FIELDS)}", "};"]
+    out += [
+        "/* float64 fields: offset of field k (into the float64 blob) is iblob[LHW_IH_COUNT + LHW_IF_COUNT + k] */",
+        "enum LhwDField {",
+    ]
+    out += [f"  LHW_DF_{n.upper()} = {k},  /* width {w}, count {s} */" for k, (n, _, w, s) in enumerate(D_FIELDS)]
+    out += [f"  LHW_DF_COUNT = {len(D_FIELDS)}", "};", "#endif", ""]
+    return "\n".join(out)
+
+
+def pack_from_mjmodel(m) -> tuple[np.ndarray, np.ndarray]:
+    """Fill the blobs from a real ``mujoco.MjModel`` (reference-side binding).
+
+    Not exercised in this container (mujoco is not installed); see INTEGRATION.md.
+    Collision candidates are rebuilt with the same static filter as our compiler.
+    """
+    from . import mjcf  # local import: mjcf depends on this module
+
+    mod = Model(
+        nq=m.nq, nv=m.nv, nu=m.nu, nbody=m.nbody, njnt=m.njnt, ngeom=m.ngeom, nsite=m.nsite,
+        iterations=m.opt.iterations, ls_iterations=m.opt.ls_iterations, cone=int(m.opt.cone),
+        disableflags=int(m.opt.disableflags), timestep=float(m.opt.timestep),
+        gravity=tuple(float(g) for g in m.opt.gravity), tolerance=float(m.opt.tolerance),
+        ls_tolerance=float(m.opt.ls_tolerance), impratio=float(m.opt.impratio),
+        meaninertia=float(m.stat.meaninertia), totalmass=float(np.sum(m.body_mass)),
+        o_margin=float(m.opt.o_margin),
+    )
+    a = mod.arrays
+    for name, _, width, sym in FIELDS:
+        if name.startswith("pair_"):
+            continue
+        if name == "actuator_trnid":
+            a[name] = np.asarray(m.actuator_trnid)[:, 0].copy()
+        elif name == "actuator_gear":
+            a[name] = np.asarray(m.actuator_gear)[:, 0].copy()
+        elif name == "dof_jntid":
+            a[name] = np.asarray(m.dof_jntid).copy()
+        else:
+            a[name] = np.asarray(getattr(m, name)).copy()
+    excludes = set()
+    for k in range(m.nexclude):
+        sig = int(m.exclude_signature[k])
+        excludes.add((sig >> 16, sig & 0xFFFF))
+    g1, g2 = mjcf.build_pairs(mod, excludes)
+    a["pair_geom1"], a["pair_geom2"] = g1, g2
+    mod.npair = len(g1)
+    return mod.pack()
+
+
+if __name__ == "__main__":
+    import os
+
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "lhw_model_fields.h")
+    with open(path, "w") as f:
+        f.write(generate_header())
+    print("wrote", path)
