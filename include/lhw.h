@@ -1,0 +1,135 @@
+/* lhw.h -- C ABI of the MI355X-native batched environment stepper + PPO update
+ * (liblhw.so, built from learninghumanoidwalking_amd/csrc for gfx950).
+ *
+ * This is the drop-in boundary of the hot path.  The reference has
+ * no FFI of its own -- it is pure Python over third-party wheels -- so each entry point
+ * below names the reference interface whose work it takes over:
+ *
+ *   lhw_env_create   <- env_fn() / BaseHumanoidEnv.__init__ + MujocoEnv.__init__
+ *                       (reference envs/common/base_humanoid_env.py:38-74,
+ *                        envs/common/mujoco_env.py:16-36, envs/cartpole/cartpole_env.py:82-107)
+ *   lhw_env_reset    <- MujocoEnv.reset -> reset_model
+ *                       (envs/common/mujoco_env.py:113-116, base_humanoid_env.py:247-276,
+ *                        envs/cartpole/cartpole_env.py:109-121)
+ *   lhw_env_step     <- env.step(action) for every env of the batch, plus the per-step episode
+ *                       bookkeeping of RolloutWorker.sample (truncation at max_traj_len,
+ *                       terminal observation for the bootstrap value, reset on episode end)
+ *                       (base_humanoid_env.py:199-227, robots/robot_base.py:41-98,
+ *                        envs/common/robot_interface.py:493-546 [PD + mj_step],
+ *                        rl/workers/rollout_worker.py:142-181)
+ *   lhw_env_get_state / lhw_env_set_state
+ *                    <- data.qpos / data.qvel reads, MujocoEnv.set_state
+ *                       (envs/common/mujoco_env.py:118-127); parity hooks
+ *   lhw_env_set_iteration <- RolloutWorker.sync_state's env.robot.iteration_count = itr
+ *                       (rl/workers/rollout_worker.py:95)
+ *   lhw_gae          <- PPOBuffer.finish_path over every trajectory of the batch
+ *                       (rl/storage/rollout_storage.py:53-85)
+ *   lhw_mlp_*, lhw_ppo_* <- Gaussian_FF_Actor / FF_V forward and PPO.update_actor_critic
+ *                       (rl/policies/actor.py:160-188, rl/policies/critic.py:41-49,
+ *                        rl/algos/ppo.py:299-406)
+ *
+ * Conventions: every function returns 0 on success or a negative LhwStatus; the message is
+ * available from lhw_last_error().  The caller owns every buffer and passes raw device (or,
+ * where stated, host) pointers -- no torch types cross this boundary.  `stream` is a
+ * hipStream_t passed as void* (NULL = the default stream); calls are asynchronous with respect
+ * to it unless stated.  One handle belongs to one device and one host thread at a time.
+ */
+#ifndef LHW_H
+#define LHW_H
+
+#include <stdint.h>
+
+#include "lhw_model_fields.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+  LHW_OK = 0,
+  LHW_ERR_ARG = -1,         /* bad argument / size mismatch */
+  LHW_ERR_HIP = -2,         /* HIP runtime error (message has hipGetErrorString) */
+  LHW_ERR_MODEL = -3,       /* model blob malformed or exceeds a compiled-in limit */
+  LHW_ERR_UNSUPPORTED = -4, /* feature outside the implemented subset */
+  LHW_ERR_NO_DEVICE = -5    /* no usable GPU: the product path has no CPU fallback */
+} LhwStatus;
+
+typedef enum {
+  LHW_TASK_CARTPOLE = 0, /* reference envs/cartpole/cartpole_env.py */
+  LHW_TASK_JVRC_WALK = 1 /* reference envs/jvrc/jvrc_walk.py + tasks/walking_task.py */
+} LhwTask;
+
+/* done flags written by lhw_env_step */
+#define LHW_DONE_TERMINATED 1u /* env.step returned done=True */
+#define LHW_DONE_TRUNCATED 2u  /* trajectory reached max_traj_len (rollout_worker.py:152) */
+
+typedef struct LhwEnv LhwEnv;
+
+typedef struct {
+  int32_t task;         /* LhwTask */
+  int32_t n_envs;       /* batch size N */
+  int32_t device;       /* HIP device ordinal */
+  int32_t frame_skip;   /* sim sub-steps per control step (control_dt / sim_dt) */
+  int32_t max_traj_len; /* >0: truncate + auto-reset like RolloutWorker.sample; 0: never reset inside step */
+  int32_t env_id_base;  /* global index of env 0 (RNG keys use env_id_base + n): multi-GPU sharding */
+  uint64_t seed;        /* counter-based RNG key (replaces the reference's global np.random stream) */
+  double action_smoothing;       /* base_humanoid_env.py:209 (unused by cartpole) */
+  const double* kp;              /* [nu] PD gains */
+  const double* kd;              /* [nu] */
+  const double* nominal_qpos;    /* [nq] reset pose (jvrc_base.py:52-54); NULL -> qpos0 */
+  const double* action_offset;   /* [nu] nominal joint pose added to targets (base_humanoid_env.py:212) */
+  const double* task_params;     /* task-specific doubles, see LHW_TP_* */
+  int32_t n_task_params;
+  const int32_t* task_iparams;   /* task-specific ints, see LHW_TI_* */
+  int32_t n_task_iparams;
+  const double* clock_lut;       /* walking: [4][period] r_frc, r_vel, l_frc, l_vel at integer phases
+                                    (tasks/rewards.py:196-300 evaluated on 0..period-1) */
+  int32_t period;
+} LhwEnvConfig;
+
+/* task_params indices (walking) */
+enum { LHW_TP_GOAL_HEIGHT = 0, LHW_TP_COUNT = 1 };
+/* task_iparams indices (walking): body ids */
+enum { LHW_TI_ROOT_BODY = 0, LHW_TI_HEAD_BODY = 1, LHW_TI_RFOOT_BODY = 2, LHW_TI_LFOOT_BODY = 3, LHW_TI_COUNT = 4 };
+
+int lhw_version(void);
+const char* lhw_last_error(void);
+
+/* model_i / model_d: packed model blobs (host pointers), layout in lhw_model_fields.h */
+int lhw_env_create(const int32_t* model_i, int64_t n_model_i, const double* model_d, int64_t n_model_d,
+                   const LhwEnvConfig* cfg, LhwEnv** out);
+int lhw_env_destroy(LhwEnv* env);
+
+int lhw_env_obs_dim(const LhwEnv* env);
+int lhw_env_act_dim(const LhwEnv* env);
+int lhw_env_num_reward_terms(const LhwEnv* env);
+int lhw_env_nq(const LhwEnv* env);
+int lhw_env_nv(const LhwEnv* env);
+
+/* Reset the envs whose mask byte is non-zero (mask_dev == NULL: all).  obs_dev [N][obs_dim] f32
+ * receives the first observation of the reset envs (rows of other envs are left untouched). */
+int lhw_env_reset(LhwEnv* env, const uint8_t* mask_dev, float* obs_dev, void* stream);
+
+/* One control step for all N envs.
+ *   act_dev      [N][act_dim] f32, in
+ *   obs_dev      [N][obs_dim] f32, out: observation to act on next (after the auto-reset, if any)
+ *   term_obs_dev [N][obs_dim] f32, out, nullable: observation returned by env.step itself
+ *                (differs from obs_dev only where the episode ended: bootstrap input)
+ *   rew_dev      [N] f32, out: sum of reward terms in the reference's dict order
+ *   done_dev     [N] u8, out: LHW_DONE_* flags
+ *   rew_terms_dev [N][num_reward_terms] f32, out, nullable */
+int lhw_env_step(LhwEnv* env, const float* act_dev, float* obs_dev, float* term_obs_dev, float* rew_dev,
+                 uint8_t* done_dev, float* rew_terms_dev, void* stream);
+
+/* Parity hooks; HOST pointers, synchronous.  qpos [N][nq], qvel [N][nv] float64. */
+int lhw_env_get_state(LhwEnv* env, double* qpos_host, double* qvel_host);
+int lhw_env_set_state(LhwEnv* env, const double* qpos_host, const double* qvel_host);
+/* Episode statistics accumulated on device since the last call: sum of finished-episode returns,
+ * sum of finished-episode lengths, number of finished episodes (host pointers, synchronous, resets them). */
+int lhw_env_pop_episode_stats(LhwEnv* env, double* ret_sum, double* len_sum, int64_t* count);
+int lhw_env_set_iteration(LhwEnv* env, int64_t iteration);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LHW_H */

@@ -1,0 +1,80 @@
+"""ctypes loader for liblhw.so (the C ABI in include/lhw.h).  No CPU fallback: if the
+library is missing or no GPU is visible, calls fail loudly."""
+from __future__ import annotations
+
+import ctypes
+import glob
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(_HERE)
+LIB_PATH = os.path.join(_HERE, "liblhw.so")
+_LIB = None
+
+
+class LhwError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"liblhw error {code}: {msg}")
+        self.code = code
+
+
+class LhwEnvConfig(ctypes.Structure):
+    _fields_ = [
+        ("task", ctypes.c_int32), ("n_envs", ctypes.c_int32), ("device", ctypes.c_int32),
+        ("frame_skip", ctypes.c_int32), ("max_traj_len", ctypes.c_int32), ("env_id_base", ctypes.c_int32),
+        ("seed", ctypes.c_uint64), ("action_smoothing", ctypes.c_double),
+        ("kp", ctypes.c_void_p), ("kd", ctypes.c_void_p), ("nominal_qpos", ctypes.c_void_p),
+        ("action_offset", ctypes.c_void_p), ("task_params", ctypes.c_void_p), ("n_task_params", ctypes.c_int32),
+        ("task_iparams", ctypes.c_void_p), ("n_task_iparams", ctypes.c_int32),
+        ("clock_lut", ctypes.c_void_p), ("period", ctypes.c_int32),
+    ]
+
+
+def sources():
+    return sorted(glob.glob(os.path.join(_HERE, "csrc", "*.hip")))
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile liblhw.so for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    srcs = sources()
+    deps = srcs + glob.glob(os.path.join(_HERE, "csrc", "*.h")) + glob.glob(os.path.join(_ROOT, "include", "*.h"))
+    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
+        return LIB_PATH
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", LIB_PATH] + srcs
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+def lib():
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise LhwError(-5, f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(there is no CPU fallback for the stepper / PPO kernels)")
+    L = ctypes.CDLL(LIB_PATH)
+    vp, i32, i64 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64
+    L.lhw_version.restype = ctypes.c_int
+    L.lhw_last_error.restype = ctypes.c_char_p
+    L.lhw_env_create.argtypes = [vp, i64, vp, i64, ctypes.POINTER(LhwEnvConfig), ctypes.POINTER(vp)]
+    L.lhw_env_destroy.argtypes = [vp]
+    for f in ("lhw_env_obs_dim", "lhw_env_act_dim", "lhw_env_num_reward_terms", "lhw_env_nq", "lhw_env_nv"):
+        getattr(L, f).argtypes = [vp]
+    L.lhw_env_reset.argtypes = [vp, vp, vp, vp]
+    L.lhw_env_step.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
+    L.lhw_env_get_state.argtypes = [vp, vp, vp]
+    L.lhw_env_set_state.argtypes = [vp, vp, vp]
+    L.lhw_env_pop_episode_stats.argtypes = [vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double),
+                                            ctypes.POINTER(i64)]
+    L.lhw_env_set_iteration.argtypes = [vp, i64]
+    _LIB = L
+    return L
+
+
+def check(rc: int):
+    if rc != 0:
+        raise LhwError(rc, lib().lhw_last_error().decode(errors="replace"))

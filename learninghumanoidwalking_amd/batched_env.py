@@ -1,0 +1,133 @@
+"""Batched environments on one MI355X: thin Python host over the C ABI (include/lhw.h).
+
+`BatchedEnv` is what the trainer uses (N envs advanced by one kernel launch per control
+step); the N=1 `BaseHumanoidEnv`-shaped adapters live in ``envs/``.  torch is used only to
+own device buffers and streams.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+from .model import Model
+
+TASK_CARTPOLE, TASK_JVRC_WALK = 0, 1
+DONE_TERMINATED, DONE_TRUNCATED = 1, 2
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _stream_ptr(device):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+class BatchedEnv:
+    """N copies of one task, state resident in HBM.
+
+    Mirrors, per env, the reference's ``env.reset()`` / ``env.step(a)`` contract (reference
+    envs/common/base_humanoid_env.py:199-276) plus the episode bookkeeping of
+    ``RolloutWorker.sample`` (reference rl/workers/rollout_worker.py:142-181) when
+    ``max_traj_len > 0``.
+    """
+
+    def __init__(self, model: Model, task: int, n_envs: int, *, frame_skip: int, kp, kd, seed: int = 0,
+                 device: int | torch.device = 0, max_traj_len: int = 0, env_id_base: int = 0,
+                 action_smoothing: float = 1.0, nominal_qpos=None, action_offset=None, task_params=None,
+                 task_iparams=None, clock_lut=None):
+        if not torch.cuda.is_available():
+            raise _lib.LhwError(-5, "no GPU visible: BatchedEnv has no CPU fallback")
+        self.device = torch.device("cuda", device) if isinstance(device, int) else device
+        self.model = model
+        self.n_envs = int(n_envs)
+        self.task = task
+        self._ib, self._db = model.pack()
+        keep = []
+
+        def arr(x, dt):
+            if x is None:
+                return None, 0
+            a = np.ascontiguousarray(x, dtype=dt)
+            keep.append(a)
+            return a.ctypes.data, a.size
+
+        cfg = _lib.LhwEnvConfig()
+        cfg.task, cfg.n_envs, cfg.device = task, self.n_envs, self.device.index or 0
+        cfg.frame_skip, cfg.max_traj_len, cfg.env_id_base = int(frame_skip), int(max_traj_len), int(env_id_base)
+        cfg.seed, cfg.action_smoothing = int(seed) & (2**64 - 1), float(action_smoothing)
+        cfg.kp, _ = arr(np.atleast_1d(kp), np.float64)
+        cfg.kd, _ = arr(np.atleast_1d(kd), np.float64)
+        cfg.nominal_qpos, _ = arr(nominal_qpos, np.float64)
+        cfg.action_offset, _ = arr(action_offset, np.float64)
+        cfg.task_params, cfg.n_task_params = arr(task_params, np.float64)
+        cfg.task_iparams, cfg.n_task_iparams = arr(task_iparams, np.int32)
+        lut, _ = arr(clock_lut, np.float64)
+        cfg.clock_lut = lut
+        cfg.period = 0 if clock_lut is None else int(np.asarray(clock_lut).shape[-1])
+        self._h = ctypes.c_void_p()
+        L = _lib.lib()
+        _lib.check(L.lhw_env_create(self._ib.ctypes.data, self._ib.size, self._db.ctypes.data, self._db.size,
+                                    ctypes.byref(cfg), ctypes.byref(self._h)))
+        self._L = L
+        self.obs_dim = L.lhw_env_obs_dim(self._h)
+        self.act_dim = L.lhw_env_act_dim(self._h)
+        self.n_terms = L.lhw_env_num_reward_terms(self._h)
+        self.nq, self.nv = L.lhw_env_nq(self._h), L.lhw_env_nv(self._h)
+        N, dev = self.n_envs, self.device
+        self.obs = torch.zeros(N, self.obs_dim, dtype=torch.float32, device=dev)
+        self.term_obs = torch.zeros(N, self.obs_dim, dtype=torch.float32, device=dev)
+        self.rew = torch.zeros(N, dtype=torch.float32, device=dev)
+        self.done = torch.zeros(N, dtype=torch.uint8, device=dev)
+        self.rew_terms = torch.zeros(N, self.n_terms, dtype=torch.float32, device=dev)
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._L.lhw_env_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def reset(self, mask: torch.Tensor | None = None) -> torch.Tensor:
+        if mask is not None:
+            assert mask.dtype == torch.uint8 and mask.is_cuda and mask.numel() == self.n_envs
+        _lib.check(self._L.lhw_env_reset(self._h, _ptr(mask), _ptr(self.obs), _stream_ptr(self.device)))
+        return self.obs
+
+    def step(self, act: torch.Tensor, obs_out: torch.Tensor | None = None, term_obs_out: torch.Tensor | None = None,
+             rew_out: torch.Tensor | None = None, done_out: torch.Tensor | None = None):
+        """act [N, act_dim] float32 on device.  Returns (obs, rew, done, term_obs) device tensors."""
+        assert act.is_cuda and act.dtype == torch.float32 and act.is_contiguous() and act.numel() == self.n_envs * self.act_dim
+        obs = self.obs if obs_out is None else obs_out
+        tob = self.term_obs if term_obs_out is None else term_obs_out
+        rew = self.rew if rew_out is None else rew_out
+        done = self.done if done_out is None else done_out
+        _lib.check(self._L.lhw_env_step(self._h, _ptr(act), _ptr(obs), _ptr(tob), _ptr(rew), _ptr(done),
+                                        _ptr(self.rew_terms), _stream_ptr(self.device)))
+        return obs, rew, done, tob
+
+    def get_state(self):
+        qpos = np.zeros((self.n_envs, self.nq))
+        qvel = np.zeros((self.n_envs, self.nv))
+        _lib.check(self._L.lhw_env_get_state(self._h, qpos.ctypes.data, qvel.ctypes.data))
+        return qpos, qvel
+
+    def set_state(self, qpos, qvel):
+        qpos = np.ascontiguousarray(qpos, dtype=np.float64).reshape(self.n_envs, self.nq)
+        qvel = np.ascontiguousarray(qvel, dtype=np.float64).reshape(self.n_envs, self.nv)
+        _lib.check(self._L.lhw_env_set_state(self._h, qpos.ctypes.data, qvel.ctypes.data))
+
+    def pop_episode_stats(self):
+        r, l, c = ctypes.c_double(), ctypes.c_double(), ctypes.c_int64()
+        _lib.check(self._L.lhw_env_pop_episode_stats(self._h, ctypes.byref(r), ctypes.byref(l), ctypes.byref(c)))
+        return r.value, l.value, c.value
+
+    def set_iteration(self, it: int):
+        _lib.check(self._L.lhw_env_set_iteration(self._h, int(it)))

@@ -1,0 +1,2 @@
+"""Host-side mirrors of the reference's environments (reference envs/__init__.py:13-19)."""
+from .cartpole import CartpoleSpec, make_cartpole  # noqa: F401
