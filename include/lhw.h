@@ -129,6 +129,49 @@ int lhw_env_set_state(LhwEnv* env, const double* qpos_host, const double* qvel_h
 int lhw_env_pop_episode_stats(LhwEnv* env, double* ret_sum, double* len_sum, int64_t* count);
 int lhw_env_set_iteration(LhwEnv* env, int64_t iteration);
 
+/* ------------------------------------------------------------------ PPO (actor/critic MLP, GAE, update) */
+typedef struct LhwPpo LhwPpo;
+
+typedef struct {
+  int32_t device;
+  int32_t obs_dim, act_dim, hidden; /* reference networks: 2 x 256 ReLU (rl/policies/actor.py:127) */
+  int32_t learn_std;                /* --learn-std: stds are a parameter (actor.py:145-148) */
+  int32_t max_rows;                 /* workspace capacity: max rows per forward / minibatch */
+  float lr, eps;                    /* Adam lr and eps; eps is also the advantage-normalisation eps (ppo.py:429-430,485) */
+  float clip, entropy_coeff, mirror_coeff, max_grad_norm;
+  /* signed-permutation mirror tables (NULL = no mirror loss): out[j] = sign[j] * in[src[j]]
+   * == x @ _get_symmetry_matrix(...) with the clock sign flip folded in (rl/envs/wrappers.py:53-85) */
+  const int32_t* mirror_obs_src; const float* mirror_obs_sign; /* [obs_dim] */
+  const int32_t* mirror_act_src; const float* mirror_act_sign; /* [act_dim] */
+} LhwPpoConfig;
+
+int lhw_ppo_create(const LhwPpoConfig* cfg, LhwPpo** out);
+int lhw_ppo_destroy(LhwPpo* ppo);
+/* number of float32 in the flat parameter vector theta (actor | stds | critic, internally padded) */
+int64_t lhw_ppo_param_count(const LhwPpo* ppo);
+/* offsets of actor W1,b1,W2,b2,W3,b3, stds, critic W1..b3, then padded obs width and padded actor out width */
+int lhw_ppo_layout(const LhwPpo* ppo, int64_t* out15);
+/* xn (and xm if non-NULL) [R][pad4(obs_dim)] <- (obs - mean)/std of R raw rows (mirrored for xm) */
+int lhw_ppo_normalize(LhwPpo* ppo, const float* obs, int64_t R, const float* obs_mean, const float* obs_std, float* xn,
+                      float* xm, void* stream);
+/* rollout inference on N rows: mu/act/logp [N][act_dim]/[N][act_dim]/[N], value [N]; any output group may be NULL */
+int lhw_ppo_forward(LhwPpo* ppo, const float* theta, const float* obs, int64_t N, const float* obs_mean,
+                    const float* obs_std, uint64_t seed, uint32_t env_id_base, uint32_t counter, int deterministic,
+                    float* mu, float* act, float* logp, float* value, void* stream);
+/* time-major [T][N] GAE(lambda); done holds LHW_DONE_* flags, vterm the critic value of the terminal
+ * observation, vfinal [N] the value of the observation after the last step */
+int lhw_gae(int32_t T, int32_t N, const float* rew, const float* val, const uint8_t* done, const float* vterm,
+            const float* vfinal, double gamma, double lam, float* ret, float* adv, void* stream);
+int lhw_moments(const float* x, int64_t n, double* out2_dev, void* stream);
+int lhw_scale_shift(float* x, int64_t n, float mean, float inv_scale, void* stream);
+/* forward + loss + backward of one minibatch; accumulates into grad and stats_dev[0..4] */
+int lhw_ppo_grad(LhwPpo* ppo, const float* theta, float* grad, const float* xn, const float* xm, const float* act,
+                 const float* old_logp, const float* adv, const float* ret, const int32_t* idx, int32_t B,
+                 float* stats_dev, void* stream);
+/* dual clip_grad_norm_ + Adam; zeroes grad */
+int lhw_ppo_apply(LhwPpo* ppo, float* theta, float* grad, float* adam_m, float* adam_v, int64_t step, float grad_scale,
+                  void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,706 @@
+// On-device PPO: actor/critic MLP forward, GAE, clipped-surrogate loss + backward, dual
+// grad-norm clip + Adam.  Takes over the arithmetic of
+//   Gaussian_FF_Actor / FF_V forward      (reference rl/policies/actor.py:160-188, critic.py:41-49)
+//   PPOBuffer.finish_path (GAE)           (reference rl/storage/rollout_storage.py:53-85)
+//   PPO.update_actor_critic               (reference rl/algos/ppo.py:299-406)
+//   advantage normalisation               (reference rl/algos/ppo.py:484-485)
+//
+// Numerics: network math is float32 like the reference (ATen fp32).  The dense layers run on
+// the gfx950 f32-input MFMA (v_mfma_f32_32x32x2_f32): bit-for-bit an fmaf chain, so results
+// differ from ATen only by summation order.  GAE accumulates in float64 like the reference.
+//
+// GEMM design (one kernel, three operand layouts): 64x64 output tile per 256-thread workgroup,
+// 4 waves in a 2x2 grid of 32x32 MFMA blocks, K staged through LDS 16 at a time, K-major LDS
+// tiles so the one-float-per-lane MFMA operands are conflict-free ds_read_b32; global loads are
+// 16-byte vectors, register-prefetched one tile ahead.  Epilogues fuse bias+ReLU (forward),
+// ReLU-mask (backward-data), column sums (bias gradients) and split-K atomic accumulation
+// (backward-weight, where the contraction runs over the minibatch).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "../../include/lhw.h"
+#include "lhw_internal.h"
+#include "lhw_rng.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define BM 64
+#define BN 64
+#define BK 16
+#define LDS_LD (64 + 4)
+
+struct GemmArgs {
+  const float* A; int lda;
+  const float* B; int ldb;
+  float* C; int ldc;
+  int M, N, K;
+  const float* bias;        // + bias[n]
+  int relu;                 // max(0, .)
+  const float* mask; int ldmask;  // *= (mask[m][n] > 0)
+  float* colsum;            // atomicAdd column sums of the stored tile
+  int atomic_out;           // atomicAdd into C (split-K)
+  int k_chunk;              // K range per blockIdx.z
+};
+
+// A_KC: A is stored [M][K] (K contiguous); else A is stored [K][M] (M contiguous) i.e. we multiply by its transpose.
+// B_KC: B is stored [N][K] (K contiguous); else B is stored [K][N].
+template <bool A_KC, bool B_KC>
+__global__ void __launch_bounds__(256) gemm_f32_kernel(GemmArgs g) {
+  __shared__ float As[BK][LDS_LD];
+  __shared__ float Bs[BK][LDS_LD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave & 1, wn = wave >> 1;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  const int kbeg = blockIdx.z * g.k_chunk;
+  const int kend = min(g.K, kbeg + g.k_chunk);
+  f32x16 acc;
+  for (int r = 0; r < 16; r++) acc[r] = 0.f;
+
+  float4 ra, rb;
+  auto load_a = [&](int k0) {
+    ra = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (A_KC) {
+      int row = m0 + (tid >> 2), k = k0 + (tid & 3) * 4;
+      if (row < g.M && k < kend) {
+        ra = *reinterpret_cast<const float4*>(g.A + (size_t)row * g.lda + k);
+        if (k + 1 >= kend) ra.y = 0.f;
+        if (k + 2 >= kend) ra.z = 0.f;
+        if (k + 3 >= kend) ra.w = 0.f;
+      }
+    } else {
+      int k = k0 + (tid >> 4), m = m0 + (tid & 15) * 4;
+      if (k < kend && m < g.M) {
+        ra = *reinterpret_cast<const float4*>(g.A + (size_t)k * g.lda + m);
+        if (m + 1 >= g.M) ra.y = 0.f;
+        if (m + 2 >= g.M) ra.z = 0.f;
+        if (m + 3 >= g.M) ra.w = 0.f;
+      }
+    }
+  };
+  auto load_b = [&](int k0) {
+    rb = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (B_KC) {
+      int row = n0 + (tid >> 2), k = k0 + (tid & 3) * 4;
+      if (row < g.N && k < kend) {
+        rb = *reinterpret_cast<const float4*>(g.B + (size_t)row * g.ldb + k);
+        if (k + 1 >= kend) rb.y = 0.f;
+        if (k + 2 >= kend) rb.z = 0.f;
+        if (k + 3 >= kend) rb.w = 0.f;
+      }
+    } else {
+      int k = k0 + (tid >> 4), n = n0 + (tid & 15) * 4;
+      if (k < kend && n < g.N) {
+        rb = *reinterpret_cast<const float4*>(g.B + (size_t)k * g.ldb + n);
+        if (n + 1 >= g.N) rb.y = 0.f;
+        if (n + 2 >= g.N) rb.z = 0.f;
+        if (n + 3 >= g.N) rb.w = 0.f;
+      }
+    }
+  };
+  auto store_tiles = [&]() {
+    if (A_KC) {
+      int row = tid >> 2, kq = (tid & 3) * 4;
+      As[kq + 0][row] = ra.x; As[kq + 1][row] = ra.y; As[kq + 2][row] = ra.z; As[kq + 3][row] = ra.w;
+    } else {
+      int k = tid >> 4, mq = (tid & 15) * 4;
+      *reinterpret_cast<float4*>(&As[k][mq]) = ra;
+    }
+    if (B_KC) {
+      int row = tid >> 2, kq = (tid & 3) * 4;
+      Bs[kq + 0][row] = rb.x; Bs[kq + 1][row] = rb.y; Bs[kq + 2][row] = rb.z; Bs[kq + 3][row] = rb.w;
+    } else {
+      int k = tid >> 4, nq = (tid & 15) * 4;
+      *reinterpret_cast<float4*>(&Bs[k][nq]) = rb;
+    }
+  };
+
+  if (kbeg < kend) {
+    load_a(kbeg);
+    load_b(kbeg);
+  }
+  for (int k0 = kbeg; k0 < kend; k0 += BK) {
+    __syncthreads();
+    store_tiles();
+    __syncthreads();
+    if (k0 + BK < kend) {
+      load_a(k0 + BK);
+      load_b(k0 + BK);
+    }
+    const int am = wm * 32 + (lane & 31), bn = wn * 32 + (lane & 31), kh = lane >> 5;
+#pragma unroll
+    for (int kk = 0; kk < BK / 2; kk++) {
+      float a = As[kk * 2 + kh][am];
+      float b = Bs[kk * 2 + kh][bn];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    }
+  }
+
+  // epilogue; C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  const int col = n0 + wn * 32 + (lane & 31);
+  float csum = 0.f;
+  const float bias = (g.bias && col < g.N) ? g.bias[col] : 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; r++) {
+    int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    if (row < g.M && col < g.N) {
+      float v = acc[r] + bias;
+      if (g.relu) v = fmaxf(v, 0.f);
+      if (g.mask) v = g.mask[(size_t)row * g.ldmask + col] > 0.f ? v : 0.f;
+      if (g.atomic_out) atomicAdd(g.C + (size_t)row * g.ldc + col, v);
+      else g.C[(size_t)row * g.ldc + col] = v;
+      csum += v;
+    }
+  }
+  if (g.colsum) {
+    csum += __shfl_xor(csum, 32);
+    if (lane < 32 && col < g.N) atomicAdd(g.colsum + col, csum);
+  }
+}
+
+template <bool A_KC, bool B_KC>
+static void launch_gemm(const GemmArgs& g, hipStream_t s) {
+  GemmArgs a = g;
+  if (a.k_chunk <= 0) a.k_chunk = a.K;
+  a.k_chunk = ((a.k_chunk + BK - 1) / BK) * BK;
+  dim3 grid((a.M + BM - 1) / BM, (a.N + BN - 1) / BN, (a.K + a.k_chunk - 1) / a.k_chunk);
+  hipLaunchKernelGGL((gemm_f32_kernel<A_KC, B_KC>), grid, dim3(256), 0, s, a);
+}
+
+// ------------------------------------------------------------------------------------------- MLP plumbing
+// Internal parameter layout of one 3-layer MLP (in D -> H -> H -> O), all float32:
+//   W1 [H][Dp]  b1 [H]  W2 [H][H]  b2 [H]  W3 [Op][H]  b3 [Op]      Dp = pad4(D), Op = pad4(O)
+// (torch Linear layout [out][in]; padded rows/columns are zero and stay zero under Adam).
+struct MlpLayout {
+  int D, Dp, H, O, Op;
+  size_t w1, b1, w2, b2, w3, b3, total;
+};
+static inline int pad4(int x) { return (x + 3) & ~3; }
+static MlpLayout mlp_layout(int D, int H, int O) {
+  MlpLayout L;
+  L.D = D; L.Dp = pad4(D); L.H = H; L.O = O; L.Op = pad4(O);
+  size_t o = 0;
+  L.w1 = o; o += (size_t)H * L.Dp;
+  L.b1 = o; o += H;
+  L.w2 = o; o += (size_t)H * H;
+  L.b2 = o; o += H;
+  L.w3 = o; o += (size_t)L.Op * H;
+  L.b3 = o; o += L.Op;
+  L.total = o;
+  return L;
+}
+
+struct LhwPpo {
+  int device, D, A, H, learn_std, max_rows;  // max_rows: capacity of the minibatch workspace (rows per net)
+  float clip, ent_coeff, mirror_coeff, grad_clip, lr, adam_eps, beta1, beta2;
+  int use_mirror;
+  MlpLayout la, lc;       // actor, critic
+  size_t off_actor, off_std, off_critic, n_params;  // flat theta: [actor | stds(A, padded to 4) | critic]
+  // mirror tables (device): obs_src[Dp], obs_sign[Dp], act_src[A], act_sign[A]
+  int *d_obs_src = nullptr, *d_act_src = nullptr;
+  float *d_obs_sign = nullptr, *d_act_sign = nullptr;
+  // workspace
+  float *xb = nullptr;   // [2R][Dp] gathered minibatch inputs (normal rows, then mirrored rows)
+  float *h1a = nullptr, *h2a = nullptr, *ya = nullptr;      // actor activations [2R][H], [2R][H], [2R][Op]
+  float *h1c = nullptr, *h2c = nullptr, *yc = nullptr;      // critic [R][H] [R][H] [R][4]
+  float *dya = nullptr, *dh2a = nullptr, *dh1a = nullptr;   // actor grads wrt activations
+  float *dyc = nullptr, *dh2c = nullptr, *dh1c = nullptr;
+  float *mb_act = nullptr, *mb_logp = nullptr, *mb_adv = nullptr, *mb_ret = nullptr;
+  float *stats = nullptr;  // [16] loss scalars; [8],[9] grad norm^2 actor/critic
+};
+
+#define HIPCHK(x)                                                                                   \
+  do {                                                                                              \
+    hipError_t e_ = (x);                                                                            \
+    if (e_ != hipSuccess) return lhw_fail(LHW_ERR_HIP, "%s failed: %s", #x, hipGetErrorString(e_)); \
+  } while (0)
+
+// y = mlp(x) for R rows; keeps h1/h2 for the backward pass
+static void mlp_forward(const MlpLayout& L, const float* theta, const float* x, int ldx, int R, float* h1, float* h2,
+                        float* y, hipStream_t s) {
+  GemmArgs g{};
+  g.A = x; g.lda = ldx; g.B = theta + L.w1; g.ldb = L.Dp; g.C = h1; g.ldc = L.H; g.M = R; g.N = L.H; g.K = L.Dp;
+  g.bias = theta + L.b1; g.relu = 1;
+  launch_gemm<true, true>(g, s);
+  g = GemmArgs{};
+  g.A = h1; g.lda = L.H; g.B = theta + L.w2; g.ldb = L.H; g.C = h2; g.ldc = L.H; g.M = R; g.N = L.H; g.K = L.H;
+  g.bias = theta + L.b2; g.relu = 1;
+  launch_gemm<true, true>(g, s);
+  g = GemmArgs{};
+  g.A = h2; g.lda = L.H; g.B = theta + L.w3; g.ldb = L.H; g.C = y; g.ldc = L.Op; g.M = R; g.N = L.O; g.K = L.H;
+  g.bias = theta + L.b3;
+  launch_gemm<true, true>(g, s);
+}
+
+// accumulates parameter gradients of one MLP given dy [R][Op]
+static void mlp_backward(const MlpLayout& L, const float* theta, float* grad, const float* x, int ldx, int R, const float* h1,
+                         const float* h2, const float* dy, float* dh2, float* dh1, int k_chunk, hipStream_t s) {
+  GemmArgs g{};
+  // dW3 [O][H] += dy^T h2 ; db3 from the loss kernel (it owns dy)
+  g.A = dy; g.lda = L.Op; g.B = h2; g.ldb = L.H; g.C = grad + L.w3; g.ldc = L.H; g.M = L.O; g.N = L.H; g.K = R;
+  g.atomic_out = 1; g.k_chunk = k_chunk;
+  launch_gemm<false, false>(g, s);
+  // dh2 = (dy W3) * (h2 > 0) ; db2 = colsum(dh2)
+  g = GemmArgs{};
+  g.A = dy; g.lda = L.Op; g.B = theta + L.w3; g.ldb = L.H; g.C = dh2; g.ldc = L.H; g.M = R; g.N = L.H; g.K = L.O;
+  g.mask = h2; g.ldmask = L.H; g.colsum = grad + L.b2;
+  launch_gemm<true, false>(g, s);
+  // dW2 += dh2^T h1
+  g = GemmArgs{};
+  g.A = dh2; g.lda = L.H; g.B = h1; g.ldb = L.H; g.C = grad + L.w2; g.ldc = L.H; g.M = L.H; g.N = L.H; g.K = R;
+  g.atomic_out = 1; g.k_chunk = k_chunk;
+  launch_gemm<false, false>(g, s);
+  // dh1 = (dh2 W2) * (h1 > 0) ; db1 = colsum(dh1)
+  g = GemmArgs{};
+  g.A = dh2; g.lda = L.H; g.B = theta + L.w2; g.ldb = L.H; g.C = dh1; g.ldc = L.H; g.M = R; g.N = L.H; g.K = L.H;
+  g.mask = h1; g.ldmask = L.H; g.colsum = grad + L.b1;
+  launch_gemm<true, false>(g, s);
+  // dW1 [H][Dp] += dh1^T x
+  g = GemmArgs{};
+  g.A = dh1; g.lda = L.H; g.B = x; g.ldb = ldx; g.C = grad + L.w1; g.ldc = L.Dp; g.M = L.H; g.N = L.Dp; g.K = R;
+  g.atomic_out = 1; g.k_chunk = k_chunk;
+  launch_gemm<false, false>(g, s);
+}
+
+// ------------------------------------------------------------------------------------------- elementwise kernels
+// (x - mean)/std into a [R][Dp] buffer (pad columns zero); optional mirrored copy
+// mirror: out[j] = sign[j] * obs[src[j]]  == obs @ M with the clock sign flip folded in
+// (reference rl/envs/wrappers.py:53-85: sin(arcsin(c)+pi) == -c)
+__global__ void normalize_kernel(const float* __restrict__ obs, int D, int Dp, size_t R, const float* __restrict__ mean,
+                                 const float* __restrict__ stdv, float* __restrict__ xn, float* __restrict__ xm,
+                                 const int* __restrict__ src, const float* __restrict__ sign) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= R * (size_t)Dp) return;
+  size_t r = i / Dp;
+  int j = (int)(i - r * Dp);
+  float v = 0.f, vm = 0.f;
+  if (j < D) {
+    v = (obs[r * D + j] - mean[j]) / stdv[j];
+    if (xm) vm = (sign[j] * obs[r * D + src[j]] - mean[j]) / stdv[j];
+  }
+  xn[i] = v;
+  if (xm) xm[i] = vm;
+}
+
+// gather a minibatch: rows idx[0..B) of xn -> xb[0..B), of xm -> xb[R..R+B) (if mirror), plus act/logp/adv/ret
+__global__ void gather_kernel(const int* __restrict__ idx, int B, int Rcap, int Dp, int A, const float* __restrict__ xn,
+                              const float* __restrict__ xm, const float* __restrict__ act, const float* __restrict__ logp,
+                              const float* __restrict__ adv, const float* __restrict__ ret, float* __restrict__ xb,
+                              float* __restrict__ mact, float* __restrict__ mlogp, float* __restrict__ madv,
+                              float* __restrict__ mret) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)B * Dp) return;
+  int m = (int)(i / Dp), j = (int)(i - (size_t)m * Dp);
+  size_t s = (size_t)idx[m];
+  xb[(size_t)m * Dp + j] = xn[s * Dp + j];
+  if (xm) xb[((size_t)Rcap + m) * Dp + j] = xm[s * Dp + j];
+  if (j < A) mact[(size_t)m * A + j] = act[s * A + j];
+  if (j == 0) { mlogp[m] = logp[s]; madv[m] = adv[s]; mret[m] = ret[s]; }
+}
+
+// rollout sampling: act = mu + std * N(0,1) (or mu), logp of the sampled action under (mu, std)
+__global__ void sample_kernel(const float* __restrict__ mu, int ldmu, int A, int N, const float* __restrict__ stdv,
+                              uint64_t seed, uint32_t env_base, uint32_t counter, int deterministic,
+                              float* __restrict__ act, float* __restrict__ logp) {
+  int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  float lp = 0.f;
+  for (int a = 0; a < A; a++) {
+    float m = mu[(size_t)n * ldmu + a], sd = stdv[a], x = m;
+    if (!deterministic) {
+      // Box-Muller on two counter-based uniforms (the reference samples torch.distributions.Normal, actor.py:180)
+      double u1 = lhw_rng_u01(seed, env_base + n, LHW_STREAM_POLICY, counter, 2 * a);
+      double u2 = lhw_rng_u01(seed, env_base + n, LHW_STREAM_POLICY, counter, 2 * a + 1);
+      float z = (float)(sqrt(-2.0 * log(1.0 - u1)) * cos(6.283185307179586 * u2));
+      x = m + sd * z;
+    }
+    act[(size_t)n * A + a] = x;
+    float d = (x - m) / sd;
+    lp += -0.5f * d * d - logf(sd) - 0.9189385332046727f;
+  }
+  logp[n] = lp;
+}
+
+// PPO losses and their gradients wrt network outputs (reference rl/algos/ppo.py:302-384, FF path, mask = 1)
+// stats: 0 actor_loss  1 critic_loss  2 mirror_loss  3 approx_kl  4 clip_fraction (all already divided by B)
+__global__ void __launch_bounds__(256) ppo_loss_kernel(int B, int Rcap, int A, int Op, const float* __restrict__ ya,
+                                                       const float* __restrict__ yc, const float* __restrict__ act,
+                                                       const float* __restrict__ old_logp, const float* __restrict__ adv,
+                                                       const float* __restrict__ ret, const float* __restrict__ stdv,
+                                                       float clip, float mirror_coeff, float ent_coeff, int use_mirror,
+                                                       const int* __restrict__ act_src, const float* __restrict__ act_sign,
+                                                       float* __restrict__ dya, float* __restrict__ dyc,
+                                                       float* __restrict__ grad_b3a, float* __restrict__ grad_b3c,
+                                                       float* __restrict__ grad_std, float* __restrict__ stats) {
+  int m = blockIdx.x * blockDim.x + threadIdx.x;
+  float s_actor = 0, s_critic = 0, s_mirror = 0, s_kl = 0, s_cf = 0;
+  const float invB = 1.f / (float)B, invBA = 1.f / ((float)B * (float)A);
+  __shared__ float red[5][4];
+  __shared__ float sb3[32];   // actor bias-3 grads, block partial
+  __shared__ float sstd[32];
+  if (threadIdx.x < 32) { sb3[threadIdx.x] = 0.f; sstd[threadIdx.x] = 0.f; }
+  __syncthreads();
+  float dcrit = 0.f;
+  if (m < B) {
+    float lp = 0.f;
+    for (int a = 0; a < A; a++) {
+      float d = (act[(size_t)m * A + a] - ya[(size_t)m * Op + a]) / stdv[a];
+      lp += -0.5f * d * d - logf(stdv[a]) - 0.9189385332046727f;
+    }
+    float logr = lp - old_logp[m];
+    float ratio = expf(logr);
+    float ad = adv[m];
+    float cl = fminf(fmaxf(ratio, 1.f - clip), 1.f + clip);
+    float cpi = ratio * ad, cll = cl * ad;
+    s_actor = -fminf(cpi, cll);
+    float dratio = (cpi <= cll) ? ad : 0.f;  // torch.min backward; ties inside the clip range carry the full gradient
+    float dlp = -invB * dratio * ratio;
+    s_kl = (ratio - 1.f) - logr;
+    s_cf = fabsf(ratio - 1.f) > clip ? 1.f : 0.f;
+    float v = yc[(size_t)m * 4];
+    float e = ret[m] - v;
+    s_critic = e * e;
+    dcrit = -2.f * e * invB;
+    dyc[(size_t)m * 4] = dcrit;
+    dyc[(size_t)m * 4 + 1] = 0.f; dyc[(size_t)m * 4 + 2] = 0.f; dyc[(size_t)m * 4 + 3] = 0.f;
+    for (int a = 0; a < Op; a++) {
+      float g = 0.f, gm = 0.f;
+      if (a < A) {
+        float mu = ya[(size_t)m * Op + a], sd = stdv[a], x = act[(size_t)m * A + a];
+        g = dlp * (x - mu) / (sd * sd);
+        if (grad_std) atomicAdd(&sstd[a], dlp * ((x - mu) * (x - mu) / (sd * sd * sd) - 1.f / sd));
+        if (use_mirror) {
+          // mirror_actions[j] = sum_i mu_mir[i] M[i][j]; M[i][src... ] stored as gather: out[j] = sign[j]*in[src[j]]
+          float mm = act_sign[a] * ya[((size_t)Rcap + m) * Op + act_src[a]];
+          float diff = mu - mm;
+          s_mirror += diff * diff;
+          g += mirror_coeff * 2.f * diff * invBA;
+        }
+        atomicAdd(&sb3[a], g);
+      }
+      dya[(size_t)m * Op + a] = g;
+      (void)gm;
+    }
+    if (use_mirror) {
+      // gradient wrt the mirrored-pass outputs: d/d mu_mir[src[a]] += -2 coeff sign[a] (mu[a]-mm[a]) / (B A)
+      for (int a = 0; a < Op; a++) dya[((size_t)Rcap + m) * Op + a] = 0.f;
+      for (int a = 0; a < A; a++) {
+        float mm = act_sign[a] * ya[((size_t)Rcap + m) * Op + act_src[a]];
+        float diff = ya[(size_t)m * Op + a] - mm;
+        float gg = -mirror_coeff * 2.f * diff * invBA * act_sign[a];
+        dya[((size_t)Rcap + m) * Op + act_src[a]] += gg;  // act_src is a permutation: no intra-thread race
+        atomicAdd(&sb3[act_src[a]], gg);
+      }
+    }
+  }
+  // block reduction of the scalars
+  float vals[5] = {s_actor * invB, s_critic * invB, s_mirror * invBA, s_kl * invB, s_cf * invB};
+  float dc = dcrit;
+  for (int o = 32; o > 0; o >>= 1) {
+    for (int k = 0; k < 5; k++) vals[k] += __shfl_xor(vals[k], o);
+    dc += __shfl_xor(dc, o);
+  }
+  int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) {
+    for (int k = 0; k < 5; k++) red[k][wave] = vals[k];
+    atomicAdd(grad_b3c, dc);
+  }
+  __syncthreads();
+  if (threadIdx.x < 5) atomicAdd(stats + threadIdx.x, red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3]);
+  if (threadIdx.x < A) {
+    atomicAdd(grad_b3a + threadIdx.x, sb3[threadIdx.x]);
+    if (grad_std) {
+      // entropy_penalty = -mean(entropy) = -mean_a(0.5 + 0.5 log 2pi + log std_a): d/d std_a = -1/(A std_a) (ppo.py:343,380)
+      float ge = blockIdx.x == 0 ? -ent_coeff / ((float)A * stdv[threadIdx.x]) : 0.f;
+      atomicAdd(grad_std + threadIdx.x, sstd[threadIdx.x] + ge);
+    }
+  }
+}
+
+// sum of squares of a flat range (grad norm), with pre-scale
+__global__ void __launch_bounds__(256) sumsq_kernel(const float* __restrict__ g, size_t n, float scale, float* __restrict__ out) {
+  float s = 0.f;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    float v = g[i] * scale;
+    s += v * v;
+  }
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  __shared__ float red[4];
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+}
+
+// clip_grad_norm_ (coef = max_norm/(norm+1e-6), applied only if < 1) + torch.optim.Adam step; zeroes the gradient
+__global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ theta, float* __restrict__ grad, float* __restrict__ m,
+                                                   float* __restrict__ v, size_t n, float gscale, const float* __restrict__ normsq,
+                                                   float max_norm, float lr, float beta1, float beta2, float eps, float bc1,
+                                                   float bc2sqrt) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float norm = sqrtf(*normsq);
+  float coef = max_norm / (norm + 1e-6f);
+  coef = coef < 1.f ? coef : 1.f;
+  float g = grad[i] * gscale * coef;
+  float mi = beta1 * m[i] + (1.f - beta1) * g;
+  float vi = beta2 * v[i] + (1.f - beta2) * g * g;
+  m[i] = mi; v[i] = vi;
+  float denom = sqrtf(vi) / bc2sqrt + eps;
+  theta[i] -= (lr / bc1) * (mi / denom);
+  grad[i] = 0.f;
+}
+
+// GAE(lambda) over a time-major rollout, one lane per env, float64 accumulation
+// (reference rl/storage/rollout_storage.py:53-85 + the bootstrap rules of rl/workers/rollout_worker.py:163-190)
+__global__ void __launch_bounds__(256) gae_kernel(int T, int N, const float* __restrict__ rew, const float* __restrict__ val,
+                                                  const uint8_t* __restrict__ done, const float* __restrict__ vterm,
+                                                  const float* __restrict__ vfinal, double gamma, double lam,
+                                                  float* __restrict__ ret, float* __restrict__ adv) {
+  int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  double gae = 0.0, nextv = (double)vfinal[n];
+  for (int t = T - 1; t >= 0; t--) {
+    size_t i = (size_t)t * N + n;
+    uint8_t f = done[i];
+    if (f) {  // trajectory ends here: bootstrap (not done) * V(terminal obs), advantage recursion restarts
+      nextv = (f & 1) ? 0.0 : (double)vterm[i];
+      gae = 0.0;
+    }
+    double v = (double)val[i];
+    double delta = (double)rew[i] + gamma * nextv - v;
+    gae = delta + gamma * lam * gae;
+    double r = gae + v;
+    ret[i] = (float)r;
+    adv[i] = (float)r - val[i];  // advantages = returns.float() - values.float() (ppo.py:484)
+    nextv = v;
+  }
+}
+
+// advantage normalisation: (a - mean) / (std_unbiased + eps) from global moments
+__global__ void moments_kernel(const float* __restrict__ x, size_t n, double* __restrict__ out) {
+  double s = 0, s2 = 0;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    double v = x[i];
+    s += v; s2 += v * v;
+  }
+  for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o); s2 += __shfl_xor(s2, o); }
+  __shared__ double red[2][4];
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s; red[1][threadIdx.x >> 6] = s2; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    atomicAdd(out, red[0][0] + red[0][1] + red[0][2] + red[0][3]);
+    atomicAdd(out + 1, red[1][0] + red[1][1] + red[1][2] + red[1][3]);
+  }
+}
+__global__ void scale_shift_kernel(float* __restrict__ x, size_t n, float mean, float inv) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) x[i] = (x[i] - mean) * inv;
+}
+
+// ------------------------------------------------------------------------------------------- C ABI
+extern "C" int lhw_ppo_create(const LhwPpoConfig* c, LhwPpo** out) {
+  if (!c || !out) return lhw_fail(LHW_ERR_ARG, "null argument");
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return lhw_fail(LHW_ERR_NO_DEVICE, "no HIP device visible: liblhw has no CPU fallback");
+  if (c->obs_dim <= 0 || c->act_dim <= 0 || c->act_dim > 32 || c->hidden <= 0 || c->hidden % 4 || c->max_rows <= 0)
+    return lhw_fail(LHW_ERR_ARG, "bad PPO dimensions (act_dim <= 32, hidden %% 4 == 0)");
+  HIPCHK(hipSetDevice(c->device));
+  LhwPpo* p = new LhwPpo();
+  p->device = c->device; p->D = c->obs_dim; p->A = c->act_dim; p->H = c->hidden; p->learn_std = c->learn_std;
+  p->max_rows = c->max_rows;
+  p->clip = c->clip; p->ent_coeff = c->entropy_coeff; p->mirror_coeff = c->mirror_coeff; p->grad_clip = c->max_grad_norm;
+  p->lr = c->lr; p->adam_eps = c->eps; p->beta1 = 0.9f; p->beta2 = 0.999f;
+  p->use_mirror = c->mirror_obs_src != nullptr;
+  p->la = mlp_layout(p->D, p->H, p->A);
+  p->lc = mlp_layout(p->D, p->H, 1);
+  p->off_actor = 0;
+  p->off_std = p->la.total;
+  p->off_critic = p->off_std + pad4(p->A);
+  p->n_params = p->off_critic + p->lc.total;
+  const size_t R = p->max_rows, Dp = p->la.Dp, H = p->H, Op = p->la.Op;
+  auto alloc = [&](float** ptr, size_t n) { return hipMalloc(ptr, sizeof(float) * n) == hipSuccess && hipMemset(*ptr, 0, sizeof(float) * n) == hipSuccess; };
+  bool ok = alloc(&p->xb, 2 * R * Dp) && alloc(&p->h1a, 2 * R * H) && alloc(&p->h2a, 2 * R * H) && alloc(&p->ya, 2 * R * Op) &&
+            alloc(&p->h1c, R * H) && alloc(&p->h2c, R * H) && alloc(&p->yc, R * 4) && alloc(&p->dya, 2 * R * Op) &&
+            alloc(&p->dh2a, 2 * R * H) && alloc(&p->dh1a, 2 * R * H) && alloc(&p->dyc, R * 4) && alloc(&p->dh2c, R * H) &&
+            alloc(&p->dh1c, R * H) && alloc(&p->mb_act, R * p->A) && alloc(&p->mb_logp, R) && alloc(&p->mb_adv, R) &&
+            alloc(&p->mb_ret, R) && alloc(&p->stats, 16);
+  if (ok && p->use_mirror) {
+    std::vector<int> osrc(Dp, 0), asrc(p->A, 0);
+    std::vector<float> osgn(Dp, 0.f), asgn(p->A, 0.f);
+    for (int j = 0; j < p->D; j++) { osrc[j] = c->mirror_obs_src[j]; osgn[j] = c->mirror_obs_sign[j]; }
+    for (int j = 0; j < p->A; j++) { asrc[j] = c->mirror_act_src[j]; asgn[j] = c->mirror_act_sign[j]; }
+    for (int j = 0; j < p->D; j++) if (osrc[j] < 0 || osrc[j] >= p->D) { ok = false; }
+    for (int j = 0; j < p->A; j++) if (asrc[j] < 0 || asrc[j] >= p->A) { ok = false; }
+    ok = ok && hipMalloc(&p->d_obs_src, sizeof(int) * Dp) == hipSuccess && hipMalloc(&p->d_act_src, sizeof(int) * p->A) == hipSuccess &&
+         hipMalloc(&p->d_obs_sign, sizeof(float) * Dp) == hipSuccess && hipMalloc(&p->d_act_sign, sizeof(float) * p->A) == hipSuccess;
+    if (ok) {
+      (void)hipMemcpy(p->d_obs_src, osrc.data(), sizeof(int) * Dp, hipMemcpyHostToDevice);
+      (void)hipMemcpy(p->d_act_src, asrc.data(), sizeof(int) * p->A, hipMemcpyHostToDevice);
+      (void)hipMemcpy(p->d_obs_sign, osgn.data(), sizeof(float) * Dp, hipMemcpyHostToDevice);
+      (void)hipMemcpy(p->d_act_sign, asgn.data(), sizeof(float) * p->A, hipMemcpyHostToDevice);
+    }
+  }
+  if (!ok) {
+    lhw_ppo_destroy(p);
+    return lhw_fail(LHW_ERR_HIP, "PPO workspace allocation failed (max_rows=%d) or bad mirror table", c->max_rows);
+  }
+  *out = p;
+  return LHW_OK;
+}
+
+extern "C" int lhw_ppo_destroy(LhwPpo* p) {
+  if (!p) return LHW_OK;
+  (void)hipSetDevice(p->device);
+  float* bufs[] = {p->xb, p->h1a, p->h2a, p->ya, p->h1c, p->h2c, p->yc, p->dya, p->dh2a, p->dh1a, p->dyc, p->dh2c, p->dh1c,
+                   p->mb_act, p->mb_logp, p->mb_adv, p->mb_ret, p->stats, p->d_obs_sign, p->d_act_sign};
+  for (float* b : bufs) if (b) (void)hipFree(b);
+  if (p->d_obs_src) (void)hipFree(p->d_obs_src);
+  if (p->d_act_src) (void)hipFree(p->d_act_src);
+  delete p;
+  return LHW_OK;
+}
+
+extern "C" int64_t lhw_ppo_param_count(const LhwPpo* p) { return p ? (int64_t)p->n_params : LHW_ERR_ARG; }
+
+// offsets (in floats) of each tensor inside the flat parameter vector:
+// out[0..5] actor W1,b1,W2,b2,W3,b3 ; out[6] stds ; out[7..12] critic W1..b3 ; out[13] obs pad width Dp ; out[14] actor Op
+extern "C" int lhw_ppo_layout(const LhwPpo* p, int64_t* out15) {
+  if (!p || !out15) return lhw_fail(LHW_ERR_ARG, "null argument");
+  const MlpLayout &a = p->la, &c = p->lc;
+  int64_t v[15] = {(int64_t)(p->off_actor + a.w1), (int64_t)(p->off_actor + a.b1), (int64_t)(p->off_actor + a.w2),
+                   (int64_t)(p->off_actor + a.b2), (int64_t)(p->off_actor + a.w3), (int64_t)(p->off_actor + a.b3),
+                   (int64_t)p->off_std,
+                   (int64_t)(p->off_critic + c.w1), (int64_t)(p->off_critic + c.b1), (int64_t)(p->off_critic + c.w2),
+                   (int64_t)(p->off_critic + c.b2), (int64_t)(p->off_critic + c.w3), (int64_t)(p->off_critic + c.b3),
+                   (int64_t)a.Dp, (int64_t)a.Op};
+  memcpy(out15, v, sizeof v);
+  return LHW_OK;
+}
+
+// normalised (and mirrored) copies of R raw observation rows: xn/xm [R][Dp]
+extern "C" int lhw_ppo_normalize(LhwPpo* p, const float* obs, int64_t R, const float* obs_mean, const float* obs_std, float* xn,
+                                 float* xm, void* stream) {
+  if (!p || !obs || !xn || R <= 0) return lhw_fail(LHW_ERR_ARG, "bad argument");
+  if (xm && !p->use_mirror) return lhw_fail(LHW_ERR_ARG, "mirror output requested but no mirror tables configured");
+  HIPCHK(hipSetDevice(p->device));
+  size_t n = (size_t)R * p->la.Dp;
+  hipLaunchKernelGGL(normalize_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, obs, p->D, p->la.Dp, (size_t)R,
+                     obs_mean, obs_std, xn, xm, p->d_obs_src, p->d_obs_sign);
+  HIPCHK(hipGetLastError());
+  return LHW_OK;
+}
+
+// Rollout inference for N rows (N <= max_rows): normalise, actor + critic forward, sample.
+//   act/logp/mu may be NULL to run the critic only; value may be NULL to run the actor only.
+extern "C" int lhw_ppo_forward(LhwPpo* p, const float* theta, const float* obs, int64_t N, const float* obs_mean,
+                               const float* obs_std, uint64_t seed, uint32_t env_id_base, uint32_t counter, int deterministic,
+                               float* mu, float* act, float* logp, float* value, void* stream) {
+  if (!p || !theta || !obs || N <= 0 || N > p->max_rows) return lhw_fail(LHW_ERR_ARG, "bad argument (N=%lld, capacity %d)", (long long)N, p ? p->max_rows : 0);
+  HIPCHK(hipSetDevice(p->device));
+  hipStream_t s = (hipStream_t)stream;
+  size_t n = (size_t)N * p->la.Dp;
+  hipLaunchKernelGGL(normalize_kernel, dim3((n + 255) / 256), dim3(256), 0, s, obs, p->D, p->la.Dp, (size_t)N, obs_mean, obs_std,
+                     p->xb, (float*)nullptr, (const int*)nullptr, (const float*)nullptr);
+  if (act || mu) {
+    mlp_forward(p->la, theta + p->off_actor, p->xb, p->la.Dp, (int)N, p->h1a, p->h2a, p->ya, s);
+    if (mu) HIPCHK(hipMemcpy2DAsync(mu, sizeof(float) * p->A, p->ya, sizeof(float) * p->la.Op, sizeof(float) * p->A, N, hipMemcpyDeviceToDevice, s));
+    if (act) {
+      if (!logp) return lhw_fail(LHW_ERR_ARG, "logp required with act");
+      hipLaunchKernelGGL(sample_kernel, dim3((N + 255) / 256), dim3(256), 0, s, p->ya, p->la.Op, p->A, (int)N, theta + p->off_std,
+                         seed, env_id_base, counter, deterministic, act, logp);
+    }
+  }
+  if (value) {
+    mlp_forward(p->lc, theta + p->off_critic, p->xb, p->la.Dp, (int)N, p->h1c, p->h2c, p->yc, s);
+    HIPCHK(hipMemcpy2DAsync(value, sizeof(float), p->yc, sizeof(float) * 4, sizeof(float), N, hipMemcpyDeviceToDevice, s));
+  }
+  HIPCHK(hipGetLastError());
+  return LHW_OK;
+}
+
+extern "C" int lhw_gae(int32_t T, int32_t N, const float* rew, const float* val, const uint8_t* done, const float* vterm,
+                       const float* vfinal, double gamma, double lam, float* ret, float* adv, void* stream) {
+  if (T <= 0 || N <= 0 || !rew || !val || !done || !vterm || !vfinal || !ret || !adv) return lhw_fail(LHW_ERR_ARG, "bad argument");
+  hipLaunchKernelGGL(gae_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, T, N, rew, val, done, vterm, vfinal,
+                     gamma, lam, ret, adv);
+  HIPCHK(hipGetLastError());
+  return LHW_OK;
+}
+
+// sum and sum of squares (float64) of x[0..n): the caller all-reduces them across GPUs, then calls lhw_scale_shift
+extern "C" int lhw_moments(const float* x, int64_t n, double* out2_dev, void* stream) {
+  if (!x || !out2_dev || n <= 0) return lhw_fail(LHW_ERR_ARG, "bad argument");
+  HIPCHK(hipMemsetAsync(out2_dev, 0, 2 * sizeof(double), (hipStream_t)stream));
+  int blocks = (int)std::min<int64_t>((n + 255) / 256, 2048);
+  hipLaunchKernelGGL(moments_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, (size_t)n, out2_dev);
+  HIPCHK(hipGetLastError());
+  return LHW_OK;
+}
+extern "C" int lhw_scale_shift(float* x, int64_t n, float mean, float inv_scale, void* stream) {
+  if (!x || n <= 0) return lhw_fail(LHW_ERR_ARG, "bad argument");
+  hipLaunchKernelGGL(scale_shift_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, (size_t)n, mean, inv_scale);
+  HIPCHK(hipGetLastError());
+  return LHW_OK;
+}
+
+// One minibatch: gather rows idx[0..B) from the iteration's buffers, forward (policy on obs and on mirrored
+// obs, critic), losses, backward.  Gradients are ACCUMULATED into grad (flat, same layout as theta);
+// stats_dev[0..4] += actor_loss, critic_loss, mirror_loss, approx_kl, clip_fraction of this minibatch.
+extern "C" int lhw_ppo_grad(LhwPpo* p, const float* theta, float* grad, const float* xn, const float* xm, const float* act,
+                            const float* old_logp, const float* adv, const float* ret, const int32_t* idx, int32_t B,
+                            float* stats_dev, void* stream) {
+  if (!p || !theta || !grad || !xn || !act || !old_logp || !adv || !ret || !idx || !stats_dev) return lhw_fail(LHW_ERR_ARG, "null argument");
+  if (B <= 0 || B > p->max_rows) return lhw_fail(LHW_ERR_ARG, "minibatch %d exceeds workspace capacity %d", B, p->max_rows);
+  const int mir = p->use_mirror && xm != nullptr;
+  HIPCHK(hipSetDevice(p->device));
+  hipStream_t s = (hipStream_t)stream;
+  const int R = p->max_rows, Dp = p->la.Dp, Op = p->la.Op;
+  size_t n = (size_t)B * Dp;
+  hipLaunchKernelGGL(gather_kernel, dim3((n + 255) / 256), dim3(256), 0, s, idx, B, R, Dp, p->A, xn, mir ? xm : nullptr, act, old_logp,
+                     adv, ret, p->xb, p->mb_act, p->mb_logp, p->mb_adv, p->mb_ret);
+  const float* th_a = theta + p->off_actor;
+  const float* th_c = theta + p->off_critic;
+  // forward: rows [0,B) and, if mirroring, rows [R, R+B)
+  mlp_forward(p->la, th_a, p->xb, Dp, B, p->h1a, p->h2a, p->ya, s);
+  if (mir)
+    mlp_forward(p->la, th_a, p->xb + (size_t)R * Dp, Dp, B, p->h1a + (size_t)R * p->H, p->h2a + (size_t)R * p->H, p->ya + (size_t)R * Op, s);
+  mlp_forward(p->lc, th_c, p->xb, Dp, B, p->h1c, p->h2c, p->yc, s);
+  hipLaunchKernelGGL(ppo_loss_kernel, dim3((B + 255) / 256), dim3(256), 0, s, B, R, p->A, Op, p->ya, p->yc, p->mb_act, p->mb_logp,
+                     p->mb_adv, p->mb_ret, theta + p->off_std, p->clip, p->mirror_coeff, p->ent_coeff, mir, p->d_act_src, p->d_act_sign, p->dya,
+                     p->dyc, grad + p->off_actor + p->la.b3, grad + p->off_critic + p->lc.b3,
+                     p->learn_std ? grad + p->off_std : (float*)nullptr, stats_dev);
+  const int kc = 512;
+  mlp_backward(p->la, th_a, grad + p->off_actor, p->xb, Dp, B, p->h1a, p->h2a, p->dya, p->dh2a, p->dh1a, kc, s);
+  if (mir)
+    mlp_backward(p->la, th_a, grad + p->off_actor, p->xb + (size_t)R * Dp, Dp, B, p->h1a + (size_t)R * p->H, p->h2a + (size_t)R * p->H,
+                 p->dya + (size_t)R * Op, p->dh2a + (size_t)R * p->H, p->dh1a + (size_t)R * p->H, kc, s);
+  mlp_backward(p->lc, th_c, grad + p->off_critic, p->xb, Dp, B, p->h1c, p->h2c, p->dyc, p->dh2c, p->dh1c, kc, s);
+  HIPCHK(hipGetLastError());
+  return LHW_OK;
+}
+
+// clip_grad_norm_ on the actor and critic parameter groups separately, then one Adam step each; zeroes grad.
+// grad_scale multiplies the gradient first (1/world_size after a sum all-reduce).  step is the 1-based Adam step count.
+extern "C" int lhw_ppo_apply(LhwPpo* p, float* theta, float* grad, float* adam_m, float* adam_v, int64_t step, float grad_scale,
+                             void* stream) {
+  if (!p || !theta || !grad || !adam_m || !adam_v || step <= 0) return lhw_fail(LHW_ERR_ARG, "bad argument");
+  HIPCHK(hipSetDevice(p->device));
+  hipStream_t s = (hipStream_t)stream;
+  HIPCHK(hipMemsetAsync(p->stats + 8, 0, 2 * sizeof(float), s));
+  const size_t na = p->learn_std ? p->off_std + p->A : p->off_std;  // actor group (+ stds if they are parameters)
+  const size_t nc = p->lc.total;
+  hipLaunchKernelGGL(sumsq_kernel, dim3(std::min<size_t>((na + 255) / 256, 512)), dim3(256), 0, s, grad, na, grad_scale, p->stats + 8);
+  hipLaunchKernelGGL(sumsq_kernel, dim3(std::min<size_t>((nc + 255) / 256, 512)), dim3(256), 0, s, grad + p->off_critic, nc, grad_scale, p->stats + 9);
+  const float bc1 = 1.f - powf(p->beta1, (float)step), bc2 = 1.f - powf(p->beta2, (float)step);
+  hipLaunchKernelGGL(adam_kernel, dim3((na + 255) / 256), dim3(256), 0, s, theta, grad, adam_m, adam_v, na, grad_scale, p->stats + 8,
+                     p->grad_clip, p->lr, p->beta1, p->beta2, p->adam_eps, bc1, sqrtf(bc2));
+  hipLaunchKernelGGL(adam_kernel, dim3((nc + 255) / 256), dim3(256), 0, s, theta + p->off_critic, grad + p->off_critic,
+                     adam_m + p->off_critic, adam_v + p->off_critic, nc, grad_scale, p->stats + 9, p->grad_clip, p->lr, p->beta1,
+                     p->beta2, p->adam_eps, bc1, sqrtf(bc2));
+  if (!p->learn_std) HIPCHK(hipMemsetAsync(grad + p->off_std, 0, sizeof(float) * pad4(p->A), s));
+  HIPCHK(hipGetLastError());
+  return LHW_OK;
+}

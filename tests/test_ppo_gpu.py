@@ -1,0 +1,174 @@
+"""On-device PPO kernels vs (a) fixtures produced by the reference's own PPO.update_actor_critic and
+(b) the CPU oracle, through the C ABI.  float32 network math: tolerances are stated per check."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+MIR_OBS = [-0.1, 1, -2, 3, -4, 11, -12, -13, 14, -15, 16, 5, -6, -7, 8, -9, 10, 23, -24, -25, 26, -27, 28, 17, -18, -19,
+           20, -21, 22] + list(range(29, 37))
+MIR_ACT = [6, -7, -8, 9, -10, 11, 0.1, -1, -2, 3, -4, 5]
+NAMES = ["w1", "b1", "w2", "b2", "w3", "b3"]
+
+
+def _kernels(g, hidden, mirror, learn_std, max_rows=256):
+    from learninghumanoidwalking_amd.ppo_kernels import PpoKernels
+    from oracle import ppo_oracle as po
+    mo = po.mirror_tables(MIR_OBS, [29, 30]) if mirror else None
+    ma = po.mirror_tables(MIR_ACT) if mirror else None
+    k = PpoKernels(37, 12, hidden=hidden, max_rows=max_rows, learn_std=learn_std, entropy_coeff=0.01 if learn_std else 0.0,
+                   mirror_obs=mo, mirror_act=ma)
+    k.set_obs_norm(g["obs_mean"], g["obs_std"])
+    return k
+
+
+def _run_updates(k, g):
+    scal = []
+    for u in range(len(g["scalars"])):
+        c = lambda n: torch.tensor(g[f"{n}_{u}"]).cuda().contiguous()
+        obs = c("obs")
+        B = obs.shape[0]
+        xn, xm = k.normalize(obs)
+        k.stats.zero_()
+        idx = torch.arange(B, dtype=torch.int32, device="cuda")
+        k.grad_minibatch(xn, xm, c("act"), c("old_logp").view(-1), c("adv").view(-1), c("ret").view(-1), idx)
+        k.apply()
+        s = k.stats.cpu().numpy()
+        scal.append(s[:5].copy())
+    return np.array(scal)
+
+
+@pytest.mark.parametrize("tag", ["h64_mirror", "h64_learnstd"])
+def test_update_matches_reference_fixture(tag):
+    g = np.load(os.path.join(G, f"ppo_{tag}.npz"))
+    mirror, learn_std = bool(g["mirror"]), bool(g["learn_std"])
+    k = _kernels(g, 64, mirror, learn_std)
+    k.set_tensors({f"a_{n}": g[f"a0_{i}"] for i, n in enumerate(NAMES)})
+    k.set_tensors({f"c_{n}": g[f"c0_{i}"] for i, n in enumerate(NAMES)})
+    k.set_tensors({"stds": g["stds0"]})
+    scal = _run_updates(k, g)
+    ref = g["scalars"]  # actor_loss, entropy_penalty, critic_loss, approx_kl, mirror_loss, imitation, clip_fraction
+    np.testing.assert_allclose(scal[:, 0], ref[:, 0], rtol=1e-4, atol=2e-6)   # actor loss
+    np.testing.assert_allclose(scal[:, 1], ref[:, 2], rtol=1e-4, atol=2e-6)   # critic loss
+    np.testing.assert_allclose(scal[:, 2], ref[:, 4], rtol=1e-4, atol=2e-7)   # mirror loss
+    np.testing.assert_allclose(scal[:, 3], ref[:, 3], rtol=1e-3, atol=2e-6)   # approx KL
+    np.testing.assert_allclose(scal[:, 4], ref[:, 6], rtol=0, atol=1e-6)      # clip fraction
+    t = k.get_tensors()
+    for i, n in enumerate(NAMES):
+        # two Adam steps of lr 3e-4: a wrong gradient SIGN moves a weight by 1.2e-3, so 3e-6 is a tight bar
+        np.testing.assert_allclose(t[f"a_{n}"].numpy(), g[f"a1_{i}"], rtol=0, atol=3e-6, err_msg=f"actor {n}")
+        np.testing.assert_allclose(t[f"c_{n}"].numpy(), g[f"c1_{i}"], rtol=0, atol=3e-6, err_msg=f"critic {n}")
+    np.testing.assert_allclose(t["stds"].numpy(), g["stds1"], rtol=0, atol=3e-6)
+
+
+def test_update_h256_matches_reference_fixture():
+    """Real network size (2x256): weights regenerate from the torch seed through reference_init."""
+    from learninghumanoidwalking_amd.ppo_kernels import reference_init
+    g = np.load(os.path.join(G, "ppo_h256_mirror.npz"))
+    k = _kernels(g, 256, True, False)
+    w0 = reference_init(37, 12, 256, 0.223, generator_seed=int(g["torch_seed"]))
+    k.set_tensors(w0)
+    scal = _run_updates(k, g)
+    ref = g["scalars"]
+    np.testing.assert_allclose(scal[:, 0], ref[:, 0], rtol=1e-4, atol=2e-6)
+    np.testing.assert_allclose(scal[:, 1], ref[:, 2], rtol=1e-4, atol=2e-6)
+    np.testing.assert_allclose(scal[:, 2], ref[:, 4], rtol=1e-4, atol=2e-7)
+    t = k.get_tensors()
+    for i, n in enumerate(NAMES):
+        for pre in ("a", "c"):
+            w1 = t[f"{pre}_{n}"].numpy()
+            np.testing.assert_allclose(w1.reshape(-1)[:64], g[f"{pre}1_head_{i}"], rtol=0, atol=3e-6)
+            dn = np.linalg.norm((w1 - w0[f"{pre}_{n}"].numpy()).astype(np.float64))
+            np.testing.assert_allclose(dn, float(g[f"{pre}1_delta_norm_{i}"]), rtol=2e-3, atol=1e-7)
+
+
+def test_forward_matches_oracle():
+    from learninghumanoidwalking_amd.ppo_kernels import PpoKernels, reference_init
+    from oracle import ppo_oracle as po
+    k = PpoKernels(37, 12, hidden=256, max_rows=1000)
+    w = reference_init(37, 12, 256, 0.223, generator_seed=5)
+    w["a_b1"] += 0.1; w["c_b3"] += 0.3  # exercise the biases
+    k.set_tensors(w)
+    rs = np.random.default_rng(0)
+    mean, std = rs.normal(size=37).astype(np.float32), (0.5 + rs.uniform(size=37)).astype(np.float32)
+    k.set_obs_norm(mean, std)
+    obs = torch.tensor(rs.normal(size=(777, 37)).astype(np.float32))
+    mu, act, logp, val = k.forward(obs.cuda(), deterministic=True)
+    xn = (obs - torch.tensor(mean)) / torch.tensor(std)
+    mu_ref = po.mlp(xn, *[w[f"a_{n}"] for n in NAMES])
+    v_ref = po.mlp(xn, *[w[f"c_{n}"] for n in NAMES])
+    np.testing.assert_allclose(mu.cpu().numpy(), mu_ref.numpy(), rtol=1e-4, atol=2e-6)
+    np.testing.assert_allclose(val.cpu().numpy(), v_ref.numpy()[:, 0], rtol=1e-4, atol=1e-5)
+    np.testing.assert_array_equal(act.cpu().numpy(), mu.cpu().numpy())
+    # stochastic: log-prob of the sampled action is consistent, noise is ~N(0, std)
+    mu2, act2, logp2, _ = k.forward(obs.cuda(), seed=3, counter=7, deterministic=False)
+    z = (act2 - mu2).cpu().numpy() / 0.223
+    assert abs(z.mean()) < 0.03 and abs(z.std() - 1) < 0.03
+    lp_ref = torch.distributions.Normal(mu2.cpu(), 0.223 * torch.ones(12)).log_prob(act2.cpu()).sum(-1)
+    np.testing.assert_allclose(logp2.cpu().numpy(), lp_ref.numpy(), rtol=1e-4, atol=1e-4)
+    # counter-based: same key -> same noise; different counter -> different noise
+    _, act3, _, _ = k.forward(obs.cuda(), seed=3, counter=7, deterministic=False)
+    _, act4, _, _ = k.forward(obs.cuda(), seed=3, counter=8, deterministic=False)
+    assert torch.equal(act2, act3) and not torch.equal(act2, act4)
+
+
+def test_gae_matches_oracle_and_toy():
+    from learninghumanoidwalking_amd.ppo_kernels import PpoKernels
+    from oracle import ppo_oracle as po
+    k = PpoKernels(5, 1, hidden=64, max_rows=64)
+    rs = np.random.default_rng(3)
+    T, N = 50, 33
+    rew = rs.normal(size=(T, N)).astype(np.float32)
+    val = rs.normal(size=(T, N)).astype(np.float32)
+    done = (rs.uniform(size=(T, N)) < 0.08).astype(np.uint8) * rs.integers(1, 4, size=(T, N)).astype(np.uint8)
+    vterm = rs.normal(size=(T, N)).astype(np.float32)
+    vfinal = rs.normal(size=N).astype(np.float32)
+    c = lambda a: torch.tensor(a).cuda()
+    ret, adv = k.gae(c(rew), c(val), c(done), c(vterm), c(vfinal), 0.99, 0.95)
+    ref = po.gae_batch(rew, val, done, vterm, vfinal, 0.99, 0.95)
+    np.testing.assert_allclose(ret.cpu().numpy(), ref, rtol=0, atol=1e-6)   # float64 scan, float32 store
+    np.testing.assert_allclose(adv.cpu().numpy(), ref - val, rtol=0, atol=1e-6)
+    # SURVEY.md 8c known answer
+    one = lambda v, n: torch.full((n, 1), v, dtype=torch.float32, device="cuda")
+    r2, _ = k.gae(one(1.0, 5), one(0.5, 5), torch.zeros(5, 1, dtype=torch.uint8, device="cuda"), one(0.0, 5), one(0.25, 1).view(1), 0.99, 0.95)
+    np.testing.assert_allclose(r2.cpu().numpy()[:, 0], [4.723518165117246, 3.9327678523309375, 3.091991336875, 2.19802375, 1.2475], rtol=0, atol=5e-7)
+
+
+def test_large_minibatch_against_oracle():
+    """B = 5000 rows (several 64-row tiles, split-K chunks, ragged edges) vs the CPU oracle."""
+    from learninghumanoidwalking_amd.ppo_kernels import PpoKernels, reference_init
+    from oracle import ppo_oracle as po
+    B, D, A, H = 5000, 37, 12, 256
+    mo, ma = po.mirror_tables(MIR_OBS, [29, 30]), po.mirror_tables(MIR_ACT)
+    k = PpoKernels(D, A, hidden=H, max_rows=B, mirror_obs=mo, mirror_act=ma)
+    w = reference_init(D, A, H, 0.223, generator_seed=21)
+    k.set_tensors(w)
+    rs = np.random.default_rng(4)
+    mean, std = rs.normal(size=D).astype(np.float32) * 0.1, (0.5 + rs.uniform(size=D)).astype(np.float32)
+    k.set_obs_norm(mean, std)
+    orc = po.OraclePPO([w[f"a_{n}"] for n in NAMES], [w[f"c_{n}"] for n in NAMES], w["stds"], mean, std, mirror_obs=mo, mirror_act=ma)
+    R = 6000
+    obs = torch.tensor(rs.normal(size=(R, D)).astype(np.float32))
+    with torch.no_grad():
+        mu = orc.mu(obs)
+    act = mu + 0.3 * torch.tensor(rs.normal(size=(R, A)).astype(np.float32))
+    with torch.no_grad():
+        old_logp = orc.log_prob(obs, act) + 0.05 * torch.tensor(rs.normal(size=(R, 1)).astype(np.float32))
+    ret = torch.tensor(rs.normal(size=(R, 1)).astype(np.float32))
+    adv = torch.tensor(rs.normal(size=(R, 1)).astype(np.float32))
+    idx = torch.tensor(rs.permutation(R)[:B].astype(np.int32))
+    li = idx.long()
+    res = orc.update(obs[li], act[li], ret[li], adv[li], old_logp[li])
+    xn, xm = k.normalize(obs.cuda())
+    k.stats.zero_()
+    k.grad_minibatch(xn, xm, act.cuda(), old_logp.view(-1).cuda(), adv.view(-1).cuda(), ret.view(-1).cuda(), idx.cuda())
+    k.apply()
+    s = k.stats.cpu().numpy()
+    np.testing.assert_allclose([s[0], s[1], s[2], s[3], s[4]], [res[0], res[2], res[4], res[3], res[6]], rtol=2e-4, atol=2e-6)
+    t = k.get_tensors()
+    for i, n in enumerate(NAMES):
+        np.testing.assert_allclose(t[f"a_{n}"].numpy(), orc.actor[i].detach().numpy(), rtol=0, atol=2e-6, err_msg=f"actor {n}")
+        np.testing.assert_allclose(t[f"c_{n}"].numpy(), orc.critic[i].detach().numpy(), rtol=0, atol=2e-6, err_msg=f"critic {n}")
