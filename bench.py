@@ -1,0 +1,194 @@
+"""Headline benchmark: env-steps/s (whole job) and PPO-iters/s of the on-device rollout + PPO update.
+
+One "step" = one PPO iteration: T control steps for each of N envs (policy + critic inference and the
+fused env step on device), GAE, then `epochs` passes of minibatch updates over the N*T samples --
+exactly the per-iteration body of the reference's PPO.train (reference rl/algos/ppo.py:459-566).
+
+    python bench.py --gpus 1 --steps 3 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
+
+Prints ONE JSON line (rank 0).  Nothing here reads /root/reference.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from types import SimpleNamespace
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+MFMA_F32_PEAK_TFLOPS = 157.3  # f32-input MFMA peak (= f32 vector peak)
+FP64_VALU_PEAK_TFLOPS = 78.6
+
+
+def cpu_baseline_worker(a):
+    """Oracle env + batch-1 torch actor/critic forward per step on one host core (the reference worker's
+    per-step work, rl/workers/rollout_worker.py:142-146).  Returns env-steps done and seconds."""
+    env_name, steps, seed = a
+    import numpy as np
+    import torch
+    torch.set_num_threads(1)
+    from oracle import make_oracle_env
+    env, obs_dim, act_dim = make_oracle_env(env_name, seed)
+    obs = env.reset()
+    W = [torch.randn(256, obs_dim) * 0.1, torch.zeros(256), torch.randn(256, 256) * 0.05, torch.zeros(256)]
+    Wa, Wc = torch.randn(act_dim, 256) * 0.01, torch.randn(1, 256) * 0.05
+    t0 = time.time()
+    with torch.no_grad():
+        for i in range(steps):
+            x = torch.as_tensor(obs, dtype=torch.float32)
+            h = torch.relu(torch.relu(x @ W[0].T + W[1]) @ W[2].T + W[3])
+            a = (h @ Wa.T + 0.223 * torch.randn(act_dim)).numpy()
+            _v = h @ Wc.T
+            obs, r, flags, _, _ = env.step_auto(a)
+    return steps, time.time() - t0
+
+
+def run_cpu_baseline(env_name, target_seconds=15.0):
+    import multiprocessing as mp
+    cores = min(os.cpu_count() or 1, 16)
+    probe, dt = cpu_baseline_worker((env_name, 50, 0))
+    per_step = dt / probe
+    steps = max(50, int(target_seconds / per_step))
+    ctx = mp.get_context("spawn")
+    t0 = time.time()
+    with ctx.Pool(cores) as pool:
+        res = pool.map(cpu_baseline_worker, [(env_name, steps, 100 + i) for i in range(cores)])
+    wall = time.time() - t0
+    total = sum(r[0] for r in res)
+    busy = max(r[1] for r in res)
+    return dict(value=total / busy, unit="env-steps/s", cores=cores, kind="port",
+                sample=f"{cores} processes x {steps} control steps of the float64 CPU oracle ({env_name}, stand-in for the "
+                       f"reference's Ray workers: oracle physics + numpy task logic + batch-1 torch actor/critic forward); "
+                       f"sampling only, no PPO update; {busy:.1f}s busy / {wall:.1f}s wall")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--env", default=os.environ.get("LHW_BENCH_ENV", "auto"))
+    ap.add_argument("--num-envs", type=int, default=4096, help="envs per GPU")
+    ap.add_argument("--traj-len", type=int, default=400, help="control steps per env per iteration (max_traj_len)")
+    ap.add_argument("--minibatch-size", type=int, default=32768, help="per-GPU minibatch rows")
+    ap.add_argument("--epochs", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-mirror", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    from learninghumanoidwalking_amd import envs as lenvs
+    from learninghumanoidwalking_amd.ppo import PPO
+    env_name = args.env
+    if env_name == "auto":
+        env_name = "jvrc_walk" if hasattr(lenvs, "JvrcWalkSpec") else "cartpole"
+    spec_cls = {"cartpole": lenvs.CartpoleSpec, "jvrc_walk": getattr(lenvs, "JvrcWalkSpec", None)}[env_name]
+    ppo_args = SimpleNamespace(
+        gamma=0.99, lam=0.95, lr=3e-4, eps=1e-5, entropy_coeff=0.0, clip=0.2, minibatch_size=args.minibatch_size,
+        epochs=args.epochs, max_traj_len=args.traj_len, num_procs=args.num_envs, num_envs=args.num_envs, max_grad_norm=0.5,
+        mirror_coeff=0.4, eval_freq=10**9, recurrent=False, imitate=None, imitate_coeff=0.3, learn_std=False,
+        std_dev=0.223, no_mirror=args.no_mirror, continued=None, logdir=os.path.join("/tmp", f"lhw_bench_{os.getpid()}"),
+        device_index=local_rank)
+    algo = PPO(spec_cls, ppo_args, seed=0)
+    if algo.obs_rms is not None:  # cartpole path: frozen running normalisation after a short warm-up (ppo.py:442-457)
+        b = algo.sample_parallel_with_workers()
+        algo.obs_rms.update(b.states.cpu().numpy())
+        algo.kernels.set_obs_norm(algo.obs_rms.mean, algo.obs_rms.std)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # per-launch timing of the env-step kernel with HIP events on the launch stream (rank 0 only)
+    env = algo.env
+    step_events = []
+    orig_step = env.step
+    timing = {"on": False}
+
+    def timed_step(*a, **k):
+        if not timing["on"]:
+            return orig_step(*a, **k)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        r = orig_step(*a, **k)
+        e1.record()
+        step_events.append((e0, e1))
+        return r
+
+    env.step = timed_step
+    for i in range(args.warmup):
+        algo.iterate(i)
+    barrier()
+    timing["on"] = rank == 0
+    t0 = time.time()
+    sample_t = opt_t = 0.0
+    for i in range(args.steps):
+        _, st, ot = algo.iterate(args.warmup + i)
+        sample_t += st
+        opt_t += ot
+    barrier()
+    elapsed = time.time() - t0
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    elapsed = float(tmax[0])
+
+    if rank == 0:
+        N, T, K = args.num_envs, args.traj_len, args.steps
+        total_env_steps = N * T * K * world
+        value = total_env_steps / elapsed
+        step_ms = [a.elapsed_time(b) for a, b in step_events]
+        avg_step_ms = float(np.mean(step_ms)) if step_ms else float("nan")
+        spec = algo.spec
+        bytes_per_env_step = spec.algorithmic_bytes_per_env_step()
+        flops_per_env_step = spec.algorithmic_flops_per_env_step()
+        achieved_gbs = bytes_per_env_step * N / (avg_step_ms * 1e-3) / 1e9
+        roofline = dict(bound="hbm", kernel=spec.step_kernel_name, achieved=achieved_gbs, peak=HBM_PEAK_GBS, unit="GB/s",
+                        frac=achieved_gbs / HBM_PEAK_GBS, traffic=None, avg_launch_ms=avg_step_ms, launches=len(step_ms),
+                        algorithmic_bytes_per_env_step=bytes_per_env_step,
+                        note="the fused control-step kernel touches each env's state once per control step, so it is "
+                             "bound by on-chip fp64 latency/VALU issue, not HBM (SURVEY.md 8d); fp64 VALU fraction below",
+                        valu_fp64=dict(achieved_tflops=flops_per_env_step * N / (avg_step_ms * 1e-3) / 1e12,
+                                       peak_tflops=FP64_VALU_PEAK_TFLOPS,
+                                       frac=flops_per_env_step * N / (avg_step_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS))
+        L = algo.last_losses
+        upd_flops = algo.kernels_update_flops_per_sample_epoch() * N * T * args.epochs if hasattr(algo, "kernels_update_flops_per_sample_epoch") else None
+        out = dict(
+            metric="env-steps/s (whole job): on-device rollout + GAE + PPO update", value=value, unit="env-steps/s",
+            n_gpus=world, steps=K, warmup=args.warmup, ms_per_step=elapsed / K * 1e3, higher_is_better=True, scaling="weak",
+            vs_baseline=None, dtype="f64 physics / f32 networks", data="synthetic",
+            config=dict(workload=f"{env_name} @ {N} envs/GPU, T={T} control steps/iter, {args.epochs} epochs, "
+                                 f"minibatch {args.minibatch_size}/GPU" + (" (JVRC stand-in model)" if env_name.startswith("jvrc") else ""),
+                        envs_per_gpu=N, traj_len=T, epochs=args.epochs, minibatch_per_gpu=args.minibatch_size,
+                        mirror=not args.no_mirror and spec.mirror_tables() is not None,
+                        frame_skip=spec.frame_skip, sim_dt=spec.sim_dt, control_dt=spec.control_dt),
+            ppo_iters_per_s=K / elapsed, sample_s_per_iter=sample_t / K, optimize_s_per_iter=opt_t / K,
+            optimizer_steps_per_iter=L.get("n_updates"), roofline=roofline)
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = run_cpu_baseline(env_name)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,13 +1,1352 @@
-// placeholder until the wave-per-env stepper lands (next commit)
+// Wave-per-environment rigid-body + soft-contact stepper with the walking task fused in.
+//
+// One 64-lane wavefront advances one humanoid by a whole control step per launch:
+//   frame_skip x { PD law -> forward dynamics -> constraint solve -> Euler }  then
+//   task state machine, rewards, termination, observation, and (optionally) the episode
+//   bookkeeping + reset of the reference's rollout worker.
+// It takes over RobotBase.step/_do_simulation (reference robots/robot_base.py:41-98),
+// RobotInterface.step_pd/set_motor_torque/step -> mujoco.mj_step (reference
+// envs/common/robot_interface.py:493-546), BaseHumanoidEnv.step/reset_model/get_obs (reference
+// envs/common/base_humanoid_env.py:177-276) and WalkingTask (reference tasks/walking_task.py:85-205,
+// tasks/rewards.py:9-194).
+//
+// Physics = the MuJoCo pipeline subset of SURVEY.md Appendix A, float64: kinematics, com-based
+// spatial quantities, CRBA (+armature), RNE bias, joint damping, motor actuation with ctrl/force
+// clamps, primitive collisions (plane-{sphere,capsule,box}, sphere-sphere, sphere-capsule,
+// capsule-capsule), joint-limit rows, pyramidal contact rows with MuJoCo's impedance / reference
+// acceleration / regulariser model, the primal Newton solver with exact line search and warm
+// start, Euler integration with implicit joint damping.
+//
+// Mapping onto CDNA4: the env's working set (body frames, spatial inertias, M, J, H ...) lives in
+// LDS for the whole launch; nv-vectors are held one element per lane (lane i <-> dof i) and
+// efc-vectors one row per lane, so mat-vec products are conflict-free LDS row/column sweeps and
+// reductions are wavefront shuffles; the only serial chains are the kinematic tree levels and the
+// Cholesky columns.  The persistent state is one contiguous 1.2 KB record per env, read and
+// written once per control step with lane-strided (coalesced) accesses.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstring>
+#include <vector>
+
 #include "lhw_internal.h"
-struct HumanoidEnv { double* ep_stats; };
-int humanoid_create(HumanoidEnv**, const std::vector<int32_t>&, const std::vector<double>&, const LhwEnvConfig*, int*, int*, int*) {
-  return lhw_fail(LHW_ERR_UNSUPPORTED, "humanoid stepper not built yet");
+#include "lhw_rng.h"
+
+#define NB 24   // bodies
+#define NV 20   // dofs
+#define LDV 21  // padded row length of nv x nv matrices and of J (odd => conflict-free 64-bit column sweeps)
+#define NQ 21
+#define NJ 16   // joints
+#define NG 16   // geoms
+#define NP 32   // collision candidate pairs
+#define NC 12   // contacts kept per step
+#define NE 64   // constraint rows (one per lane)
+#define NU 16   // actuators
+#define NTRI (NV * (NV + 1) / 2)
+#define HMINVAL 1e-15
+
+enum { JT_FREE = 0, JT_SLIDE = 2, JT_HINGE = 3 };
+enum { G_PLANE = 0, G_SPHERE = 2, G_CAPSULE = 3, G_BOX = 6 };
+enum { MODE_STANDING = 0, MODE_INPLACE = 1, MODE_FORWARD = 2 };
+
+// persistent record (doubles)
+#define R_QPOS 0
+#define R_QVEL (R_QPOS + NQ)
+#define R_WARM (R_QVEL + NV)
+#define R_SQ (R_WARM + NV)       // joint position of each actuator at the last forward pass (actuator_length / gear)
+#define R_SV (R_SQ + NU)         // joint velocity, likewise
+#define R_FRC (R_SV + NU)        // actuator_force of the last forward pass
+#define R_PREVPRED (R_FRC + NU)  // prev_prediction (action smoothing)
+#define R_PREVACT (R_PREVPRED + NU)
+#define R_PREVTQ (R_PREVACT + NU)
+#define R_MODEREF (R_PREVTQ + NU)
+#define R_EPRET (R_MODEREF + 3)
+#define REC_D 168
+static_assert(R_EPRET < REC_D, "record too small");
+// int record
+#define RI_PHASE 0
+#define RI_MODE 1
+#define RI_TRAJ 2
+#define RI_STEPCNT 3
+#define RI_RESETCNT 4
+#define RI_STARTED 5  // prev_action / prev_torque initialised (robot_base.py:82-85: only once, never reset)
+#define REC_I 8
+
+struct HModel {
+  int nq, nv, nu, nbody, njnt, ngeom, npair, nlevel, nmpair, iterations, disableflags;
+  double timestep, gravity[3], tolerance, meaninertia, totalmass;
+  const int *body_parentid, *body_rootid, *body_jntadr, *body_jntnum, *body_dofadr, *body_dofnum, *body_weldid;
+  const double *body_pos, *body_quat, *body_ipos, *body_iquat, *body_mass, *body_inertia, *body_invweight0;
+  const int *jnt_type, *jnt_bodyid, *jnt_qposadr, *jnt_dofadr, *jnt_limited;
+  const double *jnt_pos, *jnt_axis, *jnt_range, *jnt_solref, *jnt_solimp, *jnt_margin;
+  const int *dof_bodyid, *dof_jntid;
+  const double *dof_armature, *dof_damping, *dof_invweight0, *qpos0;
+  const int *geom_type, *geom_bodyid, *geom_condim, *geom_priority;
+  const double *geom_pos, *geom_quat, *geom_size, *geom_friction, *geom_solmix, *geom_solref, *geom_solimp, *geom_margin, *geom_gap;
+  const int *pair_geom1, *pair_geom2;
+  const int *actuator_trnid, *actuator_ctrllimited, *actuator_forcelimited;
+  const double *actuator_gear, *actuator_ctrlrange, *actuator_forcerange;
+  // derived tables (host-built)
+  const int *body_level, *body_subend, *mpair_i, *mpair_j, *act_dof;
+  const unsigned *body_dofmask, *dof_prevmask;
+};
+
+struct HParams {
+  int n_envs, frame_skip, max_traj_len, period;
+  int root_body, head_body, rfoot_body, lfoot_body;
+  unsigned env_id_base;
+  unsigned long long seed;
+  double action_smoothing, goal_height;
+  const double *kp, *kd, *nominal_qpos, *action_offset, *clock_lut, *neutral_pose;
+};
+
+struct HState {
+  double* rec;     // [N][REC_D]
+  int* irec;       // [N][REC_I]
+  double* ep_stats;
+};
+
+struct HumanoidEnv {
+  HModel m;
+  HParams p;
+  HState st;
+  std::vector<void*> dev_allocs;
+  int device;
+};
+
+// ------------------------------------------------------------------------------------------------ LDS working set
+struct Lds {
+  double qpos[NQ], qvel[NV], ctrl[NU];
+  double xpos[NB * 3], xquat[NB * 4], xmat[NB * 9], xipos[NB * 3];
+  double xanchor[NJ * 3], xaxis[NJ * 3];
+  double com[4];
+  double cinert[NB * 10], crb[NB * 10];
+  double cdof[NV * 6], cdofdot[NV * 6];
+  double cvel[NB * 6], cacc[NB * 6], cfrc[NB * 6], csub[NB * 6];
+  double gpos[NG * 3], gmat[NG * 9];
+  double M[NV * LDV], H[NV * LDV];
+  double J[NE * LDV];
+  double vec[NV], vec2[NV], evec[NE];
+  double qfrc_smooth[NV], qacc_smooth[NV], qacc[NV], qfrc_constraint[NV], damping[NV];
+  double efc_pos[NE], efc_margin[NE], efc_D[NE], efc_aref[NE], efc_K[NE], efc_B[NE], efc_imp[NE], efc_force[NE];
+  double con_dist[NC], con_pos[NC * 3], con_frame[NC * 9], con_mu[NC], con_solref[NC * 2], con_solimp[NC * 5], con_margin[NC];
+  int con_g1[NC], con_g2[NC], con_dim[NC], con_row[NC];
+  double sq[NU], sv[NU], frc[NU];
+  int ncon, nefc, nlim, overflow;
+};
+
+#define SYNC() __syncthreads()
+
+// ------------------------------------------------------------------------------------------------ small math
+__device__ __forceinline__ double wave_sum(double v) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
 }
-void humanoid_destroy(HumanoidEnv*) {}
-void humanoid_reset(HumanoidEnv*, const uint8_t*, float*, hipStream_t) {}
-void humanoid_step(HumanoidEnv*, const float*, float*, float*, float*, uint8_t*, float*, hipStream_t) {}
-void humanoid_get_state(HumanoidEnv*, double*, double*, hipStream_t) {}
-void humanoid_set_state(HumanoidEnv*, const double*, const double*, hipStream_t) {}
-double* humanoid_ep_stats(HumanoidEnv* h) { return h->ep_stats; }
-void humanoid_set_iteration(HumanoidEnv*, int64_t) {}
+__device__ __forceinline__ double wave_min(double v) {
+  for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o));
+  return v;
+}
+__device__ __forceinline__ double bcast(double v, int src) { return __shfl(v, src); }
+__device__ __forceinline__ double dot3(const double* a, const double* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+__device__ __forceinline__ void cross3(double* r, const double* a, const double* b) {
+  double x = a[1] * b[2] - a[2] * b[1], y = a[2] * b[0] - a[0] * b[2], z = a[0] * b[1] - a[1] * b[0];
+  r[0] = x; r[1] = y; r[2] = z;
+}
+__device__ __forceinline__ double normalize3(double* a) {
+  double n = sqrt(dot3(a, a));
+  if (n < HMINVAL) { a[0] = 1; a[1] = 0; a[2] = 0; return n; }
+  double inv = 1.0 / n;
+  a[0] *= inv; a[1] *= inv; a[2] *= inv;
+  return n;
+}
+__device__ __forceinline__ void normalize4(double* q) {
+  double n = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  if (n < HMINVAL) { q[0] = 1; q[1] = q[2] = q[3] = 0; return; }
+  double inv = 1.0 / n;
+  q[0] *= inv; q[1] *= inv; q[2] *= inv; q[3] *= inv;
+}
+__device__ __forceinline__ void mul_quat(double* r, const double* a, const double* b) {
+  double t0 = a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3];
+  double t1 = a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2];
+  double t2 = a[0] * b[2] - a[1] * b[3] + a[2] * b[0] + a[3] * b[1];
+  double t3 = a[0] * b[3] + a[1] * b[2] - a[2] * b[1] + a[3] * b[0];
+  r[0] = t0; r[1] = t1; r[2] = t2; r[3] = t3;
+}
+__device__ __forceinline__ void quat2mat(double* R, const double* q) {
+  double q00 = q[0] * q[0], q11 = q[1] * q[1], q22 = q[2] * q[2], q33 = q[3] * q[3];
+  double q01 = q[0] * q[1], q02 = q[0] * q[2], q03 = q[0] * q[3], q12 = q[1] * q[2], q13 = q[1] * q[3], q23 = q[2] * q[3];
+  R[0] = q00 + q11 - q22 - q33; R[4] = q00 - q11 + q22 - q33; R[8] = q00 - q11 - q22 + q33;
+  R[1] = 2 * (q12 - q03); R[2] = 2 * (q13 + q02); R[3] = 2 * (q12 + q03);
+  R[5] = 2 * (q23 - q01); R[6] = 2 * (q13 - q02); R[7] = 2 * (q23 + q01);
+}
+__device__ __forceinline__ void mat_vec(double* r, const double* R, const double* v) {
+  double x = R[0] * v[0] + R[1] * v[1] + R[2] * v[2], y = R[3] * v[0] + R[4] * v[1] + R[5] * v[2],
+         z = R[6] * v[0] + R[7] * v[1] + R[8] * v[2];
+  r[0] = x; r[1] = y; r[2] = z;
+}
+__device__ __forceinline__ void matT_vec(double* r, const double* R, const double* v) {
+  double x = R[0] * v[0] + R[3] * v[1] + R[6] * v[2], y = R[1] * v[0] + R[4] * v[1] + R[7] * v[2],
+         z = R[2] * v[0] + R[5] * v[1] + R[8] * v[2];
+  r[0] = x; r[1] = y; r[2] = z;
+}
+__device__ __forceinline__ void axis_angle_quat(double* q, const double* ax, double ang) {
+  double s = sin(0.5 * ang);
+  q[0] = cos(0.5 * ang); q[1] = ax[0] * s; q[2] = ax[1] * s; q[3] = ax[2] * s;
+}
+// 10-number com-based inertia times spatial motion vector [rot; lin]
+__device__ __forceinline__ void inert_vec(double* r, const double* i, const double* v) {
+  r[0] = i[0] * v[0] + i[3] * v[1] + i[4] * v[2] - i[8] * v[4] + i[7] * v[5];
+  r[1] = i[3] * v[0] + i[1] * v[1] + i[5] * v[2] + i[8] * v[3] - i[6] * v[5];
+  r[2] = i[4] * v[0] + i[5] * v[1] + i[2] * v[2] - i[7] * v[3] + i[6] * v[4];
+  r[3] = i[8] * v[1] - i[7] * v[2] + i[9] * v[3];
+  r[4] = i[6] * v[2] - i[8] * v[0] + i[9] * v[4];
+  r[5] = i[7] * v[0] - i[6] * v[1] + i[9] * v[5];
+}
+
+// ------------------------------------------------------------------------------------------------ dense SPD solve, wave-parallel
+// Left-looking Cholesky on the lower triangle of A (n x n, leading dimension LDV), in place.  Lane i owns row i.
+__device__ void chol_factor(double* A, int n, int lane) {
+  for (int j = 0; j < n; j++) {
+    double s = 0;
+    if (lane >= j && lane < n) {
+      s = A[lane * LDV + j];
+      for (int p = 0; p < j; p++) s -= A[lane * LDV + p] * A[j * LDV + p];
+    }
+    double d = sqrt(fmax(bcast(s, j), HMINVAL));
+    if (lane == j) A[j * LDV + j] = d;
+    else if (lane > j && lane < n) A[lane * LDV + j] = s / d;
+    SYNC();
+  }
+}
+// x (lane i holds element i) <- A^-1 x with A = L L^T
+__device__ double chol_solve(const double* L, int n, int lane, double x) {
+  for (int j = 0; j < n; j++) {
+    double ljj = L[j * LDV + j];
+    double yj = bcast(x, j) / ljj;
+    if (lane == j) x = yj;
+    else if (lane > j && lane < n) x -= L[lane * LDV + j] * yj;
+  }
+  for (int j = n - 1; j >= 0; j--) {
+    double ljj = L[j * LDV + j];
+    double xj = bcast(x, j) / ljj;
+    if (lane == j) x = xj;
+    else if (lane < j) x -= L[j * LDV + lane] * xj;
+  }
+  return x;
+}
+
+// ------------------------------------------------------------------------------------------------ forward dynamics phases
+__device__ void fwd_kinematics(const HModel& m, Lds& S, int lane) {
+  if (lane == 0) {
+    S.xpos[0] = S.xpos[1] = S.xpos[2] = 0;
+    S.xquat[0] = 1; S.xquat[1] = S.xquat[2] = S.xquat[3] = 0;
+    for (int k = 0; k < 9; k++) S.xmat[k] = (k % 4 == 0) ? 1.0 : 0.0;
+    S.xipos[0] = S.xipos[1] = S.xipos[2] = 0;
+  }
+  SYNC();
+  for (int lvl = 1; lvl < m.nlevel; lvl++) {
+    const int b = lane;
+    if (b < m.nbody && m.body_level[b] == lvl) {
+      const int par = m.body_parentid[b], jn = m.body_jntnum[b], ja = m.body_jntadr[b];
+      double xp[3], xq[4], R[9];
+      if (jn == 1 && m.jnt_type[ja] == JT_FREE) {
+        const int qa = m.jnt_qposadr[ja];
+        double q[4] = {S.qpos[qa + 3], S.qpos[qa + 4], S.qpos[qa + 5], S.qpos[qa + 6]};
+        normalize4(q);
+        for (int k = 0; k < 4; k++) { S.qpos[qa + 3 + k] = q[k]; xq[k] = q[k]; }
+        for (int k = 0; k < 3; k++) { xp[k] = S.qpos[qa + k]; S.xanchor[3 * ja + k] = xp[k]; S.xaxis[3 * ja + k] = m.jnt_axis[3 * ja + k]; }
+      } else {
+        double t[3], bp[3] = {m.body_pos[3 * b], m.body_pos[3 * b + 1], m.body_pos[3 * b + 2]};
+        double bq[4] = {m.body_quat[4 * b], m.body_quat[4 * b + 1], m.body_quat[4 * b + 2], m.body_quat[4 * b + 3]};
+        double pq[4] = {S.xquat[4 * par], S.xquat[4 * par + 1], S.xquat[4 * par + 2], S.xquat[4 * par + 3]};
+        mat_vec(t, &S.xmat[9 * par], bp);
+        for (int k = 0; k < 3; k++) xp[k] = S.xpos[3 * par + k] + t[k];
+        mul_quat(xq, pq, bq);
+        for (int jj = 0; jj < jn; jj++) {
+          const int j = ja + jj;
+          double ax[3] = {m.jnt_axis[3 * j], m.jnt_axis[3 * j + 1], m.jnt_axis[3 * j + 2]};
+          double jp[3] = {m.jnt_pos[3 * j], m.jnt_pos[3 * j + 1], m.jnt_pos[3 * j + 2]};
+          double waxis[3], anchor[3];
+          quat2mat(R, xq);
+          mat_vec(waxis, R, ax);
+          mat_vec(anchor, R, jp);
+          for (int k = 0; k < 3; k++) { anchor[k] += xp[k]; S.xanchor[3 * j + k] = anchor[k]; S.xaxis[3 * j + k] = waxis[k]; }
+          const double q = S.qpos[m.jnt_qposadr[j]] - m.qpos0[m.jnt_qposadr[j]];
+          if (m.jnt_type[j] == JT_SLIDE) {
+            for (int k = 0; k < 3; k++) xp[k] += waxis[k] * q;
+          } else {
+            double ql[4], v[3];
+            axis_angle_quat(ql, ax, q);
+            mul_quat(xq, xq, ql);
+            quat2mat(R, xq);
+            mat_vec(v, R, jp);
+            for (int k = 0; k < 3; k++) xp[k] = anchor[k] - v[k];
+          }
+        }
+      }
+      normalize4(xq);
+      quat2mat(R, xq);
+      double ip[3] = {m.body_ipos[3 * b], m.body_ipos[3 * b + 1], m.body_ipos[3 * b + 2]}, t[3];
+      mat_vec(t, R, ip);
+      for (int k = 0; k < 3; k++) { S.xpos[3 * b + k] = xp[k]; S.xipos[3 * b + k] = xp[k] + t[k]; }
+      for (int k = 0; k < 4; k++) S.xquat[4 * b + k] = xq[k];
+      for (int k = 0; k < 9; k++) S.xmat[9 * b + k] = R[k];
+      // rotated inertia T = Ri diag(I) Ri^T of the body (completed with the com offset in fwd_com)
+      double iq[4] = {m.body_iquat[4 * b], m.body_iquat[4 * b + 1], m.body_iquat[4 * b + 2], m.body_iquat[4 * b + 3]}, qi[4], Ri[9];
+      mul_quat(qi, xq, iq);
+      quat2mat(Ri, qi);
+      const double I0 = m.body_inertia[3 * b], I1 = m.body_inertia[3 * b + 1], I2 = m.body_inertia[3 * b + 2];
+      double* ci = &S.cinert[10 * b];
+      ci[0] = Ri[0] * I0 * Ri[0] + Ri[1] * I1 * Ri[1] + Ri[2] * I2 * Ri[2];
+      ci[1] = Ri[3] * I0 * Ri[3] + Ri[4] * I1 * Ri[4] + Ri[5] * I2 * Ri[5];
+      ci[2] = Ri[6] * I0 * Ri[6] + Ri[7] * I1 * Ri[7] + Ri[8] * I2 * Ri[8];
+      ci[3] = Ri[0] * I0 * Ri[3] + Ri[1] * I1 * Ri[4] + Ri[2] * I2 * Ri[5];
+      ci[4] = Ri[0] * I0 * Ri[6] + Ri[1] * I1 * Ri[7] + Ri[2] * I2 * Ri[8];
+      ci[5] = Ri[3] * I0 * Ri[6] + Ri[4] * I1 * Ri[7] + Ri[5] * I2 * Ri[8];
+    }
+    SYNC();
+  }
+}
+
+// subtree com of the (single) dynamic tree rooted at body 1, cinert, cdof  (mj_comPos)
+__device__ void fwd_com(const HModel& m, Lds& S, int lane) {
+  double ms = 0, mx = 0, my = 0, mz = 0;
+  if (lane >= 1 && lane < m.nbody && m.body_rootid[lane] == 1) {
+    ms = m.body_mass[lane];
+    mx = ms * S.xipos[3 * lane]; my = ms * S.xipos[3 * lane + 1]; mz = ms * S.xipos[3 * lane + 2];
+  }
+  ms = wave_sum(ms); mx = wave_sum(mx); my = wave_sum(my); mz = wave_sum(mz);
+  const double com[3] = {mx / ms, my / ms, mz / ms};
+  if (lane == 0) { S.com[0] = com[0]; S.com[1] = com[1]; S.com[2] = com[2]; }
+  if (lane >= 1 && lane < m.nbody) {
+    const int b = lane;
+    const double mass = m.body_mass[b];
+    // static bodies (their own root) use their own com as reference; they never enter M or the bias force
+    const bool dyn = m.body_rootid[b] == 1;
+    double dif[3];
+    for (int k = 0; k < 3; k++) dif[k] = dyn ? S.xipos[3 * b + k] - com[k] : 0.0;
+    double* ci = &S.cinert[10 * b];
+    ci[0] += mass * (dif[1] * dif[1] + dif[2] * dif[2]);
+    ci[1] += mass * (dif[0] * dif[0] + dif[2] * dif[2]);
+    ci[2] += mass * (dif[0] * dif[0] + dif[1] * dif[1]);
+    ci[3] -= mass * dif[0] * dif[1];
+    ci[4] -= mass * dif[0] * dif[2];
+    ci[5] -= mass * dif[1] * dif[2];
+    ci[6] = mass * dif[0]; ci[7] = mass * dif[1]; ci[8] = mass * dif[2]; ci[9] = mass;
+  }
+  if (lane < m.nv) {
+    const int d = lane, j = m.dof_jntid[d], b = m.dof_bodyid[d], t = m.jnt_type[j], k = d - m.jnt_dofadr[j];
+    double off[3], ax[3], c[6];
+    for (int a = 0; a < 3; a++) off[a] = com[a] - S.xanchor[3 * j + a];
+    if (t == JT_FREE && k < 3) {
+      for (int a = 0; a < 6; a++) c[a] = 0;
+      c[3 + k] = 1;
+    } else if (t == JT_SLIDE) {
+      c[0] = c[1] = c[2] = 0;
+      for (int a = 0; a < 3; a++) c[3 + a] = S.xaxis[3 * j + a];
+    } else {
+      if (t == JT_FREE) { ax[0] = S.xmat[9 * b + (k - 3)]; ax[1] = S.xmat[9 * b + 3 + (k - 3)]; ax[2] = S.xmat[9 * b + 6 + (k - 3)]; }
+      else for (int a = 0; a < 3; a++) ax[a] = S.xaxis[3 * j + a];
+      c[0] = ax[0]; c[1] = ax[1]; c[2] = ax[2];
+      cross3(c + 3, ax, off);
+    }
+    for (int a = 0; a < 6; a++) S.cdof[6 * d + a] = c[a];
+  }
+  SYNC();
+}
+
+// composite inertias + joint-space inertia M (mj_crb); lower triangle + mirrored upper
+__device__ void fwd_crb(const HModel& m, Lds& S, int lane) {
+  for (int it = lane; it < m.nbody * 10; it += 64) {
+    const int b = it / 10, k = it - 10 * b;
+    double s = 0;
+    if (b >= 1) for (int d = b; d < m.body_subend[b]; d++) s += S.cinert[10 * d + k];
+    S.crb[it] = s;
+  }
+  for (int it = lane; it < m.nv * LDV; it += 64) S.M[it] = 0;
+  SYNC();
+  // vec scratch: buf_i = crb[body(i)] * cdof_i  kept in csub (6 per dof)
+  if (lane < m.nv) {
+    double buf[6];
+    inert_vec(buf, &S.crb[10 * m.dof_bodyid[lane]], &S.cdof[6 * lane]);
+    for (int a = 0; a < 6; a++) S.csub[6 * lane + a] = buf[a];
+  }
+  SYNC();
+  for (int it = lane; it < m.nmpair; it += 64) {
+    const int i = m.mpair_i[it], j = m.mpair_j[it];
+    double s = 0;
+    for (int a = 0; a < 6; a++) s += S.cdof[6 * j + a] * S.csub[6 * i + a];
+    if (i == j) s += m.dof_armature[i];
+    S.M[i * LDV + j] = s;
+    S.M[j * LDV + i] = s;
+  }
+  SYNC();
+}
+
+// ---- collision (engine_collision_primitive.c restated); writes contact k of this pair when out != null
+struct RawCon { double dist, pos[3], n[3], t[3]; };
+
+__device__ __forceinline__ int col_plane_sphere(RawCon* c, const double* p1, const double* R1, const double* p2, double r, double margin) {
+  double n[3] = {R1[2], R1[5], R1[8]}, dif[3] = {p2[0] - p1[0], p2[1] - p1[1], p2[2] - p1[2]};
+  double dist = dot3(dif, n) - r;
+  if (dist > margin) return 0;
+  c->dist = dist;
+  for (int k = 0; k < 3; k++) { c->n[k] = n[k]; c->t[k] = 0; c->pos[k] = p2[k] - n[k] * (r + 0.5 * dist); }
+  return 1;
+}
+__device__ __forceinline__ int col_sphere_sphere(RawCon* c, const double* p1, double r1, const double* p2, double r2, double margin) {
+  double dif[3] = {p2[0] - p1[0], p2[1] - p1[1], p2[2] - p1[2]};
+  double cd = sqrt(dot3(dif, dif)), dist = cd - r1 - r2;
+  if (dist > margin) return 0;
+  c->dist = dist;
+  if (cd < HMINVAL) { dif[0] = 1; dif[1] = dif[2] = 0; } else { dif[0] /= cd; dif[1] /= cd; dif[2] /= cd; }
+  for (int k = 0; k < 3; k++) { c->n[k] = dif[k]; c->t[k] = 0; c->pos[k] = p1[k] + dif[k] * (r1 + 0.5 * dist); }
+  return 1;
+}
+__device__ int collide_pair(int t1, int t2, const double* p1, const double* R1, const double* s1, const double* p2,
+                            const double* R2, const double* s2, double margin, RawCon* rc) {
+  int n = 0;
+  if (t1 == G_PLANE && t2 == G_SPHERE) n = col_plane_sphere(rc, p1, R1, p2, s2[0], margin);
+  else if (t1 == G_PLANE && t2 == G_CAPSULE) {
+    double ax[3] = {R2[2], R2[5], R2[8]}, e[3];
+    for (int s = 1; s >= -1; s -= 2) {
+      for (int k = 0; k < 3; k++) e[k] = p2[k] + s * ax[k] * s2[1];
+      if (col_plane_sphere(rc + n, p1, R1, e, s2[0], margin)) { for (int k = 0; k < 3; k++) rc[n].t[k] = ax[k]; n++; }
+    }
+  } else if (t1 == G_PLANE && t2 == G_BOX) {
+    double nn[3] = {R1[2], R1[5], R1[8]}, dif[3] = {p2[0] - p1[0], p2[1] - p1[1], p2[2] - p1[2]};
+    double dist = dot3(dif, nn);
+    for (int i = 0; i < 8 && n < 4; i++) {
+      double v[3] = {(i & 1 ? s2[0] : -s2[0]), (i & 2 ? s2[1] : -s2[1]), (i & 4 ? s2[2] : -s2[2])}, corner[3];
+      mat_vec(corner, R2, v);
+      double ld = dot3(nn, corner);
+      if (dist + ld > margin || ld > 0) continue;
+      rc[n].dist = dist + ld;
+      for (int k = 0; k < 3; k++) { rc[n].n[k] = nn[k]; rc[n].t[k] = 0; rc[n].pos[k] = corner[k] + p2[k] - nn[k] * rc[n].dist * 0.5; }
+      n++;
+    }
+  } else if (t1 == G_SPHERE && t2 == G_SPHERE) n = col_sphere_sphere(rc, p1, s1[0], p2, s2[0], margin);
+  else if (t1 == G_SPHERE && t2 == G_CAPSULE) {
+    double ax[3] = {R2[2], R2[5], R2[8]}, vec[3] = {p1[0] - p2[0], p1[1] - p2[1], p1[2] - p2[2]};
+    double x = fmin(s2[1], fmax(-s2[1], dot3(ax, vec)));
+    double q[3] = {p2[0] + ax[0] * x, p2[1] + ax[1] * x, p2[2] + ax[2] * x};
+    n = col_sphere_sphere(rc, p1, s1[0], q, s2[0], margin);
+  } else if (t1 == G_CAPSULE && t2 == G_CAPSULE) {
+    double a1[3] = {R1[2], R1[5], R1[8]}, a2[3] = {R2[2], R2[5], R2[8]}, dif[3] = {p1[0] - p2[0], p1[1] - p2[1], p1[2] - p2[2]};
+    double ma = dot3(a1, a1), mb = -dot3(a1, a2), mc = dot3(a2, a2), u = -dot3(a1, dif), v = dot3(a2, dif);
+    double det = ma * mc - mb * mb;
+    if (fabs(det) >= HMINVAL) {
+      double x1 = (mc * u - mb * v) / det, x2 = (ma * v - mb * u) / det;
+      if (x1 > s1[1]) { x1 = s1[1]; x2 = (v - mb * s1[1]) / mc; }
+      else if (x1 < -s1[1]) { x1 = -s1[1]; x2 = (v + mb * s1[1]) / mc; }
+      if (x2 > s2[1]) { x2 = s2[1]; x1 = fmin(s1[1], fmax(-s1[1], (u - mb * s2[1]) / ma)); }
+      else if (x2 < -s2[1]) { x2 = -s2[1]; x1 = fmin(s1[1], fmax(-s1[1], (u + mb * s2[1]) / ma)); }
+      double q1[3], q2[3];
+      for (int k = 0; k < 3; k++) { q1[k] = p1[k] + a1[k] * x1; q2[k] = p2[k] + a2[k] * x2; }
+      n = col_sphere_sphere(rc, q1, s1[0], q2, s2[0], margin);
+    } else {
+      double q1[3], q2[3], x;
+      for (int s = -1; s <= 1 && n < 2; s += 2) {
+        for (int k = 0; k < 3; k++) q1[k] = p1[k] + s * a1[k] * s1[1];
+        double vv[3] = {q1[0] - p2[0], q1[1] - p2[1], q1[2] - p2[2]};
+        x = dot3(a2, vv);
+        if (x >= -s2[1] && x <= s2[1]) {
+          for (int k = 0; k < 3; k++) q2[k] = p2[k] + a2[k] * x;
+          n += col_sphere_sphere(rc + n, q1, s1[0], q2, s2[0], margin);
+        }
+      }
+      for (int s = -1; s <= 1 && n < 2; s += 2) {
+        for (int k = 0; k < 3; k++) q2[k] = p2[k] + s * a2[k] * s2[1];
+        double vv[3] = {q2[0] - p1[0], q2[1] - p1[1], q2[2] - p1[2]};
+        x = dot3(a1, vv);
+        if (x >= -s1[1] && x <= s1[1]) {
+          for (int k = 0; k < 3; k++) q1[k] = p1[k] + a1[k] * x;
+          n += col_sphere_sphere(rc + n, q1, s1[0], q2, s2[0], margin);
+        }
+      }
+    }
+  }
+  return n;
+}
+
+__device__ void fwd_collision(const HModel& m, Lds& S, int lane) {
+  if (lane < m.ngeom) {
+    const int g = lane, b = m.geom_bodyid[g];
+    double gp[3] = {m.geom_pos[3 * g], m.geom_pos[3 * g + 1], m.geom_pos[3 * g + 2]}, t[3];
+    double gq[4] = {m.geom_quat[4 * g], m.geom_quat[4 * g + 1], m.geom_quat[4 * g + 2], m.geom_quat[4 * g + 3]}, q[4], R[9];
+    double bq[4] = {S.xquat[4 * b], S.xquat[4 * b + 1], S.xquat[4 * b + 2], S.xquat[4 * b + 3]};
+    mat_vec(t, &S.xmat[9 * b], gp);
+    mul_quat(q, bq, gq);
+    quat2mat(R, q);
+    for (int k = 0; k < 3; k++) S.gpos[3 * g + k] = S.xpos[3 * b + k] + t[k];
+    for (int k = 0; k < 9; k++) S.gmat[9 * g + k] = R[k];
+  }
+  if (lane == 0) { S.overflow = 0; }
+  SYNC();
+  RawCon rc[4];
+  int n = 0, g1 = 0, g2 = 0;
+  double margin = 0, gap = 0;
+  if (lane < m.npair) {
+    g1 = m.pair_geom1[lane]; g2 = m.pair_geom2[lane];
+    margin = fmax(m.geom_margin[g1], m.geom_margin[g2]);
+    gap = fmax(m.geom_gap[g1], m.geom_gap[g2]);
+    double p1[3], p2[3], R1[9], R2[9], s1[3], s2[3];
+    for (int k = 0; k < 3; k++) { p1[k] = S.gpos[3 * g1 + k]; p2[k] = S.gpos[3 * g2 + k]; s1[k] = m.geom_size[3 * g1 + k]; s2[k] = m.geom_size[3 * g2 + k]; }
+    for (int k = 0; k < 9; k++) { R1[k] = S.gmat[9 * g1 + k]; R2[k] = S.gmat[9 * g2 + k]; }
+    n = collide_pair(m.geom_type[g1], m.geom_type[g2], p1, R1, s1, p2, R2, s2, margin, rc);
+  }
+  // exclusive prefix sum of contact counts across lanes (pair order == contact order)
+  int incl = n;
+  for (int o = 1; o < 64; o <<= 1) {
+    int v = __shfl_up(incl, o);
+    if (lane >= o) incl += v;
+  }
+  const int base = incl - n;
+  const int total = __shfl(incl, 63);
+  for (int k = 0; k < n; k++) {
+    const int c = base + k;
+    if (c >= NC) continue;
+    S.con_dist[c] = rc[k].dist;
+    double f[9];
+    for (int a = 0; a < 3; a++) { S.con_pos[3 * c + a] = rc[k].pos[a]; f[a] = rc[k].n[a]; f[3 + a] = rc[k].t[a]; }
+    // mju_makeFrame
+    normalize3(f);
+    if (sqrt(dot3(f + 3, f + 3)) < 0.5) {
+      f[3] = f[4] = f[5] = 0;
+      if (f[1] < 0.5 && f[1] > -0.5) f[4] = 1; else f[5] = 1;
+    }
+    double tt = dot3(f, f + 3);
+    for (int a = 0; a < 3; a++) f[3 + a] -= tt * f[a];
+    normalize3(f + 3);
+    cross3(f + 6, f, f + 3);
+    for (int a = 0; a < 9; a++) S.con_frame[9 * c + a] = f[a];
+    S.con_g1[c] = g1; S.con_g2[c] = g2;
+    const double incm = margin - gap;
+    S.con_margin[c] = incm;
+    // mj_contactParam: priority, else solmix-weighted mix; friction = max; condim = max
+    int dim;
+    double mu, sr[2], si[5];
+    const int pr1 = m.geom_priority[g1], pr2 = m.geom_priority[g2];
+    if (pr1 != pr2) {
+      const int g = pr1 > pr2 ? g1 : g2;
+      dim = m.geom_condim[g]; mu = m.geom_friction[3 * g];
+      sr[0] = m.geom_solref[2 * g]; sr[1] = m.geom_solref[2 * g + 1];
+      for (int a = 0; a < 5; a++) si[a] = m.geom_solimp[5 * g + a];
+    } else {
+      dim = max(m.geom_condim[g1], m.geom_condim[g2]);
+      const double m1 = m.geom_solmix[g1], m2 = m.geom_solmix[g2];
+      double mix;
+      if (m1 >= HMINVAL && m2 >= HMINVAL) mix = m1 / (m1 + m2);
+      else if (m1 < HMINVAL && m2 < HMINVAL) mix = 0.5;
+      else mix = m1 < HMINVAL ? 0.0 : 1.0;
+      if (m.geom_solref[2 * g1] > 0 && m.geom_solref[2 * g2] > 0)
+        for (int a = 0; a < 2; a++) sr[a] = mix * m.geom_solref[2 * g1 + a] + (1 - mix) * m.geom_solref[2 * g2 + a];
+      else
+        for (int a = 0; a < 2; a++) sr[a] = fmin(m.geom_solref[2 * g1 + a], m.geom_solref[2 * g2 + a]);
+      for (int a = 0; a < 5; a++) si[a] = mix * m.geom_solimp[5 * g1 + a] + (1 - mix) * m.geom_solimp[5 * g2 + a];
+      mu = fmax(m.geom_friction[3 * g1], m.geom_friction[3 * g2]);
+    }
+    S.con_dim[c] = (rc[k].dist >= incm) ? 0 : dim;  // 0: excluded from the constraint set (gap)
+    S.con_mu[c] = mu;
+    S.con_solref[2 * c] = sr[0]; S.con_solref[2 * c + 1] = sr[1];
+    for (int a = 0; a < 5; a++) S.con_solimp[5 * c + a] = si[a];
+  }
+  if (lane == 0) { S.ncon = min(total, NC); if (total > NC) S.overflow = 1; }
+  SYNC();
+}
+
+// getsolparam + getimpedance + KBIP + R for one row
+__device__ __forceinline__ void row_params(const HModel& m, const double* sr_in, const double* si_in, double pos, double margin,
+                                           double diagApprox, double* K, double* B, double* imp, double* R) {
+  double sr0 = sr_in[0], sr1 = sr_in[1];
+  if (!(m.disableflags & (1 << 11)) && sr0 > 0 && sr0 < 2 * m.timestep) sr0 = 2 * m.timestep;
+  double s0 = fmin(0.9999, fmax(0.0001, si_in[0])), s1 = fmin(0.9999, fmax(0.0001, si_in[1])), s2 = fmax(0.0, si_in[2]);
+  double s3 = fmin(0.9999, fmax(0.0001, si_in[3])), s4 = fmax(1.0, si_in[4]);
+  double im;
+  if (s0 == s1 || s2 <= HMINVAL) im = 0.5 * (s0 + s1);
+  else {
+    double x = fabs((pos - margin) / s2);
+    if (x >= 1) im = s1;
+    else if (x <= 0) im = s0;
+    else {
+      double y;
+      if (s4 == 1) y = x;
+      else if (x <= s3) y = pow(x, s4) / pow(s3, s4 - 1);
+      else y = 1 - pow(1 - x, s4) / pow(1 - s3, s4 - 1);
+      im = s0 + y * (s1 - s0);
+    }
+  }
+  *imp = im;
+  *R = fmax(HMINVAL, (1 - im) / im * diagApprox);
+  if (sr0 > 0) {
+    *K = 1 / fmax(HMINVAL, s1 * s1 * sr0 * sr0 * sr1 * sr1);
+    *B = 2 / fmax(HMINVAL, s1 * sr0);
+  } else {
+    *K = -sr0 / fmax(HMINVAL, s1 * s1);
+    *B = -sr1 / fmax(HMINVAL, s1);
+  }
+}
+
+// mj_makeConstraint: joint-limit rows, then contact rows (pyramidal), with mj_makeImpedance's shared pyramid R
+__device__ void fwd_constraints(const HModel& m, Lds& S, int lane) {
+  // ---- limits: lane = joint; rows ordered by joint, lower side first
+  int nl = 0, lo = 0, hi = 0;
+  double dlo = 0, dhi = 0;
+  if (lane < m.njnt && m.jnt_limited[lane] && (m.jnt_type[lane] == JT_HINGE || m.jnt_type[lane] == JT_SLIDE)) {
+    const double q = S.qpos[m.jnt_qposadr[lane]], mg = m.jnt_margin[lane];
+    dlo = q - m.jnt_range[2 * lane]; dhi = m.jnt_range[2 * lane + 1] - q;
+    lo = dlo < mg; hi = dhi < mg;
+    nl = lo + hi;
+  }
+  int incl = nl;
+  for (int o = 1; o < 64; o <<= 1) { int v = __shfl_up(incl, o); if (lane >= o) incl += v; }
+  const int lbase = incl - nl, nlim = __shfl(incl, 63);
+  // ---- contacts: lane = contact; rows = 4 (condim 3), 1 (condim 1) or 0 (excluded)
+  int nr = 0;
+  if (lane < S.ncon) nr = S.con_dim[lane] == 3 ? 4 : (S.con_dim[lane] == 1 ? 1 : 0);
+  int cincl = nr;
+  for (int o = 1; o < 64; o <<= 1) { int v = __shfl_up(cincl, o); if (lane >= o) cincl += v; }
+  const int cbase = nlim + cincl - nr;
+  int rend = nlim;
+  if (lane < S.ncon) {
+    const bool fits = nr > 0 && cbase + nr <= NE;
+    if (nr > 0 && !fits) S.overflow = 1;  // contacts whose rows do not fit are dropped (counted in ep_stats[3])
+    S.con_row[lane] = fits ? cbase : -1;
+    if (fits) rend = cbase + nr;
+  }
+  for (int o = 32; o > 0; o >>= 1) rend = max(rend, __shfl_xor(rend, o));
+  const int nefc = rend;
+  for (int it = lane; it < nefc * LDV; it += 64) S.J[it] = 0;
+  SYNC();
+  if (nl > 0) {
+    const int j = lane, d = m.jnt_dofadr[j];
+    int r = lbase;
+    double sr[2] = {m.jnt_solref[2 * j], m.jnt_solref[2 * j + 1]}, si[5];
+    for (int a = 0; a < 5; a++) si[a] = m.jnt_solimp[5 * j + a];
+    for (int side = 0; side < 2; side++) {
+      if (!(side == 0 ? lo : hi) || r >= NE) continue;
+      const double dist = side == 0 ? dlo : dhi, mg = m.jnt_margin[j];
+      double K, B, imp, R;
+      row_params(m, sr, si, dist, mg, m.dof_invweight0[d], &K, &B, &imp, &R);
+      S.J[r * LDV + d] = side == 0 ? 1.0 : -1.0;
+      S.efc_pos[r] = dist; S.efc_margin[r] = mg; S.efc_D[r] = 1 / R; S.efc_K[r] = K; S.efc_B[r] = B; S.efc_imp[r] = imp;
+      r++;
+    }
+  }
+  // contact Jacobians: item = (contact, dof)
+  const int ncon = S.ncon;
+  for (int it = lane; it < ncon * m.nv; it += 64) {
+    const int c = it / m.nv, k = it - c * m.nv, r0 = S.con_row[c];
+    if (r0 < 0) continue;
+    const int b1 = m.geom_bodyid[S.con_g1[c]], b2 = m.geom_bodyid[S.con_g2[c]];
+    const unsigned bit = 1u << k;
+    const bool in1 = m.body_dofmask[b1] & bit, in2 = m.body_dofmask[b2] & bit;
+    double d[3] = {0, 0, 0};
+    if (in1 != in2) {
+      double off[3], t[3];
+      for (int a = 0; a < 3; a++) off[a] = S.con_pos[3 * c + a] - S.com[a];
+      cross3(t, &S.cdof[6 * k], off);
+      const double sg = in2 ? 1.0 : -1.0;
+      for (int a = 0; a < 3; a++) d[a] = sg * (S.cdof[6 * k + 3 + a] + t[a]);
+    }
+    const double* f = &S.con_frame[9 * c];
+    const double jn = dot3(f, d);
+    if (S.con_dim[c] == 1) { S.J[r0 * LDV + k] = jn; continue; }
+    const double mu = S.con_mu[c], t1 = mu * dot3(f + 3, d), t2 = mu * dot3(f + 6, d);
+    S.J[(r0 + 0) * LDV + k] = jn + t1;
+    S.J[(r0 + 1) * LDV + k] = jn - t1;
+    S.J[(r0 + 2) * LDV + k] = jn + t2;
+    S.J[(r0 + 3) * LDV + k] = jn - t2;
+  }
+  // contact row parameters: item = (contact, edge)
+  for (int it = lane; it < ncon * 4; it += 64) {
+    const int c = it >> 2, e = it & 3, r0 = S.con_row[c];
+    if (r0 < 0 || (S.con_dim[c] == 1 && e > 0)) continue;
+    const int b1 = m.geom_bodyid[S.con_g1[c]], b2 = m.geom_bodyid[S.con_g2[c]];
+    const double tran = m.body_invweight0[2 * b1] + m.body_invweight0[2 * b2];
+    const double mu = S.con_mu[c];
+    double K, B, imp, R;
+    const double diag = S.con_dim[c] == 1 ? tran : tran + mu * mu * tran;
+    row_params(m, &S.con_solref[2 * c], &S.con_solimp[5 * c], S.con_dist[c], S.con_margin[c], diag, &K, &B, &imp, &R);
+    if (S.con_dim[c] == 3) R = fmax(HMINVAL, 2 * mu * mu * R);  // every pyramid edge shares 2 mu^2 R(first edge)
+    const int r = r0 + e;
+    S.efc_pos[r] = S.con_dist[c]; S.efc_margin[r] = S.con_margin[c]; S.efc_D[r] = 1 / R; S.efc_K[r] = K; S.efc_B[r] = B; S.efc_imp[r] = imp;
+  }
+  if (lane == 0) { S.nefc = nefc; S.nlim = nlim; }
+  SYNC();
+}
+
+// mj_fwdVelocity: cvel, cdof_dot, bias force (RNE, no acceleration), passive damping, constraint reference
+__device__ void fwd_velocity(const HModel& m, Lds& S, int lane) {
+  // velocity seen by dof j when its cdof_dot is formed: sum over dof_prevmask[j]
+  if (lane < m.nv) {
+    const int j = lane;
+    unsigned mask = m.dof_prevmask[j];
+    double v[6] = {0, 0, 0, 0, 0, 0};
+    const bool zero = mask == 0xFFFFFFFFu;  // translational dofs of a free joint: cdof_dot = 0
+    if (!zero)
+      while (mask) {
+        const int k = __ffs(mask) - 1;
+        mask &= mask - 1;
+        const double qv = S.qvel[k];
+        for (int a = 0; a < 6; a++) v[a] += S.cdof[6 * k + a] * qv;
+      }
+    double a3[3], b3[3], c3[3];
+    const double* cd = &S.cdof[6 * j];
+    cross3(a3, v, cd); cross3(b3, v, cd + 3); cross3(c3, v + 3, cd);
+    for (int a = 0; a < 3; a++) {
+      S.cdofdot[6 * j + a] = zero ? 0.0 : a3[a];
+      S.cdofdot[6 * j + 3 + a] = zero ? 0.0 : b3[a] + c3[a];
+    }
+  }
+  SYNC();
+  for (int it = lane; it < m.nbody * 6; it += 64) {
+    const int b = it / 6, a = it - 6 * b;
+    unsigned mask = m.body_dofmask[b];
+    double cv = 0, ca = (a >= 3) ? -m.gravity[a - 3] : 0.0;
+    while (mask) {
+      const int k = __ffs(mask) - 1;
+      mask &= mask - 1;
+      const double qv = S.qvel[k];
+      cv += S.cdof[6 * k + a] * qv;
+      ca += S.cdofdot[6 * k + a] * qv;
+    }
+    S.cvel[it] = cv;
+    S.cacc[it] = ca;
+  }
+  SYNC();
+  if (lane >= 1 && lane < m.nbody) {
+    const int b = lane;
+    double t[6], t2[6], f[6];
+    inert_vec(t, &S.cinert[10 * b], &S.cacc[6 * b]);
+    inert_vec(t2, &S.cinert[10 * b], &S.cvel[6 * b]);
+    const double* v = &S.cvel[6 * b];
+    double a3[3], b3[3], c3[3];
+    cross3(a3, v, t2); cross3(b3, v + 3, t2 + 3); cross3(c3, v, t2 + 3);
+    for (int a = 0; a < 3; a++) { f[a] = a3[a] + b3[a] + t[a]; f[3 + a] = c3[a] + t[3 + a]; }
+    for (int a = 0; a < 6; a++) S.cfrc[6 * b + a] = f[a];
+  }
+  if (lane == 0) for (int a = 0; a < 6; a++) S.cfrc[a] = 0;
+  SYNC();
+  for (int it = lane; it < m.nbody * 6; it += 64) {
+    const int b = it / 6, a = it - 6 * b;
+    double s = 0;
+    if (b >= 1) for (int d = b; d < m.body_subend[b]; d++) s += S.cfrc[6 * d + a];
+    S.csub[it] = s;
+  }
+  SYNC();
+}
+
+// One mj_forward (+ Euler).  flags: bit0 actuation enabled, bit1 integrate.
+// On return S.qacc / S.efc_force / contacts / S.sq,sv,frc describe THIS forward pass (the "stale" fields of note S).
+__device__ __noinline__ void substep(const HModel& m, Lds& S, int lane, int flags, double* warm /* lane-held */) {
+  fwd_kinematics(m, S, lane);
+  fwd_com(m, S, lane);
+  fwd_crb(m, S, lane);
+  fwd_collision(m, S, lane);
+  fwd_constraints(m, S, lane);
+  fwd_velocity(m, S, lane);
+  const int nv = m.nv, nefc = S.nefc;
+  // transmission + actuation (lane = actuator)
+  if (lane < m.nu) {
+    const int j = m.actuator_trnid[lane];
+    const double gear = m.actuator_gear[lane];
+    S.sq[lane] = (gear * S.qpos[m.jnt_qposadr[j]]) / gear;  // actuator_length / gear, as the reference computes it
+    S.sv[lane] = (gear * S.qvel[m.jnt_dofadr[j]]) / gear;
+    double f = 0;
+    if (flags & 1) {
+      double c = S.ctrl[lane];
+      if (m.actuator_ctrllimited[lane]) c = fmin(m.actuator_ctrlrange[2 * lane + 1], fmax(m.actuator_ctrlrange[2 * lane], c));
+      f = c;
+      if (m.actuator_forcelimited[lane]) f = fmin(m.actuator_forcerange[2 * lane + 1], fmax(m.actuator_forcerange[2 * lane], f));
+    }
+    S.frc[lane] = f;
+  }
+  SYNC();
+  // qfrc_smooth (lane = dof) = passive - bias + actuator
+  double fs = 0, qv = 0;
+  if (lane < nv) {
+    qv = S.qvel[lane];
+    double bias = 0;
+    const int b = m.dof_bodyid[lane];
+    for (int a = 0; a < 6; a++) bias += S.cdof[6 * lane + a] * S.csub[6 * b + a];
+    double act = 0;
+    for (int u = 0; u < m.nu; u++)
+      if (m.act_dof[u] == lane) act += m.actuator_gear[u] * S.frc[u];
+    fs = -m.dof_damping[lane] * qv - bias + act;
+    S.qfrc_smooth[lane] = fs;
+    S.vec[lane] = qv;
+  }
+  // factor M in H, qacc_smooth
+  for (int it = lane; it < nv * LDV; it += 64) S.H[it] = S.M[it];
+  SYNC();
+  chol_factor(S.H, nv, lane);
+  const double as = chol_solve(S.H, nv, lane, fs);
+  if (lane < nv) S.qacc_smooth[lane] = as;
+  // constraint reference: aref = -B (J qvel) - K imp (pos - margin)   (lane = row)
+  double aref = 0, D = 0;
+  if (lane < nefc) {
+    double jv = 0;
+    for (int k = 0; k < nv; k++) jv += S.J[lane * LDV + k] * S.vec[k];
+    aref = -S.efc_B[lane] * jv - S.efc_K[lane] * S.efc_imp[lane] * (S.efc_pos[lane] - S.efc_margin[lane]);
+    S.efc_aref[lane] = aref;
+    D = S.efc_D[lane];
+  }
+  SYNC();
+
+  double qacc = as, fcon = 0;  // lane = dof
+  if (nefc > 0) {
+    // ------------------------------------------------------------ primal Newton (engine_solver.c)
+    const double scale = 1.0 / (m.meaninertia * (nv > 1 ? nv : 1));
+    // warm start: cheaper of qacc_warmstart and qacc_smooth
+    if (!(m.disableflags & (1 << 7))) {
+      double w = *warm;
+      if (lane < nv) S.vec[lane] = w;
+      SYNC();
+      double jar = 0, Ma = 0;
+      if (lane < nefc) { for (int k = 0; k < nv; k++) jar += S.J[lane * LDV + k] * S.vec[k]; jar -= aref; }
+      if (lane < nv) for (int k = 0; k < nv; k++) Ma += S.M[lane * LDV + k] * S.vec[k];
+      double cw = (lane < nefc && jar < 0) ? 0.5 * D * jar * jar : 0.0;
+      if (lane < nv) cw += 0.5 * (Ma - fs) * (w - as);
+      cw = wave_sum(cw);
+      SYNC();
+      if (lane < nv) S.vec[lane] = as;
+      SYNC();
+      double jas = 0;
+      if (lane < nefc) { for (int k = 0; k < nv; k++) jas += S.J[lane * LDV + k] * S.vec[k]; jas -= aref; }
+      double cs = wave_sum((lane < nefc && jas < 0) ? 0.5 * D * jas * jas : 0.0);
+      qacc = (cw > cs) ? as : w;
+      SYNC();
+    }
+    double cost = 0, oldcost = 0;
+    for (int iter = 0; iter <= m.iterations; iter++) {
+      if (lane < nv) S.vec[lane] = qacc;
+      SYNC();
+      double jar = 0, Ma = 0;
+      if (lane < nefc) { for (int k = 0; k < nv; k++) jar += S.J[lane * LDV + k] * S.vec[k]; jar -= aref; }
+      if (lane < nv) for (int k = 0; k < nv; k++) Ma += S.M[lane * LDV + k] * S.vec[k];
+      const bool active = lane < nefc && jar < 0;
+      const double force = active ? -D * jar : 0.0;
+      double c = active ? 0.5 * D * jar * jar : 0.0;
+      if (lane < nv) c += 0.5 * (Ma - fs) * (qacc - as);
+      oldcost = cost;
+      cost = wave_sum(c);
+      if (lane < nefc) { S.evec[lane] = force; S.efc_force[lane] = force; }
+      SYNC();
+      double grad = 0;
+      fcon = 0;
+      if (lane < nv) {
+        for (int r = 0; r < nefc; r++) fcon += S.J[r * LDV + lane] * S.evec[r];
+        grad = Ma - fs - fcon;
+      }
+      const double gn = sqrt(wave_sum(grad * grad));
+      if (iter > 0) { if (scale * (oldcost - cost) < m.tolerance || scale * gn < m.tolerance) break; }
+      else if (scale * gn < m.tolerance) break;
+      if (iter == m.iterations) break;
+      // H = M + J^T D_active J  (lower triangle; lanes sweep the packed triangle)
+      SYNC();
+      if (lane < nefc) S.evec[lane] = active ? D : 0.0;
+      SYNC();
+      for (int e = lane; e < nv * (nv + 1) / 2; e += 64) {
+        int i = (int)((sqrt(8.0 * e + 1.0) - 1.0) * 0.5);
+        while ((i + 1) * (i + 2) / 2 <= e) i++;
+        while (i * (i + 1) / 2 > e) i--;
+        const int j = e - i * (i + 1) / 2;
+        double h = S.M[i * LDV + j];
+        for (int r = 0; r < nefc; r++) {
+          const double dr = S.evec[r];
+          if (dr != 0.0) h += dr * S.J[r * LDV + i] * S.J[r * LDV + j];
+        }
+        S.H[i * LDV + j] = h;
+      }
+      SYNC();
+      chol_factor(S.H, nv, lane);
+      const double search = -chol_solve(S.H, nv, lane, grad);
+      if (lane < nv) S.vec2[lane] = search;
+      SYNC();
+      double jv = 0, Mv = 0;
+      if (lane < nefc) for (int k = 0; k < nv; k++) jv += S.J[lane * LDV + k] * S.vec2[k];
+      if (lane < nv) for (int k = 0; k < nv; k++) Mv += S.M[lane * LDV + k] * S.vec2[k];
+      const double qg1 = wave_sum(lane < nv ? search * (Ma - fs) : 0.0);
+      const double qg2 = wave_sum(lane < nv ? 0.5 * search * Mv : 0.0);
+      // exact line search on the convex piecewise-quadratic: safeguarded Newton on its derivative
+      double alpha = 0;
+      {
+        double d1 = wave_sum((lane < nefc && jar < 0) ? D * jar * jv : 0.0) + qg1;
+        double d2 = wave_sum((lane < nefc && jar < 0) ? D * jv * jv : 0.0) + 2 * qg2;
+        if (!(d1 >= 0 || d2 <= 0)) {
+          const double d0 = fabs(d1);
+          double lo = 0, hi = -1;
+          for (int it = 0; it < 40; it++) {
+            double a = alpha - d1 / d2;
+            if (hi >= 0 && (a <= lo || a >= hi)) a = 0.5 * (lo + hi);
+            const double x = jar + a * jv;
+            const bool on = lane < nefc && x < 0;
+            d1 = wave_sum(on ? D * x * jv : 0.0) + 2 * a * qg2 + qg1;
+            d2 = wave_sum(on ? D * jv * jv : 0.0) + 2 * qg2;
+            if (d1 < 0) lo = a; else hi = a;
+            alpha = a;
+            if (fabs(d1) <= 1e-14 * d0) break;
+            if (hi >= 0 && hi - lo <= 4e-16 * hi) break;
+          }
+        }
+      }
+      if (alpha == 0) break;
+      qacc += alpha * search;
+      SYNC();
+    }
+  } else if (lane < NE) {
+    S.efc_force[lane] = 0;
+  }
+  if (lane < nv) { S.qacc[lane] = qacc; S.qfrc_constraint[lane] = fcon; }
+  *warm = qacc;  // mj_fwdConstraint: next warm start
+  SYNC();
+  if (!(flags & 2)) return;
+  // ------------------------------------------------------------ mj_Euler (implicit joint damping) + mj_advance
+  double anew = qacc;
+  const double h = m.timestep;
+  const bool eulerdamp = !(m.disableflags & (1 << 14));
+  if (eulerdamp) {
+    for (int it = lane; it < nv * LDV; it += 64) S.H[it] = S.M[it];
+    SYNC();
+    if (lane < nv) S.H[lane * LDV + lane] += h * m.dof_damping[lane];
+    SYNC();
+    chol_factor(S.H, nv, lane);
+    anew = chol_solve(S.H, nv, lane, fs + fcon);
+  }
+  if (lane < nv) S.qvel[lane] = qv + h * anew;
+  SYNC();
+  if (lane < m.njnt) {
+    const int j = lane, qa = m.jnt_qposadr[j], da = m.jnt_dofadr[j];
+    if (m.jnt_type[j] == JT_FREE) {
+      for (int k = 0; k < 3; k++) S.qpos[qa + k] += h * S.qvel[da + k];
+      double w[3] = {S.qvel[da + 3], S.qvel[da + 4], S.qvel[da + 5]};
+      double ang = h * normalize3(w), qr[4], q[4] = {S.qpos[qa + 3], S.qpos[qa + 4], S.qpos[qa + 5], S.qpos[qa + 6]};
+      axis_angle_quat(qr, w, ang);
+      normalize4(q);
+      mul_quat(q, q, qr);
+      normalize4(q);
+      for (int k = 0; k < 4; k++) S.qpos[qa + 3 + k] = q[k];
+    } else {
+      S.qpos[qa] += h * S.qvel[da];
+    }
+  }
+  SYNC();
+}
+
+// ------------------------------------------------------------------------------------------------ task layer
+__device__ __forceinline__ void sample_ref(const HParams& p, unsigned genv, unsigned stream, unsigned counter, unsigned slot0,
+                                           int mode, double* ref) {
+  if (mode == MODE_STANDING) {
+    for (int k = 0; k < 3; k++) ref[k] = lhw_rng_uniform(p.seed, genv, stream, counter, slot0 + k, -1.0, 1.0);
+  } else if (mode == MODE_INPLACE) {
+    ref[0] = lhw_rng_uniform(p.seed, genv, stream, counter, slot0, -0.5, 0.5); ref[1] = 0; ref[2] = 0;
+  } else {
+    ref[0] = 0; ref[1] = lhw_rng_uniform(p.seed, genv, stream, counter, slot0, 0.0, 0.4); ref[2] = 0;
+  }
+}
+
+// transforms3d quat2euler 'sxyz' roll/pitch (tasks/observations.py:22)
+__device__ __forceinline__ void quat_roll_pitch(const double* q, double* roll, double* pitch) {
+  const double w = q[0], x = q[1], y = q[2], z = q[3];
+  const double Nq = w * w + x * x + y * y + z * z;
+  const double s = Nq > 2.220446049250313e-16 ? 2.0 / Nq : 0.0;
+  const double X = x * s, Y = y * s, Z = z * s;
+  const double wX = w * X, wY = w * Y, wZ = w * Z, xX = x * X, xY = x * Y, xZ = x * Z, yY = y * Y, yZ = y * Z, zZ = z * Z;
+  const double M00 = 1.0 - (yY + zZ), M10 = xY + wZ, M20 = xZ - wY, M21 = yZ + wX, M22 = 1.0 - (xX + yY), M11 = 1.0 - (xX + zZ), M12 = yZ - wX;
+  const double cy = sqrt(M00 * M00 + M10 * M10);
+  if (cy > 4.0 * 2.220446049250313e-16) { *roll = atan2(M21, M22); *pitch = atan2(-M20, cy); }
+  else { *roll = atan2(-M12, M11); *pitch = atan2(-M20, cy); }
+}
+
+__device__ void write_obs(const HModel& m, const HParams& p, Lds& S, int lane, int phase, int mode, const double* mode_ref,
+                          float* o) {
+  // get_obs (base_humanoid_env.py:177-197): fresh root quaternion / angular velocity, stale motor pos/vel
+  if (lane == 0) {
+    double r, pt;
+    quat_roll_pitch(&S.qpos[3], &r, &pt);
+    o[0] = (float)r; o[1] = (float)pt;
+    o[2] = (float)S.qvel[3]; o[3] = (float)S.qvel[4]; o[4] = (float)S.qvel[5];
+    const double ang = 2 * 3.141592653589793 * (double)phase / (double)p.period;
+    o[29] = (float)sin(ang); o[30] = (float)cos(ang);
+    o[31] = mode == MODE_FORWARD ? 1.f : 0.f; o[32] = mode == MODE_INPLACE ? 1.f : 0.f; o[33] = mode == MODE_STANDING ? 1.f : 0.f;
+    o[34] = (float)mode_ref[0]; o[35] = (float)mode_ref[1]; o[36] = (float)mode_ref[2];
+  }
+  if (lane < 12) { o[5 + lane] = (float)S.sq[lane]; o[17 + lane] = (float)S.sv[lane]; }
+}
+
+// mj_objectVelocity(mjOBJ_XBODY): linear velocity of the body-frame origin, world orientation
+__device__ __forceinline__ void body_linvel(const Lds& S, int b, double* lin) {
+  const double* cv = &S.cvel[6 * b];
+  double dif[3] = {S.xpos[3 * b] - S.com[0], S.xpos[3 * b + 1] - S.com[1], S.xpos[3 * b + 2] - S.com[2]}, t[3];
+  cross3(t, dif, cv);
+  lin[0] = cv[3] - t[0]; lin[1] = cv[4] - t[1]; lin[2] = cv[5] - t[2];
+}
+
+template <int MODE>  // 0 step, 1 reset(mask), 2 set_state, 3 get_state
+__global__ void __launch_bounds__(64) humanoid_kernel(HModel m, HParams p, HState st, const float* __restrict__ act,
+                                                      float* __restrict__ obs, float* __restrict__ term_obs,
+                                                      float* __restrict__ rew, unsigned char* __restrict__ done_out,
+                                                      float* __restrict__ rew_terms, const unsigned char* __restrict__ mask,
+                                                      double* __restrict__ xq, double* __restrict__ xv) {
+  __shared__ Lds S;
+  const int env = blockIdx.x, lane = threadIdx.x;
+  if (MODE == 1 && mask && !mask[env]) return;
+  double* rec = st.rec + (size_t)env * REC_D;
+  int* irec = st.irec + (size_t)env * REC_I;
+  const unsigned genv = p.env_id_base + env;
+  if (MODE == 3) {
+    if (lane < m.nq) xq[(size_t)env * m.nq + lane] = rec[R_QPOS + lane];
+    if (lane < m.nv) xv[(size_t)env * m.nv + lane] = rec[R_QVEL + lane];
+    return;
+  }
+  // ---- load the persistent record (lane-strided)
+  double warm = 0, prevpred = 0, prevact = 0, prevtq = 0;
+  if (lane < m.nq) S.qpos[lane] = rec[R_QPOS + lane];
+  if (lane < m.nv) { S.qvel[lane] = rec[R_QVEL + lane]; warm = rec[R_WARM + lane]; }
+  if (lane < m.nu) {
+    S.sq[lane] = rec[R_SQ + lane]; S.sv[lane] = rec[R_SV + lane]; S.frc[lane] = rec[R_FRC + lane];
+    prevpred = rec[R_PREVPRED + lane]; prevact = rec[R_PREVACT + lane]; prevtq = rec[R_PREVTQ + lane];
+    S.ctrl[lane] = 0;
+  }
+  double mode_ref[3] = {rec[R_MODEREF], rec[R_MODEREF + 1], rec[R_MODEREF + 2]};
+  double ep_ret = rec[R_EPRET];
+  int phase = irec[RI_PHASE], mode = irec[RI_MODE], traj_len = irec[RI_TRAJ], started = irec[RI_STARTED];
+  unsigned step_count = (unsigned)irec[RI_STEPCNT], reset_count = (unsigned)irec[RI_RESETCNT];
+  SYNC();
+
+  bool do_reset = MODE == 1;
+  if (MODE == 2) {
+    if (lane < m.nq) S.qpos[lane] = xq[(size_t)env * m.nq + lane];
+    if (lane < m.nv) S.qvel[lane] = xv[(size_t)env * m.nv + lane];
+    SYNC();
+    substep(m, S, lane, 0, &warm);  // set_state: mj_forward with actuation disabled
+  }
+  if (MODE == 0) {
+    // ---- BaseHumanoidEnv.step: smoothing, offsets (base_humanoid_env.py:209-215); RobotBase.step (robot_base.py:64-98)
+    double target = 0, a_raw = 0;
+    if (lane < m.nu) {
+      a_raw = (double)act[(size_t)env * m.nu + lane];
+      target = p.action_smoothing * a_raw + (1 - p.action_smoothing) * prevpred + p.action_offset[lane];
+      if (!started) { prevact = target; prevtq = S.frc[lane] * m.actuator_gear[lane]; }
+    }
+    for (int k = 0; k < p.frame_skip; k++) {
+      if (lane < m.nu) {
+        // step_pd on the transmission fields of the previous forward pass (note S); ctrl = tau / gear
+        const double tau = p.kp[lane] * (target - S.sq[lane]) + p.kd[lane] * (0.0 - S.sv[lane]);
+        S.ctrl[lane] = tau / m.actuator_gear[lane];
+      }
+      SYNC();
+      substep(m, S, lane, 3, &warm);
+    }
+    // ---- WalkingTask.step (walking_task.py:149-170)
+    phase += 1;
+    if (phase >= p.period) phase = 0;
+    {
+      const bool dbl = p.clock_lut[0 * p.period + phase] == 1.0 && p.clock_lut[2 * p.period + phase] == 1.0;
+      if (lhw_rng_randint(p.seed, genv, LHW_STREAM_STEP, step_count, 0, 100) == 0 && dbl) {
+        if (mode == MODE_INPLACE) mode = MODE_STANDING;
+        else if (mode == MODE_STANDING) mode = MODE_INPLACE;
+        sample_ref(p, genv, LHW_STREAM_STEP, step_count, 1, mode, mode_ref);
+      }
+      if (lhw_rng_randint(p.seed, genv, LHW_STREAM_STEP, step_count, 4, 200) == 0 && mode != MODE_STANDING) {
+        if (mode == MODE_FORWARD) mode = MODE_INPLACE;
+        else if (mode == MODE_INPLACE) mode = MODE_FORWARD;
+        sample_ref(p, genv, LHW_STREAM_STEP, step_count, 5, mode, mode_ref);
+      }
+      step_count++;
+    }
+    // ---- calc_reward (walking_task.py:85-147) on the fields of the last forward pass
+    // per-contact quantities: lane = contact
+    double grf_r = 0, grf_l = 0, cz = 1e300;
+    int selfcol = 0, anyfoot = 0;
+    if (lane < S.ncon) {
+      const int c = lane, b1 = m.geom_bodyid[S.con_g1[c]], b2 = m.geom_bodyid[S.con_g2[c]];
+      const bool floor1 = m.body_rootid[b1] != p.root_body;
+      double fn = 0;
+      const int r0 = S.con_row[c];
+      if (r0 >= 0) {
+        if (S.con_dim[c] == 3) {
+          const double f0 = S.efc_force[r0], f1 = S.efc_force[r0 + 1], f2 = S.efc_force[r0 + 2], f3 = S.efc_force[r0 + 3], mu = S.con_mu[c];
+          const double n = f0 + f1 + f2 + f3, t1 = mu * (f0 - f1), t2 = mu * (f2 - f3);
+          fn = sqrt(n * n + t1 * t1 + t2 * t2);
+        } else fn = fabs(S.efc_force[r0]);
+      }
+      if (floor1 && b2 == p.rfoot_body) { grf_r = fn; cz = S.con_pos[3 * c + 2]; anyfoot = 1; }
+      if (floor1 && b2 == p.lfoot_body) { grf_l = fn; cz = S.con_pos[3 * c + 2]; anyfoot = 1; }
+      selfcol = (m.body_rootid[b1] == p.root_body && m.body_rootid[b2] == p.root_body) ? 1 : 0;
+    }
+    grf_r = wave_sum(grf_r); grf_l = wave_sum(grf_l); cz = wave_min(cz);
+    const bool has_foot = __any(anyfoot);
+    const bool self_collision = __any(selfcol);
+    if (!has_foot) cz = 0;
+    // joint-space sums: lane = actuator / dof
+    double s_posture = 0, s_tq = 0, s_act = 0, s_rootacc = 0, cur_tq = 0;
+    if (lane < m.nu) {
+      cur_tq = S.frc[lane] * m.actuator_gear[lane];
+      const double dq = p.neutral_pose[lane] - S.sq[lane];
+      s_posture = dq * dq;
+      s_tq = fabs(prevtq - cur_tq);
+      s_act = fabs(prevact - target);
+    }
+    if (lane >= 3 && lane < 6) s_rootacc = fabs(S.qvel[lane]);
+    if (lane < 3) s_rootacc = fabs(S.qacc[lane]);
+    s_posture = wave_sum(s_posture); s_tq = wave_sum(s_tq); s_act = wave_sum(s_act); s_rootacc = wave_sum(s_rootacc);
+    double r_sum = 0, terms[10];
+    {
+      double lv[3], rv[3], rl[3], vloc[3];
+      body_linvel(S, p.lfoot_body, lv); body_linvel(S, p.rfoot_body, rv); body_linvel(S, p.root_body, rl);
+      matT_vec(vloc, &S.xmat[9 * p.root_body], rl);
+      double rf = p.clock_lut[0 * p.period + phase], rvc = p.clock_lut[1 * p.period + phase];
+      double lf = p.clock_lut[2 * p.period + phase], lvc = p.clock_lut[3 * p.period + phase];
+      if (mode == MODE_STANDING) { rf = 1; lf = 1; rvc = -1; lvc = -1; }
+      double yaw_ref = mode_ref[0], vx = mode_ref[1], vy = mode_ref[2];
+      if (mode == MODE_STANDING) { yaw_ref = 0; vx = 0; vy = 0; }
+      else if (mode == MODE_INPLACE) { vx = 0; vy = 0; }
+      else yaw_ref = 0;
+      const double gs = sqrt(vx * vx + vy * vy);
+      const double PI4 = 3.141592653589793 / 4;
+      const double maxf = m.totalmass * 9.8 * 0.5;
+      const double nl = fmin(grf_l, maxf) / maxf * 2 - 1, nr = fmin(grf_r, maxf) / maxf * 2 - 1;
+      terms[0] = 0.225 * ((tan(PI4 * lf * nl) + tan(PI4 * rf * nr)) / 2);
+      const double nlv = fmin(sqrt(dot3(lv, lv)), 0.2) / 0.2 * 2 - 1, nrv = fmin(sqrt(dot3(rv, rv)), 0.2) / 0.2 * 2 - 1;
+      terms[1] = 0.225 * ((tan(PI4 * lvc * nlv) + tan(PI4 * rvc * nrv)) / 2);
+      terms[2] = 0.050 * exp(-0.25 * s_rootacc);
+      double herr = fabs(S.xpos[3 * p.root_body + 2] - cz - p.goal_height);
+      if (herr < 0.01 + 0.05 * gs) herr = 0;
+      terms[3] = 0.050 * exp(-40 * herr * herr);
+      const double ex = vloc[0] - vx, ey = vloc[1] - vy, en = sqrt(ex * ex + ey * ey);
+      terms[4] = 0.150 * exp(-10 * (en * en));
+      const double ye = fabs(S.qvel[5] - yaw_ref);
+      terms[5] = 0.150 * exp(-10 * (ye * ye * ye));
+      const double hx = S.xpos[3 * p.head_body] - S.xpos[3 * p.root_body], hy = S.xpos[3 * p.head_body + 1] - S.xpos[3 * p.root_body + 1];
+      terms[6] = 0.050 * exp(-10 * sqrt(hx * hx + hy * hy));
+      terms[7] = 0.050 * exp(-sqrt(s_posture));
+      terms[8] = 0.025 * exp(-0.25 * (s_tq / (double)m.nu));
+      terms[9] = 0.025 * exp(-5 * s_act / (double)m.nu);
+      for (int k = 0; k < 10; k++) r_sum += terms[k];  // python sum() over the dict, left to right
+    }
+    const double z = S.qpos[2];
+    const bool terminated = z < 0.6 || z > 1.4 || self_collision;  // walking_task.py:184-192
+    prevact = target;
+    prevtq = cur_tq;
+    prevpred = a_raw;
+    started = 1;
+    traj_len += 1;
+    ep_ret += r_sum;
+    const bool truncated = p.max_traj_len > 0 && traj_len >= p.max_traj_len;
+    write_obs(m, p, S, lane, phase, mode, mode_ref, obs + (size_t)env * 37);
+    if (term_obs) write_obs(m, p, S, lane, phase, mode, mode_ref, term_obs + (size_t)env * 37);
+    if (lane == 0) {
+      rew[env] = (float)r_sum;
+      done_out[env] = (terminated ? 1 : 0) | (truncated ? 2 : 0);
+      if (S.overflow) atomicAdd(&st.ep_stats[3], 1.0);
+      if (rew_terms) for (int k = 0; k < 10; k++) rew_terms[(size_t)env * 10 + k] = (float)terms[k];
+    }
+    if (p.max_traj_len > 0 && (terminated || truncated)) {
+      if (lane == 0) { atomicAdd(&st.ep_stats[0], ep_ret); atomicAdd(&st.ep_stats[1], (double)traj_len); atomicAdd(&st.ep_stats[2], 1.0); }
+      do_reset = true;
+    }
+  }
+  if (do_reset) {
+    // ---- MujocoEnv.reset + BaseHumanoidEnv.reset_model (mujoco_env.py:113-127, base_humanoid_env.py:247-276)
+    SYNC();
+    if (lane < m.nq) S.qpos[lane] = p.nominal_qpos[lane];
+    if (lane < m.nv) S.qvel[lane] = 0;
+    if (lane < m.nu) S.ctrl[lane] = 0;
+    warm = 0;
+    SYNC();
+    substep(m, S, lane, 0, &warm);                           // set_state: forward, actuation disabled
+    for (int k = 0; k < 3; k++) substep(m, S, lane, 3, &warm);  // three settle steps, ctrl = 0
+    // WalkingTask.reset (walking_task.py:194-205): slot 0 mode, 1..3 mode_ref, 4 phase
+    const double u = lhw_rng_u01(p.seed, genv, LHW_STREAM_RESET, reset_count, 0);
+    mode = u < 0.6 ? MODE_STANDING : (u < 0.8 ? MODE_INPLACE : MODE_FORWARD);
+    sample_ref(p, genv, LHW_STREAM_RESET, reset_count, 1, mode, mode_ref);
+    phase = lhw_rng_randint(p.seed, genv, LHW_STREAM_RESET, reset_count, 4, p.period);
+    reset_count++;
+    traj_len = 0;
+    ep_ret = 0;
+    prevpred = 0;
+    if (obs) write_obs(m, p, S, lane, phase, mode, mode_ref, obs + (size_t)env * 37);
+  }
+  // ---- store the record
+  SYNC();
+  if (lane < m.nq) rec[R_QPOS + lane] = S.qpos[lane];
+  if (lane < m.nv) { rec[R_QVEL + lane] = S.qvel[lane]; rec[R_WARM + lane] = warm; }
+  if (lane < m.nu) {
+    rec[R_SQ + lane] = S.sq[lane]; rec[R_SV + lane] = S.sv[lane]; rec[R_FRC + lane] = S.frc[lane];
+    rec[R_PREVPRED + lane] = prevpred; rec[R_PREVACT + lane] = prevact; rec[R_PREVTQ + lane] = prevtq;
+  }
+  if (lane == 0) {
+    rec[R_MODEREF] = mode_ref[0]; rec[R_MODEREF + 1] = mode_ref[1]; rec[R_MODEREF + 2] = mode_ref[2];
+    rec[R_EPRET] = ep_ret;
+    irec[RI_PHASE] = phase; irec[RI_MODE] = mode; irec[RI_TRAJ] = traj_len; irec[RI_STARTED] = started;
+    irec[RI_STEPCNT] = (int)step_count; irec[RI_RESETCNT] = (int)reset_count;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+template <typename T>
+static const T* to_dev(HumanoidEnv* h, const T* src, size_t n) {
+  void* d = nullptr;
+  if (hipMalloc(&d, std::max<size_t>(1, n) * sizeof(T)) != hipSuccess) return nullptr;
+  if (n && hipMemcpy(d, src, n * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+  h->dev_allocs.push_back(d);
+  return (const T*)d;
+}
+
+int humanoid_create(HumanoidEnv** out, const std::vector<int32_t>& mi, const std::vector<double>& md, const LhwEnvConfig* cfg,
+                    int* obs_dim, int* act_dim, int* n_terms) {
+  auto IF = [&](int f) { return mi.data() + mi[LHW_IH_COUNT + f]; };
+  auto DF = [&](int f) { return md.data() + mi[LHW_IH_COUNT + LHW_IF_COUNT + f]; };
+  const int nq = mi[LHW_IH_NQ], nv = mi[LHW_IH_NV], nu = mi[LHW_IH_NU], nb = mi[LHW_IH_NBODY], nj = mi[LHW_IH_NJNT],
+            ng = mi[LHW_IH_NGEOM], np = mi[LHW_IH_NPAIR];
+  if (nq > NQ || nv > NV || nu > NU || nb > NB || nj > NJ || ng > NG || np > NP || nb > 64 || np > 64)
+    return lhw_fail(LHW_ERR_MODEL, "model exceeds compiled limits (nq %d/%d nv %d/%d nu %d/%d nbody %d/%d njnt %d/%d ngeom %d/%d npair %d/%d)",
+                    nq, NQ, nv, NV, nu, NU, nb, NB, nj, NJ, ng, NG, np, NP);
+  if (cfg->task != LHW_TASK_JVRC_WALK) return lhw_fail(LHW_ERR_ARG, "humanoid stepper: unknown task");
+  if (nu != 12 || nq != 19 || nv != 18) return lhw_fail(LHW_ERR_UNSUPPORTED, "jvrc_walk needs a free root + 12 actuated leg hinges");
+  if (!cfg->kp || !cfg->kd || !cfg->action_offset || !cfg->clock_lut || cfg->period <= 0 || cfg->n_task_iparams < LHW_TI_COUNT ||
+      cfg->n_task_params < LHW_TP_COUNT || cfg->frame_skip <= 0)
+    return lhw_fail(LHW_ERR_ARG, "jvrc_walk config incomplete");
+  const int32_t *parent = IF(LHW_IF_BODY_PARENTID), *rootid = IF(LHW_IF_BODY_ROOTID), *jtype = IF(LHW_IF_JNT_TYPE);
+  const int32_t *bdofadr = IF(LHW_IF_BODY_DOFADR), *bdofnum = IF(LHW_IF_BODY_DOFNUM), *dparent = IF(LHW_IF_DOF_PARENTID);
+  const int32_t *djnt = IF(LHW_IF_DOF_JNTID), *jdof = IF(LHW_IF_JNT_DOFADR);
+  for (int d = 0; d < nv; d++)
+    if (DF(LHW_DF_DOF_FRICTIONLOSS)[d] != 0) return lhw_fail(LHW_ERR_UNSUPPORTED, "dof frictionloss rows are not implemented in the HIP stepper yet");
+  for (int b = 1; b < nb; b++) {
+    if (bdofnum[b] > 0 && rootid[b] != 1) return lhw_fail(LHW_ERR_UNSUPPORTED, "exactly one dynamic tree (rooted at body 1) is supported");
+    if (parent[b] >= b) return lhw_fail(LHW_ERR_MODEL, "bodies must be in depth-first order");
+  }
+  for (int j = 0; j < nj; j++)
+    if (jtype[j] != JT_FREE && jtype[j] != JT_SLIDE && jtype[j] != JT_HINGE) return lhw_fail(LHW_ERR_UNSUPPORTED, "joint type %d", jtype[j]);
+  for (int g = 0; g < ng; g++) {
+    int cd = IF(LHW_IF_GEOM_CONDIM)[g];
+    if (cd != 1 && cd != 3) return lhw_fail(LHW_ERR_UNSUPPORTED, "condim %d", cd);
+  }
+  if (mi[LHW_IH_CONE] != 0) return lhw_fail(LHW_ERR_UNSUPPORTED, "only the pyramidal cone is implemented");
+
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return lhw_fail(LHW_ERR_NO_DEVICE, "no HIP device");
+  HumanoidEnv* h = new HumanoidEnv();
+  h->device = cfg->device;
+  HModel& m = h->m;
+  memset(&m, 0, sizeof m);
+  m.nq = nq; m.nv = nv; m.nu = nu; m.nbody = nb; m.njnt = nj; m.ngeom = ng; m.npair = np;
+  m.iterations = mi[LHW_IH_ITERATIONS]; m.disableflags = mi[LHW_IH_DISABLEFLAGS];
+  m.timestep = md[LHW_DH_TIMESTEP]; m.gravity[0] = md[LHW_DH_GRAVITY_X]; m.gravity[1] = md[LHW_DH_GRAVITY_Y]; m.gravity[2] = md[LHW_DH_GRAVITY_Z];
+  m.tolerance = md[LHW_DH_TOLERANCE]; m.meaninertia = md[LHW_DH_MEANINERTIA]; m.totalmass = md[LHW_DH_TOTALMASS];
+  bool ok = true;
+#define DI(field, F, n) ok = ok && (m.field = to_dev<int>(h, IF(F), (size_t)(n))) != nullptr
+#define DD(field, F, n) ok = ok && (m.field = to_dev<double>(h, DF(F), (size_t)(n))) != nullptr
+  DI(body_parentid, LHW_IF_BODY_PARENTID, nb); DI(body_rootid, LHW_IF_BODY_ROOTID, nb); DI(body_jntadr, LHW_IF_BODY_JNTADR, nb);
+  DI(body_jntnum, LHW_IF_BODY_JNTNUM, nb); DI(body_dofadr, LHW_IF_BODY_DOFADR, nb); DI(body_dofnum, LHW_IF_BODY_DOFNUM, nb);
+  DI(body_weldid, LHW_IF_BODY_WELDID, nb);
+  DD(body_pos, LHW_DF_BODY_POS, 3 * nb); DD(body_quat, LHW_DF_BODY_QUAT, 4 * nb); DD(body_ipos, LHW_DF_BODY_IPOS, 3 * nb);
+  DD(body_iquat, LHW_DF_BODY_IQUAT, 4 * nb); DD(body_mass, LHW_DF_BODY_MASS, nb); DD(body_inertia, LHW_DF_BODY_INERTIA, 3 * nb);
+  DD(body_invweight0, LHW_DF_BODY_INVWEIGHT0, 2 * nb);
+  DI(jnt_type, LHW_IF_JNT_TYPE, nj); DI(jnt_bodyid, LHW_IF_JNT_BODYID, nj); DI(jnt_qposadr, LHW_IF_JNT_QPOSADR, nj);
+  DI(jnt_dofadr, LHW_IF_JNT_DOFADR, nj); DI(jnt_limited, LHW_IF_JNT_LIMITED, nj);
+  DD(jnt_pos, LHW_DF_JNT_POS, 3 * nj); DD(jnt_axis, LHW_DF_JNT_AXIS, 3 * nj); DD(jnt_range, LHW_DF_JNT_RANGE, 2 * nj);
+  DD(jnt_solref, LHW_DF_JNT_SOLREF, 2 * nj); DD(jnt_solimp, LHW_DF_JNT_SOLIMP, 5 * nj); DD(jnt_margin, LHW_DF_JNT_MARGIN, nj);
+  DI(dof_bodyid, LHW_IF_DOF_BODYID, nv); DI(dof_jntid, LHW_IF_DOF_JNTID, nv);
+  DD(dof_armature, LHW_DF_DOF_ARMATURE, nv); DD(dof_damping, LHW_DF_DOF_DAMPING, nv); DD(dof_invweight0, LHW_DF_DOF_INVWEIGHT0, nv);
+  DD(qpos0, LHW_DF_QPOS0, nq);
+  DI(geom_type, LHW_IF_GEOM_TYPE, ng); DI(geom_bodyid, LHW_IF_GEOM_BODYID, ng); DI(geom_condim, LHW_IF_GEOM_CONDIM, ng);
+  DI(geom_priority, LHW_IF_GEOM_PRIORITY, ng);
+  DD(geom_pos, LHW_DF_GEOM_POS, 3 * ng); DD(geom_quat, LHW_DF_GEOM_QUAT, 4 * ng); DD(geom_size, LHW_DF_GEOM_SIZE, 3 * ng);
+  DD(geom_friction, LHW_DF_GEOM_FRICTION, 3 * ng); DD(geom_solmix, LHW_DF_GEOM_SOLMIX, ng); DD(geom_solref, LHW_DF_GEOM_SOLREF, 2 * ng);
+  DD(geom_solimp, LHW_DF_GEOM_SOLIMP, 5 * ng); DD(geom_margin, LHW_DF_GEOM_MARGIN, ng); DD(geom_gap, LHW_DF_GEOM_GAP, ng);
+  DI(pair_geom1, LHW_IF_PAIR_GEOM1, np); DI(pair_geom2, LHW_IF_PAIR_GEOM2, np);
+  DI(actuator_trnid, LHW_IF_ACTUATOR_TRNID, nu); DI(actuator_ctrllimited, LHW_IF_ACTUATOR_CTRLLIMITED, nu);
+  DI(actuator_forcelimited, LHW_IF_ACTUATOR_FORCELIMITED, nu);
+  DD(actuator_gear, LHW_DF_ACTUATOR_GEAR, nu); DD(actuator_ctrlrange, LHW_DF_ACTUATOR_CTRLRANGE, 2 * nu);
+  DD(actuator_forcerange, LHW_DF_ACTUATOR_FORCERANGE, 2 * nu);
+#undef DI
+#undef DD
+  // derived tables
+  std::vector<int> level(nb, 0), subend(nb, 0), mpi, mpj, actdof(nu, 0);
+  std::vector<unsigned> bmask(nb, 0), pmask(nv, 0);
+  int nlevel = 1;
+  for (int b = 1; b < nb; b++) { level[b] = level[parent[b]] + 1; nlevel = std::max(nlevel, level[b] + 1); }
+  for (int b = nb - 1; b >= 0; b--) {
+    subend[b] = std::max(subend[b], b + 1);
+    if (b > 0) subend[parent[b]] = std::max(subend[parent[b]], subend[b]);
+  }
+  for (int b = 1; b < nb; b++) {
+    int bb = b;
+    while (bb > 0 && bdofnum[bb] == 0) bb = parent[bb];
+    if (bb > 0) for (int d = bdofadr[bb] + bdofnum[bb] - 1; d >= 0; d = dparent[d]) bmask[b] |= 1u << d;
+  }
+  for (int d = 0; d < nv; d++) {
+    const int j = djnt[d], k = d - jdof[j];
+    if (jtype[j] == JT_FREE) {
+      if (k < 3) pmask[d] = 0xFFFFFFFFu;           // marker: cdof_dot = 0
+      else pmask[d] = 7u << jdof[j];               // translations of the same joint only
+    } else {
+      for (int a = dparent[d]; a >= 0; a = dparent[a]) pmask[d] |= 1u << a;
+    }
+    for (int a = d; a >= 0; a = dparent[a]) { mpi.push_back(d); mpj.push_back(a); }
+  }
+  for (int u = 0; u < nu; u++) actdof[u] = jdof[IF(LHW_IF_ACTUATOR_TRNID)[u]];
+  m.nlevel = nlevel; m.nmpair = (int)mpi.size();
+  ok = ok && (m.body_level = to_dev<int>(h, level.data(), nb)) && (m.body_subend = to_dev<int>(h, subend.data(), nb)) &&
+       (m.mpair_i = to_dev<int>(h, mpi.data(), mpi.size())) && (m.mpair_j = to_dev<int>(h, mpj.data(), mpj.size())) &&
+       (m.act_dof = to_dev<int>(h, actdof.data(), nu)) && (m.body_dofmask = to_dev<unsigned>(h, bmask.data(), nb)) &&
+       (m.dof_prevmask = to_dev<unsigned>(h, pmask.data(), nv));
+  HParams& p = h->p;
+  memset(&p, 0, sizeof p);
+  p.n_envs = cfg->n_envs; p.frame_skip = cfg->frame_skip; p.max_traj_len = cfg->max_traj_len; p.period = cfg->period;
+  p.root_body = cfg->task_iparams[LHW_TI_ROOT_BODY]; p.head_body = cfg->task_iparams[LHW_TI_HEAD_BODY];
+  p.rfoot_body = cfg->task_iparams[LHW_TI_RFOOT_BODY]; p.lfoot_body = cfg->task_iparams[LHW_TI_LFOOT_BODY];
+  if (p.root_body != 1 || p.head_body <= 0 || p.head_body >= nb || p.rfoot_body <= 0 || p.rfoot_body >= nb || p.lfoot_body <= 0 || p.lfoot_body >= nb)
+    ok = false;
+  p.env_id_base = (unsigned)cfg->env_id_base; p.seed = cfg->seed;
+  p.action_smoothing = cfg->action_smoothing; p.goal_height = cfg->task_params[LHW_TP_GOAL_HEIGHT];
+  std::vector<double> nominal(nq), neutral(nu);
+  for (int k = 0; k < nq; k++) nominal[k] = cfg->nominal_qpos ? cfg->nominal_qpos[k] : DF(LHW_DF_QPOS0)[k];
+  for (int u = 0; u < nu; u++) neutral[u] = cfg->action_offset[u];  // task._neutral_pose == half-sitting pose == offsets (jvrc_walk.py:33)
+  ok = ok && (p.kp = to_dev<double>(h, cfg->kp, nu)) && (p.kd = to_dev<double>(h, cfg->kd, nu)) &&
+       (p.nominal_qpos = to_dev<double>(h, nominal.data(), nq)) && (p.action_offset = to_dev<double>(h, cfg->action_offset, nu)) &&
+       (p.clock_lut = to_dev<double>(h, cfg->clock_lut, (size_t)4 * cfg->period)) && (p.neutral_pose = to_dev<double>(h, neutral.data(), nu));
+  const size_t N = cfg->n_envs;
+  void *rec = nullptr, *irec = nullptr, *eps = nullptr;
+  ok = ok && hipMalloc(&rec, sizeof(double) * REC_D * N) == hipSuccess && hipMemset(rec, 0, sizeof(double) * REC_D * N) == hipSuccess &&
+       hipMalloc(&irec, sizeof(int) * REC_I * N) == hipSuccess && hipMemset(irec, 0, sizeof(int) * REC_I * N) == hipSuccess &&
+       hipMalloc(&eps, sizeof(double) * 4) == hipSuccess && hipMemset(eps, 0, sizeof(double) * 4) == hipSuccess;
+  if (rec) h->dev_allocs.push_back(rec);
+  if (irec) h->dev_allocs.push_back(irec);
+  if (eps) h->dev_allocs.push_back(eps);
+  h->st.rec = (double*)rec; h->st.irec = (int*)irec; h->st.ep_stats = (double*)eps;
+  if (!ok) { humanoid_destroy(h); return lhw_fail(LHW_ERR_HIP, "humanoid_create: device allocation failed or bad body ids"); }
+  *obs_dim = 37; *act_dim = 12; *n_terms = 10;
+  *out = h;
+  return LHW_OK;
+}
+
+void humanoid_destroy(HumanoidEnv* h) {
+  if (!h) return;
+  for (void* d : h->dev_allocs) (void)hipFree(d);
+  delete h;
+}
+
+void humanoid_reset(HumanoidEnv* h, const uint8_t* mask, float* obs, hipStream_t s) {
+  hipLaunchKernelGGL((humanoid_kernel<1>), dim3(h->p.n_envs), dim3(64), 0, s, h->m, h->p, h->st, (const float*)nullptr, obs,
+                     (float*)nullptr, (float*)nullptr, (unsigned char*)nullptr, (float*)nullptr, mask, (double*)nullptr, (double*)nullptr);
+}
+void humanoid_step(HumanoidEnv* h, const float* act, float* obs, float* term_obs, float* rew, uint8_t* done, float* rew_terms,
+                   hipStream_t s) {
+  hipLaunchKernelGGL((humanoid_kernel<0>), dim3(h->p.n_envs), dim3(64), 0, s, h->m, h->p, h->st, act, obs, term_obs, rew, done,
+                     rew_terms, (const unsigned char*)nullptr, (double*)nullptr, (double*)nullptr);
+}
+void humanoid_get_state(HumanoidEnv* h, double* qpos, double* qvel, hipStream_t s) {
+  hipLaunchKernelGGL((humanoid_kernel<3>), dim3(h->p.n_envs), dim3(64), 0, s, h->m, h->p, h->st, (const float*)nullptr, (float*)nullptr,
+                     (float*)nullptr, (float*)nullptr, (unsigned char*)nullptr, (float*)nullptr, (const unsigned char*)nullptr, qpos, qvel);
+}
+void humanoid_set_state(HumanoidEnv* h, const double* qpos, const double* qvel, hipStream_t s) {
+  hipLaunchKernelGGL((humanoid_kernel<2>), dim3(h->p.n_envs), dim3(64), 0, s, h->m, h->p, h->st, (const float*)nullptr, (float*)nullptr,
+                     (float*)nullptr, (float*)nullptr, (unsigned char*)nullptr, (float*)nullptr, (const unsigned char*)nullptr,
+                     const_cast<double*>(qpos), const_cast<double*>(qvel));
+}
+double* humanoid_ep_stats(HumanoidEnv* h) { return h->st.ep_stats; }
+void humanoid_set_iteration(HumanoidEnv*, int64_t) {}  // the walking task has no curriculum input (stepping task does)

@@ -1,0 +1,369 @@
+"""PPO learner with on-device rollouts: the host side of the hot path.
+
+Mirrors the reference's learner surface (reference rl/algos/ppo.py:27-641): ``PPO(env_fn, args,
+seed)``, ``sample_parallel_with_workers()``, ``update_actor_critic(...)``, ``train(env_fn, n_itr)``
+with the same stdout lines and checkpoint names -- but the actor-parallel Ray rollout
+(rl/workers/rollout_worker.py) is replaced by one batched environment per GPU, and every
+arithmetic step (policy/critic forward, env step, GAE, losses, backward, clip, Adam) runs in
+liblhw.so.  Only gradients cross GPUs (``torch.distributed`` all-reduce, RCCL over xGMI).
+"""
+from __future__ import annotations
+
+import datetime
+import sys
+import time
+from dataclasses import dataclass
+from pathlib import Path
+
+import numpy as np
+import torch
+
+from .ppo_kernels import PpoKernels, reference_init
+
+
+@dataclass
+class BatchData:
+    """Same fields as the reference's BatchData (rl/storage/rollout_storage.py:6-22); device tensors."""
+    states: torch.Tensor
+    actions: torch.Tensor
+    rewards: torch.Tensor
+    values: torch.Tensor
+    returns: torch.Tensor
+    dones: torch.Tensor
+    traj_idx: torch.Tensor
+    ep_lens: torch.Tensor
+    ep_rewards: torch.Tensor
+
+
+class RunningMeanStd:
+    """Chan parallel mean/variance (reference rl/envs/normalize.py:4-61)."""
+
+    def __init__(self, epsilon=1e-4, shape=()):
+        self.mean = np.zeros(shape, dtype=np.float64)
+        self.var = np.ones(shape, dtype=np.float64)
+        self.count = epsilon
+
+    def update_from_moments(self, batch_mean, batch_var, batch_count):
+        delta = batch_mean - self.mean
+        tot = self.count + batch_count
+        self.mean = self.mean + delta * batch_count / tot
+        M2 = self.var * self.count + batch_var * batch_count + np.square(delta) * self.count * batch_count / tot
+        self.var = M2 / tot
+        self.count = tot
+
+    def update(self, x):
+        x = np.asarray(x)
+        self.update_from_moments(x.mean(axis=0), x.var(axis=0), x.shape[0])
+
+    @property
+    def std(self):
+        return np.sqrt(self.var + 1e-8)
+
+
+def _dist():
+    import torch.distributed as dist
+    return dist if dist.is_available() and dist.is_initialized() else None
+
+
+class Rollout:
+    """Time-major rollout storage + collection loop for one GPU (N envs x T steps per iteration).
+
+    Semantics of RolloutWorker.sample (reference rl/workers/rollout_worker.py:97-199) for every env:
+    exactly T transitions per call, episodes carried over between calls, truncation at max_traj_len,
+    bootstrap (not done) * V(s') at episode ends and V(s_T) where the buffer fills mid-episode.
+    """
+
+    def __init__(self, env, kernels: PpoKernels, T: int, seed: int = 0):
+        self.env, self.k, self.T, self.seed = env, kernels, int(T), int(seed)
+        N, D, A, dev = env.n_envs, env.obs_dim, env.act_dim, env.device
+        self.N = N
+        self.obs = torch.zeros(T + 1, N, D, dtype=torch.float32, device=dev)
+        self.act = torch.zeros(T, N, A, dtype=torch.float32, device=dev)
+        self.mu = torch.zeros(N, A, dtype=torch.float32, device=dev)
+        self.logp = torch.zeros(T, N, dtype=torch.float32, device=dev)
+        self.val = torch.zeros(T, N, dtype=torch.float32, device=dev)
+        self.rew = torch.zeros(T, N, dtype=torch.float32, device=dev)
+        self.done = torch.zeros(T, N, dtype=torch.uint8, device=dev)
+        self.vterm = torch.zeros(T, N, dtype=torch.float32, device=dev)
+        self.vfinal = torch.zeros(N, dtype=torch.float32, device=dev)
+        self.tob = torch.zeros(N, D, dtype=torch.float32, device=dev)
+        self.counter = 0
+        self.started = False
+        self.env_base = getattr(env, "env_id_base", 0)
+
+    def collect(self, deterministic=False):
+        env, k, T = self.env, self.k, self.T
+        if not self.started:
+            self.obs[0].copy_(env.reset())
+            self.started = True
+        else:
+            self.obs[0].copy_(self.obs[T])
+        for t in range(T):
+            k.forward(self.obs[t], seed=self.seed, env_id_base=self.env_base, counter=self.counter,
+                      deterministic=deterministic, mu=self.mu, act=self.act[t], logp=self.logp[t], value=self.val[t])
+            env.step(self.act[t], obs_out=self.obs[t + 1], term_obs_out=self.tob, rew_out=self.rew[t], done_out=self.done[t])
+            k.forward(self.tob, want_actor=False, value=self.vterm[t])
+            self.counter += 1
+        k.forward(self.obs[T], want_actor=False, value=self.vfinal)
+
+
+class PPO:
+    def __init__(self, env_fn, args, seed=None):
+        self.seed = seed
+        self.gamma, self.lam, self.lr, self.eps = args.gamma, args.lam, args.lr, args.eps
+        self.ent_coeff, self.clip = args.entropy_coeff, args.clip
+        self.minibatch_size, self.epochs = args.minibatch_size, args.epochs
+        self.max_traj_len = args.max_traj_len
+        # --num-procs keeps its meaning "number of parallel environments" (per GPU) unless --num-envs is given
+        self.n_proc = int(getattr(args, "num_envs", None) or args.num_procs)
+        self.grad_clip, self.mirror_coeff = args.max_grad_norm, args.mirror_coeff
+        self.eval_freq = args.eval_freq
+        self.recurrent = getattr(args, "recurrent", False)
+        if self.recurrent:
+            raise NotImplementedError("LSTM policies are outside the hot path built so far (SURVEY.md 8f n3)")
+        if getattr(args, "imitate", None):
+            raise NotImplementedError("--imitate is outside the hot path built so far (SURVEY.md 8f n4)")
+        self.batch_size = self.n_proc * self.max_traj_len
+        self.total_steps = 0
+        self.iteration_count = 0
+        self.save_path = Path(args.logdir)
+        self.save_path.mkdir(parents=True, exist_ok=True)
+        self.best_metric = -np.inf
+        d = _dist()
+        self.rank = d.get_rank() if d else 0
+        self.world = d.get_world_size() if d else 1
+        dev_index = getattr(args, "device_index", None)
+        if dev_index is None:
+            dev_index = torch.cuda.current_device() if torch.cuda.is_available() else 0
+        self.device = torch.device("cuda", dev_index)
+
+        spec = env_fn()  # env description object (see envs/*): dims, obs norm, mirror tables, batched factory
+        self.spec = spec
+        obs_dim, act_dim = spec.obs_dim, spec.act_dim
+        mirror = None if getattr(args, "no_mirror", False) else spec.mirror_tables()
+        self.kernels = PpoKernels(
+            obs_dim, act_dim, hidden=256, max_rows=max(self.n_proc, int(self.minibatch_size or self.batch_size)),
+            device=self.device, learn_std=args.learn_std, lr=self.lr, eps=self.eps, clip=self.clip,
+            entropy_coeff=self.ent_coeff, mirror_coeff=self.mirror_coeff, max_grad_norm=self.grad_clip,
+            mirror_obs=mirror[0] if mirror else None, mirror_act=mirror[1] if mirror else None)
+        if getattr(args, "continued", None):
+            raise NotImplementedError("--continued (checkpoint interop) is not built yet (SURVEY.md 8f n1)")
+        # identical initial weights on every rank: the reference's init path under a fixed torch seed
+        gen_seed = seed if seed is not None else 0
+        cpu_state = torch.random.get_rng_state()
+        self.kernels.set_tensors(reference_init(obs_dim, act_dim, 256, args.std_dev, generator_seed=gen_seed))
+        torch.random.set_rng_state(cpu_state)
+        if spec.obs_mean is not None:
+            self.obs_rms = None
+            self.kernels.set_obs_norm(spec.obs_mean, spec.obs_std)
+            print("Using fixed observation normalization from environment.")
+        else:
+            self.obs_rms = RunningMeanStd(shape=(obs_dim,))
+            self.kernels.set_obs_norm(self.obs_rms.mean, self.obs_rms.std)
+            print("Using running observation normalization (will update during training).")
+        env_seed = (seed if seed is not None else int(time.time())) & 0x7FFFFFFF
+        self.env = spec.make_batched(self.n_proc, seed=env_seed, device=self.device, max_traj_len=self.max_traj_len,
+                                     env_id_base=self.rank * self.n_proc)
+        self.env.env_id_base = self.rank * self.n_proc
+        self.rollout = Rollout(self.env, self.kernels, self.max_traj_len, seed=env_seed ^ 0x5DEECE66D)
+        self.policy = self.kernels  # attribute names the reference's tests look for
+        self.critic = self.kernels
+        self.last_losses = {}
+
+    # ------------------------------------------------------------------ sampling
+    def sample_parallel_with_workers(self, deterministic=False) -> BatchData:
+        self.env.set_iteration(self.iteration_count)
+        ro = self.rollout
+        ro.collect(deterministic=deterministic)
+        ret, adv = self.kernels.gae(ro.rew, ro.val, ro.done, ro.vterm, ro.vfinal, self.gamma, self.lam)
+        self._adv, self._ret = adv, ret
+        T, N = ro.T, ro.N
+        rs, ls, cnt = self.env.pop_episode_stats()
+        self._ep_stats = (rs, ls, cnt)
+        return BatchData(states=ro.obs[:T].reshape(T * N, -1), actions=ro.act.reshape(T * N, -1),
+                         rewards=ro.rew.reshape(T * N, 1), values=ro.val.reshape(T * N, 1), returns=ret.reshape(T * N, 1),
+                         dones=ro.done.reshape(T * N, 1), traj_idx=torch.zeros(0),
+                         ep_lens=torch.tensor([ls / cnt] if cnt else []), ep_rewards=torch.tensor([rs / cnt] if cnt else []))
+
+    # ------------------------------------------------------------------ update
+    def _normalize_advantages(self, adv_flat):
+        """(adv - mean) / (unbiased std + eps) over the GLOBAL batch (ppo.py:484-485)."""
+        mom = self.kernels.moments(adv_flat).clone()
+        n = torch.tensor([float(adv_flat.numel())], dtype=torch.float64, device=mom.device)
+        d = _dist()
+        if d and self.world > 1:
+            pack = torch.cat([mom, n])
+            d.all_reduce(pack)
+            mom, n = pack[:2], pack[2:]
+        s, s2, n = float(mom[0]), float(mom[1]), float(n[0])
+        mean = s / n
+        var = max(0.0, (s2 - n * mean * mean) / max(1.0, n - 1.0))
+        self.kernels.scale_shift(adv_flat, mean, 1.0 / (np.sqrt(var) + self.eps))
+
+    def update_actor_critic(self, obs_batch, action_batch, return_batch, advantage_batch, mask=1, mirror_observation=None,
+                            mirror_action=None, old_log_probs=None):
+        """One optimiser step on an explicit minibatch (same 7-tuple as the reference, ppo.py:299-406).
+        ``mask`` must be 1 (FF path).  The mirror functions are configured at construction; the
+        arguments are accepted for signature compatibility."""
+        k = self.kernels
+        obs = obs_batch.to(self.device, torch.float32).contiguous()
+        B = obs.shape[0]
+        act = action_batch.to(self.device, torch.float32).contiguous()
+        if old_log_probs is None:  # the reference recomputes them with old_policy == policy before the first step
+            sd = k.get_tensors()["stds"].to(self.device)
+            mu, _, _, _ = k.forward(obs, deterministic=True, want_value=False)
+            old_log_probs = torch.distributions.Normal(mu, sd).log_prob(act).sum(-1)
+        xn, xm = k.normalize(obs)
+        k.stats.zero_()
+        idx = torch.arange(B, dtype=torch.int32, device=self.device)
+        k.grad_minibatch(xn, xm, act, old_log_probs.reshape(-1).to(self.device, torch.float32).contiguous(),
+                         advantage_batch.reshape(-1).to(self.device, torch.float32).contiguous(),
+                         return_batch.reshape(-1).to(self.device, torch.float32).contiguous(), idx)
+        self._allreduce_and_apply()
+        s = k.stats.cpu().numpy()
+        return (float(s[0]), self._entropy_penalty(), float(s[1]), float(s[3]), float(s[2]), 0.0, float(s[4]))
+
+    def _entropy_penalty(self):
+        sd = self.kernels.get_tensors()["stds"].numpy().astype(np.float64)
+        return float(-np.mean(0.5 + 0.5 * np.log(2 * np.pi) + np.log(sd)))
+
+    def _allreduce_and_apply(self):
+        d = _dist()
+        if d and self.world > 1:
+            d.all_reduce(self.kernels.grad)  # RCCL sum over xGMI: the only data-path collective
+            self.kernels.apply(grad_scale=1.0 / self.world)
+        else:
+            self.kernels.apply()
+
+    def optimize(self, itr: int):
+        """The per-iteration update of PPO.train (ppo.py:484-566): advantage normalisation, then
+        `epochs` passes of shuffled minibatches (drop_last).  Returns dict of mean losses."""
+        k, ro = self.kernels, self.rollout
+        T, N = ro.T, ro.N
+        n_samples = T * N
+        adv = self._adv.reshape(-1)
+        self._normalize_advantages(adv)
+        ret = self._ret.reshape(-1)
+        xn, xm = k.normalize(ro.obs[:T].reshape(n_samples, -1))
+        act = ro.act.reshape(n_samples, -1)
+        logp = ro.logp.reshape(-1)
+        mb = int(self.minibatch_size or n_samples)
+        mb = min(mb, n_samples)
+        k.stats.zero_()
+        n_updates = 0
+        for epoch in range(self.epochs):
+            g = torch.Generator(device=self.device)
+            base = self.seed if self.seed is not None else 0
+            g.manual_seed(base + itr * self.epochs + epoch + 1000003 * self.rank)
+            perm = torch.randperm(n_samples, generator=g, device=self.device, dtype=torch.int64).to(torch.int32)
+            for start in range(0, n_samples - mb + 1, mb):
+                k.grad_minibatch(xn, xm, act, logp, adv, ret, perm[start:start + mb])
+                self._allreduce_and_apply()
+                n_updates += 1
+        s = (k.stats / max(1, n_updates)).cpu().numpy()
+        self.last_losses = dict(actor=float(s[0]), critic=float(s[1]), mirror=float(s[2]), kl=float(s[3]),
+                                clip_fraction=float(s[4]), entropy=self._entropy_penalty(), n_updates=n_updates)
+        return self.last_losses
+
+    def iterate(self, itr: int):
+        """One PPO iteration: rollout + GAE + update.  Returns (n_samples_local, sample_time, optimize_time)."""
+        self.iteration_count = itr
+        t0 = time.time()
+        batch = self.sample_parallel_with_workers()
+        torch.cuda.synchronize(self.device)
+        t1 = time.time()
+        self.optimize(itr)
+        torch.cuda.synchronize(self.device)
+        t2 = time.time()
+        return batch, t1 - t0, t2 - t1
+
+    # ------------------------------------------------------------------ checkpoints / eval
+    def save(self, itr, metric=None):
+        """actor_{itr}.pt / critic_{itr}.pt (+ actor.pt / critic.pt when the metric improves), like
+        ModelCheckpointer.save_if_best (reference rl/utils/checkpointer.py:54-83).  The files hold plain
+        state dicts in torch layouts (pickling the reference's module classes is row n1 of SURVEY.md 8f)."""
+        if self.rank != 0:
+            return
+        t = self.kernels.get_tensors()
+        extra = dict(obs_mean=self.kernels.obs_mean.cpu(), obs_std=self.kernels.obs_std.cpu())
+        actor = {k2: v for k2, v in t.items() if k2.startswith("a_") or k2 == "stds"} | extra
+        critic = {k2: v for k2, v in t.items() if k2.startswith("c_")} | extra
+        torch.save(actor, self.save_path / f"actor_{itr}.pt")
+        torch.save(critic, self.save_path / f"critic_{itr}.pt")
+        if metric is not None and metric > self.best_metric:
+            self.best_metric = metric
+            torch.save(actor, self.save_path / "actor.pt")
+            torch.save(critic, self.save_path / "critic.pt")
+
+    def evaluate(self, itr, num_batches=5):
+        """5 deterministic batches on the same persistent envs (ppo.py:408-426)."""
+        rs = ls = cnt = 0
+        for _ in range(num_batches):
+            self.sample_parallel_with_workers(deterministic=True)
+            r, l, c = self._ep_stats
+            rs, ls, cnt = rs + r, ls + l, cnt + c
+        mean_r = rs / cnt if cnt else 0.0
+        mean_l = ls / cnt if cnt else 0.0
+        self.save(itr, mean_r)
+        return mean_r, mean_l
+
+    # ------------------------------------------------------------------ training loop
+    def train(self, env_fn, n_itr):
+        train_start = time.time()
+        k = self.kernels
+        if self.obs_rms is not None:
+            print("Warming up observation normalization...")
+            for i in range(5):  # ppo.py:442-457
+                batch = self.sample_parallel_with_workers()
+                x = batch.states.double()
+                mean, var, n = x.mean(0), x.var(0, unbiased=False), torch.tensor(float(x.shape[0]), device=x.device)
+                d = _dist()
+                if d and self.world > 1:  # Chan merge across ranks == update on the concatenated batch
+                    pack = torch.cat([mean * n, (var + mean * mean) * n, n.view(1)])
+                    d.all_reduce(pack)
+                    D = x.shape[1]
+                    n = pack[-1]
+                    mean = pack[:D] / n
+                    var = pack[D:2 * D] / n - mean * mean
+                self.obs_rms.update_from_moments(mean.cpu().numpy(), var.cpu().numpy(), float(n))
+                print(f"  Warmup batch {i + 1}: {x.shape[0] * self.world} samples, obs_rms count: {self.obs_rms.count:.0f}")
+            k.set_obs_norm(self.obs_rms.mean, self.obs_rms.std)
+            print(f"Normalization initialized with {self.obs_rms.count:.0f} samples")
+        for itr in range(n_itr):
+            print(f"********** Iteration {itr} ************")
+            batch, sample_time, optimize_time = self.iterate(itr)
+            num_samples = batch.states.shape[0] * self.world
+            print(f"Sampling took {sample_time:.2f}s for {num_samples} steps.")
+            print(f"Optimizer took: {optimize_time:.2f}s")
+            self.total_steps += num_samples
+            L = self.last_losses
+            rs, ls, cnt = self._ep_stats
+            mean_eprew = rs / cnt if cnt else float("nan")
+            mean_eplen = ls / cnt if cnt else float("nan")
+            noise = float(np.mean(k.get_tensors()["stds"].numpy()))
+            if self.rank == 0:
+                w = sys.stdout.write
+                w("-" * 37 + "\n")
+                w(f"| {'Mean Eprew':>15} | {mean_eprew:>15.5g} |\n")
+                w(f"| {'Mean Eplen':>15} | {mean_eplen:>15.5g} |\n")
+                w(f"| {'Actor loss':>15} | {L['actor']:>15.3g} |\n")
+                w(f"| {'Critic loss':>15} | {L['critic']:>15.3g} |\n")
+                w(f"| {'Mirror loss':>15} | {L['mirror']:>15.3g} |\n")
+                w(f"| {'Imitation loss':>15} | {0.0:>15.3g} |\n")
+                w(f"| {'Mean KL Div':>15} | {L['kl']:>15.3g} |\n")
+                w(f"| {'Mean Entropy':>15} | {L['entropy']:>15.3g} |\n")
+                w(f"| {'Clip Fraction':>15} | {L['clip_fraction']:>15.3g} |\n")
+                w(f"| {'Mean noise std':>15} | {noise:>15.3g} |\n")
+                w("-" * 37 + "\n")
+                sys.stdout.flush()
+            total_time = time.time() - train_start
+            fps = self.total_steps / total_time
+            iter_avg = total_time / (itr + 1)
+            eta = round((n_itr - itr) * iter_avg)
+            print(f"Total time elapsed: {total_time:.2f}s. Total steps: {self.total_steps} "
+                  f"(fps={fps:.2f}. iter-avg={iter_avg:.2f}s. ETA={datetime.timedelta(seconds=eta)})")
+            if itr == 0 or (itr + 1) % self.eval_freq == 0:
+                t0 = time.time()
+                mean_r, mean_l = self.evaluate(itr)
+                print("====EVALUATE EPISODE====")
+                print(f"(Episode length:{mean_l:.3f}. Reward:{mean_r:.3f}. Time taken:{time.time() - t0:.2f}s)")

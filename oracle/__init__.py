@@ -2,3 +2,17 @@
 
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this package.
 """
+
+
+def make_oracle_env(name, seed=0, env_id=0, max_traj_len=400):
+    """(env, obs_dim, act_dim) for the CPU baseline / parity harnesses."""
+    if name == "cartpole":
+        from learninghumanoidwalking_amd.envs import CartpoleSpec
+        from .env_cartpole import OracleCartpoleEnv
+        spec = CartpoleSpec()
+        return OracleCartpoleEnv(spec.model(), seed=seed, env_id=env_id, kp=spec.kp, kd=spec.kd, frame_skip=spec.frame_skip,
+                                 max_traj_len=max_traj_len), 5, 1
+    if name == "jvrc_walk":
+        from .env_jvrc_walk import make_oracle_jvrc_walk
+        return make_oracle_jvrc_walk(seed=seed, env_id=env_id, max_traj_len=max_traj_len), 37, 12
+    raise KeyError(name)

@@ -1,0 +1,257 @@
+"""Oracle jvrc_walk env: the reference's Python env/task/reward logic over the C oracle physics.
+TEST INFRASTRUCTURE ONLY.
+
+Follows (file:line in /root/reference): envs/common/base_humanoid_env.py:177-227 (get_obs, step),
+:247-276 (reset_model); robots/robot_base.py:41-98 (PD loop, step); envs/common/robot_interface.py
+:163-185 (actuator reads), :269-325 (foot contacts, GRF), :357-364 (body velocity), :472-484
+(self collisions), :493-533 (step_pd, set_motor_torque); tasks/walking_task.py:85-205;
+tasks/rewards.py:9-194; tasks/observations.py:12-72; envs/jvrc/jvrc_base.py:133-145;
+envs/jvrc/jvrc_walk.py:65-67.  Random draws: oracle/rng.py keyed (seed, env, stream, counter, slot)
+instead of the global np.random stream -- slot assignment documented inline
+and mirrored by the HIP kernel.
+"""
+import numpy as np
+
+from . import rng
+from .physics import OracleSim
+
+STANDING, INPLACE, FORWARD = 0, 1, 2
+ENCODE = {STANDING: [0, 0, 1], INPLACE: [0, 1, 0], FORWARD: [1, 0, 0]}  # walking_task.py:26-32
+
+
+def quat2euler_sxyz(q):
+    """transforms3d.euler.quat2euler(q) default axes 'sxyz' (SURVEY.md Appendix A)."""
+    w, x, y, z = q
+    Nq = w * w + x * x + y * y + z * z
+    s = 2.0 / Nq if Nq > np.finfo(float).eps else 0.0
+    X, Y, Z = x * s, y * s, z * s
+    wX, wY, wZ = w * X, w * Y, w * Z
+    xX, xY, xZ = x * X, x * Y, x * Z
+    yY, yZ, zZ = y * Y, y * Z, z * Z
+    M = np.array([[1.0 - (yY + zZ), xY - wZ, xZ + wY], [xY + wZ, 1.0 - (xX + zZ), yZ - wX], [xZ - wY, yZ + wX, 1.0 - (xX + yY)]])
+    cy = np.sqrt(M[0, 0] ** 2 + M[1, 0] ** 2)
+    if cy > np.finfo(float).eps * 4.0:
+        return np.arctan2(M[2, 1], M[2, 2]), np.arctan2(-M[2, 0], cy), np.arctan2(M[1, 0], M[0, 0])
+    return np.arctan2(-M[1, 2], M[1, 1]), np.arctan2(-M[2, 0], cy), 0.0
+
+
+# ---- tasks/rewards.py:9-194
+def r_fwd_vel(v, goal):
+    return np.exp(-10 * np.linalg.norm(np.atleast_1d(v) - np.atleast_1d(goal)) ** 2)
+
+
+def r_yaw_vel(y, ref):
+    return np.exp(-10 * np.abs(y - ref) ** 3)
+
+
+def r_action(a, pa):
+    return np.exp(-5 * np.sum(np.abs(pa - a)) / len(a))
+
+
+def r_torque(t, pt):
+    return np.exp(-0.25 * (np.sum(np.abs(pt - t)) / len(t)))
+
+
+def r_height(h, goal, goal_speed, cz=0):
+    err = np.abs(h - cz - goal)
+    if err < 0.01 + 0.05 * goal_speed:
+        err = 0
+    return np.exp(-40 * np.square(err))
+
+
+def r_root_accel(qvel, qacc):
+    return np.exp(-0.25 * (np.abs(qvel[3:6]).sum() + np.abs(qacc[0:3]).sum()))
+
+
+def r_clock(l_val, r_val, l_clock, r_clock, max_val):
+    nl = min(l_val, max_val) / max_val * 2 - 1
+    nr = min(r_val, max_val) / max_val * 2 - 1
+    return (np.tan(np.pi / 4 * l_clock * nl) + np.tan(np.pi / 4 * r_clock * nr)) / 2
+
+
+class OracleJvrcWalkEnv:
+    TERMS = ["foot_frc_score", "foot_vel_score", "root_accel", "height_error", "com_vel_error", "yaw_vel_error",
+             "upper_body_reward", "posture_error", "torque_penalty", "action_penalty"]
+
+    def __init__(self, spec, seed=0, env_id=0, max_traj_len=0):
+        self.spec = spec
+        self.m = spec.model()
+        self.sim = OracleSim(self.m)
+        self.seed, self.env_id, self.max_traj_len = seed, env_id, max_traj_len
+        self.gear = self.m.actuator_gear.copy()
+        self.root, self.head, self.rfoot, self.lfoot = spec.body_ids()
+        self.lut = spec.clock_lut()
+        self.period = spec.period
+        self.mass = float(self.m.body_mass.sum())
+        self.offset = spec.action_offset()
+        self.prev_prediction = np.zeros(12)
+        self.prev_action = None
+        self.prev_torque = None
+        self.reset_count = 0
+        self.step_count = 0
+        self.traj_len = 0
+        self.mode, self.mode_ref, self.phase = STANDING, np.zeros(3), 0
+
+    # ---- RobotInterface subset
+    def _act_pos(self):
+        return self.sim.actuator_length / self.gear
+
+    def _act_vel(self):
+        return self.sim.actuator_velocity / self.gear
+
+    def _act_torque(self):
+        return self.sim.actuator_force * self.gear
+
+    def _foot_floor_contacts(self, foot_body):
+        out = []
+        m = self.m
+        for i in range(self.sim.ncon):
+            c = self.sim.contact(i)
+            b1, b2 = m.geom_bodyid[c["geom1"]], m.geom_bodyid[c["geom2"]]
+            if m.body_rootid[b1] != self.root and b2 == foot_body:   # robot_interface.py:278-283 (robot root is body 1)
+                out.append((i, c))
+        return out
+
+    def _grf(self, foot_body):
+        return sum(np.linalg.norm(self.sim.contact_force(i)) for i, _ in self._foot_floor_contacts(foot_body))
+
+    def _self_collision(self):
+        m = self.m
+        for i in range(self.sim.ncon):
+            c = self.sim.contact(i)
+            if m.body_rootid[m.geom_bodyid[c["geom1"]]] == self.root and m.body_rootid[m.geom_bodyid[c["geom2"]]] == self.root:
+                return True
+        return False
+
+    def _sample_ref(self, counter, stream, slot0):
+        s, e = self.seed, self.env_id
+        if self.mode == STANDING:
+            return np.array([rng.uniform(s, e, stream, counter, slot0 + k, -1.0, 1.0) for k in range(3)])
+        if self.mode == INPLACE:
+            return np.array([rng.uniform(s, e, stream, counter, slot0, -0.5, 0.5), 0.0, 0.0])
+        return np.array([0.0, rng.uniform(s, e, stream, counter, slot0, 0.0, 0.4), 0.0])
+
+    # ---- BaseHumanoidEnv
+    def get_obs(self):
+        q, v = self.sim.qpos, self.sim.qvel
+        r, p, _ = quat2euler_sxyz(q[3:7])
+        clock = [np.sin(2 * np.pi * self.phase / self.period), np.cos(2 * np.pi * self.phase / self.period)]
+        return np.concatenate([[r], [p], v[3:6], self._act_pos(), self._act_vel(), clock, ENCODE[self.mode], self.mode_ref])
+
+    def set_state(self, qpos, qvel):
+        self.sim.qpos[:] = qpos
+        self.sim.qvel[:] = qvel
+        self.sim.forward(actuation=False)
+
+    def reset(self):
+        s, e, c = self.seed, self.env_id, self.reset_count
+        self.sim.reset_data()
+        self.set_state(self.spec.nominal_pose, np.zeros(self.m.nv))
+        for _ in range(3):      # base_humanoid_env.py:268-269, ctrl is zero after mj_resetData
+            self.sim.step()
+        # WalkingTask.reset (walking_task.py:194-205): slot 0 mode, 1..3 mode_ref, 4 phase
+        u = rng.u01(s, e, rng.STREAM_RESET, c, 0)
+        self.mode = STANDING if u < 0.6 else (INPLACE if u < 0.8 else FORWARD)
+        self.mode_ref = self._sample_ref(c, rng.STREAM_RESET, 1)
+        self.phase = rng.randint(s, e, rng.STREAM_RESET, c, 4, self.period)
+        self.reset_count += 1
+        self.traj_len = 0
+        self.prev_prediction = np.zeros(12)
+        return self.get_obs()
+
+    def _task_step(self):
+        s, e, c = self.seed, self.env_id, self.step_count
+        self.phase += 1
+        if self.phase >= self.period:
+            self.phase = 0
+        dbl = self.lut[0, self.phase] == 1 and self.lut[2, self.phase] == 1
+        if rng.randint(s, e, rng.STREAM_STEP, c, 0, 100) == 0 and dbl:      # slot 0; mode_ref slots 1..3
+            if self.mode == INPLACE:
+                self.mode = STANDING
+            elif self.mode == STANDING:
+                self.mode = INPLACE
+            self.mode_ref = self._sample_ref(c, rng.STREAM_STEP, 1)
+        if rng.randint(s, e, rng.STREAM_STEP, c, 4, 200) == 0 and self.mode != STANDING:   # slot 4; mode_ref slots 5..7
+            if self.mode == FORWARD:
+                self.mode = INPLACE
+            elif self.mode == INPLACE:
+                self.mode = FORWARD
+            self.mode_ref = self._sample_ref(c, rng.STREAM_STEP, 5)
+        self.step_count += 1
+
+    def _calc_reward(self, prev_torque, prev_action, action):
+        sim = self.sim
+        l_vel = sim.object_velocity(self.lfoot, 1)[3:6]
+        r_vel = sim.object_velocity(self.rfoot, 1)[3:6]
+        l_frc, r_frc = self._grf(self.lfoot), self._grf(self.rfoot)
+        head, rootp = sim.xpos[self.head][0:2], sim.xpos[self.root][0:2]
+        root_h = sim.xpos[self.root][2]
+        root_vel_xy = sim.object_velocity(self.root, 1)[3:5]
+        qvel, qacc = sim.qvel, sim.qacc
+        tq = self._act_torque()
+        pose = self._act_pos()[:12]
+        cons = self._foot_floor_contacts(self.rfoot) + self._foot_floor_contacts(self.lfoot)
+        cz = min(c["pos"][2] for _, c in cons) if cons else 0
+        ph = self.phase
+        rf, rv, lf, lv = self.lut[0, ph], self.lut[1, ph], self.lut[2, ph], self.lut[3, ph]
+        if self.mode == STANDING:
+            rf, lf, rv, lv = 1, 1, -1, -1
+        yaw_ref, vx, vy = self.mode_ref
+        if self.mode == STANDING:
+            yaw_ref, vx, vy = 0.0, 0.0, 0.0
+        elif self.mode == INPLACE:
+            vx, vy = 0.0, 0.0
+        else:
+            yaw_ref = 0.0
+        goal = np.array([vx, vy])
+        gs = float(np.linalg.norm(goal))
+        return dict(
+            foot_frc_score=0.225 * r_clock(l_frc, r_frc, lf, rf, self.mass * 9.8 * 0.5),
+            foot_vel_score=0.225 * r_clock(np.linalg.norm(l_vel), np.linalg.norm(r_vel), lv, rv, 0.2),
+            root_accel=0.050 * r_root_accel(qvel, qacc),
+            height_error=0.050 * r_height(root_h, self.spec.goal_height, gs, cz),
+            com_vel_error=0.150 * r_fwd_vel(root_vel_xy, goal),
+            yaw_vel_error=0.150 * r_yaw_vel(qvel[5], yaw_ref),
+            upper_body_reward=0.050 * np.exp(-10 * np.linalg.norm(head - rootp)),
+            posture_error=0.050 * np.exp(-np.linalg.norm(self.spec.half_sitting_pose - pose)),
+            torque_penalty=0.025 * r_torque(tq, prev_torque),
+            action_penalty=0.025 * r_action(action, prev_action),
+        )
+
+    def step(self, action):
+        sp, sim = self.spec, self.sim
+        action = np.asarray(action, dtype=np.float32).astype(np.float64)   # policy outputs float32
+        targets = sp.action_smoothing * action + (1 - sp.action_smoothing) * self.prev_prediction
+        act = targets + self.offset                                        # robot_base.py:80
+        if self.prev_action is None:
+            self.prev_action = act
+        if self.prev_torque is None:
+            self.prev_torque = np.asarray(self._act_torque()).copy()
+        for _ in range(sp.frame_skip):                                     # robot_base.py:56-62
+            tau = sp.kp * (act - self._act_pos()) + sp.kd * (0.0 - self._act_vel())
+            sim.ctrl[:] = tau / self.gear
+            sim.step()
+        self._task_step()
+        terms = self._calc_reward(self.prev_torque, self.prev_action, act)
+        q = sim.qpos
+        done = bool(q[2] < 0.6 or q[2] > 1.4 or self._self_collision())   # walking_task.py:184-192
+        self.prev_action = act
+        self.prev_torque = np.asarray(self._act_torque()).copy()
+        obs = self.get_obs()
+        self.prev_prediction = action
+        self.traj_len += 1
+        return obs, sum(terms.values()), done, terms
+
+    def step_auto(self, action):
+        obs, r, done, terms = self.step(action)
+        truncated = self.max_traj_len > 0 and self.traj_len >= self.max_traj_len
+        flags = int(done) | (2 if truncated else 0)
+        term_obs = obs
+        if self.max_traj_len > 0 and (done or truncated):
+            obs = self.reset()
+        return obs, r, flags, term_obs, terms
+
+
+def make_oracle_jvrc_walk(seed=0, env_id=0, max_traj_len=0):
+    from learninghumanoidwalking_amd.envs.jvrc_walk import JvrcWalkSpec
+    return OracleJvrcWalkEnv(JvrcWalkSpec(), seed=seed, env_id=env_id, max_traj_len=max_traj_len)
