@@ -138,15 +138,45 @@ struct Lds {
 #define SYNC() __syncthreads()
 
 // ------------------------------------------------------------------------------------------------ small math
+// Wavefront reductions on the DPP path (row_shr 1/2/4/8 inside each 16-lane row, then row_bcast 15/31 across rows:
+// an inclusive scan whose last lane holds the total) instead of ds_bpermute shuffles: ~20 VALU ops and no LDS
+// round trips per reduction.  gfx950 is GFX9-family, so row_bcast is available.
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ int dpp_i(int v, int ident) { return __builtin_amdgcn_update_dpp(ident, v, CTRL, ROWMASK, 0xf, false); }
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ double dpp_d(double v, double ident) {
+  int lo = dpp_i<CTRL, ROWMASK>(__double2loint(v), __double2loint(ident));
+  int hi = dpp_i<CTRL, ROWMASK>(__double2hiint(v), __double2hiint(ident));
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double bcast(double v, int src /* wave-uniform */) {
+  int lo = __builtin_amdgcn_readlane(__double2loint(v), src), hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+  return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ double wave_sum(double v) {
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  return v;
+  v += dpp_d<0x111, 0xf>(v, 0.0); v += dpp_d<0x112, 0xf>(v, 0.0); v += dpp_d<0x114, 0xf>(v, 0.0); v += dpp_d<0x118, 0xf>(v, 0.0);
+  v += dpp_d<0x142, 0xa>(v, 0.0); v += dpp_d<0x143, 0xc>(v, 0.0);
+  return bcast(v, 63);
 }
 __device__ __forceinline__ double wave_min(double v) {
-  for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o));
+  const double inf = __longlong_as_double(0x7ff0000000000000ll);
+  v = fmin(v, dpp_d<0x111, 0xf>(v, inf)); v = fmin(v, dpp_d<0x112, 0xf>(v, inf)); v = fmin(v, dpp_d<0x114, 0xf>(v, inf));
+  v = fmin(v, dpp_d<0x118, 0xf>(v, inf)); v = fmin(v, dpp_d<0x142, 0xa>(v, inf)); v = fmin(v, dpp_d<0x143, 0xc>(v, inf));
+  return bcast(v, 63);
+}
+// inclusive prefix sum across the wave; *total receives the wave total
+__device__ __forceinline__ int wave_scan(int v, int* total) {
+  v += dpp_i<0x111, 0xf>(v, 0); v += dpp_i<0x112, 0xf>(v, 0); v += dpp_i<0x114, 0xf>(v, 0); v += dpp_i<0x118, 0xf>(v, 0);
+  v += dpp_i<0x142, 0xa>(v, 0); v += dpp_i<0x143, 0xc>(v, 0);
+  *total = __builtin_amdgcn_readlane(v, 63);
   return v;
 }
-__device__ __forceinline__ double bcast(double v, int src) { return __shfl(v, src); }
+__device__ __forceinline__ int wave_max_i(int v) {
+  const int lo = -2147483647 - 1;
+  v = max(v, dpp_i<0x111, 0xf>(v, lo)); v = max(v, dpp_i<0x112, 0xf>(v, lo)); v = max(v, dpp_i<0x114, 0xf>(v, lo));
+  v = max(v, dpp_i<0x118, 0xf>(v, lo)); v = max(v, dpp_i<0x142, 0xa>(v, lo)); v = max(v, dpp_i<0x143, 0xc>(v, lo));
+  return __builtin_amdgcn_readlane(v, 63);
+}
 __device__ __forceinline__ double dot3(const double* a, const double* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
 __device__ __forceinline__ void cross3(double* r, const double* a, const double* b) {
   double x = a[1] * b[2] - a[2] * b[1], y = a[2] * b[0] - a[0] * b[2], z = a[0] * b[1] - a[1] * b[0];
@@ -204,35 +234,65 @@ __device__ __forceinline__ void inert_vec(double* r, const double* i, const doub
 }
 
 // ------------------------------------------------------------------------------------------------ dense SPD solve, wave-parallel
-// Left-looking Cholesky on the lower triangle of A (n x n, leading dimension LDV), in place.  Lane i owns row i.
-__device__ void chol_factor(double* A, int n, int lane) {
-  for (int j = 0; j < n; j++) {
-    double s = 0;
-    if (lane >= j && lane < n) {
-      s = A[lane * LDV + j];
-      for (int p = 0; p < j; p++) s -= A[lane * LDV + p] * A[j * LDV + p];
+// x <- A^-1 x for the SPD matrix whose lower triangle is in LDS (n x n, leading dimension LDV); lane i owns row i and
+// element i of x.  Left-looking Cholesky with row i held in lane i's registers: column step j needs row j of L, which is
+// read back from LDS with j independent broadcast loads (one latency exposure per step instead of one per product).
+// The loops are fully unrolled over the compile-time bound NV so the row stays in VGPRs.  A is overwritten by L.
+__device__ double chol_solve_inplace(double* A, int n, int lane, double x) {
+  double r[NV];
+  const int i = lane < n ? lane : 0;
+#pragma unroll
+  for (int p = 0; p < NV; p++) r[p] = (p < n) ? A[i * LDV + p] : 0.0;
+  double invd[NV];
+#pragma unroll
+  for (int j = 0; j < NV; j++) {
+    if (j < n) {
+      double s0 = r[j], s1 = 0.0;
+#pragma unroll
+      for (int p = 0; p + 1 < j; p += 2) {
+        s0 -= r[p] * A[j * LDV + p];
+        s1 -= r[p + 1] * A[j * LDV + p + 1];
+      }
+      if (j & 1) s0 -= r[j - 1] * A[j * LDV + j - 1];
+      const double s = s0 + s1;
+      const double d = sqrt(fmax(bcast(s, j), HMINVAL));
+      const double id = 1.0 / d;
+      invd[j] = id;
+      const double l = (lane == j) ? d : s * id;
+      r[j] = l;
+      if (lane >= j && lane < n) A[lane * LDV + j] = l;
+      SYNC();
+    } else invd[j] = 0.0;
+  }
+  // forward substitution L y = x : column sweep, l_ij from registers
+#pragma unroll
+  for (int j = 0; j < NV; j++)
+    if (j < n) {
+      const double yj = bcast(x, j) * invd[j];
+      x = (lane == j) ? yj : ((lane > j) ? x - r[j] * yj : x);
     }
-    double d = sqrt(fmax(bcast(s, j), HMINVAL));
-    if (lane == j) A[j * LDV + j] = d;
-    else if (lane > j && lane < n) A[lane * LDV + j] = s / d;
-    SYNC();
-  }
-}
-// x (lane i holds element i) <- A^-1 x with A = L L^T
-__device__ double chol_solve(const double* L, int n, int lane, double x) {
-  for (int j = 0; j < n; j++) {
-    double ljj = L[j * LDV + j];
-    double yj = bcast(x, j) / ljj;
-    if (lane == j) x = yj;
-    else if (lane > j && lane < n) x -= L[lane * LDV + j] * yj;
-  }
-  for (int j = n - 1; j >= 0; j--) {
-    double ljj = L[j * LDV + j];
-    double xj = bcast(x, j) / ljj;
-    if (lane == j) x = xj;
-    else if (lane < j) x -= L[j * LDV + lane] * xj;
-  }
+  // backward substitution L^T z = y : row j of L read across lanes
+  double col[NV];
+#pragma unroll
+  for (int j = 0; j < NV; j++) col[j] = (j < n && lane < j) ? A[j * LDV + lane] : 0.0;
+#pragma unroll
+  for (int j = NV - 1; j >= 0; j--)
+    if (j < n) {
+      const double xj = bcast(x, j) * invd[j];
+      x = (lane == j) ? xj : ((lane < j) ? x - col[j] * xj : x);
+    }
   return x;
+}
+
+// y_lane = sum_k row[k] * v[k] with the row in registers and v broadcast from LDS
+__device__ __forceinline__ double row_dot(const double* row, const double* v, int n) {
+  double a0 = 0, a1 = 0;
+#pragma unroll
+  for (int k = 0; k < NV; k += 2) {
+    if (k < n) a0 += row[k] * v[k];
+    if (k + 1 < n) a1 += row[k + 1] * v[k + 1];
+  }
+  return a0 + a1;
 }
 
 // ------------------------------------------------------------------------------------------------ forward dynamics phases
@@ -383,58 +443,92 @@ __device__ void fwd_crb(const HModel& m, Lds& S, int lane) {
   SYNC();
 }
 
-// ---- collision (engine_collision_primitive.c restated); writes contact k of this pair when out != null
-struct RawCon { double dist, pos[3], n[3], t[3]; };
+// ---- collision (engine_collision_primitive.c restated).  Two passes over the same narrow phase: pass 0 counts the
+// contacts of each candidate pair (lane = pair), a wave scan gives every pair its slot range in pair order, pass 1
+// recomputes and writes straight into the LDS contact arrays (no per-lane contact records in scratch).
+struct ConSink {
+  Lds* S;
+  int base, n, write, g1, g2;
+  __device__ __forceinline__ void emit(double dist, const double* pos, const double* nrm, const double* tan) {
+    if (write) {
+      const int c = base + n;
+      if (c < NC) {
+        Lds& L = *S;
+        L.con_dist[c] = dist;
+        double f[9];
+        for (int a = 0; a < 3; a++) { L.con_pos[3 * c + a] = pos[a]; f[a] = nrm[a]; f[3 + a] = tan[a]; }
+        // mju_makeFrame
+        normalize3(f);
+        if (sqrt(dot3(f + 3, f + 3)) < 0.5) {
+          f[3] = f[4] = f[5] = 0;
+          if (f[1] < 0.5 && f[1] > -0.5) f[4] = 1; else f[5] = 1;
+        }
+        const double tt = dot3(f, f + 3);
+        for (int a = 0; a < 3; a++) f[3 + a] -= tt * f[a];
+        normalize3(f + 3);
+        cross3(f + 6, f, f + 3);
+        for (int a = 0; a < 9; a++) L.con_frame[9 * c + a] = f[a];
+        L.con_g1[c] = g1; L.con_g2[c] = g2;
+      }
+    }
+    n++;
+  }
+};
 
-__device__ __forceinline__ int col_plane_sphere(RawCon* c, const double* p1, const double* R1, const double* p2, double r, double margin) {
+__device__ __forceinline__ void col_plane_sphere(ConSink& k, const double* p1, const double* R1, const double* p2, double r,
+                                                 double margin, const double* tan) {
   double n[3] = {R1[2], R1[5], R1[8]}, dif[3] = {p2[0] - p1[0], p2[1] - p1[1], p2[2] - p1[2]};
-  double dist = dot3(dif, n) - r;
-  if (dist > margin) return 0;
-  c->dist = dist;
-  for (int k = 0; k < 3; k++) { c->n[k] = n[k]; c->t[k] = 0; c->pos[k] = p2[k] - n[k] * (r + 0.5 * dist); }
-  return 1;
+  const double dist = dot3(dif, n) - r;
+  if (dist > margin) return;
+  double pos[3];
+  for (int a = 0; a < 3; a++) pos[a] = p2[a] - n[a] * (r + 0.5 * dist);
+  k.emit(dist, pos, n, tan);
 }
-__device__ __forceinline__ int col_sphere_sphere(RawCon* c, const double* p1, double r1, const double* p2, double r2, double margin) {
+__device__ __forceinline__ void col_sphere_sphere(ConSink& k, const double* p1, double r1, const double* p2, double r2, double margin) {
   double dif[3] = {p2[0] - p1[0], p2[1] - p1[1], p2[2] - p1[2]};
-  double cd = sqrt(dot3(dif, dif)), dist = cd - r1 - r2;
-  if (dist > margin) return 0;
-  c->dist = dist;
+  const double cd = sqrt(dot3(dif, dif)), dist = cd - r1 - r2;
+  if (dist > margin) return;
   if (cd < HMINVAL) { dif[0] = 1; dif[1] = dif[2] = 0; } else { dif[0] /= cd; dif[1] /= cd; dif[2] /= cd; }
-  for (int k = 0; k < 3; k++) { c->n[k] = dif[k]; c->t[k] = 0; c->pos[k] = p1[k] + dif[k] * (r1 + 0.5 * dist); }
-  return 1;
+  double pos[3];
+  const double zero[3] = {0, 0, 0};
+  for (int a = 0; a < 3; a++) pos[a] = p1[a] + dif[a] * (r1 + 0.5 * dist);
+  k.emit(dist, pos, dif, zero);
 }
-__device__ int collide_pair(int t1, int t2, const double* p1, const double* R1, const double* s1, const double* p2,
-                            const double* R2, const double* s2, double margin, RawCon* rc) {
-  int n = 0;
-  if (t1 == G_PLANE && t2 == G_SPHERE) n = col_plane_sphere(rc, p1, R1, p2, s2[0], margin);
+__device__ void collide_pair(ConSink& k, const HModel& m, const Lds& S, int g1, int g2, double margin) {
+  const double zero[3] = {0, 0, 0};
+  const int t1 = m.geom_type[g1], t2 = m.geom_type[g2];
+  double p1[3], p2[3], R1[9], R2[9], s1[3], s2[3];
+  for (int a = 0; a < 3; a++) { p1[a] = S.gpos[3 * g1 + a]; p2[a] = S.gpos[3 * g2 + a]; s1[a] = m.geom_size[3 * g1 + a]; s2[a] = m.geom_size[3 * g2 + a]; }
+  for (int a = 0; a < 9; a++) { R1[a] = S.gmat[9 * g1 + a]; R2[a] = S.gmat[9 * g2 + a]; }
+  if (t1 == G_PLANE && t2 == G_SPHERE) col_plane_sphere(k, p1, R1, p2, s2[0], margin, zero);
   else if (t1 == G_PLANE && t2 == G_CAPSULE) {
     double ax[3] = {R2[2], R2[5], R2[8]}, e[3];
     for (int s = 1; s >= -1; s -= 2) {
-      for (int k = 0; k < 3; k++) e[k] = p2[k] + s * ax[k] * s2[1];
-      if (col_plane_sphere(rc + n, p1, R1, e, s2[0], margin)) { for (int k = 0; k < 3; k++) rc[n].t[k] = ax[k]; n++; }
+      for (int a = 0; a < 3; a++) e[a] = p2[a] + s * ax[a] * s2[1];
+      col_plane_sphere(k, p1, R1, e, s2[0], margin, ax);  // tangent aligned with the capsule axis
     }
   } else if (t1 == G_PLANE && t2 == G_BOX) {
     double nn[3] = {R1[2], R1[5], R1[8]}, dif[3] = {p2[0] - p1[0], p2[1] - p1[1], p2[2] - p1[2]};
-    double dist = dot3(dif, nn);
-    for (int i = 0; i < 8 && n < 4; i++) {
-      double v[3] = {(i & 1 ? s2[0] : -s2[0]), (i & 2 ? s2[1] : -s2[1]), (i & 4 ? s2[2] : -s2[2])}, corner[3];
+    const double dist = dot3(dif, nn);
+    const int n0 = k.n;
+    for (int i = 0; i < 8 && k.n - n0 < 4; i++) {
+      double v[3] = {(i & 1 ? s2[0] : -s2[0]), (i & 2 ? s2[1] : -s2[1]), (i & 4 ? s2[2] : -s2[2])}, corner[3], pos[3];
       mat_vec(corner, R2, v);
-      double ld = dot3(nn, corner);
+      const double ld = dot3(nn, corner);
       if (dist + ld > margin || ld > 0) continue;
-      rc[n].dist = dist + ld;
-      for (int k = 0; k < 3; k++) { rc[n].n[k] = nn[k]; rc[n].t[k] = 0; rc[n].pos[k] = corner[k] + p2[k] - nn[k] * rc[n].dist * 0.5; }
-      n++;
+      for (int a = 0; a < 3; a++) pos[a] = corner[a] + p2[a] - nn[a] * (dist + ld) * 0.5;
+      k.emit(dist + ld, pos, nn, zero);
     }
-  } else if (t1 == G_SPHERE && t2 == G_SPHERE) n = col_sphere_sphere(rc, p1, s1[0], p2, s2[0], margin);
+  } else if (t1 == G_SPHERE && t2 == G_SPHERE) col_sphere_sphere(k, p1, s1[0], p2, s2[0], margin);
   else if (t1 == G_SPHERE && t2 == G_CAPSULE) {
     double ax[3] = {R2[2], R2[5], R2[8]}, vec[3] = {p1[0] - p2[0], p1[1] - p2[1], p1[2] - p2[2]};
-    double x = fmin(s2[1], fmax(-s2[1], dot3(ax, vec)));
+    const double x = fmin(s2[1], fmax(-s2[1], dot3(ax, vec)));
     double q[3] = {p2[0] + ax[0] * x, p2[1] + ax[1] * x, p2[2] + ax[2] * x};
-    n = col_sphere_sphere(rc, p1, s1[0], q, s2[0], margin);
+    col_sphere_sphere(k, p1, s1[0], q, s2[0], margin);
   } else if (t1 == G_CAPSULE && t2 == G_CAPSULE) {
     double a1[3] = {R1[2], R1[5], R1[8]}, a2[3] = {R2[2], R2[5], R2[8]}, dif[3] = {p1[0] - p2[0], p1[1] - p2[1], p1[2] - p2[2]};
-    double ma = dot3(a1, a1), mb = -dot3(a1, a2), mc = dot3(a2, a2), u = -dot3(a1, dif), v = dot3(a2, dif);
-    double det = ma * mc - mb * mb;
+    const double ma = dot3(a1, a1), mb = -dot3(a1, a2), mc = dot3(a2, a2), u = -dot3(a1, dif), v = dot3(a2, dif);
+    const double det = ma * mc - mb * mb;
     if (fabs(det) >= HMINVAL) {
       double x1 = (mc * u - mb * v) / det, x2 = (ma * v - mb * u) / det;
       if (x1 > s1[1]) { x1 = s1[1]; x2 = (v - mb * s1[1]) / mc; }
@@ -442,31 +536,31 @@ __device__ int collide_pair(int t1, int t2, const double* p1, const double* R1, 
       if (x2 > s2[1]) { x2 = s2[1]; x1 = fmin(s1[1], fmax(-s1[1], (u - mb * s2[1]) / ma)); }
       else if (x2 < -s2[1]) { x2 = -s2[1]; x1 = fmin(s1[1], fmax(-s1[1], (u + mb * s2[1]) / ma)); }
       double q1[3], q2[3];
-      for (int k = 0; k < 3; k++) { q1[k] = p1[k] + a1[k] * x1; q2[k] = p2[k] + a2[k] * x2; }
-      n = col_sphere_sphere(rc, q1, s1[0], q2, s2[0], margin);
+      for (int a = 0; a < 3; a++) { q1[a] = p1[a] + a1[a] * x1; q2[a] = p2[a] + a2[a] * x2; }
+      col_sphere_sphere(k, q1, s1[0], q2, s2[0], margin);
     } else {
+      const int n0 = k.n;
       double q1[3], q2[3], x;
-      for (int s = -1; s <= 1 && n < 2; s += 2) {
-        for (int k = 0; k < 3; k++) q1[k] = p1[k] + s * a1[k] * s1[1];
+      for (int s = -1; s <= 1 && k.n - n0 < 2; s += 2) {
+        for (int a = 0; a < 3; a++) q1[a] = p1[a] + s * a1[a] * s1[1];
         double vv[3] = {q1[0] - p2[0], q1[1] - p2[1], q1[2] - p2[2]};
         x = dot3(a2, vv);
         if (x >= -s2[1] && x <= s2[1]) {
-          for (int k = 0; k < 3; k++) q2[k] = p2[k] + a2[k] * x;
-          n += col_sphere_sphere(rc + n, q1, s1[0], q2, s2[0], margin);
+          for (int a = 0; a < 3; a++) q2[a] = p2[a] + a2[a] * x;
+          col_sphere_sphere(k, q1, s1[0], q2, s2[0], margin);
         }
       }
-      for (int s = -1; s <= 1 && n < 2; s += 2) {
-        for (int k = 0; k < 3; k++) q2[k] = p2[k] + s * a2[k] * s2[1];
+      for (int s = -1; s <= 1 && k.n - n0 < 2; s += 2) {
+        for (int a = 0; a < 3; a++) q2[a] = p2[a] + s * a2[a] * s2[1];
         double vv[3] = {q2[0] - p1[0], q2[1] - p1[1], q2[2] - p1[2]};
         x = dot3(a1, vv);
         if (x >= -s1[1] && x <= s1[1]) {
-          for (int k = 0; k < 3; k++) q1[k] = p1[k] + a1[k] * x;
-          n += col_sphere_sphere(rc + n, q1, s1[0], q2, s2[0], margin);
+          for (int a = 0; a < 3; a++) q1[a] = p1[a] + a1[a] * x;
+          col_sphere_sphere(k, q1, s1[0], q2, s2[0], margin);
         }
       }
     }
   }
-  return n;
 }
 
 __device__ void fwd_collision(const HModel& m, Lds& S, int lane) {
@@ -483,47 +577,26 @@ __device__ void fwd_collision(const HModel& m, Lds& S, int lane) {
   }
   if (lane == 0) { S.overflow = 0; }
   SYNC();
-  RawCon rc[4];
-  int n = 0, g1 = 0, g2 = 0;
-  double margin = 0, gap = 0;
-  if (lane < m.npair) {
+  int g1 = 0, g2 = 0;
+  double margin = 0;
+  const bool have = lane < m.npair;
+  if (have) {
     g1 = m.pair_geom1[lane]; g2 = m.pair_geom2[lane];
     margin = fmax(m.geom_margin[g1], m.geom_margin[g2]);
-    gap = fmax(m.geom_gap[g1], m.geom_gap[g2]);
-    double p1[3], p2[3], R1[9], R2[9], s1[3], s2[3];
-    for (int k = 0; k < 3; k++) { p1[k] = S.gpos[3 * g1 + k]; p2[k] = S.gpos[3 * g2 + k]; s1[k] = m.geom_size[3 * g1 + k]; s2[k] = m.geom_size[3 * g2 + k]; }
-    for (int k = 0; k < 9; k++) { R1[k] = S.gmat[9 * g1 + k]; R2[k] = S.gmat[9 * g2 + k]; }
-    n = collide_pair(m.geom_type[g1], m.geom_type[g2], p1, R1, s1, p2, R2, s2, margin, rc);
   }
-  // exclusive prefix sum of contact counts across lanes (pair order == contact order)
-  int incl = n;
-  for (int o = 1; o < 64; o <<= 1) {
-    int v = __shfl_up(incl, o);
-    if (lane >= o) incl += v;
-  }
-  const int base = incl - n;
-  const int total = __shfl(incl, 63);
-  for (int k = 0; k < n; k++) {
-    const int c = base + k;
-    if (c >= NC) continue;
-    S.con_dist[c] = rc[k].dist;
-    double f[9];
-    for (int a = 0; a < 3; a++) { S.con_pos[3 * c + a] = rc[k].pos[a]; f[a] = rc[k].n[a]; f[3 + a] = rc[k].t[a]; }
-    // mju_makeFrame
-    normalize3(f);
-    if (sqrt(dot3(f + 3, f + 3)) < 0.5) {
-      f[3] = f[4] = f[5] = 0;
-      if (f[1] < 0.5 && f[1] > -0.5) f[4] = 1; else f[5] = 1;
-    }
-    double tt = dot3(f, f + 3);
-    for (int a = 0; a < 3; a++) f[3 + a] -= tt * f[a];
-    normalize3(f + 3);
-    cross3(f + 6, f, f + 3);
-    for (int a = 0; a < 9; a++) S.con_frame[9 * c + a] = f[a];
-    S.con_g1[c] = g1; S.con_g2[c] = g2;
-    const double incm = margin - gap;
-    S.con_margin[c] = incm;
-    // mj_contactParam: priority, else solmix-weighted mix; friction = max; condim = max
+  ConSink k{&S, 0, 0, 0, g1, g2};
+  if (have) collide_pair(k, m, S, g1, g2, margin);
+  int total;
+  const int base = wave_scan(k.n, &total) - k.n;
+  k.base = base; k.n = 0; k.write = 1;
+  if (have && base < NC) collide_pair(k, m, S, g1, g2, margin);
+  if (lane == 0) { S.ncon = min(total, NC); if (total > NC) S.overflow = 1; }
+  SYNC();
+  // mj_contactParam (lane = contact): priority, else solmix-weighted mix; friction = max; condim = max
+  if (lane < S.ncon) {
+    const int c = lane;
+    g1 = S.con_g1[c]; g2 = S.con_g2[c];
+    const double incm = fmax(m.geom_margin[g1], m.geom_margin[g2]) - fmax(m.geom_gap[g1], m.geom_gap[g2]);
     int dim;
     double mu, sr[2], si[5];
     const int pr1 = m.geom_priority[g1], pr2 = m.geom_priority[g2];
@@ -546,12 +619,12 @@ __device__ void fwd_collision(const HModel& m, Lds& S, int lane) {
       for (int a = 0; a < 5; a++) si[a] = mix * m.geom_solimp[5 * g1 + a] + (1 - mix) * m.geom_solimp[5 * g2 + a];
       mu = fmax(m.geom_friction[3 * g1], m.geom_friction[3 * g2]);
     }
-    S.con_dim[c] = (rc[k].dist >= incm) ? 0 : dim;  // 0: excluded from the constraint set (gap)
+    S.con_margin[c] = incm;
+    S.con_dim[c] = (S.con_dist[c] >= incm) ? 0 : dim;  // 0: excluded from the constraint set (gap)
     S.con_mu[c] = mu;
     S.con_solref[2 * c] = sr[0]; S.con_solref[2 * c + 1] = sr[1];
     for (int a = 0; a < 5; a++) S.con_solimp[5 * c + a] = si[a];
   }
-  if (lane == 0) { S.ncon = min(total, NC); if (total > NC) S.overflow = 1; }
   SYNC();
 }
 
@@ -571,6 +644,7 @@ __device__ __forceinline__ void row_params(const HModel& m, const double* sr_in,
     else {
       double y;
       if (s4 == 1) y = x;
+      else if (s4 == 2) y = (x <= s3) ? x * x / s3 : 1 - (1 - x) * (1 - x) / (1 - s3);  // default solimp power, no pow()
       else if (x <= s3) y = pow(x, s4) / pow(s3, s4 - 1);
       else y = 1 - pow(1 - x, s4) / pow(1 - s3, s4 - 1);
       im = s0 + y * (s1 - s0);
@@ -598,15 +672,13 @@ __device__ void fwd_constraints(const HModel& m, Lds& S, int lane) {
     lo = dlo < mg; hi = dhi < mg;
     nl = lo + hi;
   }
-  int incl = nl;
-  for (int o = 1; o < 64; o <<= 1) { int v = __shfl_up(incl, o); if (lane >= o) incl += v; }
-  const int lbase = incl - nl, nlim = __shfl(incl, 63);
+  int nlim;
+  const int lbase = wave_scan(nl, &nlim) - nl;
   // ---- contacts: lane = contact; rows = 4 (condim 3), 1 (condim 1) or 0 (excluded)
   int nr = 0;
   if (lane < S.ncon) nr = S.con_dim[lane] == 3 ? 4 : (S.con_dim[lane] == 1 ? 1 : 0);
-  int cincl = nr;
-  for (int o = 1; o < 64; o <<= 1) { int v = __shfl_up(cincl, o); if (lane >= o) cincl += v; }
-  const int cbase = nlim + cincl - nr;
+  int crows;
+  const int cbase = nlim + wave_scan(nr, &crows) - nr;
   int rend = nlim;
   if (lane < S.ncon) {
     const bool fits = nr > 0 && cbase + nr <= NE;
@@ -614,8 +686,7 @@ __device__ void fwd_constraints(const HModel& m, Lds& S, int lane) {
     S.con_row[lane] = fits ? cbase : -1;
     if (fits) rend = cbase + nr;
   }
-  for (int o = 32; o > 0; o >>= 1) rend = max(rend, __shfl_xor(rend, o));
-  const int nefc = rend;
+  const int nefc = wave_max_i(rend);
   for (int it = lane; it < nefc * LDV; it += 64) S.J[it] = 0;
   SYNC();
   if (nl > 0) {
@@ -777,20 +848,30 @@ __device__ __noinline__ void substep(const HModel& m, Lds& S, int lane, int flag
     S.qfrc_smooth[lane] = fs;
     S.vec[lane] = qv;
   }
-  // factor M in H, qacc_smooth
+  // factor M (copy in H), qacc_smooth
   for (int it = lane; it < nv * LDV; it += 64) S.H[it] = S.M[it];
   SYNC();
-  chol_factor(S.H, nv, lane);
-  const double as = chol_solve(S.H, nv, lane, fs);
+  const double as = chol_solve_inplace(S.H, nv, lane, fs);
   if (lane < nv) S.qacc_smooth[lane] = as;
+  // rows of M (lane = dof) and J (lane = row) stay in registers for every product of the solve
+  double Mrow[NV], Jrow[NV];
+  {
+    const int im = lane < nv ? lane : 0, ij = lane < nefc ? lane : 0;
+#pragma unroll
+    for (int k = 0; k < NV; k++) {
+      Mrow[k] = (k < nv && lane < nv) ? S.M[im * LDV + k] : 0.0;
+      Jrow[k] = (k < nv && lane < nefc) ? S.J[ij * LDV + k] : 0.0;
+    }
+  }
   // constraint reference: aref = -B (J qvel) - K imp (pos - margin)   (lane = row)
   double aref = 0, D = 0;
-  if (lane < nefc) {
-    double jv = 0;
-    for (int k = 0; k < nv; k++) jv += S.J[lane * LDV + k] * S.vec[k];
-    aref = -S.efc_B[lane] * jv - S.efc_K[lane] * S.efc_imp[lane] * (S.efc_pos[lane] - S.efc_margin[lane]);
-    S.efc_aref[lane] = aref;
-    D = S.efc_D[lane];
+  {
+    const double jv0 = row_dot(Jrow, S.vec, nv);
+    if (lane < nefc) {
+      aref = -S.efc_B[lane] * jv0 - S.efc_K[lane] * S.efc_imp[lane] * (S.efc_pos[lane] - S.efc_margin[lane]);
+      S.efc_aref[lane] = aref;
+      D = S.efc_D[lane];
+    }
   }
   SYNC();
 
@@ -800,21 +881,15 @@ __device__ __noinline__ void substep(const HModel& m, Lds& S, int lane, int flag
     const double scale = 1.0 / (m.meaninertia * (nv > 1 ? nv : 1));
     // warm start: cheaper of qacc_warmstart and qacc_smooth
     if (!(m.disableflags & (1 << 7))) {
-      double w = *warm;
-      if (lane < nv) S.vec[lane] = w;
+      const double w = *warm;
+      if (lane < nv) { S.vec[lane] = w; S.vec2[lane] = as; }
       SYNC();
-      double jar = 0, Ma = 0;
-      if (lane < nefc) { for (int k = 0; k < nv; k++) jar += S.J[lane * LDV + k] * S.vec[k]; jar -= aref; }
-      if (lane < nv) for (int k = 0; k < nv; k++) Ma += S.M[lane * LDV + k] * S.vec[k];
+      const double jar = row_dot(Jrow, S.vec, nv) - aref, Ma = row_dot(Mrow, S.vec, nv);
+      const double jas = row_dot(Jrow, S.vec2, nv) - aref;
       double cw = (lane < nefc && jar < 0) ? 0.5 * D * jar * jar : 0.0;
       if (lane < nv) cw += 0.5 * (Ma - fs) * (w - as);
       cw = wave_sum(cw);
-      SYNC();
-      if (lane < nv) S.vec[lane] = as;
-      SYNC();
-      double jas = 0;
-      if (lane < nefc) { for (int k = 0; k < nv; k++) jas += S.J[lane * LDV + k] * S.vec[k]; jas -= aref; }
-      double cs = wave_sum((lane < nefc && jas < 0) ? 0.5 * D * jas * jas : 0.0);
+      const double cs = wave_sum((lane < nefc && jas < 0) ? 0.5 * D * jas * jas : 0.0);
       qacc = (cw > cs) ? as : w;
       SYNC();
     }
@@ -822,21 +897,28 @@ __device__ __noinline__ void substep(const HModel& m, Lds& S, int lane, int flag
     for (int iter = 0; iter <= m.iterations; iter++) {
       if (lane < nv) S.vec[lane] = qacc;
       SYNC();
-      double jar = 0, Ma = 0;
-      if (lane < nefc) { for (int k = 0; k < nv; k++) jar += S.J[lane * LDV + k] * S.vec[k]; jar -= aref; }
-      if (lane < nv) for (int k = 0; k < nv; k++) Ma += S.M[lane * LDV + k] * S.vec[k];
+      const double jar = row_dot(Jrow, S.vec, nv) - aref, Ma = row_dot(Mrow, S.vec, nv);
       const bool active = lane < nefc && jar < 0;
       const double force = active ? -D * jar : 0.0;
       double c = active ? 0.5 * D * jar * jar : 0.0;
       if (lane < nv) c += 0.5 * (Ma - fs) * (qacc - as);
       oldcost = cost;
       cost = wave_sum(c);
-      if (lane < nefc) { S.evec[lane] = force; S.efc_force[lane] = force; }
+      if (lane < NE) { S.evec[lane] = force; S.efc_force[lane] = force; S.efc_aref[lane] = active ? D : 0.0; }  // efc_aref reused: D_active
       SYNC();
       double grad = 0;
       fcon = 0;
       if (lane < nv) {
-        for (int r = 0; r < nefc; r++) fcon += S.J[r * LDV + lane] * S.evec[r];
+        double f0 = 0, f1 = 0, f2 = 0, f3 = 0;
+        int r = 0;
+        for (; r + 3 < nefc; r += 4) {
+          f0 += S.J[r * LDV + lane] * S.evec[r];
+          f1 += S.J[(r + 1) * LDV + lane] * S.evec[r + 1];
+          f2 += S.J[(r + 2) * LDV + lane] * S.evec[r + 2];
+          f3 += S.J[(r + 3) * LDV + lane] * S.evec[r + 3];
+        }
+        for (; r < nefc; r++) f0 += S.J[r * LDV + lane] * S.evec[r];
+        fcon = (f0 + f1) + (f2 + f3);
         grad = Ma - fs - fcon;
       }
       const double gn = sqrt(wave_sum(grad * grad));
@@ -844,29 +926,25 @@ __device__ __noinline__ void substep(const HModel& m, Lds& S, int lane, int flag
       else if (scale * gn < m.tolerance) break;
       if (iter == m.iterations) break;
       // H = M + J^T D_active J  (lower triangle; lanes sweep the packed triangle)
-      SYNC();
-      if (lane < nefc) S.evec[lane] = active ? D : 0.0;
-      SYNC();
       for (int e = lane; e < nv * (nv + 1) / 2; e += 64) {
-        int i = (int)((sqrt(8.0 * e + 1.0) - 1.0) * 0.5);
+        int i = (int)((sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
         while ((i + 1) * (i + 2) / 2 <= e) i++;
         while (i * (i + 1) / 2 > e) i--;
         const int j = e - i * (i + 1) / 2;
-        double h = S.M[i * LDV + j];
-        for (int r = 0; r < nefc; r++) {
-          const double dr = S.evec[r];
-          if (dr != 0.0) h += dr * S.J[r * LDV + i] * S.J[r * LDV + j];
+        double h0 = S.M[i * LDV + j], h1 = 0;
+        int r = 0;
+        for (; r + 1 < nefc; r += 2) {
+          h0 += S.efc_aref[r] * S.J[r * LDV + i] * S.J[r * LDV + j];
+          h1 += S.efc_aref[r + 1] * S.J[(r + 1) * LDV + i] * S.J[(r + 1) * LDV + j];
         }
-        S.H[i * LDV + j] = h;
+        if (r < nefc) h0 += S.efc_aref[r] * S.J[r * LDV + i] * S.J[r * LDV + j];
+        S.H[i * LDV + j] = h0 + h1;
       }
       SYNC();
-      chol_factor(S.H, nv, lane);
-      const double search = -chol_solve(S.H, nv, lane, grad);
+      const double search = -chol_solve_inplace(S.H, nv, lane, grad);
       if (lane < nv) S.vec2[lane] = search;
       SYNC();
-      double jv = 0, Mv = 0;
-      if (lane < nefc) for (int k = 0; k < nv; k++) jv += S.J[lane * LDV + k] * S.vec2[k];
-      if (lane < nv) for (int k = 0; k < nv; k++) Mv += S.M[lane * LDV + k] * S.vec2[k];
+      const double jv = row_dot(Jrow, S.vec2, nv), Mv = row_dot(Mrow, S.vec2, nv);
       const double qg1 = wave_sum(lane < nv ? search * (Ma - fs) : 0.0);
       const double qg2 = wave_sum(lane < nv ? 0.5 * search * Mv : 0.0);
       // exact line search on the convex piecewise-quadratic: safeguarded Newton on its derivative
@@ -911,8 +989,7 @@ __device__ __noinline__ void substep(const HModel& m, Lds& S, int lane, int flag
     SYNC();
     if (lane < nv) S.H[lane * LDV + lane] += h * m.dof_damping[lane];
     SYNC();
-    chol_factor(S.H, nv, lane);
-    anew = chol_solve(S.H, nv, lane, fs + fcon);
+    anew = chol_solve_inplace(S.H, nv, lane, fs + fcon);
   }
   if (lane < nv) S.qvel[lane] = qv + h * anew;
   SYNC();
