@@ -129,5 +129,11 @@ class BatchedEnv:
         _lib.check(self._L.lhw_env_pop_episode_stats(self._h, ctypes.byref(r), ctypes.byref(l), ctypes.byref(c)))
         return r.value, l.value, c.value
 
+    def phase_cycles(self, enable=True):
+        """Per-phase shader-clock cycles of env 0 since the last call (diagnostic, wave-per-env stepper only)."""
+        out = np.zeros(16, dtype=np.int64)
+        _lib.check(self._L.lhw_env_phase_cycles(self._h, int(enable), out.ctypes.data))
+        return out
+
     def set_iteration(self, it: int):
         _lib.check(self._L.lhw_env_set_iteration(self._h, int(it)))

@@ -245,6 +245,17 @@ extern "C" int lhw_env_pop_episode_stats(LhwEnv* e, double* ret_sum, double* len
   return LHW_OK;
 }
 
+/* resident workgroups (= waves) per CU the runtime grants the wave-per-env step kernel */
+extern "C" int lhw_debug_stepper_occupancy(void) { return humanoid_occupancy(); }
+
+extern "C" int lhw_env_phase_cycles(LhwEnv* e, int enable, int64_t* out16) {
+  if (!e || !e->hum) return lhw_fail(LHW_ERR_UNSUPPORTED, "phase profiling exists for the wave-per-env stepper only");
+  HIPCHK(hipSetDevice(e->device));
+  static_assert(sizeof(long long) == sizeof(int64_t), "");
+  if (humanoid_profile(e->hum, enable, (long long*)out16)) return lhw_fail(LHW_ERR_HIP, "profile buffer");
+  return LHW_OK;
+}
+
 extern "C" int lhw_env_set_iteration(LhwEnv* e, int64_t iteration) {
   if (!e) return lhw_fail(LHW_ERR_ARG, "null env");
   if (e->hum) humanoid_set_iteration(e->hum, iteration);

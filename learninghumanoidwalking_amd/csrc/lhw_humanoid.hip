@@ -32,16 +32,16 @@
 #include "lhw_internal.h"
 #include "lhw_rng.h"
 
-#define NB 24   // bodies
-#define NV 20   // dofs
-#define LDV 21  // padded row length of nv x nv matrices and of J (odd => conflict-free 64-bit column sweeps)
-#define NQ 21
-#define NJ 16   // joints
-#define NG 16   // geoms
-#define NP 32   // collision candidate pairs
+#define NB 20   // bodies
+#define NV 18   // dofs
+#define LDV 19  // padded row length of nv x nv matrices and of J (odd => conflict-free 64-bit column sweeps)
+#define NQ 19
+#define NJ 14   // joints
+#define NG 12   // geoms
+#define NP 24   // collision candidate pairs
 #define NC 12   // contacts kept per step
-#define NE 64   // constraint rows (one per lane)
-#define NU 16   // actuators
+#define NE 48   // constraint rows (one per lane)
+#define NU 12   // actuators
 #define NTRI (NV * (NV + 1) / 2)
 #define HMINVAL 1e-15
 
@@ -89,6 +89,7 @@ struct HModel {
   // derived tables (host-built)
   const int *body_level, *body_subend, *mpair_i, *mpair_j, *act_dof;
   const unsigned *body_dofmask, *dof_prevmask;
+  int track_body[3];  // bodies whose spatial velocity must survive the sub-step (task reads them afterwards)
 };
 
 struct HParams {
@@ -104,7 +105,17 @@ struct HState {
   double* rec;     // [N][REC_D]
   int* irec;       // [N][REC_I]
   double* ep_stats;
+  long long* prof; // optional [16] per-phase cycle counters accumulated by env 0 (NULL = off)
 };
+#define PROF_BEGIN() long long prof_t = (st_prof && lane == 0) ? (long long)clock64() : 0
+#define PROF_MARK(slot)                                                  \
+  do {                                                                   \
+    if (st_prof && lane == 0) {                                          \
+      long long now_ = (long long)clock64();                             \
+      st_prof[slot] += now_ - prof_t;                                    \
+      prof_t = now_;                                                     \
+    }                                                                    \
+  } while (0)
 
 struct HumanoidEnv {
   HModel m;
@@ -115,23 +126,51 @@ struct HumanoidEnv {
 };
 
 // ------------------------------------------------------------------------------------------------ LDS working set
+// Working set of one env.  Everything that is only live inside one stage of the sub-step shares the union region U:
+//   stage A  kinematics + collision : cinert(partial) xmat xipos xanchor xaxis xquat gpos gmat
+//   stage B  com / CRBA / RNE       : cinert crb cdofdot cvel cacc cfrc csub
+//   stage C  constraints + solve    : J, H (the efc row parameters sit in H until the reference acceleration is formed)
+// which keeps the block at ~19 KB so that 8 waves stay resident per CU.
+#define U_CINERT 0
+#define U_XMAT (U_CINERT + NB * 10)
+#define U_XIPOS (U_XMAT + NB * 9)
+#define U_XANCHOR (U_XIPOS + NB * 3)
+#define U_XAXIS (U_XANCHOR + NJ * 3)
+#define U_XQUAT (U_XAXIS + NJ * 3)
+#define U_GPOS (U_XQUAT + NB * 4)
+#define U_GMAT (U_GPOS + NG * 3)
+#define U_END_A (U_GMAT + NG * 9)
+#define U_CRB (U_CINERT + NB * 10)
+#define U_CDOFDOT (U_CRB + NB * 10)
+#define U_CVEL (U_CDOFDOT + NV * 6)
+#define U_CACC (U_CVEL + NB * 6)
+#define U_CFRC (U_CACC + NB * 6)
+#define U_CSUB (U_CFRC + NB * 6)
+#define U_END_B (U_CSUB + NB * 6)
+#define U_J 0
+#define U_H (U_J + NE * LDV)
+#define U_EPOS (U_H)
+#define U_EMARGIN (U_EPOS + NE)
+#define U_EK (U_EMARGIN + NE)
+#define U_EB (U_EK + NE)
+#define U_EIMP (U_EB + NE)
+#define U_END_C (U_H + NV * LDV)
+#define USIZE (U_END_C > U_END_B ? (U_END_C > U_END_A ? U_END_C : U_END_A) : (U_END_B > U_END_A ? U_END_B : U_END_A))
+static_assert(U_EIMP + NE <= U_END_C, "efc row parameters must fit in the H slot");
+
 struct Lds {
   double qpos[NQ], qvel[NV], ctrl[NU];
-  double xpos[NB * 3], xquat[NB * 4], xmat[NB * 9], xipos[NB * 3];
-  double xanchor[NJ * 3], xaxis[NJ * 3];
-  double com[4];
-  double cinert[NB * 10], crb[NB * 10];
-  double cdof[NV * 6], cdofdot[NV * 6];
-  double cvel[NB * 6], cacc[NB * 6], cfrc[NB * 6], csub[NB * 6];
-  double gpos[NG * 3], gmat[NG * 9];
-  double M[NV * LDV], H[NV * LDV];
-  double J[NE * LDV];
-  double vec[NV], vec2[NV], evec[NE];
-  double qfrc_smooth[NV], qacc_smooth[NV], qacc[NV], qfrc_constraint[NV], damping[NV];
-  double efc_pos[NE], efc_margin[NE], efc_D[NE], efc_aref[NE], efc_K[NE], efc_B[NE], efc_imp[NE], efc_force[NE];
+  double xpos[NB * 3];
+  double rootmat[9], com[4], svel[18];   // root xmat; tree com; cvel of the three tracked bodies (root, right foot, left foot)
+  double cdof[NV * 6];
+  double M[NV * LDV];
+  double vec[NV], vec2[NV], evec[NE], dact[NE];
+  double qacc[NV];
+  double efc_D[NE], efc_force[NE];
   double con_dist[NC], con_pos[NC * 3], con_frame[NC * 9], con_mu[NC], con_solref[NC * 2], con_solimp[NC * 5], con_margin[NC];
   int con_g1[NC], con_g2[NC], con_dim[NC], con_row[NC];
   double sq[NU], sv[NU], frc[NU];
+  double U[USIZE];
   int ncon, nefc, nlim, overflow;
 };
 
@@ -244,24 +283,22 @@ __device__ double chol_solve_inplace(double* A, int n, int lane, double x) {
 #pragma unroll
   for (int p = 0; p < NV; p++) r[p] = (p < n) ? A[i * LDV + p] : 0.0;
   double invd[NV];
+  // factorisation entirely in registers: row j of L is broadcast from lane j with v_readlane (no LDS round trip, no barrier)
 #pragma unroll
   for (int j = 0; j < NV; j++) {
     if (j < n) {
       double s0 = r[j], s1 = 0.0;
 #pragma unroll
       for (int p = 0; p + 1 < j; p += 2) {
-        s0 -= r[p] * A[j * LDV + p];
-        s1 -= r[p + 1] * A[j * LDV + p + 1];
+        s0 -= r[p] * bcast(r[p], j);
+        s1 -= r[p + 1] * bcast(r[p + 1], j);
       }
-      if (j & 1) s0 -= r[j - 1] * A[j * LDV + j - 1];
+      if (j & 1) s0 -= r[j - 1] * bcast(r[j - 1], j);
       const double s = s0 + s1;
-      const double d = sqrt(fmax(bcast(s, j), HMINVAL));
-      const double id = 1.0 / d;
+      const double piv = fmax(bcast(s, j), HMINVAL);
+      const double id = rsqrt(piv);
       invd[j] = id;
-      const double l = (lane == j) ? d : s * id;
-      r[j] = l;
-      if (lane >= j && lane < n) A[lane * LDV + j] = l;
-      SYNC();
+      r[j] = (lane == j) ? piv * id : s * id;
     } else invd[j] = 0.0;
   }
   // forward substitution L y = x : column sweep, l_ij from registers
@@ -271,7 +308,14 @@ __device__ double chol_solve_inplace(double* A, int n, int lane, double x) {
       const double yj = bcast(x, j) * invd[j];
       x = (lane == j) ? yj : ((lane > j) ? x - r[j] * yj : x);
     }
-  // backward substitution L^T z = y : row j of L read across lanes
+  // backward substitution L^T z = y needs column `lane` of L: one transposing pass through LDS
+  SYNC();
+  if (lane < n) {
+#pragma unroll
+    for (int p = 0; p < NV; p++)
+      if (p < n && p <= lane) A[lane * LDV + p] = r[p];
+  }
+  SYNC();
   double col[NV];
 #pragma unroll
   for (int j = 0; j < NV; j++) col[j] = (j < n && lane < j) ? A[j * LDV + lane] : 0.0;
@@ -299,9 +343,9 @@ __device__ __forceinline__ double row_dot(const double* row, const double* v, in
 __device__ void fwd_kinematics(const HModel& m, Lds& S, int lane) {
   if (lane == 0) {
     S.xpos[0] = S.xpos[1] = S.xpos[2] = 0;
-    S.xquat[0] = 1; S.xquat[1] = S.xquat[2] = S.xquat[3] = 0;
-    for (int k = 0; k < 9; k++) S.xmat[k] = (k % 4 == 0) ? 1.0 : 0.0;
-    S.xipos[0] = S.xipos[1] = S.xipos[2] = 0;
+    S.U[U_XQUAT + 0] = 1; S.U[U_XQUAT + 1] = S.U[U_XQUAT + 2] = S.U[U_XQUAT + 3] = 0;
+    for (int k = 0; k < 9; k++) S.U[U_XMAT + k] = (k % 4 == 0) ? 1.0 : 0.0;
+    S.U[U_XIPOS + 0] = S.U[U_XIPOS + 1] = S.U[U_XIPOS + 2] = 0;
   }
   SYNC();
   for (int lvl = 1; lvl < m.nlevel; lvl++) {
@@ -314,12 +358,12 @@ __device__ void fwd_kinematics(const HModel& m, Lds& S, int lane) {
         double q[4] = {S.qpos[qa + 3], S.qpos[qa + 4], S.qpos[qa + 5], S.qpos[qa + 6]};
         normalize4(q);
         for (int k = 0; k < 4; k++) { S.qpos[qa + 3 + k] = q[k]; xq[k] = q[k]; }
-        for (int k = 0; k < 3; k++) { xp[k] = S.qpos[qa + k]; S.xanchor[3 * ja + k] = xp[k]; S.xaxis[3 * ja + k] = m.jnt_axis[3 * ja + k]; }
+        for (int k = 0; k < 3; k++) { xp[k] = S.qpos[qa + k]; S.U[U_XANCHOR + 3 * ja + k] = xp[k]; S.U[U_XAXIS + 3 * ja + k] = m.jnt_axis[3 * ja + k]; }
       } else {
         double t[3], bp[3] = {m.body_pos[3 * b], m.body_pos[3 * b + 1], m.body_pos[3 * b + 2]};
         double bq[4] = {m.body_quat[4 * b], m.body_quat[4 * b + 1], m.body_quat[4 * b + 2], m.body_quat[4 * b + 3]};
-        double pq[4] = {S.xquat[4 * par], S.xquat[4 * par + 1], S.xquat[4 * par + 2], S.xquat[4 * par + 3]};
-        mat_vec(t, &S.xmat[9 * par], bp);
+        double pq[4] = {S.U[U_XQUAT + 4 * par], S.U[U_XQUAT + 4 * par + 1], S.U[U_XQUAT + 4 * par + 2], S.U[U_XQUAT + 4 * par + 3]};
+        mat_vec(t, &S.U[U_XMAT + 9 * par], bp);
         for (int k = 0; k < 3; k++) xp[k] = S.xpos[3 * par + k] + t[k];
         mul_quat(xq, pq, bq);
         for (int jj = 0; jj < jn; jj++) {
@@ -330,7 +374,7 @@ __device__ void fwd_kinematics(const HModel& m, Lds& S, int lane) {
           quat2mat(R, xq);
           mat_vec(waxis, R, ax);
           mat_vec(anchor, R, jp);
-          for (int k = 0; k < 3; k++) { anchor[k] += xp[k]; S.xanchor[3 * j + k] = anchor[k]; S.xaxis[3 * j + k] = waxis[k]; }
+          for (int k = 0; k < 3; k++) { anchor[k] += xp[k]; S.U[U_XANCHOR + 3 * j + k] = anchor[k]; S.U[U_XAXIS + 3 * j + k] = waxis[k]; }
           const double q = S.qpos[m.jnt_qposadr[j]] - m.qpos0[m.jnt_qposadr[j]];
           if (m.jnt_type[j] == JT_SLIDE) {
             for (int k = 0; k < 3; k++) xp[k] += waxis[k] * q;
@@ -348,15 +392,15 @@ __device__ void fwd_kinematics(const HModel& m, Lds& S, int lane) {
       quat2mat(R, xq);
       double ip[3] = {m.body_ipos[3 * b], m.body_ipos[3 * b + 1], m.body_ipos[3 * b + 2]}, t[3];
       mat_vec(t, R, ip);
-      for (int k = 0; k < 3; k++) { S.xpos[3 * b + k] = xp[k]; S.xipos[3 * b + k] = xp[k] + t[k]; }
-      for (int k = 0; k < 4; k++) S.xquat[4 * b + k] = xq[k];
-      for (int k = 0; k < 9; k++) S.xmat[9 * b + k] = R[k];
+      for (int k = 0; k < 3; k++) { S.xpos[3 * b + k] = xp[k]; S.U[U_XIPOS + 3 * b + k] = xp[k] + t[k]; }
+      for (int k = 0; k < 4; k++) S.U[U_XQUAT + 4 * b + k] = xq[k];
+      for (int k = 0; k < 9; k++) S.U[U_XMAT + 9 * b + k] = R[k];
       // rotated inertia T = Ri diag(I) Ri^T of the body (completed with the com offset in fwd_com)
       double iq[4] = {m.body_iquat[4 * b], m.body_iquat[4 * b + 1], m.body_iquat[4 * b + 2], m.body_iquat[4 * b + 3]}, qi[4], Ri[9];
       mul_quat(qi, xq, iq);
       quat2mat(Ri, qi);
       const double I0 = m.body_inertia[3 * b], I1 = m.body_inertia[3 * b + 1], I2 = m.body_inertia[3 * b + 2];
-      double* ci = &S.cinert[10 * b];
+      double* ci = &S.U[U_CINERT + 10 * b];
       ci[0] = Ri[0] * I0 * Ri[0] + Ri[1] * I1 * Ri[1] + Ri[2] * I2 * Ri[2];
       ci[1] = Ri[3] * I0 * Ri[3] + Ri[4] * I1 * Ri[4] + Ri[5] * I2 * Ri[5];
       ci[2] = Ri[6] * I0 * Ri[6] + Ri[7] * I1 * Ri[7] + Ri[8] * I2 * Ri[8];
@@ -366,6 +410,7 @@ __device__ void fwd_kinematics(const HModel& m, Lds& S, int lane) {
     }
     SYNC();
   }
+  if (lane < 9) S.rootmat[lane] = S.U[U_XMAT + 9 * 1 + lane];
 }
 
 // subtree com of the (single) dynamic tree rooted at body 1, cinert, cdof  (mj_comPos)
@@ -373,7 +418,7 @@ __device__ void fwd_com(const HModel& m, Lds& S, int lane) {
   double ms = 0, mx = 0, my = 0, mz = 0;
   if (lane >= 1 && lane < m.nbody && m.body_rootid[lane] == 1) {
     ms = m.body_mass[lane];
-    mx = ms * S.xipos[3 * lane]; my = ms * S.xipos[3 * lane + 1]; mz = ms * S.xipos[3 * lane + 2];
+    mx = ms * S.U[U_XIPOS + 3 * lane]; my = ms * S.U[U_XIPOS + 3 * lane + 1]; mz = ms * S.U[U_XIPOS + 3 * lane + 2];
   }
   ms = wave_sum(ms); mx = wave_sum(mx); my = wave_sum(my); mz = wave_sum(mz);
   const double com[3] = {mx / ms, my / ms, mz / ms};
@@ -384,8 +429,8 @@ __device__ void fwd_com(const HModel& m, Lds& S, int lane) {
     // static bodies (their own root) use their own com as reference; they never enter M or the bias force
     const bool dyn = m.body_rootid[b] == 1;
     double dif[3];
-    for (int k = 0; k < 3; k++) dif[k] = dyn ? S.xipos[3 * b + k] - com[k] : 0.0;
-    double* ci = &S.cinert[10 * b];
+    for (int k = 0; k < 3; k++) dif[k] = dyn ? S.U[U_XIPOS + 3 * b + k] - com[k] : 0.0;
+    double* ci = &S.U[U_CINERT + 10 * b];
     ci[0] += mass * (dif[1] * dif[1] + dif[2] * dif[2]);
     ci[1] += mass * (dif[0] * dif[0] + dif[2] * dif[2]);
     ci[2] += mass * (dif[0] * dif[0] + dif[1] * dif[1]);
@@ -397,16 +442,16 @@ __device__ void fwd_com(const HModel& m, Lds& S, int lane) {
   if (lane < m.nv) {
     const int d = lane, j = m.dof_jntid[d], b = m.dof_bodyid[d], t = m.jnt_type[j], k = d - m.jnt_dofadr[j];
     double off[3], ax[3], c[6];
-    for (int a = 0; a < 3; a++) off[a] = com[a] - S.xanchor[3 * j + a];
+    for (int a = 0; a < 3; a++) off[a] = com[a] - S.U[U_XANCHOR + 3 * j + a];
     if (t == JT_FREE && k < 3) {
       for (int a = 0; a < 6; a++) c[a] = 0;
       c[3 + k] = 1;
     } else if (t == JT_SLIDE) {
       c[0] = c[1] = c[2] = 0;
-      for (int a = 0; a < 3; a++) c[3 + a] = S.xaxis[3 * j + a];
+      for (int a = 0; a < 3; a++) c[3 + a] = S.U[U_XAXIS + 3 * j + a];
     } else {
-      if (t == JT_FREE) { ax[0] = S.xmat[9 * b + (k - 3)]; ax[1] = S.xmat[9 * b + 3 + (k - 3)]; ax[2] = S.xmat[9 * b + 6 + (k - 3)]; }
-      else for (int a = 0; a < 3; a++) ax[a] = S.xaxis[3 * j + a];
+      if (t == JT_FREE) { ax[0] = S.U[U_XMAT + 9 * b + (k - 3)]; ax[1] = S.U[U_XMAT + 9 * b + 3 + (k - 3)]; ax[2] = S.U[U_XMAT + 9 * b + 6 + (k - 3)]; }
+      else for (int a = 0; a < 3; a++) ax[a] = S.U[U_XAXIS + 3 * j + a];
       c[0] = ax[0]; c[1] = ax[1]; c[2] = ax[2];
       cross3(c + 3, ax, off);
     }
@@ -420,22 +465,22 @@ __device__ void fwd_crb(const HModel& m, Lds& S, int lane) {
   for (int it = lane; it < m.nbody * 10; it += 64) {
     const int b = it / 10, k = it - 10 * b;
     double s = 0;
-    if (b >= 1) for (int d = b; d < m.body_subend[b]; d++) s += S.cinert[10 * d + k];
-    S.crb[it] = s;
+    if (b >= 1) for (int d = b; d < m.body_subend[b]; d++) s += S.U[U_CINERT + 10 * d + k];
+    S.U[U_CRB + it] = s;
   }
   for (int it = lane; it < m.nv * LDV; it += 64) S.M[it] = 0;
   SYNC();
   // vec scratch: buf_i = crb[body(i)] * cdof_i  kept in csub (6 per dof)
   if (lane < m.nv) {
     double buf[6];
-    inert_vec(buf, &S.crb[10 * m.dof_bodyid[lane]], &S.cdof[6 * lane]);
-    for (int a = 0; a < 6; a++) S.csub[6 * lane + a] = buf[a];
+    inert_vec(buf, &S.U[U_CRB + 10 * m.dof_bodyid[lane]], &S.cdof[6 * lane]);
+    for (int a = 0; a < 6; a++) S.U[U_CSUB + 6 * lane + a] = buf[a];
   }
   SYNC();
   for (int it = lane; it < m.nmpair; it += 64) {
     const int i = m.mpair_i[it], j = m.mpair_j[it];
     double s = 0;
-    for (int a = 0; a < 6; a++) s += S.cdof[6 * j + a] * S.csub[6 * i + a];
+    for (int a = 0; a < 6; a++) s += S.cdof[6 * j + a] * S.U[U_CSUB + 6 * i + a];
     if (i == j) s += m.dof_armature[i];
     S.M[i * LDV + j] = s;
     S.M[j * LDV + i] = s;
@@ -498,8 +543,8 @@ __device__ void collide_pair(ConSink& k, const HModel& m, const Lds& S, int g1, 
   const double zero[3] = {0, 0, 0};
   const int t1 = m.geom_type[g1], t2 = m.geom_type[g2];
   double p1[3], p2[3], R1[9], R2[9], s1[3], s2[3];
-  for (int a = 0; a < 3; a++) { p1[a] = S.gpos[3 * g1 + a]; p2[a] = S.gpos[3 * g2 + a]; s1[a] = m.geom_size[3 * g1 + a]; s2[a] = m.geom_size[3 * g2 + a]; }
-  for (int a = 0; a < 9; a++) { R1[a] = S.gmat[9 * g1 + a]; R2[a] = S.gmat[9 * g2 + a]; }
+  for (int a = 0; a < 3; a++) { p1[a] = S.U[U_GPOS + 3 * g1 + a]; p2[a] = S.U[U_GPOS + 3 * g2 + a]; s1[a] = m.geom_size[3 * g1 + a]; s2[a] = m.geom_size[3 * g2 + a]; }
+  for (int a = 0; a < 9; a++) { R1[a] = S.U[U_GMAT + 9 * g1 + a]; R2[a] = S.U[U_GMAT + 9 * g2 + a]; }
   if (t1 == G_PLANE && t2 == G_SPHERE) col_plane_sphere(k, p1, R1, p2, s2[0], margin, zero);
   else if (t1 == G_PLANE && t2 == G_CAPSULE) {
     double ax[3] = {R2[2], R2[5], R2[8]}, e[3];
@@ -568,12 +613,12 @@ __device__ void fwd_collision(const HModel& m, Lds& S, int lane) {
     const int g = lane, b = m.geom_bodyid[g];
     double gp[3] = {m.geom_pos[3 * g], m.geom_pos[3 * g + 1], m.geom_pos[3 * g + 2]}, t[3];
     double gq[4] = {m.geom_quat[4 * g], m.geom_quat[4 * g + 1], m.geom_quat[4 * g + 2], m.geom_quat[4 * g + 3]}, q[4], R[9];
-    double bq[4] = {S.xquat[4 * b], S.xquat[4 * b + 1], S.xquat[4 * b + 2], S.xquat[4 * b + 3]};
-    mat_vec(t, &S.xmat[9 * b], gp);
+    double bq[4] = {S.U[U_XQUAT + 4 * b], S.U[U_XQUAT + 4 * b + 1], S.U[U_XQUAT + 4 * b + 2], S.U[U_XQUAT + 4 * b + 3]};
+    mat_vec(t, &S.U[U_XMAT + 9 * b], gp);
     mul_quat(q, bq, gq);
     quat2mat(R, q);
-    for (int k = 0; k < 3; k++) S.gpos[3 * g + k] = S.xpos[3 * b + k] + t[k];
-    for (int k = 0; k < 9; k++) S.gmat[9 * g + k] = R[k];
+    for (int k = 0; k < 3; k++) S.U[U_GPOS + 3 * g + k] = S.xpos[3 * b + k] + t[k];
+    for (int k = 0; k < 9; k++) S.U[U_GMAT + 9 * g + k] = R[k];
   }
   if (lane == 0) { S.overflow = 0; }
   SYNC();
@@ -687,7 +732,7 @@ __device__ void fwd_constraints(const HModel& m, Lds& S, int lane) {
     if (fits) rend = cbase + nr;
   }
   const int nefc = wave_max_i(rend);
-  for (int it = lane; it < nefc * LDV; it += 64) S.J[it] = 0;
+  for (int it = lane; it < nefc * LDV; it += 64) S.U[U_J + it] = 0;
   SYNC();
   if (nl > 0) {
     const int j = lane, d = m.jnt_dofadr[j];
@@ -699,8 +744,8 @@ __device__ void fwd_constraints(const HModel& m, Lds& S, int lane) {
       const double dist = side == 0 ? dlo : dhi, mg = m.jnt_margin[j];
       double K, B, imp, R;
       row_params(m, sr, si, dist, mg, m.dof_invweight0[d], &K, &B, &imp, &R);
-      S.J[r * LDV + d] = side == 0 ? 1.0 : -1.0;
-      S.efc_pos[r] = dist; S.efc_margin[r] = mg; S.efc_D[r] = 1 / R; S.efc_K[r] = K; S.efc_B[r] = B; S.efc_imp[r] = imp;
+      S.U[U_J + r * LDV + d] = side == 0 ? 1.0 : -1.0;
+      S.U[U_EPOS + r] = dist; S.U[U_EMARGIN + r] = mg; S.efc_D[r] = 1 / R; S.U[U_EK + r] = K; S.U[U_EB + r] = B; S.U[U_EIMP + r] = imp;
       r++;
     }
   }
@@ -722,12 +767,12 @@ __device__ void fwd_constraints(const HModel& m, Lds& S, int lane) {
     }
     const double* f = &S.con_frame[9 * c];
     const double jn = dot3(f, d);
-    if (S.con_dim[c] == 1) { S.J[r0 * LDV + k] = jn; continue; }
+    if (S.con_dim[c] == 1) { S.U[U_J + r0 * LDV + k] = jn; continue; }
     const double mu = S.con_mu[c], t1 = mu * dot3(f + 3, d), t2 = mu * dot3(f + 6, d);
-    S.J[(r0 + 0) * LDV + k] = jn + t1;
-    S.J[(r0 + 1) * LDV + k] = jn - t1;
-    S.J[(r0 + 2) * LDV + k] = jn + t2;
-    S.J[(r0 + 3) * LDV + k] = jn - t2;
+    S.U[U_J + (r0 + 0) * LDV + k] = jn + t1;
+    S.U[U_J + (r0 + 1) * LDV + k] = jn - t1;
+    S.U[U_J + (r0 + 2) * LDV + k] = jn + t2;
+    S.U[U_J + (r0 + 3) * LDV + k] = jn - t2;
   }
   // contact row parameters: item = (contact, edge)
   for (int it = lane; it < ncon * 4; it += 64) {
@@ -741,14 +786,14 @@ __device__ void fwd_constraints(const HModel& m, Lds& S, int lane) {
     row_params(m, &S.con_solref[2 * c], &S.con_solimp[5 * c], S.con_dist[c], S.con_margin[c], diag, &K, &B, &imp, &R);
     if (S.con_dim[c] == 3) R = fmax(HMINVAL, 2 * mu * mu * R);  // every pyramid edge shares 2 mu^2 R(first edge)
     const int r = r0 + e;
-    S.efc_pos[r] = S.con_dist[c]; S.efc_margin[r] = S.con_margin[c]; S.efc_D[r] = 1 / R; S.efc_K[r] = K; S.efc_B[r] = B; S.efc_imp[r] = imp;
+    S.U[U_EPOS + r] = S.con_dist[c]; S.U[U_EMARGIN + r] = S.con_margin[c]; S.efc_D[r] = 1 / R; S.U[U_EK + r] = K; S.U[U_EB + r] = B; S.U[U_EIMP + r] = imp;
   }
   if (lane == 0) { S.nefc = nefc; S.nlim = nlim; }
   SYNC();
 }
 
 // mj_fwdVelocity: cvel, cdof_dot, bias force (RNE, no acceleration), passive damping, constraint reference
-__device__ void fwd_velocity(const HModel& m, Lds& S, int lane) {
+__device__ double fwd_velocity(const HModel& m, Lds& S, int lane) {
   // velocity seen by dof j when its cdof_dot is formed: sum over dof_prevmask[j]
   if (lane < m.nv) {
     const int j = lane;
@@ -766,8 +811,8 @@ __device__ void fwd_velocity(const HModel& m, Lds& S, int lane) {
     const double* cd = &S.cdof[6 * j];
     cross3(a3, v, cd); cross3(b3, v, cd + 3); cross3(c3, v + 3, cd);
     for (int a = 0; a < 3; a++) {
-      S.cdofdot[6 * j + a] = zero ? 0.0 : a3[a];
-      S.cdofdot[6 * j + 3 + a] = zero ? 0.0 : b3[a] + c3[a];
+      S.U[U_CDOFDOT + 6 * j + a] = zero ? 0.0 : a3[a];
+      S.U[U_CDOFDOT + 6 * j + 3 + a] = zero ? 0.0 : b3[a] + c3[a];
     }
   }
   SYNC();
@@ -780,43 +825,58 @@ __device__ void fwd_velocity(const HModel& m, Lds& S, int lane) {
       mask &= mask - 1;
       const double qv = S.qvel[k];
       cv += S.cdof[6 * k + a] * qv;
-      ca += S.cdofdot[6 * k + a] * qv;
+      ca += S.U[U_CDOFDOT + 6 * k + a] * qv;
     }
-    S.cvel[it] = cv;
-    S.cacc[it] = ca;
+    S.U[U_CVEL + it] = cv;
+    S.U[U_CACC + it] = ca;
   }
   SYNC();
   if (lane >= 1 && lane < m.nbody) {
     const int b = lane;
     double t[6], t2[6], f[6];
-    inert_vec(t, &S.cinert[10 * b], &S.cacc[6 * b]);
-    inert_vec(t2, &S.cinert[10 * b], &S.cvel[6 * b]);
-    const double* v = &S.cvel[6 * b];
+    inert_vec(t, &S.U[U_CINERT + 10 * b], &S.U[U_CACC + 6 * b]);
+    inert_vec(t2, &S.U[U_CINERT + 10 * b], &S.U[U_CVEL + 6 * b]);
+    const double* v = &S.U[U_CVEL + 6 * b];
     double a3[3], b3[3], c3[3];
     cross3(a3, v, t2); cross3(b3, v + 3, t2 + 3); cross3(c3, v, t2 + 3);
     for (int a = 0; a < 3; a++) { f[a] = a3[a] + b3[a] + t[a]; f[3 + a] = c3[a] + t[3 + a]; }
-    for (int a = 0; a < 6; a++) S.cfrc[6 * b + a] = f[a];
+    for (int a = 0; a < 6; a++) S.U[U_CFRC + 6 * b + a] = f[a];
   }
-  if (lane == 0) for (int a = 0; a < 6; a++) S.cfrc[a] = 0;
+  if (lane == 0) for (int a = 0; a < 6; a++) S.U[U_CFRC + a] = 0;
   SYNC();
   for (int it = lane; it < m.nbody * 6; it += 64) {
     const int b = it / 6, a = it - 6 * b;
     double s = 0;
-    if (b >= 1) for (int d = b; d < m.body_subend[b]; d++) s += S.cfrc[6 * d + a];
-    S.csub[it] = s;
+    if (b >= 1) for (int d = b; d < m.body_subend[b]; d++) s += S.U[U_CFRC + 6 * d + a];
+    S.U[U_CSUB + it] = s;
+  }
+  if (lane < 18) S.svel[lane] = S.U[U_CVEL + 6 * m.track_body[lane / 6] + lane % 6];
+  SYNC();
+  double bias = 0;
+  if (lane < m.nv) {
+    const int b = m.dof_bodyid[lane];
+    for (int a = 0; a < 6; a++) bias += S.cdof[6 * lane + a] * S.U[U_CSUB + 6 * b + a];
   }
   SYNC();
+  return bias;
 }
 
 // One mj_forward (+ Euler).  flags: bit0 actuation enabled, bit1 integrate.
 // On return S.qacc / S.efc_force / contacts / S.sq,sv,frc describe THIS forward pass (the "stale" fields of note S).
-__device__ __noinline__ void substep(const HModel& m, Lds& S, int lane, int flags, double* warm /* lane-held */) {
+__device__ __forceinline__ void substep(const HModel& m, Lds& S, int lane, int flags, double* warm /* lane-held */, long long* st_prof) {
+  PROF_BEGIN();
   fwd_kinematics(m, S, lane);
+  PROF_MARK(0);
+  fwd_collision(m, S, lane);   // stage A temporaries (geom frames) die here
+  PROF_MARK(3);
   fwd_com(m, S, lane);
+  PROF_MARK(1);
   fwd_crb(m, S, lane);
-  fwd_collision(m, S, lane);
-  fwd_constraints(m, S, lane);
-  fwd_velocity(m, S, lane);
+  PROF_MARK(2);
+  const double bias = fwd_velocity(m, S, lane);  // stage B temporaries die here
+  PROF_MARK(5);
+  fwd_constraints(m, S, lane);  // stage C: J over the dead stage-B region, row parameters in the H slot
+  PROF_MARK(4);
   const int nv = m.nv, nefc = S.nefc;
   // transmission + actuation (lane = actuator)
   if (lane < m.nu) {
@@ -838,21 +898,13 @@ __device__ __noinline__ void substep(const HModel& m, Lds& S, int lane, int flag
   double fs = 0, qv = 0;
   if (lane < nv) {
     qv = S.qvel[lane];
-    double bias = 0;
-    const int b = m.dof_bodyid[lane];
-    for (int a = 0; a < 6; a++) bias += S.cdof[6 * lane + a] * S.csub[6 * b + a];
     double act = 0;
     for (int u = 0; u < m.nu; u++)
       if (m.act_dof[u] == lane) act += m.actuator_gear[u] * S.frc[u];
     fs = -m.dof_damping[lane] * qv - bias + act;
-    S.qfrc_smooth[lane] = fs;
     S.vec[lane] = qv;
   }
-  // factor M (copy in H), qacc_smooth
-  for (int it = lane; it < nv * LDV; it += 64) S.H[it] = S.M[it];
   SYNC();
-  const double as = chol_solve_inplace(S.H, nv, lane, fs);
-  if (lane < nv) S.qacc_smooth[lane] = as;
   // rows of M (lane = dof) and J (lane = row) stay in registers for every product of the solve
   double Mrow[NV], Jrow[NV];
   {
@@ -860,21 +912,26 @@ __device__ __noinline__ void substep(const HModel& m, Lds& S, int lane, int flag
 #pragma unroll
     for (int k = 0; k < NV; k++) {
       Mrow[k] = (k < nv && lane < nv) ? S.M[im * LDV + k] : 0.0;
-      Jrow[k] = (k < nv && lane < nefc) ? S.J[ij * LDV + k] : 0.0;
+      Jrow[k] = (k < nv && lane < nefc) ? S.U[U_J + ij * LDV + k] : 0.0;
     }
   }
-  // constraint reference: aref = -B (J qvel) - K imp (pos - margin)   (lane = row)
+  // constraint reference: aref = -B (J qvel) - K imp (pos - margin)   (lane = row); consumes the row parameters
+  // parked in the H slot, which the factorisations below then overwrite
   double aref = 0, D = 0;
   {
     const double jv0 = row_dot(Jrow, S.vec, nv);
     if (lane < nefc) {
-      aref = -S.efc_B[lane] * jv0 - S.efc_K[lane] * S.efc_imp[lane] * (S.efc_pos[lane] - S.efc_margin[lane]);
-      S.efc_aref[lane] = aref;
+      aref = -S.U[U_EB + lane] * jv0 - S.U[U_EK + lane] * S.U[U_EIMP + lane] * (S.U[U_EPOS + lane] - S.U[U_EMARGIN + lane]);
       D = S.efc_D[lane];
     }
   }
   SYNC();
+  // factor M (copy in H), qacc_smooth
+  for (int it = lane; it < nv * LDV; it += 64) S.U[U_H + it] = S.M[it];
+  SYNC();
+  const double as = chol_solve_inplace(S.U + U_H, nv, lane, fs);
 
+  PROF_MARK(6);
   double qacc = as, fcon = 0;  // lane = dof
   if (nefc > 0) {
     // ------------------------------------------------------------ primal Newton (engine_solver.c)
@@ -904,7 +961,7 @@ __device__ __noinline__ void substep(const HModel& m, Lds& S, int lane, int flag
       if (lane < nv) c += 0.5 * (Ma - fs) * (qacc - as);
       oldcost = cost;
       cost = wave_sum(c);
-      if (lane < NE) { S.evec[lane] = force; S.efc_force[lane] = force; S.efc_aref[lane] = active ? D : 0.0; }  // efc_aref reused: D_active
+      if (lane < NE) { S.evec[lane] = force; S.efc_force[lane] = force; S.dact[lane] = active ? D : 0.0; }
       SYNC();
       double grad = 0;
       fcon = 0;
@@ -912,12 +969,12 @@ __device__ __noinline__ void substep(const HModel& m, Lds& S, int lane, int flag
         double f0 = 0, f1 = 0, f2 = 0, f3 = 0;
         int r = 0;
         for (; r + 3 < nefc; r += 4) {
-          f0 += S.J[r * LDV + lane] * S.evec[r];
-          f1 += S.J[(r + 1) * LDV + lane] * S.evec[r + 1];
-          f2 += S.J[(r + 2) * LDV + lane] * S.evec[r + 2];
-          f3 += S.J[(r + 3) * LDV + lane] * S.evec[r + 3];
+          f0 += S.U[U_J + r * LDV + lane] * S.evec[r];
+          f1 += S.U[U_J + (r + 1) * LDV + lane] * S.evec[r + 1];
+          f2 += S.U[U_J + (r + 2) * LDV + lane] * S.evec[r + 2];
+          f3 += S.U[U_J + (r + 3) * LDV + lane] * S.evec[r + 3];
         }
-        for (; r < nefc; r++) f0 += S.J[r * LDV + lane] * S.evec[r];
+        for (; r < nefc; r++) f0 += S.U[U_J + r * LDV + lane] * S.evec[r];
         fcon = (f0 + f1) + (f2 + f3);
         grad = Ma - fs - fcon;
       }
@@ -934,14 +991,14 @@ __device__ __noinline__ void substep(const HModel& m, Lds& S, int lane, int flag
         double h0 = S.M[i * LDV + j], h1 = 0;
         int r = 0;
         for (; r + 1 < nefc; r += 2) {
-          h0 += S.efc_aref[r] * S.J[r * LDV + i] * S.J[r * LDV + j];
-          h1 += S.efc_aref[r + 1] * S.J[(r + 1) * LDV + i] * S.J[(r + 1) * LDV + j];
+          h0 += S.dact[r] * S.U[U_J + r * LDV + i] * S.U[U_J + r * LDV + j];
+          h1 += S.dact[r + 1] * S.U[U_J + (r + 1) * LDV + i] * S.U[U_J + (r + 1) * LDV + j];
         }
-        if (r < nefc) h0 += S.efc_aref[r] * S.J[r * LDV + i] * S.J[r * LDV + j];
-        S.H[i * LDV + j] = h0 + h1;
+        if (r < nefc) h0 += S.dact[r] * S.U[U_J + r * LDV + i] * S.U[U_J + r * LDV + j];
+        S.U[U_H + i * LDV + j] = h0 + h1;
       }
       SYNC();
-      const double search = -chol_solve_inplace(S.H, nv, lane, grad);
+      const double search = -chol_solve_inplace(S.U + U_H, nv, lane, grad);
       if (lane < nv) S.vec2[lane] = search;
       SYNC();
       const double jv = row_dot(Jrow, S.vec2, nv), Mv = row_dot(Mrow, S.vec2, nv);
@@ -976,20 +1033,21 @@ __device__ __noinline__ void substep(const HModel& m, Lds& S, int lane, int flag
   } else if (lane < NE) {
     S.efc_force[lane] = 0;
   }
-  if (lane < nv) { S.qacc[lane] = qacc; S.qfrc_constraint[lane] = fcon; }
+  if (lane < nv) S.qacc[lane] = qacc;
   *warm = qacc;  // mj_fwdConstraint: next warm start
   SYNC();
+  PROF_MARK(7);
   if (!(flags & 2)) return;
   // ------------------------------------------------------------ mj_Euler (implicit joint damping) + mj_advance
   double anew = qacc;
   const double h = m.timestep;
   const bool eulerdamp = !(m.disableflags & (1 << 14));
   if (eulerdamp) {
-    for (int it = lane; it < nv * LDV; it += 64) S.H[it] = S.M[it];
+    for (int it = lane; it < nv * LDV; it += 64) S.U[U_H + it] = S.M[it];
     SYNC();
-    if (lane < nv) S.H[lane * LDV + lane] += h * m.dof_damping[lane];
+    if (lane < nv) S.U[U_H + lane * LDV + lane] += h * m.dof_damping[lane];
     SYNC();
-    anew = chol_solve_inplace(S.H, nv, lane, fs + fcon);
+    anew = chol_solve_inplace(S.U + U_H, nv, lane, fs + fcon);
   }
   if (lane < nv) S.qvel[lane] = qv + h * anew;
   SYNC();
@@ -1009,6 +1067,7 @@ __device__ __noinline__ void substep(const HModel& m, Lds& S, int lane, int flag
     }
   }
   SYNC();
+  PROF_MARK(8);
 }
 
 // ------------------------------------------------------------------------------------------------ task layer
@@ -1053,15 +1112,15 @@ __device__ void write_obs(const HModel& m, const HParams& p, Lds& S, int lane, i
 }
 
 // mj_objectVelocity(mjOBJ_XBODY): linear velocity of the body-frame origin, world orientation
-__device__ __forceinline__ void body_linvel(const Lds& S, int b, double* lin) {
-  const double* cv = &S.cvel[6 * b];
+__device__ __forceinline__ void body_linvel(const Lds& S, int slot /* 0 root, 1 right foot, 2 left foot */, int b, double* lin) {
+  const double* cv = &S.svel[6 * slot];
   double dif[3] = {S.xpos[3 * b] - S.com[0], S.xpos[3 * b + 1] - S.com[1], S.xpos[3 * b + 2] - S.com[2]}, t[3];
   cross3(t, dif, cv);
   lin[0] = cv[3] - t[0]; lin[1] = cv[4] - t[1]; lin[2] = cv[5] - t[2];
 }
 
 template <int MODE>  // 0 step, 1 reset(mask), 2 set_state, 3 get_state
-__global__ void __launch_bounds__(64) humanoid_kernel(HModel m, HParams p, HState st, const float* __restrict__ act,
+__global__ void __launch_bounds__(64, 2) humanoid_kernel(HModel m, HParams p, HState st, const float* __restrict__ act,
                                                       float* __restrict__ obs, float* __restrict__ term_obs,
                                                       float* __restrict__ rew, unsigned char* __restrict__ done_out,
                                                       float* __restrict__ rew_terms, const unsigned char* __restrict__ mask,
@@ -1072,6 +1131,9 @@ __global__ void __launch_bounds__(64) humanoid_kernel(HModel m, HParams p, HStat
   double* rec = st.rec + (size_t)env * REC_D;
   int* irec = st.irec + (size_t)env * REC_I;
   const unsigned genv = p.env_id_base + env;
+  long long* sprof = (env == 0) ? st.prof : nullptr;
+  long long* st_prof = sprof;
+  PROF_BEGIN();
   if (MODE == 3) {
     if (lane < m.nq) xq[(size_t)env * m.nq + lane] = rec[R_QPOS + lane];
     if (lane < m.nv) xv[(size_t)env * m.nv + lane] = rec[R_QVEL + lane];
@@ -1097,7 +1159,7 @@ __global__ void __launch_bounds__(64) humanoid_kernel(HModel m, HParams p, HStat
     if (lane < m.nq) S.qpos[lane] = xq[(size_t)env * m.nq + lane];
     if (lane < m.nv) S.qvel[lane] = xv[(size_t)env * m.nv + lane];
     SYNC();
-    substep(m, S, lane, 0, &warm);  // set_state: mj_forward with actuation disabled
+    substep(m, S, lane, 0, &warm, sprof);  // set_state: mj_forward with actuation disabled
   }
   if (MODE == 0) {
     // ---- BaseHumanoidEnv.step: smoothing, offsets (base_humanoid_env.py:209-215); RobotBase.step (robot_base.py:64-98)
@@ -1114,8 +1176,9 @@ __global__ void __launch_bounds__(64) humanoid_kernel(HModel m, HParams p, HStat
         S.ctrl[lane] = tau / m.actuator_gear[lane];
       }
       SYNC();
-      substep(m, S, lane, 3, &warm);
+      substep(m, S, lane, 3, &warm, sprof);
     }
+    PROF_MARK(9);  // control-step prologue (load, PD) is folded into slot 9 with the sub-step loop overheads
     // ---- WalkingTask.step (walking_task.py:149-170)
     phase += 1;
     if (phase >= p.period) phase = 0;
@@ -1172,8 +1235,8 @@ __global__ void __launch_bounds__(64) humanoid_kernel(HModel m, HParams p, HStat
     double r_sum = 0, terms[10];
     {
       double lv[3], rv[3], rl[3], vloc[3];
-      body_linvel(S, p.lfoot_body, lv); body_linvel(S, p.rfoot_body, rv); body_linvel(S, p.root_body, rl);
-      matT_vec(vloc, &S.xmat[9 * p.root_body], rl);
+      body_linvel(S, 2, p.lfoot_body, lv); body_linvel(S, 1, p.rfoot_body, rv); body_linvel(S, 0, p.root_body, rl);
+      matT_vec(vloc, S.rootmat, rl);
       double rf = p.clock_lut[0 * p.period + phase], rvc = p.clock_lut[1 * p.period + phase];
       double lf = p.clock_lut[2 * p.period + phase], lvc = p.clock_lut[3 * p.period + phase];
       if (mode == MODE_STANDING) { rf = 1; lf = 1; rvc = -1; lvc = -1; }
@@ -1233,8 +1296,8 @@ __global__ void __launch_bounds__(64) humanoid_kernel(HModel m, HParams p, HStat
     if (lane < m.nu) S.ctrl[lane] = 0;
     warm = 0;
     SYNC();
-    substep(m, S, lane, 0, &warm);                           // set_state: forward, actuation disabled
-    for (int k = 0; k < 3; k++) substep(m, S, lane, 3, &warm);  // three settle steps, ctrl = 0
+    substep(m, S, lane, 0, &warm, sprof);                           // set_state: forward, actuation disabled
+    for (int k = 0; k < 3; k++) substep(m, S, lane, 3, &warm, sprof);  // three settle steps, ctrl = 0
     // WalkingTask.reset (walking_task.py:194-205): slot 0 mode, 1..3 mode_ref, 4 phase
     const double u = lhw_rng_u01(p.seed, genv, LHW_STREAM_RESET, reset_count, 0);
     mode = u < 0.6 ? MODE_STANDING : (u < 0.8 ? MODE_INPLACE : MODE_FORWARD);
@@ -1246,6 +1309,7 @@ __global__ void __launch_bounds__(64) humanoid_kernel(HModel m, HParams p, HStat
     prevpred = 0;
     if (obs) write_obs(m, p, S, lane, phase, mode, mode_ref, obs + (size_t)env * 37);
   }
+  PROF_MARK(10);
   // ---- store the record
   SYNC();
   if (lane < m.nq) rec[R_QPOS + lane] = S.qpos[lane];
@@ -1367,6 +1431,8 @@ int humanoid_create(HumanoidEnv** out, const std::vector<int32_t>& mi, const std
   }
   for (int u = 0; u < nu; u++) actdof[u] = jdof[IF(LHW_IF_ACTUATOR_TRNID)[u]];
   m.nlevel = nlevel; m.nmpair = (int)mpi.size();
+  m.track_body[0] = cfg->task_iparams[LHW_TI_ROOT_BODY]; m.track_body[1] = cfg->task_iparams[LHW_TI_RFOOT_BODY];
+  m.track_body[2] = cfg->task_iparams[LHW_TI_LFOOT_BODY];
   ok = ok && (m.body_level = to_dev<int>(h, level.data(), nb)) && (m.body_subend = to_dev<int>(h, subend.data(), nb)) &&
        (m.mpair_i = to_dev<int>(h, mpi.data(), mpi.size())) && (m.mpair_j = to_dev<int>(h, mpj.data(), mpj.size())) &&
        (m.act_dof = to_dev<int>(h, actdof.data(), nu)) && (m.body_dofmask = to_dev<unsigned>(h, bmask.data(), nb)) &&
@@ -1394,7 +1460,7 @@ int humanoid_create(HumanoidEnv** out, const std::vector<int32_t>& mi, const std
   if (rec) h->dev_allocs.push_back(rec);
   if (irec) h->dev_allocs.push_back(irec);
   if (eps) h->dev_allocs.push_back(eps);
-  h->st.rec = (double*)rec; h->st.irec = (int*)irec; h->st.ep_stats = (double*)eps;
+  h->st.rec = (double*)rec; h->st.irec = (int*)irec; h->st.ep_stats = (double*)eps; h->st.prof = nullptr;
   if (!ok) { humanoid_destroy(h); return lhw_fail(LHW_ERR_HIP, "humanoid_create: device allocation failed or bad body ids"); }
   *obs_dim = 37; *act_dim = 12; *n_terms = 10;
   *out = h;
@@ -1426,4 +1492,24 @@ void humanoid_set_state(HumanoidEnv* h, const double* qpos, const double* qvel, 
                      const_cast<double*>(qpos), const_cast<double*>(qvel));
 }
 double* humanoid_ep_stats(HumanoidEnv* h) { return h->st.ep_stats; }
+int humanoid_occupancy() {
+  int nb = -1;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, humanoid_kernel<0>, 64, 0) != hipSuccess) return -1;
+  return nb;
+}
+int humanoid_profile(HumanoidEnv* h, int enable, long long* out16) {
+  if (enable && !h->st.prof) {
+    void* d = nullptr;
+    if (hipMalloc(&d, 16 * sizeof(long long)) != hipSuccess) return -1;
+    (void)hipMemset(d, 0, 16 * sizeof(long long));
+    h->dev_allocs.push_back(d);
+    h->st.prof = (long long*)d;
+  }
+  if (out16 && h->st.prof) {
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpy(out16, h->st.prof, 16 * sizeof(long long), hipMemcpyDeviceToHost);
+    (void)hipMemset(h->st.prof, 0, 16 * sizeof(long long));
+  }
+  return 0;
+}
 void humanoid_set_iteration(HumanoidEnv*, int64_t) {}  // the walking task has no curriculum input (stepping task does)

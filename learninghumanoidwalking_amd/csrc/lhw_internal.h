@@ -20,3 +20,5 @@ void humanoid_get_state(HumanoidEnv* h, double* qpos, double* qvel, hipStream_t 
 void humanoid_set_state(HumanoidEnv* h, const double* qpos, const double* qvel, hipStream_t s);
 double* humanoid_ep_stats(HumanoidEnv* h);
 void humanoid_set_iteration(HumanoidEnv* h, int64_t it);
+int humanoid_occupancy();
+int humanoid_profile(HumanoidEnv* h, int enable, long long* out16);

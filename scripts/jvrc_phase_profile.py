@@ -1,0 +1,25 @@
+"""Per-phase cycle breakdown of the wave-per-env stepper (env 0) under full load (4096 envs)."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from learninghumanoidwalking_amd.envs.jvrc_walk import JvrcWalkSpec
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+spec = JvrcWalkSpec()
+env = spec.make_batched(N, seed=1, device=0, max_traj_len=400)
+env.reset()
+act = torch.randn(N, 12, device="cuda") * 0.1
+for _ in range(3): env.step(act)
+env.phase_cycles(True)
+steps = 10
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(steps): env.step(act)
+e1.record(); torch.cuda.synchronize()
+c = env.phase_cycles(True)
+from learninghumanoidwalking_amd import _lib
+print("occupancy blocks/CU (runtime query):", _lib.lib().lhw_debug_stepper_occupancy())
+names = ["kinematics", "com/cdof", "crba", "collision", "constraints", "velocity/rne", "smooth solve", "newton", "euler", "prologue", "task/reward"]
+tot = c[:11].sum()
+print(f"N={N} ms/step {e0.elapsed_time(e1)/steps:.3f}  env0 cycles/control-step {tot/steps:.0f}  per sub-step {tot/steps/25:.0f}")
+for n, v in zip(names, c[:11]): print(f"  {n:14s} {v/steps/25:9.0f} cyc/substep  {100*v/tot:5.1f}%")
