@@ -130,7 +130,9 @@ int lhw_env_pop_episode_stats(LhwEnv* env, double* ret_sum, double* len_sum, int
 int lhw_env_set_iteration(LhwEnv* env, int64_t iteration);
 /* Diagnostic: shader-clock cycles env 0 spent in each phase of the wave-per-env stepper since the last call
  * (slots: 0 kinematics, 1 com/cdof, 2 CRBA, 3 collision, 4 constraint rows, 5 velocity/RNE, 6 smooth solve,
- * 7 Newton, 8 Euler, 9 control-step prologue, 10 task/reward/reset).  enable != 0 turns the counters on. */
+ * 7 Newton, 8 Euler tail (integration), 9 whole control step incl. the above, 10 task/reward/reset,
+ * 11 actuation + row loads + reference acceleration, 12 factor/solve of M, 13 factor/solve of M + h*damping).
+ * enable != 0 turns the counters on. */
 int lhw_env_phase_cycles(LhwEnv* env, int enable, int64_t* out16);
 /* Diagnostic: resident workgroups per CU the HIP runtime reports for the wave-per-env step kernel. */
 int lhw_debug_stepper_occupancy(void);

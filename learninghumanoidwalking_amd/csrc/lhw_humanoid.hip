@@ -72,24 +72,68 @@ static_assert(R_EPRET < REC_D, "record too small");
 #define RI_STARTED 5  // prev_action / prev_torque initialised (robot_base.py:82-85: only once, never reset)
 #define REC_I 8
 
+// Model constants, packed host-side into one array-of-structs table per "lane role" (body, joint, dof, geom, pair,
+// actuator): a lane fetches the record of its body/dof/... with one burst of independent loads, and the kernel argument
+// block carries a dozen base pointers instead of seventy (the latter spilled most of the SGPR file).
+#define BDS 28  // body_d: pos3 quat4 ipos3 iquat4 inertia3 jnt_axis3 jnt_pos3 qpos0(joint) | mass invweight0[2] pad
+#define BD_MASS 24
+#define BD_INVW 25
+#define BIS 8   // body_i: parent level jnt_type(-1 welded) qposadr | rootid subtree_end dofmask jntadr
+#define BI_ROOT 4
+#define BI_SUBEND 5
+#define BI_DOFMASK 6
+#define BI_JNTADR 7
+#define BI_LEVEL 1
+#define JDS 10  // jnt_d: range2 solref2 solimp5 margin
+#define JD_RANGE 0
+#define JD_SOLREF 2
+#define JD_SOLIMP 4
+#define JD_MARGIN 9
+#define JIS 4   // jnt_i: type limited qposadr dofadr
+#define JI_TYPE 0
+#define JI_LIMITED 1
+#define JI_QADR 2
+#define JI_DADR 3
+#define DDS 4   // dof_d: armature damping invweight0 pad
+#define DD_ARMATURE 0
+#define DD_DAMPING 1
+#define DD_INVW 2
+#define DIS 4   // dof_i: body joint kind(0 free-trans 1 free-rot 2 slide 3 hinge) prevmask
+#define DI_BODY 0
+#define DI_JNT 1
+#define DI_KIND 2
+#define DI_PREVMASK 3
+#define GDS 23  // geom_d: pos3 quat4 size3 friction3 solmix solref2 solimp5 margin gap
+#define GD_POS 0
+#define GD_QUAT 3
+#define GD_SIZE 7
+#define GD_FRICTION 10
+#define GD_SOLMIX 13
+#define GD_SOLREF 14
+#define GD_SOLIMP 16
+#define GD_MARGIN 21
+#define GD_GAP 22
+#define GIS 4   // geom_i: type body condim priority
+#define GI_TYPE 0
+#define GI_BODY 1
+#define GI_CONDIM 2
+#define GI_PRIORITY 3
+#define ADS 6   // act_d: gear ctrlrange2 forcerange2 pad
+#define AD_GEAR 0
+#define AD_CTRLRANGE 1
+#define AD_FORCERANGE 3
+#define AIS 4   // act_i: dof joint ctrllimited forcelimited
+#define AI_DOF 0
+#define AI_JNT 1
+#define AI_CTRLLIMITED 2
+#define AI_FORCELIMITED 3
+
 struct HModel {
   int nq, nv, nu, nbody, njnt, ngeom, npair, nlevel, nmpair, iterations, disableflags;
   double timestep, gravity[3], tolerance, meaninertia, totalmass;
-  const int *body_parentid, *body_rootid, *body_jntadr, *body_jntnum, *body_dofadr, *body_dofnum, *body_weldid;
-  const double *body_pos, *body_quat, *body_ipos, *body_iquat, *body_mass, *body_inertia, *body_invweight0;
-  const int *jnt_type, *jnt_bodyid, *jnt_qposadr, *jnt_dofadr, *jnt_limited;
-  const double *jnt_pos, *jnt_axis, *jnt_range, *jnt_solref, *jnt_solimp, *jnt_margin;
-  const int *dof_bodyid, *dof_jntid;
-  const double *dof_armature, *dof_damping, *dof_invweight0, *qpos0;
-  const int *geom_type, *geom_bodyid, *geom_condim, *geom_priority;
-  const double *geom_pos, *geom_quat, *geom_size, *geom_friction, *geom_solmix, *geom_solref, *geom_solimp, *geom_margin, *geom_gap;
-  const int *pair_geom1, *pair_geom2;
-  const int *actuator_trnid, *actuator_ctrllimited, *actuator_forcelimited;
-  const double *actuator_gear, *actuator_ctrlrange, *actuator_forcerange;
-  // derived tables (host-built)
-  const int *body_level, *body_subend, *mpair_i, *mpair_j, *act_dof;
-  const unsigned *body_dofmask, *dof_prevmask;
-  int track_body[3];  // bodies whose spatial velocity must survive the sub-step (task reads them afterwards)
+  const double *body_d, *jnt_d, *dof_d, *geom_d, *act_d;
+  const int *body_i, *jnt_i, *dof_i, *geom_i, *act_i, *pair_i, *mpair;
+  int track_body[3];  // bodies whose spatial velocity must survive the sub-step (the task reads them afterwards)
 };
 
 struct HParams {
@@ -296,7 +340,9 @@ __device__ double chol_solve_inplace(double* A, int n, int lane, double x) {
       if (j & 1) s0 -= r[j - 1] * bcast(r[j - 1], j);
       const double s = s0 + s1;
       const double piv = fmax(bcast(s, j), HMINVAL);
-      const double id = rsqrt(piv);
+      double id = __builtin_amdgcn_rsq(piv);
+      id = id * (1.5 - 0.5 * piv * id * id);
+      id = id * (1.5 - 0.5 * piv * id * id);
       invd[j] = id;
       r[j] = (lane == j) ? piv * id : s * id;
     } else invd[j] = 0.0;
@@ -347,68 +393,77 @@ __device__ void fwd_kinematics(const HModel& m, Lds& S, int lane) {
     for (int k = 0; k < 9; k++) S.U[U_XMAT + k] = (k % 4 == 0) ? 1.0 : 0.0;
     S.U[U_XIPOS + 0] = S.U[U_XIPOS + 1] = S.U[U_XIPOS + 2] = 0;
   }
+  // every lane fetches the constants of "its" body up front (bodies carry at most one joint: checked at create)
+  const int b = lane;
+  const bool valid = b >= 1 && b < m.nbody;
+  double kd[24];
+  int par = 0, mylvl = -1, jt = -1, qa = 0;
+  if (valid) {
+#pragma unroll
+    for (int k = 0; k < 24; k++) kd[k] = m.body_d[BDS * b + k];
+    par = m.body_i[BIS * b]; mylvl = m.body_i[BIS * b + 1]; jt = m.body_i[BIS * b + 2]; qa = m.body_i[BIS * b + 3];
+  }
+  const int ja = valid ? m.body_i[BIS * (b) + BI_JNTADR] : 0;
+  double qj = 0, sn = 0, cs = 1;
+  if (valid && (jt == JT_HINGE || jt == JT_SLIDE)) {
+    qj = S.qpos[qa] - kd[23];
+    if (jt == JT_HINGE) sincos(0.5 * qj, &sn, &cs);  // joint rotation quaternion needs no parent data: off the serial chain
+  }
   SYNC();
   for (int lvl = 1; lvl < m.nlevel; lvl++) {
-    const int b = lane;
-    if (b < m.nbody && m.body_level[b] == lvl) {
-      const int par = m.body_parentid[b], jn = m.body_jntnum[b], ja = m.body_jntadr[b];
+    if (mylvl == lvl) {
       double xp[3], xq[4], R[9];
-      if (jn == 1 && m.jnt_type[ja] == JT_FREE) {
-        const int qa = m.jnt_qposadr[ja];
+      if (jt == JT_FREE) {
         double q[4] = {S.qpos[qa + 3], S.qpos[qa + 4], S.qpos[qa + 5], S.qpos[qa + 6]};
         normalize4(q);
         for (int k = 0; k < 4; k++) { S.qpos[qa + 3 + k] = q[k]; xq[k] = q[k]; }
-        for (int k = 0; k < 3; k++) { xp[k] = S.qpos[qa + k]; S.U[U_XANCHOR + 3 * ja + k] = xp[k]; S.U[U_XAXIS + 3 * ja + k] = m.jnt_axis[3 * ja + k]; }
+        for (int k = 0; k < 3; k++) { xp[k] = S.qpos[qa + k]; S.U[U_XANCHOR + 3 * ja + k] = xp[k]; S.U[U_XAXIS + 3 * ja + k] = kd[17 + k]; }
       } else {
-        double t[3], bp[3] = {m.body_pos[3 * b], m.body_pos[3 * b + 1], m.body_pos[3 * b + 2]};
-        double bq[4] = {m.body_quat[4 * b], m.body_quat[4 * b + 1], m.body_quat[4 * b + 2], m.body_quat[4 * b + 3]};
+        double t[3];
         double pq[4] = {S.U[U_XQUAT + 4 * par], S.U[U_XQUAT + 4 * par + 1], S.U[U_XQUAT + 4 * par + 2], S.U[U_XQUAT + 4 * par + 3]};
-        mat_vec(t, &S.U[U_XMAT + 9 * par], bp);
+        mat_vec(t, &S.U[U_XMAT + 9 * par], kd);
         for (int k = 0; k < 3; k++) xp[k] = S.xpos[3 * par + k] + t[k];
-        mul_quat(xq, pq, bq);
-        for (int jj = 0; jj < jn; jj++) {
-          const int j = ja + jj;
-          double ax[3] = {m.jnt_axis[3 * j], m.jnt_axis[3 * j + 1], m.jnt_axis[3 * j + 2]};
-          double jp[3] = {m.jnt_pos[3 * j], m.jnt_pos[3 * j + 1], m.jnt_pos[3 * j + 2]};
+        mul_quat(xq, pq, kd + 3);
+        if (jt >= 0) {
           double waxis[3], anchor[3];
           quat2mat(R, xq);
-          mat_vec(waxis, R, ax);
-          mat_vec(anchor, R, jp);
-          for (int k = 0; k < 3; k++) { anchor[k] += xp[k]; S.U[U_XANCHOR + 3 * j + k] = anchor[k]; S.U[U_XAXIS + 3 * j + k] = waxis[k]; }
-          const double q = S.qpos[m.jnt_qposadr[j]] - m.qpos0[m.jnt_qposadr[j]];
-          if (m.jnt_type[j] == JT_SLIDE) {
-            for (int k = 0; k < 3; k++) xp[k] += waxis[k] * q;
+          mat_vec(waxis, R, kd + 17);
+          mat_vec(anchor, R, kd + 20);
+          for (int k = 0; k < 3; k++) { anchor[k] += xp[k]; S.U[U_XANCHOR + 3 * ja + k] = anchor[k]; S.U[U_XAXIS + 3 * ja + k] = waxis[k]; }
+          if (jt == JT_SLIDE) {
+            for (int k = 0; k < 3; k++) xp[k] += waxis[k] * qj;
           } else {
-            double ql[4], v[3];
-            axis_angle_quat(ql, ax, q);
+            double ql[4] = {cs, kd[17] * sn, kd[18] * sn, kd[19] * sn}, v[3];
             mul_quat(xq, xq, ql);
             quat2mat(R, xq);
-            mat_vec(v, R, jp);
+            mat_vec(v, R, kd + 20);
             for (int k = 0; k < 3; k++) xp[k] = anchor[k] - v[k];
           }
         }
       }
       normalize4(xq);
       quat2mat(R, xq);
-      double ip[3] = {m.body_ipos[3 * b], m.body_ipos[3 * b + 1], m.body_ipos[3 * b + 2]}, t[3];
-      mat_vec(t, R, ip);
+      double t[3];
+      mat_vec(t, R, kd + 7);
       for (int k = 0; k < 3; k++) { S.xpos[3 * b + k] = xp[k]; S.U[U_XIPOS + 3 * b + k] = xp[k] + t[k]; }
       for (int k = 0; k < 4; k++) S.U[U_XQUAT + 4 * b + k] = xq[k];
       for (int k = 0; k < 9; k++) S.U[U_XMAT + 9 * b + k] = R[k];
-      // rotated inertia T = Ri diag(I) Ri^T of the body (completed with the com offset in fwd_com)
-      double iq[4] = {m.body_iquat[4 * b], m.body_iquat[4 * b + 1], m.body_iquat[4 * b + 2], m.body_iquat[4 * b + 3]}, qi[4], Ri[9];
-      mul_quat(qi, xq, iq);
-      quat2mat(Ri, qi);
-      const double I0 = m.body_inertia[3 * b], I1 = m.body_inertia[3 * b + 1], I2 = m.body_inertia[3 * b + 2];
-      double* ci = &S.U[U_CINERT + 10 * b];
-      ci[0] = Ri[0] * I0 * Ri[0] + Ri[1] * I1 * Ri[1] + Ri[2] * I2 * Ri[2];
-      ci[1] = Ri[3] * I0 * Ri[3] + Ri[4] * I1 * Ri[4] + Ri[5] * I2 * Ri[5];
-      ci[2] = Ri[6] * I0 * Ri[6] + Ri[7] * I1 * Ri[7] + Ri[8] * I2 * Ri[8];
-      ci[3] = Ri[0] * I0 * Ri[3] + Ri[1] * I1 * Ri[4] + Ri[2] * I2 * Ri[5];
-      ci[4] = Ri[0] * I0 * Ri[6] + Ri[1] * I1 * Ri[7] + Ri[2] * I2 * Ri[8];
-      ci[5] = Ri[3] * I0 * Ri[6] + Ri[4] * I1 * Ri[7] + Ri[5] * I2 * Ri[8];
     }
     SYNC();
+  }
+  // rotated inertia T = Ri diag(I) Ri^T of each body (completed with the com offset in fwd_com): all bodies at once
+  if (valid) {
+    double xq[4] = {S.U[U_XQUAT + 4 * b], S.U[U_XQUAT + 4 * b + 1], S.U[U_XQUAT + 4 * b + 2], S.U[U_XQUAT + 4 * b + 3]}, qi[4], Ri[9];
+    mul_quat(qi, xq, kd + 10);
+    quat2mat(Ri, qi);
+    const double I0 = kd[14], I1 = kd[15], I2 = kd[16];
+    double* ci = &S.U[U_CINERT + 10 * b];
+    ci[0] = Ri[0] * I0 * Ri[0] + Ri[1] * I1 * Ri[1] + Ri[2] * I2 * Ri[2];
+    ci[1] = Ri[3] * I0 * Ri[3] + Ri[4] * I1 * Ri[4] + Ri[5] * I2 * Ri[5];
+    ci[2] = Ri[6] * I0 * Ri[6] + Ri[7] * I1 * Ri[7] + Ri[8] * I2 * Ri[8];
+    ci[3] = Ri[0] * I0 * Ri[3] + Ri[1] * I1 * Ri[4] + Ri[2] * I2 * Ri[5];
+    ci[4] = Ri[0] * I0 * Ri[6] + Ri[1] * I1 * Ri[7] + Ri[2] * I2 * Ri[8];
+    ci[5] = Ri[3] * I0 * Ri[6] + Ri[4] * I1 * Ri[7] + Ri[5] * I2 * Ri[8];
   }
   if (lane < 9) S.rootmat[lane] = S.U[U_XMAT + 9 * 1 + lane];
 }
@@ -416,8 +471,8 @@ __device__ void fwd_kinematics(const HModel& m, Lds& S, int lane) {
 // subtree com of the (single) dynamic tree rooted at body 1, cinert, cdof  (mj_comPos)
 __device__ void fwd_com(const HModel& m, Lds& S, int lane) {
   double ms = 0, mx = 0, my = 0, mz = 0;
-  if (lane >= 1 && lane < m.nbody && m.body_rootid[lane] == 1) {
-    ms = m.body_mass[lane];
+  if (lane >= 1 && lane < m.nbody && m.body_i[BIS * (lane) + BI_ROOT] == 1) {
+    ms = m.body_d[BDS * (lane) + BD_MASS];
     mx = ms * S.U[U_XIPOS + 3 * lane]; my = ms * S.U[U_XIPOS + 3 * lane + 1]; mz = ms * S.U[U_XIPOS + 3 * lane + 2];
   }
   ms = wave_sum(ms); mx = wave_sum(mx); my = wave_sum(my); mz = wave_sum(mz);
@@ -425,9 +480,9 @@ __device__ void fwd_com(const HModel& m, Lds& S, int lane) {
   if (lane == 0) { S.com[0] = com[0]; S.com[1] = com[1]; S.com[2] = com[2]; }
   if (lane >= 1 && lane < m.nbody) {
     const int b = lane;
-    const double mass = m.body_mass[b];
+    const double mass = m.body_d[BDS * (b) + BD_MASS];
     // static bodies (their own root) use their own com as reference; they never enter M or the bias force
-    const bool dyn = m.body_rootid[b] == 1;
+    const bool dyn = m.body_i[BIS * (b) + BI_ROOT] == 1;
     double dif[3];
     for (int k = 0; k < 3; k++) dif[k] = dyn ? S.U[U_XIPOS + 3 * b + k] - com[k] : 0.0;
     double* ci = &S.U[U_CINERT + 10 * b];
@@ -440,7 +495,8 @@ __device__ void fwd_com(const HModel& m, Lds& S, int lane) {
     ci[6] = mass * dif[0]; ci[7] = mass * dif[1]; ci[8] = mass * dif[2]; ci[9] = mass;
   }
   if (lane < m.nv) {
-    const int d = lane, j = m.dof_jntid[d], b = m.dof_bodyid[d], t = m.jnt_type[j], k = d - m.jnt_dofadr[j];
+    const int d = lane, j = m.dof_i[DIS * (d) + DI_JNT], b = m.dof_i[DIS * (d) + DI_BODY], kind = m.dof_i[DIS * (d) + DI_KIND];
+    const int t = kind <= 1 ? JT_FREE : (kind == 2 ? JT_SLIDE : JT_HINGE), k = d - m.jnt_i[JIS * (j) + JI_DADR];
     double off[3], ax[3], c[6];
     for (int a = 0; a < 3; a++) off[a] = com[a] - S.U[U_XANCHOR + 3 * j + a];
     if (t == JT_FREE && k < 3) {
@@ -465,7 +521,7 @@ __device__ void fwd_crb(const HModel& m, Lds& S, int lane) {
   for (int it = lane; it < m.nbody * 10; it += 64) {
     const int b = it / 10, k = it - 10 * b;
     double s = 0;
-    if (b >= 1) for (int d = b; d < m.body_subend[b]; d++) s += S.U[U_CINERT + 10 * d + k];
+    if (b >= 1) for (int d = b; d < m.body_i[BIS * (b) + BI_SUBEND]; d++) s += S.U[U_CINERT + 10 * d + k];
     S.U[U_CRB + it] = s;
   }
   for (int it = lane; it < m.nv * LDV; it += 64) S.M[it] = 0;
@@ -473,15 +529,15 @@ __device__ void fwd_crb(const HModel& m, Lds& S, int lane) {
   // vec scratch: buf_i = crb[body(i)] * cdof_i  kept in csub (6 per dof)
   if (lane < m.nv) {
     double buf[6];
-    inert_vec(buf, &S.U[U_CRB + 10 * m.dof_bodyid[lane]], &S.cdof[6 * lane]);
+    inert_vec(buf, &S.U[U_CRB + 10 * m.dof_i[DIS * (lane) + DI_BODY]], &S.cdof[6 * lane]);
     for (int a = 0; a < 6; a++) S.U[U_CSUB + 6 * lane + a] = buf[a];
   }
   SYNC();
   for (int it = lane; it < m.nmpair; it += 64) {
-    const int i = m.mpair_i[it], j = m.mpair_j[it];
+    const int i = m.mpair[2 * (it) + 0], j = m.mpair[2 * (it) + 1];
     double s = 0;
     for (int a = 0; a < 6; a++) s += S.cdof[6 * j + a] * S.U[U_CSUB + 6 * i + a];
-    if (i == j) s += m.dof_armature[i];
+    if (i == j) s += m.dof_d[DDS * (i) + DD_ARMATURE];
     S.M[i * LDV + j] = s;
     S.M[j * LDV + i] = s;
   }
@@ -541,9 +597,9 @@ __device__ __forceinline__ void col_sphere_sphere(ConSink& k, const double* p1, 
 }
 __device__ void collide_pair(ConSink& k, const HModel& m, const Lds& S, int g1, int g2, double margin) {
   const double zero[3] = {0, 0, 0};
-  const int t1 = m.geom_type[g1], t2 = m.geom_type[g2];
+  const int t1 = m.geom_i[GIS * (g1) + GI_TYPE], t2 = m.geom_i[GIS * (g2) + GI_TYPE];
   double p1[3], p2[3], R1[9], R2[9], s1[3], s2[3];
-  for (int a = 0; a < 3; a++) { p1[a] = S.U[U_GPOS + 3 * g1 + a]; p2[a] = S.U[U_GPOS + 3 * g2 + a]; s1[a] = m.geom_size[3 * g1 + a]; s2[a] = m.geom_size[3 * g2 + a]; }
+  for (int a = 0; a < 3; a++) { p1[a] = S.U[U_GPOS + 3 * g1 + a]; p2[a] = S.U[U_GPOS + 3 * g2 + a]; s1[a] = m.geom_d[GDS * (g1) + GD_SIZE + a]; s2[a] = m.geom_d[GDS * (g2) + GD_SIZE + a]; }
   for (int a = 0; a < 9; a++) { R1[a] = S.U[U_GMAT + 9 * g1 + a]; R2[a] = S.U[U_GMAT + 9 * g2 + a]; }
   if (t1 == G_PLANE && t2 == G_SPHERE) col_plane_sphere(k, p1, R1, p2, s2[0], margin, zero);
   else if (t1 == G_PLANE && t2 == G_CAPSULE) {
@@ -610,9 +666,9 @@ __device__ void collide_pair(ConSink& k, const HModel& m, const Lds& S, int g1, 
 
 __device__ void fwd_collision(const HModel& m, Lds& S, int lane) {
   if (lane < m.ngeom) {
-    const int g = lane, b = m.geom_bodyid[g];
-    double gp[3] = {m.geom_pos[3 * g], m.geom_pos[3 * g + 1], m.geom_pos[3 * g + 2]}, t[3];
-    double gq[4] = {m.geom_quat[4 * g], m.geom_quat[4 * g + 1], m.geom_quat[4 * g + 2], m.geom_quat[4 * g + 3]}, q[4], R[9];
+    const int g = lane, b = m.geom_i[GIS * (g) + GI_BODY];
+    double gp[3] = {m.geom_d[GDS * (g) + GD_POS], m.geom_d[GDS * (g) + GD_POS + 1], m.geom_d[GDS * (g) + GD_POS + 2]}, t[3];
+    double gq[4] = {m.geom_d[GDS * (g) + GD_QUAT], m.geom_d[GDS * (g) + GD_QUAT + 1], m.geom_d[GDS * (g) + GD_QUAT + 2], m.geom_d[GDS * (g) + GD_QUAT + 3]}, q[4], R[9];
     double bq[4] = {S.U[U_XQUAT + 4 * b], S.U[U_XQUAT + 4 * b + 1], S.U[U_XQUAT + 4 * b + 2], S.U[U_XQUAT + 4 * b + 3]};
     mat_vec(t, &S.U[U_XMAT + 9 * b], gp);
     mul_quat(q, bq, gq);
@@ -626,8 +682,8 @@ __device__ void fwd_collision(const HModel& m, Lds& S, int lane) {
   double margin = 0;
   const bool have = lane < m.npair;
   if (have) {
-    g1 = m.pair_geom1[lane]; g2 = m.pair_geom2[lane];
-    margin = fmax(m.geom_margin[g1], m.geom_margin[g2]);
+    g1 = m.pair_i[2 * (lane) + 0]; g2 = m.pair_i[2 * (lane) + 1];
+    margin = fmax(m.geom_d[GDS * (g1) + GD_MARGIN], m.geom_d[GDS * (g2) + GD_MARGIN]);
   }
   ConSink k{&S, 0, 0, 0, g1, g2};
   if (have) collide_pair(k, m, S, g1, g2, margin);
@@ -641,28 +697,28 @@ __device__ void fwd_collision(const HModel& m, Lds& S, int lane) {
   if (lane < S.ncon) {
     const int c = lane;
     g1 = S.con_g1[c]; g2 = S.con_g2[c];
-    const double incm = fmax(m.geom_margin[g1], m.geom_margin[g2]) - fmax(m.geom_gap[g1], m.geom_gap[g2]);
+    const double incm = fmax(m.geom_d[GDS * (g1) + GD_MARGIN], m.geom_d[GDS * (g2) + GD_MARGIN]) - fmax(m.geom_d[GDS * (g1) + GD_GAP], m.geom_d[GDS * (g2) + GD_GAP]);
     int dim;
     double mu, sr[2], si[5];
-    const int pr1 = m.geom_priority[g1], pr2 = m.geom_priority[g2];
+    const int pr1 = m.geom_i[GIS * (g1) + GI_PRIORITY], pr2 = m.geom_i[GIS * (g2) + GI_PRIORITY];
     if (pr1 != pr2) {
       const int g = pr1 > pr2 ? g1 : g2;
-      dim = m.geom_condim[g]; mu = m.geom_friction[3 * g];
-      sr[0] = m.geom_solref[2 * g]; sr[1] = m.geom_solref[2 * g + 1];
-      for (int a = 0; a < 5; a++) si[a] = m.geom_solimp[5 * g + a];
+      dim = m.geom_i[GIS * (g) + GI_CONDIM]; mu = m.geom_d[GDS * (g) + GD_FRICTION];
+      sr[0] = m.geom_d[GDS * (g) + GD_SOLREF]; sr[1] = m.geom_d[GDS * (g) + GD_SOLREF + 1];
+      for (int a = 0; a < 5; a++) si[a] = m.geom_d[GDS * (g) + GD_SOLIMP + a];
     } else {
-      dim = max(m.geom_condim[g1], m.geom_condim[g2]);
-      const double m1 = m.geom_solmix[g1], m2 = m.geom_solmix[g2];
+      dim = max(m.geom_i[GIS * (g1) + GI_CONDIM], m.geom_i[GIS * (g2) + GI_CONDIM]);
+      const double m1 = m.geom_d[GDS * (g1) + GD_SOLMIX], m2 = m.geom_d[GDS * (g2) + GD_SOLMIX];
       double mix;
       if (m1 >= HMINVAL && m2 >= HMINVAL) mix = m1 / (m1 + m2);
       else if (m1 < HMINVAL && m2 < HMINVAL) mix = 0.5;
       else mix = m1 < HMINVAL ? 0.0 : 1.0;
-      if (m.geom_solref[2 * g1] > 0 && m.geom_solref[2 * g2] > 0)
-        for (int a = 0; a < 2; a++) sr[a] = mix * m.geom_solref[2 * g1 + a] + (1 - mix) * m.geom_solref[2 * g2 + a];
+      if (m.geom_d[GDS * (g1) + GD_SOLREF] > 0 && m.geom_d[GDS * (g2) + GD_SOLREF] > 0)
+        for (int a = 0; a < 2; a++) sr[a] = mix * m.geom_d[GDS * (g1) + GD_SOLREF + a] + (1 - mix) * m.geom_d[GDS * (g2) + GD_SOLREF + a];
       else
-        for (int a = 0; a < 2; a++) sr[a] = fmin(m.geom_solref[2 * g1 + a], m.geom_solref[2 * g2 + a]);
-      for (int a = 0; a < 5; a++) si[a] = mix * m.geom_solimp[5 * g1 + a] + (1 - mix) * m.geom_solimp[5 * g2 + a];
-      mu = fmax(m.geom_friction[3 * g1], m.geom_friction[3 * g2]);
+        for (int a = 0; a < 2; a++) sr[a] = fmin(m.geom_d[GDS * (g1) + GD_SOLREF + a], m.geom_d[GDS * (g2) + GD_SOLREF + a]);
+      for (int a = 0; a < 5; a++) si[a] = mix * m.geom_d[GDS * (g1) + GD_SOLIMP + a] + (1 - mix) * m.geom_d[GDS * (g2) + GD_SOLIMP + a];
+      mu = fmax(m.geom_d[GDS * (g1) + GD_FRICTION], m.geom_d[GDS * (g2) + GD_FRICTION]);
     }
     S.con_margin[c] = incm;
     S.con_dim[c] = (S.con_dist[c] >= incm) ? 0 : dim;  // 0: excluded from the constraint set (gap)
@@ -711,9 +767,9 @@ __device__ void fwd_constraints(const HModel& m, Lds& S, int lane) {
   // ---- limits: lane = joint; rows ordered by joint, lower side first
   int nl = 0, lo = 0, hi = 0;
   double dlo = 0, dhi = 0;
-  if (lane < m.njnt && m.jnt_limited[lane] && (m.jnt_type[lane] == JT_HINGE || m.jnt_type[lane] == JT_SLIDE)) {
-    const double q = S.qpos[m.jnt_qposadr[lane]], mg = m.jnt_margin[lane];
-    dlo = q - m.jnt_range[2 * lane]; dhi = m.jnt_range[2 * lane + 1] - q;
+  if (lane < m.njnt && m.jnt_i[JIS * (lane) + JI_LIMITED] && (m.jnt_i[JIS * (lane) + JI_TYPE] == JT_HINGE || m.jnt_i[JIS * (lane) + JI_TYPE] == JT_SLIDE)) {
+    const double q = S.qpos[m.jnt_i[JIS * (lane) + JI_QADR]], mg = m.jnt_d[JDS * (lane) + JD_MARGIN];
+    dlo = q - m.jnt_d[JDS * (lane) + JD_RANGE]; dhi = m.jnt_d[JDS * (lane) + JD_RANGE + 1] - q;
     lo = dlo < mg; hi = dhi < mg;
     nl = lo + hi;
   }
@@ -735,15 +791,15 @@ __device__ void fwd_constraints(const HModel& m, Lds& S, int lane) {
   for (int it = lane; it < nefc * LDV; it += 64) S.U[U_J + it] = 0;
   SYNC();
   if (nl > 0) {
-    const int j = lane, d = m.jnt_dofadr[j];
+    const int j = lane, d = m.jnt_i[JIS * (j) + JI_DADR];
     int r = lbase;
-    double sr[2] = {m.jnt_solref[2 * j], m.jnt_solref[2 * j + 1]}, si[5];
-    for (int a = 0; a < 5; a++) si[a] = m.jnt_solimp[5 * j + a];
+    double sr[2] = {m.jnt_d[JDS * (j) + JD_SOLREF], m.jnt_d[JDS * (j) + JD_SOLREF + 1]}, si[5];
+    for (int a = 0; a < 5; a++) si[a] = m.jnt_d[JDS * (j) + JD_SOLIMP + a];
     for (int side = 0; side < 2; side++) {
       if (!(side == 0 ? lo : hi) || r >= NE) continue;
-      const double dist = side == 0 ? dlo : dhi, mg = m.jnt_margin[j];
+      const double dist = side == 0 ? dlo : dhi, mg = m.jnt_d[JDS * (j) + JD_MARGIN];
       double K, B, imp, R;
-      row_params(m, sr, si, dist, mg, m.dof_invweight0[d], &K, &B, &imp, &R);
+      row_params(m, sr, si, dist, mg, m.dof_d[DDS * (d) + DD_INVW], &K, &B, &imp, &R);
       S.U[U_J + r * LDV + d] = side == 0 ? 1.0 : -1.0;
       S.U[U_EPOS + r] = dist; S.U[U_EMARGIN + r] = mg; S.efc_D[r] = 1 / R; S.U[U_EK + r] = K; S.U[U_EB + r] = B; S.U[U_EIMP + r] = imp;
       r++;
@@ -754,9 +810,9 @@ __device__ void fwd_constraints(const HModel& m, Lds& S, int lane) {
   for (int it = lane; it < ncon * m.nv; it += 64) {
     const int c = it / m.nv, k = it - c * m.nv, r0 = S.con_row[c];
     if (r0 < 0) continue;
-    const int b1 = m.geom_bodyid[S.con_g1[c]], b2 = m.geom_bodyid[S.con_g2[c]];
+    const int b1 = m.geom_i[GIS * (S.con_g1[c]) + GI_BODY], b2 = m.geom_i[GIS * (S.con_g2[c]) + GI_BODY];
     const unsigned bit = 1u << k;
-    const bool in1 = m.body_dofmask[b1] & bit, in2 = m.body_dofmask[b2] & bit;
+    const bool in1 = ((unsigned)m.body_i[BIS * (b1) + BI_DOFMASK] & bit) != 0, in2 = ((unsigned)m.body_i[BIS * (b2) + BI_DOFMASK] & bit) != 0;
     double d[3] = {0, 0, 0};
     if (in1 != in2) {
       double off[3], t[3];
@@ -778,8 +834,8 @@ __device__ void fwd_constraints(const HModel& m, Lds& S, int lane) {
   for (int it = lane; it < ncon * 4; it += 64) {
     const int c = it >> 2, e = it & 3, r0 = S.con_row[c];
     if (r0 < 0 || (S.con_dim[c] == 1 && e > 0)) continue;
-    const int b1 = m.geom_bodyid[S.con_g1[c]], b2 = m.geom_bodyid[S.con_g2[c]];
-    const double tran = m.body_invweight0[2 * b1] + m.body_invweight0[2 * b2];
+    const int b1 = m.geom_i[GIS * (S.con_g1[c]) + GI_BODY], b2 = m.geom_i[GIS * (S.con_g2[c]) + GI_BODY];
+    const double tran = m.body_d[BDS * (b1) + BD_INVW] + m.body_d[BDS * (b2) + BD_INVW];
     const double mu = S.con_mu[c];
     double K, B, imp, R;
     const double diag = S.con_dim[c] == 1 ? tran : tran + mu * mu * tran;
@@ -797,7 +853,7 @@ __device__ double fwd_velocity(const HModel& m, Lds& S, int lane) {
   // velocity seen by dof j when its cdof_dot is formed: sum over dof_prevmask[j]
   if (lane < m.nv) {
     const int j = lane;
-    unsigned mask = m.dof_prevmask[j];
+    unsigned mask = (unsigned)m.dof_i[DIS * (j) + DI_PREVMASK];
     double v[6] = {0, 0, 0, 0, 0, 0};
     const bool zero = mask == 0xFFFFFFFFu;  // translational dofs of a free joint: cdof_dot = 0
     if (!zero)
@@ -818,7 +874,7 @@ __device__ double fwd_velocity(const HModel& m, Lds& S, int lane) {
   SYNC();
   for (int it = lane; it < m.nbody * 6; it += 64) {
     const int b = it / 6, a = it - 6 * b;
-    unsigned mask = m.body_dofmask[b];
+    unsigned mask = (unsigned)m.body_i[BIS * (b) + BI_DOFMASK];
     double cv = 0, ca = (a >= 3) ? -m.gravity[a - 3] : 0.0;
     while (mask) {
       const int k = __ffs(mask) - 1;
@@ -847,14 +903,14 @@ __device__ double fwd_velocity(const HModel& m, Lds& S, int lane) {
   for (int it = lane; it < m.nbody * 6; it += 64) {
     const int b = it / 6, a = it - 6 * b;
     double s = 0;
-    if (b >= 1) for (int d = b; d < m.body_subend[b]; d++) s += S.U[U_CFRC + 6 * d + a];
+    if (b >= 1) for (int d = b; d < m.body_i[BIS * (b) + BI_SUBEND]; d++) s += S.U[U_CFRC + 6 * d + a];
     S.U[U_CSUB + it] = s;
   }
   if (lane < 18) S.svel[lane] = S.U[U_CVEL + 6 * m.track_body[lane / 6] + lane % 6];
   SYNC();
   double bias = 0;
   if (lane < m.nv) {
-    const int b = m.dof_bodyid[lane];
+    const int b = m.dof_i[DIS * (lane) + DI_BODY];
     for (int a = 0; a < 6; a++) bias += S.cdof[6 * lane + a] * S.U[U_CSUB + 6 * b + a];
   }
   SYNC();
@@ -880,16 +936,16 @@ __device__ __forceinline__ void substep(const HModel& m, Lds& S, int lane, int f
   const int nv = m.nv, nefc = S.nefc;
   // transmission + actuation (lane = actuator)
   if (lane < m.nu) {
-    const int j = m.actuator_trnid[lane];
-    const double gear = m.actuator_gear[lane];
-    S.sq[lane] = (gear * S.qpos[m.jnt_qposadr[j]]) / gear;  // actuator_length / gear, as the reference computes it
-    S.sv[lane] = (gear * S.qvel[m.jnt_dofadr[j]]) / gear;
+    const int j = m.act_i[AIS * (lane) + AI_JNT];
+    const double gear = m.act_d[ADS * (lane) + AD_GEAR];
+    S.sq[lane] = (gear * S.qpos[m.jnt_i[JIS * (j) + JI_QADR]]) / gear;  // actuator_length / gear, as the reference computes it
+    S.sv[lane] = (gear * S.qvel[m.jnt_i[JIS * (j) + JI_DADR]]) / gear;
     double f = 0;
     if (flags & 1) {
       double c = S.ctrl[lane];
-      if (m.actuator_ctrllimited[lane]) c = fmin(m.actuator_ctrlrange[2 * lane + 1], fmax(m.actuator_ctrlrange[2 * lane], c));
+      if (m.act_i[AIS * (lane) + AI_CTRLLIMITED]) c = fmin(m.act_d[ADS * (lane) + AD_CTRLRANGE + 1], fmax(m.act_d[ADS * (lane) + AD_CTRLRANGE], c));
       f = c;
-      if (m.actuator_forcelimited[lane]) f = fmin(m.actuator_forcerange[2 * lane + 1], fmax(m.actuator_forcerange[2 * lane], f));
+      if (m.act_i[AIS * (lane) + AI_FORCELIMITED]) f = fmin(m.act_d[ADS * (lane) + AD_FORCERANGE + 1], fmax(m.act_d[ADS * (lane) + AD_FORCERANGE], f));
     }
     S.frc[lane] = f;
   }
@@ -900,8 +956,8 @@ __device__ __forceinline__ void substep(const HModel& m, Lds& S, int lane, int f
     qv = S.qvel[lane];
     double act = 0;
     for (int u = 0; u < m.nu; u++)
-      if (m.act_dof[u] == lane) act += m.actuator_gear[u] * S.frc[u];
-    fs = -m.dof_damping[lane] * qv - bias + act;
+      if (m.act_i[AIS * (u) + AI_DOF] == lane) act += m.act_d[ADS * (u) + AD_GEAR] * S.frc[u];
+    fs = -m.dof_d[DDS * (lane) + DD_DAMPING] * qv - bias + act;
     S.vec[lane] = qv;
   }
   SYNC();
@@ -926,10 +982,12 @@ __device__ __forceinline__ void substep(const HModel& m, Lds& S, int lane, int f
     }
   }
   SYNC();
+  PROF_MARK(11);
   // factor M (copy in H), qacc_smooth
   for (int it = lane; it < nv * LDV; it += 64) S.U[U_H + it] = S.M[it];
   SYNC();
   const double as = chol_solve_inplace(S.U + U_H, nv, lane, fs);
+  PROF_MARK(12);
 
   PROF_MARK(6);
   double qacc = as, fcon = 0;  // lane = dof
@@ -1045,15 +1103,16 @@ __device__ __forceinline__ void substep(const HModel& m, Lds& S, int lane, int f
   if (eulerdamp) {
     for (int it = lane; it < nv * LDV; it += 64) S.U[U_H + it] = S.M[it];
     SYNC();
-    if (lane < nv) S.U[U_H + lane * LDV + lane] += h * m.dof_damping[lane];
+    if (lane < nv) S.U[U_H + lane * LDV + lane] += h * m.dof_d[DDS * (lane) + DD_DAMPING];
     SYNC();
     anew = chol_solve_inplace(S.U + U_H, nv, lane, fs + fcon);
   }
+  PROF_MARK(13);
   if (lane < nv) S.qvel[lane] = qv + h * anew;
   SYNC();
   if (lane < m.njnt) {
-    const int j = lane, qa = m.jnt_qposadr[j], da = m.jnt_dofadr[j];
-    if (m.jnt_type[j] == JT_FREE) {
+    const int j = lane, qa = m.jnt_i[JIS * (j) + JI_QADR], da = m.jnt_i[JIS * (j) + JI_DADR];
+    if (m.jnt_i[JIS * (j) + JI_TYPE] == JT_FREE) {
       for (int k = 0; k < 3; k++) S.qpos[qa + k] += h * S.qvel[da + k];
       double w[3] = {S.qvel[da + 3], S.qvel[da + 4], S.qvel[da + 5]};
       double ang = h * normalize3(w), qr[4], q[4] = {S.qpos[qa + 3], S.qpos[qa + 4], S.qpos[qa + 5], S.qpos[qa + 6]};
@@ -1167,13 +1226,13 @@ __global__ void __launch_bounds__(64, 2) humanoid_kernel(HModel m, HParams p, HS
     if (lane < m.nu) {
       a_raw = (double)act[(size_t)env * m.nu + lane];
       target = p.action_smoothing * a_raw + (1 - p.action_smoothing) * prevpred + p.action_offset[lane];
-      if (!started) { prevact = target; prevtq = S.frc[lane] * m.actuator_gear[lane]; }
+      if (!started) { prevact = target; prevtq = S.frc[lane] * m.act_d[ADS * (lane) + AD_GEAR]; }
     }
     for (int k = 0; k < p.frame_skip; k++) {
       if (lane < m.nu) {
         // step_pd on the transmission fields of the previous forward pass (note S); ctrl = tau / gear
         const double tau = p.kp[lane] * (target - S.sq[lane]) + p.kd[lane] * (0.0 - S.sv[lane]);
-        S.ctrl[lane] = tau / m.actuator_gear[lane];
+        S.ctrl[lane] = tau / m.act_d[ADS * (lane) + AD_GEAR];
       }
       SYNC();
       substep(m, S, lane, 3, &warm, sprof);
@@ -1201,8 +1260,8 @@ __global__ void __launch_bounds__(64, 2) humanoid_kernel(HModel m, HParams p, HS
     double grf_r = 0, grf_l = 0, cz = 1e300;
     int selfcol = 0, anyfoot = 0;
     if (lane < S.ncon) {
-      const int c = lane, b1 = m.geom_bodyid[S.con_g1[c]], b2 = m.geom_bodyid[S.con_g2[c]];
-      const bool floor1 = m.body_rootid[b1] != p.root_body;
+      const int c = lane, b1 = m.geom_i[GIS * (S.con_g1[c]) + GI_BODY], b2 = m.geom_i[GIS * (S.con_g2[c]) + GI_BODY];
+      const bool floor1 = m.body_i[BIS * (b1) + BI_ROOT] != p.root_body;
       double fn = 0;
       const int r0 = S.con_row[c];
       if (r0 >= 0) {
@@ -1214,7 +1273,7 @@ __global__ void __launch_bounds__(64, 2) humanoid_kernel(HModel m, HParams p, HS
       }
       if (floor1 && b2 == p.rfoot_body) { grf_r = fn; cz = S.con_pos[3 * c + 2]; anyfoot = 1; }
       if (floor1 && b2 == p.lfoot_body) { grf_l = fn; cz = S.con_pos[3 * c + 2]; anyfoot = 1; }
-      selfcol = (m.body_rootid[b1] == p.root_body && m.body_rootid[b2] == p.root_body) ? 1 : 0;
+      selfcol = (m.body_i[BIS * (b1) + BI_ROOT] == p.root_body && m.body_i[BIS * (b2) + BI_ROOT] == p.root_body) ? 1 : 0;
     }
     grf_r = wave_sum(grf_r); grf_l = wave_sum(grf_l); cz = wave_min(cz);
     const bool has_foot = __any(anyfoot);
@@ -1223,7 +1282,7 @@ __global__ void __launch_bounds__(64, 2) humanoid_kernel(HModel m, HParams p, HS
     // joint-space sums: lane = actuator / dof
     double s_posture = 0, s_tq = 0, s_act = 0, s_rootacc = 0, cur_tq = 0;
     if (lane < m.nu) {
-      cur_tq = S.frc[lane] * m.actuator_gear[lane];
+      cur_tq = S.frc[lane] * m.act_d[ADS * (lane) + AD_GEAR];
       const double dq = p.neutral_pose[lane] - S.sq[lane];
       s_posture = dq * dq;
       s_tq = fabs(prevtq - cur_tq);
@@ -1378,35 +1437,8 @@ int humanoid_create(HumanoidEnv** out, const std::vector<int32_t>& mi, const std
   m.timestep = md[LHW_DH_TIMESTEP]; m.gravity[0] = md[LHW_DH_GRAVITY_X]; m.gravity[1] = md[LHW_DH_GRAVITY_Y]; m.gravity[2] = md[LHW_DH_GRAVITY_Z];
   m.tolerance = md[LHW_DH_TOLERANCE]; m.meaninertia = md[LHW_DH_MEANINERTIA]; m.totalmass = md[LHW_DH_TOTALMASS];
   bool ok = true;
-#define DI(field, F, n) ok = ok && (m.field = to_dev<int>(h, IF(F), (size_t)(n))) != nullptr
-#define DD(field, F, n) ok = ok && (m.field = to_dev<double>(h, DF(F), (size_t)(n))) != nullptr
-  DI(body_parentid, LHW_IF_BODY_PARENTID, nb); DI(body_rootid, LHW_IF_BODY_ROOTID, nb); DI(body_jntadr, LHW_IF_BODY_JNTADR, nb);
-  DI(body_jntnum, LHW_IF_BODY_JNTNUM, nb); DI(body_dofadr, LHW_IF_BODY_DOFADR, nb); DI(body_dofnum, LHW_IF_BODY_DOFNUM, nb);
-  DI(body_weldid, LHW_IF_BODY_WELDID, nb);
-  DD(body_pos, LHW_DF_BODY_POS, 3 * nb); DD(body_quat, LHW_DF_BODY_QUAT, 4 * nb); DD(body_ipos, LHW_DF_BODY_IPOS, 3 * nb);
-  DD(body_iquat, LHW_DF_BODY_IQUAT, 4 * nb); DD(body_mass, LHW_DF_BODY_MASS, nb); DD(body_inertia, LHW_DF_BODY_INERTIA, 3 * nb);
-  DD(body_invweight0, LHW_DF_BODY_INVWEIGHT0, 2 * nb);
-  DI(jnt_type, LHW_IF_JNT_TYPE, nj); DI(jnt_bodyid, LHW_IF_JNT_BODYID, nj); DI(jnt_qposadr, LHW_IF_JNT_QPOSADR, nj);
-  DI(jnt_dofadr, LHW_IF_JNT_DOFADR, nj); DI(jnt_limited, LHW_IF_JNT_LIMITED, nj);
-  DD(jnt_pos, LHW_DF_JNT_POS, 3 * nj); DD(jnt_axis, LHW_DF_JNT_AXIS, 3 * nj); DD(jnt_range, LHW_DF_JNT_RANGE, 2 * nj);
-  DD(jnt_solref, LHW_DF_JNT_SOLREF, 2 * nj); DD(jnt_solimp, LHW_DF_JNT_SOLIMP, 5 * nj); DD(jnt_margin, LHW_DF_JNT_MARGIN, nj);
-  DI(dof_bodyid, LHW_IF_DOF_BODYID, nv); DI(dof_jntid, LHW_IF_DOF_JNTID, nv);
-  DD(dof_armature, LHW_DF_DOF_ARMATURE, nv); DD(dof_damping, LHW_DF_DOF_DAMPING, nv); DD(dof_invweight0, LHW_DF_DOF_INVWEIGHT0, nv);
-  DD(qpos0, LHW_DF_QPOS0, nq);
-  DI(geom_type, LHW_IF_GEOM_TYPE, ng); DI(geom_bodyid, LHW_IF_GEOM_BODYID, ng); DI(geom_condim, LHW_IF_GEOM_CONDIM, ng);
-  DI(geom_priority, LHW_IF_GEOM_PRIORITY, ng);
-  DD(geom_pos, LHW_DF_GEOM_POS, 3 * ng); DD(geom_quat, LHW_DF_GEOM_QUAT, 4 * ng); DD(geom_size, LHW_DF_GEOM_SIZE, 3 * ng);
-  DD(geom_friction, LHW_DF_GEOM_FRICTION, 3 * ng); DD(geom_solmix, LHW_DF_GEOM_SOLMIX, ng); DD(geom_solref, LHW_DF_GEOM_SOLREF, 2 * ng);
-  DD(geom_solimp, LHW_DF_GEOM_SOLIMP, 5 * ng); DD(geom_margin, LHW_DF_GEOM_MARGIN, ng); DD(geom_gap, LHW_DF_GEOM_GAP, ng);
-  DI(pair_geom1, LHW_IF_PAIR_GEOM1, np); DI(pair_geom2, LHW_IF_PAIR_GEOM2, np);
-  DI(actuator_trnid, LHW_IF_ACTUATOR_TRNID, nu); DI(actuator_ctrllimited, LHW_IF_ACTUATOR_CTRLLIMITED, nu);
-  DI(actuator_forcelimited, LHW_IF_ACTUATOR_FORCELIMITED, nu);
-  DD(actuator_gear, LHW_DF_ACTUATOR_GEAR, nu); DD(actuator_ctrlrange, LHW_DF_ACTUATOR_CTRLRANGE, 2 * nu);
-  DD(actuator_forcerange, LHW_DF_ACTUATOR_FORCERANGE, 2 * nu);
-#undef DI
-#undef DD
-  // derived tables
-  std::vector<int> level(nb, 0), subend(nb, 0), mpi, mpj, actdof(nu, 0);
+  // ---- derived structure
+  std::vector<int> level(nb, 0), subend(nb, 0), mp;
   std::vector<unsigned> bmask(nb, 0), pmask(nv, 0);
   int nlevel = 1;
   for (int b = 1; b < nb; b++) { level[b] = level[parent[b]] + 1; nlevel = std::max(nlevel, level[b] + 1); }
@@ -1427,16 +1459,79 @@ int humanoid_create(HumanoidEnv** out, const std::vector<int32_t>& mi, const std
     } else {
       for (int a = dparent[d]; a >= 0; a = dparent[a]) pmask[d] |= 1u << a;
     }
-    for (int a = d; a >= 0; a = dparent[a]) { mpi.push_back(d); mpj.push_back(a); }
+    for (int a = d; a >= 0; a = dparent[a]) { mp.push_back(d); mp.push_back(a); }
   }
-  for (int u = 0; u < nu; u++) actdof[u] = jdof[IF(LHW_IF_ACTUATOR_TRNID)[u]];
-  m.nlevel = nlevel; m.nmpair = (int)mpi.size();
+  // ---- packed per-role tables
+  std::vector<double> body_d((size_t)nb * BDS, 0.0), jnt_d((size_t)nj * JDS, 0.0), dof_d((size_t)nv * DDS, 0.0),
+      geom_d((size_t)ng * GDS, 0.0), act_d((size_t)nu * ADS, 0.0);
+  std::vector<int> body_i((size_t)nb * BIS, 0), jnt_i((size_t)nj * JIS, 0), dof_i((size_t)nv * DIS, 0), geom_i((size_t)ng * GIS, 0),
+      act_i((size_t)nu * AIS, 0), pair_i((size_t)np * 2, 0);
+  for (int b = 0; b < nb; b++) {
+    double* k = &body_d[(size_t)BDS * b];
+    for (int a = 0; a < 3; a++) { k[a] = DF(LHW_DF_BODY_POS)[3 * b + a]; k[7 + a] = DF(LHW_DF_BODY_IPOS)[3 * b + a]; k[14 + a] = DF(LHW_DF_BODY_INERTIA)[3 * b + a]; }
+    for (int a = 0; a < 4; a++) { k[3 + a] = DF(LHW_DF_BODY_QUAT)[4 * b + a]; k[10 + a] = DF(LHW_DF_BODY_IQUAT)[4 * b + a]; }
+    k[BD_MASS] = DF(LHW_DF_BODY_MASS)[b];
+    k[BD_INVW] = DF(LHW_DF_BODY_INVWEIGHT0)[2 * b]; k[BD_INVW + 1] = DF(LHW_DF_BODY_INVWEIGHT0)[2 * b + 1];
+    const int jn = IF(LHW_IF_BODY_JNTNUM)[b], ja = IF(LHW_IF_BODY_JNTADR)[b];
+    int* bi = &body_i[(size_t)BIS * b];
+    bi[0] = parent[b]; bi[BI_LEVEL] = level[b]; bi[2] = -1; bi[3] = 0;
+    bi[BI_ROOT] = rootid[b]; bi[BI_SUBEND] = subend[b]; bi[BI_DOFMASK] = (int)bmask[b]; bi[BI_JNTADR] = ja < 0 ? 0 : ja;
+    if (jn > 1) { humanoid_destroy(h); return lhw_fail(LHW_ERR_UNSUPPORTED, "bodies with more than one joint are not supported by the wave-per-env stepper"); }
+    if (jn == 1) {
+      for (int a = 0; a < 3; a++) { k[17 + a] = DF(LHW_DF_JNT_AXIS)[3 * ja + a]; k[20 + a] = DF(LHW_DF_JNT_POS)[3 * ja + a]; }
+      bi[2] = jtype[ja]; bi[3] = IF(LHW_IF_JNT_QPOSADR)[ja];
+      k[23] = jtype[ja] == JT_FREE ? 0.0 : DF(LHW_DF_QPOS0)[IF(LHW_IF_JNT_QPOSADR)[ja]];
+    }
+  }
+  for (int j = 0; j < nj; j++) {
+    double* k = &jnt_d[(size_t)JDS * j];
+    k[JD_RANGE] = DF(LHW_DF_JNT_RANGE)[2 * j]; k[JD_RANGE + 1] = DF(LHW_DF_JNT_RANGE)[2 * j + 1];
+    k[JD_SOLREF] = DF(LHW_DF_JNT_SOLREF)[2 * j]; k[JD_SOLREF + 1] = DF(LHW_DF_JNT_SOLREF)[2 * j + 1];
+    for (int a = 0; a < 5; a++) k[JD_SOLIMP + a] = DF(LHW_DF_JNT_SOLIMP)[5 * j + a];
+    k[JD_MARGIN] = DF(LHW_DF_JNT_MARGIN)[j];
+    int* ji = &jnt_i[(size_t)JIS * j];
+    ji[JI_TYPE] = jtype[j]; ji[JI_LIMITED] = IF(LHW_IF_JNT_LIMITED)[j]; ji[JI_QADR] = IF(LHW_IF_JNT_QPOSADR)[j]; ji[JI_DADR] = jdof[j];
+  }
+  for (int d = 0; d < nv; d++) {
+    double* k = &dof_d[(size_t)DDS * d];
+    k[DD_ARMATURE] = DF(LHW_DF_DOF_ARMATURE)[d]; k[DD_DAMPING] = DF(LHW_DF_DOF_DAMPING)[d]; k[DD_INVW] = DF(LHW_DF_DOF_INVWEIGHT0)[d];
+    int* di = &dof_i[(size_t)DIS * d];
+    const int j = djnt[d], kk = d - jdof[j];
+    di[DI_BODY] = IF(LHW_IF_DOF_BODYID)[d]; di[DI_JNT] = j;
+    di[DI_KIND] = jtype[j] == JT_FREE ? (kk < 3 ? 0 : 1) : (jtype[j] == JT_SLIDE ? 2 : 3);
+    di[DI_PREVMASK] = (int)pmask[d];
+  }
+  for (int g = 0; g < ng; g++) {
+    double* k = &geom_d[(size_t)GDS * g];
+    for (int a = 0; a < 3; a++) { k[GD_POS + a] = DF(LHW_DF_GEOM_POS)[3 * g + a]; k[GD_SIZE + a] = DF(LHW_DF_GEOM_SIZE)[3 * g + a]; k[GD_FRICTION + a] = DF(LHW_DF_GEOM_FRICTION)[3 * g + a]; }
+    for (int a = 0; a < 4; a++) k[GD_QUAT + a] = DF(LHW_DF_GEOM_QUAT)[4 * g + a];
+    k[GD_SOLMIX] = DF(LHW_DF_GEOM_SOLMIX)[g];
+    k[GD_SOLREF] = DF(LHW_DF_GEOM_SOLREF)[2 * g]; k[GD_SOLREF + 1] = DF(LHW_DF_GEOM_SOLREF)[2 * g + 1];
+    for (int a = 0; a < 5; a++) k[GD_SOLIMP + a] = DF(LHW_DF_GEOM_SOLIMP)[5 * g + a];
+    k[GD_MARGIN] = DF(LHW_DF_GEOM_MARGIN)[g]; k[GD_GAP] = DF(LHW_DF_GEOM_GAP)[g];
+    int* gi = &geom_i[(size_t)GIS * g];
+    gi[GI_TYPE] = IF(LHW_IF_GEOM_TYPE)[g]; gi[GI_BODY] = IF(LHW_IF_GEOM_BODYID)[g]; gi[GI_CONDIM] = IF(LHW_IF_GEOM_CONDIM)[g];
+    gi[GI_PRIORITY] = IF(LHW_IF_GEOM_PRIORITY)[g];
+  }
+  for (int q = 0; q < np; q++) { pair_i[2 * q] = IF(LHW_IF_PAIR_GEOM1)[q]; pair_i[2 * q + 1] = IF(LHW_IF_PAIR_GEOM2)[q]; }
+  for (int u = 0; u < nu; u++) {
+    double* k = &act_d[(size_t)ADS * u];
+    k[AD_GEAR] = DF(LHW_DF_ACTUATOR_GEAR)[u];
+    k[AD_CTRLRANGE] = DF(LHW_DF_ACTUATOR_CTRLRANGE)[2 * u]; k[AD_CTRLRANGE + 1] = DF(LHW_DF_ACTUATOR_CTRLRANGE)[2 * u + 1];
+    k[AD_FORCERANGE] = DF(LHW_DF_ACTUATOR_FORCERANGE)[2 * u]; k[AD_FORCERANGE + 1] = DF(LHW_DF_ACTUATOR_FORCERANGE)[2 * u + 1];
+    int* ai = &act_i[(size_t)AIS * u];
+    const int j = IF(LHW_IF_ACTUATOR_TRNID)[u];
+    ai[AI_DOF] = jdof[j]; ai[AI_JNT] = j; ai[AI_CTRLLIMITED] = IF(LHW_IF_ACTUATOR_CTRLLIMITED)[u]; ai[AI_FORCELIMITED] = IF(LHW_IF_ACTUATOR_FORCELIMITED)[u];
+  }
+  m.nlevel = nlevel; m.nmpair = (int)mp.size() / 2;
   m.track_body[0] = cfg->task_iparams[LHW_TI_ROOT_BODY]; m.track_body[1] = cfg->task_iparams[LHW_TI_RFOOT_BODY];
   m.track_body[2] = cfg->task_iparams[LHW_TI_LFOOT_BODY];
-  ok = ok && (m.body_level = to_dev<int>(h, level.data(), nb)) && (m.body_subend = to_dev<int>(h, subend.data(), nb)) &&
-       (m.mpair_i = to_dev<int>(h, mpi.data(), mpi.size())) && (m.mpair_j = to_dev<int>(h, mpj.data(), mpj.size())) &&
-       (m.act_dof = to_dev<int>(h, actdof.data(), nu)) && (m.body_dofmask = to_dev<unsigned>(h, bmask.data(), nb)) &&
-       (m.dof_prevmask = to_dev<unsigned>(h, pmask.data(), nv));
+  ok = ok && (m.body_d = to_dev<double>(h, body_d.data(), body_d.size())) && (m.jnt_d = to_dev<double>(h, jnt_d.data(), jnt_d.size())) &&
+       (m.dof_d = to_dev<double>(h, dof_d.data(), dof_d.size())) && (m.geom_d = to_dev<double>(h, geom_d.data(), geom_d.size())) &&
+       (m.act_d = to_dev<double>(h, act_d.data(), act_d.size())) && (m.body_i = to_dev<int>(h, body_i.data(), body_i.size())) &&
+       (m.jnt_i = to_dev<int>(h, jnt_i.data(), jnt_i.size())) && (m.dof_i = to_dev<int>(h, dof_i.data(), dof_i.size())) &&
+       (m.geom_i = to_dev<int>(h, geom_i.data(), geom_i.size())) && (m.act_i = to_dev<int>(h, act_i.data(), act_i.size())) &&
+       (m.pair_i = to_dev<int>(h, pair_i.data(), pair_i.size())) && (m.mpair = to_dev<int>(h, mp.data(), mp.size()));
   HParams& p = h->p;
   memset(&p, 0, sizeof p);
   p.n_envs = cfg->n_envs; p.frame_skip = cfg->frame_skip; p.max_traj_len = cfg->max_traj_len; p.period = cfg->period;

@@ -23,3 +23,4 @@ names = ["kinematics", "com/cdof", "crba", "collision", "constraints", "velocity
 tot = c[:11].sum()
 print(f"N={N} ms/step {e0.elapsed_time(e1)/steps:.3f}  env0 cycles/control-step {tot/steps:.0f}  per sub-step {tot/steps/25:.0f}")
 for n, v in zip(names, c[:11]): print(f"  {n:14s} {v/steps/25:9.0f} cyc/substep  {100*v/tot:5.1f}%")
+print("  detail slots 11..15:", (c[11:16]/steps/25).astype(int))
