@@ -1,0 +1,58 @@
+"""Cross-rank reductions of the data-parallel trainer (pure torch: run on RCCL in production and on
+gloo in the CPU tests).  Environments are sharded across GPUs with no data-path collective; only
+these scalars and the flat gradient cross ranks."""
+from __future__ import annotations
+
+import math
+
+import torch
+
+
+def dist():
+    import torch.distributed as d
+    return d if d.is_available() and d.is_initialized() else None
+
+
+def global_mean_std(sum_x: torch.Tensor, sum_x2: torch.Tensor, n: float):
+    """Mean and UNBIASED std of the union of all ranks' samples from per-rank (sum, sum of squares, count).
+    Matches torch's ``x.mean()`` / ``x.std()`` on the concatenated batch (reference rl/algos/ppo.py:485)."""
+    pack = torch.stack([sum_x.double().reshape(()), sum_x2.double().reshape(()),
+                        torch.tensor(float(n), dtype=torch.float64, device=sum_x.device)])
+    d = dist()
+    if d and d.get_world_size() > 1:
+        d.all_reduce(pack)
+    s, s2, cnt = (float(v) for v in pack)
+    mean = s / cnt
+    var = max(0.0, (s2 - cnt * mean * mean) / max(1.0, cnt - 1.0))
+    return mean, math.sqrt(var), cnt
+
+
+def global_batch_moments(x: torch.Tensor):
+    """Per-feature mean / biased variance / count of the union of all ranks' rows (RunningMeanStd.update
+    on the concatenated batch, reference rl/envs/normalize.py:16-33)."""
+    x = x.double()
+    n = torch.tensor([float(x.shape[0])], dtype=torch.float64, device=x.device)
+    pack = torch.cat([x.sum(0), (x * x).sum(0), n])
+    d = dist()
+    if d and d.get_world_size() > 1:
+        d.all_reduce(pack)
+    D = x.shape[1]
+    cnt = pack[-1]
+    mean = pack[:D] / cnt
+    var = (pack[D:2 * D] / cnt - mean * mean).clamp_min(0.0)
+    return mean, var, float(cnt)
+
+
+def allreduce_grad_(flat_grad: torch.Tensor) -> float:
+    """Sum-all-reduce the flat gradient in place; returns the scale (1/world) that turns the sum of per-rank
+    mean-gradients into the mean over the global minibatch."""
+    d = dist()
+    if d and d.get_world_size() > 1:
+        d.all_reduce(flat_grad)
+        return 1.0 / d.get_world_size()
+    return 1.0
+
+
+def shard_env_ids(n_envs_per_rank: int, rank: int) -> int:
+    """Global index of this rank's first environment (RNG keys use global env ids)."""
+    return rank * n_envs_per_rank

@@ -18,6 +18,7 @@ from pathlib import Path
 import numpy as np
 import torch
 
+from . import dist_utils
 from .ppo_kernels import PpoKernels, reference_init
 
 
@@ -163,8 +164,8 @@ class PPO:
             print("Using running observation normalization (will update during training).")
         env_seed = (seed if seed is not None else int(time.time())) & 0x7FFFFFFF
         self.env = spec.make_batched(self.n_proc, seed=env_seed, device=self.device, max_traj_len=self.max_traj_len,
-                                     env_id_base=self.rank * self.n_proc)
-        self.env.env_id_base = self.rank * self.n_proc
+                                     env_id_base=dist_utils.shard_env_ids(self.n_proc, self.rank))
+        self.env.env_id_base = dist_utils.shard_env_ids(self.n_proc, self.rank)
         self.rollout = Rollout(self.env, self.kernels, self.max_traj_len, seed=env_seed ^ 0x5DEECE66D)
         self.policy = self.kernels  # attribute names the reference's tests look for
         self.critic = self.kernels
@@ -189,16 +190,8 @@ class PPO:
     def _normalize_advantages(self, adv_flat):
         """(adv - mean) / (unbiased std + eps) over the GLOBAL batch (ppo.py:484-485)."""
         mom = self.kernels.moments(adv_flat).clone()
-        n = torch.tensor([float(adv_flat.numel())], dtype=torch.float64, device=mom.device)
-        d = _dist()
-        if d and self.world > 1:
-            pack = torch.cat([mom, n])
-            d.all_reduce(pack)
-            mom, n = pack[:2], pack[2:]
-        s, s2, n = float(mom[0]), float(mom[1]), float(n[0])
-        mean = s / n
-        var = max(0.0, (s2 - n * mean * mean) / max(1.0, n - 1.0))
-        self.kernels.scale_shift(adv_flat, mean, 1.0 / (np.sqrt(var) + self.eps))
+        mean, std, _ = dist_utils.global_mean_std(mom[0], mom[1], adv_flat.numel())
+        self.kernels.scale_shift(adv_flat, mean, 1.0 / (std + self.eps))
 
     def update_actor_critic(self, obs_batch, action_batch, return_batch, advantage_batch, mask=1, mirror_observation=None,
                             mirror_action=None, old_log_probs=None):
@@ -228,12 +221,8 @@ class PPO:
         return float(-np.mean(0.5 + 0.5 * np.log(2 * np.pi) + np.log(sd)))
 
     def _allreduce_and_apply(self):
-        d = _dist()
-        if d and self.world > 1:
-            d.all_reduce(self.kernels.grad)  # RCCL sum over xGMI: the only data-path collective
-            self.kernels.apply(grad_scale=1.0 / self.world)
-        else:
-            self.kernels.apply()
+        scale = dist_utils.allreduce_grad_(self.kernels.grad)  # RCCL sum over xGMI: the only data-path collective
+        self.kernels.apply(grad_scale=scale)
 
     def optimize(self, itr: int):
         """The per-iteration update of PPO.train (ppo.py:484-566): advantage normalisation, then
@@ -315,18 +304,9 @@ class PPO:
             print("Warming up observation normalization...")
             for i in range(5):  # ppo.py:442-457
                 batch = self.sample_parallel_with_workers()
-                x = batch.states.double()
-                mean, var, n = x.mean(0), x.var(0, unbiased=False), torch.tensor(float(x.shape[0]), device=x.device)
-                d = _dist()
-                if d and self.world > 1:  # Chan merge across ranks == update on the concatenated batch
-                    pack = torch.cat([mean * n, (var + mean * mean) * n, n.view(1)])
-                    d.all_reduce(pack)
-                    D = x.shape[1]
-                    n = pack[-1]
-                    mean = pack[:D] / n
-                    var = pack[D:2 * D] / n - mean * mean
-                self.obs_rms.update_from_moments(mean.cpu().numpy(), var.cpu().numpy(), float(n))
-                print(f"  Warmup batch {i + 1}: {x.shape[0] * self.world} samples, obs_rms count: {self.obs_rms.count:.0f}")
+                mean, var, n = dist_utils.global_batch_moments(batch.states)  # == update on the concatenated batch
+                self.obs_rms.update_from_moments(mean.cpu().numpy(), var.cpu().numpy(), n)
+                print(f"  Warmup batch {i + 1}: {int(n)} samples, obs_rms count: {self.obs_rms.count:.0f}")
             k.set_obs_norm(self.obs_rms.mean, self.obs_rms.std)
             print(f"Normalization initialized with {self.obs_rms.count:.0f} samples")
         for itr in range(n_itr):

@@ -1,0 +1,96 @@
+"""MJCF-subset compiler and packed model format (CPU)."""
+import os
+
+import numpy as np
+import pytest
+
+from learninghumanoidwalking_amd import mjcf, model
+from learninghumanoidwalking_amd.envs.cartpole import CARTPOLE_XML
+from learninghumanoidwalking_amd.envs.jvrc_walk import JVRC_STANDIN_XML, LEG_JOINTS
+
+REF_CARTPOLE = "/root/reference/envs/cartpole/cartpole.xml"
+
+
+def test_cartpole_known_facts():
+    m = mjcf.compile_file(CARTPOLE_XML, 0.005)
+    assert (m.nq, m.nv, m.nu, m.nbody, m.npair) == (2, 2, 1, 3, 0)
+    assert m.timestep == 0.005
+    # cart box .4x.2x.1 m at density 1000 = 8 kg; pole capsule ~4.1987 kg with com at z=.3
+    np.testing.assert_allclose(m.body_mass, [0, 8.0, 4.198738581], rtol=1e-8)
+    np.testing.assert_allclose(m.body_ipos[2], [0, 0, 0.3], atol=1e-15)
+    assert m.jnt_limited.tolist() == [1, 0] and m.jnt_range[0].tolist() == [-1, 1]
+    np.testing.assert_allclose(m.jnt_solref[0], [0.08, 1])
+    np.testing.assert_allclose(m.dof_damping, [0.05, 0.05])
+    assert m.actuator_gear[0] == 50 and m.actuator_ctrllimited[0] == 0
+    # dof_invweight0 = diag(M(qpos0)^-1)
+    M = mjcf.mass_matrix0(m)
+    np.testing.assert_allclose(m.dof_invweight0, np.diag(np.linalg.inv(M)), rtol=1e-12)
+    np.testing.assert_allclose(m.meaninertia, np.trace(M) / 2)
+
+
+@pytest.mark.skipif(not os.path.exists(REF_CARTPOLE), reason="reference checkout not present")
+def test_own_cartpole_asset_equals_reference_xml():
+    """The repo's cartpole.xml is a re-authored file; the reference's XML must compile to the same dynamics."""
+    a = mjcf.compile_file(CARTPOLE_XML, 0.005)
+    b = mjcf.compile_file(REF_CARTPOLE, 0.005)
+    for f in ("body_mass", "body_ipos", "body_inertia", "body_pos", "jnt_axis", "jnt_range", "jnt_solref", "jnt_solimp",
+              "dof_damping", "dof_armature", "dof_invweight0", "body_invweight0", "actuator_gear", "qpos0"):
+        np.testing.assert_allclose(a.arrays[f], b.arrays[f], atol=1e-15, err_msg=f)
+    assert (a.nq, a.nv, a.nu, a.npair) == (b.nq, b.nv, b.nu, b.npair)  # the extra decoration geoms never collide
+
+
+def test_jvrc_standin_structure():
+    m = mjcf.compile_file(JVRC_STANDIN_XML)
+    assert (m.nq, m.nv, m.nu) == (19, 18, 12)
+    assert [m.jnt_names[j] for j in m.actuator_trnid] == LEG_JOINTS            # gen_xml.py:44-57
+    assert m.actuator_names == [j + "_motor" for j in LEG_JOINTS]              # robot_interface.py:134
+    assert m.body_names[1] == "PELVIS_S" and m.body_names[-1] == "floor"      # floor body appended last (gen_xml.py:156-158)
+    assert m.dof_parentid.tolist() == [-1, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 5, 12, 13, 14, 15, 16]
+    names = {(m.geom_names[a], m.geom_names[b]) for a, b in zip(m.pair_geom1, m.pair_geom2)}
+    assert ("floor", "R_ANKLE_P_S-foot") in names and ("floor", "L_ANKLE_P_S-foot") in names
+    assert ("R_KNEE_S-geom", "L_KNEE_S-geom") in names                         # self-collision candidates exist
+    assert not any("foot" in a and "foot" in b for a, b in names)              # masked: no box-box narrow phase yet
+    assert all(m.geom_type[a] <= m.geom_type[b] for a, b in zip(m.pair_geom1, m.pair_geom2))
+    foot = m.geom_id("R_ANKLE_P_S-foot")
+    np.testing.assert_allclose(m.geom_size[foot], [0.1, 0.05, 0.01])           # gen_xml.py:117-122
+    np.testing.assert_allclose(m.geom_pos[foot], [0.029, 0, -0.09778])
+    assert abs(m.totalmass - 62.0) < 1e-9
+    assert (m.dof_invweight0 > 0).all() and (m.body_invweight0[1:-1, 0] > 0).all() and m.body_invweight0[-1, 0] == 0
+
+
+def test_pack_layout_roundtrip():
+    m = mjcf.compile_file(JVRC_STANDIN_XML)
+    ib, db = m.pack()
+    assert ib.dtype == np.int32 and db.dtype == np.float64
+    assert np.uint32(ib[0]) == model.MAGIC and ib[1] == model.VERSION
+    for k, (name, _, width, sym) in enumerate(model.I_FIELDS):
+        off = ib[len(model.I_HEADER) + k]
+        n = width * m.count(sym)
+        np.testing.assert_array_equal(ib[off:off + n], np.asarray(m.arrays[name]).reshape(-1), err_msg=name)
+    for k, (name, _, width, sym) in enumerate(model.D_FIELDS):
+        off = ib[len(model.I_HEADER) + len(model.I_FIELDS) + k]
+        n = width * m.count(sym)
+        np.testing.assert_array_equal(db[off:off + n], np.asarray(m.arrays[name]).reshape(-1), err_msg=name)
+    hdr = open(os.path.join(os.path.dirname(__file__), "..", "include", "lhw_model_fields.h")).read()
+    assert hdr == model.generate_header(), "include/lhw_model_fields.h is stale: run python -m learninghumanoidwalking_amd.model"
+
+
+def test_unsupported_features_raise():
+    base = "<mujoco><worldbody><body><joint type='%s'/><geom type='%s' size='.1 .1 .1'/></body></worldbody></mujoco>"
+    with pytest.raises(mjcf.MjcfError):
+        mjcf.compile_string(base % ("ball", "sphere"))
+    with pytest.raises(mjcf.MjcfError):
+        mjcf.compile_string(base % ("hinge", "mesh"))
+    with pytest.raises(mjcf.MjcfError):   # box-box has no narrow phase yet
+        mjcf.compile_string("<mujoco><worldbody><body><freejoint/><geom type='box' size='.1 .1 .1'/></body>"
+                            "<body pos='1 0 0'><freejoint/><geom type='box' size='.1 .1 .1'/></body></worldbody></mujoco>")
+
+
+def test_euler_and_fromto_orientation():
+    xml = ("<mujoco><compiler angle='degree'/><worldbody><body euler='90 0 0'><joint/>"
+           "<geom type='capsule' fromto='0 0 0 1 0 0' size='.05'/></body></worldbody></mujoco>")
+    m = mjcf.compile_string(xml)
+    np.testing.assert_allclose(m.body_quat[1], [np.cos(np.pi / 4), np.sin(np.pi / 4), 0, 0], atol=1e-15)
+    R = mjcf.quat2mat(m.geom_quat[0])
+    np.testing.assert_allclose(R[:, 2], [1, 0, 0], atol=1e-12)   # capsule axis along fromto
+    assert abs(m.geom_size[0][1] - 0.5) < 1e-15

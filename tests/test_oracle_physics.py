@@ -1,0 +1,106 @@
+"""Analytic invariants of the float64 CPU oracle (oracle/mjc_oracle.c).  The oracle's parity with MuJoCo
+itself is UNPINNED (no MuJoCo in the container, no golden physics vectors in the reference: SURVEY.md 8c);
+these checks need no oracle of their own."""
+import numpy as np
+
+from learninghumanoidwalking_amd import mjcf
+from learninghumanoidwalking_amd.envs.cartpole import CARTPOLE_XML
+from learninghumanoidwalking_amd.envs.jvrc_walk import JVRC_STANDIN_XML, JvrcWalkSpec
+from oracle.physics import OracleSim
+
+
+def _energy(m, s):
+    s.forward(False)
+    ke = 0.5 * s.qvel @ s.M @ s.qvel
+    pe = sum(m.body_mass[b] * 9.81 * s.xipos[b, 2] for b in range(m.nbody))
+    return ke + pe
+
+
+def test_cartpole_energy_drift_is_first_order_in_h():
+    drift = []
+    for h in (0.001, 0.0005, 0.00025):
+        m = mjcf.compile_file(CARTPOLE_XML, h)
+        m.arrays["dof_damping"][:] = 0
+        s = OracleSim(m)
+        s.qpos[:] = [0.0, 1.0]
+        s.qvel[:] = [0.3, -0.5]
+        e0 = _energy(m, s)
+        s.step(int(round(1.0 / h)))
+        drift.append((_energy(m, s) - e0) / abs(e0))
+    assert abs(drift[0]) < 0.02
+    assert 1.8 < drift[0] / drift[1] < 2.2 and 1.8 < drift[1] / drift[2] < 2.2   # semi-implicit Euler: O(h)
+
+
+def test_mass_matrix_matches_compile_time_jacobian_form():
+    m = mjcf.compile_file(JVRC_STANDIN_XML)
+    s = OracleSim(m)
+    s.forward(False)
+    np.testing.assert_allclose(s.M, mjcf.mass_matrix0(m), rtol=1e-11, atol=1e-12)   # CRBA == sum_b J^T I J at qpos0
+    np.testing.assert_allclose(s.M, s.M.T, atol=0)
+
+
+def test_free_fall_matches_closed_form():
+    m = mjcf.compile_file(JVRC_STANDIN_XML)
+    s = OracleSim(m)
+    s.qpos[2] = 5.0
+    n, h = 500, m.timestep
+    s.step(n)
+    assert abs(s.qpos[2] - (5.0 - 9.81 * h * h * n * (n + 1) / 2)) < 1e-9       # semi-implicit Euler closed form
+    assert abs(s.qvel[2] + 9.81 * h * n) < 1e-10
+    assert s.ncon == 0
+
+
+def test_standing_ground_reaction_equals_weight():
+    """scripts/test_contact_behavior.py's gate in the reference: total GRF ~ m g once settled."""
+    spec = JvrcWalkSpec()
+    m = spec.model()
+    s = OracleSim(m)
+    s.qpos[:] = spec.nominal_pose
+    gear = m.actuator_gear
+    target = spec.nominal_pose[7:]
+    for _ in range(700):
+        q, w = s.actuator_length / gear, s.actuator_velocity / gear
+        s.ctrl[:] = (spec.kp * (target - q) - spec.kd * w) / gear
+        s.step()
+    assert s.ncon == 8                                                          # four corners per foot
+    normal = sum(s.contact_force(i)[0] for i in range(s.ncon))
+    assert abs(normal - m.totalmass * 9.81) / (m.totalmass * 9.81) < 5e-3
+    assert max(abs(s.contact(i)["dist"]) for i in range(s.ncon)) < 2e-3         # soft contact: sub-2mm penetration
+    assert all(s.contact(i)["geom1"] == m.geom_id("floor") for i in range(s.ncon))   # plane is always geom1
+    assert s.niter <= 3
+    # left/right symmetry of a symmetric pose
+    np.testing.assert_allclose(s.qpos[7:13], s.qpos[13:19] * np.array([1, -1, -1, 1, -1, 1]), atol=1e-9)
+
+
+def test_joint_limit_is_a_soft_wall():
+    m = mjcf.compile_file(CARTPOLE_XML, 0.005)
+    s = OracleSim(m)
+    s.qpos[:] = [0.95, 0.1]
+    s.qvel[:] = [3.0, 0.0]
+    hit, xmax = 0, 0.0
+    for _ in range(200):
+        s.step()
+        hit += s.nefc > 0
+        xmax = max(xmax, s.qpos[0])
+    assert hit > 0 and 1.0 < xmax < 1.1 and s.qpos[0] < 1.0
+
+
+def test_contact_force_decode_and_friction_pyramid():
+    """A box pushed sideways on the floor: tangential force bounded by mu * normal (pyramid), opposite to motion."""
+    xml = ("<mujoco><option timestep='0.001'/><worldbody><geom name='floor' type='plane' size='0 0 1'/>"
+           "<body name='b' pos='0 0 0.1'><freejoint/><geom name='box' type='box' size='.1 .1 .1' mass='2'/></body>"
+           "</worldbody></mujoco>")
+    m = mjcf.compile_string(xml)
+    s = OracleSim(m)
+    s.step(300)
+    s.qvel[0] = 0.2
+    v0 = s.qvel[0]
+    s.step(1)                # the fields below describe the forward pass of this step (state before integration)
+    f = sum(s.contact_force(i) for i in range(s.ncon))
+    mu = s.contact(0)["mu"]
+    assert s.ncon == 4 and f[0] > 0
+    tang = np.hypot(f[1], f[2])
+    assert 0 < tang <= mu * f[0] * (1 + 1e-9)          # inside the friction pyramid
+    assert s.qvel[0] < v0                              # friction decelerates the slide
+    # each pyramid edge force is non-negative (unilateral rows)
+    assert (s.efc("efc_force") >= 0).all()
