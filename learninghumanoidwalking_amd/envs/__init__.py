@@ -3,3 +3,9 @@ from .cartpole import CartpoleSpec, make_cartpole  # noqa: F401
 from .jvrc_walk import JvrcWalkSpec  # noqa: F401
 
 ENVIRONMENTS = {"cartpole": CartpoleSpec, "jvrc_walk": JvrcWalkSpec}
+
+
+def single_env(name, **kw):
+    """The reference's ``Env(path_to_yaml)`` single-env object for ``name`` (GPU required)."""
+    from . import adapters
+    return {"cartpole": adapters.CartpoleEnv, "jvrc_walk": adapters.JvrcWalkEnv}[name](**kw)

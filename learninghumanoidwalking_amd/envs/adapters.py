@@ -1,0 +1,68 @@
+"""N=1 views of the batched environments with the reference's single-env surface
+(reference envs/common/base_humanoid_env.py, tests/test_environments.py:39-266): ``reset() -> ndarray``,
+``step(a) -> (ndarray, float, bool, dict)``, ``observation_space`` / ``action_space`` zero arrays,
+``obs_mean`` / ``obs_std``, ``robot.{iteration_count, mirrored_obs, mirrored_acts, clock_inds}``."""
+from __future__ import annotations
+
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+from .cartpole import CartpoleSpec
+from .jvrc_walk import JvrcWalkSpec
+
+
+class _SingleEnv:
+    TERMS: list = []
+
+    def __init__(self, spec, seed=0, device=0):
+        self.spec = spec
+        self._env = spec.make_batched(1, seed=seed, device=device, max_traj_len=0)
+        self.observation_space = np.zeros(spec.obs_dim)
+        self.action_space = np.zeros(spec.act_dim)
+        self.base_obs_len, self.history_len = spec.obs_dim, 1
+        if spec.obs_mean is not None:
+            self.obs_mean, self.obs_std = np.asarray(spec.obs_mean), np.asarray(spec.obs_std)
+        self.robot = SimpleNamespace(iteration_count=np.inf)
+        self._mask = torch.ones(1, dtype=torch.uint8, device=self._env.device)
+        self._act = torch.zeros(1, spec.act_dim, dtype=torch.float32, device=self._env.device)
+
+    def reset(self):
+        return self._env.reset(self._mask).cpu().numpy()[0].astype(np.float64)
+
+    def step(self, action):
+        a = np.asarray(action, dtype=np.float32).reshape(1, -1)
+        if a.shape[1] != self.spec.act_dim:
+            raise AssertionError(f"Action vector length expected to be: {self.spec.act_dim} but is {a.shape[1]}")
+        self._act.copy_(torch.from_numpy(a))
+        obs, rew, done, _ = self._env.step(self._act)
+        terms = self._env.rew_terms.cpu().numpy()[0]
+        info = {k: float(v) for k, v in zip(self.TERMS, terms)}
+        return obs.cpu().numpy()[0].astype(np.float64), float(rew.cpu()[0]), bool(int(done.cpu()[0]) & 1), info
+
+    def get_state(self):
+        q, v = self._env.get_state()
+        return q[0], v[0]
+
+    def close(self):
+        self._env.close()
+
+
+class CartpoleEnv(_SingleEnv):
+    TERMS = ["upright", "center", "velocity", "action"]          # cartpole_env.py:182-187
+
+    def __init__(self, path_to_yaml=None, seed=0, device=0):
+        super().__init__(CartpoleSpec(), seed=seed, device=device)
+        self.robot.iteration_count = 0
+
+
+class JvrcWalkEnv(_SingleEnv):
+    TERMS = ["foot_frc_score", "foot_vel_score", "root_accel", "height_error", "com_vel_error", "yaw_vel_error",
+             "upper_body_reward", "posture_error", "torque_penalty", "action_penalty"]   # walking_task.py:131-146
+
+    def __init__(self, path_to_yaml=None, seed=0, device=0):
+        spec = JvrcWalkSpec(yaml_path=path_to_yaml) if path_to_yaml else JvrcWalkSpec()
+        super().__init__(spec, seed=seed, device=device)
+        mo, ma, clock = spec.mirror_inds()
+        self.robot.mirrored_obs, self.robot.mirrored_acts, self.robot.clock_inds = mo, ma, clock

@@ -1,0 +1,70 @@
+"""Single-env surface and the run_experiment.py entry point on the GPU (mirrors reference tests/test_environments.py
+and tests/test_training.py:206-235)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("name", ["cartpole", "jvrc_walk"])
+def test_single_env_surface(name):
+    from learninghumanoidwalking_amd.envs import single_env
+    env = single_env(name, seed=1)
+    obs = env.reset()
+    assert isinstance(obs, np.ndarray) and obs.shape == env.observation_space.shape and np.isfinite(obs).all()
+    rs = np.random.default_rng(0)
+    for _ in range(30):
+        a = rs.uniform(-1, 1, env.action_space.shape[0]) * 0.3
+        obs, r, done, info = env.step(a)
+        # tests/test_environments.py:250-266 step signature, :174-188 reward = sum of components
+        assert isinstance(obs, np.ndarray) and isinstance(r, float) and isinstance(done, bool) and isinstance(info, dict)
+        assert obs.shape == env.observation_space.shape and np.isfinite(obs).all() and np.isfinite(r)
+        assert abs(r - sum(info.values())) < 1e-6
+        if done:
+            env.reset()
+    if name == "jvrc_walk":   # tests/test_environments.py:194-226 mirror / clock index validity
+        assert len(env.robot.mirrored_obs) == 37 and len(env.robot.mirrored_acts) == 12 and env.robot.clock_inds == [29, 30]
+        assert env.obs_mean.shape == (37,) and env.obs_std.shape == (37,)
+    with pytest.raises(AssertionError):
+        env.step(np.zeros(env.action_space.shape[0] + 1))
+    env.close()
+
+
+def test_run_experiment_train_cartpole(tmp_path):
+    cmd = [sys.executable, os.path.join(ROOT, "run_experiment.py"), "train", "--env", "cartpole", "--logdir", str(tmp_path),
+           "--n-itr", "2", "--num-envs", "64", "--max-traj-len", "50", "--minibatch-size", "256", "--eval-freq", "100",
+           "--learn-std", "--entropy-coeff", "0.01", "--std-dev", "0.15", "--seed", "0"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "Sampling took" in out.stdout and "Optimizer took" in out.stdout and "fps=" in out.stdout   # scripts/benchmark_training.py:75-79
+    run = [d for d in os.listdir(tmp_path) if d.endswith("_cartpole")]
+    assert len(run) == 1
+    files = os.listdir(os.path.join(tmp_path, run[0]))
+    assert "actor_0.pt" in files and "critic_0.pt" in files and "experiment.pkl" in files
+
+
+def test_ppo_learns_cartpole_a_little():
+    """Sanity of the whole loop: mean episode return rises over 15 iterations of cartpole swing-up."""
+    from types import SimpleNamespace
+    from learninghumanoidwalking_amd.envs import CartpoleSpec
+    from learninghumanoidwalking_amd.ppo import PPO
+    args = SimpleNamespace(gamma=0.99, lam=0.95, lr=3e-4, eps=1e-5, entropy_coeff=0.01, clip=0.2, minibatch_size=4096, epochs=3,
+                           max_traj_len=200, num_procs=512, num_envs=512, max_grad_norm=0.5, mirror_coeff=0.4, eval_freq=10**9,
+                           recurrent=False, imitate=None, learn_std=True, std_dev=0.3, no_mirror=True, continued=None,
+                           logdir="/tmp/lhw_test_learn", device_index=0)
+    algo = PPO(CartpoleSpec, args, seed=1)
+    b = algo.sample_parallel_with_workers()
+    algo.obs_rms.update(b.states.cpu().numpy())
+    algo.kernels.set_obs_norm(algo.obs_rms.mean, algo.obs_rms.std)
+    rets = []
+    for itr in range(15):
+        algo.iterate(itr)
+        rs, ls, cnt = algo._ep_stats
+        rets.append(rs / max(cnt, 1))
+        assert np.isfinite(list(algo.last_losses.values())).all()
+    assert np.mean(rets[-3:]) > np.mean(rets[:3]) * 1.05, rets
