@@ -75,9 +75,21 @@ static_assert(R_EPRET < REC_D, "record too small");
 // Model constants, packed host-side into one array-of-structs table per "lane role" (body, joint, dof, geom, pair,
 // actuator): a lane fetches the record of its body/dof/... with one burst of independent loads, and the kernel argument
 // block carries a dozen base pointers instead of seventy (the latter spilled most of the SGPR file).
-#define BDS 28  // body_d: pos3 quat4 ipos3 iquat4 inertia3 jnt_axis3 jnt_pos3 qpos0(joint) | mass invweight0[2] pad
-#define BD_MASS 24
-#define BD_INVW 25
+// body_d: pos3 R_body9 ipos3 R_inertial9 inertia3 jnt_axis3 jnt_pos3 qpos0(joint) R_body*jnt_pos3 R_body*jnt_axis3 | mass invweight0[2]
+#define BDS 44
+#define BD_POS 0
+#define BD_RBODY 3
+#define BD_IPOS 12
+#define BD_RINERT 15
+#define BD_INERTIA 24
+#define BD_JAXIS 27
+#define BD_JPOS 30
+#define BD_Q0 33
+#define BD_V1 34
+#define BD_V2 37
+#define BD_NKIN 40
+#define BD_MASS 40
+#define BD_INVW 41
 #define BIS 8   // body_i: parent level jnt_type(-1 welded) qposadr | rootid subtree_end dofmask jntadr
 #define BI_ROOT 4
 #define BI_SUBEND 5
@@ -103,16 +115,16 @@ static_assert(R_EPRET < REC_D, "record too small");
 #define DI_JNT 1
 #define DI_KIND 2
 #define DI_PREVMASK 3
-#define GDS 23  // geom_d: pos3 quat4 size3 friction3 solmix solref2 solimp5 margin gap
+#define GDS 28  // geom_d: pos3 R_local9 size3 friction3 solmix solref2 solimp5 margin gap
 #define GD_POS 0
-#define GD_QUAT 3
-#define GD_SIZE 7
-#define GD_FRICTION 10
-#define GD_SOLMIX 13
-#define GD_SOLREF 14
-#define GD_SOLIMP 16
-#define GD_MARGIN 21
-#define GD_GAP 22
+#define GD_RLOC 3
+#define GD_SIZE 12
+#define GD_FRICTION 15
+#define GD_SOLMIX 18
+#define GD_SOLREF 19
+#define GD_SOLIMP 21
+#define GD_MARGIN 26
+#define GD_GAP 27
 #define GIS 4   // geom_i: type body condim priority
 #define GI_TYPE 0
 #define GI_BODY 1
@@ -180,8 +192,7 @@ struct HumanoidEnv {
 #define U_XIPOS (U_XMAT + NB * 9)
 #define U_XANCHOR (U_XIPOS + NB * 3)
 #define U_XAXIS (U_XANCHOR + NJ * 3)
-#define U_XQUAT (U_XAXIS + NJ * 3)
-#define U_GPOS (U_XQUAT + NB * 4)
+#define U_GPOS (U_XAXIS + NJ * 3)
 #define U_GMAT (U_GPOS + NG * 3)
 #define U_END_A (U_GMAT + NG * 9)
 #define U_CRB (U_CINERT + NB * 10)
@@ -302,6 +313,12 @@ __device__ __forceinline__ void matT_vec(double* r, const double* R, const doubl
          z = R[2] * v[0] + R[5] * v[1] + R[8] * v[2];
   r[0] = x; r[1] = y; r[2] = z;
 }
+__device__ __forceinline__ void mat_mul(double* C, const double* A, const double* B) {
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int j = 0; j < 3; j++) C[3 * i + j] = A[3 * i] * B[j] + A[3 * i + 1] * B[3 + j] + A[3 * i + 2] * B[6 + j];
+}
 __device__ __forceinline__ void axis_angle_quat(double* q, const double* ax, double ang) {
   double s = sin(0.5 * ang);
   q[0] = cos(0.5 * ang); q[1] = ax[0] * s; q[2] = ax[1] * s; q[3] = ax[2] * s;
@@ -322,55 +339,53 @@ __device__ __forceinline__ void inert_vec(double* r, const double* i, const doub
 // read back from LDS with j independent broadcast loads (one latency exposure per step instead of one per product).
 // The loops are fully unrolled over the compile-time bound NV so the row stays in VGPRs.  A is overwritten by L.
 __device__ double chol_solve_inplace(double* A, int n, int lane, double x) {
+  // The matrix is treated as NV x NV: rows/columns >= n hold the identity (callers keep that padding in LDS), so the
+  // whole routine is straight-line code without exec-mask juggling.  Lanes >= NV shadow row NV-1 and are ignored.
+  (void)n;
   double r[NV];
-  const int i = lane < n ? lane : 0;
+  const int i = lane < NV ? lane : NV - 1;
 #pragma unroll
-  for (int p = 0; p < NV; p++) r[p] = (p < n) ? A[i * LDV + p] : 0.0;
+  for (int p = 0; p < NV; p++) r[p] = A[i * LDV + p];
   double invd[NV];
-  // factorisation entirely in registers: row j of L is broadcast from lane j with v_readlane (no LDS round trip, no barrier)
 #pragma unroll
   for (int j = 0; j < NV; j++) {
-    if (j < n) {
-      double s0 = r[j], s1 = 0.0;
+    double s0 = r[j], s1 = 0.0;
 #pragma unroll
-      for (int p = 0; p + 1 < j; p += 2) {
-        s0 -= r[p] * bcast(r[p], j);
-        s1 -= r[p + 1] * bcast(r[p + 1], j);
-      }
-      if (j & 1) s0 -= r[j - 1] * bcast(r[j - 1], j);
-      const double s = s0 + s1;
-      const double piv = fmax(bcast(s, j), HMINVAL);
-      double id = __builtin_amdgcn_rsq(piv);
-      id = id * (1.5 - 0.5 * piv * id * id);
-      id = id * (1.5 - 0.5 * piv * id * id);
-      invd[j] = id;
-      r[j] = (lane == j) ? piv * id : s * id;
-    } else invd[j] = 0.0;
-  }
-  // forward substitution L y = x : column sweep, l_ij from registers
-#pragma unroll
-  for (int j = 0; j < NV; j++)
-    if (j < n) {
-      const double yj = bcast(x, j) * invd[j];
-      x = (lane == j) ? yj : ((lane > j) ? x - r[j] * yj : x);
+    for (int p = 0; p + 1 < j; p += 2) {
+      s0 -= r[p] * bcast(r[p], j);
+      s1 -= r[p + 1] * bcast(r[p + 1], j);
     }
-  // backward substitution L^T z = y needs column `lane` of L: one transposing pass through LDS
-  SYNC();
-  if (lane < n) {
+    if (j & 1) s0 -= r[j - 1] * bcast(r[j - 1], j);
+    const double s = s0 + s1;
+    const double piv = fmax(bcast(s, j), HMINVAL);
+    double id = __builtin_amdgcn_rsq(piv);
+    id = id * (1.5 - 0.5 * piv * id * id);
+    id = id * (1.5 - 0.5 * piv * id * id);
+    invd[j] = id;
+    r[j] = (lane == j) ? piv * id : s * id;
+  }
+  // forward substitution L y = x : column sweep, l_ij from registers (lanes < j keep their value)
 #pragma unroll
-    for (int p = 0; p < NV; p++)
-      if (p < n && p <= lane) A[lane * LDV + p] = r[p];
+  for (int j = 0; j < NV; j++) {
+    const double yj = bcast(x, j) * invd[j];
+    x = (lane == j) ? yj : ((lane > j) ? x - r[j] * yj : x);
+  }
+  // backward substitution L^T z = y needs column `lane` of L: one transposing pass through LDS (full rows, no predicates;
+  // the upper triangle receives don't-care values that nothing reads)
+  SYNC();
+  if (lane < NV) {
+#pragma unroll
+    for (int p = 0; p < NV; p++) A[lane * LDV + p] = r[p];
   }
   SYNC();
   double col[NV];
 #pragma unroll
-  for (int j = 0; j < NV; j++) col[j] = (j < n && lane < j) ? A[j * LDV + lane] : 0.0;
+  for (int j = 0; j < NV; j++) col[j] = A[j * LDV + i];
 #pragma unroll
-  for (int j = NV - 1; j >= 0; j--)
-    if (j < n) {
-      const double xj = bcast(x, j) * invd[j];
-      x = (lane == j) ? xj : ((lane < j) ? x - col[j] * xj : x);
-    }
+  for (int j = NV - 1; j >= 0; j--) {
+    const double xj = bcast(x, j) * invd[j];
+    x = (lane == j) ? xj : ((lane < j) ? x - col[j] * xj : x);
+  }
   return x;
 }
 
@@ -386,77 +401,88 @@ __device__ __forceinline__ double row_dot(const double* row, const double* v, in
 }
 
 // ------------------------------------------------------------------------------------------------ forward dynamics phases
+// mj_kinematics with rotation matrices: each lane precombines its body's local transform R_loc = R_body * R_joint(q)
+// (off the serial chain), so a tree level costs one 3x3 product and four matrix-vector products.
 __device__ void fwd_kinematics(const HModel& m, Lds& S, int lane) {
   if (lane == 0) {
     S.xpos[0] = S.xpos[1] = S.xpos[2] = 0;
-    S.U[U_XQUAT + 0] = 1; S.U[U_XQUAT + 1] = S.U[U_XQUAT + 2] = S.U[U_XQUAT + 3] = 0;
     for (int k = 0; k < 9; k++) S.U[U_XMAT + k] = (k % 4 == 0) ? 1.0 : 0.0;
     S.U[U_XIPOS + 0] = S.U[U_XIPOS + 1] = S.U[U_XIPOS + 2] = 0;
   }
-  // every lane fetches the constants of "its" body up front (bodies carry at most one joint: checked at create)
   const int b = lane;
   const bool valid = b >= 1 && b < m.nbody;
-  double kd[24];
-  int par = 0, mylvl = -1, jt = -1, qa = 0;
+  double kd[BD_NKIN];
+  int par = 0, mylvl = -1, jt = -1, qa = 0, ja = 0;
   if (valid) {
 #pragma unroll
-    for (int k = 0; k < 24; k++) kd[k] = m.body_d[BDS * b + k];
+    for (int k = 0; k < BD_NKIN; k++) kd[k] = m.body_d[BDS * b + k];
     par = m.body_i[BIS * b]; mylvl = m.body_i[BIS * b + 1]; jt = m.body_i[BIS * b + 2]; qa = m.body_i[BIS * b + 3];
+    ja = m.body_i[BIS * b + BI_JNTADR];
   }
-  const int ja = valid ? m.body_i[BIS * (b) + BI_JNTADR] : 0;
-  double qj = 0, sn = 0, cs = 1;
+  double Rloc[9], qj = 0;
+#pragma unroll
+  for (int k = 0; k < 9; k++) Rloc[k] = valid ? kd[BD_RBODY + k] : 0.0;
   if (valid && (jt == JT_HINGE || jt == JT_SLIDE)) {
-    qj = S.qpos[qa] - kd[23];
-    if (jt == JT_HINGE) sincos(0.5 * qj, &sn, &cs);  // joint rotation quaternion needs no parent data: off the serial chain
+    qj = S.qpos[qa] - kd[BD_Q0];
+    if (jt == JT_HINGE) {
+      double sn, cs;
+      sincos(qj, &sn, &cs);
+      const double ax = kd[BD_JAXIS], ay = kd[BD_JAXIS + 1], az = kd[BD_JAXIS + 2], t = 1.0 - cs;
+      const double Rj[9] = {cs + t * ax * ax, t * ax * ay - sn * az, t * ax * az + sn * ay,
+                            t * ax * ay + sn * az, cs + t * ay * ay, t * ay * az - sn * ax,
+                            t * ax * az - sn * ay, t * ay * az + sn * ax, cs + t * az * az};
+      double Rb[9];
+#pragma unroll
+      for (int k = 0; k < 9; k++) Rb[k] = Rloc[k];
+      mat_mul(Rloc, Rb, Rj);
+    }
   }
   SYNC();
   for (int lvl = 1; lvl < m.nlevel; lvl++) {
     if (mylvl == lvl) {
-      double xp[3], xq[4], R[9];
+      double xp[3], R[9];
       if (jt == JT_FREE) {
         double q[4] = {S.qpos[qa + 3], S.qpos[qa + 4], S.qpos[qa + 5], S.qpos[qa + 6]};
         normalize4(q);
-        for (int k = 0; k < 4; k++) { S.qpos[qa + 3 + k] = q[k]; xq[k] = q[k]; }
-        for (int k = 0; k < 3; k++) { xp[k] = S.qpos[qa + k]; S.U[U_XANCHOR + 3 * ja + k] = xp[k]; S.U[U_XAXIS + 3 * ja + k] = kd[17 + k]; }
+        for (int k = 0; k < 4; k++) S.qpos[qa + 3 + k] = q[k];
+        quat2mat(R, q);
+        for (int k = 0; k < 3; k++) { xp[k] = S.qpos[qa + k]; S.U[U_XANCHOR + 3 * ja + k] = xp[k]; S.U[U_XAXIS + 3 * ja + k] = kd[BD_JAXIS + k]; }
       } else {
-        double t[3];
-        double pq[4] = {S.U[U_XQUAT + 4 * par], S.U[U_XQUAT + 4 * par + 1], S.U[U_XQUAT + 4 * par + 2], S.U[U_XQUAT + 4 * par + 3]};
-        mat_vec(t, &S.U[U_XMAT + 9 * par], kd);
+        double Rp[9], t[3];
+#pragma unroll
+        for (int k = 0; k < 9; k++) Rp[k] = S.U[U_XMAT + 9 * par + k];
+        mat_vec(t, Rp, kd + BD_POS);
         for (int k = 0; k < 3; k++) xp[k] = S.xpos[3 * par + k] + t[k];
-        mul_quat(xq, pq, kd + 3);
+        mat_mul(R, Rp, Rloc);
         if (jt >= 0) {
           double waxis[3], anchor[3];
-          quat2mat(R, xq);
-          mat_vec(waxis, R, kd + 17);
-          mat_vec(anchor, R, kd + 20);
+          mat_vec(waxis, Rp, kd + BD_V2);
+          mat_vec(anchor, Rp, kd + BD_V1);
           for (int k = 0; k < 3; k++) { anchor[k] += xp[k]; S.U[U_XANCHOR + 3 * ja + k] = anchor[k]; S.U[U_XAXIS + 3 * ja + k] = waxis[k]; }
           if (jt == JT_SLIDE) {
             for (int k = 0; k < 3; k++) xp[k] += waxis[k] * qj;
           } else {
-            double ql[4] = {cs, kd[17] * sn, kd[18] * sn, kd[19] * sn}, v[3];
-            mul_quat(xq, xq, ql);
-            quat2mat(R, xq);
-            mat_vec(v, R, kd + 20);
+            double v[3];
+            mat_vec(v, R, kd + BD_JPOS);
             for (int k = 0; k < 3; k++) xp[k] = anchor[k] - v[k];
           }
         }
       }
-      normalize4(xq);
-      quat2mat(R, xq);
       double t[3];
-      mat_vec(t, R, kd + 7);
+      mat_vec(t, R, kd + BD_IPOS);
       for (int k = 0; k < 3; k++) { S.xpos[3 * b + k] = xp[k]; S.U[U_XIPOS + 3 * b + k] = xp[k] + t[k]; }
-      for (int k = 0; k < 4; k++) S.U[U_XQUAT + 4 * b + k] = xq[k];
+#pragma unroll
       for (int k = 0; k < 9; k++) S.U[U_XMAT + 9 * b + k] = R[k];
     }
     SYNC();
   }
   // rotated inertia T = Ri diag(I) Ri^T of each body (completed with the com offset in fwd_com): all bodies at once
   if (valid) {
-    double xq[4] = {S.U[U_XQUAT + 4 * b], S.U[U_XQUAT + 4 * b + 1], S.U[U_XQUAT + 4 * b + 2], S.U[U_XQUAT + 4 * b + 3]}, qi[4], Ri[9];
-    mul_quat(qi, xq, kd + 10);
-    quat2mat(Ri, qi);
-    const double I0 = kd[14], I1 = kd[15], I2 = kd[16];
+    double R[9], Ri[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) R[k] = S.U[U_XMAT + 9 * b + k];
+    mat_mul(Ri, R, kd + BD_RINERT);
+    const double I0 = kd[BD_INERTIA], I1 = kd[BD_INERTIA + 1], I2 = kd[BD_INERTIA + 2];
     double* ci = &S.U[U_CINERT + 10 * b];
     ci[0] = Ri[0] * I0 * Ri[0] + Ri[1] * I1 * Ri[1] + Ri[2] * I2 * Ri[2];
     ci[1] = Ri[3] * I0 * Ri[3] + Ri[4] * I1 * Ri[4] + Ri[5] * I2 * Ri[5];
@@ -524,7 +550,10 @@ __device__ void fwd_crb(const HModel& m, Lds& S, int lane) {
     if (b >= 1) for (int d = b; d < m.body_i[BIS * (b) + BI_SUBEND]; d++) s += S.U[U_CINERT + 10 * d + k];
     S.U[U_CRB + it] = s;
   }
-  for (int it = lane; it < m.nv * LDV; it += 64) S.M[it] = 0;
+  for (int it = lane; it < NV * LDV; it += 64) {
+    const int i = it / LDV, j = it - i * LDV;
+    S.M[it] = (i == j && i >= m.nv) ? 1.0 : 0.0;
+  }
   SYNC();
   // vec scratch: buf_i = crb[body(i)] * cdof_i  kept in csub (6 per dof)
   if (lane < m.nv) {
@@ -668,11 +697,11 @@ __device__ void fwd_collision(const HModel& m, Lds& S, int lane) {
   if (lane < m.ngeom) {
     const int g = lane, b = m.geom_i[GIS * (g) + GI_BODY];
     double gp[3] = {m.geom_d[GDS * (g) + GD_POS], m.geom_d[GDS * (g) + GD_POS + 1], m.geom_d[GDS * (g) + GD_POS + 2]}, t[3];
-    double gq[4] = {m.geom_d[GDS * (g) + GD_QUAT], m.geom_d[GDS * (g) + GD_QUAT + 1], m.geom_d[GDS * (g) + GD_QUAT + 2], m.geom_d[GDS * (g) + GD_QUAT + 3]}, q[4], R[9];
-    double bq[4] = {S.U[U_XQUAT + 4 * b], S.U[U_XQUAT + 4 * b + 1], S.U[U_XQUAT + 4 * b + 2], S.U[U_XQUAT + 4 * b + 3]};
-    mat_vec(t, &S.U[U_XMAT + 9 * b], gp);
-    mul_quat(q, bq, gq);
-    quat2mat(R, q);
+    double Rl[9], Rb[9], R[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) { Rl[k] = m.geom_d[GDS * g + GD_RLOC + k]; Rb[k] = S.U[U_XMAT + 9 * b + k]; }
+    mat_vec(t, Rb, gp);
+    mat_mul(R, Rb, Rl);
     for (int k = 0; k < 3; k++) S.U[U_GPOS + 3 * g + k] = S.xpos[3 * b + k] + t[k];
     for (int k = 0; k < 9; k++) S.U[U_GMAT + 9 * g + k] = R[k];
   }
@@ -984,7 +1013,7 @@ __device__ __forceinline__ void substep(const HModel& m, Lds& S, int lane, int f
   SYNC();
   PROF_MARK(11);
   // factor M (copy in H), qacc_smooth
-  for (int it = lane; it < nv * LDV; it += 64) S.U[U_H + it] = S.M[it];
+  for (int it = lane; it < NV * LDV; it += 64) S.U[U_H + it] = S.M[it];
   SYNC();
   const double as = chol_solve_inplace(S.U + U_H, nv, lane, fs);
   PROF_MARK(12);
@@ -1101,7 +1130,7 @@ __device__ __forceinline__ void substep(const HModel& m, Lds& S, int lane, int f
   const double h = m.timestep;
   const bool eulerdamp = !(m.disableflags & (1 << 14));
   if (eulerdamp) {
-    for (int it = lane; it < nv * LDV; it += 64) S.U[U_H + it] = S.M[it];
+    for (int it = lane; it < NV * LDV; it += 64) S.U[U_H + it] = S.M[it];
     SYNC();
     if (lane < nv) S.U[U_H + lane * LDV + lane] += h * m.dof_d[DDS * (lane) + DD_DAMPING];
     SYNC();
@@ -1386,6 +1415,14 @@ __global__ void __launch_bounds__(64, 2) humanoid_kernel(HModel m, HParams p, HS
 }
 
 // ------------------------------------------------------------------------------------------------ host side
+static void h_quat2mat(double* R, const double* q) {
+  const double q00 = q[0] * q[0], q11 = q[1] * q[1], q22 = q[2] * q[2], q33 = q[3] * q[3];
+  const double q01 = q[0] * q[1], q02 = q[0] * q[2], q03 = q[0] * q[3], q12 = q[1] * q[2], q13 = q[1] * q[3], q23 = q[2] * q[3];
+  R[0] = q00 + q11 - q22 - q33; R[4] = q00 - q11 + q22 - q33; R[8] = q00 - q11 - q22 + q33;
+  R[1] = 2 * (q12 - q03); R[2] = 2 * (q13 + q02); R[3] = 2 * (q12 + q03);
+  R[5] = 2 * (q23 - q01); R[6] = 2 * (q13 - q02); R[7] = 2 * (q23 + q01);
+}
+
 template <typename T>
 static const T* to_dev(HumanoidEnv* h, const T* src, size_t n) {
   void* d = nullptr;
@@ -1468,8 +1505,9 @@ int humanoid_create(HumanoidEnv** out, const std::vector<int32_t>& mi, const std
       act_i((size_t)nu * AIS, 0), pair_i((size_t)np * 2, 0);
   for (int b = 0; b < nb; b++) {
     double* k = &body_d[(size_t)BDS * b];
-    for (int a = 0; a < 3; a++) { k[a] = DF(LHW_DF_BODY_POS)[3 * b + a]; k[7 + a] = DF(LHW_DF_BODY_IPOS)[3 * b + a]; k[14 + a] = DF(LHW_DF_BODY_INERTIA)[3 * b + a]; }
-    for (int a = 0; a < 4; a++) { k[3 + a] = DF(LHW_DF_BODY_QUAT)[4 * b + a]; k[10 + a] = DF(LHW_DF_BODY_IQUAT)[4 * b + a]; }
+    for (int a = 0; a < 3; a++) { k[BD_POS + a] = DF(LHW_DF_BODY_POS)[3 * b + a]; k[BD_IPOS + a] = DF(LHW_DF_BODY_IPOS)[3 * b + a]; k[BD_INERTIA + a] = DF(LHW_DF_BODY_INERTIA)[3 * b + a]; }
+    h_quat2mat(k + BD_RBODY, DF(LHW_DF_BODY_QUAT) + 4 * b);
+    h_quat2mat(k + BD_RINERT, DF(LHW_DF_BODY_IQUAT) + 4 * b);
     k[BD_MASS] = DF(LHW_DF_BODY_MASS)[b];
     k[BD_INVW] = DF(LHW_DF_BODY_INVWEIGHT0)[2 * b]; k[BD_INVW + 1] = DF(LHW_DF_BODY_INVWEIGHT0)[2 * b + 1];
     const int jn = IF(LHW_IF_BODY_JNTNUM)[b], ja = IF(LHW_IF_BODY_JNTADR)[b];
@@ -1478,9 +1516,13 @@ int humanoid_create(HumanoidEnv** out, const std::vector<int32_t>& mi, const std
     bi[BI_ROOT] = rootid[b]; bi[BI_SUBEND] = subend[b]; bi[BI_DOFMASK] = (int)bmask[b]; bi[BI_JNTADR] = ja < 0 ? 0 : ja;
     if (jn > 1) { humanoid_destroy(h); return lhw_fail(LHW_ERR_UNSUPPORTED, "bodies with more than one joint are not supported by the wave-per-env stepper"); }
     if (jn == 1) {
-      for (int a = 0; a < 3; a++) { k[17 + a] = DF(LHW_DF_JNT_AXIS)[3 * ja + a]; k[20 + a] = DF(LHW_DF_JNT_POS)[3 * ja + a]; }
+      for (int a = 0; a < 3; a++) { k[BD_JAXIS + a] = DF(LHW_DF_JNT_AXIS)[3 * ja + a]; k[BD_JPOS + a] = DF(LHW_DF_JNT_POS)[3 * ja + a]; }
+      for (int a = 0; a < 3; a++) {  // R_body * jnt_pos and R_body * jnt_axis (anchor / axis in the parent frame)
+        k[BD_V1 + a] = k[BD_RBODY + 3 * a] * k[BD_JPOS] + k[BD_RBODY + 3 * a + 1] * k[BD_JPOS + 1] + k[BD_RBODY + 3 * a + 2] * k[BD_JPOS + 2];
+        k[BD_V2 + a] = k[BD_RBODY + 3 * a] * k[BD_JAXIS] + k[BD_RBODY + 3 * a + 1] * k[BD_JAXIS + 1] + k[BD_RBODY + 3 * a + 2] * k[BD_JAXIS + 2];
+      }
       bi[2] = jtype[ja]; bi[3] = IF(LHW_IF_JNT_QPOSADR)[ja];
-      k[23] = jtype[ja] == JT_FREE ? 0.0 : DF(LHW_DF_QPOS0)[IF(LHW_IF_JNT_QPOSADR)[ja]];
+      k[BD_Q0] = jtype[ja] == JT_FREE ? 0.0 : DF(LHW_DF_QPOS0)[IF(LHW_IF_JNT_QPOSADR)[ja]];
     }
   }
   for (int j = 0; j < nj; j++) {
@@ -1504,7 +1546,7 @@ int humanoid_create(HumanoidEnv** out, const std::vector<int32_t>& mi, const std
   for (int g = 0; g < ng; g++) {
     double* k = &geom_d[(size_t)GDS * g];
     for (int a = 0; a < 3; a++) { k[GD_POS + a] = DF(LHW_DF_GEOM_POS)[3 * g + a]; k[GD_SIZE + a] = DF(LHW_DF_GEOM_SIZE)[3 * g + a]; k[GD_FRICTION + a] = DF(LHW_DF_GEOM_FRICTION)[3 * g + a]; }
-    for (int a = 0; a < 4; a++) k[GD_QUAT + a] = DF(LHW_DF_GEOM_QUAT)[4 * g + a];
+    h_quat2mat(k + GD_RLOC, DF(LHW_DF_GEOM_QUAT) + 4 * g);
     k[GD_SOLMIX] = DF(LHW_DF_GEOM_SOLMIX)[g];
     k[GD_SOLREF] = DF(LHW_DF_GEOM_SOLREF)[2 * g]; k[GD_SOLREF + 1] = DF(LHW_DF_GEOM_SOLREF)[2 * g + 1];
     for (int a = 0; a < 5; a++) k[GD_SOLIMP + a] = DF(LHW_DF_GEOM_SOLIMP)[5 * g + a];
