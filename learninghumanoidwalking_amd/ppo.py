@@ -147,14 +147,28 @@ class PPO:
             device=self.device, learn_std=args.learn_std, lr=self.lr, eps=self.eps, clip=self.clip,
             entropy_coeff=self.ent_coeff, mirror_coeff=self.mirror_coeff, max_grad_norm=self.grad_clip,
             mirror_obs=mirror[0] if mirror else None, mirror_act=mirror[1] if mirror else None)
-        if getattr(args, "continued", None):
-            raise NotImplementedError("--continued (checkpoint interop) is not built yet (SURVEY.md 8f n1)")
-        # identical initial weights on every rank: the reference's init path under a fixed torch seed
-        gen_seed = seed if seed is not None else 0
-        cpu_state = torch.random.get_rng_state()
-        self.kernels.set_tensors(reference_init(obs_dim, act_dim, 256, args.std_dev, generator_seed=gen_seed))
-        torch.random.set_rng_state(cpu_state)
-        if spec.obs_mean is not None:
+        continued = getattr(args, "continued", None)
+        if continued:
+            # --continued actor_X.pt: load actor + sibling critic, re-initialise stds, keep the embedded obs
+            # normalisation (reference rl/algos/ppo.py:69-82)
+            from .checkpoint import load_reference_checkpoint
+            cpath = Path(Path(continued).parent, "critic" + str(continued).split("actor")[1])
+            t, om, osd = load_reference_checkpoint(continued, cpath)
+            t["stds"] = args.std_dev * torch.ones(act_dim)
+            self.kernels.set_tensors(t)
+            self.kernels.set_obs_norm(om.numpy(), osd.numpy())
+            self.obs_rms = None
+            print("Loaded (pre-trained) actor from: ", continued)
+            print("Loaded (pre-trained) critic from: ", cpath)
+        else:
+            # identical initial weights on every rank: the reference's init path under a fixed torch seed
+            gen_seed = seed if seed is not None else 0
+            cpu_state = torch.random.get_rng_state()
+            self.kernels.set_tensors(reference_init(obs_dim, act_dim, 256, args.std_dev, generator_seed=gen_seed))
+            torch.random.set_rng_state(cpu_state)
+        if continued:
+            pass
+        elif spec.obs_mean is not None:
             self.obs_rms = None
             self.kernels.set_obs_norm(spec.obs_mean, spec.obs_std)
             print("Using fixed observation normalization from environment.")
@@ -269,20 +283,17 @@ class PPO:
     # ------------------------------------------------------------------ checkpoints / eval
     def save(self, itr, metric=None):
         """actor_{itr}.pt / critic_{itr}.pt (+ actor.pt / critic.pt when the metric improves), like
-        ModelCheckpointer.save_if_best (reference rl/utils/checkpointer.py:54-83).  The files hold plain
-        state dicts in torch layouts (pickling the reference's module classes is row n1 of SURVEY.md 8f)."""
+        ModelCheckpointer.save_if_best (reference rl/utils/checkpointer.py:54-83).  The files are whole-module
+        pickles naming the reference's classes, so `run_experiment.py eval` / `--continued` of the reference load them."""
         if self.rank != 0:
             return
+        from .checkpoint import save_reference_checkpoint
         t = self.kernels.get_tensors()
-        extra = dict(obs_mean=self.kernels.obs_mean.cpu(), obs_std=self.kernels.obs_std.cpu())
-        actor = {k2: v for k2, v in t.items() if k2.startswith("a_") or k2 == "stds"} | extra
-        critic = {k2: v for k2, v in t.items() if k2.startswith("c_")} | extra
-        torch.save(actor, self.save_path / f"actor_{itr}.pt")
-        torch.save(critic, self.save_path / f"critic_{itr}.pt")
+        om, osd = self.kernels.obs_mean.cpu(), self.kernels.obs_std.cpu()
+        save_reference_checkpoint(t, om, osd, self.kernels.learn_std, self.save_path / f"actor_{itr}.pt", self.save_path / f"critic_{itr}.pt")
         if metric is not None and metric > self.best_metric:
             self.best_metric = metric
-            torch.save(actor, self.save_path / "actor.pt")
-            torch.save(critic, self.save_path / "critic.pt")
+            save_reference_checkpoint(t, om, osd, self.kernels.learn_std, self.save_path / "actor.pt", self.save_path / "critic.pt")
 
     def evaluate(self, itr, num_batches=5):
         """5 deterministic batches on the same persistent envs (ppo.py:408-426)."""

@@ -46,6 +46,12 @@ def test_run_experiment_train_cartpole(tmp_path):
     assert len(run) == 1
     files = os.listdir(os.path.join(tmp_path, run[0]))
     assert "actor_0.pt" in files and "critic_0.pt" in files and "experiment.pkl" in files
+    # --continued from the checkpoint just written (reference tests/test_evaluation.py: train -> save -> load -> continue)
+    actor = os.path.join(tmp_path, run[0], "actor_0.pt")
+    cmd2 = [c for c in cmd if c not in ("--learn-std",)] + ["--continued", actor, "--n-itr", "1"]
+    out2 = subprocess.run(cmd2, capture_output=True, text=True, timeout=600)
+    assert out2.returncode == 0, out2.stdout[-2000:] + out2.stderr[-2000:]
+    assert "Loaded (pre-trained) actor from" in out2.stdout
 
 
 def test_ppo_learns_cartpole_a_little():
