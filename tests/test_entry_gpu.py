@@ -74,3 +74,20 @@ def test_ppo_learns_cartpole_a_little():
         rets.append(rs / max(cnt, 1))
         assert np.isfinite(list(algo.last_losses.values())).all()
     assert np.mean(rets[-3:]) > np.mean(rets[:3]) * 1.05, rets
+
+
+def test_bench_two_ranks_sharing_one_gpu():
+    """N>1 path of bench.py end to end (env sharding, gradient / advantage all-reduces, max-over-ranks timing) with two
+    ranks on the one GPU of the test box over gloo; on the 8-GPU node the same code runs one rank per GPU over RCCL."""
+    import json
+    env = dict(os.environ, LHW_SHARE_GPU="1", MASTER_ADDR="127.0.0.1")
+    port = 29600 + (os.getpid() % 1000)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
+           "--num-envs", "128", "--traj-len", "8", "--minibatch-size", "256", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    assert abs(d["value"] - 2 * 128 * 8 / (d["ms_per_step"] / 1e3)) / d["value"] < 1e-6   # whole-job aggregate
