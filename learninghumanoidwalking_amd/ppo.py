@@ -177,6 +177,7 @@ class PPO:
             self.kernels.set_obs_norm(self.obs_rms.mean, self.obs_rms.std)
             print("Using running observation normalization (will update during training).")
         env_seed = (seed if seed is not None else int(time.time())) & 0x7FFFFFFF
+        self.env_seed = env_seed
         self.env = spec.make_batched(self.n_proc, seed=env_seed, device=self.device, max_traj_len=self.max_traj_len,
                                      env_id_base=dist_utils.shard_env_ids(self.n_proc, self.rank))
         self.env.env_id_base = dist_utils.shard_env_ids(self.n_proc, self.rank)
