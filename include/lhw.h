@@ -56,7 +56,8 @@ typedef enum {
 
 typedef enum {
   LHW_TASK_CARTPOLE = 0, /* reference envs/cartpole/cartpole_env.py */
-  LHW_TASK_JVRC_WALK = 1 /* reference envs/jvrc/jvrc_walk.py + tasks/walking_task.py */
+  LHW_TASK_JVRC_WALK = 1, /* reference envs/jvrc/jvrc_walk.py + tasks/walking_task.py */
+  LHW_TASK_H1_STAND = 2   /* reference envs/h1/h1_env.py + tasks/standing_task.py (+ domain_randomization.py) */
 } LhwTask;
 
 /* done flags written by lhw_env_step */
@@ -87,10 +88,15 @@ typedef struct {
   int32_t period;
 } LhwEnvConfig;
 
-/* task_params indices (walking) */
-enum { LHW_TP_GOAL_HEIGHT = 0, LHW_TP_COUNT = 1 };
-/* task_iparams indices (walking): body ids */
-enum { LHW_TI_ROOT_BODY = 0, LHW_TI_HEAD_BODY = 1, LHW_TI_RFOOT_BODY = 2, LHW_TI_LFOOT_BODY = 3, LHW_TI_COUNT = 4 };
+/* task_params indices: [0] target root height (walking goal_height / standing 0.98); H1 standing adds the
+ * init-noise half-width (rad), perturbation force / torque magnitudes and 35 per-entry observation-noise half-widths */
+enum { LHW_TP_GOAL_HEIGHT = 0, LHW_TP_COUNT = 1, LHW_TP_H1_INIT_NOISE = 1, LHW_TP_H1_FORCE_MAG = 2, LHW_TP_H1_TORQUE_MAG = 3,
+       LHW_TP_H1_OBS_NOISE = 4 };
+/* task_iparams indices: body ids of root, head (walking) / torso (standing), right foot, left foot; H1 standing adds the
+ * randomisation intervals in control steps, the perturbed bodies, and the randomised dofs (10) and bodies (11) */
+enum { LHW_TI_ROOT_BODY = 0, LHW_TI_HEAD_BODY = 1, LHW_TI_RFOOT_BODY = 2, LHW_TI_LFOOT_BODY = 3, LHW_TI_COUNT = 4,
+       LHW_TI_H1_DYNRAND_INTERVAL = 4, LHW_TI_H1_PERTURB_INTERVAL = 5, LHW_TI_H1_N_PBODY = 6, LHW_TI_H1_PBODY = 7,
+       LHW_TI_H1_RAND_DOF = 9, LHW_TI_H1_RAND_BODY = 19 };
 
 int lhw_version(void);
 const char* lhw_last_error(void);

@@ -14,7 +14,7 @@ import torch
 from . import _lib
 from .model import Model
 
-TASK_CARTPOLE, TASK_JVRC_WALK = 0, 1
+TASK_CARTPOLE, TASK_JVRC_WALK, TASK_H1_STAND = 0, 1, 2
 DONE_TERMINATED, DONE_TRUNCATED = 1, 2
 
 

@@ -70,7 +70,18 @@ static_assert(R_EPRET < REC_D, "record too small");
 #define RI_STEPCNT 3
 #define RI_RESETCNT 4
 #define RI_STARTED 5  // prev_action / prev_torque initialised (robot_base.py:82-85: only once, never reset)
+#define RI_OBSCNT 6   // number of get_obs calls so far (observation-noise RNG counter)
 #define REC_I 8
+// per-env model parameters touched by dynamics randomisation / perturbation (domain_randomization.py:10-56)
+#define P_DAMP 0
+#define P_FLOSS (P_DAMP + NV)
+#define P_MASS (P_FLOSS + NV)
+#define P_IPOS (P_MASS + NB)
+#define P_XFRC (P_IPOS + NB * 3)  // xfrc_applied of up to two perturbed bodies: force3 torque3 each
+#define PRM_D 128
+static_assert(P_XFRC + 12 <= PRM_D, "parameter record too small");
+enum { TASK_WALK = 1, TASK_STAND = 2 };
+enum { LHW_STREAM_OBS = 4 };
 
 // Model constants, packed host-side into one array-of-structs table per "lane role" (body, joint, dof, geom, pair,
 // actuator): a lane fetches the record of its body/dof/... with one burst of independent loads, and the kernel argument
@@ -106,10 +117,13 @@ static_assert(R_EPRET < REC_D, "record too small");
 #define JI_LIMITED 1
 #define JI_QADR 2
 #define JI_DADR 3
-#define DDS 4   // dof_d: armature damping invweight0 pad
+#define DDS 12  // dof_d: armature damping invweight0 frictionloss solref2 solimp5 pad
 #define DD_ARMATURE 0
 #define DD_DAMPING 1
 #define DD_INVW 2
+#define DD_FLOSS 3
+#define DD_SOLREF 4
+#define DD_SOLIMP 6
 #define DIS 4   // dof_i: body joint kind(0 free-trans 1 free-rot 2 slide 3 hinge) prevmask
 #define DI_BODY 0
 #define DI_JNT 1
@@ -149,17 +163,21 @@ struct HModel {
 };
 
 struct HParams {
-  int n_envs, frame_skip, max_traj_len, period;
+  int n_envs, frame_skip, max_traj_len, period, task;
   int root_body, head_body, rfoot_body, lfoot_body;
+  int env_params;                       // 1: damping / frictionloss / mass / ipos / xfrc come from the per-env record
+  int dynrand_interval, perturb_interval, n_pbody, pbody[2];
+  int rand_dof[10], rand_body[11], n_rand_dof, n_rand_body;
   unsigned env_id_base;
   unsigned long long seed;
-  double action_smoothing, goal_height;
-  const double *kp, *kd, *nominal_qpos, *action_offset, *clock_lut, *neutral_pose;
+  double action_smoothing, goal_height, init_noise, force_mag, torque_mag;
+  const double *kp, *kd, *nominal_qpos, *action_offset, *clock_lut, *neutral_pose, *obs_noise;
 };
 
 struct HState {
   double* rec;     // [N][REC_D]
   int* irec;       // [N][REC_I]
+  double* prm;     // [N][PRM_D] per-env model parameters (NULL unless the task randomises them)
   double* ep_stats;
   long long* prof; // optional [16] per-phase cycle counters accumulated by env 0 (NULL = off)
 };
@@ -209,9 +227,10 @@ struct HumanoidEnv {
 #define U_EK (U_EMARGIN + NE)
 #define U_EB (U_EK + NE)
 #define U_EIMP (U_EB + NE)
+#define U_EFL (U_EIMP + NE)
 #define U_END_C (U_H + NV * LDV)
 #define USIZE (U_END_C > U_END_B ? (U_END_C > U_END_A ? U_END_C : U_END_A) : (U_END_B > U_END_A ? U_END_B : U_END_A))
-static_assert(U_EIMP + NE <= U_END_C, "efc row parameters must fit in the H slot");
+static_assert(U_EFL + NE <= U_END_C, "efc row parameters must fit in the H slot");
 
 struct Lds {
   double qpos[NQ], qvel[NV], ctrl[NU];
@@ -225,6 +244,7 @@ struct Lds {
   double con_dist[NC], con_pos[NC * 3], con_frame[NC * 9], con_mu[NC], con_solref[NC * 2], con_solimp[NC * 5], con_margin[NC];
   int con_g1[NC], con_g2[NC], con_dim[NC], con_row[NC];
   double sq[NU], sv[NU], frc[NU];
+  double damp[NV], floss[NV], bmass[NB], bipos[NB * 3], xfrc[12];  // per-env parameters, loaded once per launch
   double U[USIZE];
   int ncon, nefc, nlim, overflow;
 };
@@ -469,7 +489,7 @@ __device__ void fwd_kinematics(const HModel& m, Lds& S, int lane) {
         }
       }
       double t[3];
-      mat_vec(t, R, kd + BD_IPOS);
+      mat_vec(t, R, &S.bipos[3 * b]);
       for (int k = 0; k < 3; k++) { S.xpos[3 * b + k] = xp[k]; S.U[U_XIPOS + 3 * b + k] = xp[k] + t[k]; }
 #pragma unroll
       for (int k = 0; k < 9; k++) S.U[U_XMAT + 9 * b + k] = R[k];
@@ -495,10 +515,10 @@ __device__ void fwd_kinematics(const HModel& m, Lds& S, int lane) {
 }
 
 // subtree com of the (single) dynamic tree rooted at body 1, cinert, cdof  (mj_comPos)
-__device__ void fwd_com(const HModel& m, Lds& S, int lane) {
+__device__ double fwd_com(const HModel& m, const HParams& p, Lds& S, int lane) {
   double ms = 0, mx = 0, my = 0, mz = 0;
   if (lane >= 1 && lane < m.nbody && m.body_i[BIS * (lane) + BI_ROOT] == 1) {
-    ms = m.body_d[BDS * (lane) + BD_MASS];
+    ms = S.bmass[lane];
     mx = ms * S.U[U_XIPOS + 3 * lane]; my = ms * S.U[U_XIPOS + 3 * lane + 1]; mz = ms * S.U[U_XIPOS + 3 * lane + 2];
   }
   ms = wave_sum(ms); mx = wave_sum(mx); my = wave_sum(my); mz = wave_sum(mz);
@@ -506,7 +526,7 @@ __device__ void fwd_com(const HModel& m, Lds& S, int lane) {
   if (lane == 0) { S.com[0] = com[0]; S.com[1] = com[1]; S.com[2] = com[2]; }
   if (lane >= 1 && lane < m.nbody) {
     const int b = lane;
-    const double mass = m.body_d[BDS * (b) + BD_MASS];
+    const double mass = S.bmass[b];
     // static bodies (their own root) use their own com as reference; they never enter M or the bias force
     const bool dyn = m.body_i[BIS * (b) + BI_ROOT] == 1;
     double dif[3];
@@ -540,6 +560,20 @@ __device__ void fwd_com(const HModel& m, Lds& S, int lane) {
     for (int a = 0; a < 6; a++) S.cdof[6 * d + a] = c[a];
   }
   SYNC();
+  // mj_xfrcAccumulate: Cartesian force / torque applied at the com of the perturbed bodies -> joint space
+  double qapp = 0;
+  if (p.env_params && lane < m.nv) {
+    for (int k = 0; k < p.n_pbody; k++) {
+      const int pb = p.pbody[k];
+      if (!(((unsigned)m.body_i[BIS * pb + BI_DOFMASK] >> lane) & 1u)) continue;
+      double off[3], t[3];
+      for (int a = 0; a < 3; a++) off[a] = S.U[U_XIPOS + 3 * pb + a] - com[a];
+      cross3(t, &S.cdof[6 * lane], off);
+      for (int a = 0; a < 3; a++)
+        qapp += (S.cdof[6 * lane + 3 + a] + t[a]) * S.xfrc[6 * k + a] + S.cdof[6 * lane + a] * S.xfrc[6 * k + 3 + a];
+    }
+  }
+  return qapp;
 }
 
 // composite inertias + joint-space inertia M (mj_crb); lower triangle + mirrored upper
@@ -793,6 +827,10 @@ __device__ __forceinline__ void row_params(const HModel& m, const double* sr_in,
 
 // mj_makeConstraint: joint-limit rows, then contact rows (pyramidal), with mj_makeImpedance's shared pyramid R
 __device__ void fwd_constraints(const HModel& m, Lds& S, int lane) {
+  // ---- frictionloss rows: lane = dof (mj_instantiateFriction); they come first
+  const double myfl = lane < m.nv ? S.floss[lane] : 0.0;
+  int nfr;
+  const int fbase = wave_scan(myfl > 0 ? 1 : 0, &nfr) - (myfl > 0 ? 1 : 0);
   // ---- limits: lane = joint; rows ordered by joint, lower side first
   int nl = 0, lo = 0, hi = 0;
   double dlo = 0, dhi = 0;
@@ -803,7 +841,8 @@ __device__ void fwd_constraints(const HModel& m, Lds& S, int lane) {
     nl = lo + hi;
   }
   int nlim;
-  const int lbase = wave_scan(nl, &nlim) - nl;
+  const int lbase = nfr + wave_scan(nl, &nlim) - nl;
+  nlim += nfr;  // rows that precede the contact rows
   // ---- contacts: lane = contact; rows = 4 (condim 3), 1 (condim 1) or 0 (excluded)
   int nr = 0;
   if (lane < S.ncon) nr = S.con_dim[lane] == 3 ? 4 : (S.con_dim[lane] == 1 ? 1 : 0);
@@ -818,7 +857,17 @@ __device__ void fwd_constraints(const HModel& m, Lds& S, int lane) {
   }
   const int nefc = wave_max_i(rend);
   for (int it = lane; it < nefc * LDV; it += 64) S.U[U_J + it] = 0;
+  if (lane < NE) S.U[U_EFL + lane] = 0;
   SYNC();
+  if (myfl > 0 && fbase < NE) {
+    const int d = lane, r = fbase;
+    double sr[2] = {m.dof_d[DDS * d + DD_SOLREF], m.dof_d[DDS * d + DD_SOLREF + 1]}, si[5], K, B, imp, R;
+    for (int a = 0; a < 5; a++) si[a] = m.dof_d[DDS * d + DD_SOLIMP + a];
+    row_params(m, sr, si, 0.0, 0.0, m.dof_d[DDS * d + DD_INVW], &K, &B, &imp, &R);
+    S.U[U_J + r * LDV + d] = 1.0;
+    S.U[U_EPOS + r] = 0; S.U[U_EMARGIN + r] = 0; S.efc_D[r] = 1 / R; S.U[U_EK + r] = K; S.U[U_EB + r] = B; S.U[U_EIMP + r] = imp;
+    S.U[U_EFL + r] = myfl;
+  }
   if (nl > 0) {
     const int j = lane, d = m.jnt_i[JIS * (j) + JI_DADR];
     int r = lbase;
@@ -946,15 +995,43 @@ __device__ double fwd_velocity(const HModel& m, Lds& S, int lane) {
   return bias;
 }
 
+// mj_constraintUpdate for one row at residual x = J a - aref: limit / contact rows are one-sided quadratics, frictionloss
+// rows (fl > 0) are Huber: quadratic for |x| < R fl, linear beyond with |force| = fl.
+__device__ __forceinline__ void row_eval(bool valid, double fl, double D, double x, double* cost, double* force, double* dact) {
+  double c = 0, f = 0, da = 0;
+  if (valid) {
+    if (fl > 0) {
+      const double Rf = fl / D;
+      if (x <= -Rf) { f = fl; c = -0.5 * Rf * fl - fl * x; }
+      else if (x >= Rf) { f = -fl; c = -0.5 * Rf * fl + fl * x; }
+      else { f = -D * x; c = 0.5 * D * x * x; da = D; }
+    } else if (x < 0) { f = -D * x; c = 0.5 * D * x * x; da = D; }
+  }
+  *cost = c; *force = f; *dact = da;
+}
+// first / second derivative contributions of one row along the search direction (jv = J search)
+__device__ __forceinline__ void row_deriv(bool valid, double fl, double D, double x, double jv, double* d1, double* d2) {
+  double a = 0, b = 0;
+  if (valid) {
+    if (fl > 0) {
+      const double Rf = fl / D;
+      if (x <= -Rf) a = -fl * jv;
+      else if (x >= Rf) a = fl * jv;
+      else { a = D * x * jv; b = D * jv * jv; }
+    } else if (x < 0) { a = D * x * jv; b = D * jv * jv; }
+  }
+  *d1 = a; *d2 = b;
+}
+
 // One mj_forward (+ Euler).  flags: bit0 actuation enabled, bit1 integrate.
 // On return S.qacc / S.efc_force / contacts / S.sq,sv,frc describe THIS forward pass (the "stale" fields of note S).
-__device__ __forceinline__ void substep(const HModel& m, Lds& S, int lane, int flags, double* warm /* lane-held */, long long* st_prof) {
+__device__ __forceinline__ void substep(const HModel& m, const HParams& p, Lds& S, int lane, int flags, double* warm /* lane-held */, long long* st_prof) {
   PROF_BEGIN();
   fwd_kinematics(m, S, lane);
   PROF_MARK(0);
   fwd_collision(m, S, lane);   // stage A temporaries (geom frames) die here
   PROF_MARK(3);
-  fwd_com(m, S, lane);
+  const double qapp = fwd_com(m, p, S, lane);
   PROF_MARK(1);
   fwd_crb(m, S, lane);
   PROF_MARK(2);
@@ -986,7 +1063,7 @@ __device__ __forceinline__ void substep(const HModel& m, Lds& S, int lane, int f
     double act = 0;
     for (int u = 0; u < m.nu; u++)
       if (m.act_i[AIS * (u) + AI_DOF] == lane) act += m.act_d[ADS * (u) + AD_GEAR] * S.frc[u];
-    fs = -m.dof_d[DDS * (lane) + DD_DAMPING] * qv - bias + act;
+    fs = -S.damp[lane] * qv - bias + act + qapp;
     S.vec[lane] = qv;
   }
   SYNC();
@@ -1002,12 +1079,14 @@ __device__ __forceinline__ void substep(const HModel& m, Lds& S, int lane, int f
   }
   // constraint reference: aref = -B (J qvel) - K imp (pos - margin)   (lane = row); consumes the row parameters
   // parked in the H slot, which the factorisations below then overwrite
-  double aref = 0, D = 0;
+  double aref = 0, D = 0, fl = 0;
+  const bool isrow = lane < nefc;
   {
     const double jv0 = row_dot(Jrow, S.vec, nv);
-    if (lane < nefc) {
+    if (isrow) {
       aref = -S.U[U_EB + lane] * jv0 - S.U[U_EK + lane] * S.U[U_EIMP + lane] * (S.U[U_EPOS + lane] - S.U[U_EMARGIN + lane]);
       D = S.efc_D[lane];
+      fl = S.U[U_EFL + lane];
     }
   }
   SYNC();
@@ -1030,10 +1109,12 @@ __device__ __forceinline__ void substep(const HModel& m, Lds& S, int lane, int f
       SYNC();
       const double jar = row_dot(Jrow, S.vec, nv) - aref, Ma = row_dot(Mrow, S.vec, nv);
       const double jas = row_dot(Jrow, S.vec2, nv) - aref;
-      double cw = (lane < nefc && jar < 0) ? 0.5 * D * jar * jar : 0.0;
+      double cw, cs0, tf, td;
+      row_eval(isrow, fl, D, jar, &cw, &tf, &td);
+      row_eval(isrow, fl, D, jas, &cs0, &tf, &td);
       if (lane < nv) cw += 0.5 * (Ma - fs) * (w - as);
       cw = wave_sum(cw);
-      const double cs = wave_sum((lane < nefc && jas < 0) ? 0.5 * D * jas * jas : 0.0);
+      const double cs = wave_sum(cs0);
       qacc = (cw > cs) ? as : w;
       SYNC();
     }
@@ -1042,13 +1123,12 @@ __device__ __forceinline__ void substep(const HModel& m, Lds& S, int lane, int f
       if (lane < nv) S.vec[lane] = qacc;
       SYNC();
       const double jar = row_dot(Jrow, S.vec, nv) - aref, Ma = row_dot(Mrow, S.vec, nv);
-      const bool active = lane < nefc && jar < 0;
-      const double force = active ? -D * jar : 0.0;
-      double c = active ? 0.5 * D * jar * jar : 0.0;
+      double c, force, dactive;
+      row_eval(isrow, fl, D, jar, &c, &force, &dactive);
       if (lane < nv) c += 0.5 * (Ma - fs) * (qacc - as);
       oldcost = cost;
       cost = wave_sum(c);
-      if (lane < NE) { S.evec[lane] = force; S.efc_force[lane] = force; S.dact[lane] = active ? D : 0.0; }
+      if (lane < NE) { S.evec[lane] = force; S.efc_force[lane] = force; S.dact[lane] = dactive; }
       SYNC();
       double grad = 0;
       fcon = 0;
@@ -1094,18 +1174,19 @@ __device__ __forceinline__ void substep(const HModel& m, Lds& S, int lane, int f
       // exact line search on the convex piecewise-quadratic: safeguarded Newton on its derivative
       double alpha = 0;
       {
-        double d1 = wave_sum((lane < nefc && jar < 0) ? D * jar * jv : 0.0) + qg1;
-        double d2 = wave_sum((lane < nefc && jar < 0) ? D * jv * jv : 0.0) + 2 * qg2;
+        double r1, r2;
+        row_deriv(isrow, fl, D, jar, jv, &r1, &r2);
+        double d1 = wave_sum(r1) + qg1;
+        double d2 = wave_sum(r2) + 2 * qg2;
         if (!(d1 >= 0 || d2 <= 0)) {
           const double d0 = fabs(d1);
           double lo = 0, hi = -1;
           for (int it = 0; it < 40; it++) {
             double a = alpha - d1 / d2;
             if (hi >= 0 && (a <= lo || a >= hi)) a = 0.5 * (lo + hi);
-            const double x = jar + a * jv;
-            const bool on = lane < nefc && x < 0;
-            d1 = wave_sum(on ? D * x * jv : 0.0) + 2 * a * qg2 + qg1;
-            d2 = wave_sum(on ? D * jv * jv : 0.0) + 2 * qg2;
+            row_deriv(isrow, fl, D, jar + a * jv, jv, &r1, &r2);
+            d1 = wave_sum(r1) + 2 * a * qg2 + qg1;
+            d2 = wave_sum(r2) + 2 * qg2;
             if (d1 < 0) lo = a; else hi = a;
             alpha = a;
             if (fabs(d1) <= 1e-14 * d0) break;
@@ -1132,7 +1213,7 @@ __device__ __forceinline__ void substep(const HModel& m, Lds& S, int lane, int f
   if (eulerdamp) {
     for (int it = lane; it < NV * LDV; it += 64) S.U[U_H + it] = S.M[it];
     SYNC();
-    if (lane < nv) S.U[U_H + lane * LDV + lane] += h * m.dof_d[DDS * (lane) + DD_DAMPING];
+    if (lane < nv) S.U[U_H + lane * LDV + lane] += h * S.damp[lane];
     SYNC();
     anew = chol_solve_inplace(S.U + U_H, nv, lane, fs + fcon);
   }
@@ -1199,6 +1280,51 @@ __device__ void write_obs(const HModel& m, const HParams& p, Lds& S, int lane, i
   if (lane < 12) { o[5 + lane] = (float)S.sq[lane]; o[17 + lane] = (float)S.sv[lane]; }
 }
 
+// H1 robot state (h1_base.py:95-119): [roll, pitch, ang vel 3, motor pos 10, motor vel 10, motor torque 10] plus uniform
+// observation noise drawn per entry on every get_obs (base_humanoid_env.py:307-338); lane = observation entry
+__device__ void write_obs_h1(const HModel& m, const HParams& p, Lds& S, int lane, unsigned genv, unsigned obs_count, float* o,
+                             float* o2) {
+  if (lane < 35) {
+    double v;
+    if (lane < 2) {
+      double r, pt;
+      quat_roll_pitch(&S.qpos[3], &r, &pt);
+      v = lane == 0 ? r : pt;
+    } else if (lane < 5) v = S.qvel[3 + (lane - 2)];
+    else if (lane < 15) v = S.sq[lane - 5];
+    else if (lane < 25) v = S.sv[lane - 15];
+    else v = S.frc[lane - 25] * m.act_d[ADS * (lane - 25) + AD_GEAR];
+    const double sc = p.obs_noise[lane];
+    if (sc > 0) v += lhw_rng_uniform(p.seed, genv, LHW_STREAM_OBS, obs_count, lane, -sc, sc);
+    if (o) o[lane] = (float)v;
+    if (o2) o2[lane] = (float)v;
+  }
+}
+
+// randomize_dynamics (domain_randomization.py:29-56): leg dof frictionloss / damping, then mass scale and inertial
+// offset of pelvis + leg bodies relative to the DEFAULT model.  Writes the LDS copies (used immediately on reset) and
+// the per-env record.  slot0 = first RNG slot (0 on reset, 1 in step).
+__device__ void randomize_dynamics(const HModel& m, const HParams& p, Lds& S, double* prm, int lane, unsigned genv,
+                                   unsigned stream, unsigned counter, unsigned slot0) {
+  if (lane < p.n_rand_dof) {
+    const int d = p.rand_dof[lane];
+    const double fl = lhw_rng_uniform(p.seed, genv, stream, counter, slot0 + 2 * lane, 0.0, 2.0);
+    const double dm = lhw_rng_uniform(p.seed, genv, stream, counter, slot0 + 2 * lane + 1, 0.02, 2.0);
+    S.floss[d] = fl; S.damp[d] = dm;
+    prm[P_FLOSS + d] = fl; prm[P_DAMP + d] = dm;
+  }
+  if (lane < p.n_rand_body) {
+    const int b = p.rand_body[lane];
+    const unsigned base = slot0 + 20 + 4 * lane;
+    const double ms = m.body_d[BDS * b + BD_MASS] * lhw_rng_uniform(p.seed, genv, stream, counter, base, 0.95, 1.05);
+    S.bmass[b] = ms; prm[P_MASS + b] = ms;
+    for (int a = 0; a < 3; a++) {
+      const double ip = m.body_d[BDS * b + BD_IPOS + a] + lhw_rng_uniform(p.seed, genv, stream, counter, base + 1 + a, -0.01, 0.01);
+      S.bipos[3 * b + a] = ip; prm[P_IPOS + 3 * b + a] = ip;
+    }
+  }
+}
+
 // mj_objectVelocity(mjOBJ_XBODY): linear velocity of the body-frame origin, world orientation
 __device__ __forceinline__ void body_linvel(const Lds& S, int slot /* 0 root, 1 right foot, 2 left foot */, int b, double* lin) {
   const double* cv = &S.svel[6 * slot];
@@ -1207,7 +1333,7 @@ __device__ __forceinline__ void body_linvel(const Lds& S, int slot /* 0 root, 1 
   lin[0] = cv[3] - t[0]; lin[1] = cv[4] - t[1]; lin[2] = cv[5] - t[2];
 }
 
-template <int MODE>  // 0 step, 1 reset(mask), 2 set_state, 3 get_state
+template <int MODE, int TASK>  // MODE: 0 step, 1 reset(mask), 2 set_state, 3 get_state; TASK: TASK_WALK / TASK_STAND
 __global__ void __launch_bounds__(64, 2) humanoid_kernel(HModel m, HParams p, HState st, const float* __restrict__ act,
                                                       float* __restrict__ obs, float* __restrict__ term_obs,
                                                       float* __restrict__ rew, unsigned char* __restrict__ done_out,
@@ -1217,6 +1343,8 @@ __global__ void __launch_bounds__(64, 2) humanoid_kernel(HModel m, HParams p, HS
   const int env = blockIdx.x, lane = threadIdx.x;
   if (MODE == 1 && mask && !mask[env]) return;
   double* rec = st.rec + (size_t)env * REC_D;
+  double* prm = st.prm ? st.prm + (size_t)env * PRM_D : nullptr;
+  const int OBS = TASK == TASK_WALK ? 37 : 35;
   int* irec = st.irec + (size_t)env * REC_I;
   const unsigned genv = p.env_id_base + env;
   long long* sprof = (env == 0) ? st.prof : nullptr;
@@ -1239,7 +1367,17 @@ __global__ void __launch_bounds__(64, 2) humanoid_kernel(HModel m, HParams p, HS
   double mode_ref[3] = {rec[R_MODEREF], rec[R_MODEREF + 1], rec[R_MODEREF + 2]};
   double ep_ret = rec[R_EPRET];
   int phase = irec[RI_PHASE], mode = irec[RI_MODE], traj_len = irec[RI_TRAJ], started = irec[RI_STARTED];
-  unsigned step_count = (unsigned)irec[RI_STEPCNT], reset_count = (unsigned)irec[RI_RESETCNT];
+  unsigned step_count = (unsigned)irec[RI_STEPCNT], reset_count = (unsigned)irec[RI_RESETCNT], obs_count = (unsigned)irec[RI_OBSCNT];
+  // per-env model parameters (or the shared defaults) -> LDS, once per launch
+  if (lane < m.nv) {
+    S.damp[lane] = prm ? prm[P_DAMP + lane] : m.dof_d[DDS * lane + DD_DAMPING];
+    S.floss[lane] = prm ? prm[P_FLOSS + lane] : m.dof_d[DDS * lane + DD_FLOSS];
+  }
+  if (lane < m.nbody) {
+    S.bmass[lane] = prm ? prm[P_MASS + lane] : m.body_d[BDS * lane + BD_MASS];
+    for (int a = 0; a < 3; a++) S.bipos[3 * lane + a] = prm ? prm[P_IPOS + 3 * lane + a] : m.body_d[BDS * lane + BD_IPOS + a];
+  }
+  if (lane < 12) S.xfrc[lane] = prm ? prm[P_XFRC + lane] : 0.0;
   SYNC();
 
   bool do_reset = MODE == 1;
@@ -1247,7 +1385,7 @@ __global__ void __launch_bounds__(64, 2) humanoid_kernel(HModel m, HParams p, HS
     if (lane < m.nq) S.qpos[lane] = xq[(size_t)env * m.nq + lane];
     if (lane < m.nv) S.qvel[lane] = xv[(size_t)env * m.nv + lane];
     SYNC();
-    substep(m, S, lane, 0, &warm, sprof);  // set_state: mj_forward with actuation disabled
+    substep(m, p, S, lane, 0, &warm, sprof);  // set_state: mj_forward with actuation disabled
   }
   if (MODE == 0) {
     // ---- BaseHumanoidEnv.step: smoothing, offsets (base_humanoid_env.py:209-215); RobotBase.step (robot_base.py:64-98)
@@ -1264,9 +1402,23 @@ __global__ void __launch_bounds__(64, 2) humanoid_kernel(HModel m, HParams p, HS
         S.ctrl[lane] = tau / m.act_d[ADS * (lane) + AD_GEAR];
       }
       SYNC();
-      substep(m, S, lane, 3, &warm, sprof);
+      substep(m, p, S, lane, 3, &warm, sprof);
     }
     PROF_MARK(9);  // control-step prologue (load, PD) is folded into slot 9 with the sub-step loop overheads
+    double r_sum = 0, terms[10], cur_tq = 0;
+    bool terminated = false;
+    if (lane < m.nu) cur_tq = S.frc[lane] * m.act_d[ADS * (lane) + AD_GEAR];
+    // self-collision scan of the contacts of the last forward pass (robot_interface.py:472-484)
+    bool self_collision;
+    {
+      int selfcol = 0;
+      if (lane < S.ncon) {
+        const int b1 = m.geom_i[GIS * (S.con_g1[lane]) + GI_BODY], b2 = m.geom_i[GIS * (S.con_g2[lane]) + GI_BODY];
+        selfcol = (m.body_i[BIS * (b1) + BI_ROOT] == p.root_body && m.body_i[BIS * (b2) + BI_ROOT] == p.root_body) ? 1 : 0;
+      }
+      self_collision = __any(selfcol);
+    }
+    if (TASK == TASK_WALK) {
     // ---- WalkingTask.step (walking_task.py:149-170)
     phase += 1;
     if (phase >= p.period) phase = 0;
@@ -1287,7 +1439,7 @@ __global__ void __launch_bounds__(64, 2) humanoid_kernel(HModel m, HParams p, HS
     // ---- calc_reward (walking_task.py:85-147) on the fields of the last forward pass
     // per-contact quantities: lane = contact
     double grf_r = 0, grf_l = 0, cz = 1e300;
-    int selfcol = 0, anyfoot = 0;
+    int anyfoot = 0;
     if (lane < S.ncon) {
       const int c = lane, b1 = m.geom_i[GIS * (S.con_g1[c]) + GI_BODY], b2 = m.geom_i[GIS * (S.con_g2[c]) + GI_BODY];
       const bool floor1 = m.body_i[BIS * (b1) + BI_ROOT] != p.root_body;
@@ -1302,16 +1454,13 @@ __global__ void __launch_bounds__(64, 2) humanoid_kernel(HModel m, HParams p, HS
       }
       if (floor1 && b2 == p.rfoot_body) { grf_r = fn; cz = S.con_pos[3 * c + 2]; anyfoot = 1; }
       if (floor1 && b2 == p.lfoot_body) { grf_l = fn; cz = S.con_pos[3 * c + 2]; anyfoot = 1; }
-      selfcol = (m.body_i[BIS * (b1) + BI_ROOT] == p.root_body && m.body_i[BIS * (b2) + BI_ROOT] == p.root_body) ? 1 : 0;
     }
     grf_r = wave_sum(grf_r); grf_l = wave_sum(grf_l); cz = wave_min(cz);
     const bool has_foot = __any(anyfoot);
-    const bool self_collision = __any(selfcol);
     if (!has_foot) cz = 0;
     // joint-space sums: lane = actuator / dof
-    double s_posture = 0, s_tq = 0, s_act = 0, s_rootacc = 0, cur_tq = 0;
+    double s_posture = 0, s_tq = 0, s_act = 0, s_rootacc = 0;
     if (lane < m.nu) {
-      cur_tq = S.frc[lane] * m.act_d[ADS * (lane) + AD_GEAR];
       const double dq = p.neutral_pose[lane] - S.sq[lane];
       s_posture = dq * dq;
       s_tq = fabs(prevtq - cur_tq);
@@ -1320,7 +1469,6 @@ __global__ void __launch_bounds__(64, 2) humanoid_kernel(HModel m, HParams p, HS
     if (lane >= 3 && lane < 6) s_rootacc = fabs(S.qvel[lane]);
     if (lane < 3) s_rootacc = fabs(S.qacc[lane]);
     s_posture = wave_sum(s_posture); s_tq = wave_sum(s_tq); s_act = wave_sum(s_act); s_rootacc = wave_sum(s_rootacc);
-    double r_sum = 0, terms[10];
     {
       double lv[3], rv[3], rl[3], vloc[3];
       body_linvel(S, 2, p.lfoot_body, lv); body_linvel(S, 1, p.rfoot_body, rv); body_linvel(S, 0, p.root_body, rl);
@@ -1354,8 +1502,36 @@ __global__ void __launch_bounds__(64, 2) humanoid_kernel(HModel m, HParams p, HS
       terms[9] = 0.025 * exp(-5 * s_act / (double)m.nu);
       for (int k = 0; k < 10; k++) r_sum += terms[k];  // python sum() over the dict, left to right
     }
-    const double z = S.qpos[2];
-    const bool terminated = z < 0.6 || z > 1.4 || self_collision;  // walking_task.py:184-192
+      const double z = S.qpos[2];
+      terminated = z < 0.6 || z > 1.4 || self_collision;  // walking_task.py:184-192
+    } else {
+      // ---- StandingTask.calc_reward / done (standing_task.py:49-131) on the fields of the last forward pass
+      double s_posture = 0, s_tau = 0;
+      if (lane < m.nu) {
+        const double dq = S.sq[lane] - p.neutral_pose[lane];
+        s_posture = dq * dq;
+        s_tau = cur_tq * cur_tq;
+      }
+      s_posture = wave_sum(s_posture); s_tau = wave_sum(s_tau);
+      double rl[3], vloc[3], dh[3], hloc[3];
+      body_linvel(S, 0, p.root_body, rl);
+      matT_vec(vloc, S.rootmat, rl);
+      for (int a = 0; a < 3; a++) dh[a] = S.xpos[3 * p.head_body + a] - S.xpos[3 * p.root_body + a];
+      matT_vec(hloc, S.rootmat, dh);      // torso position in the pelvis frame: inv(root_pose) . head_pose
+      const double fwd = sqrt(vloc[0] * vloc[0] + vloc[1] * vloc[1]), yaw = fabs(S.qvel[5]);
+      const double herr = fabs(S.xpos[3 * p.root_body + 2] - p.goal_height);
+      const double uerr = sqrt(hloc[0] * hloc[0] + hloc[1] * hloc[1]);
+      terms[0] = 0.3 * exp(-4 * (fwd * fwd));
+      terms[1] = 0.3 * exp(-4 * (yaw * yaw));
+      terms[2] = 0.1 * exp(-0.5 * (herr * herr));
+      terms[3] = 0.1 * exp(-40 * (uerr * uerr));
+      terms[4] = 0.1 * exp(-5e-5 * s_tau);
+      terms[5] = 0.1 * exp(-1 * s_posture);
+      for (int k = 0; k < 6; k++) r_sum += terms[k];
+      for (int k = 6; k < 10; k++) terms[k] = 0;
+      const double z = S.qpos[2];
+      terminated = z < 0.9 || z > 1.4 || self_collision;  // standing_task.py:111-131
+    }
     prevact = target;
     prevtq = cur_tq;
     prevpred = a_raw;
@@ -1363,13 +1539,38 @@ __global__ void __launch_bounds__(64, 2) humanoid_kernel(HModel m, HParams p, HS
     traj_len += 1;
     ep_ret += r_sum;
     const bool truncated = p.max_traj_len > 0 && traj_len >= p.max_traj_len;
-    write_obs(m, p, S, lane, phase, mode, mode_ref, obs + (size_t)env * 37);
-    if (term_obs) write_obs(m, p, S, lane, phase, mode, mode_ref, term_obs + (size_t)env * 37);
+    const int NT = TASK == TASK_WALK ? 10 : 6;
+    if (TASK == TASK_WALK) {
+      write_obs(m, p, S, lane, phase, mode, mode_ref, obs + (size_t)env * OBS);
+      if (term_obs) write_obs(m, p, S, lane, phase, mode, mode_ref, term_obs + (size_t)env * OBS);
+    } else {
+      write_obs_h1(m, p, S, lane, genv, obs_count, obs + (size_t)env * OBS, term_obs ? term_obs + (size_t)env * OBS : nullptr);
+      obs_count++;
+      // post-observation randomisation draws (base_humanoid_env.py:221-225): slot 0 / 70 are the interval triggers
+      if (p.dynrand_interval > 0 && lhw_rng_randint(p.seed, genv, LHW_STREAM_STEP, step_count, 0, p.dynrand_interval) == 0)
+        randomize_dynamics(m, p, S, prm, lane, genv, LHW_STREAM_STEP, step_count, 1);
+      if (p.perturb_interval > 0 && lhw_rng_randint(p.seed, genv, LHW_STREAM_STEP, step_count, 70, p.perturb_interval) == 0) {
+        // apply_perturbation (domain_randomization.py:10-26): per body force / torque, then a coin flip that clears ALL
+        double xf[12];
+        for (int k = 0; k < 12; k++) xf[k] = S.xfrc[k];
+        for (int k = 0; k < p.n_pbody; k++) {
+          for (int a = 0; a < 3; a++) {
+            xf[6 * k + a] = lhw_rng_uniform(p.seed, genv, LHW_STREAM_STEP, step_count, 71 + 7 * k + a, -p.force_mag, p.force_mag);
+            xf[6 * k + 3 + a] = lhw_rng_uniform(p.seed, genv, LHW_STREAM_STEP, step_count, 74 + 7 * k + a, -p.torque_mag, p.torque_mag);
+          }
+          if (lhw_rng_randint(p.seed, genv, LHW_STREAM_STEP, step_count, 77 + 7 * k, 2) == 0)
+            for (int j = 0; j < 12; j++) xf[j] = 0;
+        }
+        SYNC();
+        if (lane < 12) { S.xfrc[lane] = xf[lane]; prm[P_XFRC + lane] = xf[lane]; }
+      }
+      step_count++;
+    }
     if (lane == 0) {
       rew[env] = (float)r_sum;
       done_out[env] = (terminated ? 1 : 0) | (truncated ? 2 : 0);
       if (S.overflow) atomicAdd(&st.ep_stats[3], 1.0);
-      if (rew_terms) for (int k = 0; k < 10; k++) rew_terms[(size_t)env * 10 + k] = (float)terms[k];
+      if (rew_terms) for (int k = 0; k < NT; k++) rew_terms[(size_t)env * NT + k] = (float)terms[k];
     }
     if (p.max_traj_len > 0 && (terminated || truncated)) {
       if (lane == 0) { atomicAdd(&st.ep_stats[0], ep_ret); atomicAdd(&st.ep_stats[1], (double)traj_len); atomicAdd(&st.ep_stats[2], 1.0); }
@@ -1383,19 +1584,44 @@ __global__ void __launch_bounds__(64, 2) humanoid_kernel(HModel m, HParams p, HS
     if (lane < m.nv) S.qvel[lane] = 0;
     if (lane < m.nu) S.ctrl[lane] = 0;
     warm = 0;
+    if (TASK == TASK_STAND) {
+      // mj_resetData clears xfrc_applied; dynamics randomisation on reset (base_humanoid_env.py:254-255), slots 0..63
+      if (lane < 12) { S.xfrc[lane] = 0; prm[P_XFRC + lane] = 0; }
+      if (p.dynrand_interval > 0) randomize_dynamics(m, p, S, prm, lane, genv, LHW_STREAM_RESET, reset_count, 0);
+      SYNC();
+      if (p.init_noise > 0) {  // _apply_init_noise (base_humanoid_env.py:278-305): slot 64 root z, 65/66 roll/pitch, 67.. joints
+        const double cn = p.init_noise;
+        if (lane == 0) {
+          const double z0 = p.nominal_qpos[2];
+          S.qpos[2] = lhw_rng_uniform(p.seed, genv, LHW_STREAM_RESET, reset_count, 64, z0, z0 + 0.02);
+          const double ai = 0.5 * lhw_rng_uniform(p.seed, genv, LHW_STREAM_RESET, reset_count, 65, -cn, cn);
+          const double aj = 0.5 * lhw_rng_uniform(p.seed, genv, LHW_STREAM_RESET, reset_count, 66, -cn, cn);
+          const double ci = cos(ai), si = sin(ai), cj = cos(aj), sj = sin(aj);   // euler2quat(ai, aj, 0), static xyz
+          S.qpos[3] = cj * ci; S.qpos[4] = cj * si; S.qpos[5] = sj * ci; S.qpos[6] = -sj * si;
+        }
+        if (lane >= 7 && lane < m.nq) S.qpos[lane] += lhw_rng_uniform(p.seed, genv, LHW_STREAM_RESET, reset_count, 67 + (lane - 7), -cn, cn);
+      }
+    }
     SYNC();
-    substep(m, S, lane, 0, &warm, sprof);                           // set_state: forward, actuation disabled
-    for (int k = 0; k < 3; k++) substep(m, S, lane, 3, &warm, sprof);  // three settle steps, ctrl = 0
-    // WalkingTask.reset (walking_task.py:194-205): slot 0 mode, 1..3 mode_ref, 4 phase
-    const double u = lhw_rng_u01(p.seed, genv, LHW_STREAM_RESET, reset_count, 0);
-    mode = u < 0.6 ? MODE_STANDING : (u < 0.8 ? MODE_INPLACE : MODE_FORWARD);
-    sample_ref(p, genv, LHW_STREAM_RESET, reset_count, 1, mode, mode_ref);
-    phase = lhw_rng_randint(p.seed, genv, LHW_STREAM_RESET, reset_count, 4, p.period);
+    substep(m, p, S, lane, 0, &warm, sprof);                           // set_state: forward, actuation disabled
+    for (int k = 0; k < 3; k++) substep(m, p, S, lane, 3, &warm, sprof);  // three settle steps, ctrl = 0
+    if (TASK == TASK_WALK) {
+      // WalkingTask.reset (walking_task.py:194-205): slot 0 mode, 1..3 mode_ref, 4 phase
+      const double u = lhw_rng_u01(p.seed, genv, LHW_STREAM_RESET, reset_count, 0);
+      mode = u < 0.6 ? MODE_STANDING : (u < 0.8 ? MODE_INPLACE : MODE_FORWARD);
+      sample_ref(p, genv, LHW_STREAM_RESET, reset_count, 1, mode, mode_ref);
+      phase = lhw_rng_randint(p.seed, genv, LHW_STREAM_RESET, reset_count, 4, p.period);
+    }
     reset_count++;
     traj_len = 0;
     ep_ret = 0;
     prevpred = 0;
-    if (obs) write_obs(m, p, S, lane, phase, mode, mode_ref, obs + (size_t)env * 37);
+    if (TASK == TASK_WALK) {
+      if (obs) write_obs(m, p, S, lane, phase, mode, mode_ref, obs + (size_t)env * OBS);
+    } else {
+      write_obs_h1(m, p, S, lane, genv, obs_count, obs ? obs + (size_t)env * OBS : nullptr, nullptr);  // the counter advances either way
+      obs_count++;
+    }
   }
   PROF_MARK(10);
   // ---- store the record
@@ -1410,7 +1636,7 @@ __global__ void __launch_bounds__(64, 2) humanoid_kernel(HModel m, HParams p, HS
     rec[R_MODEREF] = mode_ref[0]; rec[R_MODEREF + 1] = mode_ref[1]; rec[R_MODEREF + 2] = mode_ref[2];
     rec[R_EPRET] = ep_ret;
     irec[RI_PHASE] = phase; irec[RI_MODE] = mode; irec[RI_TRAJ] = traj_len; irec[RI_STARTED] = started;
-    irec[RI_STEPCNT] = (int)step_count; irec[RI_RESETCNT] = (int)reset_count;
+    irec[RI_STEPCNT] = (int)step_count; irec[RI_RESETCNT] = (int)reset_count; irec[RI_OBSCNT] = (int)obs_count;
   }
 }
 
@@ -1441,16 +1667,18 @@ int humanoid_create(HumanoidEnv** out, const std::vector<int32_t>& mi, const std
   if (nq > NQ || nv > NV || nu > NU || nb > NB || nj > NJ || ng > NG || np > NP || nb > 64 || np > 64)
     return lhw_fail(LHW_ERR_MODEL, "model exceeds compiled limits (nq %d/%d nv %d/%d nu %d/%d nbody %d/%d njnt %d/%d ngeom %d/%d npair %d/%d)",
                     nq, NQ, nv, NV, nu, NU, nb, NB, nj, NJ, ng, NG, np, NP);
-  if (cfg->task != LHW_TASK_JVRC_WALK) return lhw_fail(LHW_ERR_ARG, "humanoid stepper: unknown task");
-  if (nu != 12 || nq != 19 || nv != 18) return lhw_fail(LHW_ERR_UNSUPPORTED, "jvrc_walk needs a free root + 12 actuated leg hinges");
-  if (!cfg->kp || !cfg->kd || !cfg->action_offset || !cfg->clock_lut || cfg->period <= 0 || cfg->n_task_iparams < LHW_TI_COUNT ||
-      cfg->n_task_params < LHW_TP_COUNT || cfg->frame_skip <= 0)
-    return lhw_fail(LHW_ERR_ARG, "jvrc_walk config incomplete");
+  const bool walk = cfg->task == LHW_TASK_JVRC_WALK, stand = cfg->task == LHW_TASK_H1_STAND;
+  if (!walk && !stand) return lhw_fail(LHW_ERR_ARG, "humanoid stepper: unknown task");
+  if (walk && (nu != 12 || nq != 19 || nv != 18)) return lhw_fail(LHW_ERR_UNSUPPORTED, "jvrc_walk needs a free root + 12 actuated leg hinges");
+  if (stand && (nu != 10 || nq != 17 || nv != 16)) return lhw_fail(LHW_ERR_UNSUPPORTED, "h1 needs a free root + 10 actuated leg hinges");
+  if (!cfg->kp || !cfg->kd || !cfg->action_offset || cfg->n_task_iparams < LHW_TI_COUNT || cfg->n_task_params < LHW_TP_COUNT || cfg->frame_skip <= 0)
+    return lhw_fail(LHW_ERR_ARG, "humanoid task config incomplete");
+  if (walk && (!cfg->clock_lut || cfg->period <= 0)) return lhw_fail(LHW_ERR_ARG, "jvrc_walk needs the gait clock table");
+  if (stand && (cfg->n_task_params < LHW_TP_H1_OBS_NOISE + 35 || cfg->n_task_iparams < LHW_TI_H1_RAND_BODY + 11))
+    return lhw_fail(LHW_ERR_ARG, "h1 task parameter arrays too short");
   const int32_t *parent = IF(LHW_IF_BODY_PARENTID), *rootid = IF(LHW_IF_BODY_ROOTID), *jtype = IF(LHW_IF_JNT_TYPE);
   const int32_t *bdofadr = IF(LHW_IF_BODY_DOFADR), *bdofnum = IF(LHW_IF_BODY_DOFNUM), *dparent = IF(LHW_IF_DOF_PARENTID);
   const int32_t *djnt = IF(LHW_IF_DOF_JNTID), *jdof = IF(LHW_IF_JNT_DOFADR);
-  for (int d = 0; d < nv; d++)
-    if (DF(LHW_DF_DOF_FRICTIONLOSS)[d] != 0) return lhw_fail(LHW_ERR_UNSUPPORTED, "dof frictionloss rows are not implemented in the HIP stepper yet");
   for (int b = 1; b < nb; b++) {
     if (bdofnum[b] > 0 && rootid[b] != 1) return lhw_fail(LHW_ERR_UNSUPPORTED, "exactly one dynamic tree (rooted at body 1) is supported");
     if (parent[b] >= b) return lhw_fail(LHW_ERR_MODEL, "bodies must be in depth-first order");
@@ -1537,6 +1765,9 @@ int humanoid_create(HumanoidEnv** out, const std::vector<int32_t>& mi, const std
   for (int d = 0; d < nv; d++) {
     double* k = &dof_d[(size_t)DDS * d];
     k[DD_ARMATURE] = DF(LHW_DF_DOF_ARMATURE)[d]; k[DD_DAMPING] = DF(LHW_DF_DOF_DAMPING)[d]; k[DD_INVW] = DF(LHW_DF_DOF_INVWEIGHT0)[d];
+    k[DD_FLOSS] = DF(LHW_DF_DOF_FRICTIONLOSS)[d];
+    k[DD_SOLREF] = DF(LHW_DF_DOF_SOLREF)[2 * d]; k[DD_SOLREF + 1] = DF(LHW_DF_DOF_SOLREF)[2 * d + 1];
+    for (int a = 0; a < 5; a++) k[DD_SOLIMP + a] = DF(LHW_DF_DOF_SOLIMP)[5 * d + a];
     int* di = &dof_i[(size_t)DIS * d];
     const int j = djnt[d], kk = d - jdof[j];
     di[DI_BODY] = IF(LHW_IF_DOF_BODYID)[d]; di[DI_JNT] = j;
@@ -1583,13 +1814,45 @@ int humanoid_create(HumanoidEnv** out, const std::vector<int32_t>& mi, const std
     ok = false;
   p.env_id_base = (unsigned)cfg->env_id_base; p.seed = cfg->seed;
   p.action_smoothing = cfg->action_smoothing; p.goal_height = cfg->task_params[LHW_TP_GOAL_HEIGHT];
+  p.task = walk ? TASK_WALK : TASK_STAND;
+  std::vector<double> obs_noise(35, 0.0);
+  if (stand) {
+    p.init_noise = cfg->task_params[LHW_TP_H1_INIT_NOISE]; p.force_mag = cfg->task_params[LHW_TP_H1_FORCE_MAG];
+    p.torque_mag = cfg->task_params[LHW_TP_H1_TORQUE_MAG];
+    for (int k = 0; k < 35; k++) obs_noise[k] = cfg->task_params[LHW_TP_H1_OBS_NOISE + k];
+    const int32_t* ti = cfg->task_iparams;
+    p.dynrand_interval = ti[LHW_TI_H1_DYNRAND_INTERVAL]; p.perturb_interval = ti[LHW_TI_H1_PERTURB_INTERVAL];
+    p.n_pbody = ti[LHW_TI_H1_N_PBODY]; p.pbody[0] = ti[LHW_TI_H1_PBODY]; p.pbody[1] = ti[LHW_TI_H1_PBODY + 1];
+    p.n_rand_dof = 10; p.n_rand_body = 11;
+    for (int k = 0; k < 10; k++) p.rand_dof[k] = ti[LHW_TI_H1_RAND_DOF + k];
+    for (int k = 0; k < 11; k++) p.rand_body[k] = ti[LHW_TI_H1_RAND_BODY + k];
+    if (p.n_pbody < 0 || p.n_pbody > 2) ok = false;
+    for (int k = 0; k < p.n_pbody; k++) if (p.pbody[k] <= 0 || p.pbody[k] >= nb) ok = false;
+    for (int k = 0; k < 10; k++) if (p.rand_dof[k] < 0 || p.rand_dof[k] >= nv) ok = false;
+    for (int k = 0; k < 11; k++) if (p.rand_body[k] <= 0 || p.rand_body[k] >= nb) ok = false;
+    p.env_params = 1;
+  }
   std::vector<double> nominal(nq), neutral(nu);
   for (int k = 0; k < nq; k++) nominal[k] = cfg->nominal_qpos ? cfg->nominal_qpos[k] : DF(LHW_DF_QPOS0)[k];
   for (int u = 0; u < nu; u++) neutral[u] = cfg->action_offset[u];  // task._neutral_pose == half-sitting pose == offsets (jvrc_walk.py:33)
   ok = ok && (p.kp = to_dev<double>(h, cfg->kp, nu)) && (p.kd = to_dev<double>(h, cfg->kd, nu)) &&
        (p.nominal_qpos = to_dev<double>(h, nominal.data(), nq)) && (p.action_offset = to_dev<double>(h, cfg->action_offset, nu)) &&
-       (p.clock_lut = to_dev<double>(h, cfg->clock_lut, (size_t)4 * cfg->period)) && (p.neutral_pose = to_dev<double>(h, neutral.data(), nu));
+       (p.clock_lut = to_dev<double>(h, cfg->clock_lut, walk ? (size_t)4 * cfg->period : 0)) &&
+       (p.neutral_pose = to_dev<double>(h, neutral.data(), nu)) && (p.obs_noise = to_dev<double>(h, obs_noise.data(), 35));
   const size_t N = cfg->n_envs;
+  h->st.prm = nullptr;
+  if (ok && p.env_params) {
+    // per-env parameter records start from the model's defaults
+    std::vector<double> one(PRM_D, 0.0), all((size_t)PRM_D * N);
+    for (int d = 0; d < nv; d++) { one[P_DAMP + d] = DF(LHW_DF_DOF_DAMPING)[d]; one[P_FLOSS + d] = DF(LHW_DF_DOF_FRICTIONLOSS)[d]; }
+    for (int b = 0; b < nb; b++) {
+      one[P_MASS + b] = DF(LHW_DF_BODY_MASS)[b];
+      for (int a = 0; a < 3; a++) one[P_IPOS + 3 * b + a] = DF(LHW_DF_BODY_IPOS)[3 * b + a];
+    }
+    for (size_t n = 0; n < N; n++) std::copy(one.begin(), one.end(), all.begin() + n * PRM_D);
+    h->st.prm = const_cast<double*>(to_dev<double>(h, all.data(), all.size()));
+    ok = ok && h->st.prm != nullptr;
+  }
   void *rec = nullptr, *irec = nullptr, *eps = nullptr;
   ok = ok && hipMalloc(&rec, sizeof(double) * REC_D * N) == hipSuccess && hipMemset(rec, 0, sizeof(double) * REC_D * N) == hipSuccess &&
        hipMalloc(&irec, sizeof(int) * REC_I * N) == hipSuccess && hipMemset(irec, 0, sizeof(int) * REC_I * N) == hipSuccess &&
@@ -1599,7 +1862,7 @@ int humanoid_create(HumanoidEnv** out, const std::vector<int32_t>& mi, const std
   if (eps) h->dev_allocs.push_back(eps);
   h->st.rec = (double*)rec; h->st.irec = (int*)irec; h->st.ep_stats = (double*)eps; h->st.prof = nullptr;
   if (!ok) { humanoid_destroy(h); return lhw_fail(LHW_ERR_HIP, "humanoid_create: device allocation failed or bad body ids"); }
-  *obs_dim = 37; *act_dim = 12; *n_terms = 10;
+  *obs_dim = walk ? 37 : 35; *act_dim = nu; *n_terms = walk ? 10 : 6;
   *out = h;
   return LHW_OK;
 }
@@ -1610,28 +1873,32 @@ void humanoid_destroy(HumanoidEnv* h) {
   delete h;
 }
 
+#define LAUNCH(MODE, ...)                                                                                          \
+  do {                                                                                                             \
+    if (h->p.task == TASK_WALK) hipLaunchKernelGGL((humanoid_kernel<MODE, TASK_WALK>), dim3(h->p.n_envs), dim3(64), 0, s, h->m, h->p, h->st, __VA_ARGS__); \
+    else hipLaunchKernelGGL((humanoid_kernel<MODE, TASK_STAND>), dim3(h->p.n_envs), dim3(64), 0, s, h->m, h->p, h->st, __VA_ARGS__);                     \
+  } while (0)
+
 void humanoid_reset(HumanoidEnv* h, const uint8_t* mask, float* obs, hipStream_t s) {
-  hipLaunchKernelGGL((humanoid_kernel<1>), dim3(h->p.n_envs), dim3(64), 0, s, h->m, h->p, h->st, (const float*)nullptr, obs,
-                     (float*)nullptr, (float*)nullptr, (unsigned char*)nullptr, (float*)nullptr, mask, (double*)nullptr, (double*)nullptr);
+  LAUNCH(1, (const float*)nullptr, obs, (float*)nullptr, (float*)nullptr, (unsigned char*)nullptr, (float*)nullptr, mask,
+         (double*)nullptr, (double*)nullptr);
 }
 void humanoid_step(HumanoidEnv* h, const float* act, float* obs, float* term_obs, float* rew, uint8_t* done, float* rew_terms,
                    hipStream_t s) {
-  hipLaunchKernelGGL((humanoid_kernel<0>), dim3(h->p.n_envs), dim3(64), 0, s, h->m, h->p, h->st, act, obs, term_obs, rew, done,
-                     rew_terms, (const unsigned char*)nullptr, (double*)nullptr, (double*)nullptr);
+  LAUNCH(0, act, obs, term_obs, rew, done, rew_terms, (const unsigned char*)nullptr, (double*)nullptr, (double*)nullptr);
 }
 void humanoid_get_state(HumanoidEnv* h, double* qpos, double* qvel, hipStream_t s) {
-  hipLaunchKernelGGL((humanoid_kernel<3>), dim3(h->p.n_envs), dim3(64), 0, s, h->m, h->p, h->st, (const float*)nullptr, (float*)nullptr,
-                     (float*)nullptr, (float*)nullptr, (unsigned char*)nullptr, (float*)nullptr, (const unsigned char*)nullptr, qpos, qvel);
+  LAUNCH(3, (const float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, (unsigned char*)nullptr, (float*)nullptr,
+         (const unsigned char*)nullptr, qpos, qvel);
 }
 void humanoid_set_state(HumanoidEnv* h, const double* qpos, const double* qvel, hipStream_t s) {
-  hipLaunchKernelGGL((humanoid_kernel<2>), dim3(h->p.n_envs), dim3(64), 0, s, h->m, h->p, h->st, (const float*)nullptr, (float*)nullptr,
-                     (float*)nullptr, (float*)nullptr, (unsigned char*)nullptr, (float*)nullptr, (const unsigned char*)nullptr,
-                     const_cast<double*>(qpos), const_cast<double*>(qvel));
+  LAUNCH(2, (const float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, (unsigned char*)nullptr, (float*)nullptr,
+         (const unsigned char*)nullptr, const_cast<double*>(qpos), const_cast<double*>(qvel));
 }
 double* humanoid_ep_stats(HumanoidEnv* h) { return h->st.ep_stats; }
 int humanoid_occupancy() {
   int nb = -1;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, humanoid_kernel<0>, 64, 0) != hipSuccess) return -1;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, humanoid_kernel<0, TASK_WALK>, 64, 0) != hipSuccess) return -1;
   return nb;
 }
 int humanoid_profile(HumanoidEnv* h, int enable, long long* out16) {

@@ -1,0 +1,184 @@
+"""Oracle H1 standing env: the reference's Python env/task logic over the C oracle physics.  TEST INFRASTRUCTURE ONLY.
+
+Follows (file:line in /root/reference): envs/h1/h1_base.py:95-119 (35-D robot state with observation noise),
+envs/common/base_humanoid_env.py:199-338 (step, reset_model, init noise, observation noise),
+envs/common/domain_randomization.py:10-56 (perturbation, dynamics randomisation), tasks/standing_task.py:49-131,
+robots/robot_base.py:41-98.  Random draws: oracle/rng.py with the slot layout documented inline (mirrored by the kernel).
+"""
+import numpy as np
+
+from . import rng
+from .env_jvrc_walk import quat2euler_sxyz
+from .physics import OracleSim
+
+STREAM_OBS = 4
+
+
+def euler2quat_sxyz(ai, aj, ak):
+    """transforms3d.euler.euler2quat, static xyz."""
+    ai, aj, ak = ai / 2.0, aj / 2.0, ak / 2.0
+    ci, si, cj, sj, ck, sk = np.cos(ai), np.sin(ai), np.cos(aj), np.sin(aj), np.cos(ak), np.sin(ak)
+    cc, cs, sc, ss = ci * ck, ci * sk, si * ck, si * sk
+    return np.array([cj * cc + sj * ss, cj * sc - sj * cs, cj * ss + sj * cc, cj * cs - sj * sc])
+
+
+def quat2mat(q):
+    w, x, y, z = q
+    Nq = w * w + x * x + y * y + z * z
+    s = 2.0 / Nq
+    X, Y, Z = x * s, y * s, z * s
+    wX, wY, wZ, xX, xY, xZ, yY, yZ, zZ = w * X, w * Y, w * Z, x * X, x * Y, x * Z, y * Y, y * Z, z * Z
+    return np.array([[1.0 - (yY + zZ), xY - wZ, xZ + wY], [xY + wZ, 1.0 - (xX + zZ), yZ - wX], [xZ - wY, yZ + wX, 1.0 - (xX + yY)]])
+
+
+class OracleH1Env:
+    TERMS = ["com_vel_error", "yaw_vel_error", "height", "upperbody", "joint_torque_reward", "posture"]
+
+    def __init__(self, spec, seed=0, env_id=0, max_traj_len=0):
+        self.spec = spec
+        self.m = spec.model().copy()          # per-env model: dynamics randomisation edits it
+        self.default = spec.model()
+        self.sim = OracleSim(self.m)
+        self.seed, self.env_id, self.max_traj_len = seed, env_id, max_traj_len
+        self.gear = self.m.actuator_gear.copy()
+        self.root, self.torso, self.rfoot, self.lfoot = spec.body_ids()
+        self.offset = spec.action_offset()
+        self.rand_dofs, self.rand_bodies = spec.rand_dofs(), spec.rand_bodies()
+        self.pbodies = [self.m.body_id(b) for b in spec.perturb_bodies]
+        self.prev_prediction = np.zeros(10)
+        self.prev_action = self.prev_torque = None
+        self.reset_count = self.step_count = self.obs_count = self.traj_len = 0
+
+    def _act_pos(self):
+        return self.sim.actuator_length / self.gear
+
+    def _act_vel(self):
+        return self.sim.actuator_velocity / self.gear
+
+    def _act_torque(self):
+        return self.sim.actuator_force * self.gear
+
+    def _self_collision(self):
+        m = self.m
+        for i in range(self.sim.ncon):
+            c = self.sim.contact(i)
+            if m.body_rootid[m.geom_bodyid[c["geom1"]]] == self.root and m.body_rootid[m.geom_bodyid[c["geom2"]]] == self.root:
+                return True
+        return False
+
+    def _randomize_dynamics(self, stream, counter, slot0):
+        """domain_randomization.py:29-56; slots: per leg dof (frictionloss, damping), then per body (mass scale, ipos xyz)."""
+        s, e, a = self.seed, self.env_id, self.m.arrays
+        for k, d in enumerate(self.rand_dofs):
+            a["dof_frictionloss"][d] = rng.uniform(s, e, stream, counter, slot0 + 2 * k, 0.0, 2.0)
+            a["dof_damping"][d] = rng.uniform(s, e, stream, counter, slot0 + 2 * k + 1, 0.02, 2.0)
+        for k, b in enumerate(self.rand_bodies):
+            base = slot0 + 20 + 4 * k
+            a["body_mass"][b] = self.default.body_mass[b] * rng.uniform(s, e, stream, counter, base, 0.95, 1.05)
+            for ax in range(3):
+                a["body_ipos"][b, ax] = self.default.body_ipos[b, ax] + rng.uniform(s, e, stream, counter, base + 1 + ax, -0.01, 0.01)
+        self.sim.repack()
+
+    def _apply_perturbation(self, counter):
+        """domain_randomization.py:10-26; slots 70.. : per body force xyz, torque xyz, coin."""
+        s, e, sp = self.seed, self.env_id, self.spec
+        for k, b in enumerate(self.pbodies):
+            base = 71 + 7 * k
+            for ax in range(3):
+                self.sim.xfrc_applied[b, ax] = rng.uniform(s, e, rng.STREAM_STEP, counter, base + ax, -sp.force_magnitude, sp.force_magnitude)
+                self.sim.xfrc_applied[b, 3 + ax] = rng.uniform(s, e, rng.STREAM_STEP, counter, base + 3 + ax, -sp.torque_magnitude, sp.torque_magnitude)
+            if rng.randint(s, e, rng.STREAM_STEP, counter, base + 6, 2) == 0:
+                self.sim.xfrc_applied[:] = 0
+
+    def get_obs(self):
+        q, v = self.sim.qpos, self.sim.qvel
+        r, p, _ = quat2euler_sxyz(q[3:7])
+        state = np.concatenate([[r], [p], v[3:6], self._act_pos(), self._act_vel(), self._act_torque()])
+        sc = self.spec.obs_noise_scale
+        if self.spec.obs_noise_enabled:
+            noise = np.array([rng.uniform(self.seed, self.env_id, STREAM_OBS, self.obs_count, k, -sc[k], sc[k]) for k in range(35)])
+            state = state + noise
+        self.obs_count += 1
+        return state
+
+    def set_state(self, qpos, qvel):
+        self.sim.qpos[:] = qpos
+        self.sim.qvel[:] = qvel
+        self.sim.forward(actuation=False)
+
+    def reset(self):
+        s, e, c, sp = self.seed, self.env_id, self.reset_count, self.spec
+        self.sim.reset_data()
+        if sp.dynrand_interval > 0:
+            self._randomize_dynamics(rng.STREAM_RESET, c, 0)
+        qpos = sp.nominal_pose.copy()
+        cn = np.deg2rad(sp.init_noise_deg)
+        if cn > 0:    # base_humanoid_env.py:278-305; slots 64 root z, 65/66 roll/pitch, 67.. joints
+            qpos[2] = rng.uniform(s, e, rng.STREAM_RESET, c, 64, qpos[2], qpos[2] + 0.02)
+            qpos[3:7] = euler2quat_sxyz(rng.uniform(s, e, rng.STREAM_RESET, c, 65, -cn, cn), rng.uniform(s, e, rng.STREAM_RESET, c, 66, -cn, cn), 0)
+            for k in range(10):
+                qpos[7 + k] += rng.uniform(s, e, rng.STREAM_RESET, c, 67 + k, -cn, cn)
+        self.set_state(qpos, np.zeros(self.m.nv))
+        for _ in range(3):
+            self.sim.step()
+        self.reset_count += 1
+        self.traj_len = 0
+        self.prev_prediction = np.zeros(10)
+        return self.get_obs()
+
+    def _calc_reward(self):
+        sim = self.sim
+        R = sim.xmat[self.root].reshape(3, 3)
+        head = R.T @ (sim.xpos[self.torso] - sim.xpos[self.root])
+        root_vel = sim.object_velocity(self.root, 1)[3:5]
+        return dict(
+            com_vel_error=0.3 * np.exp(-4 * np.square(np.linalg.norm(root_vel))),
+            yaw_vel_error=0.3 * np.exp(-4 * np.square(np.linalg.norm(sim.qvel[5]))),
+            height=0.1 * np.exp(-0.5 * np.square(np.linalg.norm(sim.xpos[self.root][2] - 0.98))),
+            upperbody=0.1 * np.exp(-40 * np.square(np.linalg.norm(head[:2]))),
+            joint_torque_reward=0.1 * np.exp(-5e-5 * np.square(np.linalg.norm(self._act_torque()))),
+            posture=0.1 * np.exp(-1 * np.square(np.linalg.norm(self._act_pos()[:10] - self.spec.half_sitting_pose))),
+        )
+
+    def step(self, action):
+        sp, sim = self.spec, self.sim
+        action = np.asarray(action, dtype=np.float32).astype(np.float64)
+        targets = sp.action_smoothing * action + (1 - sp.action_smoothing) * self.prev_prediction
+        act = targets + self.offset
+        if self.prev_action is None:
+            self.prev_action = act
+        if self.prev_torque is None:
+            self.prev_torque = np.asarray(self._act_torque()).copy()
+        for _ in range(sp.frame_skip):
+            tau = sp.kp * (act - self._act_pos()) + sp.kd * (0.0 - self._act_vel())
+            sim.ctrl[:] = tau / self.gear
+            sim.step()
+        terms = self._calc_reward()
+        z = sim.qpos[2]
+        done = bool(z < 0.9 or z > 1.4 or self._self_collision())
+        self.prev_action = act
+        self.prev_torque = np.asarray(self._act_torque()).copy()
+        obs = self.get_obs()
+        self.prev_prediction = action
+        c = self.step_count    # post-obs randomisation draws (base_humanoid_env.py:221-225): slot 0 / 70 triggers
+        if sp.dynrand_interval > 0 and rng.randint(self.seed, self.env_id, rng.STREAM_STEP, c, 0, sp.dynrand_interval) == 0:
+            self._randomize_dynamics(rng.STREAM_STEP, c, 1)
+        if sp.perturb_interval > 0 and rng.randint(self.seed, self.env_id, rng.STREAM_STEP, c, 70, sp.perturb_interval) == 0:
+            self._apply_perturbation(c)
+        self.step_count += 1
+        self.traj_len += 1
+        return obs, sum(terms.values()), done, terms
+
+    def step_auto(self, action):
+        obs, r, done, terms = self.step(action)
+        truncated = self.max_traj_len > 0 and self.traj_len >= self.max_traj_len
+        flags = int(done) | (2 if truncated else 0)
+        term_obs = obs
+        if self.max_traj_len > 0 and (done or truncated):
+            obs = self.reset()
+        return obs, r, flags, term_obs, terms
+
+
+def make_oracle_h1(seed=0, env_id=0, max_traj_len=0):
+    from learninghumanoidwalking_amd.envs.h1 import H1Spec
+    return OracleH1Env(H1Spec(), seed=seed, env_id=env_id, max_traj_len=max_traj_len)

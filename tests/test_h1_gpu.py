@@ -1,0 +1,123 @@
+"""H1 standing task (H1 stand-in model): HIP stepper with frictionloss rows, per-env dynamics randomisation, applied
+perturbation wrenches, observation / initialisation noise -- vs the float64 CPU oracle through the C ABI."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _pair(n, seed, max_traj_len=0):
+    import torch
+    from learninghumanoidwalking_amd.envs.h1 import H1Spec
+    from oracle.env_h1 import OracleH1Env
+    assert torch.cuda.is_available()
+    spec = H1Spec()
+    env = spec.make_batched(n, seed=seed, device=0, max_traj_len=max_traj_len)
+    orc = [OracleH1Env(spec, seed=seed, env_id=i, max_traj_len=max_traj_len) for i in range(n)]
+    return spec, env, orc
+
+
+def _states(orc):
+    return np.array([o.sim.qpos.copy() for o in orc]), np.array([o.sim.qvel.copy() for o in orc])
+
+
+def test_reset_with_randomisation_matches_oracle():
+    spec, env, orc = _pair(8, seed=3)
+    obs = env.reset().cpu().numpy()
+    ref = np.array([o.reset() for o in orc])
+    q, v = env.get_state()
+    oq, ov = _states(orc)
+    np.testing.assert_allclose(q, oq, rtol=0, atol=1e-12)
+    np.testing.assert_allclose(v, ov, rtol=0, atol=1e-10)
+    np.testing.assert_allclose(obs, ref, rtol=1e-6, atol=2e-6)
+    assert np.ptp(oq[:, 2]) > 1e-4 and np.ptp(oq[:, 7]) > 1e-3     # init noise actually differs between envs
+    assert all(o.sim.nefc >= 10 for o in orc)                       # frictionloss rows are active after dyn-rand
+
+
+def test_action_tape_resynchronised_with_dynrand_and_perturbation():
+    import torch
+    N, T = 4, 120
+    spec, env, orc = _pair(N, seed=12)
+    env.reset()
+    for o in orc:
+        o.reset()
+    tape = (np.random.default_rng(5).normal(size=(T, N, 10)) * 0.05).astype(np.float32)
+    n_done = n_pert = n_dyn = 0
+    prev_damp = [o.m.dof_damping.copy() for o in orc]
+    for t in range(T):
+        obs, rew, done, _ = env.step(torch.from_numpy(tape[t]).cuda())
+        res = [o.step(tape[t, i]) for i, o in enumerate(orc)]
+        q, v = env.get_state()
+        oq, ov = _states(orc)
+        np.testing.assert_allclose(q, oq, rtol=0, atol=1e-8, err_msg=f"qpos t={t}")
+        np.testing.assert_allclose(v, ov, rtol=0, atol=1e-7, err_msg=f"qvel t={t}")
+        np.testing.assert_allclose(obs.cpu().numpy(), np.array([r[0] for r in res]), rtol=1e-5, atol=2e-5, err_msg=f"obs t={t}")
+        np.testing.assert_allclose(rew.cpu().numpy(), np.array([r[1] for r in res]), rtol=0, atol=2e-6, err_msg=f"rew t={t}")
+        terms = np.array([[r[3][k] for k in o.TERMS] for r, o in zip(res, orc)])
+        np.testing.assert_allclose(env.rew_terms.cpu().numpy(), terms, rtol=0, atol=2e-6, err_msg=f"terms t={t}")
+        flags = np.array([int(r[2]) for r in res], dtype=np.uint8)
+        np.testing.assert_array_equal(done.cpu().numpy() & 1, flags, err_msg=f"done t={t}")
+        n_done += int(flags.sum())
+        n_pert += sum(np.abs(o.sim.xfrc_applied).max() > 0 for o in orc)
+        for i, o in enumerate(orc):
+            if not np.array_equal(prev_damp[i], o.m.dof_damping):
+                n_dyn += 1
+                prev_damp[i] = o.m.dof_damping.copy()
+        if t % 5 == 4 or flags.any():
+            for i, o in enumerate(orc):
+                if flags[i]:
+                    o.set_state(spec.nominal_pose, np.zeros(16))
+                else:
+                    o.set_state(o.sim.qpos.copy(), o.sim.qvel.copy())
+            oq, ov = _states(orc)
+            env.set_state(oq, ov)
+    assert n_done > 0 and n_dyn > 0, (n_done, n_dyn)
+    assert abs(float((env.rew_terms.sum(1) - env.rew).abs().max())) < 1e-6
+
+
+def test_perturbation_wrench_changes_motion_like_oracle():
+    """Force the perturbation path: interval 1 control step, so wrenches are drawn (and half the time cleared) every step."""
+    import torch
+    from learninghumanoidwalking_amd.envs.h1 import H1Spec
+    from oracle.env_h1 import OracleH1Env
+    spec = H1Spec()
+    spec.perturb_interval = 1
+    spec.force_magnitude, spec.torque_magnitude = 200.0, 40.0
+    N = 4
+    env = spec.make_batched(N, seed=7, device=0)
+    orc = [OracleH1Env(spec, seed=7, env_id=i) for i in range(N)]
+    env.reset()
+    for o in orc:
+        o.reset()
+    act = np.zeros((N, 10), np.float32)
+    seen = 0
+    for t in range(12):
+        env.step(torch.from_numpy(act).cuda())
+        for i, o in enumerate(orc):
+            o.step(act[i])
+        seen += sum(np.abs(o.sim.xfrc_applied).max() > 0 for o in orc)
+        q, v = env.get_state()
+        oq, ov = _states(orc)
+        np.testing.assert_allclose(q, oq, rtol=0, atol=1e-9, err_msg=f"t={t}")
+        np.testing.assert_allclose(v, ov, rtol=0, atol=1e-8, err_msg=f"t={t}")
+    assert seen > 0
+
+
+def test_auto_reset_flags():
+    import torch
+    N, T, L = 6, 60, 25
+    spec, env, orc = _pair(N, seed=21, max_traj_len=L)
+    env.reset()
+    for o in orc:
+        o.reset()
+    tape = (np.random.default_rng(7).normal(size=(T, N, 10)) * 0.1).astype(np.float32)
+    seen = 0
+    for t in range(T):
+        obs, rew, done, tob = env.step(torch.from_numpy(tape[t]).cuda())
+        res = [o.step_auto(tape[t, i]) for i, o in enumerate(orc)]
+        flags = np.array([r[2] for r in res], dtype=np.uint8)
+        np.testing.assert_array_equal(done.cpu().numpy(), flags, err_msg=f"flags t={t}")
+        np.testing.assert_allclose(obs.cpu().numpy(), np.array([r[0] for r in res]), rtol=1e-4, atol=1e-4, err_msg=f"obs t={t}")
+        np.testing.assert_allclose(tob.cpu().numpy(), np.array([r[3] for r in res]), rtol=1e-4, atol=1e-4, err_msg=f"term obs t={t}")
+        seen |= int(np.bitwise_or.reduce(flags))
+    assert seen & 1
