@@ -107,7 +107,7 @@ def main():
     env_name = args.env
     if env_name == "auto":
         env_name = "jvrc_walk" if hasattr(lenvs, "JvrcWalkSpec") else "cartpole"
-    spec_cls = {"cartpole": lenvs.CartpoleSpec, "jvrc_walk": getattr(lenvs, "JvrcWalkSpec", None)}[env_name]
+    spec_cls = lenvs.ENVIRONMENTS[env_name]
     ppo_args = SimpleNamespace(
         gamma=0.99, lam=0.95, lr=3e-4, eps=1e-5, entropy_coeff=0.0, clip=0.2, minibatch_size=args.minibatch_size,
         epochs=args.epochs, max_traj_len=args.traj_len, num_procs=args.num_envs, num_envs=args.num_envs, max_grad_norm=0.5,
@@ -184,7 +184,7 @@ def main():
             n_gpus=world, steps=K, warmup=args.warmup, ms_per_step=elapsed / K * 1e3, higher_is_better=True, scaling="weak",
             vs_baseline=None, dtype="f64 physics / f32 networks", data="synthetic",
             config=dict(workload=f"{env_name} @ {N} envs/GPU, T={T} control steps/iter, {args.epochs} epochs, "
-                                 f"minibatch {args.minibatch_size}/GPU" + (" (JVRC stand-in model)" if env_name.startswith("jvrc") else ""),
+                                 f"minibatch {args.minibatch_size}/GPU" + (" (JVRC stand-in model)" if env_name.startswith("jvrc") else " (H1 stand-in model)" if env_name.startswith("h1") else ""),
                         envs_per_gpu=N, traj_len=T, epochs=args.epochs, minibatch_per_gpu=args.minibatch_size,
                         mirror=not args.no_mirror and spec.mirror_tables() is not None,
                         frame_skip=spec.frame_skip, sim_dt=spec.sim_dt, control_dt=spec.control_dt),

@@ -1,11 +1,12 @@
 """Host-side mirrors of the reference's environments (reference envs/__init__.py:13-19)."""
 from .cartpole import CartpoleSpec, make_cartpole  # noqa: F401
+from .h1 import H1Spec  # noqa: F401
 from .jvrc_walk import JvrcWalkSpec  # noqa: F401
 
-ENVIRONMENTS = {"cartpole": CartpoleSpec, "jvrc_walk": JvrcWalkSpec}
+ENVIRONMENTS = {"cartpole": CartpoleSpec, "jvrc_walk": JvrcWalkSpec, "h1": H1Spec}
 
 
 def single_env(name, **kw):
     """The reference's ``Env(path_to_yaml)`` single-env object for ``name`` (GPU required)."""
     from . import adapters
-    return {"cartpole": adapters.CartpoleEnv, "jvrc_walk": adapters.JvrcWalkEnv}[name](**kw)
+    return {"cartpole": adapters.CartpoleEnv, "jvrc_walk": adapters.JvrcWalkEnv, "h1": adapters.H1Env}[name](**kw)

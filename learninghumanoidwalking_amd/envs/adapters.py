@@ -10,6 +10,7 @@ import numpy as np
 import torch
 
 from .cartpole import CartpoleSpec
+from .h1 import H1Spec
 from .jvrc_walk import JvrcWalkSpec
 
 
@@ -66,3 +67,10 @@ class JvrcWalkEnv(_SingleEnv):
         super().__init__(spec, seed=seed, device=device)
         mo, ma, clock = spec.mirror_inds()
         self.robot.mirrored_obs, self.robot.mirrored_acts, self.robot.clock_inds = mo, ma, clock
+
+
+class H1Env(_SingleEnv):
+    TERMS = ["com_vel_error", "yaw_vel_error", "height", "upperbody", "joint_torque_reward", "posture"]   # standing_task.py:99-106
+
+    def __init__(self, path_to_yaml=None, seed=0, device=0):
+        super().__init__(H1Spec(yaml_path=path_to_yaml) if path_to_yaml else H1Spec(), seed=seed, device=device)

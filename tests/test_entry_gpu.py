@@ -11,7 +11,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("name", ["cartpole", "jvrc_walk"])
+@pytest.mark.parametrize("name", ["cartpole", "jvrc_walk", "h1"])
 def test_single_env_surface(name):
     from learninghumanoidwalking_amd.envs import single_env
     env = single_env(name, seed=1)

@@ -94,3 +94,17 @@ def test_euler_and_fromto_orientation():
     R = mjcf.quat2mat(m.geom_quat[0])
     np.testing.assert_allclose(R[:, 2], [1, 0, 0], atol=1e-12)   # capsule axis along fromto
     assert abs(m.geom_size[0][1] - 0.5) < 1e-15
+
+
+def test_h1_standin_structure():
+    from learninghumanoidwalking_amd.envs.h1 import H1Spec, LEG_JOINTS as H1_LEGS
+    spec = H1Spec()
+    m = spec.model()
+    assert (m.nq, m.nv, m.nu) == (17, 16, 10)
+    assert [m.jnt_names[j] for j in m.actuator_trnid] == H1_LEGS and m.actuator_names == [j + "_motor" for j in H1_LEGS]
+    assert m.body_names[1] == "pelvis" and not m.jnt_limited.any() and not m.actuator_ctrllimited.any()   # configs/base.yaml:9-10
+    assert m.body_mass[m.body_id("pelvis")] == 8.89 and m.body_mass[m.body_id("torso_link")] == 21.289     # h1_base.py:44-45
+    assert spec.dynrand_interval == 20 and spec.perturb_interval == 200 and spec.frame_skip == 25
+    assert len(spec.rand_bodies()) == 11 and len(spec.rand_dofs()) == 10
+    np.testing.assert_allclose(spec.obs_noise_scale, [0.05] * 5 + [0.02] * 10 + [0.05] * 10 + [5.0] * 10)
+    assert len(spec.task_iparams()) == 30 and len(spec.task_params()) == 39
