@@ -40,8 +40,7 @@ struct GemmArgs {
   const float* bias;        // + bias[n]
   int relu;                 // max(0, .)
   const float* mask; int ldmask;  // *= (mask[m][n] > 0)
-  float* colsum;            // atomicAdd column sums of the stored tile
-  int atomic_out;           // atomicAdd into C (split-K)
+  float* part;              // split-K: slice z stores its partial product at part + z*M*N (row-major, ld N); reduced in slice order afterwards
   int k_chunk;              // K range per blockIdx.z
 };
 
@@ -140,8 +139,8 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(GemmArgs g) {
 
   // epilogue; C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
   const int col = n0 + wn * 32 + (lane & 31);
-  float csum = 0.f;
   const float bias = (g.bias && col < g.N) ? g.bias[col] : 0.f;
+  float* part = g.part ? g.part + (size_t)blockIdx.z * g.M * g.N : nullptr;
 #pragma unroll
   for (int r = 0; r < 16; r++) {
     int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
@@ -149,15 +148,32 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(GemmArgs g) {
       float v = acc[r] + bias;
       if (g.relu) v = fmaxf(v, 0.f);
       if (g.mask) v = g.mask[(size_t)row * g.ldmask + col] > 0.f ? v : 0.f;
-      if (g.atomic_out) atomicAdd(g.C + (size_t)row * g.ldc + col, v);
+      if (part) part[(size_t)row * g.N + col] = v;
       else g.C[(size_t)row * g.ldc + col] = v;
-      csum += v;
     }
   }
-  if (g.colsum) {
-    csum += __shfl_xor(csum, 32);
-    if (lane < 32 && col < g.N) atomicAdd(g.colsum + col, csum);
-  }
+}
+
+// out[row*ldc + col] += sum over slices (in slice order) of part[z][row*N + col]: deterministic split-K reduction
+__global__ void __launch_bounds__(256) reduce_slices_kernel(const float* __restrict__ part, int nslices, int M, int N, float* __restrict__ out, int ldc) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= M * N) return;
+  float s = 0.f;
+  for (int z = 0; z < nslices; z++) s += part[(size_t)z * M * N + i];
+  const int row = i / N, col = i - row * N;
+  out[(size_t)row * ldc + col] += s;
+}
+
+// out[col] += sum over rows of X[row][col] in a fixed order: 64 columns per block, 4 row groups summed strided then combined
+__global__ void __launch_bounds__(256) colsum_det_kernel(const float* __restrict__ X, int rows, int ld, int ncols, float* __restrict__ out) {
+  __shared__ float red[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6;
+  float s = 0.f;
+  if (c < ncols)
+    for (int r = g; r < rows; r += 4) s += X[(size_t)r * ld + c];
+  red[g][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (g == 0 && c < ncols) out[c] += (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
 template <bool A_KC, bool B_KC>
@@ -167,6 +183,10 @@ static void launch_gemm(const GemmArgs& g, hipStream_t s) {
   a.k_chunk = ((a.k_chunk + BK - 1) / BK) * BK;
   dim3 grid((a.M + BM - 1) / BM, (a.N + BN - 1) / BN, (a.K + a.k_chunk - 1) / a.k_chunk);
   hipLaunchKernelGGL((gemm_f32_kernel<A_KC, B_KC>), grid, dim3(256), 0, s, a);
+  if (a.part) {  // ordered reduction of the split-K slices into the (accumulating) destination
+    const int n = a.M * a.N;
+    hipLaunchKernelGGL(reduce_slices_kernel, dim3((n + 255) / 256), dim3(256), 0, s, a.part, (int)grid.z, a.M, a.N, a.C, a.ldc);
+  }
 }
 
 // ------------------------------------------------------------------------------------------- MLP plumbing
@@ -209,6 +229,12 @@ struct LhwPpo {
   float *dyc = nullptr, *dh2c = nullptr, *dh1c = nullptr;
   float *mb_act = nullptr, *mb_logp = nullptr, *mb_adv = nullptr, *mb_ret = nullptr;
   float *stats = nullptr;  // [16] loss scalars; [8],[9] grad norm^2 actor/critic
+  float *part = nullptr;       // split-K partial tiles [max slices][H*H]
+  float *dstd = nullptr;       // per-row d loss / d std [R][Op]
+  float *stats_part = nullptr; // per-block loss partials [blocks][5]
+  float *norm_part = nullptr;  // [2][SUMSQ_BLOCKS]
+  double *mom_part = nullptr;  // [MOM_BLOCKS][2]
+  int max_slices = 0;
 };
 
 #define HIPCHK(x)                                                                                   \
@@ -234,33 +260,40 @@ static void mlp_forward(const MlpLayout& L, const float* theta, const float* x, 
   launch_gemm<true, true>(g, s);
 }
 
-// accumulates parameter gradients of one MLP given dy [R][Op]
+// accumulates parameter gradients of one MLP given dy [R][Op]; every reduction runs in a fixed order (same seed ->
+// bitwise identical weights, the property the reference's tests/test_determinism.py checks)
+static void colsum_det(const float* X, int rows, int ld, int ncols, float* out, hipStream_t s) {
+  hipLaunchKernelGGL(colsum_det_kernel, dim3((ncols + 63) / 64), dim3(256), 0, s, X, rows, ld, ncols, out);
+}
 static void mlp_backward(const MlpLayout& L, const float* theta, float* grad, const float* x, int ldx, int R, const float* h1,
-                         const float* h2, const float* dy, float* dh2, float* dh1, int k_chunk, hipStream_t s) {
+                         const float* h2, const float* dy, float* dh2, float* dh1, int k_chunk, float* part, hipStream_t s) {
   GemmArgs g{};
-  // dW3 [O][H] += dy^T h2 ; db3 from the loss kernel (it owns dy)
+  // dW3 [O][H] += dy^T h2 ; db3 += colsum(dy)
   g.A = dy; g.lda = L.Op; g.B = h2; g.ldb = L.H; g.C = grad + L.w3; g.ldc = L.H; g.M = L.O; g.N = L.H; g.K = R;
-  g.atomic_out = 1; g.k_chunk = k_chunk;
+  g.part = part; g.k_chunk = k_chunk;
   launch_gemm<false, false>(g, s);
-  // dh2 = (dy W3) * (h2 > 0) ; db2 = colsum(dh2)
+  colsum_det(dy, R, L.Op, L.O, grad + L.b3, s);
+  // dh2 = (dy W3) * (h2 > 0) ; db2 += colsum(dh2)
   g = GemmArgs{};
   g.A = dy; g.lda = L.Op; g.B = theta + L.w3; g.ldb = L.H; g.C = dh2; g.ldc = L.H; g.M = R; g.N = L.H; g.K = L.O;
-  g.mask = h2; g.ldmask = L.H; g.colsum = grad + L.b2;
+  g.mask = h2; g.ldmask = L.H;
   launch_gemm<true, false>(g, s);
+  colsum_det(dh2, R, L.H, L.H, grad + L.b2, s);
   // dW2 += dh2^T h1
   g = GemmArgs{};
   g.A = dh2; g.lda = L.H; g.B = h1; g.ldb = L.H; g.C = grad + L.w2; g.ldc = L.H; g.M = L.H; g.N = L.H; g.K = R;
-  g.atomic_out = 1; g.k_chunk = k_chunk;
+  g.part = part; g.k_chunk = k_chunk;
   launch_gemm<false, false>(g, s);
-  // dh1 = (dh2 W2) * (h1 > 0) ; db1 = colsum(dh1)
+  // dh1 = (dh2 W2) * (h1 > 0) ; db1 += colsum(dh1)
   g = GemmArgs{};
   g.A = dh2; g.lda = L.H; g.B = theta + L.w2; g.ldb = L.H; g.C = dh1; g.ldc = L.H; g.M = R; g.N = L.H; g.K = L.H;
-  g.mask = h1; g.ldmask = L.H; g.colsum = grad + L.b1;
+  g.mask = h1; g.ldmask = L.H;
   launch_gemm<true, false>(g, s);
+  colsum_det(dh1, R, L.H, L.H, grad + L.b1, s);
   // dW1 [H][Dp] += dh1^T x
   g = GemmArgs{};
   g.A = dh1; g.lda = L.H; g.B = x; g.ldb = ldx; g.C = grad + L.w1; g.ldc = L.Dp; g.M = L.H; g.N = L.Dp; g.K = R;
-  g.atomic_out = 1; g.k_chunk = k_chunk;
+  g.part = part; g.k_chunk = k_chunk;
   launch_gemm<false, false>(g, s);
 }
 
@@ -323,26 +356,22 @@ __global__ void sample_kernel(const float* __restrict__ mu, int ldmu, int A, int
   logp[n] = lp;
 }
 
-// PPO losses and their gradients wrt network outputs (reference rl/algos/ppo.py:302-384, FF path, mask = 1)
-// stats: 0 actor_loss  1 critic_loss  2 mirror_loss  3 approx_kl  4 clip_fraction (all already divided by B)
+// PPO losses and their gradients wrt network outputs (reference rl/algos/ppo.py:302-384, FF path, mask = 1).
+// No atomics: bias / std gradients are column sums of dya / dyc / dstd taken afterwards in a fixed order, and the loss
+// scalars are written as per-block partials [gridDim.x][5]: 0 actor_loss 1 critic_loss 2 mirror_loss 3 approx_kl
+// 4 clip_fraction (already divided by B).
 __global__ void __launch_bounds__(256) ppo_loss_kernel(int B, int Rcap, int A, int Op, const float* __restrict__ ya,
                                                        const float* __restrict__ yc, const float* __restrict__ act,
                                                        const float* __restrict__ old_logp, const float* __restrict__ adv,
                                                        const float* __restrict__ ret, const float* __restrict__ stdv,
-                                                       float clip, float mirror_coeff, float ent_coeff, int use_mirror,
+                                                       float clip, float mirror_coeff, int use_mirror,
                                                        const int* __restrict__ act_src, const float* __restrict__ act_sign,
                                                        float* __restrict__ dya, float* __restrict__ dyc,
-                                                       float* __restrict__ grad_b3a, float* __restrict__ grad_b3c,
-                                                       float* __restrict__ grad_std, float* __restrict__ stats) {
+                                                       float* __restrict__ dstd /* [B][Op] or NULL */, float* __restrict__ stats_part) {
   int m = blockIdx.x * blockDim.x + threadIdx.x;
   float s_actor = 0, s_critic = 0, s_mirror = 0, s_kl = 0, s_cf = 0;
   const float invB = 1.f / (float)B, invBA = 1.f / ((float)B * (float)A);
   __shared__ float red[5][4];
-  __shared__ float sb3[32];   // actor bias-3 grads, block partial
-  __shared__ float sstd[32];
-  if (threadIdx.x < 32) { sb3[threadIdx.x] = 0.f; sstd[threadIdx.x] = 0.f; }
-  __syncthreads();
-  float dcrit = 0.f;
   if (m < B) {
     float lp = 0.f;
     for (int a = 0; a < A; a++) {
@@ -362,65 +391,58 @@ __global__ void __launch_bounds__(256) ppo_loss_kernel(int B, int Rcap, int A, i
     float v = yc[(size_t)m * 4];
     float e = ret[m] - v;
     s_critic = e * e;
-    dcrit = -2.f * e * invB;
-    dyc[(size_t)m * 4] = dcrit;
+    dyc[(size_t)m * 4] = -2.f * e * invB;
     dyc[(size_t)m * 4 + 1] = 0.f; dyc[(size_t)m * 4 + 2] = 0.f; dyc[(size_t)m * 4 + 3] = 0.f;
+    if (use_mirror) for (int a = 0; a < Op; a++) dya[((size_t)Rcap + m) * Op + a] = 0.f;
     for (int a = 0; a < Op; a++) {
-      float g = 0.f, gm = 0.f;
+      float g = 0.f, gs = 0.f;
       if (a < A) {
         float mu = ya[(size_t)m * Op + a], sd = stdv[a], x = act[(size_t)m * A + a];
         g = dlp * (x - mu) / (sd * sd);
-        if (grad_std) atomicAdd(&sstd[a], dlp * ((x - mu) * (x - mu) / (sd * sd * sd) - 1.f / sd));
+        gs = dlp * ((x - mu) * (x - mu) / (sd * sd * sd) - 1.f / sd);
         if (use_mirror) {
-          // mirror_actions[j] = sum_i mu_mir[i] M[i][j]; M[i][src... ] stored as gather: out[j] = sign[j]*in[src[j]]
+          // mirror_actions[a] = sign[a] * mu_mir[src[a]]  (== mu_mir @ M_a, rl/envs/wrappers.py:49-51)
           float mm = act_sign[a] * ya[((size_t)Rcap + m) * Op + act_src[a]];
           float diff = mu - mm;
           s_mirror += diff * diff;
           g += mirror_coeff * 2.f * diff * invBA;
+          // gradient wrt the mirrored-pass output it came from (act_src is a permutation: each slot written once)
+          dya[((size_t)Rcap + m) * Op + act_src[a]] = -mirror_coeff * 2.f * diff * invBA * act_sign[a];
         }
-        atomicAdd(&sb3[a], g);
       }
       dya[(size_t)m * Op + a] = g;
-      (void)gm;
-    }
-    if (use_mirror) {
-      // gradient wrt the mirrored-pass outputs: d/d mu_mir[src[a]] += -2 coeff sign[a] (mu[a]-mm[a]) / (B A)
-      for (int a = 0; a < Op; a++) dya[((size_t)Rcap + m) * Op + a] = 0.f;
-      for (int a = 0; a < A; a++) {
-        float mm = act_sign[a] * ya[((size_t)Rcap + m) * Op + act_src[a]];
-        float diff = ya[(size_t)m * Op + a] - mm;
-        float gg = -mirror_coeff * 2.f * diff * invBA * act_sign[a];
-        dya[((size_t)Rcap + m) * Op + act_src[a]] += gg;  // act_src is a permutation: no intra-thread race
-        atomicAdd(&sb3[act_src[a]], gg);
-      }
+      if (dstd) dstd[(size_t)m * Op + a] = gs;
     }
   }
-  // block reduction of the scalars
+  // block reduction of the scalars in a fixed order (xor butterfly inside the wave, then waves 0..3)
   float vals[5] = {s_actor * invB, s_critic * invB, s_mirror * invBA, s_kl * invB, s_cf * invB};
-  float dc = dcrit;
-  for (int o = 32; o > 0; o >>= 1) {
+  for (int o = 32; o > 0; o >>= 1)
     for (int k = 0; k < 5; k++) vals[k] += __shfl_xor(vals[k], o);
-    dc += __shfl_xor(dc, o);
-  }
   int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (lane == 0) {
+  if (lane == 0)
     for (int k = 0; k < 5; k++) red[k][wave] = vals[k];
-    atomicAdd(grad_b3c, dc);
-  }
   __syncthreads();
-  if (threadIdx.x < 5) atomicAdd(stats + threadIdx.x, red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3]);
-  if (threadIdx.x < A) {
-    atomicAdd(grad_b3a + threadIdx.x, sb3[threadIdx.x]);
-    if (grad_std) {
-      // entropy_penalty = -mean(entropy) = -mean_a(0.5 + 0.5 log 2pi + log std_a): d/d std_a = -1/(A std_a) (ppo.py:343,380)
-      float ge = blockIdx.x == 0 ? -ent_coeff / ((float)A * stdv[threadIdx.x]) : 0.f;
-      atomicAdd(grad_std + threadIdx.x, sstd[threadIdx.x] + ge);
-    }
-  }
+  if (threadIdx.x < 5) stats_part[(size_t)blockIdx.x * 5 + threadIdx.x] = (red[threadIdx.x][0] + red[threadIdx.x][1]) + (red[threadIdx.x][2] + red[threadIdx.x][3]);
 }
 
-// sum of squares of a flat range (grad norm), with pre-scale
-__global__ void __launch_bounds__(256) sumsq_kernel(const float* __restrict__ g, size_t n, float scale, float* __restrict__ out) {
+// out[k] += sum_b part[b][n] in block order (single block; n small)
+__global__ void reduce_rows_kernel(const float* __restrict__ part, int nrows, int n, float* __restrict__ out) {
+  int k = threadIdx.x;
+  if (k >= n) return;
+  float s = 0.f;
+  for (int b = 0; b < nrows; b++) s += part[(size_t)b * n + k];
+  out[k] += s;
+}
+
+// entropy_penalty = -mean(entropy) = -mean_a(0.5 + 0.5 log 2pi + log std_a): d/d std_a = -1/(A std_a) (ppo.py:343,380)
+__global__ void entropy_grad_kernel(const float* __restrict__ stdv, int A, float ent_coeff, float* __restrict__ grad_std) {
+  int a = threadIdx.x;
+  if (a < A) grad_std[a] += -ent_coeff / ((float)A * stdv[a]);
+}
+
+// sum of squares of a flat range (grad norm), with pre-scale: per-block partials (fixed grid), summed in block order
+#define SUMSQ_BLOCKS 128
+__global__ void __launch_bounds__(256) sumsq_kernel(const float* __restrict__ g, size_t n, float scale, float* __restrict__ part) {
   float s = 0.f;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
     float v = g[i] * scale;
@@ -430,7 +452,14 @@ __global__ void __launch_bounds__(256) sumsq_kernel(const float* __restrict__ g,
   __shared__ float red[4];
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+  if (threadIdx.x == 0) part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+__global__ void sumsq_final_kernel(const float* __restrict__ part, int n, float* __restrict__ out) {
+  if (threadIdx.x == 0) {
+    float s = 0.f;
+    for (int b = 0; b < n; b++) s += part[b];
+    *out = s;
+  }
 }
 
 // clip_grad_norm_ (coef = max_norm/(norm+1e-6), applied only if < 1) + torch.optim.Adam step; zeroes the gradient
@@ -479,7 +508,8 @@ __global__ void __launch_bounds__(256) gae_kernel(int T, int N, const float* __r
 }
 
 // advantage normalisation: (a - mean) / (std_unbiased + eps) from global moments
-__global__ void moments_kernel(const float* __restrict__ x, size_t n, double* __restrict__ out) {
+#define MOM_BLOCKS 256
+__global__ void __launch_bounds__(256) moments_kernel(const float* __restrict__ x, size_t n, double* __restrict__ part) {
   double s = 0, s2 = 0;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
     double v = x[i];
@@ -490,8 +520,15 @@ __global__ void moments_kernel(const float* __restrict__ x, size_t n, double* __
   if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s; red[1][threadIdx.x >> 6] = s2; }
   __syncthreads();
   if (threadIdx.x == 0) {
-    atomicAdd(out, red[0][0] + red[0][1] + red[0][2] + red[0][3]);
-    atomicAdd(out + 1, red[1][0] + red[1][1] + red[1][2] + red[1][3]);
+    part[2 * blockIdx.x] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+    part[2 * blockIdx.x + 1] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+  }
+}
+__global__ void moments_final_kernel(const double* __restrict__ part, int n, double* __restrict__ out) {
+  if (threadIdx.x < 2) {
+    double s = 0;
+    for (int b = 0; b < n; b++) s += part[2 * b + threadIdx.x];
+    out[threadIdx.x] = s;
   }
 }
 __global__ void scale_shift_kernel(float* __restrict__ x, size_t n, float mean, float inv) {
@@ -526,7 +563,11 @@ extern "C" int lhw_ppo_create(const LhwPpoConfig* c, LhwPpo** out) {
             alloc(&p->h1c, R * H) && alloc(&p->h2c, R * H) && alloc(&p->yc, R * 4) && alloc(&p->dya, 2 * R * Op) &&
             alloc(&p->dh2a, 2 * R * H) && alloc(&p->dh1a, 2 * R * H) && alloc(&p->dyc, R * 4) && alloc(&p->dh2c, R * H) &&
             alloc(&p->dh1c, R * H) && alloc(&p->mb_act, R * p->A) && alloc(&p->mb_logp, R) && alloc(&p->mb_adv, R) &&
-            alloc(&p->mb_ret, R) && alloc(&p->stats, 16);
+            alloc(&p->mb_ret, R) && alloc(&p->stats, 16) && alloc(&p->dstd, R * Op) && alloc(&p->stats_part, ((R + 255) / 256) * 5) &&
+            alloc(&p->norm_part, 2 * SUMSQ_BLOCKS);
+  p->max_slices = (int)((R + 511) / 512);
+  ok = ok && alloc(&p->part, (size_t)p->max_slices * H * std::max<size_t>(H, Dp)) &&
+       hipMalloc(&p->mom_part, sizeof(double) * 2 * MOM_BLOCKS) == hipSuccess;
   if (ok && p->use_mirror) {
     std::vector<int> osrc(Dp, 0), asrc(p->A, 0);
     std::vector<float> osgn(Dp, 0.f), asgn(p->A, 0.f);
@@ -555,10 +596,12 @@ extern "C" int lhw_ppo_destroy(LhwPpo* p) {
   if (!p) return LHW_OK;
   (void)hipSetDevice(p->device);
   float* bufs[] = {p->xb, p->h1a, p->h2a, p->ya, p->h1c, p->h2c, p->yc, p->dya, p->dh2a, p->dh1a, p->dyc, p->dh2c, p->dh1c,
-                   p->mb_act, p->mb_logp, p->mb_adv, p->mb_ret, p->stats, p->d_obs_sign, p->d_act_sign};
+                   p->mb_act, p->mb_logp, p->mb_adv, p->mb_ret, p->stats, p->d_obs_sign, p->d_act_sign, p->part, p->dstd, p->stats_part,
+                   p->norm_part};
   for (float* b : bufs) if (b) (void)hipFree(b);
   if (p->d_obs_src) (void)hipFree(p->d_obs_src);
   if (p->d_act_src) (void)hipFree(p->d_act_src);
+  if (p->mom_part) (void)hipFree(p->mom_part);
   delete p;
   return LHW_OK;
 }
@@ -633,9 +676,10 @@ extern "C" int lhw_gae(int32_t T, int32_t N, const float* rew, const float* val,
 // sum and sum of squares (float64) of x[0..n): the caller all-reduces them across GPUs, then calls lhw_scale_shift
 extern "C" int lhw_moments(const float* x, int64_t n, double* out2_dev, void* stream) {
   if (!x || !out2_dev || n <= 0) return lhw_fail(LHW_ERR_ARG, "bad argument");
-  HIPCHK(hipMemsetAsync(out2_dev, 0, 2 * sizeof(double), (hipStream_t)stream));
-  int blocks = (int)std::min<int64_t>((n + 255) / 256, 2048);
-  hipLaunchKernelGGL(moments_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, (size_t)n, out2_dev);
+  static thread_local double* scratch = nullptr;  // per-thread, per-process partial buffer (device of the first call)
+  if (!scratch) HIPCHK(hipMalloc(&scratch, sizeof(double) * 2 * MOM_BLOCKS));
+  hipLaunchKernelGGL(moments_kernel, dim3(MOM_BLOCKS), dim3(256), 0, (hipStream_t)stream, x, (size_t)n, scratch);
+  hipLaunchKernelGGL(moments_final_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, scratch, MOM_BLOCKS, out2_dev);
   HIPCHK(hipGetLastError());
   return LHW_OK;
 }
@@ -668,16 +712,21 @@ extern "C" int lhw_ppo_grad(LhwPpo* p, const float* theta, float* grad, const fl
   if (mir)
     mlp_forward(p->la, th_a, p->xb + (size_t)R * Dp, Dp, B, p->h1a + (size_t)R * p->H, p->h2a + (size_t)R * p->H, p->ya + (size_t)R * Op, s);
   mlp_forward(p->lc, th_c, p->xb, Dp, B, p->h1c, p->h2c, p->yc, s);
-  hipLaunchKernelGGL(ppo_loss_kernel, dim3((B + 255) / 256), dim3(256), 0, s, B, R, p->A, Op, p->ya, p->yc, p->mb_act, p->mb_logp,
-                     p->mb_adv, p->mb_ret, theta + p->off_std, p->clip, p->mirror_coeff, p->ent_coeff, mir, p->d_act_src, p->d_act_sign, p->dya,
-                     p->dyc, grad + p->off_actor + p->la.b3, grad + p->off_critic + p->lc.b3,
-                     p->learn_std ? grad + p->off_std : (float*)nullptr, stats_dev);
+  const int nblk = (B + 255) / 256;
+  hipLaunchKernelGGL(ppo_loss_kernel, dim3(nblk), dim3(256), 0, s, B, R, p->A, Op, p->ya, p->yc, p->mb_act, p->mb_logp,
+                     p->mb_adv, p->mb_ret, theta + p->off_std, p->clip, p->mirror_coeff, mir, p->d_act_src, p->d_act_sign, p->dya,
+                     p->dyc, p->learn_std ? p->dstd : (float*)nullptr, p->stats_part);
+  hipLaunchKernelGGL(reduce_rows_kernel, dim3(1), dim3(64), 0, s, p->stats_part, nblk, 5, stats_dev);
+  if (p->learn_std) {
+    colsum_det(p->dstd, B, Op, p->A, grad + p->off_std, s);
+    hipLaunchKernelGGL(entropy_grad_kernel, dim3(1), dim3(64), 0, s, theta + p->off_std, p->A, p->ent_coeff, grad + p->off_std);
+  }
   const int kc = 512;
-  mlp_backward(p->la, th_a, grad + p->off_actor, p->xb, Dp, B, p->h1a, p->h2a, p->dya, p->dh2a, p->dh1a, kc, s);
+  mlp_backward(p->la, th_a, grad + p->off_actor, p->xb, Dp, B, p->h1a, p->h2a, p->dya, p->dh2a, p->dh1a, kc, p->part, s);
   if (mir)
     mlp_backward(p->la, th_a, grad + p->off_actor, p->xb + (size_t)R * Dp, Dp, B, p->h1a + (size_t)R * p->H, p->h2a + (size_t)R * p->H,
-                 p->dya + (size_t)R * Op, p->dh2a + (size_t)R * p->H, p->dh1a + (size_t)R * p->H, kc, s);
-  mlp_backward(p->lc, th_c, grad + p->off_critic, p->xb, Dp, B, p->h1c, p->h2c, p->dyc, p->dh2c, p->dh1c, kc, s);
+                 p->dya + (size_t)R * Op, p->dh2a + (size_t)R * p->H, p->dh1a + (size_t)R * p->H, kc, p->part, s);
+  mlp_backward(p->lc, th_c, grad + p->off_critic, p->xb, Dp, B, p->h1c, p->h2c, p->dyc, p->dh2c, p->dh1c, kc, p->part, s);
   HIPCHK(hipGetLastError());
   return LHW_OK;
 }
@@ -689,11 +738,12 @@ extern "C" int lhw_ppo_apply(LhwPpo* p, float* theta, float* grad, float* adam_m
   if (!p || !theta || !grad || !adam_m || !adam_v || step <= 0) return lhw_fail(LHW_ERR_ARG, "bad argument");
   HIPCHK(hipSetDevice(p->device));
   hipStream_t s = (hipStream_t)stream;
-  HIPCHK(hipMemsetAsync(p->stats + 8, 0, 2 * sizeof(float), s));
   const size_t na = p->learn_std ? p->off_std + p->A : p->off_std;  // actor group (+ stds if they are parameters)
   const size_t nc = p->lc.total;
-  hipLaunchKernelGGL(sumsq_kernel, dim3(std::min<size_t>((na + 255) / 256, 512)), dim3(256), 0, s, grad, na, grad_scale, p->stats + 8);
-  hipLaunchKernelGGL(sumsq_kernel, dim3(std::min<size_t>((nc + 255) / 256, 512)), dim3(256), 0, s, grad + p->off_critic, nc, grad_scale, p->stats + 9);
+  hipLaunchKernelGGL(sumsq_kernel, dim3(SUMSQ_BLOCKS), dim3(256), 0, s, grad, na, grad_scale, p->norm_part);
+  hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(64), 0, s, p->norm_part, SUMSQ_BLOCKS, p->stats + 8);
+  hipLaunchKernelGGL(sumsq_kernel, dim3(SUMSQ_BLOCKS), dim3(256), 0, s, grad + p->off_critic, nc, grad_scale, p->norm_part + SUMSQ_BLOCKS);
+  hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(64), 0, s, p->norm_part + SUMSQ_BLOCKS, SUMSQ_BLOCKS, p->stats + 9);
   const float bc1 = 1.f - powf(p->beta1, (float)step), bc2 = 1.f - powf(p->beta2, (float)step);
   hipLaunchKernelGGL(adam_kernel, dim3((na + 255) / 256), dim3(256), 0, s, theta, grad, adam_m, adam_v, na, grad_scale, p->stats + 8,
                      p->grad_clip, p->lr, p->beta1, p->beta2, p->adam_eps, bc1, sqrtf(bc2));

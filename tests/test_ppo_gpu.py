@@ -172,3 +172,31 @@ def test_large_minibatch_against_oracle():
     for i, n in enumerate(NAMES):
         np.testing.assert_allclose(t[f"a_{n}"].numpy(), orc.actor[i].detach().numpy(), rtol=0, atol=2e-6, err_msg=f"actor {n}")
         np.testing.assert_allclose(t[f"c_{n}"].numpy(), orc.critic[i].detach().numpy(), rtol=0, atol=2e-6, err_msg=f"critic {n}")
+
+
+def test_update_is_bitwise_deterministic():
+    """Same inputs -> bitwise identical parameters after several optimiser steps (no floating-point atomics anywhere in
+    the update: split-K slices, bias column sums and loss scalars are reduced in a fixed order).  This is the property the
+    reference's tests/test_determinism.py:79-146 asserts with torch.equal on CPU."""
+    from learninghumanoidwalking_amd.ppo_kernels import PpoKernels, reference_init
+    from oracle import ppo_oracle as po
+    B, D, A, H = 3000, 37, 12, 256
+    mo, ma = po.mirror_tables(MIR_OBS, [29, 30]), po.mirror_tables(MIR_ACT)
+    rs = np.random.default_rng(9)
+    obs = torch.tensor(rs.normal(size=(4000, D)).astype(np.float32)).cuda()
+    act = torch.tensor(rs.normal(size=(4000, A)).astype(np.float32) * 0.3).cuda()
+    logp = torch.tensor(rs.normal(size=4000).astype(np.float32) - 8).cuda()
+    adv = torch.tensor(rs.normal(size=4000).astype(np.float32)).cuda()
+    ret = torch.tensor(rs.normal(size=4000).astype(np.float32)).cuda()
+    idx = torch.tensor(rs.permutation(4000)[:B].astype(np.int32)).cuda()
+    outs = []
+    for rep in range(3):
+        k = PpoKernels(D, A, hidden=H, max_rows=B, learn_std=True, entropy_coeff=0.01, mirror_obs=mo, mirror_act=ma)
+        k.set_tensors(reference_init(D, A, H, 0.223, generator_seed=21))
+        xn, xm = k.normalize(obs)
+        for _ in range(4):
+            k.grad_minibatch(xn, xm, act, logp, adv, ret, idx)
+            k.apply()
+        outs.append((k.theta.clone(), k.stats.clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][0], outs[2][0])
+    assert torch.equal(outs[0][1][:5], outs[1][1][:5])
