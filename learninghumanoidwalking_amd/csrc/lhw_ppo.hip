@@ -164,16 +164,26 @@ __global__ void __launch_bounds__(256) reduce_slices_kernel(const float* __restr
   out[(size_t)row * ldc + col] += s;
 }
 
-// out[col] += sum over rows of X[row][col] in a fixed order: 64 columns per block, 4 row groups summed strided then combined
-__global__ void __launch_bounds__(256) colsum_det_kernel(const float* __restrict__ X, int rows, int ld, int ncols, float* __restrict__ out) {
+// Deterministic column sums, two stages.  Stage 1: block (col tile, row chunk) sums its rows of 64 columns (4 strided
+// row groups combined in a fixed order) into part[chunk][col].  Stage 2: out[col] += sum over chunks in chunk order.
+#define COLSUM_CHUNKS 128
+__global__ void __launch_bounds__(256) colsum_det_kernel(const float* __restrict__ X, int rows, int ld, int ncols, float* __restrict__ part) {
   __shared__ float red[4][64];
   const int c = blockIdx.x * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6;
+  const int per = (rows + COLSUM_CHUNKS - 1) / COLSUM_CHUNKS, r0 = blockIdx.y * per, r1 = min(rows, r0 + per);
   float s = 0.f;
   if (c < ncols)
-    for (int r = g; r < rows; r += 4) s += X[(size_t)r * ld + c];
+    for (int r = r0 + g; r < r1; r += 4) s += X[(size_t)r * ld + c];
   red[g][threadIdx.x & 63] = s;
   __syncthreads();
-  if (g == 0 && c < ncols) out[c] += (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+  if (g == 0 && c < ncols) part[(size_t)blockIdx.y * ncols + c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+__global__ void __launch_bounds__(256) colsum_final_kernel(const float* __restrict__ part, int ncols, float* __restrict__ out) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= ncols) return;
+  float s = 0.f;
+  for (int k = 0; k < COLSUM_CHUNKS; k++) s += part[(size_t)k * ncols + c];
+  out[c] += s;
 }
 
 template <bool A_KC, bool B_KC>
@@ -262,8 +272,9 @@ static void mlp_forward(const MlpLayout& L, const float* theta, const float* x, 
 
 // accumulates parameter gradients of one MLP given dy [R][Op]; every reduction runs in a fixed order (same seed ->
 // bitwise identical weights, the property the reference's tests/test_determinism.py checks)
-static void colsum_det(const float* X, int rows, int ld, int ncols, float* out, hipStream_t s) {
-  hipLaunchKernelGGL(colsum_det_kernel, dim3((ncols + 63) / 64), dim3(256), 0, s, X, rows, ld, ncols, out);
+static void colsum_det(const float* X, int rows, int ld, int ncols, float* out, float* scratch /* [COLSUM_CHUNKS][ncols] */, hipStream_t s) {
+  hipLaunchKernelGGL(colsum_det_kernel, dim3((ncols + 63) / 64, COLSUM_CHUNKS), dim3(256), 0, s, X, rows, ld, ncols, scratch);
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((ncols + 255) / 256), dim3(256), 0, s, scratch, ncols, out);
 }
 static void mlp_backward(const MlpLayout& L, const float* theta, float* grad, const float* x, int ldx, int R, const float* h1,
                          const float* h2, const float* dy, float* dh2, float* dh1, int k_chunk, float* part, hipStream_t s) {
@@ -272,13 +283,13 @@ static void mlp_backward(const MlpLayout& L, const float* theta, float* grad, co
   g.A = dy; g.lda = L.Op; g.B = h2; g.ldb = L.H; g.C = grad + L.w3; g.ldc = L.H; g.M = L.O; g.N = L.H; g.K = R;
   g.part = part; g.k_chunk = k_chunk;
   launch_gemm<false, false>(g, s);
-  colsum_det(dy, R, L.Op, L.O, grad + L.b3, s);
+  colsum_det(dy, R, L.Op, L.O, grad + L.b3, part, s);
   // dh2 = (dy W3) * (h2 > 0) ; db2 += colsum(dh2)
   g = GemmArgs{};
   g.A = dy; g.lda = L.Op; g.B = theta + L.w3; g.ldb = L.H; g.C = dh2; g.ldc = L.H; g.M = R; g.N = L.H; g.K = L.O;
   g.mask = h2; g.ldmask = L.H;
   launch_gemm<true, false>(g, s);
-  colsum_det(dh2, R, L.H, L.H, grad + L.b2, s);
+  colsum_det(dh2, R, L.H, L.H, grad + L.b2, part, s);
   // dW2 += dh2^T h1
   g = GemmArgs{};
   g.A = dh2; g.lda = L.H; g.B = h1; g.ldb = L.H; g.C = grad + L.w2; g.ldc = L.H; g.M = L.H; g.N = L.H; g.K = R;
@@ -289,7 +300,7 @@ static void mlp_backward(const MlpLayout& L, const float* theta, float* grad, co
   g.A = dh2; g.lda = L.H; g.B = theta + L.w2; g.ldb = L.H; g.C = dh1; g.ldc = L.H; g.M = R; g.N = L.H; g.K = L.H;
   g.mask = h1; g.ldmask = L.H;
   launch_gemm<true, false>(g, s);
-  colsum_det(dh1, R, L.H, L.H, grad + L.b1, s);
+  colsum_det(dh1, R, L.H, L.H, grad + L.b1, part, s);
   // dW1 [H][Dp] += dh1^T x
   g = GemmArgs{};
   g.A = dh1; g.lda = L.H; g.B = x; g.ldb = ldx; g.C = grad + L.w1; g.ldc = L.Dp; g.M = L.H; g.N = L.Dp; g.K = R;
@@ -566,7 +577,7 @@ extern "C" int lhw_ppo_create(const LhwPpoConfig* c, LhwPpo** out) {
             alloc(&p->mb_ret, R) && alloc(&p->stats, 16) && alloc(&p->dstd, R * Op) && alloc(&p->stats_part, ((R + 255) / 256) * 5) &&
             alloc(&p->norm_part, 2 * SUMSQ_BLOCKS);
   p->max_slices = (int)((R + 511) / 512);
-  ok = ok && alloc(&p->part, (size_t)p->max_slices * H * std::max<size_t>(H, Dp)) &&
+  ok = ok && alloc(&p->part, std::max<size_t>((size_t)p->max_slices * H * std::max<size_t>(H, Dp), (size_t)COLSUM_CHUNKS * H)) &&
        hipMalloc(&p->mom_part, sizeof(double) * 2 * MOM_BLOCKS) == hipSuccess;
   if (ok && p->use_mirror) {
     std::vector<int> osrc(Dp, 0), asrc(p->A, 0);
@@ -718,7 +729,7 @@ extern "C" int lhw_ppo_grad(LhwPpo* p, const float* theta, float* grad, const fl
                      p->dyc, p->learn_std ? p->dstd : (float*)nullptr, p->stats_part);
   hipLaunchKernelGGL(reduce_rows_kernel, dim3(1), dim3(64), 0, s, p->stats_part, nblk, 5, stats_dev);
   if (p->learn_std) {
-    colsum_det(p->dstd, B, Op, p->A, grad + p->off_std, s);
+    colsum_det(p->dstd, B, Op, p->A, grad + p->off_std, p->part, s);
     hipLaunchKernelGGL(entropy_grad_kernel, dim3(1), dim3(64), 0, s, theta + p->off_std, p->A, p->ent_coeff, grad + p->off_std);
   }
   const int kc = 512;
