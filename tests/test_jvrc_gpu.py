@@ -102,3 +102,71 @@ def test_auto_reset_flags_and_obs():
     assert seen & 1 and seen & 2, "need both terminations and truncations in the tape"
     ret, length, count = env.pop_episode_stats()
     assert count > 0 and length > 0
+
+
+def test_contact_variety_fallen_and_tangled_poses():
+    """Edge cases of the collision / constraint code that upright walking never reaches: a robot lying on the floor
+    (plane-sphere, plane-capsule contacts), legs pushed through each other (capsule-capsule, sphere-capsule self
+    collisions), joints far outside their ranges (limit rows on both sides).  Three control steps from each pose."""
+    import torch
+    spec, env, orc = _pair(12, seed=2)
+    env.reset()
+    for o in orc:
+        o.reset()
+    m = spec.model()
+    rs = np.random.default_rng(11)
+    N = 12
+    q = np.tile(spec.nominal_pose, (N, 1))
+    v = np.zeros((N, 18))
+    lo, hi = m.jnt_range[1:, 0], m.jnt_range[1:, 1]
+    for i in range(N):
+        if i < 5:            # lying / kneeling: low root, random orientation
+            q[i, 2] = rs.uniform(0.12, 0.45)
+            quat = rs.normal(size=4)
+            q[i, 3:7] = quat / np.linalg.norm(quat)
+            q[i, 7:] = rs.uniform(lo, hi)
+        elif i < 9:          # legs crossed / tangled in the air: hip roll + yaw push the shins through each other
+            q[i, 2] = 1.3
+            q[i, 7:] = spec.nominal_pose[7:]
+            q[i, 8], q[i, 14] = rs.uniform(0.2, 0.34), rs.uniform(-0.34, -0.2)      # R/L hip roll inwards
+            q[i, 9], q[i, 15] = rs.uniform(-0.5, 0.5), rs.uniform(-0.5, 0.5)
+        else:                # joint limits violated on both sides
+            q[i, 2] = 1.2
+            q[i, 7:] = np.where(rs.uniform(size=12) < 0.5, lo - rs.uniform(0.02, 0.2, 12), hi + rs.uniform(0.02, 0.2, 12))
+        v[i] = rs.normal(size=18) * 0.3
+    # two poses found offline with the oracle in which a hip sphere rests on the floor (plane-sphere narrow phase)
+    for i, pose in ((3, [0.0, 0.0, 0.0707, -0.003, 0.4379, -0.8595, 0.2636, -0.793, 0.1178, -0.2801, 0.1269, -0.1164, -0.9956, -1.8286,
+                         0.3116, -0.2094, 1.6397, -0.3666, 0.8188]),
+                    (4, [0.0, 0.0, 0.1663, 0.5789, -0.0961, -0.6284, 0.5106, 0.5913, -0.7438, 0.2413, 1.4991, -0.5754, 0.2749, -2.0439,
+                         0.5141, 0.0133, 2.267, -0.5294, 0.5728])):
+        q[i] = pose
+        q[i, 3:7] /= np.linalg.norm(q[i, 3:7])
+        v[i] = 0
+    env.set_state(q, v)
+    for i, o in enumerate(orc):
+        o.set_state(q[i], v[i])
+    kinds = set()
+    max_ncon = 0
+    act = (rs.normal(size=(3, N, 12)) * 0.2).astype(np.float32)
+    for t in range(3):
+        obs, rew, done, _ = env.step(torch.from_numpy(act[t]).cuda())
+        res = [o.step(act[t, i]) for i, o in enumerate(orc)]
+        for o in orc:
+            max_ncon = max(max_ncon, o.sim.ncon)
+            for kcon in range(o.sim.ncon):
+                c = o.sim.contact(kcon)
+                kinds.add((int(m.geom_type[c["geom1"]]), int(m.geom_type[c["geom2"]])))
+            if o.sim.nefc > 4 * o.sim.ncon:
+                kinds.add("limit")
+        keep = np.array([o.sim.ncon <= 12 for o in orc])     # the kernel keeps at most 12 contacts (flagged, see DESIGN.md)
+        gq, gv = env.get_state()
+        oq, ov = _states(orc)
+        np.testing.assert_allclose(gq[keep], oq[keep], rtol=0, atol=1e-8, err_msg=f"qpos t={t}")
+        np.testing.assert_allclose(gv[keep], ov[keep], rtol=0, atol=1e-6, err_msg=f"qvel t={t}")
+        np.testing.assert_array_equal((done.cpu().numpy() & 1)[keep], np.array([int(r[2]) for r in res])[keep])
+        env.set_state(oq, ov)
+        for o in orc:
+            o.set_state(o.sim.qpos.copy(), o.sim.qvel.copy())
+    assert {(0, 2), (0, 3), (0, 6), "limit"} <= kinds, kinds          # plane-sphere, plane-capsule, plane-box, limit rows
+    assert (3, 3) in kinds or (2, 3) in kinds, kinds                     # a leg-leg self collision happened
+    assert keep.sum() >= 8, f"too many poses exceeded the contact cap (max ncon {max_ncon})"
