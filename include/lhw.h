@@ -133,6 +133,10 @@ int lhw_env_set_state(LhwEnv* env, const double* qpos_host, const double* qvel_h
 /* Episode statistics accumulated on device since the last call: sum of finished-episode returns,
  * sum of finished-episode lengths, number of finished episodes (host pointers, synchronous, resets them). */
 int lhw_env_pop_episode_stats(LhwEnv* env, double* ret_sum, double* len_sum, int64_t* count);
+/* Fault counters since the last call (host pointers, synchronous, resets them): control steps in which contacts were
+ * dropped because more than the compiled-in cap were active, and control steps in which an env's state became
+ * non-finite (the env is flagged terminated, its outputs are zeroed, and it is reset like any finished episode). */
+int lhw_env_pop_fault_stats(LhwEnv* env, int64_t* contact_overflow, int64_t* diverged);
 int lhw_env_set_iteration(LhwEnv* env, int64_t iteration);
 /* Diagnostic: shader-clock cycles env 0 spent in each phase of the wave-per-env stepper since the last call
  * (slots: 0 kinematics, 1 com/cdof, 2 CRBA, 3 collision, 4 constraint rows, 5 velocity/RNE, 6 smooth solve,

@@ -135,5 +135,11 @@ class BatchedEnv:
         _lib.check(self._L.lhw_env_phase_cycles(self._h, int(enable), out.ctypes.data))
         return out
 
+    def pop_fault_stats(self):
+        """(contact-overflow steps, diverged-env steps) since the last call."""
+        a, b = ctypes.c_int64(), ctypes.c_int64()
+        _lib.check(self._L.lhw_env_pop_fault_stats(self._h, ctypes.byref(a), ctypes.byref(b)))
+        return a.value, b.value
+
     def set_iteration(self, it: int):
         _lib.check(self._L.lhw_env_set_iteration(self._h, int(it)))

@@ -256,6 +256,21 @@ extern "C" int lhw_env_phase_cycles(LhwEnv* e, int enable, int64_t* out16) {
   return LHW_OK;
 }
 
+extern "C" int lhw_env_pop_fault_stats(LhwEnv* e, int64_t* contact_overflow, int64_t* diverged) {
+  if (!e) return lhw_fail(LHW_ERR_ARG, "null env");
+  if (contact_overflow) *contact_overflow = 0;
+  if (diverged) *diverged = 0;
+  if (!e->hum) return LHW_OK;  // the cartpole kernel has neither contacts nor a divergence path
+  HIPCHK(hipSetDevice(e->device));
+  double h[2];
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpy(h, humanoid_ep_stats(e->hum) + 3, sizeof h, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemset(humanoid_ep_stats(e->hum) + 3, 0, sizeof h));
+  if (contact_overflow) *contact_overflow = (int64_t)h[0];
+  if (diverged) *diverged = (int64_t)h[1];
+  return LHW_OK;
+}
+
 extern "C" int lhw_env_set_iteration(LhwEnv* e, int64_t iteration) {
   if (!e) return lhw_fail(LHW_ERR_ARG, "null env");
   if (e->hum) humanoid_set_iteration(e->hum, iteration);

@@ -1532,6 +1532,23 @@ __global__ void __launch_bounds__(64, 2) humanoid_kernel(HModel m, HParams p, HS
       const double z = S.qpos[2];
       terminated = z < 0.9 || z > 1.4 || self_collision;  // standing_task.py:111-131
     }
+    // failure detection: a non-finite state ends the episode (counted in ep_stats[4]); outputs are sanitised so one
+    // diverged env cannot poison the batch (the reference has no equivalent: a NaN there propagates into the buffers)
+    {
+      bool bad = false;
+      if (lane < m.nq) bad = !isfinite(S.qpos[lane]);
+      if (lane < m.nv) bad = bad || !isfinite(S.qvel[lane]) || !isfinite(S.qacc[lane]);
+      if (__any(bad) || !isfinite(r_sum)) {
+        terminated = true;
+        r_sum = 0;
+        for (int k = 0; k < 10; k++) terms[k] = 0;
+        if (lane < m.nq) S.qpos[lane] = p.nominal_qpos[lane];
+        if (lane < m.nv) { S.qvel[lane] = 0; S.qacc[lane] = 0; }
+        if (lane < m.nu) { S.sq[lane] = p.action_offset[lane]; S.sv[lane] = 0; S.frc[lane] = 0; cur_tq = 0; }
+        if (lane == 0) atomicAdd(&st.ep_stats[4], 1.0);
+        SYNC();
+      }
+    }
     prevact = target;
     prevtq = cur_tq;
     prevpred = a_raw;
@@ -1856,7 +1873,7 @@ int humanoid_create(HumanoidEnv** out, const std::vector<int32_t>& mi, const std
   void *rec = nullptr, *irec = nullptr, *eps = nullptr;
   ok = ok && hipMalloc(&rec, sizeof(double) * REC_D * N) == hipSuccess && hipMemset(rec, 0, sizeof(double) * REC_D * N) == hipSuccess &&
        hipMalloc(&irec, sizeof(int) * REC_I * N) == hipSuccess && hipMemset(irec, 0, sizeof(int) * REC_I * N) == hipSuccess &&
-       hipMalloc(&eps, sizeof(double) * 4) == hipSuccess && hipMemset(eps, 0, sizeof(double) * 4) == hipSuccess;
+       hipMalloc(&eps, sizeof(double) * 8) == hipSuccess && hipMemset(eps, 0, sizeof(double) * 8) == hipSuccess;
   if (rec) h->dev_allocs.push_back(rec);
   if (irec) h->dev_allocs.push_back(irec);
   if (eps) h->dev_allocs.push_back(eps);

@@ -170,3 +170,24 @@ def test_contact_variety_fallen_and_tangled_poses():
     assert {(0, 2), (0, 3), (0, 6), "limit"} <= kinds, kinds          # plane-sphere, plane-capsule, plane-box, limit rows
     assert (3, 3) in kinds or (2, 3) in kinds, kinds                     # a leg-leg self collision happened
     assert keep.sum() >= 8, f"too many poses exceeded the contact cap (max ncon {max_ncon})"
+
+
+def test_diverged_env_is_contained():
+    """A non-finite state must end that env's episode, be counted, and leave every output finite."""
+    import torch
+    spec, env, orc = _pair(4, seed=1, max_traj_len=100)
+    env.reset()
+    q, v = env.get_state()
+    v[2, 7] = np.nan
+    env.set_state(q, v)
+    act = torch.zeros(4, 12, device="cuda")
+    obs, rew, done, tob = env.step(act)
+    d = done.cpu().numpy()
+    assert d[2] & 1 and not (d[[0, 1, 3]] & 1).any()
+    assert torch.isfinite(obs).all() and torch.isfinite(rew).all() and torch.isfinite(tob).all()
+    over, div = env.pop_fault_stats()
+    assert div == 1
+    obs, rew, done, _ = env.step(act)       # the env was reset and keeps running
+    assert torch.isfinite(obs).all() and not (done.cpu().numpy() & 1).any()
+    q, v = env.get_state()
+    assert np.isfinite(q).all() and np.isfinite(v).all()
