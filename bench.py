@@ -24,6 +24,24 @@ MFMA_F32_PEAK_TFLOPS = 157.3  # f32-input MFMA peak (= f32 vector peak)
 FP64_VALU_PEAK_TFLOPS = 78.6
 
 
+def pmc_traffic_per_launch(kernel_substr):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc summaries (profiles/), applying
+    the gfx950 correction of MI355X_MICROARCH.md (FETCH_SIZE under-reports coalesced reads by 2x; WRITE_SIZE uncalibrated).
+    Returns (bytes or None, note)."""
+    import csv
+    vals = {}
+    for name in ("fetch_size", "write_size"):
+        path = os.path.join(ROOT, "profiles", f"r01_jvrc_walk_step_pmc_{name}.csv")
+        if not os.path.exists(path):
+            return None, "no PMC summary committed"
+        for row in csv.DictReader(open(path)):
+            if kernel_substr in row["kernel"]:
+                vals[name] = float(row["mean"]) * 1024.0
+    if len(vals) != 2:
+        return None, "kernel not found in the PMC summaries"
+    return 2.0 * vals["fetch_size"] + vals["write_size"], "profiles/r01_jvrc_walk_step_pmc_{fetch,write}_size.csv: 2*FETCH_SIZE + WRITE_SIZE"
+
+
 def cpu_baseline_worker(a):
     """Oracle env + batch-1 torch actor/critic forward per step on one host core (the reference worker's
     per-step work, rl/workers/rollout_worker.py:142-146).  Returns env-steps done and seconds."""
@@ -169,8 +187,11 @@ def main():
         bytes_per_env_step = spec.algorithmic_bytes_per_env_step()
         flops_per_env_step = spec.algorithmic_flops_per_env_step()
         achieved_gbs = bytes_per_env_step * N / (avg_step_ms * 1e-3) / 1e9
+        traffic, traffic_note = (pmc_traffic_per_launch("humanoid_kernel<0, 1>") if env_name == "jvrc_walk" and N == 4096
+                                 else (None, "PMC summary exists for jvrc_walk @ 4096 envs only"))
         roofline = dict(bound="hbm", kernel=spec.step_kernel_name, achieved=achieved_gbs, peak=HBM_PEAK_GBS, unit="GB/s",
-                        frac=achieved_gbs / HBM_PEAK_GBS, traffic=None, avg_launch_ms=avg_step_ms, launches=len(step_ms),
+                        frac=achieved_gbs / HBM_PEAK_GBS, traffic=traffic, traffic_source=traffic_note,
+                        algorithmic_bytes_per_launch=bytes_per_env_step * N, avg_launch_ms=avg_step_ms, launches=len(step_ms),
                         algorithmic_bytes_per_env_step=bytes_per_env_step,
                         note="the fused control-step kernel touches each env's state once per control step, so it is "
                              "bound by on-chip fp64 latency/VALU issue, not HBM (SURVEY.md 8d); fp64 VALU fraction below",

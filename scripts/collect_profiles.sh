@@ -1,0 +1,23 @@
+#!/bin/bash
+# Run on the GPU box (via gpurun): kernel-trace stats, HBM traffic counters (separate --pmc passes), SQ instruction-mix
+# counters, per-phase cycle breakdown and the bench line.  Outputs under gpurun_out/profiles_raw/ (copy the summaries
+# into profiles/ afterwards).
+set -u
+OUT=/root/repo/gpurun_out/profiles_raw
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+python /root/repo/bench.py --steps 3 --warmup 1 2>/dev/null | tail -1 > $OUT/bench_jvrc_walk_1gpu.json
+python /root/repo/bench.py --env h1 --num-envs 8192 --steps 2 --warmup 1 2>/dev/null | tail -1 > $OUT/bench_h1_8192_1gpu.json
+python /root/repo/bench.py --env cartpole --steps 3 --warmup 1 2>/dev/null | tail -1 > $OUT/bench_cartpole_1gpu.json
+rm -rf /tmp/kt; timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -- python /root/repo/bench.py --steps 1 --warmup 1 --no-cpu-baseline > /tmp/kt.log 2>&1
+cp /tmp/kt/*/*kernel_stats.csv $OUT/jvrc_walk_kernel_stats.csv
+for C in FETCH_SIZE WRITE_SIZE; do
+  rm -rf /tmp/pm; timeout 300 rocprofv3 --pmc $C --output-format csv -d /tmp/pm -- python /root/repo/scripts/step_only.py 4096 6 > /tmp/pm.log 2>&1
+  python /root/repo/scripts/pmc_summary.py /tmp/pm > $OUT/jvrc_walk_step_pmc_$C.csv
+done
+for C in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_SALU SQ_IFETCH SQ_INSTS_SMEM" "SQC_ICACHE_REQ SQC_ICACHE_MISSES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_FLAT"; do
+  rm -rf /tmp/pm; timeout 300 rocprofv3 --pmc $C --output-format csv -d /tmp/pm -- python /root/repo/scripts/step_only.py 4096 4 > /tmp/pm.log 2>&1
+  python /root/repo/scripts/pmc_summary.py /tmp/pm | grep -E "kernel,|humanoid_kernel<0" >> $OUT/jvrc_walk_step_pmc_sq.csv
+done
+python /root/repo/scripts/jvrc_phase_profile.py 4096 > $OUT/jvrc_walk_phase_cycles.txt 2>/dev/null
+ls -la $OUT
