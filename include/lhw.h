@@ -57,7 +57,8 @@ typedef enum {
 typedef enum {
   LHW_TASK_CARTPOLE = 0, /* reference envs/cartpole/cartpole_env.py */
   LHW_TASK_JVRC_WALK = 1, /* reference envs/jvrc/jvrc_walk.py + tasks/walking_task.py */
-  LHW_TASK_H1_STAND = 2   /* reference envs/h1/h1_env.py + tasks/standing_task.py (+ domain_randomization.py) */
+  LHW_TASK_H1_STAND = 2,  /* reference envs/h1/h1_env.py + tasks/standing_task.py (+ domain_randomization.py) */
+  LHW_TASK_JVRC_STEP = 3  /* reference envs/jvrc/jvrc_step.py + tasks/stepping_task.py (box terrain, footstep targets) */
 } LhwTask;
 
 /* done flags written by lhw_env_step */
@@ -92,11 +93,19 @@ typedef struct {
  * init-noise half-width (rad), perturbation force / torque magnitudes and 35 per-entry observation-noise half-widths */
 enum { LHW_TP_GOAL_HEIGHT = 0, LHW_TP_COUNT = 1, LHW_TP_H1_INIT_NOISE = 1, LHW_TP_H1_FORCE_MAG = 2, LHW_TP_H1_TORQUE_MAG = 3,
        LHW_TP_H1_OBS_NOISE = 4 };
+/* stepping task: local offsets of the right / left foot force sites on the foot bodies, target radius
+ * (stepping_task.py:268), half sizes of the terrain boxes (:325), then the footstep plans of the CURVED mode:
+ * count, and per plan 1 + 20*3 doubles = length, (x, y, theta) rows (stepping_task.py:52-64) */
+enum { LHW_TP_STEP_RSITE = 1, LHW_TP_STEP_LSITE = 4, LHW_TP_STEP_RADIUS = 7, LHW_TP_STEP_BOX_SIZE = 8, LHW_TP_STEP_NPLANS = 11,
+       LHW_TP_STEP_PLANS = 12, LHW_STEP_MAX_SEQ = 20 };
 /* task_iparams indices: body ids of root, head (walking) / torso (standing), right foot, left foot; H1 standing adds the
  * randomisation intervals in control steps, the perturbed bodies, and the randomised dofs (10) and bodies (11) */
 enum { LHW_TI_ROOT_BODY = 0, LHW_TI_HEAD_BODY = 1, LHW_TI_RFOOT_BODY = 2, LHW_TI_LFOOT_BODY = 3, LHW_TI_COUNT = 4,
        LHW_TI_H1_DYNRAND_INTERVAL = 4, LHW_TI_H1_PERTURB_INTERVAL = 5, LHW_TI_H1_N_PBODY = 6, LHW_TI_H1_PBODY = 7,
        LHW_TI_H1_RAND_DOF = 9, LHW_TI_H1_RAND_BODY = 19 };
+/* stepping task: first terrain-box geom id (boxes are contiguous), box count (<= 20), floor geom id, target dwell in
+ * control steps (stepping_task.py:269) */
+enum { LHW_TI_STEP_BOX_GEOM0 = 4, LHW_TI_STEP_NBOX = 5, LHW_TI_STEP_FLOOR_GEOM = 6, LHW_TI_STEP_DELAY_FRAMES = 7, LHW_TI_STEP_COUNT = 8 };
 
 int lhw_version(void);
 const char* lhw_last_error(void);
@@ -126,6 +135,10 @@ int lhw_env_reset(LhwEnv* env, const uint8_t* mask_dev, float* obs_dev, void* st
  *   rew_terms_dev [N][num_reward_terms] f32, out, nullable */
 int lhw_env_step(LhwEnv* env, const float* act_dev, float* obs_dev, float* term_obs_dev, float* rew_dev,
                  uint8_t* done_dev, float* rew_terms_dev, void* stream);
+
+/* Test hook: copy the per-env stepping-task record to host: seq [N][20][6] = (x y z theta cos sin) of every target step /
+ * terrain box, floor_z [N], and istate [N][5] = t1 t2 target_reached target_reached_frames sequence_length. */
+int lhw_env_debug_step_record(LhwEnv* env, double* seq, double* floor_z, int32_t* istate);
 
 /* Parity hooks; HOST pointers, synchronous.  qpos [N][nq], qvel [N][nv] float64. */
 int lhw_env_get_state(LhwEnv* env, double* qpos_host, double* qvel_host);

@@ -14,7 +14,7 @@ import torch
 from . import _lib
 from .model import Model
 
-TASK_CARTPOLE, TASK_JVRC_WALK, TASK_H1_STAND = 0, 1, 2
+TASK_CARTPOLE, TASK_JVRC_WALK, TASK_H1_STAND, TASK_JVRC_STEP = 0, 1, 2, 3
 DONE_TERMINATED, DONE_TRUNCATED = 1, 2
 
 
@@ -140,6 +140,14 @@ class BatchedEnv:
         a, b = ctypes.c_int64(), ctypes.c_int64()
         _lib.check(self._L.lhw_env_pop_fault_stats(self._h, ctypes.byref(a), ctypes.byref(b)))
         return a.value, b.value
+
+    def debug_step_record(self):
+        """Stepping task test hook: (sequence [N,20,6] = x y z theta cos sin, floor_z [N], istate [N,5] = t1 t2 reached frames nseq)."""
+        seq = np.zeros((self.n_envs, 20, 6))
+        fz = np.zeros(self.n_envs)
+        ist = np.zeros((self.n_envs, 5), np.int32)
+        _lib.check(self._L.lhw_env_debug_step_record(self._h, seq.ctypes.data, fz.ctypes.data, ist.ctypes.data))
+        return seq, fz, ist
 
     def set_iteration(self, it: int):
         _lib.check(self._L.lhw_env_set_iteration(self._h, int(it)))

@@ -154,7 +154,7 @@ extern "C" int lhw_env_create(const int32_t* model_i, int64_t n_model_i, const d
   e->task = cfg->task; e->n_envs = cfg->n_envs; e->device = cfg->device;
   e->nq = model_i[LHW_IH_NQ]; e->nv = model_i[LHW_IH_NV]; e->nu = model_i[LHW_IH_NU];
   if (cfg->task == LHW_TASK_CARTPOLE) rc = create_cartpole(e, cfg);
-  else if (cfg->task == LHW_TASK_JVRC_WALK || cfg->task == LHW_TASK_H1_STAND) rc = humanoid_create(&e->hum, e->mi, e->md, cfg, &e->obs_dim, &e->act_dim, &e->n_terms);
+  else if (cfg->task == LHW_TASK_JVRC_WALK || cfg->task == LHW_TASK_H1_STAND || cfg->task == LHW_TASK_JVRC_STEP) rc = humanoid_create(&e->hum, e->mi, e->md, cfg, &e->obs_dim, &e->act_dim, &e->n_terms);
   else rc = lhw_fail(LHW_ERR_ARG, "unknown task %d", cfg->task);
   if (rc == LHW_OK) {
     if (hipMalloc(&e->stage_q, sizeof(double) * (size_t)e->n_envs * e->nq) != hipSuccess ||
@@ -268,6 +268,12 @@ extern "C" int lhw_env_pop_fault_stats(LhwEnv* e, int64_t* contact_overflow, int
   HIPCHK(hipMemset(humanoid_ep_stats(e->hum) + 3, 0, sizeof h));
   if (contact_overflow) *contact_overflow = (int64_t)h[0];
   if (diverged) *diverged = (int64_t)h[1];
+  return LHW_OK;
+}
+
+extern "C" int lhw_env_debug_step_record(LhwEnv* e, double* seq, double* floor_z, int32_t* istate) {
+  if (!e || !e->hum || e->task != LHW_TASK_JVRC_STEP) return lhw_fail(LHW_ERR_ARG, "step record: not a stepping-task env");
+  if (humanoid_step_record(e->hum, seq, floor_z, istate)) return lhw_fail(LHW_ERR_HIP, "step record copy failed");
   return LHW_OK;
 }
 

@@ -37,10 +37,9 @@
 #define LDV 19  // padded row length of nv x nv matrices and of J (odd => conflict-free 64-bit column sweeps)
 #define NQ 19
 #define NJ 14   // joints
-#define NG 12   // geoms
-#define NP 24   // collision candidate pairs
-#define NC 12   // contacts kept per step
-#define NE 48   // constraint rows (one per lane)
+#define NG 32   // geoms
+#define NP 64   // collision candidate pairs (one per lane)
+// contacts kept per step (NC) and constraint rows (NE, one per lane) are per-task capacities: see LdsT
 #define NU 12   // actuators
 #define NTRI (NV * (NV + 1) / 2)
 #define HMINVAL 1e-15
@@ -48,6 +47,7 @@
 enum { JT_FREE = 0, JT_SLIDE = 2, JT_HINGE = 3 };
 enum { G_PLANE = 0, G_SPHERE = 2, G_CAPSULE = 3, G_BOX = 6 };
 enum { MODE_STANDING = 0, MODE_INPLACE = 1, MODE_FORWARD = 2 };
+enum { WALK_CURVED = 0, WALK_STANDING = 1, WALK_BACKWARD = 2, WALK_LATERAL = 3, WALK_FORWARD = 4 };  // stepping_task.py:282-285
 
 // persistent record (doubles)
 #define R_QPOS 0
@@ -71,7 +71,17 @@ static_assert(R_EPRET < REC_D, "record too small");
 #define RI_RESETCNT 4
 #define RI_STARTED 5  // prev_action / prev_torque initialised (robot_base.py:82-85: only once, never reset)
 #define RI_OBSCNT 6   // number of get_obs calls so far (observation-noise RNG counter)
-#define REC_I 8
+#define RI_T1 7       // stepping task: indices of the current / next target step, hit flag + dwell counter, sequence length
+#define RI_T2 8
+#define RI_REACHED 9
+#define RI_FRAMES 10
+#define RI_NSEQ 11
+#define REC_I 16
+// stepping-task record (doubles): 20 target steps x (x y z theta cos sin) = poses of the 20 terrain boxes, floor height
+#define T_SEQ 0
+#define T_FLOOR 120
+#define TER_D 128
+#define MAX_SEQ 20
 // per-env model parameters touched by dynamics randomisation / perturbation (domain_randomization.py:10-56)
 #define P_DAMP 0
 #define P_FLOSS (P_DAMP + NV)
@@ -80,7 +90,7 @@ static_assert(R_EPRET < REC_D, "record too small");
 #define P_XFRC (P_IPOS + NB * 3)  // xfrc_applied of up to two perturbed bodies: force3 torque3 each
 #define PRM_D 128
 static_assert(P_XFRC + 12 <= PRM_D, "parameter record too small");
-enum { TASK_WALK = 1, TASK_STAND = 2 };
+enum { TASK_WALK = 1, TASK_STAND = 2, TASK_STEP = 3 };
 enum { LHW_STREAM_OBS = 4 };
 
 // Model constants, packed host-side into one array-of-structs table per "lane role" (body, joint, dof, geom, pair,
@@ -160,6 +170,7 @@ struct HModel {
   const double *body_d, *jnt_d, *dof_d, *geom_d, *act_d;
   const int *body_i, *jnt_i, *dof_i, *geom_i, *act_i, *pair_i, *mpair;
   int track_body[3];  // bodies whose spatial velocity must survive the sub-step (the task reads them afterwards)
+  double track_off[9];  // local offset of the tracked point on each of them (foot force sites for the stepping task)
 };
 
 struct HParams {
@@ -168,6 +179,9 @@ struct HParams {
   int env_params;                       // 1: damping / frictionloss / mass / ipos / xfrc come from the per-env record
   int dynrand_interval, perturb_interval, n_pbody, pbody[2];
   int rand_dof[10], rand_body[11], n_rand_dof, n_rand_body;
+  int box_geom0, nbox, floor_geom, delay_frames, nplans, iteration;  // stepping task
+  double target_radius;
+  const double* plans;                  // [nplans][1 + MAX_SEQ * 3]: length, then (x y theta) rows
   unsigned env_id_base;
   unsigned long long seed;
   double action_smoothing, goal_height, init_noise, force_mag, torque_mag;
@@ -178,6 +192,7 @@ struct HState {
   double* rec;     // [N][REC_D]
   int* irec;       // [N][REC_I]
   double* prm;     // [N][PRM_D] per-env model parameters (NULL unless the task randomises them)
+  double* ter;     // [N][TER_D] stepping-task record (NULL for the other tasks)
   double* ep_stats;
   long long* prof; // optional [16] per-phase cycle counters accumulated by env 0 (NULL = off)
 };
@@ -220,6 +235,9 @@ struct HumanoidEnv {
 #define U_CFRC (U_CACC + NB * 6)
 #define U_CSUB (U_CFRC + NB * 6)
 #define U_END_B (U_CSUB + NB * 6)
+// stage C offsets depend on the row capacity of the task's LDS layout (template parameter L of every phase function)
+#define NE (L::NE_)
+#define NC (L::NC_)
 #define U_J 0
 #define U_H (U_J + NE * LDV)
 #define U_EPOS (U_H)
@@ -228,24 +246,27 @@ struct HumanoidEnv {
 #define U_EB (U_EK + NE)
 #define U_EIMP (U_EB + NE)
 #define U_EFL (U_EIMP + NE)
-#define U_END_C (U_H + NV * LDV)
-#define USIZE (U_END_C > U_END_B ? (U_END_C > U_END_A ? U_END_C : U_END_A) : (U_END_B > U_END_A ? U_END_B : U_END_A))
-static_assert(U_EFL + NE <= U_END_C, "efc row parameters must fit in the H slot");
+constexpr int cmax(int a, int b) { return a > b ? a : b; }
 
-struct Lds {
+template <int NE_T, int NC_T>
+struct LdsT {
+  static constexpr int NE_ = NE_T, NC_ = NC_T;
+  // H slot: the nv x nv factor, or the six per-row parameter arrays parked there before the reference acceleration is formed
+  static constexpr int USIZE_ = cmax(cmax(U_END_A, U_END_B), NE_T * LDV + cmax(NV * LDV, 6 * NE_T));
   double qpos[NQ], qvel[NV], ctrl[NU];
   double xpos[NB * 3];
   double rootmat[9], com[4], svel[18];   // root xmat; tree com; cvel of the three tracked bodies (root, right foot, left foot)
+  double spos[9], rootquat[4];           // world position of the tracked points (body origin + local offset); root xquat
   double cdof[NV * 6];
   double M[NV * LDV];
-  double vec[NV], vec2[NV], evec[NE], dact[NE];
+  double vec[NV], vec2[NV], evec[NE_T], dact[NE_T];
   double qacc[NV];
-  double efc_D[NE], efc_force[NE];
-  double con_dist[NC], con_pos[NC * 3], con_frame[NC * 9], con_mu[NC], con_solref[NC * 2], con_solimp[NC * 5], con_margin[NC];
-  int con_g1[NC], con_g2[NC], con_dim[NC], con_row[NC];
+  double efc_D[NE_T], efc_force[NE_T];
+  double con_dist[NC_T], con_pos[NC_T * 3], con_frame[NC_T * 9], con_mu[NC_T], con_solref[NC_T * 2], con_solimp[NC_T * 5], con_margin[NC_T];
+  int con_g1[NC_T], con_g2[NC_T], con_dim[NC_T], con_row[NC_T];
   double sq[NU], sv[NU], frc[NU];
   double damp[NV], floss[NV], bmass[NB], bipos[NB * 3], xfrc[12];  // per-env parameters, loaded once per launch
-  double U[USIZE];
+  double U[USIZE_];
   int ncon, nefc, nlim, overflow;
 };
 
@@ -423,7 +444,8 @@ __device__ __forceinline__ double row_dot(const double* row, const double* v, in
 // ------------------------------------------------------------------------------------------------ forward dynamics phases
 // mj_kinematics with rotation matrices: each lane precombines its body's local transform R_loc = R_body * R_joint(q)
 // (off the serial chain), so a tree level costs one 3x3 product and four matrix-vector products.
-__device__ void fwd_kinematics(const HModel& m, Lds& S, int lane) {
+template <class L>
+__device__ void fwd_kinematics(const HModel& m, L& S, int lane) {
   if (lane == 0) {
     S.xpos[0] = S.xpos[1] = S.xpos[2] = 0;
     for (int k = 0; k < 9; k++) S.U[U_XMAT + k] = (k % 4 == 0) ? 1.0 : 0.0;
@@ -464,7 +486,7 @@ __device__ void fwd_kinematics(const HModel& m, Lds& S, int lane) {
       if (jt == JT_FREE) {
         double q[4] = {S.qpos[qa + 3], S.qpos[qa + 4], S.qpos[qa + 5], S.qpos[qa + 6]};
         normalize4(q);
-        for (int k = 0; k < 4; k++) S.qpos[qa + 3 + k] = q[k];
+        for (int k = 0; k < 4; k++) { S.qpos[qa + 3 + k] = q[k]; S.rootquat[k] = q[k]; }
         quat2mat(R, q);
         for (int k = 0; k < 3; k++) { xp[k] = S.qpos[qa + k]; S.U[U_XANCHOR + 3 * ja + k] = xp[k]; S.U[U_XAXIS + 3 * ja + k] = kd[BD_JAXIS + k]; }
       } else {
@@ -512,10 +534,20 @@ __device__ void fwd_kinematics(const HModel& m, Lds& S, int lane) {
     ci[5] = Ri[3] * I0 * Ri[6] + Ri[4] * I1 * Ri[7] + Ri[5] * I2 * Ri[8];
   }
   if (lane < 9) S.rootmat[lane] = S.U[U_XMAT + 9 * 1 + lane];
+#pragma unroll
+  for (int t = 0; t < 3; t++)
+    if (lane == 16 + t) {  // tracked points: body origin + R * local offset
+      const int tb = m.track_body[t];
+      const double off[3] = {m.track_off[3 * t], m.track_off[3 * t + 1], m.track_off[3 * t + 2]};
+      double w[3];
+      mat_vec(w, &S.U[U_XMAT + 9 * tb], off);
+      for (int k = 0; k < 3; k++) S.spos[3 * t + k] = S.xpos[3 * tb + k] + w[k];
+    }
 }
 
 // subtree com of the (single) dynamic tree rooted at body 1, cinert, cdof  (mj_comPos)
-__device__ double fwd_com(const HModel& m, const HParams& p, Lds& S, int lane) {
+template <class L>
+__device__ double fwd_com(const HModel& m, const HParams& p, L& S, int lane) {
   double ms = 0, mx = 0, my = 0, mz = 0;
   if (lane >= 1 && lane < m.nbody && m.body_i[BIS * (lane) + BI_ROOT] == 1) {
     ms = S.bmass[lane];
@@ -577,7 +609,8 @@ __device__ double fwd_com(const HModel& m, const HParams& p, Lds& S, int lane) {
 }
 
 // composite inertias + joint-space inertia M (mj_crb); lower triangle + mirrored upper
-__device__ void fwd_crb(const HModel& m, Lds& S, int lane) {
+template <class L>
+__device__ void fwd_crb(const HModel& m, L& S, int lane) {
   for (int it = lane; it < m.nbody * 10; it += 64) {
     const int b = it / 10, k = it - 10 * b;
     double s = 0;
@@ -610,17 +643,18 @@ __device__ void fwd_crb(const HModel& m, Lds& S, int lane) {
 // ---- collision (engine_collision_primitive.c restated).  Two passes over the same narrow phase: pass 0 counts the
 // contacts of each candidate pair (lane = pair), a wave scan gives every pair its slot range in pair order, pass 1
 // recomputes and writes straight into the LDS contact arrays (no per-lane contact records in scratch).
+template <class L>
 struct ConSink {
-  Lds* S;
+  L* S;
   int base, n, write, g1, g2;
   __device__ __forceinline__ void emit(double dist, const double* pos, const double* nrm, const double* tan) {
     if (write) {
       const int c = base + n;
       if (c < NC) {
-        Lds& L = *S;
-        L.con_dist[c] = dist;
+        L& Z = *S;
+        Z.con_dist[c] = dist;
         double f[9];
-        for (int a = 0; a < 3; a++) { L.con_pos[3 * c + a] = pos[a]; f[a] = nrm[a]; f[3 + a] = tan[a]; }
+        for (int a = 0; a < 3; a++) { Z.con_pos[3 * c + a] = pos[a]; f[a] = nrm[a]; f[3 + a] = tan[a]; }
         // mju_makeFrame
         normalize3(f);
         if (sqrt(dot3(f + 3, f + 3)) < 0.5) {
@@ -631,15 +665,16 @@ struct ConSink {
         for (int a = 0; a < 3; a++) f[3 + a] -= tt * f[a];
         normalize3(f + 3);
         cross3(f + 6, f, f + 3);
-        for (int a = 0; a < 9; a++) L.con_frame[9 * c + a] = f[a];
-        L.con_g1[c] = g1; L.con_g2[c] = g2;
+        for (int a = 0; a < 9; a++) Z.con_frame[9 * c + a] = f[a];
+        Z.con_g1[c] = g1; Z.con_g2[c] = g2;
       }
     }
     n++;
   }
 };
 
-__device__ __forceinline__ void col_plane_sphere(ConSink& k, const double* p1, const double* R1, const double* p2, double r,
+template <class L>
+__device__ __forceinline__ void col_plane_sphere(ConSink<L>& k, const double* p1, const double* R1, const double* p2, double r,
                                                  double margin, const double* tan) {
   double n[3] = {R1[2], R1[5], R1[8]}, dif[3] = {p2[0] - p1[0], p2[1] - p1[1], p2[2] - p1[2]};
   const double dist = dot3(dif, n) - r;
@@ -648,7 +683,8 @@ __device__ __forceinline__ void col_plane_sphere(ConSink& k, const double* p1, c
   for (int a = 0; a < 3; a++) pos[a] = p2[a] - n[a] * (r + 0.5 * dist);
   k.emit(dist, pos, n, tan);
 }
-__device__ __forceinline__ void col_sphere_sphere(ConSink& k, const double* p1, double r1, const double* p2, double r2, double margin) {
+template <class L>
+__device__ __forceinline__ void col_sphere_sphere(ConSink<L>& k, const double* p1, double r1, const double* p2, double r2, double margin) {
   double dif[3] = {p2[0] - p1[0], p2[1] - p1[1], p2[2] - p1[2]};
   const double cd = sqrt(dot3(dif, dif)), dist = cd - r1 - r2;
   if (dist > margin) return;
@@ -658,7 +694,133 @@ __device__ __forceinline__ void col_sphere_sphere(ConSink& k, const double* p1, 
   for (int a = 0; a < 3; a++) pos[a] = p1[a] + dif[a] * (r1 + 0.5 * dist);
   k.emit(dist, pos, dif, zero);
 }
-__device__ void collide_pair(ConSink& k, const HModel& m, const Lds& S, int g1, int g2, double margin) {
+// Box-box: separating-axis test over the 15 candidate axes (3 + 3 face normals, 9 edge cross products; ties go to the
+// faces of geom2, an edge axis must beat the best face by 1e-6), then either a face contact -- the incident face polygon
+// is clipped against the side planes of the reference face (Sutherland-Hodgman) and the vertices at or below the
+// reference face within `margin` become contacts, at most 4, deepest first -- or a single edge-edge contact at the
+// mid-point of the closest points of the two edges.  This is the classical SAT + clipping construction (as in ODE's
+// dBoxBox), NOT a restatement of MuJoCo's mjc_BoxBox, whose source could not be consulted: the two agree for face-face
+// resting contacts (what the stair terrain produces) and may differ in contact count / placement in edge cases
+// (DESIGN.md section 6).  The CPU checker used by the tests implements the same statements in the same order.
+template <class L>
+__device__ __noinline__ void col_box_box(ConSink<L>& k, const double* p1, const double* R1, const double* s1, const double* p2,
+                                         const double* R2, const double* s2, double margin) {
+  const double zero[3] = {0, 0, 0};
+  double A[3][3], B[3][3], d[3] = {p2[0] - p1[0], p2[1] - p1[1], p2[2] - p1[2]};
+  for (int i = 0; i < 3; i++)
+    for (int c = 0; c < 3; c++) { A[i][c] = R1[3 * c + i]; B[i][c] = R2[3 * c + i]; }
+  double R[3][3], AR[3][3], ta[3], tb[3];
+  for (int i = 0; i < 3; i++) {
+    ta[i] = dot3(d, A[i]); tb[i] = dot3(d, B[i]);
+    for (int j = 0; j < 3; j++) { R[i][j] = dot3(A[i], B[j]); AR[i][j] = fabs(R[i][j]) + 1e-12; }
+  }
+  double best = -1e300;
+  int code = -1;
+  for (int i = 0; i < 3; i++) {
+    const double s = fabs(ta[i]) - (s1[i] + s2[0] * AR[i][0] + s2[1] * AR[i][1] + s2[2] * AR[i][2]);
+    if (s > margin) return;
+    if (s > best) { best = s; code = i; }
+  }
+  for (int j = 0; j < 3; j++) {
+    const double s = fabs(tb[j]) - (s2[j] + s1[0] * AR[0][j] + s1[1] * AR[1][j] + s1[2] * AR[2][j]);
+    if (s > margin) return;
+    if (s > best - 1e-9) { if (s > best) best = s; code = 3 + j; }
+  }
+  double ebest = -1e300;
+  int ecode = -1;
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) {
+      const double len2 = 1.0 - R[i][j] * R[i][j];
+      if (len2 < 1e-12) continue;
+      const int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+      const double tl = ta[i2] * R[i1][j] - ta[i1] * R[i2][j];
+      const double ra = s1[i1] * AR[i2][j] + s1[i2] * AR[i1][j], rb = s2[j1] * AR[i][j2] + s2[j2] * AR[i][j1];
+      const double s = (fabs(tl) - ra - rb) / sqrt(len2);
+      if (s > margin) return;
+      if (s > ebest) { ebest = s; ecode = 6 + 3 * i + j; }
+    }
+  if (ecode >= 0 && ebest > best + 1e-6) {
+    const int i = (ecode - 6) / 3, j = (ecode - 6) % 3;
+    double n[3];
+    cross3(n, A[i], B[j]);
+    normalize3(n);
+    if (dot3(n, d) < 0) { n[0] = -n[0]; n[1] = -n[1]; n[2] = -n[2]; }
+    double pa[3] = {p1[0], p1[1], p1[2]}, pb[3] = {p2[0], p2[1], p2[2]};
+    for (int c = 0; c < 3; c++) {
+      if (c != i) { const double sg = dot3(n, A[c]) > 0 ? 1.0 : -1.0; for (int a = 0; a < 3; a++) pa[a] += sg * s1[c] * A[c][a]; }
+      if (c != j) { const double sg = dot3(n, B[c]) > 0 ? -1.0 : 1.0; for (int a = 0; a < 3; a++) pb[a] += sg * s2[c] * B[c][a]; }
+    }
+    const double w[3] = {pa[0] - pb[0], pa[1] - pb[1], pa[2] - pb[2]};
+    const double bq = R[i][j], dd = dot3(A[i], w), ee = dot3(B[j], w), den = 1.0 - bq * bq;
+    const double al = (bq * ee - dd) / den, be = (ee - bq * dd) / den;
+    double pos[3];
+    for (int a = 0; a < 3; a++) pos[a] = 0.5 * ((pa[a] + al * A[i][a]) + (pb[a] + be * B[j][a]));
+    k.emit(ebest, pos, n, zero);
+    return;
+  }
+  const bool refB = code >= 3;
+  const int ax = refB ? code - 3 : code;
+  const double *pr = refB ? p2 : p1, *pc = refB ? p1 : p2, *sr = refB ? s2 : s1, *sc = refB ? s1 : s2;
+  double (*Ar)[3] = refB ? B : A;
+  double (*Ac)[3] = refB ? A : B;
+  double n[3] = {Ar[ax][0], Ar[ax][1], Ar[ax][2]};
+  if (dot3(n, d) < 0) { n[0] = -n[0]; n[1] = -n[1]; n[2] = -n[2]; }
+  const double nr[3] = {refB ? -n[0] : n[0], refB ? -n[1] : n[1], refB ? -n[2] : n[2]};
+  double fc[3];
+  for (int a = 0; a < 3; a++) fc[a] = pr[a] + nr[a] * sr[ax];
+  int kc = 0;
+  double bestdot = -1;
+  for (int c = 0; c < 3; c++) { const double v = fabs(dot3(nr, Ac[c])); if (v > bestdot) { bestdot = v; kc = c; } }
+  const double sgn = dot3(nr, Ac[kc]) > 0 ? -1.0 : 1.0;
+  const int ku = (kc + 1) % 3, kv = (kc + 2) % 3;
+  double poly[8][3], tmp[8][3];
+  int np = 4;
+  for (int q = 0; q < 4; q++) {
+    const double su = (q == 0 || q == 3) ? 1.0 : -1.0, sv = (q < 2) ? 1.0 : -1.0;
+    for (int a = 0; a < 3; a++) poly[q][a] = pc[a] + sgn * sc[kc] * Ac[kc][a] + su * sc[ku] * Ac[ku][a] + sv * sc[kv] * Ac[kv][a];
+  }
+  const int ru = (ax + 1) % 3, rv = (ax + 2) % 3;
+  for (int pl = 0; pl < 4 && np > 0; pl++) {
+    const double* axis = (pl < 2) ? Ar[ru] : Ar[rv];
+    const double half = (pl < 2) ? sr[ru] : sr[rv], sg = (pl & 1) ? -1.0 : 1.0;
+    int nq = 0;
+    for (int q = 0; q < np; q++) {
+      const double *x0 = poly[q], *x1 = poly[(q + 1) % np];
+      const double w0[3] = {x0[0] - pr[0], x0[1] - pr[1], x0[2] - pr[2]}, w1[3] = {x1[0] - pr[0], x1[1] - pr[1], x1[2] - pr[2]};
+      const double e0 = sg * dot3(w0, axis) - half, e1 = sg * dot3(w1, axis) - half;
+      if (e0 <= 0) { if (nq < 8) { for (int a = 0; a < 3; a++) tmp[nq][a] = x0[a]; nq++; } }
+      if ((e0 <= 0) != (e1 <= 0)) {
+        const double tt = e0 / (e0 - e1);
+        if (nq < 8) { for (int a = 0; a < 3; a++) tmp[nq][a] = x0[a] + tt * (x1[a] - x0[a]); nq++; }
+      }
+    }
+    np = nq;
+    for (int q = 0; q < np; q++) for (int a = 0; a < 3; a++) poly[q][a] = tmp[q][a];
+  }
+  double dep[8];
+  int idx[8], cnt = 0;
+  for (int q = 0; q < np; q++) {
+    const double w0[3] = {poly[q][0] - fc[0], poly[q][1] - fc[1], poly[q][2] - fc[2]};
+    const double dq = dot3(w0, nr);
+    if (dq <= margin) { dep[cnt] = dq; idx[cnt] = q; cnt++; }
+  }
+  for (int a = 1; a < cnt; a++) {
+    const double dv = dep[a];
+    const int iv = idx[a];
+    int b = a - 1;
+    while (b >= 0 && dep[b] > dv) { dep[b + 1] = dep[b]; idx[b + 1] = idx[b]; b--; }
+    dep[b + 1] = dv; idx[b + 1] = iv;
+  }
+  if (cnt > 4) cnt = 4;
+  for (int q = 0; q < cnt; q++) {
+    double pos[3];
+    for (int a = 0; a < 3; a++) pos[a] = poly[idx[q]][a] - nr[a] * dep[q] * 0.5;
+    k.emit(dep[q], pos, n, zero);
+  }
+}
+
+template <bool BOXBOX, class L>
+__device__ void collide_pair(ConSink<L>& k, const HModel& m, const L& S, int g1, int g2, double margin) {
   const double zero[3] = {0, 0, 0};
   const int t1 = m.geom_i[GIS * (g1) + GI_TYPE], t2 = m.geom_i[GIS * (g2) + GI_TYPE];
   double p1[3], p2[3], R1[9], R2[9], s1[3], s2[3];
@@ -683,6 +845,8 @@ __device__ void collide_pair(ConSink& k, const HModel& m, const Lds& S, int g1, 
       for (int a = 0; a < 3; a++) pos[a] = corner[a] + p2[a] - nn[a] * (dist + ld) * 0.5;
       k.emit(dist + ld, pos, nn, zero);
     }
+  } else if (BOXBOX && t1 == G_BOX && t2 == G_BOX) {
+    if constexpr (BOXBOX) col_box_box(k, p1, R1, s1, p2, R2, s2, margin);  // only the stepping task's kernels carry this code
   } else if (t1 == G_SPHERE && t2 == G_SPHERE) col_sphere_sphere(k, p1, s1[0], p2, s2[0], margin);
   else if (t1 == G_SPHERE && t2 == G_CAPSULE) {
     double ax[3] = {R2[2], R2[5], R2[8]}, vec[3] = {p1[0] - p2[0], p1[1] - p2[1], p1[2] - p2[2]};
@@ -727,7 +891,8 @@ __device__ void collide_pair(ConSink& k, const HModel& m, const Lds& S, int g1, 
   }
 }
 
-__device__ void fwd_collision(const HModel& m, Lds& S, int lane) {
+template <bool BOXBOX, class L>
+__device__ void fwd_collision(const HModel& m, const HParams& p, L& S, int lane, const double* ter) {
   if (lane < m.ngeom) {
     const int g = lane, b = m.geom_i[GIS * (g) + GI_BODY];
     double gp[3] = {m.geom_d[GDS * (g) + GD_POS], m.geom_d[GDS * (g) + GD_POS + 1], m.geom_d[GDS * (g) + GD_POS + 2]}, t[3];
@@ -736,24 +901,38 @@ __device__ void fwd_collision(const HModel& m, Lds& S, int lane) {
     for (int k = 0; k < 9; k++) { Rl[k] = m.geom_d[GDS * g + GD_RLOC + k]; Rb[k] = S.U[U_XMAT + 9 * b + k]; }
     mat_vec(t, Rb, gp);
     mat_mul(R, Rb, Rl);
-    for (int k = 0; k < 3; k++) S.U[U_GPOS + 3 * g + k] = S.xpos[3 * b + k] + t[k];
+    double wp[3] = {S.xpos[3 * b] + t[0], S.xpos[3 * b + 1] + t[1], S.xpos[3 * b + 2] + t[2]};
+    if (ter) {  // stepping task: the 20 boxes sit under the target steps, the floor is lowered in FORWARD mode
+      const int kb = g - p.box_geom0;
+      if (kb >= 0 && kb < p.nbox) {
+        const double* sq = ter + T_SEQ + 6 * kb;
+        const double c = sq[4], sn = sq[5];
+        wp[0] = sq[0]; wp[1] = sq[1]; wp[2] = sq[2] - m.geom_d[GDS * g + GD_SIZE + 2];
+        R[0] = c; R[1] = -sn; R[2] = 0; R[3] = sn; R[4] = c; R[5] = 0; R[6] = 0; R[7] = 0; R[8] = 1;
+      } else if (g == p.floor_geom) wp[2] += ter[T_FLOOR];
+    }
+    for (int k = 0; k < 3; k++) S.U[U_GPOS + 3 * g + k] = wp[k];
     for (int k = 0; k < 9; k++) S.U[U_GMAT + 9 * g + k] = R[k];
   }
   if (lane == 0) { S.overflow = 0; }
   SYNC();
   int g1 = 0, g2 = 0;
   double margin = 0;
-  const bool have = lane < m.npair;
+  bool have = lane < m.npair;
   if (have) {
     g1 = m.pair_i[2 * (lane) + 0]; g2 = m.pair_i[2 * (lane) + 1];
     margin = fmax(m.geom_d[GDS * (g1) + GD_MARGIN], m.geom_d[GDS * (g2) + GD_MARGIN]);
+    // boxes only collide while the floor is lowered (KNOWN DEVIATION, DESIGN.md section 6: coplanar floor + box contacts
+    // of the reference would need more constraint rows than a wave has lanes)
+    if (ter && ter[T_FLOOR] == 0.0 && ((g1 >= p.box_geom0 && g1 < p.box_geom0 + p.nbox) || (g2 >= p.box_geom0 && g2 < p.box_geom0 + p.nbox)))
+      have = false;
   }
-  ConSink k{&S, 0, 0, 0, g1, g2};
-  if (have) collide_pair(k, m, S, g1, g2, margin);
+  ConSink<L> k{&S, 0, 0, 0, g1, g2};
+  if (have) collide_pair<BOXBOX>(k, m, S, g1, g2, margin);
   int total;
   const int base = wave_scan(k.n, &total) - k.n;
   k.base = base; k.n = 0; k.write = 1;
-  if (have && base < NC) collide_pair(k, m, S, g1, g2, margin);
+  if (have && base < NC) collide_pair<BOXBOX>(k, m, S, g1, g2, margin);
   if (lane == 0) { S.ncon = min(total, NC); if (total > NC) S.overflow = 1; }
   SYNC();
   // mj_contactParam (lane = contact): priority, else solmix-weighted mix; friction = max; condim = max
@@ -826,7 +1005,8 @@ __device__ __forceinline__ void row_params(const HModel& m, const double* sr_in,
 }
 
 // mj_makeConstraint: joint-limit rows, then contact rows (pyramidal), with mj_makeImpedance's shared pyramid R
-__device__ void fwd_constraints(const HModel& m, Lds& S, int lane) {
+template <class L>
+__device__ void fwd_constraints(const HModel& m, L& S, int lane) {
   // ---- frictionloss rows: lane = dof (mj_instantiateFriction); they come first
   const double myfl = lane < m.nv ? S.floss[lane] : 0.0;
   int nfr;
@@ -927,7 +1107,8 @@ __device__ void fwd_constraints(const HModel& m, Lds& S, int lane) {
 }
 
 // mj_fwdVelocity: cvel, cdof_dot, bias force (RNE, no acceleration), passive damping, constraint reference
-__device__ double fwd_velocity(const HModel& m, Lds& S, int lane) {
+template <class L>
+__device__ double fwd_velocity(const HModel& m, L& S, int lane) {
   // velocity seen by dof j when its cdof_dot is formed: sum over dof_prevmask[j]
   if (lane < m.nv) {
     const int j = lane;
@@ -1025,11 +1206,13 @@ __device__ __forceinline__ void row_deriv(bool valid, double fl, double D, doubl
 
 // One mj_forward (+ Euler).  flags: bit0 actuation enabled, bit1 integrate.
 // On return S.qacc / S.efc_force / contacts / S.sq,sv,frc describe THIS forward pass (the "stale" fields of note S).
-__device__ __forceinline__ void substep(const HModel& m, const HParams& p, Lds& S, int lane, int flags, double* warm /* lane-held */, long long* st_prof) {
+template <bool BOXBOX, class L>
+__device__ __forceinline__ void substep(const HModel& m, const HParams& p, L& S, int lane, int flags, double* warm /* lane-held */, long long* st_prof,
+                                        const double* ter) {
   PROF_BEGIN();
   fwd_kinematics(m, S, lane);
   PROF_MARK(0);
-  fwd_collision(m, S, lane);   // stage A temporaries (geom frames) die here
+  fwd_collision<BOXBOX>(m, p, S, lane, ter);   // stage A temporaries (geom frames) die here
   PROF_MARK(3);
   const double qapp = fwd_com(m, p, S, lane);
   PROF_MARK(1);
@@ -1264,7 +1447,8 @@ __device__ __forceinline__ void quat_roll_pitch(const double* q, double* roll, d
   else { *roll = atan2(-M12, M11); *pitch = atan2(-M20, cy); }
 }
 
-__device__ void write_obs(const HModel& m, const HParams& p, Lds& S, int lane, int phase, int mode, const double* mode_ref,
+template <class L>
+__device__ void write_obs(const HModel& m, const HParams& p, L& S, int lane, int phase, int mode, const double* mode_ref,
                           float* o) {
   // get_obs (base_humanoid_env.py:177-197): fresh root quaternion / angular velocity, stale motor pos/vel
   if (lane == 0) {
@@ -1280,9 +1464,25 @@ __device__ void write_obs(const HModel& m, const HParams& p, Lds& S, int lane, i
   if (lane < 12) { o[5 + lane] = (float)S.sq[lane]; o[17 + lane] = (float)S.sv[lane]; }
 }
 
+// jvrc_step observation (jvrc_step.py:66-77): robot state, clock, goal steps x[2] y[2] z[2] theta[2]
+template <class L>
+__device__ void write_obs_step(const HModel& m, const HParams& p, L& S, int lane, int phase, const double* goal, float* o) {
+  if (lane == 0) {
+    double r, pt;
+    quat_roll_pitch(&S.qpos[3], &r, &pt);
+    o[0] = (float)r; o[1] = (float)pt;
+    o[2] = (float)S.qvel[3]; o[3] = (float)S.qvel[4]; o[4] = (float)S.qvel[5];
+    const double ang = 2 * 3.141592653589793 * (double)phase / (double)p.period;
+    o[29] = (float)sin(ang); o[30] = (float)cos(ang);
+    for (int k = 0; k < 8; k++) o[31 + k] = (float)goal[k];
+  }
+  if (lane < 12) { o[5 + lane] = (float)S.sq[lane]; o[17 + lane] = (float)S.sv[lane]; }
+}
+
 // H1 robot state (h1_base.py:95-119): [roll, pitch, ang vel 3, motor pos 10, motor vel 10, motor torque 10] plus uniform
 // observation noise drawn per entry on every get_obs (base_humanoid_env.py:307-338); lane = observation entry
-__device__ void write_obs_h1(const HModel& m, const HParams& p, Lds& S, int lane, unsigned genv, unsigned obs_count, float* o,
+template <class L>
+__device__ void write_obs_h1(const HModel& m, const HParams& p, L& S, int lane, unsigned genv, unsigned obs_count, float* o,
                              float* o2) {
   if (lane < 35) {
     double v;
@@ -1304,7 +1504,8 @@ __device__ void write_obs_h1(const HModel& m, const HParams& p, Lds& S, int lane
 // randomize_dynamics (domain_randomization.py:29-56): leg dof frictionloss / damping, then mass scale and inertial
 // offset of pelvis + leg bodies relative to the DEFAULT model.  Writes the LDS copies (used immediately on reset) and
 // the per-env record.  slot0 = first RNG slot (0 on reset, 1 in step).
-__device__ void randomize_dynamics(const HModel& m, const HParams& p, Lds& S, double* prm, int lane, unsigned genv,
+template <class L>
+__device__ void randomize_dynamics(const HModel& m, const HParams& p, L& S, double* prm, int lane, unsigned genv,
                                    unsigned stream, unsigned counter, unsigned slot0) {
   if (lane < p.n_rand_dof) {
     const int d = p.rand_dof[lane];
@@ -1326,7 +1527,8 @@ __device__ void randomize_dynamics(const HModel& m, const HParams& p, Lds& S, do
 }
 
 // mj_objectVelocity(mjOBJ_XBODY): linear velocity of the body-frame origin, world orientation
-__device__ __forceinline__ void body_linvel(const Lds& S, int slot /* 0 root, 1 right foot, 2 left foot */, int b, double* lin) {
+template <class L>
+__device__ __forceinline__ void body_linvel(const L& S, int slot /* 0 root, 1 right foot, 2 left foot */, int b, double* lin) {
   const double* cv = &S.svel[6 * slot];
   double dif[3] = {S.xpos[3 * b] - S.com[0], S.xpos[3 * b + 1] - S.com[1], S.xpos[3 * b + 2] - S.com[2]}, t[3];
   cross3(t, dif, cv);
@@ -1339,12 +1541,14 @@ __global__ void __launch_bounds__(64, 2) humanoid_kernel(HModel m, HParams p, HS
                                                       float* __restrict__ rew, unsigned char* __restrict__ done_out,
                                                       float* __restrict__ rew_terms, const unsigned char* __restrict__ mask,
                                                       double* __restrict__ xq, double* __restrict__ xv) {
-  __shared__ Lds S;
+  using L = LdsT<(TASK == TASK_STEP ? 64 : 48), (TASK == TASK_STEP ? 16 : 12)>;
+  __shared__ L S;
   const int env = blockIdx.x, lane = threadIdx.x;
   if (MODE == 1 && mask && !mask[env]) return;
   double* rec = st.rec + (size_t)env * REC_D;
   double* prm = st.prm ? st.prm + (size_t)env * PRM_D : nullptr;
-  const int OBS = TASK == TASK_WALK ? 37 : 35;
+  double* ter = (TASK == TASK_STEP) ? st.ter + (size_t)env * TER_D : nullptr;
+  const int OBS = TASK == TASK_WALK ? 37 : (TASK == TASK_STEP ? 39 : 35);
   int* irec = st.irec + (size_t)env * REC_I;
   const unsigned genv = p.env_id_base + env;
   long long* sprof = (env == 0) ? st.prof : nullptr;
@@ -1368,6 +1572,9 @@ __global__ void __launch_bounds__(64, 2) humanoid_kernel(HModel m, HParams p, HS
   double ep_ret = rec[R_EPRET];
   int phase = irec[RI_PHASE], mode = irec[RI_MODE], traj_len = irec[RI_TRAJ], started = irec[RI_STARTED];
   unsigned step_count = (unsigned)irec[RI_STEPCNT], reset_count = (unsigned)irec[RI_RESETCNT], obs_count = (unsigned)irec[RI_OBSCNT];
+  int t1 = 0, t2 = 0, reached = 0, frames = 0, nseq = 2;
+  double goal[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (TASK == TASK_STEP) { t1 = irec[RI_T1]; t2 = irec[RI_T2]; reached = irec[RI_REACHED]; frames = irec[RI_FRAMES]; nseq = irec[RI_NSEQ]; }
   // per-env model parameters (or the shared defaults) -> LDS, once per launch
   if (lane < m.nv) {
     S.damp[lane] = prm ? prm[P_DAMP + lane] : m.dof_d[DDS * lane + DD_DAMPING];
@@ -1385,7 +1592,7 @@ __global__ void __launch_bounds__(64, 2) humanoid_kernel(HModel m, HParams p, HS
     if (lane < m.nq) S.qpos[lane] = xq[(size_t)env * m.nq + lane];
     if (lane < m.nv) S.qvel[lane] = xv[(size_t)env * m.nv + lane];
     SYNC();
-    substep(m, p, S, lane, 0, &warm, sprof);  // set_state: mj_forward with actuation disabled
+    substep<TASK == TASK_STEP>(m, p, S, lane, 0, &warm, sprof, ter);  // set_state: mj_forward with actuation disabled
   }
   if (MODE == 0) {
     // ---- BaseHumanoidEnv.step: smoothing, offsets (base_humanoid_env.py:209-215); RobotBase.step (robot_base.py:64-98)
@@ -1402,7 +1609,7 @@ __global__ void __launch_bounds__(64, 2) humanoid_kernel(HModel m, HParams p, HS
         S.ctrl[lane] = tau / m.act_d[ADS * (lane) + AD_GEAR];
       }
       SYNC();
-      substep(m, p, S, lane, 3, &warm, sprof);
+      substep<TASK == TASK_STEP>(m, p, S, lane, 3, &warm, sprof, ter);
     }
     PROF_MARK(9);  // control-step prologue (load, PD) is folded into slot 9 with the sub-step loop overheads
     double r_sum = 0, terms[10], cur_tq = 0;
@@ -1417,6 +1624,28 @@ __global__ void __launch_bounds__(64, 2) humanoid_kernel(HModel m, HParams p, HS
         selfcol = (m.body_i[BIS * (b1) + BI_ROOT] == p.root_body && m.body_i[BIS * (b2) + BI_ROOT] == p.root_body) ? 1 : 0;
       }
       self_collision = __any(selfcol);
+    }
+    // ground reaction forces and lowest foot-floor contact point (robot_interface.py:269-325): lane = contact
+    double grf_r = 0, grf_l = 0, cz = 1e300;
+    if (TASK != TASK_STAND) {
+      int anyfoot = 0;
+      if (lane < S.ncon) {
+        const int c = lane, b1 = m.geom_i[GIS * (S.con_g1[c]) + GI_BODY], b2 = m.geom_i[GIS * (S.con_g2[c]) + GI_BODY];
+        const bool floor1 = m.body_i[BIS * (b1) + BI_ROOT] != p.root_body;
+        double fn = 0;
+        const int r0 = S.con_row[c];
+        if (r0 >= 0) {
+          if (S.con_dim[c] == 3) {
+            const double f0 = S.efc_force[r0], f1 = S.efc_force[r0 + 1], f2 = S.efc_force[r0 + 2], f3 = S.efc_force[r0 + 3], mu = S.con_mu[c];
+            const double n = f0 + f1 + f2 + f3, t1f = mu * (f0 - f1), t2f = mu * (f2 - f3);
+            fn = sqrt(n * n + t1f * t1f + t2f * t2f);
+          } else fn = fabs(S.efc_force[r0]);
+        }
+        if (floor1 && b2 == p.rfoot_body) { grf_r = fn; cz = S.con_pos[3 * c + 2]; anyfoot = 1; }
+        if (floor1 && b2 == p.lfoot_body) { grf_l = fn; cz = S.con_pos[3 * c + 2]; anyfoot = 1; }
+      }
+      grf_r = wave_sum(grf_r); grf_l = wave_sum(grf_l); cz = wave_min(cz);
+      if (!__any(anyfoot)) cz = 0;
     }
     if (TASK == TASK_WALK) {
     // ---- WalkingTask.step (walking_task.py:149-170)
@@ -1437,27 +1666,6 @@ __global__ void __launch_bounds__(64, 2) humanoid_kernel(HModel m, HParams p, HS
       step_count++;
     }
     // ---- calc_reward (walking_task.py:85-147) on the fields of the last forward pass
-    // per-contact quantities: lane = contact
-    double grf_r = 0, grf_l = 0, cz = 1e300;
-    int anyfoot = 0;
-    if (lane < S.ncon) {
-      const int c = lane, b1 = m.geom_i[GIS * (S.con_g1[c]) + GI_BODY], b2 = m.geom_i[GIS * (S.con_g2[c]) + GI_BODY];
-      const bool floor1 = m.body_i[BIS * (b1) + BI_ROOT] != p.root_body;
-      double fn = 0;
-      const int r0 = S.con_row[c];
-      if (r0 >= 0) {
-        if (S.con_dim[c] == 3) {
-          const double f0 = S.efc_force[r0], f1 = S.efc_force[r0 + 1], f2 = S.efc_force[r0 + 2], f3 = S.efc_force[r0 + 3], mu = S.con_mu[c];
-          const double n = f0 + f1 + f2 + f3, t1 = mu * (f0 - f1), t2 = mu * (f2 - f3);
-          fn = sqrt(n * n + t1 * t1 + t2 * t2);
-        } else fn = fabs(S.efc_force[r0]);
-      }
-      if (floor1 && b2 == p.rfoot_body) { grf_r = fn; cz = S.con_pos[3 * c + 2]; anyfoot = 1; }
-      if (floor1 && b2 == p.lfoot_body) { grf_l = fn; cz = S.con_pos[3 * c + 2]; anyfoot = 1; }
-    }
-    grf_r = wave_sum(grf_r); grf_l = wave_sum(grf_l); cz = wave_min(cz);
-    const bool has_foot = __any(anyfoot);
-    if (!has_foot) cz = 0;
     // joint-space sums: lane = actuator / dof
     double s_posture = 0, s_tq = 0, s_act = 0, s_rootacc = 0;
     if (lane < m.nu) {
@@ -1504,6 +1712,70 @@ __global__ void __launch_bounds__(64, 2) humanoid_kernel(HModel m, HParams p, HS
     }
       const double z = S.qpos[2];
       terminated = z < 0.6 || z > 1.4 || self_collision;  // walking_task.py:184-192
+    } else if (TASK == TASK_STEP) {
+      // ---- SteppingTask.step (stepping_task.py:211-243) on the stale site / body frames
+      phase += 1;
+      if (phase >= p.period) phase = 0;
+      const double lp[3] = {S.spos[6], S.spos[7], S.spos[8]}, rp[3] = {S.spos[3], S.spos[4], S.spos[5]};
+      const double rootp[3] = {S.xpos[3 * p.root_body], S.xpos[3 * p.root_body + 1], S.xpos[3 * p.root_body + 2]};
+      {
+        const double* tg = ter + T_SEQ + 6 * t1;
+        const double dl = sqrt((lp[0] - tg[0]) * (lp[0] - tg[0]) + (lp[1] - tg[1]) * (lp[1] - tg[1]) + (lp[2] - tg[2]) * (lp[2] - tg[2]));
+        const double dr = sqrt((rp[0] - tg[0]) * (rp[0] - tg[0]) + (rp[1] - tg[1]) * (rp[1] - tg[1]) + (rp[2] - tg[2]) * (rp[2] - tg[2]));
+        if (dl < p.target_radius || dr < p.target_radius) { reached = 1; frames += 1; }
+        else { reached = 0; frames = 0; }
+        if (reached && frames >= p.delay_frames) {  // update_target_steps
+          t1 = t2; t2 += 1;
+          if (t2 == nseq) t2 = nseq - 1;
+          reached = 0; frames = 0;
+        }
+      }
+      // update_goal_steps (stepping_task.py:184-202): the two targets in the root frame
+      if (mode != WALK_STANDING) {
+        for (int i = 0; i < 2; i++) {
+          const double* sq = ter + T_SEQ + 6 * (i ? t2 : t1);
+          const double dvec[3] = {sq[0] - rootp[0], sq[1] - rootp[1], sq[2] - rootp[2]};
+          double rel[3];
+          matT_vec(rel, S.rootmat, dvec);
+          const double M00 = S.rootmat[0] * sq[4] + S.rootmat[3] * sq[5], M10 = S.rootmat[1] * sq[4] + S.rootmat[4] * sq[5];
+          const double cy = sqrt(M00 * M00 + M10 * M10);
+          goal[i] = rel[0]; goal[2 + i] = rel[1]; goal[4 + i] = rel[2];
+          goal[6 + i] = cy > 4.0 * 2.220446049250313e-16 ? atan2(M10, M00) : 0.0;
+        }
+      }
+      step_count++;
+      // ---- calc_reward (stepping_task.py:81-123)
+      {
+        const double* tg = ter + T_SEQ + 6 * t1;
+        const double* tg2 = ter + T_SEQ + 6 * t2;
+        double lv[3], rv[3];
+        body_linvel(S, 2, p.lfoot_body, lv); body_linvel(S, 1, p.rfoot_body, rv);
+        double rf = p.clock_lut[0 * p.period + phase], rvc = p.clock_lut[1 * p.period + phase];
+        double lf = p.clock_lut[2 * p.period + phase], lvc = p.clock_lut[3 * p.period + phase];
+        if (mode == WALK_STANDING) { rf = 1; lf = 1; rvc = -1; lvc = -1; }
+        const double PI4 = 3.141592653589793 / 4;
+        const double maxf = m.totalmass * 9.8 * 0.5;
+        const double nl = fmin(grf_l, maxf) / maxf * 2 - 1, nr = fmin(grf_r, maxf) / maxf * 2 - 1;
+        terms[0] = 0.150 * ((tan(PI4 * lf * nl) + tan(PI4 * rf * nr)) / 2);
+        const double nlv = fmin(sqrt(dot3(lv, lv)), 0.2) / 0.2 * 2 - 1, nrv = fmin(sqrt(dot3(rv, rv)), 0.2) / 0.2 * 2 - 1;
+        terms[1] = 0.150 * ((tan(PI4 * lvc * nlv) + tan(PI4 * rvc * nrv)) / 2);
+        const double inner = cos(0.5 * tg[3]) * S.rootquat[0] + sin(0.5 * tg[3]) * S.rootquat[3];
+        terms[2] = 0.050 * exp(-(10 * (1 - inner * inner)));
+        double herr = fabs(rootp[2] - cz - p.goal_height);
+        if (herr < 0.01) herr = 0;
+        terms[3] = 0.050 * exp(-40 * herr * herr);
+        const double dl = sqrt((lp[0] - tg[0]) * (lp[0] - tg[0]) + (lp[1] - tg[1]) * (lp[1] - tg[1]) + (lp[2] - tg[2]) * (lp[2] - tg[2]));
+        const double dr = sqrt((rp[0] - tg[0]) * (rp[0] - tg[0]) + (rp[1] - tg[1]) * (rp[1] - tg[1]) + (rp[2] - tg[2]) * (rp[2] - tg[2]));
+        const double hit = reached ? exp(-fmin(dl, dr) / 0.25) : 0.0;
+        const double mx = (tg[0] + tg2[0]) / 2, my = (tg[1] + tg2[1]) / 2;
+        const double progress = exp(-sqrt((rootp[0] - mx) * (rootp[0] - mx) + (rootp[1] - my) * (rootp[1] - my)) / 2);
+        terms[4] = 0.450 * (0.8 * hit + 0.2 * progress);
+        const double hx = S.xpos[3 * p.head_body] - rootp[0], hy = S.xpos[3 * p.head_body + 1] - rootp[1], hn = sqrt(hx * hx + hy * hy);
+        terms[5] = 0.050 * exp(-10 * (hn * hn));
+        for (int k = 0; k < 6; k++) r_sum += terms[k];
+        for (int k = 6; k < 10; k++) terms[k] = 0;
+      }
+      terminated = (rootp[2] - fmin(lp[2], rp[2])) < 0.6 || self_collision;  // stepping_task.py:247-259
     } else {
       // ---- StandingTask.calc_reward / done (standing_task.py:49-131) on the fields of the last forward pass
       double s_posture = 0, s_tau = 0;
@@ -1560,6 +1832,9 @@ __global__ void __launch_bounds__(64, 2) humanoid_kernel(HModel m, HParams p, HS
     if (TASK == TASK_WALK) {
       write_obs(m, p, S, lane, phase, mode, mode_ref, obs + (size_t)env * OBS);
       if (term_obs) write_obs(m, p, S, lane, phase, mode, mode_ref, term_obs + (size_t)env * OBS);
+    } else if (TASK == TASK_STEP) {
+      write_obs_step(m, p, S, lane, phase, goal, obs + (size_t)env * OBS);
+      if (term_obs) write_obs_step(m, p, S, lane, phase, goal, term_obs + (size_t)env * OBS);
     } else {
       write_obs_h1(m, p, S, lane, genv, obs_count, obs + (size_t)env * OBS, term_obs ? term_obs + (size_t)env * OBS : nullptr);
       obs_count++;
@@ -1620,8 +1895,8 @@ __global__ void __launch_bounds__(64, 2) humanoid_kernel(HModel m, HParams p, HS
       }
     }
     SYNC();
-    substep(m, p, S, lane, 0, &warm, sprof);                           // set_state: forward, actuation disabled
-    for (int k = 0; k < 3; k++) substep(m, p, S, lane, 3, &warm, sprof);  // three settle steps, ctrl = 0
+    substep<TASK == TASK_STEP>(m, p, S, lane, 0, &warm, sprof, ter);                           // set_state: forward, actuation disabled
+    for (int k = 0; k < 3; k++) substep<TASK == TASK_STEP>(m, p, S, lane, 3, &warm, sprof, ter);  // three settle steps, ctrl = 0
     if (TASK == TASK_WALK) {
       // WalkingTask.reset (walking_task.py:194-205): slot 0 mode, 1..3 mode_ref, 4 phase
       const double u = lhw_rng_u01(p.seed, genv, LHW_STREAM_RESET, reset_count, 0);
@@ -1629,12 +1904,84 @@ __global__ void __launch_bounds__(64, 2) humanoid_kernel(HModel m, HParams p, HS
       sample_ref(p, genv, LHW_STREAM_RESET, reset_count, 1, mode, mode_ref);
       phase = lhw_rng_randint(p.seed, genv, LHW_STREAM_RESET, reset_count, 4, p.period);
     }
+    if (TASK == TASK_STEP) {
+      // ---- SteppingTask.reset (stepping_task.py:261-334); RNG slots: 0 phase, 1 mode, 2 mode-specific choice, 3 first-step
+      // offset, 4 number of flat steps.  Lane k builds target step k (running sums are replayed per lane so that every
+      // value is produced by the same sequence of additions as in the reference's loops).
+      for (int k = 0; k < 8; k++) goal[k] = 0;
+      reached = 0; frames = 0;
+      phase = lhw_rng_randint(p.seed, genv, LHW_STREAM_RESET, reset_count, 0, 2) == 0 ? 0 : p.period / 2;
+      const double u = lhw_rng_u01(p.seed, genv, LHW_STREAM_RESET, reset_count, 1);
+      mode = u < 0.15 ? WALK_CURVED : (u < 0.2 ? WALK_STANDING : (u < 0.4 ? WALK_BACKWARD : (u < 0.7 ? WALK_LATERAL : WALK_FORWARD)));
+      const int k = lane;
+      double sx = 0, sy = 0, sz = 0, sth = 0;
+      if (mode == WALK_CURVED) {
+        const double* row = p.plans + (size_t)lhw_rng_randint(p.seed, genv, LHW_STREAM_RESET, reset_count, 2, p.nplans) * (1 + MAX_SEQ * 3);
+        nseq = (int)row[0];
+        if (k < nseq) { sx = row[1 + 3 * k]; sy = row[2 + 3 * k]; sth = row[3 + 3 * k]; }
+      } else if (mode == WALK_LATERAL) {
+        const double sgn = lhw_rng_randint(p.seed, genv, LHW_STREAM_RESET, reset_count, 2, 2) == 0 ? -1.0 : 1.0;
+        nseq = 19;
+        double y = 0;
+        for (int i = 1; i <= k + 1 && i < 20; i++) {
+          if (i % 2) y += 0.4; else y -= (2.0 / 3.0) * 0.4;
+        }
+        sy = sgn * y;
+      } else {
+        const int num_steps = mode == WALK_STANDING ? 1 : 20;
+        const double size = mode == WALK_BACKWARD ? -0.1 : 0.3, gap = 0.15;
+        double height = 0;
+        if (mode == WALK_FORWARD) {
+          const double hh = fmin(1.0, fmax(0.0, ((double)p.iteration - 3000.0) / 8000.0)) * 0.1;
+          height = lhw_rng_randint(p.seed, genv, LHW_STREAM_RESET, reset_count, 2, 2) == 0 ? -hh : hh;
+        }
+        const double uf = lhw_rng_uniform(p.seed, genv, LHW_STREAM_RESET, reset_count, 3, 0.095, 0.105);
+        const bool neg = (double)phase == 0.5 * (double)p.period;
+        const int cflat = 2 + (int)lhw_rng_randint(p.seed, genv, LHW_STREAM_RESET, reset_count, 4, 2);
+        nseq = num_steps == 1 ? 2 : 20;
+        if (k == 0) sy = neg ? -1 * uf : 1 * uf;
+        else {
+          double x = 0, y = neg ? -gap : gap, z = 0;
+          const int last = (k >= nseq - 1) ? num_steps - 2 : k;   // the final step replays the whole loop
+          for (int i = 1; i <= last; i++) {
+            x += size; y *= -1;
+            if (i > cflat) z += height;
+          }
+          if (k >= nseq - 1) { sx = x + size; sy = -y; sz = z; }
+          else { sx = x; sy = y; sz = z; }
+        }
+      }
+      // transform_sequence (stepping_task.py:125-138): relative to the feet mid-point and the root yaw (stale frames)
+      const double mid0 = (S.xpos[3 * p.lfoot_body] + S.xpos[3 * p.rfoot_body]) / 2, mid1 = (S.xpos[3 * p.lfoot_body + 1] + S.xpos[3 * p.rfoot_body + 1]) / 2;
+      double yaw;
+      {
+        const double w = S.rootquat[0], x = S.rootquat[1], y = S.rootquat[2], z = S.rootquat[3];
+        const double Nq = w * w + x * x + y * y + z * z, sc = Nq > 2.220446049250313e-16 ? 2.0 / Nq : 0.0;
+        const double Y = y * sc, Z = z * sc;
+        const double M00 = 1.0 - (y * Y + z * Z), M10 = x * Y + w * Z, cy = sqrt(M00 * M00 + M10 * M10);
+        yaw = cy > 4.0 * 2.220446049250313e-16 ? atan2(M10, M00) : 0.0;
+      }
+      if (k < MAX_SEQ) {
+        double out[6] = {0.0, 0.0, -1.0, 0.0, 1.0, 0.0};
+        if (k < nseq) {
+          const double cyw = cos(yaw), syw = sin(yaw);
+          out[0] = mid0 + sx * cyw - sy * syw; out[1] = mid1 + sx * syw + sy * cyw; out[2] = sz; out[3] = yaw + sth;
+          out[4] = cos(out[3]); out[5] = sin(out[3]);
+        }
+        for (int a = 0; a < 6; a++) ter[T_SEQ + 6 * k + a] = out[a];
+      }
+      if (lane == 0) ter[T_FLOOR] = mode == WALK_FORWARD ? -2.0 : 0.0;   // stepping_task.py:330-334
+      t1 = 0; t2 = 1;                                                   // update_target_steps from t1 = t2 = 0
+      if (t2 == nseq) t2 = nseq - 1;
+    }
     reset_count++;
     traj_len = 0;
     ep_ret = 0;
     prevpred = 0;
     if (TASK == TASK_WALK) {
       if (obs) write_obs(m, p, S, lane, phase, mode, mode_ref, obs + (size_t)env * OBS);
+    } else if (TASK == TASK_STEP) {
+      if (obs) write_obs_step(m, p, S, lane, phase, goal, obs + (size_t)env * OBS);
     } else {
       write_obs_h1(m, p, S, lane, genv, obs_count, obs ? obs + (size_t)env * OBS : nullptr, nullptr);  // the counter advances either way
       obs_count++;
@@ -1654,6 +2001,7 @@ __global__ void __launch_bounds__(64, 2) humanoid_kernel(HModel m, HParams p, HS
     rec[R_EPRET] = ep_ret;
     irec[RI_PHASE] = phase; irec[RI_MODE] = mode; irec[RI_TRAJ] = traj_len; irec[RI_STARTED] = started;
     irec[RI_STEPCNT] = (int)step_count; irec[RI_RESETCNT] = (int)reset_count; irec[RI_OBSCNT] = (int)obs_count;
+    if (TASK == TASK_STEP) { irec[RI_T1] = t1; irec[RI_T2] = t2; irec[RI_REACHED] = reached; irec[RI_FRAMES] = frames; irec[RI_NSEQ] = nseq; }
   }
 }
 
@@ -1679,25 +2027,52 @@ int humanoid_create(HumanoidEnv** out, const std::vector<int32_t>& mi, const std
                     int* obs_dim, int* act_dim, int* n_terms) {
   auto IF = [&](int f) { return mi.data() + mi[LHW_IH_COUNT + f]; };
   auto DF = [&](int f) { return md.data() + mi[LHW_IH_COUNT + LHW_IF_COUNT + f]; };
-  const int nq = mi[LHW_IH_NQ], nv = mi[LHW_IH_NV], nu = mi[LHW_IH_NU], nb = mi[LHW_IH_NBODY], nj = mi[LHW_IH_NJNT],
+  const int nq = mi[LHW_IH_NQ], nv = mi[LHW_IH_NV], nu = mi[LHW_IH_NU], nbm = mi[LHW_IH_NBODY], nj = mi[LHW_IH_NJNT],
             ng = mi[LHW_IH_NGEOM], np = mi[LHW_IH_NPAIR];
+  // Static bodies (children of the world without joints: floor, terrain boxes) never move: their geoms are attached to
+  // the world body with the composed pose and the bodies themselves are dropped from the kinematic tables.
+  std::vector<int> bmap(nbm, 0), bsrc(1, 0);
+  for (int b = 1; b < nbm; b++) {
+    if (IF(LHW_IF_BODY_ROOTID)[b] == 1) { bmap[b] = (int)bsrc.size(); bsrc.push_back(b); }
+    else if (IF(LHW_IF_BODY_PARENTID)[b] != 0 || IF(LHW_IF_BODY_DOFNUM)[b] > 0)
+      return lhw_fail(LHW_ERR_UNSUPPORTED, "exactly one dynamic tree (rooted at body 1) plus static children of the world is supported");
+  }
+  const int nb = (int)bsrc.size();
   if (nq > NQ || nv > NV || nu > NU || nb > NB || nj > NJ || ng > NG || np > NP || nb > 64 || np > 64)
     return lhw_fail(LHW_ERR_MODEL, "model exceeds compiled limits (nq %d/%d nv %d/%d nu %d/%d nbody %d/%d njnt %d/%d ngeom %d/%d npair %d/%d)",
                     nq, NQ, nv, NV, nu, NU, nb, NB, nj, NJ, ng, NG, np, NP);
-  const bool walk = cfg->task == LHW_TASK_JVRC_WALK, stand = cfg->task == LHW_TASK_H1_STAND;
+  const bool stepping = cfg->task == LHW_TASK_JVRC_STEP;
+  const bool walk = cfg->task == LHW_TASK_JVRC_WALK || stepping, stand = cfg->task == LHW_TASK_H1_STAND;  // walk: JVRC robot + gait clock
   if (!walk && !stand) return lhw_fail(LHW_ERR_ARG, "humanoid stepper: unknown task");
-  if (walk && (nu != 12 || nq != 19 || nv != 18)) return lhw_fail(LHW_ERR_UNSUPPORTED, "jvrc_walk needs a free root + 12 actuated leg hinges");
+  if (walk && (nu != 12 || nq != 19 || nv != 18)) return lhw_fail(LHW_ERR_UNSUPPORTED, "jvrc tasks need a free root + 12 actuated leg hinges");
   if (stand && (nu != 10 || nq != 17 || nv != 16)) return lhw_fail(LHW_ERR_UNSUPPORTED, "h1 needs a free root + 10 actuated leg hinges");
   if (!cfg->kp || !cfg->kd || !cfg->action_offset || cfg->n_task_iparams < LHW_TI_COUNT || cfg->n_task_params < LHW_TP_COUNT || cfg->frame_skip <= 0)
     return lhw_fail(LHW_ERR_ARG, "humanoid task config incomplete");
   if (walk && (!cfg->clock_lut || cfg->period <= 0)) return lhw_fail(LHW_ERR_ARG, "jvrc_walk needs the gait clock table");
   if (stand && (cfg->n_task_params < LHW_TP_H1_OBS_NOISE + 35 || cfg->n_task_iparams < LHW_TI_H1_RAND_BODY + 11))
     return lhw_fail(LHW_ERR_ARG, "h1 task parameter arrays too short");
-  const int32_t *parent = IF(LHW_IF_BODY_PARENTID), *rootid = IF(LHW_IF_BODY_ROOTID), *jtype = IF(LHW_IF_JNT_TYPE);
-  const int32_t *bdofadr = IF(LHW_IF_BODY_DOFADR), *bdofnum = IF(LHW_IF_BODY_DOFNUM), *dparent = IF(LHW_IF_DOF_PARENTID);
+  int nplans = 0;
+  if (stepping) {
+    if (cfg->n_task_iparams < LHW_TI_STEP_COUNT || cfg->n_task_params < LHW_TP_STEP_PLANS) return lhw_fail(LHW_ERR_ARG, "stepping task parameter arrays too short");
+    nplans = (int)cfg->task_params[LHW_TP_STEP_NPLANS];
+    if (nplans < 1 || cfg->n_task_params < LHW_TP_STEP_PLANS + nplans * (1 + LHW_STEP_MAX_SEQ * 3)) return lhw_fail(LHW_ERR_ARG, "stepping task: footstep plan table missing or short");
+    for (int q = 0; q < nplans; q++) {
+      const double len = cfg->task_params[LHW_TP_STEP_PLANS + (size_t)q * (1 + LHW_STEP_MAX_SEQ * 3)];
+      if (!(len >= 2 && len <= LHW_STEP_MAX_SEQ)) return lhw_fail(LHW_ERR_ARG, "stepping task: plan %d has %g steps (2..%d supported)", q, len, LHW_STEP_MAX_SEQ);
+    }
+    const int b0 = cfg->task_iparams[LHW_TI_STEP_BOX_GEOM0], nbx = cfg->task_iparams[LHW_TI_STEP_NBOX], fg = cfg->task_iparams[LHW_TI_STEP_FLOOR_GEOM];
+    if (nbx != MAX_SEQ || b0 < 0 || b0 + nbx > ng || fg < 0 || fg >= ng) return lhw_fail(LHW_ERR_ARG, "stepping task: bad terrain geom ids");
+    for (int g = b0; g < b0 + nbx; g++)
+      if (IF(LHW_IF_GEOM_TYPE)[g] != G_BOX || bmap[IF(LHW_IF_GEOM_BODYID)[g]] != 0) return lhw_fail(LHW_ERR_ARG, "stepping task: terrain geoms must be boxes on static bodies");
+    if (IF(LHW_IF_GEOM_TYPE)[fg] != G_PLANE) return lhw_fail(LHW_ERR_ARG, "stepping task: floor geom must be a plane");
+  }
+  const int32_t *jtype = IF(LHW_IF_JNT_TYPE), *dparent = IF(LHW_IF_DOF_PARENTID);
   const int32_t *djnt = IF(LHW_IF_DOF_JNTID), *jdof = IF(LHW_IF_JNT_DOFADR);
+  // per-body model arrays re-indexed by the compacted body id
+  std::vector<int32_t> parent(nb, 0), rootid(nb, 0), bdofadr(nb, 0), bdofnum(nb, 0);
   for (int b = 1; b < nb; b++) {
-    if (bdofnum[b] > 0 && rootid[b] != 1) return lhw_fail(LHW_ERR_UNSUPPORTED, "exactly one dynamic tree (rooted at body 1) is supported");
+    parent[b] = bmap[IF(LHW_IF_BODY_PARENTID)[bsrc[b]]]; rootid[b] = 1;
+    bdofadr[b] = IF(LHW_IF_BODY_DOFADR)[bsrc[b]]; bdofnum[b] = IF(LHW_IF_BODY_DOFNUM)[bsrc[b]];
     if (parent[b] >= b) return lhw_fail(LHW_ERR_MODEL, "bodies must be in depth-first order");
   }
   for (int j = 0; j < nj; j++)
@@ -1707,6 +2082,9 @@ int humanoid_create(HumanoidEnv** out, const std::vector<int32_t>& mi, const std
     if (cd != 1 && cd != 3) return lhw_fail(LHW_ERR_UNSUPPORTED, "condim %d", cd);
   }
   if (mi[LHW_IH_CONE] != 0) return lhw_fail(LHW_ERR_UNSUPPORTED, "only the pyramidal cone is implemented");
+  for (int q = 0; q < np; q++)
+    if (!stepping && IF(LHW_IF_GEOM_TYPE)[IF(LHW_IF_PAIR_GEOM1)[q]] == G_BOX && IF(LHW_IF_GEOM_TYPE)[IF(LHW_IF_PAIR_GEOM2)[q]] == G_BOX)
+      return lhw_fail(LHW_ERR_UNSUPPORTED, "box-box pairs are only compiled into the stepping-task kernels");
 
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return lhw_fail(LHW_ERR_NO_DEVICE, "no HIP device");
@@ -1750,12 +2128,13 @@ int humanoid_create(HumanoidEnv** out, const std::vector<int32_t>& mi, const std
       act_i((size_t)nu * AIS, 0), pair_i((size_t)np * 2, 0);
   for (int b = 0; b < nb; b++) {
     double* k = &body_d[(size_t)BDS * b];
-    for (int a = 0; a < 3; a++) { k[BD_POS + a] = DF(LHW_DF_BODY_POS)[3 * b + a]; k[BD_IPOS + a] = DF(LHW_DF_BODY_IPOS)[3 * b + a]; k[BD_INERTIA + a] = DF(LHW_DF_BODY_INERTIA)[3 * b + a]; }
-    h_quat2mat(k + BD_RBODY, DF(LHW_DF_BODY_QUAT) + 4 * b);
-    h_quat2mat(k + BD_RINERT, DF(LHW_DF_BODY_IQUAT) + 4 * b);
-    k[BD_MASS] = DF(LHW_DF_BODY_MASS)[b];
-    k[BD_INVW] = DF(LHW_DF_BODY_INVWEIGHT0)[2 * b]; k[BD_INVW + 1] = DF(LHW_DF_BODY_INVWEIGHT0)[2 * b + 1];
-    const int jn = IF(LHW_IF_BODY_JNTNUM)[b], ja = IF(LHW_IF_BODY_JNTADR)[b];
+    const int mb = bsrc[b];
+    for (int a = 0; a < 3; a++) { k[BD_POS + a] = DF(LHW_DF_BODY_POS)[3 * mb + a]; k[BD_IPOS + a] = DF(LHW_DF_BODY_IPOS)[3 * mb + a]; k[BD_INERTIA + a] = DF(LHW_DF_BODY_INERTIA)[3 * mb + a]; }
+    h_quat2mat(k + BD_RBODY, DF(LHW_DF_BODY_QUAT) + 4 * mb);
+    h_quat2mat(k + BD_RINERT, DF(LHW_DF_BODY_IQUAT) + 4 * mb);
+    k[BD_MASS] = DF(LHW_DF_BODY_MASS)[mb];
+    k[BD_INVW] = DF(LHW_DF_BODY_INVWEIGHT0)[2 * mb]; k[BD_INVW + 1] = DF(LHW_DF_BODY_INVWEIGHT0)[2 * mb + 1];
+    const int jn = IF(LHW_IF_BODY_JNTNUM)[mb], ja = IF(LHW_IF_BODY_JNTADR)[mb];
     int* bi = &body_i[(size_t)BIS * b];
     bi[0] = parent[b]; bi[BI_LEVEL] = level[b]; bi[2] = -1; bi[3] = 0;
     bi[BI_ROOT] = rootid[b]; bi[BI_SUBEND] = subend[b]; bi[BI_DOFMASK] = (int)bmask[b]; bi[BI_JNTADR] = ja < 0 ? 0 : ja;
@@ -1787,7 +2166,7 @@ int humanoid_create(HumanoidEnv** out, const std::vector<int32_t>& mi, const std
     for (int a = 0; a < 5; a++) k[DD_SOLIMP + a] = DF(LHW_DF_DOF_SOLIMP)[5 * d + a];
     int* di = &dof_i[(size_t)DIS * d];
     const int j = djnt[d], kk = d - jdof[j];
-    di[DI_BODY] = IF(LHW_IF_DOF_BODYID)[d]; di[DI_JNT] = j;
+    di[DI_BODY] = bmap[IF(LHW_IF_DOF_BODYID)[d]]; di[DI_JNT] = j;
     di[DI_KIND] = jtype[j] == JT_FREE ? (kk < 3 ? 0 : 1) : (jtype[j] == JT_SLIDE ? 2 : 3);
     di[DI_PREVMASK] = (int)pmask[d];
   }
@@ -1795,12 +2174,25 @@ int humanoid_create(HumanoidEnv** out, const std::vector<int32_t>& mi, const std
     double* k = &geom_d[(size_t)GDS * g];
     for (int a = 0; a < 3; a++) { k[GD_POS + a] = DF(LHW_DF_GEOM_POS)[3 * g + a]; k[GD_SIZE + a] = DF(LHW_DF_GEOM_SIZE)[3 * g + a]; k[GD_FRICTION + a] = DF(LHW_DF_GEOM_FRICTION)[3 * g + a]; }
     h_quat2mat(k + GD_RLOC, DF(LHW_DF_GEOM_QUAT) + 4 * g);
+    const int gmb = IF(LHW_IF_GEOM_BODYID)[g];
+    if (gmb != 0 && bmap[gmb] == 0) {  // geom of a static body: fold the body pose in
+      double Rb[9], Rg[9], pg[3];
+      h_quat2mat(Rb, DF(LHW_DF_BODY_QUAT) + 4 * gmb);
+      for (int a = 0; a < 9; a++) Rg[a] = k[GD_RLOC + a];
+      for (int a = 0; a < 3; a++) pg[a] = k[GD_POS + a];
+      for (int r = 0; r < 3; r++) {
+        k[GD_POS + r] = DF(LHW_DF_BODY_POS)[3 * gmb + r] + Rb[3 * r] * pg[0] + Rb[3 * r + 1] * pg[1] + Rb[3 * r + 2] * pg[2];
+        for (int c = 0; c < 3; c++) k[GD_RLOC + 3 * r + c] = Rb[3 * r] * Rg[c] + Rb[3 * r + 1] * Rg[3 + c] + Rb[3 * r + 2] * Rg[6 + c];
+      }
+    }
     k[GD_SOLMIX] = DF(LHW_DF_GEOM_SOLMIX)[g];
     k[GD_SOLREF] = DF(LHW_DF_GEOM_SOLREF)[2 * g]; k[GD_SOLREF + 1] = DF(LHW_DF_GEOM_SOLREF)[2 * g + 1];
     for (int a = 0; a < 5; a++) k[GD_SOLIMP + a] = DF(LHW_DF_GEOM_SOLIMP)[5 * g + a];
     k[GD_MARGIN] = DF(LHW_DF_GEOM_MARGIN)[g]; k[GD_GAP] = DF(LHW_DF_GEOM_GAP)[g];
+    if (stepping && g >= cfg->task_iparams[LHW_TI_STEP_BOX_GEOM0] && g < cfg->task_iparams[LHW_TI_STEP_BOX_GEOM0] + MAX_SEQ)
+      for (int a = 0; a < 3; a++) k[GD_SIZE + a] = cfg->task_params[LHW_TP_STEP_BOX_SIZE + a];  // stepping_task.py:325
     int* gi = &geom_i[(size_t)GIS * g];
-    gi[GI_TYPE] = IF(LHW_IF_GEOM_TYPE)[g]; gi[GI_BODY] = IF(LHW_IF_GEOM_BODYID)[g]; gi[GI_CONDIM] = IF(LHW_IF_GEOM_CONDIM)[g];
+    gi[GI_TYPE] = IF(LHW_IF_GEOM_TYPE)[g]; gi[GI_BODY] = bmap[gmb]; gi[GI_CONDIM] = IF(LHW_IF_GEOM_CONDIM)[g];
     gi[GI_PRIORITY] = IF(LHW_IF_GEOM_PRIORITY)[g];
   }
   for (int q = 0; q < np; q++) { pair_i[2 * q] = IF(LHW_IF_PAIR_GEOM1)[q]; pair_i[2 * q + 1] = IF(LHW_IF_PAIR_GEOM2)[q]; }
@@ -1814,8 +2206,8 @@ int humanoid_create(HumanoidEnv** out, const std::vector<int32_t>& mi, const std
     ai[AI_DOF] = jdof[j]; ai[AI_JNT] = j; ai[AI_CTRLLIMITED] = IF(LHW_IF_ACTUATOR_CTRLLIMITED)[u]; ai[AI_FORCELIMITED] = IF(LHW_IF_ACTUATOR_FORCELIMITED)[u];
   }
   m.nlevel = nlevel; m.nmpair = (int)mp.size() / 2;
-  m.track_body[0] = cfg->task_iparams[LHW_TI_ROOT_BODY]; m.track_body[1] = cfg->task_iparams[LHW_TI_RFOOT_BODY];
-  m.track_body[2] = cfg->task_iparams[LHW_TI_LFOOT_BODY];
+  auto BID = [&](int f) { const int b = cfg->task_iparams[f]; return (b >= 0 && b < nbm) ? bmap[b] : -1; };
+  m.track_body[0] = BID(LHW_TI_ROOT_BODY); m.track_body[1] = BID(LHW_TI_RFOOT_BODY); m.track_body[2] = BID(LHW_TI_LFOOT_BODY);
   ok = ok && (m.body_d = to_dev<double>(h, body_d.data(), body_d.size())) && (m.jnt_d = to_dev<double>(h, jnt_d.data(), jnt_d.size())) &&
        (m.dof_d = to_dev<double>(h, dof_d.data(), dof_d.size())) && (m.geom_d = to_dev<double>(h, geom_d.data(), geom_d.size())) &&
        (m.act_d = to_dev<double>(h, act_d.data(), act_d.size())) && (m.body_i = to_dev<int>(h, body_i.data(), body_i.size())) &&
@@ -1825,13 +2217,20 @@ int humanoid_create(HumanoidEnv** out, const std::vector<int32_t>& mi, const std
   HParams& p = h->p;
   memset(&p, 0, sizeof p);
   p.n_envs = cfg->n_envs; p.frame_skip = cfg->frame_skip; p.max_traj_len = cfg->max_traj_len; p.period = cfg->period;
-  p.root_body = cfg->task_iparams[LHW_TI_ROOT_BODY]; p.head_body = cfg->task_iparams[LHW_TI_HEAD_BODY];
-  p.rfoot_body = cfg->task_iparams[LHW_TI_RFOOT_BODY]; p.lfoot_body = cfg->task_iparams[LHW_TI_LFOOT_BODY];
+  p.root_body = BID(LHW_TI_ROOT_BODY); p.head_body = BID(LHW_TI_HEAD_BODY);
+  p.rfoot_body = BID(LHW_TI_RFOOT_BODY); p.lfoot_body = BID(LHW_TI_LFOOT_BODY);
   if (p.root_body != 1 || p.head_body <= 0 || p.head_body >= nb || p.rfoot_body <= 0 || p.rfoot_body >= nb || p.lfoot_body <= 0 || p.lfoot_body >= nb)
     ok = false;
   p.env_id_base = (unsigned)cfg->env_id_base; p.seed = cfg->seed;
   p.action_smoothing = cfg->action_smoothing; p.goal_height = cfg->task_params[LHW_TP_GOAL_HEIGHT];
-  p.task = walk ? TASK_WALK : TASK_STAND;
+  p.task = stepping ? TASK_STEP : (walk ? TASK_WALK : TASK_STAND);
+  if (stepping) {
+    p.box_geom0 = cfg->task_iparams[LHW_TI_STEP_BOX_GEOM0]; p.nbox = cfg->task_iparams[LHW_TI_STEP_NBOX];
+    p.floor_geom = cfg->task_iparams[LHW_TI_STEP_FLOOR_GEOM]; p.delay_frames = cfg->task_iparams[LHW_TI_STEP_DELAY_FRAMES];
+    p.nplans = nplans; p.target_radius = cfg->task_params[LHW_TP_STEP_RADIUS];
+    for (int a = 0; a < 3; a++) { m.track_off[3 + a] = cfg->task_params[LHW_TP_STEP_RSITE + a]; m.track_off[6 + a] = cfg->task_params[LHW_TP_STEP_LSITE + a]; }
+    ok = ok && (p.plans = to_dev<double>(h, cfg->task_params + LHW_TP_STEP_PLANS, (size_t)nplans * (1 + LHW_STEP_MAX_SEQ * 3)));
+  }
   std::vector<double> obs_noise(35, 0.0);
   if (stand) {
     p.init_noise = cfg->task_params[LHW_TP_H1_INIT_NOISE]; p.force_mag = cfg->task_params[LHW_TP_H1_FORCE_MAG];
@@ -1839,10 +2238,10 @@ int humanoid_create(HumanoidEnv** out, const std::vector<int32_t>& mi, const std
     for (int k = 0; k < 35; k++) obs_noise[k] = cfg->task_params[LHW_TP_H1_OBS_NOISE + k];
     const int32_t* ti = cfg->task_iparams;
     p.dynrand_interval = ti[LHW_TI_H1_DYNRAND_INTERVAL]; p.perturb_interval = ti[LHW_TI_H1_PERTURB_INTERVAL];
-    p.n_pbody = ti[LHW_TI_H1_N_PBODY]; p.pbody[0] = ti[LHW_TI_H1_PBODY]; p.pbody[1] = ti[LHW_TI_H1_PBODY + 1];
+    p.n_pbody = ti[LHW_TI_H1_N_PBODY]; p.pbody[0] = BID(LHW_TI_H1_PBODY); p.pbody[1] = BID(LHW_TI_H1_PBODY + 1);
     p.n_rand_dof = 10; p.n_rand_body = 11;
     for (int k = 0; k < 10; k++) p.rand_dof[k] = ti[LHW_TI_H1_RAND_DOF + k];
-    for (int k = 0; k < 11; k++) p.rand_body[k] = ti[LHW_TI_H1_RAND_BODY + k];
+    for (int k = 0; k < 11; k++) p.rand_body[k] = BID(LHW_TI_H1_RAND_BODY + k);
     if (p.n_pbody < 0 || p.n_pbody > 2) ok = false;
     for (int k = 0; k < p.n_pbody; k++) if (p.pbody[k] <= 0 || p.pbody[k] >= nb) ok = false;
     for (int k = 0; k < 10; k++) if (p.rand_dof[k] < 0 || p.rand_dof[k] >= nv) ok = false;
@@ -1863,12 +2262,26 @@ int humanoid_create(HumanoidEnv** out, const std::vector<int32_t>& mi, const std
     std::vector<double> one(PRM_D, 0.0), all((size_t)PRM_D * N);
     for (int d = 0; d < nv; d++) { one[P_DAMP + d] = DF(LHW_DF_DOF_DAMPING)[d]; one[P_FLOSS + d] = DF(LHW_DF_DOF_FRICTIONLOSS)[d]; }
     for (int b = 0; b < nb; b++) {
-      one[P_MASS + b] = DF(LHW_DF_BODY_MASS)[b];
-      for (int a = 0; a < 3; a++) one[P_IPOS + 3 * b + a] = DF(LHW_DF_BODY_IPOS)[3 * b + a];
+      one[P_MASS + b] = DF(LHW_DF_BODY_MASS)[bsrc[b]];
+      for (int a = 0; a < 3; a++) one[P_IPOS + 3 * b + a] = DF(LHW_DF_BODY_IPOS)[3 * bsrc[b] + a];
     }
     for (size_t n = 0; n < N; n++) std::copy(one.begin(), one.end(), all.begin() + n * PRM_D);
     h->st.prm = const_cast<double*>(to_dev<double>(h, all.data(), all.size()));
     ok = ok && h->st.prm != nullptr;
+  }
+  h->st.ter = nullptr;
+  if (ok && stepping) {
+    // before the first reset the boxes sit where the model file puts them (all at the pose of the first box) and the floor at 0
+    std::vector<double> one(TER_D, 0.0), all((size_t)TER_D * N);
+    const int g0 = p.box_geom0;
+    for (int k = 0; k < MAX_SEQ; k++) {
+      const double* gd = &geom_d[(size_t)GDS * (g0 + k)];
+      one[T_SEQ + 6 * k] = gd[GD_POS]; one[T_SEQ + 6 * k + 1] = gd[GD_POS + 1]; one[T_SEQ + 6 * k + 2] = gd[GD_POS + 2] + gd[GD_SIZE + 2];
+      one[T_SEQ + 6 * k + 3] = 0; one[T_SEQ + 6 * k + 4] = 1; one[T_SEQ + 6 * k + 5] = 0;
+    }
+    for (size_t n = 0; n < N; n++) std::copy(one.begin(), one.end(), all.begin() + n * TER_D);
+    h->st.ter = const_cast<double*>(to_dev<double>(h, all.data(), all.size()));
+    ok = ok && h->st.ter != nullptr;
   }
   void *rec = nullptr, *irec = nullptr, *eps = nullptr;
   ok = ok && hipMalloc(&rec, sizeof(double) * REC_D * N) == hipSuccess && hipMemset(rec, 0, sizeof(double) * REC_D * N) == hipSuccess &&
@@ -1879,7 +2292,7 @@ int humanoid_create(HumanoidEnv** out, const std::vector<int32_t>& mi, const std
   if (eps) h->dev_allocs.push_back(eps);
   h->st.rec = (double*)rec; h->st.irec = (int*)irec; h->st.ep_stats = (double*)eps; h->st.prof = nullptr;
   if (!ok) { humanoid_destroy(h); return lhw_fail(LHW_ERR_HIP, "humanoid_create: device allocation failed or bad body ids"); }
-  *obs_dim = walk ? 37 : 35; *act_dim = nu; *n_terms = walk ? 10 : 6;
+  *obs_dim = stepping ? 39 : (walk ? 37 : 35); *act_dim = nu; *n_terms = (walk && !stepping) ? 10 : 6;
   *out = h;
   return LHW_OK;
 }
@@ -1893,6 +2306,7 @@ void humanoid_destroy(HumanoidEnv* h) {
 #define LAUNCH(MODE, ...)                                                                                          \
   do {                                                                                                             \
     if (h->p.task == TASK_WALK) hipLaunchKernelGGL((humanoid_kernel<MODE, TASK_WALK>), dim3(h->p.n_envs), dim3(64), 0, s, h->m, h->p, h->st, __VA_ARGS__); \
+    else if (h->p.task == TASK_STEP) hipLaunchKernelGGL((humanoid_kernel<MODE, TASK_STEP>), dim3(h->p.n_envs), dim3(64), 0, s, h->m, h->p, h->st, __VA_ARGS__); \
     else hipLaunchKernelGGL((humanoid_kernel<MODE, TASK_STAND>), dim3(h->p.n_envs), dim3(64), 0, s, h->m, h->p, h->st, __VA_ARGS__);                     \
   } while (0)
 
@@ -1933,4 +2347,20 @@ int humanoid_profile(HumanoidEnv* h, int enable, long long* out16) {
   }
   return 0;
 }
-void humanoid_set_iteration(HumanoidEnv*, int64_t) {}  // the walking task has no curriculum input (stepping task does)
+// curriculum input of the stepping task (stair height, stepping_task.py:305); the other tasks ignore it
+void humanoid_set_iteration(HumanoidEnv* h, int64_t it) { h->p.iteration = (int)std::min<int64_t>(it, 1 << 30); }
+int humanoid_step_record(HumanoidEnv* h, double* seq, double* floor_z, int32_t* istate) {
+  if (!h->st.ter) return -1;
+  const size_t N = h->p.n_envs;
+  std::vector<double> ter(N * TER_D);
+  std::vector<int> irec(N * REC_I);
+  if (hipDeviceSynchronize() != hipSuccess) return -1;
+  if (hipMemcpy(ter.data(), h->st.ter, ter.size() * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  if (hipMemcpy(irec.data(), h->st.irec, irec.size() * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  for (size_t n = 0; n < N; n++) {
+    if (seq) std::copy(ter.begin() + n * TER_D + T_SEQ, ter.begin() + n * TER_D + T_SEQ + MAX_SEQ * 6, seq + n * MAX_SEQ * 6);
+    if (floor_z) floor_z[n] = ter[n * TER_D + T_FLOOR];
+    if (istate) { const int* r = &irec[n * REC_I]; int32_t* o = istate + n * 5; o[0] = r[RI_T1]; o[1] = r[RI_T2]; o[2] = r[RI_REACHED]; o[3] = r[RI_FRAMES]; o[4] = r[RI_NSEQ]; }
+  }
+  return 0;
+}

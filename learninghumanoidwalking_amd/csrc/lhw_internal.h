@@ -22,3 +22,4 @@ double* humanoid_ep_stats(HumanoidEnv* h);
 void humanoid_set_iteration(HumanoidEnv* h, int64_t it);
 int humanoid_occupancy();
 int humanoid_profile(HumanoidEnv* h, int enable, long long* out16);
+int humanoid_step_record(HumanoidEnv* h, double* seq, double* floor_z, int32_t* istate);

@@ -1,9 +1,10 @@
 """Host-side mirrors of the reference's environments (reference envs/__init__.py:13-19)."""
 from .cartpole import CartpoleSpec, make_cartpole  # noqa: F401
 from .h1 import H1Spec  # noqa: F401
+from .jvrc_step import JvrcStepSpec  # noqa: F401
 from .jvrc_walk import JvrcWalkSpec  # noqa: F401
 
-ENVIRONMENTS = {"cartpole": CartpoleSpec, "jvrc_walk": JvrcWalkSpec, "h1": H1Spec}
+ENVIRONMENTS = {"cartpole": CartpoleSpec, "jvrc_walk": JvrcWalkSpec, "jvrc_step": JvrcStepSpec, "h1": H1Spec}
 
 
 def single_env(name, **kw):

@@ -218,6 +218,10 @@ class OracleJvrcWalkEnv:
             action_penalty=0.025 * r_action(action, prev_action),
         )
 
+    def _done(self):
+        q = self.sim.qpos
+        return bool(q[2] < 0.6 or q[2] > 1.4 or self._self_collision())   # walking_task.py:184-192
+
     def step(self, action):
         sp, sim = self.spec, self.sim
         action = np.asarray(action, dtype=np.float32).astype(np.float64)   # policy outputs float32
@@ -233,8 +237,7 @@ class OracleJvrcWalkEnv:
             sim.step()
         self._task_step()
         terms = self._calc_reward(self.prev_torque, self.prev_action, act)
-        q = sim.qpos
-        done = bool(q[2] < 0.6 or q[2] > 1.4 or self._self_collision())   # walking_task.py:184-192
+        done = self._done()
         self.prev_action = act
         self.prev_torque = np.asarray(self._act_torque()).copy()
         obs = self.get_obs()

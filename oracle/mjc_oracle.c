@@ -548,6 +548,130 @@ static int capsuleCapsule(RawCon* c, const double* p1, const double* R1, const d
   return n;
 }
 
+/* Box-box: separating-axis test over the 15 candidate axes, then either a face contact (the incident face polygon is
+ * clipped against the side planes of the reference face; vertices at or below the reference face within `margin` become
+ * contacts, at most 4, deepest first) or a single edge-edge contact.  This is the classical SAT + clipping construction
+ * (as in ODE's dBoxBox); it is NOT a restatement of MuJoCo's mjc_BoxBox, whose source could not be consulted -- contact
+ * points of the two agree for face-face resting contacts (the case the stair terrain produces) and may differ in count and
+ * placement for edge cases.  The HIP kernel implements exactly this algorithm (csrc/lhw_humanoid.hip box_box). */
+static int boxBox(RawCon* out, const double* p1, const double* R1, const double* s1, const double* p2, const double* R2,
+                  const double* s2, double margin) {
+  double A[3][3], B[3][3], d[3] = {p2[0] - p1[0], p2[1] - p1[1], p2[2] - p1[2]};
+  for (int i = 0; i < 3; i++)
+    for (int k = 0; k < 3; k++) { A[i][k] = R1[3 * k + i]; B[i][k] = R2[3 * k + i]; } /* axis i = column i */
+  double R[3][3], AR[3][3], ta[3], tb[3];
+  for (int i = 0; i < 3; i++) {
+    ta[i] = dot3(d, A[i]); tb[i] = dot3(d, B[i]);
+    for (int j = 0; j < 3; j++) { R[i][j] = dot3(A[i], B[j]); AR[i][j] = fabs(R[i][j]) + 1e-12; }
+  }
+  /* face axes */
+  double best = -1e300; int code = -1; /* code 0..2: A face i, 3..5: B face j, 6..14: edge i*3+j */
+  for (int i = 0; i < 3; i++) {
+    double s = fabs(ta[i]) - (s1[i] + s2[0] * AR[i][0] + s2[1] * AR[i][1] + s2[2] * AR[i][2]);
+    if (s > margin) return 0;
+    if (s > best) { best = s; code = i; }
+  }
+  for (int j = 0; j < 3; j++) {
+    double s = fabs(tb[j]) - (s2[j] + s1[0] * AR[0][j] + s1[1] * AR[1][j] + s1[2] * AR[2][j]);
+    if (s > margin) return 0;
+    if (s > best - 1e-9) { if (s > best) best = s; code = 3 + j; } /* ties go to the faces of geom2 */
+  }
+  /* edge axes a_i x b_j */
+  double ebest = -1e300; int ecode = -1;
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) {
+      double len2 = 1.0 - R[i][j] * R[i][j];
+      if (len2 < 1e-12) continue;
+      int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+      double tl = ta[i2] * R[i1][j] - ta[i1] * R[i2][j];
+      double ra = s1[i1] * AR[i2][j] + s1[i2] * AR[i1][j], rb = s2[j1] * AR[i][j2] + s2[j2] * AR[i][j1];
+      double s = (fabs(tl) - ra - rb) / sqrt(len2);
+      if (s > margin) return 0;
+      if (s > ebest) { ebest = s; ecode = 6 + 3 * i + j; }
+    }
+  if (ecode >= 0 && ebest > best + 1e-6) {
+    /* ---- edge-edge */
+    int i = (ecode - 6) / 3, j = (ecode - 6) % 3;
+    double n[3];
+    cross3(n, A[i], B[j]);
+    normalize3(n);
+    if (dot3(n, d) < 0) { n[0] = -n[0]; n[1] = -n[1]; n[2] = -n[2]; }
+    double pa[3] = {p1[0], p1[1], p1[2]}, pb[3] = {p2[0], p2[1], p2[2]};
+    for (int k = 0; k < 3; k++) {
+      if (k != i) { double sg = dot3(n, A[k]) > 0 ? 1.0 : -1.0; for (int a = 0; a < 3; a++) pa[a] += sg * s1[k] * A[k][a]; }
+      if (k != j) { double sg = dot3(n, B[k]) > 0 ? -1.0 : 1.0; for (int a = 0; a < 3; a++) pb[a] += sg * s2[k] * B[k][a]; }
+    }
+    /* closest points of the lines pa + al*A[i], pb + be*B[j] */
+    double w[3] = {pa[0] - pb[0], pa[1] - pb[1], pa[2] - pb[2]};
+    double bq = R[i][j], dd = dot3(A[i], w), ee = dot3(B[j], w), den = 1.0 - bq * bq;
+    double al = (bq * ee - dd) / den, be = (ee - bq * dd) / den;
+    double qa[3], qb[3];
+    for (int a = 0; a < 3; a++) { qa[a] = pa[a] + al * A[i][a]; qb[a] = pb[a] + be * B[j][a]; }
+    out[0].dist = ebest;
+    for (int a = 0; a < 3; a++) { out[0].frame[a] = n[a]; out[0].frame[3 + a] = 0; out[0].pos[a] = 0.5 * (qa[a] + qb[a]); }
+    return 1;
+  }
+  /* ---- face contact: reference box r (owner of the axis), incident box c */
+  int refB = code >= 3, ax = refB ? code - 3 : code;
+  const double *pr = refB ? p2 : p1, *pc = refB ? p1 : p2, *sr = refB ? s2 : s1, *sc = refB ? s1 : s2;
+  double (*Ar)[3] = refB ? B : A, (*Ac)[3] = refB ? A : B;
+  double n[3] = {Ar[ax][0], Ar[ax][1], Ar[ax][2]};           /* geom1 -> geom2 */
+  if (dot3(n, d) < 0) { n[0] = -n[0]; n[1] = -n[1]; n[2] = -n[2]; }
+  double nr[3] = {refB ? -n[0] : n[0], refB ? -n[1] : n[1], refB ? -n[2] : n[2]}; /* outward normal of the reference face */
+  double fc[3];
+  for (int a = 0; a < 3; a++) fc[a] = pr[a] + nr[a] * sr[ax];
+  /* incident face: most anti-parallel to nr */
+  int kc = 0; double bestdot = -1;
+  for (int k = 0; k < 3; k++) { double v = fabs(dot3(nr, Ac[k])); if (v > bestdot) { bestdot = v; kc = k; } }
+  double sgn = dot3(nr, Ac[kc]) > 0 ? -1.0 : 1.0;
+  int ku = (kc + 1) % 3, kv = (kc + 2) % 3;
+  double poly[8][3], tmp[8][3];
+  int np = 4;
+  for (int q = 0; q < 4; q++) {
+    double su = (q == 0 || q == 3) ? 1.0 : -1.0, sv = (q < 2) ? 1.0 : -1.0;
+    for (int a = 0; a < 3; a++) poly[q][a] = pc[a] + sgn * sc[kc] * Ac[kc][a] + su * sc[ku] * Ac[ku][a] + sv * sc[kv] * Ac[kv][a];
+  }
+  int ru = (ax + 1) % 3, rv = (ax + 2) % 3;
+  for (int pl = 0; pl < 4 && np > 0; pl++) { /* Sutherland-Hodgman against sign*(x-pr).axis <= half */
+    const double* axis = (pl < 2) ? Ar[ru] : Ar[rv];
+    double half = (pl < 2) ? sr[ru] : sr[rv], sg = (pl & 1) ? -1.0 : 1.0;
+    int nq = 0;
+    for (int q = 0; q < np; q++) {
+      const double *x0 = poly[q], *x1 = poly[(q + 1) % np];
+      double w0[3] = {x0[0] - pr[0], x0[1] - pr[1], x0[2] - pr[2]}, w1[3] = {x1[0] - pr[0], x1[1] - pr[1], x1[2] - pr[2]};
+      double e0 = sg * dot3(w0, axis) - half, e1 = sg * dot3(w1, axis) - half;
+      if (e0 <= 0) { if (nq < 8) { memcpy(tmp[nq], x0, 3 * sizeof(double)); nq++; } }
+      if ((e0 <= 0) != (e1 <= 0)) {
+        double tt = e0 / (e0 - e1);
+        if (nq < 8) { for (int a = 0; a < 3; a++) tmp[nq][a] = x0[a] + tt * (x1[a] - x0[a]); nq++; }
+      }
+    }
+    np = nq;
+    memcpy(poly, tmp, sizeof(double) * 3 * np);
+  }
+  /* depths; keep at most 4, deepest first (stable) */
+  double dep[8]; int idx[8], cnt = 0;
+  for (int q = 0; q < np; q++) {
+    double w0[3] = {poly[q][0] - fc[0], poly[q][1] - fc[1], poly[q][2] - fc[2]};
+    double dq = dot3(w0, nr);
+    if (dq <= margin) { dep[cnt] = dq; idx[cnt] = q; cnt++; }
+  }
+  for (int a = 1; a < cnt; a++) { /* insertion sort by depth */
+    double dv = dep[a]; int iv = idx[a], b = a - 1;
+    while (b >= 0 && dep[b] > dv) { dep[b + 1] = dep[b]; idx[b + 1] = idx[b]; b--; }
+    dep[b + 1] = dv; idx[b + 1] = iv;
+  }
+  if (cnt > 4) cnt = 4;
+  for (int q = 0; q < cnt; q++) {
+    out[q].dist = dep[q];
+    for (int a = 0; a < 3; a++) {
+      out[q].frame[a] = n[a]; out[q].frame[3 + a] = 0;
+      out[q].pos[a] = poly[idx[q]][a] - nr[a] * dep[q] * 0.5;
+    }
+  }
+  return cnt;
+}
+
 /* mj_collision + mj_setContact parameter mixing */
 static void collision(OData* d) {
   const OModel* m = &d->m;
@@ -571,6 +695,7 @@ static void collision(OData* d) {
     else if (t1 == GEOM_SPHERE && t2 == GEOM_SPHERE) n = sphereSphereRaw(rc, p1, s1[0], p2, s2[0], margin);
     else if (t1 == GEOM_SPHERE && t2 == GEOM_CAPSULE) n = sphereCapsule(rc, p1, s1[0], p2, R2, s2, margin);
     else if (t1 == GEOM_CAPSULE && t2 == GEOM_CAPSULE) n = capsuleCapsule(rc, p1, R1, s1, p2, R2, s2, margin);
+    else if (t1 == GEOM_BOX && t2 == GEOM_BOX) n = boxBox(rc, p1, R1, s1, p2, R2, s2, margin);
     for (int i = 0; i < n; i++) {
       if (d->ncon >= MAXCON) { d->warning_contactfull = 1; return; }
       OContact* c = d->contact + d->ncon++;

@@ -81,9 +81,9 @@ def test_unsupported_features_raise():
         mjcf.compile_string(base % ("ball", "sphere"))
     with pytest.raises(mjcf.MjcfError):
         mjcf.compile_string(base % ("hinge", "mesh"))
-    with pytest.raises(mjcf.MjcfError):   # box-box has no narrow phase yet
+    with pytest.raises(mjcf.MjcfError):   # box-capsule has no narrow phase
         mjcf.compile_string("<mujoco><worldbody><body><freejoint/><geom type='box' size='.1 .1 .1'/></body>"
-                            "<body pos='1 0 0'><freejoint/><geom type='box' size='.1 .1 .1'/></body></worldbody></mujoco>")
+                            "<body pos='1 0 0'><freejoint/><geom type='capsule' size='.1 .1'/></body></worldbody></mujoco>")
 
 
 def test_euler_and_fromto_orientation():
