@@ -10,4 +10,5 @@ ENVIRONMENTS = {"cartpole": CartpoleSpec, "jvrc_walk": JvrcWalkSpec, "jvrc_step"
 def single_env(name, **kw):
     """The reference's ``Env(path_to_yaml)`` single-env object for ``name`` (GPU required)."""
     from . import adapters
-    return {"cartpole": adapters.CartpoleEnv, "jvrc_walk": adapters.JvrcWalkEnv, "h1": adapters.H1Env}[name](**kw)
+    return {"cartpole": adapters.CartpoleEnv, "jvrc_walk": adapters.JvrcWalkEnv, "jvrc_step": adapters.JvrcStepEnv,
+            "h1": adapters.H1Env}[name](**kw)

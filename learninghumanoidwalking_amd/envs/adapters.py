@@ -11,6 +11,7 @@ import torch
 
 from .cartpole import CartpoleSpec
 from .h1 import H1Spec
+from .jvrc_step import JvrcStepSpec
 from .jvrc_walk import JvrcWalkSpec
 
 
@@ -67,6 +68,21 @@ class JvrcWalkEnv(_SingleEnv):
         super().__init__(spec, seed=seed, device=device)
         mo, ma, clock = spec.mirror_inds()
         self.robot.mirrored_obs, self.robot.mirrored_acts, self.robot.clock_inds = mo, ma, clock
+
+
+class JvrcStepEnv(_SingleEnv):
+    TERMS = ["foot_frc_score", "foot_vel_score", "orient_cost", "height_error", "step_reward", "upper_body_reward"]  # stepping_task.py:109-122
+
+    def __init__(self, path_to_yaml=None, seed=0, device=0):
+        spec = JvrcStepSpec(yaml_path=path_to_yaml) if path_to_yaml else JvrcStepSpec()
+        super().__init__(spec, seed=seed, device=device)
+        mo, ma, clock = spec.mirror_inds()
+        self.robot.mirrored_obs, self.robot.mirrored_acts, self.robot.clock_inds = mo, ma, clock
+        self.robot.iteration_count = 0
+
+    def reset(self):
+        self._env.set_iteration(int(min(self.robot.iteration_count, 1 << 30)))   # rollout_worker.py:95 curriculum input
+        return super().reset()
 
 
 class H1Env(_SingleEnv):

@@ -50,15 +50,24 @@ class OracleJvrcStepEnv(OracleJvrcWalkEnv):
             m.geom_size[g] = (0.15, 1.0, 0.1)     # compile-time size only matters for the total mass, already computed)
         self.sim.repack()
 
+    # ---- random draws of one SteppingTask.reset, in the order the reference consumes np.random (stepping_task.py:278-311,
+    # 140-165); every draw is made even where the reference would skip it: counter-based slots make that harmless
+    def _draws(self, c):
+        s, e = self.seed, self.env_id
+        R = rng.STREAM_RESET
+        return dict(phase_half=rng.randint(s, e, R, c, 0, 2) != 0, mode_u=rng.u01(s, e, R, c, 1),
+                    choice=rng.randint(s, e, R, c, 2, 2), plan=rng.randint(s, e, R, c, 2, len(self.spec.plans)),
+                    first_u=rng.uniform(s, e, R, c, 3, 0.095, 0.105), cflat=2 + rng.randint(s, e, R, c, 4, 2))
+
     # ---- SteppingTask.generate_step_sequence (stepping_task.py:140-182)
-    def _generate(self, c):
-        s, e, sp = self.seed, self.env_id, self.spec
+    def _generate(self, dr):
+        sp = self.spec
         d = dict(step_size=0.3, step_gap=0.15, step_height=0.0, num_steps=20)
         if self.mode == CURVED:
-            plan = sp.plans[rng.randint(s, e, rng.STREAM_RESET, c, 2, len(sp.plans))]
+            plan = sp.plans[dr["plan"]]
             return [np.array([p[0], p[1], 0.0, p[2]]) for p in plan]
         if self.mode == LATERAL:
-            sgn = -1.0 if rng.randint(s, e, rng.STREAM_RESET, c, 2, 2) == 0 else 1.0
+            sgn = -1.0 if dr["choice"] == 0 else 1.0
             seq, y = [], 0.0
             for i in range(1, 20):
                 if i % 2:
@@ -73,15 +82,15 @@ class OracleJvrcStepEnv(OracleJvrcWalkEnv):
             d["step_size"] = -0.1
         elif self.mode == FORWARD:
             h = np.clip((self.iteration_count - 3000) / 8000, 0, 1) * 0.1
-            d["step_height"] = -h if rng.randint(s, e, rng.STREAM_RESET, c, 2, 2) == 0 else h
-        u = rng.uniform(s, e, rng.STREAM_RESET, c, 3, 0.095, 0.105)
+            d["step_height"] = -h if dr["choice"] == 0 else h
+        u = dr["first_u"]
         if self.phase == 0.5 * self.period:
             first, y = np.array([0.0, -1 * u, 0.0, 0.0]), -d["step_gap"]
         else:
             first, y = np.array([0.0, 1 * u, 0.0, 0.0]), d["step_gap"]
         seq = [first]
         x, z = 0.0, 0.0
-        cflat = 2 + rng.randint(s, e, rng.STREAM_RESET, c, 4, 2)       # np.random.randint(2, 4)
+        cflat = dr["cflat"]                                           # np.random.randint(2, 4)
         for i in range(1, d["num_steps"] - 1):
             x += d["step_size"]
             y *= -1
@@ -91,15 +100,16 @@ class OracleJvrcStepEnv(OracleJvrcWalkEnv):
         seq.append(np.array([x + d["step_size"], -y, z, 0.0]))
         return seq
 
-    def _task_reset(self, c):
-        s, e, sim = self.seed, self.env_id, self.sim
+    def _task_reset(self, c, draws=None):
+        sim = self.sim
+        dr = draws if draws is not None else self._draws(c)
         self.goal = np.zeros(8)
         self.target_reached, self.target_reached_frames = False, 0
         self.t1 = self.t2 = 0
-        self.phase = 0 if rng.randint(s, e, rng.STREAM_RESET, c, 0, 2) == 0 else int(self.period / 2)
-        u = rng.u01(s, e, rng.STREAM_RESET, c, 1)
+        self.phase = int(self.period / 2) if dr["phase_half"] else 0
+        u = dr["mode_u"]
         self.mode = CURVED if u < 0.15 else (STANDING if u < 0.2 else (BACKWARD if u < 0.4 else (LATERAL if u < 0.7 else FORWARD)))
-        seq = self._generate(c)
+        seq = self._generate(dr)
         # transform_sequence (stepping_task.py:125-138) on the stale body frames
         mid = (sim.xpos[self.lfoot] + sim.xpos[self.rfoot]) / 2
         yaw = quat2euler_sxyz(sim.xquat[self.root])[2]

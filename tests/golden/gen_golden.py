@@ -195,13 +195,180 @@ def gen_misc():
              mir_obs=_get_symmetry_matrix(JVRC_MIR_OBS), mir_act=_get_symmetry_matrix(JVRC_MIR_ACT))
 
 
+def gen_stepping():
+    """Executes the reference's SteppingTask (tasks/stepping_task.py) against a scripted fake RobotInterface: reset for
+    every walk mode / initial phase / curriculum iteration with the np.random draws forced to listed values, then a run
+    of step() / calc_reward() / done() calls on scripted kinematic states.  Stored: inputs, forced draws and every output
+    the oracle env (oracle/env_jvrc_step.py) must reproduce."""
+    import random as pyrandom
+    sys.path.insert(0, OUT)
+    import _tf3_min
+    _tf3_min.install(sys.modules)
+    from tasks import stepping_task as st
+    cwd = os.getcwd()
+
+    class Obj:
+        def __init__(self, **k):
+            self.__dict__.update(k)
+
+    class FakeModel:
+        def __init__(self):
+            self.bodies = {f"box{i + 1:02d}": Obj(pos=np.zeros(3), quat=np.zeros(4)) for i in range(20)}
+            self.bodies["floor"] = Obj(pos=np.zeros(3), quat=np.array([1.0, 0, 0, 0]))
+            self.geoms = {f"box{i + 1:02d}": Obj(size=np.array([1.0, 1.0, 0.1]), rgba=np.zeros(4)) for i in range(20)}
+
+        def body(self, n):
+            return self.bodies[n]
+
+        def geom(self, n):
+            return self.geoms[n]
+
+    class FakeClient:
+        def __init__(self):
+            self.model = FakeModel()
+            self.k = {}
+
+        def get_robot_mass(self):
+            return 16062.0
+
+        def get_object_xpos_by_name(self, name, typ):
+            return self.k["xpos"][name]
+
+        def get_object_xquat_by_name(self, name, typ):
+            return self.k["xquat"][name]
+
+        def get_lfoot_body_pos(self):
+            return self.k["xpos"]["lfoot"].copy()
+
+        def get_rfoot_body_pos(self):
+            return self.k["xpos"]["rfoot"].copy()
+
+        def get_lfoot_body_vel(self, frame=0):
+            return [self.k["lvel"], np.zeros(3)]
+
+        def get_rfoot_body_vel(self, frame=0):
+            return [self.k["rvel"], np.zeros(3)]
+
+        def get_lfoot_grf(self):
+            return self.k["lgrf"]
+
+        def get_rfoot_grf(self):
+            return self.k["rgrf"]
+
+        def check_rfoot_floor_collision(self):
+            return len(self.k["rcon"]) > 0
+
+        def check_lfoot_floor_collision(self):
+            return len(self.k["lcon"]) > 0
+
+        def get_rfoot_floor_contacts(self):
+            return [(i, Obj(pos=np.array(p))) for i, p in enumerate(self.k["rcon"])]
+
+        def get_lfoot_floor_contacts(self):
+            return [(i, Obj(pos=np.array(p))) for i, p in enumerate(self.k["lcon"])]
+
+        def check_self_collisions(self):
+            return self.k["selfcol"]
+
+    rs = np.random.default_rng(42)
+    cases = []
+    real = dict(choice=np.random.choice, uniform=np.random.uniform, randint=np.random.randint, pychoice=pyrandom.choice)
+    MODES = [st.WalkModes.CURVED, st.WalkModes.STANDING, st.WalkModes.BACKWARD, st.WalkModes.LATERAL, st.WalkModes.FORWARD]
+    out = {}
+    n = 0
+    for mode_idx in range(5):
+        for phase_half in (False, True):
+            for itr in (0, 7000, 20000):
+                if mode_idx != 4 and itr != 0:
+                    continue
+                client = FakeClient()
+                os.chdir(REF)          # the constructor opens "utils/footstep_plans.txt" relative to the cwd
+                try:
+                    task = st.SteppingTask(client=client, dt=0.025, neutral_foot_orient=np.array([1, 0, 0, 0]), root_body="root",
+                                           lfoot_body="lfoot", rfoot_body="rfoot", head_body="head")
+                finally:
+                    os.chdir(cwd)
+                task._goal_height_ref, task._total_duration, task._swing_duration, task._stance_duration = 0.80, 1.1, 0.75, 0.35
+                yaw = rs.uniform(-1, 1)
+                rootq = _tf3_min.euler2quat(rs.uniform(-0.1, 0.1), rs.uniform(-0.1, 0.1), yaw)
+                client.k = dict(xpos=dict(root=np.array([rs.uniform(-1, 1), rs.uniform(-1, 1), 0.8]), head=np.zeros(3),
+                                          lfoot=np.array([rs.uniform(-1, 1), rs.uniform(-1, 1), 0.1]),
+                                          rfoot=np.array([rs.uniform(-1, 1), rs.uniform(-1, 1), 0.1])),
+                                xquat=dict(root=rootq))
+                choice, first_u, cflat, plan_idx = int(rs.integers(0, 2)), float(rs.uniform(0.095, 0.105)), int(rs.integers(2, 4)), int(rs.integers(0, len(task.plans)))
+                queue = []
+
+                def fake_choice(a, p=None, _q=queue):
+                    _q.append("c")
+                    k = len([x for x in _q if x == "c"])
+                    if k == 1:                       # initial phase: np.random.choice([0, period / 2])
+                        return a[1] if phase_half else a[0]
+                    if k == 2:                       # walk mode
+                        return MODES[mode_idx]
+                    return a[choice]                 # LATERAL side / FORWARD stair direction
+                np.random.choice = fake_choice
+                np.random.uniform = lambda lo, hi, *_a: first_u
+                np.random.randint = lambda lo, hi=None, *_a: cflat
+                pyrandom.choice = lambda seq: seq[plan_idx]
+                try:
+                    task.reset(iter_count=itr)
+                finally:
+                    np.random.choice, np.random.uniform, np.random.randint, pyrandom.choice = real["choice"], real["uniform"], real["randint"], real["pychoice"]
+                pre = f"r{n}_"
+                out[pre + "in"] = np.concatenate([[mode_idx, int(phase_half), itr, choice, first_u, cflat, plan_idx],
+                                                  client.k["xpos"]["root"], client.k["xpos"]["lfoot"], client.k["xpos"]["rfoot"], rootq])
+                out[pre + "plan"] = np.array(task.plans[plan_idx])
+                out[pre + "sequence"] = np.array(task.sequence)
+                out[pre + "state"] = np.array([task._phase, task._period, task.t1, task.t2, task.delay_frames, task.target_radius])
+                out[pre + "boxpos"] = np.array([client.model.body(f"box{i + 1:02d}").pos for i in range(20)])
+                out[pre + "boxquat"] = np.array([client.model.body(f"box{i + 1:02d}").quat for i in range(20)])
+                out[pre + "floor"] = client.model.body("floor").pos.copy()
+                # ---- a run of control steps on scripted kinematics: feet hop onto successive targets
+                T = 110
+                log_goal, log_rew, log_done, log_state, log_kin = [], [], [], [], []
+                for t in range(T):
+                    tgt = np.array(task.sequence[task.t1][0:3])
+                    near = (t // 36) % 3 != 2         # dwell on the target long enough to advance it (30 frames), then wander off
+                    lpos = tgt + rs.normal(size=3) * (0.05 if near else 0.5)
+                    rpos = tgt + rs.normal(size=3) * 0.4
+                    rq = _tf3_min.euler2quat(rs.uniform(-0.2, 0.2), rs.uniform(-0.2, 0.2), rs.uniform(-3, 3))
+                    rootp = np.array([tgt[0] + rs.normal() * 0.3, tgt[1] + rs.normal() * 0.3, 0.8 + rs.normal() * 0.1])
+                    if t % 17 == 16:
+                        rootp[2] = min(lpos[2], rpos[2]) + 0.55          # triggers the height termination
+                    rcon = [[0, 0, rs.uniform(-0.02, 0.1)]] if t % 3 else []
+                    lcon = [[0, 0, rs.uniform(-0.02, 0.1)], [0, 0, rs.uniform(-0.02, 0.1)]] if t % 4 else []
+                    client.k = dict(xpos=dict(root=rootp, head=rootp + np.array([rs.normal() * 0.05, rs.normal() * 0.05, 0.5]), lfoot=lpos, rfoot=rpos,
+                                              lf_force=lpos, rf_force=rpos),
+                                    xquat=dict(root=rq, lf_force=rq, rf_force=rq), lvel=rs.normal(size=3) * 0.2, rvel=rs.normal(size=3) * 0.2,
+                                    lgrf=float(rs.uniform(0, 600)), rgrf=float(rs.uniform(0, 600)), rcon=rcon, lcon=lcon, selfcol=bool(t % 29 == 28))
+                    task.step()
+                    rew = task.calc_reward(None, None, None)
+                    log_goal.append(np.concatenate([task._goal_steps_x, task._goal_steps_y, task._goal_steps_z, task._goal_steps_theta]))
+                    log_rew.append([rew[k] for k in ("foot_frc_score", "foot_vel_score", "orient_cost", "height_error", "step_reward", "upper_body_reward")])
+                    log_done.append(int(task.done()))
+                    log_state.append([task._phase, task.t1, task.t2, int(task.target_reached), task.target_reached_frames])
+                    log_kin.append(np.concatenate([rootp, client.k["xpos"]["head"], lpos, rpos, rq, client.k["lvel"], client.k["rvel"],
+                                                   [client.k["lgrf"], client.k["rgrf"], float(client.k["selfcol"]),
+                                                    min([c[2] for c in rcon + lcon]) if (rcon or lcon) else 0.0, float(bool(rcon or lcon))]]))
+                out[pre + "goal"], out[pre + "rew"], out[pre + "done"] = np.array(log_goal), np.array(log_rew), np.array(log_done)
+                out[pre + "tstate"], out[pre + "kin"] = np.array(log_state), np.array(log_kin)
+                n += 1
+    out["n"] = n
+    np.savez_compressed(os.path.join(OUT, "stepping.npz"), **out)
+    print("stepping golden:", n, "cases")
+
+
 if __name__ == "__main__":
     sys.path.insert(0, REF)
     _stub_modules()
+    if len(sys.argv) > 1 and sys.argv[1] == "stepping":     # regenerate only the stepping-task fixture
+        gen_stepping()
+        sys.exit(0)
     gen_gae()
     gen_clock()
     gen_misc()
     gen_ppo("h64_mirror", 64, 96, True, False, 2, 11)
     gen_ppo("h64_learnstd", 64, 70, False, True, 2, 12)
     gen_ppo("h256_mirror", 256, 128, True, False, 1, 13)
+    gen_stepping()
     print("golden fixtures written to", OUT)
