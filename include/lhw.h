@@ -58,7 +58,9 @@ typedef enum {
   LHW_TASK_CARTPOLE = 0, /* reference envs/cartpole/cartpole_env.py */
   LHW_TASK_JVRC_WALK = 1, /* reference envs/jvrc/jvrc_walk.py + tasks/walking_task.py */
   LHW_TASK_H1_STAND = 2,  /* reference envs/h1/h1_env.py + tasks/standing_task.py (+ domain_randomization.py) */
-  LHW_TASK_JVRC_STEP = 3  /* reference envs/jvrc/jvrc_step.py + tasks/stepping_task.py (box terrain, footstep targets) */
+  LHW_TASK_JVRC_STEP = 3, /* reference envs/jvrc/jvrc_step.py + tasks/stepping_task.py (box terrain, footstep targets) */
+  LHW_TASK_H1_WALK = 4    /* reference envs/h1/h1_walk.py: H1 robot (noise, randomisation as H1_STAND) + tasks/walking_task.py;
+                             task_params / task_iparams as LHW_TASK_H1_STAND, plus clock_lut / period */
 } LhwTask;
 
 /* done flags written by lhw_env_step */

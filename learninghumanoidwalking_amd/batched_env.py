@@ -14,7 +14,7 @@ import torch
 from . import _lib
 from .model import Model
 
-TASK_CARTPOLE, TASK_JVRC_WALK, TASK_H1_STAND, TASK_JVRC_STEP = 0, 1, 2, 3
+TASK_CARTPOLE, TASK_JVRC_WALK, TASK_H1_STAND, TASK_JVRC_STEP, TASK_H1_WALK = 0, 1, 2, 3, 4
 DONE_TERMINATED, DONE_TRUNCATED = 1, 2
 
 

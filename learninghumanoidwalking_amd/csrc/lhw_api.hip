@@ -154,7 +154,7 @@ extern "C" int lhw_env_create(const int32_t* model_i, int64_t n_model_i, const d
   e->task = cfg->task; e->n_envs = cfg->n_envs; e->device = cfg->device;
   e->nq = model_i[LHW_IH_NQ]; e->nv = model_i[LHW_IH_NV]; e->nu = model_i[LHW_IH_NU];
   if (cfg->task == LHW_TASK_CARTPOLE) rc = create_cartpole(e, cfg);
-  else if (cfg->task == LHW_TASK_JVRC_WALK || cfg->task == LHW_TASK_H1_STAND || cfg->task == LHW_TASK_JVRC_STEP) rc = humanoid_create(&e->hum, e->mi, e->md, cfg, &e->obs_dim, &e->act_dim, &e->n_terms);
+  else if (cfg->task == LHW_TASK_JVRC_WALK || cfg->task == LHW_TASK_H1_STAND || cfg->task == LHW_TASK_JVRC_STEP || cfg->task == LHW_TASK_H1_WALK) rc = humanoid_create(&e->hum, e->mi, e->md, cfg, &e->obs_dim, &e->act_dim, &e->n_terms);
   else rc = lhw_fail(LHW_ERR_ARG, "unknown task %d", cfg->task);
   if (rc == LHW_OK) {
     if (hipMalloc(&e->stage_q, sizeof(double) * (size_t)e->n_envs * e->nq) != hipSuccess ||

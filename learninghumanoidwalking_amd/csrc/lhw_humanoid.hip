@@ -90,7 +90,7 @@ static_assert(R_EPRET < REC_D, "record too small");
 #define P_XFRC (P_IPOS + NB * 3)  // xfrc_applied of up to two perturbed bodies: force3 torque3 each
 #define PRM_D 128
 static_assert(P_XFRC + 12 <= PRM_D, "parameter record too small");
-enum { TASK_WALK = 1, TASK_STAND = 2, TASK_STEP = 3 };
+enum { TASK_WALK = 1, TASK_STAND = 2, TASK_STEP = 3, TASK_H1WALK = 4 };
 enum { LHW_STREAM_OBS = 4 };
 
 // Model constants, packed host-side into one array-of-structs table per "lane role" (body, joint, dof, geom, pair,
@@ -444,7 +444,7 @@ __device__ __forceinline__ double row_dot(const double* row, const double* v, in
 // ------------------------------------------------------------------------------------------------ forward dynamics phases
 // mj_kinematics with rotation matrices: each lane precombines its body's local transform R_loc = R_body * R_joint(q)
 // (off the serial chain), so a tree level costs one 3x3 product and four matrix-vector products.
-template <class L>
+template <bool STEPT, class L>
 __device__ void fwd_kinematics(const HModel& m, L& S, int lane) {
   if (lane == 0) {
     S.xpos[0] = S.xpos[1] = S.xpos[2] = 0;
@@ -486,7 +486,7 @@ __device__ void fwd_kinematics(const HModel& m, L& S, int lane) {
       if (jt == JT_FREE) {
         double q[4] = {S.qpos[qa + 3], S.qpos[qa + 4], S.qpos[qa + 5], S.qpos[qa + 6]};
         normalize4(q);
-        for (int k = 0; k < 4; k++) { S.qpos[qa + 3 + k] = q[k]; S.rootquat[k] = q[k]; }
+        for (int k = 0; k < 4; k++) { S.qpos[qa + 3 + k] = q[k]; if (STEPT) S.rootquat[k] = q[k]; }
         quat2mat(R, q);
         for (int k = 0; k < 3; k++) { xp[k] = S.qpos[qa + k]; S.U[U_XANCHOR + 3 * ja + k] = xp[k]; S.U[U_XAXIS + 3 * ja + k] = kd[BD_JAXIS + k]; }
       } else {
@@ -534,15 +534,15 @@ __device__ void fwd_kinematics(const HModel& m, L& S, int lane) {
     ci[5] = Ri[3] * I0 * Ri[6] + Ri[4] * I1 * Ri[7] + Ri[5] * I2 * Ri[8];
   }
   if (lane < 9) S.rootmat[lane] = S.U[U_XMAT + 9 * 1 + lane];
-#pragma unroll
-  for (int t = 0; t < 3; t++)
-    if (lane == 16 + t) {  // tracked points: body origin + R * local offset
-      const int tb = m.track_body[t];
-      const double off[3] = {m.track_off[3 * t], m.track_off[3 * t + 1], m.track_off[3 * t + 2]};
-      double w[3];
-      mat_vec(w, &S.U[U_XMAT + 9 * tb], off);
-      for (int k = 0; k < 3; k++) S.spos[3 * t + k] = S.xpos[3 * tb + k] + w[k];
-    }
+  if (STEPT && lane < 3) {  // tracked points (foot force sites): body origin + R * local offset, lane = point
+    const int tb = lane == 0 ? m.track_body[0] : (lane == 1 ? m.track_body[1] : m.track_body[2]);
+    const double off[3] = {lane == 0 ? m.track_off[0] : (lane == 1 ? m.track_off[3] : m.track_off[6]),
+                           lane == 0 ? m.track_off[1] : (lane == 1 ? m.track_off[4] : m.track_off[7]),
+                           lane == 0 ? m.track_off[2] : (lane == 1 ? m.track_off[5] : m.track_off[8])};
+    double w[3];
+    mat_vec(w, &S.U[U_XMAT + 9 * tb], off);
+    for (int k = 0; k < 3; k++) S.spos[3 * lane + k] = S.xpos[3 * tb + k] + w[k];
+  }
 }
 
 // subtree com of the (single) dynamic tree rooted at body 1, cinert, cdof  (mj_comPos)
@@ -702,10 +702,23 @@ __device__ __forceinline__ void col_sphere_sphere(ConSink<L>& k, const double* p
 // dBoxBox), NOT a restatement of MuJoCo's mjc_BoxBox, whose source could not be consulted: the two agree for face-face
 // resting contacts (what the stair terrain produces) and may differ in contact count / placement in edge cases
 // (DESIGN.md section 6).  The CPU checker used by the tests implements the same statements in the same order.
+struct BoxRec {  // contacts of one box-box pair, kept between the counting and the writing pass of fwd_collision
+  double dist[4], pos[12], n[3];
+  int cnt;
+  __device__ __forceinline__ void emit(double d_, const double* pos_, const double* n_, const double*) {
+    if (cnt < 4) {
+      dist[cnt] = d_;
+      for (int a = 0; a < 3; a++) { pos[3 * cnt + a] = pos_[a]; n[a] = n_[a]; }
+      cnt++;
+    }
+  }
+};
 template <class L>
-__device__ __noinline__ void col_box_box(ConSink<L>& k, const double* p1, const double* R1, const double* s1, const double* p2,
-                                         const double* R2, const double* s2, double margin) {
+__device__ __noinline__ void col_box_box(BoxRec& k, const HModel& m, const L& S, int g1, int g2, double margin) {
   const double zero[3] = {0, 0, 0};
+  double p1[3], p2[3], R1[9], R2[9], s1[3], s2[3];
+  for (int a = 0; a < 3; a++) { p1[a] = S.U[U_GPOS + 3 * g1 + a]; p2[a] = S.U[U_GPOS + 3 * g2 + a]; s1[a] = m.geom_d[GDS * (g1) + GD_SIZE + a]; s2[a] = m.geom_d[GDS * (g2) + GD_SIZE + a]; }
+  for (int a = 0; a < 9; a++) { R1[a] = S.U[U_GMAT + 9 * g1 + a]; R2[a] = S.U[U_GMAT + 9 * g2 + a]; }
   double A[3][3], B[3][3], d[3] = {p2[0] - p1[0], p2[1] - p1[1], p2[2] - p1[2]};
   for (int i = 0; i < 3; i++)
     for (int c = 0; c < 3; c++) { A[i][c] = R1[3 * c + i]; B[i][c] = R2[3 * c + i]; }
@@ -819,7 +832,7 @@ __device__ __noinline__ void col_box_box(ConSink<L>& k, const double* p1, const 
   }
 }
 
-template <bool BOXBOX, class L>
+template <class L>
 __device__ void collide_pair(ConSink<L>& k, const HModel& m, const L& S, int g1, int g2, double margin) {
   const double zero[3] = {0, 0, 0};
   const int t1 = m.geom_i[GIS * (g1) + GI_TYPE], t2 = m.geom_i[GIS * (g2) + GI_TYPE];
@@ -845,8 +858,6 @@ __device__ void collide_pair(ConSink<L>& k, const HModel& m, const L& S, int g1,
       for (int a = 0; a < 3; a++) pos[a] = corner[a] + p2[a] - nn[a] * (dist + ld) * 0.5;
       k.emit(dist + ld, pos, nn, zero);
     }
-  } else if (BOXBOX && t1 == G_BOX && t2 == G_BOX) {
-    if constexpr (BOXBOX) col_box_box(k, p1, R1, s1, p2, R2, s2, margin);  // only the stepping task's kernels carry this code
   } else if (t1 == G_SPHERE && t2 == G_SPHERE) col_sphere_sphere(k, p1, s1[0], p2, s2[0], margin);
   else if (t1 == G_SPHERE && t2 == G_CAPSULE) {
     double ax[3] = {R2[2], R2[5], R2[8]}, vec[3] = {p1[0] - p2[0], p1[1] - p2[1], p1[2] - p2[2]};
@@ -902,7 +913,7 @@ __device__ void fwd_collision(const HModel& m, const HParams& p, L& S, int lane,
     mat_vec(t, Rb, gp);
     mat_mul(R, Rb, Rl);
     double wp[3] = {S.xpos[3 * b] + t[0], S.xpos[3 * b + 1] + t[1], S.xpos[3 * b + 2] + t[2]};
-    if (ter) {  // stepping task: the 20 boxes sit under the target steps, the floor is lowered in FORWARD mode
+    if (BOXBOX && ter) {  // stepping task: the 20 boxes sit under the target steps, the floor is lowered in FORWARD mode
       const int kb = g - p.box_geom0;
       if (kb >= 0 && kb < p.nbox) {
         const double* sq = ter + T_SEQ + 6 * kb;
@@ -924,15 +935,32 @@ __device__ void fwd_collision(const HModel& m, const HParams& p, L& S, int lane,
     margin = fmax(m.geom_d[GDS * (g1) + GD_MARGIN], m.geom_d[GDS * (g2) + GD_MARGIN]);
     // boxes only collide while the floor is lowered (KNOWN DEVIATION, DESIGN.md section 6: coplanar floor + box contacts
     // of the reference would need more constraint rows than a wave has lanes)
-    if (ter && ter[T_FLOOR] == 0.0 && ((g1 >= p.box_geom0 && g1 < p.box_geom0 + p.nbox) || (g2 >= p.box_geom0 && g2 < p.box_geom0 + p.nbox)))
+    if (BOXBOX && ter && ter[T_FLOOR] == 0.0 && ((g1 >= p.box_geom0 && g1 < p.box_geom0 + p.nbox) || (g2 >= p.box_geom0 && g2 < p.box_geom0 + p.nbox)))
       have = false;
   }
   ConSink<L> k{&S, 0, 0, 0, g1, g2};
-  if (have) collide_pair<BOXBOX>(k, m, S, g1, g2, margin);
+  // box-box pairs (stepping-task kernels only) run the SAT + clipping once, in the counting pass, and replay the recorded
+  // contacts in the writing pass; every other pair type is cheap enough to be evaluated twice
+  BoxRec br;
+  br.cnt = 0;
+  bool boxpair = false;
+  if constexpr (BOXBOX) boxpair = have && m.geom_i[GIS * g1 + GI_TYPE] == G_BOX && m.geom_i[GIS * g2 + GI_TYPE] == G_BOX;
+  if (have && !boxpair) collide_pair(k, m, S, g1, g2, margin);
+  if constexpr (BOXBOX) {
+    if (__any(boxpair)) {
+      if (boxpair) { col_box_box(br, m, S, g1, g2, margin); k.n = br.cnt; }
+    }
+  }
   int total;
   const int base = wave_scan(k.n, &total) - k.n;
   k.base = base; k.n = 0; k.write = 1;
-  if (have && base < NC) collide_pair<BOXBOX>(k, m, S, g1, g2, margin);
+  if (have && !boxpair && base < NC) collide_pair(k, m, S, g1, g2, margin);
+  if constexpr (BOXBOX) {
+    if (boxpair && base < NC) {
+      const double zero[3] = {0, 0, 0};
+      for (int q = 0; q < br.cnt; q++) k.emit(br.dist[q], &br.pos[3 * q], br.n, zero);
+    }
+  }
   if (lane == 0) { S.ncon = min(total, NC); if (total > NC) S.overflow = 1; }
   SYNC();
   // mj_contactParam (lane = contact): priority, else solmix-weighted mix; friction = max; condim = max
@@ -1210,7 +1238,7 @@ template <bool BOXBOX, class L>
 __device__ __forceinline__ void substep(const HModel& m, const HParams& p, L& S, int lane, int flags, double* warm /* lane-held */, long long* st_prof,
                                         const double* ter) {
   PROF_BEGIN();
-  fwd_kinematics(m, S, lane);
+  fwd_kinematics<BOXBOX>(m, S, lane);
   PROF_MARK(0);
   fwd_collision<BOXBOX>(m, p, S, lane, ter);   // stage A temporaries (geom frames) die here
   PROF_MARK(3);
@@ -1479,6 +1507,16 @@ __device__ void write_obs_step(const HModel& m, const HParams& p, L& S, int lane
   if (lane < 12) { o[5 + lane] = (float)S.sq[lane]; o[17 + lane] = (float)S.sv[lane]; }
 }
 
+// external state of the walking envs (jvrc_walk.py:65-67, h1_walk.py:118-123): clock, mode one-hot, mode reference
+__device__ __forceinline__ void write_obs_walk_ext(const HParams& p, int lane, int phase, int mode, const double* mode_ref, float* o) {
+  if (lane == 0) {
+    const double ang = 2 * 3.141592653589793 * (double)phase / (double)p.period;
+    o[0] = (float)sin(ang); o[1] = (float)cos(ang);
+    o[2] = mode == MODE_FORWARD ? 1.f : 0.f; o[3] = mode == MODE_INPLACE ? 1.f : 0.f; o[4] = mode == MODE_STANDING ? 1.f : 0.f;
+    o[5] = (float)mode_ref[0]; o[6] = (float)mode_ref[1]; o[7] = (float)mode_ref[2];
+  }
+}
+
 // H1 robot state (h1_base.py:95-119): [roll, pitch, ang vel 3, motor pos 10, motor vel 10, motor torque 10] plus uniform
 // observation noise drawn per entry on every get_obs (base_humanoid_env.py:307-338); lane = observation entry
 template <class L>
@@ -1548,7 +1586,10 @@ __global__ void __launch_bounds__(64, 2) humanoid_kernel(HModel m, HParams p, HS
   double* rec = st.rec + (size_t)env * REC_D;
   double* prm = st.prm ? st.prm + (size_t)env * PRM_D : nullptr;
   double* ter = (TASK == TASK_STEP) ? st.ter + (size_t)env * TER_D : nullptr;
-  const int OBS = TASK == TASK_WALK ? 37 : (TASK == TASK_STEP ? 39 : 35);
+  // WALKT: WalkingTask (jvrc_walk, h1_walk); H1R: H1 robot state with observation noise + domain randomisation (h1, h1_walk)
+  constexpr bool WALKT = TASK == TASK_WALK || TASK == TASK_H1WALK, H1R = TASK == TASK_STAND || TASK == TASK_H1WALK;
+  constexpr unsigned WS = TASK == TASK_H1WALK ? 100u : 0u;   // RNG slot base of the walking-task draws (the H1 randomisation owns slots 0..99)
+  const int OBS = TASK == TASK_WALK ? 37 : (TASK == TASK_STEP ? 39 : (TASK == TASK_H1WALK ? 43 : 35));
   int* irec = st.irec + (size_t)env * REC_I;
   const unsigned genv = p.env_id_base + env;
   long long* sprof = (env == 0) ? st.prof : nullptr;
@@ -1647,23 +1688,23 @@ __global__ void __launch_bounds__(64, 2) humanoid_kernel(HModel m, HParams p, HS
       grf_r = wave_sum(grf_r); grf_l = wave_sum(grf_l); cz = wave_min(cz);
       if (!__any(anyfoot)) cz = 0;
     }
-    if (TASK == TASK_WALK) {
+    if (WALKT) {
     // ---- WalkingTask.step (walking_task.py:149-170)
     phase += 1;
     if (phase >= p.period) phase = 0;
     {
       const bool dbl = p.clock_lut[0 * p.period + phase] == 1.0 && p.clock_lut[2 * p.period + phase] == 1.0;
-      if (lhw_rng_randint(p.seed, genv, LHW_STREAM_STEP, step_count, 0, 100) == 0 && dbl) {
+      if (lhw_rng_randint(p.seed, genv, LHW_STREAM_STEP, step_count, WS + 0, 100) == 0 && dbl) {
         if (mode == MODE_INPLACE) mode = MODE_STANDING;
         else if (mode == MODE_STANDING) mode = MODE_INPLACE;
-        sample_ref(p, genv, LHW_STREAM_STEP, step_count, 1, mode, mode_ref);
+        sample_ref(p, genv, LHW_STREAM_STEP, step_count, WS + 1, mode, mode_ref);
       }
-      if (lhw_rng_randint(p.seed, genv, LHW_STREAM_STEP, step_count, 4, 200) == 0 && mode != MODE_STANDING) {
+      if (lhw_rng_randint(p.seed, genv, LHW_STREAM_STEP, step_count, WS + 4, 200) == 0 && mode != MODE_STANDING) {
         if (mode == MODE_FORWARD) mode = MODE_INPLACE;
         else if (mode == MODE_INPLACE) mode = MODE_FORWARD;
-        sample_ref(p, genv, LHW_STREAM_STEP, step_count, 5, mode, mode_ref);
+        sample_ref(p, genv, LHW_STREAM_STEP, step_count, WS + 5, mode, mode_ref);
       }
-      step_count++;
+      if (!H1R) step_count++;   // h1_walk: the counter advances after the post-observation randomisation draws below
     }
     // ---- calc_reward (walking_task.py:85-147) on the fields of the last forward pass
     // joint-space sums: lane = actuator / dof
@@ -1828,7 +1869,7 @@ __global__ void __launch_bounds__(64, 2) humanoid_kernel(HModel m, HParams p, HS
     traj_len += 1;
     ep_ret += r_sum;
     const bool truncated = p.max_traj_len > 0 && traj_len >= p.max_traj_len;
-    const int NT = TASK == TASK_WALK ? 10 : 6;
+    const int NT = WALKT ? 10 : 6;
     if (TASK == TASK_WALK) {
       write_obs(m, p, S, lane, phase, mode, mode_ref, obs + (size_t)env * OBS);
       if (term_obs) write_obs(m, p, S, lane, phase, mode, mode_ref, term_obs + (size_t)env * OBS);
@@ -1837,6 +1878,10 @@ __global__ void __launch_bounds__(64, 2) humanoid_kernel(HModel m, HParams p, HS
       if (term_obs) write_obs_step(m, p, S, lane, phase, goal, term_obs + (size_t)env * OBS);
     } else {
       write_obs_h1(m, p, S, lane, genv, obs_count, obs + (size_t)env * OBS, term_obs ? term_obs + (size_t)env * OBS : nullptr);
+      if (TASK == TASK_H1WALK) {
+        write_obs_walk_ext(p, lane, phase, mode, mode_ref, obs + (size_t)env * OBS + 35);
+        if (term_obs) write_obs_walk_ext(p, lane, phase, mode, mode_ref, term_obs + (size_t)env * OBS + 35);
+      }
       obs_count++;
       // post-observation randomisation draws (base_humanoid_env.py:221-225): slot 0 / 70 are the interval triggers
       if (p.dynrand_interval > 0 && lhw_rng_randint(p.seed, genv, LHW_STREAM_STEP, step_count, 0, p.dynrand_interval) == 0)
@@ -1876,7 +1921,7 @@ __global__ void __launch_bounds__(64, 2) humanoid_kernel(HModel m, HParams p, HS
     if (lane < m.nv) S.qvel[lane] = 0;
     if (lane < m.nu) S.ctrl[lane] = 0;
     warm = 0;
-    if (TASK == TASK_STAND) {
+    if (H1R) {
       // mj_resetData clears xfrc_applied; dynamics randomisation on reset (base_humanoid_env.py:254-255), slots 0..63
       if (lane < 12) { S.xfrc[lane] = 0; prm[P_XFRC + lane] = 0; }
       if (p.dynrand_interval > 0) randomize_dynamics(m, p, S, prm, lane, genv, LHW_STREAM_RESET, reset_count, 0);
@@ -1897,12 +1942,12 @@ __global__ void __launch_bounds__(64, 2) humanoid_kernel(HModel m, HParams p, HS
     SYNC();
     substep<TASK == TASK_STEP>(m, p, S, lane, 0, &warm, sprof, ter);                           // set_state: forward, actuation disabled
     for (int k = 0; k < 3; k++) substep<TASK == TASK_STEP>(m, p, S, lane, 3, &warm, sprof, ter);  // three settle steps, ctrl = 0
-    if (TASK == TASK_WALK) {
-      // WalkingTask.reset (walking_task.py:194-205): slot 0 mode, 1..3 mode_ref, 4 phase
-      const double u = lhw_rng_u01(p.seed, genv, LHW_STREAM_RESET, reset_count, 0);
+    if (WALKT) {
+      // WalkingTask.reset (walking_task.py:194-205): slot 0 mode, 1..3 mode_ref, 4 phase (+100 for h1_walk)
+      const double u = lhw_rng_u01(p.seed, genv, LHW_STREAM_RESET, reset_count, WS + 0);
       mode = u < 0.6 ? MODE_STANDING : (u < 0.8 ? MODE_INPLACE : MODE_FORWARD);
-      sample_ref(p, genv, LHW_STREAM_RESET, reset_count, 1, mode, mode_ref);
-      phase = lhw_rng_randint(p.seed, genv, LHW_STREAM_RESET, reset_count, 4, p.period);
+      sample_ref(p, genv, LHW_STREAM_RESET, reset_count, WS + 1, mode, mode_ref);
+      phase = lhw_rng_randint(p.seed, genv, LHW_STREAM_RESET, reset_count, WS + 4, p.period);
     }
     if (TASK == TASK_STEP) {
       // ---- SteppingTask.reset (stepping_task.py:261-334); RNG slots: 0 phase, 1 mode, 2 mode-specific choice, 3 first-step
@@ -1984,6 +2029,7 @@ __global__ void __launch_bounds__(64, 2) humanoid_kernel(HModel m, HParams p, HS
       if (obs) write_obs_step(m, p, S, lane, phase, goal, obs + (size_t)env * OBS);
     } else {
       write_obs_h1(m, p, S, lane, genv, obs_count, obs ? obs + (size_t)env * OBS : nullptr, nullptr);  // the counter advances either way
+      if (TASK == TASK_H1WALK && obs) write_obs_walk_ext(p, lane, phase, mode, mode_ref, obs + (size_t)env * OBS + 35);
       obs_count++;
     }
   }
@@ -2041,14 +2087,15 @@ int humanoid_create(HumanoidEnv** out, const std::vector<int32_t>& mi, const std
   if (nq > NQ || nv > NV || nu > NU || nb > NB || nj > NJ || ng > NG || np > NP || nb > 64 || np > 64)
     return lhw_fail(LHW_ERR_MODEL, "model exceeds compiled limits (nq %d/%d nv %d/%d nu %d/%d nbody %d/%d njnt %d/%d ngeom %d/%d npair %d/%d)",
                     nq, NQ, nv, NV, nu, NU, nb, NB, nj, NJ, ng, NG, np, NP);
-  const bool stepping = cfg->task == LHW_TASK_JVRC_STEP;
-  const bool walk = cfg->task == LHW_TASK_JVRC_WALK || stepping, stand = cfg->task == LHW_TASK_H1_STAND;  // walk: JVRC robot + gait clock
+  const bool stepping = cfg->task == LHW_TASK_JVRC_STEP, h1walk = cfg->task == LHW_TASK_H1_WALK;
+  const bool walk = cfg->task == LHW_TASK_JVRC_WALK || stepping;             // JVRC robot + gait clock
+  const bool stand = cfg->task == LHW_TASK_H1_STAND || h1walk;               // H1 robot: observation noise, domain randomisation
   if (!walk && !stand) return lhw_fail(LHW_ERR_ARG, "humanoid stepper: unknown task");
   if (walk && (nu != 12 || nq != 19 || nv != 18)) return lhw_fail(LHW_ERR_UNSUPPORTED, "jvrc tasks need a free root + 12 actuated leg hinges");
   if (stand && (nu != 10 || nq != 17 || nv != 16)) return lhw_fail(LHW_ERR_UNSUPPORTED, "h1 needs a free root + 10 actuated leg hinges");
   if (!cfg->kp || !cfg->kd || !cfg->action_offset || cfg->n_task_iparams < LHW_TI_COUNT || cfg->n_task_params < LHW_TP_COUNT || cfg->frame_skip <= 0)
     return lhw_fail(LHW_ERR_ARG, "humanoid task config incomplete");
-  if (walk && (!cfg->clock_lut || cfg->period <= 0)) return lhw_fail(LHW_ERR_ARG, "jvrc_walk needs the gait clock table");
+  if ((walk || h1walk) && (!cfg->clock_lut || cfg->period <= 0)) return lhw_fail(LHW_ERR_ARG, "walking / stepping tasks need the gait clock table");
   if (stand && (cfg->n_task_params < LHW_TP_H1_OBS_NOISE + 35 || cfg->n_task_iparams < LHW_TI_H1_RAND_BODY + 11))
     return lhw_fail(LHW_ERR_ARG, "h1 task parameter arrays too short");
   int nplans = 0;
@@ -2223,7 +2270,7 @@ int humanoid_create(HumanoidEnv** out, const std::vector<int32_t>& mi, const std
     ok = false;
   p.env_id_base = (unsigned)cfg->env_id_base; p.seed = cfg->seed;
   p.action_smoothing = cfg->action_smoothing; p.goal_height = cfg->task_params[LHW_TP_GOAL_HEIGHT];
-  p.task = stepping ? TASK_STEP : (walk ? TASK_WALK : TASK_STAND);
+  p.task = stepping ? TASK_STEP : (walk ? TASK_WALK : (h1walk ? TASK_H1WALK : TASK_STAND));
   if (stepping) {
     p.box_geom0 = cfg->task_iparams[LHW_TI_STEP_BOX_GEOM0]; p.nbox = cfg->task_iparams[LHW_TI_STEP_NBOX];
     p.floor_geom = cfg->task_iparams[LHW_TI_STEP_FLOOR_GEOM]; p.delay_frames = cfg->task_iparams[LHW_TI_STEP_DELAY_FRAMES];
@@ -2253,7 +2300,7 @@ int humanoid_create(HumanoidEnv** out, const std::vector<int32_t>& mi, const std
   for (int u = 0; u < nu; u++) neutral[u] = cfg->action_offset[u];  // task._neutral_pose == half-sitting pose == offsets (jvrc_walk.py:33)
   ok = ok && (p.kp = to_dev<double>(h, cfg->kp, nu)) && (p.kd = to_dev<double>(h, cfg->kd, nu)) &&
        (p.nominal_qpos = to_dev<double>(h, nominal.data(), nq)) && (p.action_offset = to_dev<double>(h, cfg->action_offset, nu)) &&
-       (p.clock_lut = to_dev<double>(h, cfg->clock_lut, walk ? (size_t)4 * cfg->period : 0)) &&
+       (p.clock_lut = to_dev<double>(h, cfg->clock_lut, (walk || h1walk) ? (size_t)4 * cfg->period : 0)) &&
        (p.neutral_pose = to_dev<double>(h, neutral.data(), nu)) && (p.obs_noise = to_dev<double>(h, obs_noise.data(), 35));
   const size_t N = cfg->n_envs;
   h->st.prm = nullptr;
@@ -2292,7 +2339,7 @@ int humanoid_create(HumanoidEnv** out, const std::vector<int32_t>& mi, const std
   if (eps) h->dev_allocs.push_back(eps);
   h->st.rec = (double*)rec; h->st.irec = (int*)irec; h->st.ep_stats = (double*)eps; h->st.prof = nullptr;
   if (!ok) { humanoid_destroy(h); return lhw_fail(LHW_ERR_HIP, "humanoid_create: device allocation failed or bad body ids"); }
-  *obs_dim = stepping ? 39 : (walk ? 37 : 35); *act_dim = nu; *n_terms = (walk && !stepping) ? 10 : 6;
+  *obs_dim = stepping ? 39 : (walk ? 37 : (h1walk ? 43 : 35)); *act_dim = nu; *n_terms = ((walk && !stepping) || h1walk) ? 10 : 6;
   *out = h;
   return LHW_OK;
 }
@@ -2307,6 +2354,7 @@ void humanoid_destroy(HumanoidEnv* h) {
   do {                                                                                                             \
     if (h->p.task == TASK_WALK) hipLaunchKernelGGL((humanoid_kernel<MODE, TASK_WALK>), dim3(h->p.n_envs), dim3(64), 0, s, h->m, h->p, h->st, __VA_ARGS__); \
     else if (h->p.task == TASK_STEP) hipLaunchKernelGGL((humanoid_kernel<MODE, TASK_STEP>), dim3(h->p.n_envs), dim3(64), 0, s, h->m, h->p, h->st, __VA_ARGS__); \
+    else if (h->p.task == TASK_H1WALK) hipLaunchKernelGGL((humanoid_kernel<MODE, TASK_H1WALK>), dim3(h->p.n_envs), dim3(64), 0, s, h->m, h->p, h->st, __VA_ARGS__); \
     else hipLaunchKernelGGL((humanoid_kernel<MODE, TASK_STAND>), dim3(h->p.n_envs), dim3(64), 0, s, h->m, h->p, h->st, __VA_ARGS__);                     \
   } while (0)
 

@@ -11,6 +11,7 @@ import torch
 
 from .cartpole import CartpoleSpec
 from .h1 import H1Spec
+from .h1_walk import H1WalkSpec
 from .jvrc_step import JvrcStepSpec
 from .jvrc_walk import JvrcWalkSpec
 
@@ -90,3 +91,13 @@ class H1Env(_SingleEnv):
 
     def __init__(self, path_to_yaml=None, seed=0, device=0):
         super().__init__(H1Spec(yaml_path=path_to_yaml) if path_to_yaml else H1Spec(), seed=seed, device=device)
+
+
+class H1WalkEnv(_SingleEnv):
+    TERMS = JvrcWalkEnv.TERMS          # same WalkingTask reward dictionary
+
+    def __init__(self, path_to_yaml=None, seed=0, device=0):
+        spec = H1WalkSpec(yaml_path=path_to_yaml) if path_to_yaml else H1WalkSpec()
+        super().__init__(spec, seed=seed, device=device)
+        mo, ma, clock = spec.mirror_inds()
+        self.robot.mirrored_obs, self.robot.mirrored_acts, self.robot.clock_inds = mo, ma, clock

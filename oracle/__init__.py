@@ -18,6 +18,9 @@ def make_oracle_env(name, seed=0, env_id=0, max_traj_len=400):
     if name == "jvrc_step":
         from .env_jvrc_step import make_oracle_jvrc_step
         return make_oracle_jvrc_step(seed=seed, env_id=env_id, max_traj_len=max_traj_len), 39, 12
+    if name == "h1_walk":
+        from .env_h1_walk import make_oracle_h1_walk
+        return make_oracle_h1_walk(seed=seed, env_id=env_id, max_traj_len=max_traj_len), 43, 10
     if name == "h1":
         from .env_h1 import make_oracle_h1
         return make_oracle_h1(seed=seed, env_id=env_id, max_traj_len=max_traj_len), 35, 10

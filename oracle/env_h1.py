@@ -121,12 +121,23 @@ class OracleH1Env:
         self.set_state(qpos, np.zeros(self.m.nv))
         for _ in range(3):
             self.sim.step()
+        self._task_reset(c)
         self.reset_count += 1
         self.traj_len = 0
         self.prev_prediction = np.zeros(10)
         return self.get_obs()
 
-    def _calc_reward(self):
+    def _task_reset(self, c):      # StandingTask.reset draws nothing
+        pass
+
+    def _task_step(self, c):
+        pass
+
+    def _done(self):
+        z = self.sim.qpos[2]
+        return bool(z < 0.9 or z > 1.4 or self._self_collision())     # standing_task.py:111-131
+
+    def _calc_reward(self, prev_torque=None, prev_action=None, action=None):
         sim = self.sim
         R = sim.xmat[self.root].reshape(3, 3)
         head = R.T @ (sim.xpos[self.torso] - sim.xpos[self.root])
@@ -153,9 +164,9 @@ class OracleH1Env:
             tau = sp.kp * (act - self._act_pos()) + sp.kd * (0.0 - self._act_vel())
             sim.ctrl[:] = tau / self.gear
             sim.step()
-        terms = self._calc_reward()
-        z = sim.qpos[2]
-        done = bool(z < 0.9 or z > 1.4 or self._self_collision())
+        self._task_step(self.step_count)
+        terms = self._calc_reward(self.prev_torque, self.prev_action, act)
+        done = self._done()
         self.prev_action = act
         self.prev_torque = np.asarray(self._act_torque()).copy()
         obs = self.get_obs()

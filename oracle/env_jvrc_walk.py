@@ -72,6 +72,7 @@ def r_clock(l_val, r_val, l_clock, r_clock, max_val):
 class OracleJvrcWalkEnv:
     TERMS = ["foot_frc_score", "foot_vel_score", "root_accel", "height_error", "com_vel_error", "yaw_vel_error",
              "upper_body_reward", "posture_error", "torque_penalty", "action_penalty"]
+    WSLOT = 0      # first RNG slot of the walking-task draws (h1_walk moves them to 100: the H1 randomisation owns 0..99)
 
     def __init__(self, spec, seed=0, env_id=0, max_traj_len=0):
         self.spec = spec
@@ -149,35 +150,42 @@ class OracleJvrcWalkEnv:
         self.set_state(self.spec.nominal_pose, np.zeros(self.m.nv))
         for _ in range(3):      # base_humanoid_env.py:268-269, ctrl is zero after mj_resetData
             self.sim.step()
-        # WalkingTask.reset (walking_task.py:194-205): slot 0 mode, 1..3 mode_ref, 4 phase
-        u = rng.u01(s, e, rng.STREAM_RESET, c, 0)
-        self.mode = STANDING if u < 0.6 else (INPLACE if u < 0.8 else FORWARD)
-        self.mode_ref = self._sample_ref(c, rng.STREAM_RESET, 1)
-        self.phase = rng.randint(s, e, rng.STREAM_RESET, c, 4, self.period)
+        self._walk_task_reset(c)
         self.reset_count += 1
         self.traj_len = 0
         self.prev_prediction = np.zeros(12)
         return self.get_obs()
 
+    def _walk_task_reset(self, c):
+        # WalkingTask.reset (walking_task.py:194-205): slot 0 mode, 1..3 mode_ref, 4 phase
+        s, e, w = self.seed, self.env_id, self.WSLOT
+        u = rng.u01(s, e, rng.STREAM_RESET, c, w + 0)
+        self.mode = STANDING if u < 0.6 else (INPLACE if u < 0.8 else FORWARD)
+        self.mode_ref = self._sample_ref(c, rng.STREAM_RESET, w + 1)
+        self.phase = rng.randint(s, e, rng.STREAM_RESET, c, w + 4, self.period)
+
     def _task_step(self):
-        s, e, c = self.seed, self.env_id, self.step_count
+        self._walk_task_step(self.step_count)
+        self.step_count += 1
+
+    def _walk_task_step(self, c):
+        s, e, w = self.seed, self.env_id, self.WSLOT
         self.phase += 1
         if self.phase >= self.period:
             self.phase = 0
         dbl = self.lut[0, self.phase] == 1 and self.lut[2, self.phase] == 1
-        if rng.randint(s, e, rng.STREAM_STEP, c, 0, 100) == 0 and dbl:      # slot 0; mode_ref slots 1..3
+        if rng.randint(s, e, rng.STREAM_STEP, c, w + 0, 100) == 0 and dbl:      # slot 0; mode_ref slots 1..3
             if self.mode == INPLACE:
                 self.mode = STANDING
             elif self.mode == STANDING:
                 self.mode = INPLACE
-            self.mode_ref = self._sample_ref(c, rng.STREAM_STEP, 1)
-        if rng.randint(s, e, rng.STREAM_STEP, c, 4, 200) == 0 and self.mode != STANDING:   # slot 4; mode_ref slots 5..7
+            self.mode_ref = self._sample_ref(c, rng.STREAM_STEP, w + 1)
+        if rng.randint(s, e, rng.STREAM_STEP, c, w + 4, 200) == 0 and self.mode != STANDING:   # slot 4; mode_ref slots 5..7
             if self.mode == FORWARD:
                 self.mode = INPLACE
             elif self.mode == INPLACE:
                 self.mode = FORWARD
-            self.mode_ref = self._sample_ref(c, rng.STREAM_STEP, 5)
-        self.step_count += 1
+            self.mode_ref = self._sample_ref(c, rng.STREAM_STEP, w + 5)
 
     def _calc_reward(self, prev_torque, prev_action, action):
         sim = self.sim

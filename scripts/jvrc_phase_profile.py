@@ -2,11 +2,16 @@
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
-from learninghumanoidwalking_amd.envs.jvrc_walk import JvrcWalkSpec
+from learninghumanoidwalking_amd.envs import ENVIRONMENTS
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
-spec = JvrcWalkSpec()
-env = spec.make_batched(N, seed=1, device=0, max_traj_len=400)
+name = sys.argv[2] if len(sys.argv) > 2 else "jvrc_walk"          # jvrc_walk | jvrc_step
+seed = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+spec = ENVIRONMENTS[name]()
+env = spec.make_batched(N, seed=seed, device=0, max_traj_len=400)
 env.reset()
+if name == "jvrc_step":
+    _, fz, _ = env.debug_step_record()
+    print(f"jvrc_step seed {seed}: env 0 {'stands on the boxes (FORWARD mode)' if fz[0] != 0 else 'stands on the floor'}; {int((fz != 0).sum())}/{N} envs on boxes")
 act = torch.randn(N, 12, device="cuda") * 0.1
 for _ in range(3): env.step(act)
 env.phase_cycles(True)

@@ -187,12 +187,20 @@ def gen_ppo(tag, hidden, B, mirror, learn_std, n_updates, seed):
     np.savez_compressed(os.path.join(OUT, f"ppo_{tag}.npz"), **out)
 
 
+# reference envs/h1/h1_walk.py:68-113 (35 robot-state entries + 8 external), actions left(5) / right(5)
+H1W_MIR_OBS = [-0.1, 1, -2, 3, -4, -10, -11, 12, 13, 14, -5, -6, 7, 8, 9, -20, -21, 22, 23, 24, -15, -16, 17, 18, 19,
+               -30, -31, 32, 33, 34, -25, -26, 27, 28, 29] + list(range(35, 43))
+H1W_MIR_ACT = [-5, -6, 7, 8, 9, -0.1, -1, 2, 3, 4]
+
+
 def gen_misc():
     from rl.utils.seeding import get_worker_seed
     from rl.envs.wrappers import _get_symmetry_matrix
     np.savez(os.path.join(OUT, "misc.npz"),
              worker_seeds=np.array([get_worker_seed(0, 0), get_worker_seed(7, 3), get_worker_seed(123456, 11, 1)], dtype=np.int64),
-             mir_obs=_get_symmetry_matrix(JVRC_MIR_OBS), mir_act=_get_symmetry_matrix(JVRC_MIR_ACT))
+             mir_obs=_get_symmetry_matrix(JVRC_MIR_OBS), mir_act=_get_symmetry_matrix(JVRC_MIR_ACT),
+             mir_obs_h1walk=_get_symmetry_matrix(H1W_MIR_OBS), mir_act_h1walk=_get_symmetry_matrix(H1W_MIR_ACT),
+             mir_obs_step=_get_symmetry_matrix(JVRC_MIR_OBS[:29] + list(range(29, 39))))
 
 
 def gen_stepping():
@@ -363,6 +371,9 @@ if __name__ == "__main__":
     _stub_modules()
     if len(sys.argv) > 1 and sys.argv[1] == "stepping":     # regenerate only the stepping-task fixture
         gen_stepping()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "misc":
+        gen_misc()
         sys.exit(0)
     gen_gae()
     gen_clock()

@@ -11,7 +11,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("name", ["cartpole", "jvrc_walk", "jvrc_step", "h1"])
+@pytest.mark.parametrize("name", ["cartpole", "jvrc_walk", "jvrc_step", "h1", "h1_walk"])
 def test_single_env_surface(name):
     from learninghumanoidwalking_amd.envs import single_env
     env = single_env(name, seed=1)
@@ -30,6 +30,8 @@ def test_single_env_surface(name):
     if name == "jvrc_walk":   # tests/test_environments.py:194-226 mirror / clock index validity
         assert len(env.robot.mirrored_obs) == 37 and len(env.robot.mirrored_acts) == 12 and env.robot.clock_inds == [29, 30]
         assert env.obs_mean.shape == (37,) and env.obs_std.shape == (37,)
+    if name == "h1_walk":
+        assert len(env.robot.mirrored_obs) == 43 and len(env.robot.mirrored_acts) == 10 and env.robot.clock_inds == [35, 36]
     if name == "jvrc_step":
         assert len(env.robot.mirrored_obs) == 39 and env.robot.clock_inds == [29, 30] and env.obs_mean.shape == (39,)
         assert set(info) == {"foot_frc_score", "foot_vel_score", "orient_cost", "height_error", "step_reward", "upper_body_reward"}

@@ -1,0 +1,93 @@
+"""h1_walk (reference envs/h1/h1_walk.py: H1 robot state + noise + domain randomisation with the WalkingTask) on the HIP
+stepper vs the CPU oracle through the C ABI (H1 stand-in model; physics parity unpinned, see tests/test_jvrc_gpu.py)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _pair(n, seed, max_traj_len=0):
+    import torch
+    from learninghumanoidwalking_amd.envs.h1_walk import H1WalkSpec
+    from oracle.env_h1_walk import OracleH1WalkEnv
+    assert torch.cuda.is_available()
+    spec = H1WalkSpec()
+    env = spec.make_batched(n, seed=seed, device=0, max_traj_len=max_traj_len)
+    orc = [OracleH1WalkEnv(spec, seed=seed, env_id=i, max_traj_len=max_traj_len) for i in range(n)]
+    return spec, env, orc
+
+
+def _states(orc):
+    return np.array([o.sim.qpos.copy() for o in orc]), np.array([o.sim.qvel.copy() for o in orc])
+
+
+def test_reset_matches_oracle():
+    spec, env, orc = _pair(24, seed=3)
+    obs = env.reset().cpu().numpy()
+    ref = np.array([o.reset() for o in orc])
+    q, v = env.get_state()
+    oq, ov = _states(orc)
+    np.testing.assert_allclose(q, oq, rtol=0, atol=1e-12)
+    np.testing.assert_allclose(v, ov, rtol=0, atol=1e-10)
+    np.testing.assert_allclose(obs, ref, rtol=1e-6, atol=2e-6)
+    assert obs.shape == (24, 43)
+    assert len({tuple(r[37:40]) for r in ref}) >= 2            # several walk modes drawn
+    assert np.ptp(oq[:, 7]) > 1e-3                              # init noise differs between envs
+
+
+def test_action_tape_resynchronised():
+    import torch
+    N, T = 6, 130
+    spec, env, orc = _pair(N, seed=12)
+    env.reset()
+    for o in orc:
+        o.reset()
+    tape = (np.random.default_rng(5).normal(size=(T, N, 10)) * 0.08).astype(np.float32)
+    n_done = n_switch = 0
+    modes = [o.mode for o in orc]
+    for t in range(T):
+        obs, rew, done, _ = env.step(torch.from_numpy(tape[t]).cuda())
+        res = [o.step(tape[t, i]) for i, o in enumerate(orc)]
+        q, v = env.get_state()
+        oq, ov = _states(orc)
+        np.testing.assert_allclose(q, oq, rtol=0, atol=1e-8, err_msg=f"qpos t={t}")
+        np.testing.assert_allclose(v, ov, rtol=0, atol=1e-7, err_msg=f"qvel t={t}")
+        np.testing.assert_allclose(obs.cpu().numpy(), np.array([r[0] for r in res]), rtol=1e-5, atol=2e-5, err_msg=f"obs t={t}")
+        np.testing.assert_allclose(rew.cpu().numpy(), np.array([r[1] for r in res]), rtol=0, atol=2e-6, err_msg=f"rew t={t}")
+        terms = np.array([[r[3][k] for k in o.TERMS] for r, o in zip(res, orc)])
+        np.testing.assert_allclose(env.rew_terms.cpu().numpy(), terms, rtol=0, atol=2e-6, err_msg=f"terms t={t}")
+        flags = np.array([int(r[2]) for r in res], dtype=np.uint8)
+        np.testing.assert_array_equal(done.cpu().numpy() & 1, flags, err_msg=f"done t={t}")
+        n_done += int(flags.sum())
+        n_switch += sum(o.mode != m0 for o, m0 in zip(orc, modes))
+        modes = [o.mode for o in orc]
+        if t % 5 == 4 or flags.any():
+            for i, o in enumerate(orc):
+                if flags[i]:
+                    o.set_state(spec.nominal_pose, np.zeros(16))
+                else:
+                    o.set_state(o.sim.qpos.copy(), o.sim.qvel.copy())
+            oq, ov = _states(orc)
+            env.set_state(oq, ov)
+    assert n_done > 0, "tape never made a robot fall"
+    assert abs(float((env.rew_terms.sum(1) - env.rew).abs().max())) < 1e-6
+
+
+def test_auto_reset_flags_and_obs():
+    import torch
+    N, T, L = 6, 60, 25
+    spec, env, orc = _pair(N, seed=21, max_traj_len=L)
+    env.reset()
+    for o in orc:
+        o.reset()
+    tape = (np.random.default_rng(7).normal(size=(T, N, 10)) * 0.15).astype(np.float32)
+    seen = 0
+    for t in range(T):
+        obs, rew, done, tob = env.step(torch.from_numpy(tape[t]).cuda())
+        res = [o.step_auto(tape[t, i]) for i, o in enumerate(orc)]
+        flags = np.array([r[2] for r in res], dtype=np.uint8)
+        np.testing.assert_array_equal(done.cpu().numpy(), flags, err_msg=f"flags t={t}")
+        np.testing.assert_allclose(obs.cpu().numpy(), np.array([r[0] for r in res]), rtol=1e-4, atol=1e-4, err_msg=f"obs t={t}")
+        np.testing.assert_allclose(tob.cpu().numpy(), np.array([r[3] for r in res]), rtol=1e-4, atol=1e-4, err_msg=f"term obs t={t}")
+        seen |= int(np.bitwise_or.reduce(flags))
+    assert seen & 2

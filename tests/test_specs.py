@@ -33,6 +33,29 @@ def test_mirror_tables_equal_reference_matrices():
     np.testing.assert_allclose(a[:, asrc] * asign, a @ g["mir_act"], atol=0)
 
 
+def test_mirror_tables_of_h1_walk_and_jvrc_step_equal_reference_matrices():
+    from learninghumanoidwalking_amd.envs import H1WalkSpec, JvrcStepSpec
+    g = np.load(os.path.join(G, "misc.npz"))
+    for spec, D, A, mo, ma, clock in ((H1WalkSpec(), 43, 10, g["mir_obs_h1walk"], g["mir_act_h1walk"], [35, 36]),
+                                      (JvrcStepSpec(), 39, 12, g["mir_obs_step"], g["mir_act"], [29, 30])):
+        (osrc, osign), (asrc, asign) = spec.mirror_tables()
+        x = np.random.default_rng(0).normal(size=(4, D))
+        ref = x @ mo
+        ref[:, clock] *= -1
+        np.testing.assert_allclose(x[:, osrc] * osign, ref, atol=0)
+        a = np.random.default_rng(1).normal(size=(4, A))
+        np.testing.assert_allclose(a[:, asrc] * asign, a @ ma, atol=0)
+        assert spec.mirror_inds()[2] == clock and spec.obs_mean.shape == (D,) and spec.obs_std.shape == (D,)
+
+
+def test_h1_walk_clock_matches_reference_spline_table():
+    from learninghumanoidwalking_amd.envs import H1WalkSpec
+    g = np.load(os.path.join(G, "rewards.npz"))
+    s = H1WalkSpec()
+    assert s.period == 40
+    np.testing.assert_allclose(s.clock_lut(), g["h1_lut"], rtol=0, atol=1e-15)
+
+
 def test_oracle_reward_terms_equal_reference_functions():
     from oracle import env_jvrc_walk as e
     g = np.load(os.path.join(G, "rewards.npz"))
