@@ -197,7 +197,13 @@ int lhw_gae(int32_t T, int32_t N, const float* rew, const float* val, const uint
             const float* vfinal, double gamma, double lam, float* ret, float* adv, void* stream);
 int lhw_moments(const float* x, int64_t n, double* out2_dev, void* stream);
 int lhw_scale_shift(float* x, int64_t n, float mean, float inv_scale, void* stream);
-/* forward + loss + backward of one minibatch; accumulates into grad and stats_dev[0..4] */
+/* Imitation term of the NEXT lhw_ppo_grad call (reference rl/algos/ppo.py:360-368, rl/algos/imitation.py): the host
+ * evaluates env.imitation_projector() and the frozen expert policy, and passes the expert means scattered into a dense
+ * [B][act_dim] target with a [B][act_dim] 0/1 mask (minibatch row order), the coefficient and the number of selected
+ * entries (denominator of the mean).  NULL target disarms. */
+int lhw_ppo_set_imitation(LhwPpo* ppo, const float* target, const uint8_t* mask, float coeff, int64_t n_selected);
+/* forward + loss + backward of one minibatch; accumulates into grad and stats_dev[0..5]
+ * (actor, critic, mirror, approx_kl, clip_fraction, imitation) */
 int lhw_ppo_grad(LhwPpo* ppo, const float* theta, float* grad, const float* xn, const float* xm, const float* act,
                  const float* old_logp, const float* adv, const float* ret, const int32_t* idx, int32_t B,
                  float* stats_dev, void* stream);

@@ -126,3 +126,15 @@ def load_reference_checkpoint(actor_path, critic_path):
     if hasattr(actor, "stds"):
         t["stds"] = torch.as_tensor(actor.stds).detach().float().clone()
     return t, torch.as_tensor(actor.obs_mean).float(), torch.as_tensor(actor.obs_std).float()
+
+
+def load_reference_actor(actor_path):
+    """Actor-only load (the expert of ``--imitate``): -> (tensors a_*, obs_mean, obs_std, hidden width)."""
+    with reference_classes():
+        actor = torch.load(actor_path, weights_only=False, map_location="cpu")
+    a = actor.actor_layers
+    if len(a) != 2 or a[0].weight.shape[0] != a[1].weight.shape[0]:
+        raise ValueError("only two equal-width hidden layers are supported for the expert policy")
+    t = dict(a_w1=a[0].weight, a_b1=a[0].bias, a_w2=a[1].weight, a_b2=a[1].bias, a_w3=actor.means.weight, a_b3=actor.means.bias)
+    t = {k: v.detach().float().clone() for k, v in t.items()}
+    return t, torch.as_tensor(actor.obs_mean).float(), torch.as_tensor(actor.obs_std).float(), int(a[0].weight.shape[0])

@@ -241,7 +241,10 @@ struct LhwPpo {
   float *stats = nullptr;  // [16] loss scalars; [8],[9] grad norm^2 actor/critic
   float *part = nullptr;       // split-K partial tiles [max slices][H*H]
   float *dstd = nullptr;       // per-row d loss / d std [R][Op]
-  float *stats_part = nullptr; // per-block loss partials [blocks][5]
+  float *stats_part = nullptr; // per-block loss partials [blocks][NSTAT]
+  const float* imit_target = nullptr;          // imitation term of the NEXT lhw_ppo_grad call (lhw_ppo_set_imitation)
+  const unsigned char* imit_mask = nullptr;
+  float imit_coeff = 0.f, imit_inv_count = 0.f;
   float *norm_part = nullptr;  // [2][SUMSQ_BLOCKS]
   double *mom_part = nullptr;  // [MOM_BLOCKS][2]
   int max_slices = 0;
@@ -369,8 +372,12 @@ __global__ void sample_kernel(const float* __restrict__ mu, int ldmu, int A, int
 
 // PPO losses and their gradients wrt network outputs (reference rl/algos/ppo.py:302-384, FF path, mask = 1).
 // No atomics: bias / std gradients are column sums of dya / dyc / dstd taken afterwards in a fixed order, and the loss
-// scalars are written as per-block partials [gridDim.x][5]: 0 actor_loss 1 critic_loss 2 mirror_loss 3 approx_kl
-// 4 clip_fraction (already divided by B).
+// scalars are written as per-block partials [gridDim.x][6]: 0 actor_loss 1 critic_loss 2 mirror_loss 3 approx_kl
+// 4 clip_fraction (already divided by B) 5 imitation_loss.
+// Imitation term (ppo.py:360-368): imitation_loss = mean over the selected (sample, action dim) entries of
+// (mu - expert)^2; the host evaluates the env's projector and the frozen expert and hands over the dense target / mask
+// in minibatch order (lhw_ppo_set_imitation); here the term enters the loss scalar and d loss / d mu.
+#define NSTAT 6
 __global__ void __launch_bounds__(256) ppo_loss_kernel(int B, int Rcap, int A, int Op, const float* __restrict__ ya,
                                                        const float* __restrict__ yc, const float* __restrict__ act,
                                                        const float* __restrict__ old_logp, const float* __restrict__ adv,
@@ -378,11 +385,14 @@ __global__ void __launch_bounds__(256) ppo_loss_kernel(int B, int Rcap, int A, i
                                                        float clip, float mirror_coeff, int use_mirror,
                                                        const int* __restrict__ act_src, const float* __restrict__ act_sign,
                                                        float* __restrict__ dya, float* __restrict__ dyc,
-                                                       float* __restrict__ dstd /* [B][Op] or NULL */, float* __restrict__ stats_part) {
+                                                       float* __restrict__ dstd /* [B][Op] or NULL */, float* __restrict__ stats_part,
+                                                       const float* __restrict__ imit_target /* [B][A] or NULL */,
+                                                       const unsigned char* __restrict__ imit_mask /* [B][A] */, float imit_coeff,
+                                                       float imit_inv_count) {
   int m = blockIdx.x * blockDim.x + threadIdx.x;
-  float s_actor = 0, s_critic = 0, s_mirror = 0, s_kl = 0, s_cf = 0;
+  float s_actor = 0, s_critic = 0, s_mirror = 0, s_kl = 0, s_cf = 0, s_imit = 0;
   const float invB = 1.f / (float)B, invBA = 1.f / ((float)B * (float)A);
-  __shared__ float red[5][4];
+  __shared__ float red[NSTAT][4];
   if (m < B) {
     float lp = 0.f;
     for (int a = 0; a < A; a++) {
@@ -420,20 +430,25 @@ __global__ void __launch_bounds__(256) ppo_loss_kernel(int B, int Rcap, int A, i
           // gradient wrt the mirrored-pass output it came from (act_src is a permutation: each slot written once)
           dya[((size_t)Rcap + m) * Op + act_src[a]] = -mirror_coeff * 2.f * diff * invBA * act_sign[a];
         }
+        if (imit_target && imit_mask[(size_t)m * A + a]) {
+          float diff = mu - imit_target[(size_t)m * A + a];
+          s_imit += diff * diff;
+          g += imit_coeff * 2.f * diff * imit_inv_count;
+        }
       }
       dya[(size_t)m * Op + a] = g;
       if (dstd) dstd[(size_t)m * Op + a] = gs;
     }
   }
   // block reduction of the scalars in a fixed order (xor butterfly inside the wave, then waves 0..3)
-  float vals[5] = {s_actor * invB, s_critic * invB, s_mirror * invBA, s_kl * invB, s_cf * invB};
+  float vals[NSTAT] = {s_actor * invB, s_critic * invB, s_mirror * invBA, s_kl * invB, s_cf * invB, s_imit * imit_inv_count};
   for (int o = 32; o > 0; o >>= 1)
-    for (int k = 0; k < 5; k++) vals[k] += __shfl_xor(vals[k], o);
+    for (int k = 0; k < NSTAT; k++) vals[k] += __shfl_xor(vals[k], o);
   int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (lane == 0)
-    for (int k = 0; k < 5; k++) red[k][wave] = vals[k];
+    for (int k = 0; k < NSTAT; k++) red[k][wave] = vals[k];
   __syncthreads();
-  if (threadIdx.x < 5) stats_part[(size_t)blockIdx.x * 5 + threadIdx.x] = (red[threadIdx.x][0] + red[threadIdx.x][1]) + (red[threadIdx.x][2] + red[threadIdx.x][3]);
+  if (threadIdx.x < NSTAT) stats_part[(size_t)blockIdx.x * NSTAT + threadIdx.x] = (red[threadIdx.x][0] + red[threadIdx.x][1]) + (red[threadIdx.x][2] + red[threadIdx.x][3]);
 }
 
 // out[k] += sum_b part[b][n] in block order (single block; n small)
@@ -574,7 +589,7 @@ extern "C" int lhw_ppo_create(const LhwPpoConfig* c, LhwPpo** out) {
             alloc(&p->h1c, R * H) && alloc(&p->h2c, R * H) && alloc(&p->yc, R * 4) && alloc(&p->dya, 2 * R * Op) &&
             alloc(&p->dh2a, 2 * R * H) && alloc(&p->dh1a, 2 * R * H) && alloc(&p->dyc, R * 4) && alloc(&p->dh2c, R * H) &&
             alloc(&p->dh1c, R * H) && alloc(&p->mb_act, R * p->A) && alloc(&p->mb_logp, R) && alloc(&p->mb_adv, R) &&
-            alloc(&p->mb_ret, R) && alloc(&p->stats, 16) && alloc(&p->dstd, R * Op) && alloc(&p->stats_part, ((R + 255) / 256) * 5) &&
+            alloc(&p->mb_ret, R) && alloc(&p->stats, 16) && alloc(&p->dstd, R * Op) && alloc(&p->stats_part, ((R + 255) / 256) * NSTAT) &&
             alloc(&p->norm_part, 2 * SUMSQ_BLOCKS);
   p->max_slices = (int)((R + 511) / 512);
   ok = ok && alloc(&p->part, std::max<size_t>((size_t)p->max_slices * H * std::max<size_t>(H, Dp), (size_t)COLSUM_CHUNKS * H)) &&
@@ -704,6 +719,15 @@ extern "C" int lhw_scale_shift(float* x, int64_t n, float mean, float inv_scale,
 // One minibatch: gather rows idx[0..B) from the iteration's buffers, forward (policy on obs and on mirrored
 // obs, critic), losses, backward.  Gradients are ACCUMULATED into grad (flat, same layout as theta);
 // stats_dev[0..4] += actor_loss, critic_loss, mirror_loss, approx_kl, clip_fraction of this minibatch.
+// Arms the imitation term for the next lhw_ppo_grad call: target / mask are device arrays [B][act_dim] in minibatch row
+// order (row r belongs to idx[r]); n_selected = number of set mask entries (the mean's denominator).
+extern "C" int lhw_ppo_set_imitation(LhwPpo* p, const float* target, const uint8_t* mask, float coeff, int64_t n_selected) {
+  if (!p) return lhw_fail(LHW_ERR_ARG, "null ppo");
+  if (!target || !mask || n_selected <= 0) { p->imit_target = nullptr; p->imit_mask = nullptr; return LHW_OK; }
+  p->imit_target = target; p->imit_mask = mask; p->imit_coeff = coeff; p->imit_inv_count = 1.f / (float)n_selected;
+  return LHW_OK;
+}
+
 extern "C" int lhw_ppo_grad(LhwPpo* p, const float* theta, float* grad, const float* xn, const float* xm, const float* act,
                             const float* old_logp, const float* adv, const float* ret, const int32_t* idx, int32_t B,
                             float* stats_dev, void* stream) {
@@ -726,8 +750,10 @@ extern "C" int lhw_ppo_grad(LhwPpo* p, const float* theta, float* grad, const fl
   const int nblk = (B + 255) / 256;
   hipLaunchKernelGGL(ppo_loss_kernel, dim3(nblk), dim3(256), 0, s, B, R, p->A, Op, p->ya, p->yc, p->mb_act, p->mb_logp,
                      p->mb_adv, p->mb_ret, theta + p->off_std, p->clip, p->mirror_coeff, mir, p->d_act_src, p->d_act_sign, p->dya,
-                     p->dyc, p->learn_std ? p->dstd : (float*)nullptr, p->stats_part);
-  hipLaunchKernelGGL(reduce_rows_kernel, dim3(1), dim3(64), 0, s, p->stats_part, nblk, 5, stats_dev);
+                     p->dyc, p->learn_std ? p->dstd : (float*)nullptr, p->stats_part, p->imit_target, p->imit_mask, p->imit_coeff,
+                     p->imit_inv_count);
+  p->imit_target = nullptr; p->imit_mask = nullptr;   // armed for one call only
+  hipLaunchKernelGGL(reduce_rows_kernel, dim3(1), dim3(64), 0, s, p->stats_part, nblk, NSTAT, stats_dev);
   if (p->learn_std) {
     colsum_det(p->dstd, B, Op, p->A, grad + p->off_std, p->part, s);
     hipLaunchKernelGGL(entropy_grad_kernel, dim3(1), dim3(64), 0, s, theta + p->off_std, p->A, p->ent_coeff, grad + p->off_std);

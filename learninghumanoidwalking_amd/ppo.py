@@ -122,8 +122,7 @@ class PPO:
         self.recurrent = getattr(args, "recurrent", False)
         if self.recurrent:
             raise NotImplementedError("LSTM policies are outside the hot path built so far (SURVEY.md 8f n3)")
-        if getattr(args, "imitate", None):
-            raise NotImplementedError("--imitate is outside the hot path built so far (SURVEY.md 8f n4)")
+        self.imitate_coeff = float(getattr(args, "imitate_coeff", 0.3))
         self.batch_size = self.n_proc * self.max_traj_len
         self.total_steps = 0
         self.iteration_count = 0
@@ -182,6 +181,17 @@ class PPO:
                                      env_id_base=dist_utils.shard_env_ids(self.n_proc, self.rank))
         self.env.env_id_base = dist_utils.shard_env_ids(self.n_proc, self.rank)
         self.rollout = Rollout(self.env, self.kernels, self.max_traj_len, seed=env_seed ^ 0x5DEECE66D)
+        # --imitate: frozen expert + the env's projector (reference rl/algos/ppo.py:111-122)
+        self.base_policy, self.imitation_projector = None, None
+        if getattr(args, "imitate", None):
+            factory = getattr(spec, "imitation_projector", None)
+            projector = factory() if callable(factory) else None
+            if projector is None:
+                raise ValueError(f"--imitate was passed but env {type(spec).__name__} does not implement "
+                                 "imitation_projector(); cannot construct expert query.")
+            from .imitation import FrozenActor
+            self.base_policy = FrozenActor(args.imitate, self.device, max_rows=self.kernels.max_rows)
+            self.imitation_projector = projector
         self.policy = self.kernels  # attribute names the reference's tests look for
         self.critic = self.kernels
         self.last_losses = {}
@@ -226,10 +236,24 @@ class PPO:
         idx = torch.arange(B, dtype=torch.int32, device=self.device)
         k.grad_minibatch(xn, xm, act, old_log_probs.reshape(-1).to(self.device, torch.float32).contiguous(),
                          advantage_batch.reshape(-1).to(self.device, torch.float32).contiguous(),
-                         return_batch.reshape(-1).to(self.device, torch.float32).contiguous(), idx)
+                         return_batch.reshape(-1).to(self.device, torch.float32).contiguous(), idx,
+                         imitation=self._imitation_term(obs))
         self._allreduce_and_apply()
         s = k.stats.cpu().numpy()
-        return (float(s[0]), self._entropy_penalty(), float(s[1]), float(s[3]), float(s[2]), 0.0, float(s[4]))
+        return (float(s[0]), self._entropy_penalty(), float(s[1]), float(s[3]), float(s[2]), float(s[5]), float(s[4]))
+
+    def _imitation_term(self, obs_mb):
+        """Imitation loss inputs of one minibatch of RAW observations (ppo.py:360-368): ask the env's projector what the
+        expert should see, run the frozen expert, scatter its means into the dense target the loss kernel reads."""
+        if self.imitation_projector is None:
+            return None
+        from .imitation import dense_imitation_target
+        query = self.imitation_projector(obs_mb)
+        if not bool(query.sample_mask.any()):
+            return None
+        target = self.base_policy(query.expert_obs)
+        dense, mask, count = dense_imitation_target(query, target, obs_mb.shape[0], self.spec.act_dim)
+        return (self.imitate_coeff, dense, mask, count) if count > 0 else None
 
     def _entropy_penalty(self):
         sd = self.kernels.get_tensors()["stds"].numpy().astype(np.float64)
@@ -248,7 +272,8 @@ class PPO:
         adv = self._adv.reshape(-1)
         self._normalize_advantages(adv)
         ret = self._ret.reshape(-1)
-        xn, xm = k.normalize(ro.obs[:T].reshape(n_samples, -1))
+        raw_obs = ro.obs[:T].reshape(n_samples, -1)
+        xn, xm = k.normalize(raw_obs)
         act = ro.act.reshape(n_samples, -1)
         logp = ro.logp.reshape(-1)
         mb = int(self.minibatch_size or n_samples)
@@ -261,12 +286,14 @@ class PPO:
             g.manual_seed(base + itr * self.epochs + epoch + 1000003 * self.rank)
             perm = torch.randperm(n_samples, generator=g, device=self.device, dtype=torch.int64).to(torch.int32)
             for start in range(0, n_samples - mb + 1, mb):
-                k.grad_minibatch(xn, xm, act, logp, adv, ret, perm[start:start + mb])
+                mb_idx = perm[start:start + mb]
+                imit = self._imitation_term(raw_obs.index_select(0, mb_idx.long())) if self.imitation_projector is not None else None
+                k.grad_minibatch(xn, xm, act, logp, adv, ret, mb_idx, imitation=imit)
                 self._allreduce_and_apply()
                 n_updates += 1
         s = (k.stats / max(1, n_updates)).cpu().numpy()
         self.last_losses = dict(actor=float(s[0]), critic=float(s[1]), mirror=float(s[2]), kl=float(s[3]),
-                                clip_fraction=float(s[4]), entropy=self._entropy_penalty(), n_updates=n_updates)
+                                clip_fraction=float(s[4]), imitation=float(s[5]), entropy=self._entropy_penalty(), n_updates=n_updates)
         return self.last_losses
 
     def iterate(self, itr: int):
@@ -341,7 +368,7 @@ class PPO:
                 w(f"| {'Actor loss':>15} | {L['actor']:>15.3g} |\n")
                 w(f"| {'Critic loss':>15} | {L['critic']:>15.3g} |\n")
                 w(f"| {'Mirror loss':>15} | {L['mirror']:>15.3g} |\n")
-                w(f"| {'Imitation loss':>15} | {0.0:>15.3g} |\n")
+                w(f"| {'Imitation loss':>15} | {L.get('imitation', 0.0):>15.3g} |\n")
                 w(f"| {'Mean KL Div':>15} | {L['kl']:>15.3g} |\n")
                 w(f"| {'Mean Entropy':>15} | {L['entropy']:>15.3g} |\n")
                 w(f"| {'Clip Fraction':>15} | {L['clip_fraction']:>15.3g} |\n")

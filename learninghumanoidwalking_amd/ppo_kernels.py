@@ -181,8 +181,15 @@ class PpoKernels:
     def scale_shift(self, x, mean, inv):
         _lib.check(self._L.lhw_scale_shift(_p(x), x.numel(), float(mean), float(inv), self._stream()))
 
-    def grad_minibatch(self, xn, xm, act, old_logp, adv, ret, idx):
+    def grad_minibatch(self, xn, xm, act, old_logp, adv, ret, idx, imitation=None):
+        """``imitation`` = (coeff, target [B, A] f32, mask [B, A] u8, n_selected): the imitation term of this minibatch
+        (rows in ``idx`` order), see lhw_ppo_set_imitation."""
         B = idx.numel()
+        if imitation is not None:
+            coeff, target, mask, count = imitation
+            assert target.shape == (B, self.act_dim) and mask.shape == (B, self.act_dim) and mask.dtype == torch.uint8
+            self._imit_keep = (target.contiguous(), mask.contiguous())      # must outlive the asynchronous kernel
+            _lib.check(self._L.lhw_ppo_set_imitation(self._h, _p(self._imit_keep[0]), _p(self._imit_keep[1]), float(coeff), int(count)))
         _lib.check(self._L.lhw_ppo_grad(self._h, _p(self.theta), _p(self.grad), _p(xn), _p(xm), _p(act), _p(old_logp),
                                         _p(adv), _p(ret), _p(idx), B, _p(self.stats), self._stream()))
 

@@ -108,8 +108,9 @@ class OraclePPO:
     def log_prob(self, obs, act):
         return torch.distributions.Normal(self.mu(obs), self.stds).log_prob(act).sum(-1, keepdim=True)
 
-    def update(self, obs, act, ret, adv, old_logp):
-        """obs [B,D], act [B,A], ret/adv/old_logp [B,1] float32 tensors."""
+    def update(self, obs, act, ret, adv, old_logp, imit=None):
+        """obs [B,D], act [B,A], ret/adv/old_logp [B,1] float32 tensors.  imit = (coeff, sample_mask [B] bool,
+        action_indices [k] long, expert_means [n_active, k]) adds the imitation term of ppo.py:360-368."""
         pdf = torch.distributions.Normal(self.mu(obs), self.stds)
         logp = pdf.log_prob(act).sum(-1, keepdim=True)
         ratio = (logp - old_logp).exp()
@@ -131,7 +132,13 @@ class OraclePPO:
             mirror_loss = torch.zeros_like(actor_loss)
         with torch.no_grad():
             approx_kl = torch.mean((ratio - 1) - (logp - old_logp))
-        total = actor_loss + self.mir * mirror_loss + self.ent * entropy_penalty + critic_loss
+        imitation_loss = torch.zeros_like(actor_loss)
+        imit_coeff = 0.0
+        if imit is not None and bool(imit[1].any()):
+            imit_coeff, smask, aidx, target = imit
+            pred = pdf.mean[smask][:, aidx]
+            imitation_loss = (pred - target).pow(2).mean()
+        total = actor_loss + self.mir * mirror_loss + imit_coeff * imitation_loss + self.ent * entropy_penalty + critic_loss
         self.aopt.zero_grad()
         self.copt.zero_grad()
         total.backward()
@@ -140,5 +147,5 @@ class OraclePPO:
         torch.nn.utils.clip_grad_norm_(self.critic, self.gc)
         self.aopt.step()
         self.copt.step()
-        return (actor_loss.item(), entropy_penalty.item(), critic_loss.item(), approx_kl.item(), mirror_loss.item(), 0.0,
-                clip_fraction)
+        return (actor_loss.item(), entropy_penalty.item(), critic_loss.item(), approx_kl.item(), mirror_loss.item(),
+                imitation_loss.item(), clip_fraction)

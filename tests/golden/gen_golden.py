@@ -103,7 +103,7 @@ JVRC_MIR_ACT = [6, -7, -8, 9, -10, 11, 0.1, -1, -2, 3, -4, 5]
 JVRC_CLOCK = [29, 30]
 
 
-def gen_ppo(tag, hidden, B, mirror, learn_std, n_updates, seed):
+def gen_ppo(tag, hidden, B, mirror, learn_std, n_updates, seed, imitate=False):
     from argparse import Namespace
     from rl.algos.ppo import PPO
     from rl.envs.wrappers import SymmetricEnv
@@ -124,6 +124,19 @@ def gen_ppo(tag, hidden, B, mirror, learn_std, n_updates, seed):
     ppo.old_policy = copy.deepcopy(policy)
     ppo.clip, ppo.ent_coeff, ppo.mirror_coeff, ppo.imitate_coeff, ppo.grad_clip = 0.2, 0.01 if learn_std else 0.0, 0.4, 0.3, 0.5
     ppo.recurrent, ppo.imitation_projector, ppo.base_policy = False, None, None
+    base = None
+    if imitate:   # rl/algos/ppo.py:360-368 with an env-style projector (rl/algos/imitation.py contract)
+        from rl.algos.imitation import ImitationQuery
+        base = Gaussian_FF_Actor(20, 3, layers=(32, 32), init_std=0.1, learn_std=False, bounded=False)
+        base.obs_mean, base.obs_std = torch.zeros(20), torch.ones(20)
+        base.eval()
+
+        class Proj:
+            def __call__(self, obs_batch):
+                mask = obs_batch[:, 0] > 0
+                return ImitationQuery(expert_obs=obs_batch[mask][:, :20], sample_mask=mask, action_indices=torch.tensor([0, 2, 5]))
+
+        ppo.imitation_projector, ppo.base_policy = Proj(), base
     ppo.actor_optimizer = torch.optim.Adam(policy.parameters(), lr=3e-4, eps=1e-5)
     ppo.critic_optimizer = torch.optim.Adam(critic.parameters(), lr=3e-4, eps=1e-5)
     sym = SymmetricEnv.__new__(SymmetricEnv)
@@ -142,7 +155,12 @@ def gen_ppo(tag, hidden, B, mirror, learn_std, n_updates, seed):
              critic.critic_layers[1].bias, critic.network_out.weight, critic.network_out.bias]
         return [x.detach().numpy().copy() for x in a], [x.detach().numpy().copy() for x in c]
 
-    out = dict(obs_mean=obs_mean, obs_std=obs_std, hidden=hidden, learn_std=int(learn_std), mirror=int(mirror))
+    out = dict(obs_mean=obs_mean, obs_std=obs_std, hidden=hidden, learn_std=int(learn_std), mirror=int(mirror), imitate=int(imitate))
+    if imitate:
+        eb = [base.actor_layers[0].weight, base.actor_layers[0].bias, base.actor_layers[1].weight, base.actor_layers[1].bias,
+              base.means.weight, base.means.bias]
+        for kk, w in enumerate(eb):
+            out[f"e_{kk}"] = w.detach().numpy().copy()
     a0, c0 = weights(policy, critic)
     for k, w in enumerate(a0):
         out[f"a0_{k}"] = w
@@ -372,6 +390,9 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "stepping":     # regenerate only the stepping-task fixture
         gen_stepping()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "imitate":
+        gen_ppo("h64_imitate", 64, 80, True, False, 2, 14, imitate=True)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "misc":
         gen_misc()
         sys.exit(0)
@@ -381,5 +402,6 @@ if __name__ == "__main__":
     gen_ppo("h64_mirror", 64, 96, True, False, 2, 11)
     gen_ppo("h64_learnstd", 64, 70, False, True, 2, 12)
     gen_ppo("h256_mirror", 256, 128, True, False, 1, 13)
+    gen_ppo("h64_imitate", 64, 80, True, False, 2, 14, imitate=True)
     gen_stepping()
     print("golden fixtures written to", OUT)

@@ -96,3 +96,47 @@ def test_bench_two_ranks_sharing_one_gpu():
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
     assert abs(d["value"] - 2 * 128 * 8 / (d["ms_per_step"] / 1e3)) / d["value"] < 1e-6   # whole-job aggregate
+
+
+def test_ppo_imitate_wiring(tmp_path):
+    """--imitate: expert checkpoint + env projector are picked up, the imitation loss is reported, and an env without a
+    projector raises the reference's error (reference tests/test_imitation.py)."""
+    import torch
+    from types import SimpleNamespace
+    from learninghumanoidwalking_amd.checkpoint import save_reference_checkpoint
+    from learninghumanoidwalking_amd.envs import CartpoleSpec, JvrcWalkSpec
+    from learninghumanoidwalking_amd.imitation import ImitationQuery
+    from learninghumanoidwalking_amd.ppo import PPO
+    from learninghumanoidwalking_amd.ppo_kernels import PpoKernels, reference_init
+
+    # expert: a 37 -> 12 actor written in the reference's checkpoint format
+    ek = PpoKernels(37, 12, hidden=256, max_rows=64)
+    ek.set_tensors(reference_init(37, 12, 256, 0.2, generator_seed=5))
+    ek.set_obs_norm(np.zeros(37), np.ones(37))
+    expert_path = os.path.join(tmp_path, "actor.pt")
+    save_reference_checkpoint(ek.get_tensors(), torch.zeros(37), torch.ones(37), False, expert_path, os.path.join(tmp_path, "critic.pt"))
+    assert os.path.exists(expert_path)
+
+    class Projector:
+        def __call__(self, obs_batch):
+            mask = obs_batch[:, 33] > 0.5           # standing-mode samples only
+            return ImitationQuery(expert_obs=obs_batch[mask], sample_mask=mask, action_indices=torch.arange(12))
+
+    class Spec(JvrcWalkSpec):
+        def imitation_projector(self):
+            return Projector()
+
+    def args(**kw):
+        d = dict(gamma=0.99, lam=0.95, lr=3e-4, eps=1e-5, entropy_coeff=0.0, clip=0.2, minibatch_size=256, epochs=1, max_traj_len=8,
+                 num_procs=64, num_envs=64, max_grad_norm=0.5, mirror_coeff=0.4, eval_freq=10**9, recurrent=False, imitate=expert_path,
+                 imitate_coeff=0.3, learn_std=False, std_dev=0.223, no_mirror=False, continued=None, logdir=str(tmp_path / "log"),
+                 device_index=0)
+        d.update(kw)
+        return SimpleNamespace(**d)
+
+    algo = PPO(Spec, args(), seed=1)
+    assert algo.imitation_projector is not None and algo.base_policy is not None
+    algo.iterate(0)
+    assert algo.last_losses["imitation"] > 0
+    with pytest.raises(ValueError, match="imitation_projector"):
+        PPO(CartpoleSpec, args(), seed=1)

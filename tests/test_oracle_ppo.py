@@ -54,3 +54,22 @@ def test_update_actor_critic_matches_reference(tag):
         np.testing.assert_allclose(orc.actor[k].detach().numpy(), g[f"a1_{k}"], rtol=0, atol=2e-6)
         np.testing.assert_allclose(orc.critic[k].detach().numpy(), g[f"c1_{k}"], rtol=0, atol=2e-6)
     np.testing.assert_allclose(orc.stds.detach().numpy(), g["stds1"], rtol=0, atol=2e-6)
+
+
+def test_update_with_imitation_matches_reference():
+    """Reference PPO.update_actor_critic with an imitation projector + frozen expert (gen_golden.py gen_ppo imitate=True)."""
+    g = np.load(os.path.join(G, "ppo_h64_imitate.npz"))
+    mo, ma = po.mirror_tables(MIR_OBS, [29, 30]), po.mirror_tables(MIR_ACT)
+    orc = po.OraclePPO([g[f"a0_{k}"] for k in range(6)], [g[f"c0_{k}"] for k in range(6)], g["stds0"], g["obs_mean"], g["obs_std"],
+                       mirror_obs=mo, mirror_act=ma)
+    expert = [torch.tensor(g[f"e_{k}"]) for k in range(6)]
+    for u in range(len(g["scalars"])):
+        t = lambda k: torch.tensor(g[f"{k}_{u}"])
+        obs = t("obs")
+        smask = obs[:, 0] > 0
+        target = po.mlp(obs[smask][:, :20], *expert)          # expert normalisation is the identity in the fixture
+        res = orc.update(obs, t("act"), t("ret"), t("adv"), t("old_logp"), imit=(0.3, smask, torch.tensor([0, 2, 5]), target))
+        np.testing.assert_allclose(res, g["scalars"][u], rtol=2e-5, atol=2e-6)
+        assert res[5] > 0
+    for k in range(6):
+        np.testing.assert_allclose(orc.actor[k].detach().numpy(), g[f"a1_{k}"], rtol=0, atol=2e-6)

@@ -200,3 +200,72 @@ def test_update_is_bitwise_deterministic():
         outs.append((k.theta.clone(), k.stats.clone()))
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][0], outs[2][0])
     assert torch.equal(outs[0][1][:5], outs[1][1][:5])
+
+
+def _imit_inputs(g, u, coeff=0.3):
+    """Dense imitation target / mask of update u of the imitation fixture, built with the oracle MLP as the expert."""
+    from oracle import ppo_oracle as po
+    from learninghumanoidwalking_amd.imitation import ImitationQuery, dense_imitation_target
+    obs = torch.tensor(g[f"obs_{u}"])
+    smask = obs[:, 0] > 0
+    expert = [torch.tensor(g[f"e_{k}"]) for k in range(6)]
+    target = po.mlp(obs[smask][:, :20], *expert)
+    q = ImitationQuery(expert_obs=obs[smask][:, :20], sample_mask=smask, action_indices=torch.tensor([0, 2, 5]))
+    dense, mask, count = dense_imitation_target(q, target.cuda(), obs.shape[0], 12)
+    return (coeff, dense, mask, count), (smask, target)
+
+
+def test_update_with_imitation_matches_reference_fixture():
+    g = np.load(os.path.join(G, "ppo_h64_imitate.npz"))
+    k = _kernels(g, 64, True, False)
+    k.set_tensors({f"a_{n}": g[f"a0_{i}"] for i, n in enumerate(NAMES)})
+    k.set_tensors({f"c_{n}": g[f"c0_{i}"] for i, n in enumerate(NAMES)})
+    k.set_tensors({"stds": g["stds0"]})
+    for u in range(len(g["scalars"])):
+        c = lambda n: torch.tensor(g[f"{n}_{u}"]).cuda().contiguous()
+        obs = c("obs")
+        xn, xm = k.normalize(obs)
+        k.stats.zero_()
+        idx = torch.arange(obs.shape[0], dtype=torch.int32, device="cuda")
+        imit, _ = _imit_inputs(g, u)
+        k.grad_minibatch(xn, xm, c("act"), c("old_logp").view(-1), c("adv").view(-1), c("ret").view(-1), idx, imitation=imit)
+        k.apply()
+        s = k.stats.cpu().numpy()
+        ref = g["scalars"][u]
+        np.testing.assert_allclose(s[5], ref[5], rtol=1e-4, atol=1e-9)            # imitation loss
+        np.testing.assert_allclose([s[0], s[1], s[2]], [ref[0], ref[2], ref[4]], rtol=1e-4, atol=2e-6)
+    t = k.get_tensors()
+    for i, n in enumerate(NAMES):
+        np.testing.assert_allclose(t[f"a_{n}"].numpy(), g[f"a1_{i}"], rtol=0, atol=3e-6, err_msg=f"actor {n}")
+
+
+def test_imitation_gradient_against_oracle_with_a_dominant_coefficient():
+    """With coefficient 200 the imitation term dominates the actor gradient: post-Adam actor weights must follow the
+    oracle's autograd (a missing / mis-scaled term would show at the 1e-4 level, the bar is 5e-6)."""
+    from oracle import ppo_oracle as po
+    g = np.load(os.path.join(G, "ppo_h64_imitate.npz"))
+    k = _kernels(g, 64, True, False)
+    k.set_tensors({f"a_{n}": g[f"a0_{i}"] for i, n in enumerate(NAMES)})
+    k.set_tensors({f"c_{n}": g[f"c0_{i}"] for i, n in enumerate(NAMES)})
+    k.set_tensors({"stds": g["stds0"]})
+    mo, ma = po.mirror_tables(MIR_OBS, [29, 30]), po.mirror_tables(MIR_ACT)
+    orc = po.OraclePPO([g[f"a0_{i}"] for i in range(6)], [g[f"c0_{i}"] for i in range(6)], g["stds0"], g["obs_mean"], g["obs_std"],
+                       mirror_obs=mo, mirror_act=ma)
+    for u in range(2):
+        c = lambda n: torch.tensor(g[f"{n}_{u}"]).cuda().contiguous()
+        obs = c("obs")
+        xn, xm = k.normalize(obs)
+        k.stats.zero_()
+        idx = torch.arange(obs.shape[0], dtype=torch.int32, device="cuda")
+        imit, (smask, target) = _imit_inputs(g, u, coeff=200.0)
+        k.grad_minibatch(xn, xm, c("act"), c("old_logp").view(-1), c("adv").view(-1), c("ret").view(-1), idx, imitation=imit)
+        k.apply()
+        tt = lambda n: torch.tensor(g[f"{n}_{u}"])
+        res = orc.update(tt("obs"), tt("act"), tt("ret"), tt("adv"), tt("old_logp"), imit=(200.0, smask, torch.tensor([0, 2, 5]), target))
+        np.testing.assert_allclose(k.stats.cpu().numpy()[5], res[5], rtol=1e-4)
+    t = k.get_tensors()
+    for i, n in enumerate(NAMES):
+        np.testing.assert_allclose(t[f"a_{n}"].numpy(), orc.actor[i].detach().numpy(), rtol=0, atol=5e-6, err_msg=f"actor {n}")
+    # the term did matter: weights differ from the no-imitation fixture by much more than the tolerance
+    g0 = np.load(os.path.join(G, "ppo_h64_imitate.npz"))
+    assert np.abs(t["a_w3"].numpy() - g0["a1_4"]).max() > 1e-4
