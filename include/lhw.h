@@ -211,6 +211,35 @@ int lhw_ppo_grad(LhwPpo* ppo, const float* theta, float* grad, const float* xn, 
 int lhw_ppo_apply(LhwPpo* ppo, float* theta, float* grad, float* adam_m, float* adam_v, int64_t step, float grad_scale,
                   void* stream);
 
+/* ------------------------------------------------------------------ recurrent PPO (LSTM actor / critic)
+ * Gaussian_LSTM_Actor / LSTM_V: two stacked LSTMCells (hidden) + linear read-out (reference rl/policies/actor.py:191-286,
+ * critic.py:52-112); rollout one cell step per control step with state reset at episode starts
+ * (rl/workers/rollout_worker.py:134-137,174-177); update by BPTT over whole trajectories (rl/algos/ppo.py:512-533) --
+ * a minibatch is a set of env columns of the time-major rollout, with the state zeroed where an episode starts inside a
+ * column (equivalent to the reference's padded trajectory list with masked losses).  Uses LhwPpoConfig (max_rows unused). */
+typedef struct LhwRnn LhwRnn;
+int lhw_rnn_create(const LhwPpoConfig* cfg, int32_t seq_len, int32_t seq_cols, int32_t rollout_rows, LhwRnn** out);
+int lhw_rnn_destroy(LhwRnn* rnn);
+int64_t lhw_rnn_param_count(const LhwRnn* rnn);
+/* offsets: [0..7] actor Wcat1 ([4H][pad4(obs)+H] = [W_ih | W_hh]) b_ih1 b_hh1 Wcat2 ([4H][2H]) b_ih2 b_hh2 Wout bout,
+ * [8] stds, [9..16] critic likewise, [17] padded obs width, [18] padded actor read-out width */
+int lhw_rnn_layout(const LhwRnn* rnn, int64_t* out19);
+/* one rollout step on N rows; reset [N] (device, may be NULL) marks rows whose episode starts with this observation;
+ * commit != 0 advances the stored hidden state, 0 evaluates only (terminal / final values) */
+int lhw_rnn_forward(LhwRnn* rnn, const float* theta, const float* obs, int64_t N, const float* obs_mean, const float* obs_std,
+                    const uint8_t* reset, uint64_t seed, uint32_t env_id_base, uint32_t counter, int deterministic, int commit,
+                    float* mu, float* act, float* logp, float* value, void* stream);
+/* BPTT of one minibatch = columns cols[0..B) of the time-major [T][N] rollout (xn / xm [T*N][pad4(obs)] normalised /
+ * mirrored observations from lhw_ppo_normalize-compatible layout, done = LHW_DONE_* flags); accumulates grad, stats_dev[0..5] */
+int lhw_rnn_grad(LhwRnn* rnn, const float* theta, float* grad, int32_t T, int32_t N, const float* xn, const float* xm,
+                 const float* act, const float* old_logp, const float* adv, const float* ret, const uint8_t* done,
+                 const int32_t* cols, int32_t B, float* stats_dev, void* stream);
+int lhw_rnn_apply(LhwRnn* rnn, float* theta, float* grad, float* adam_m, float* adam_v, int64_t step, float grad_scale,
+                  void* stream);
+/* xn (and xm) for the recurrent path: same as lhw_ppo_normalize but on an LhwRnn handle */
+int lhw_rnn_normalize(LhwRnn* rnn, const float* obs, int64_t R, const float* obs_mean, const float* obs_std, float* xn,
+                      float* xm, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

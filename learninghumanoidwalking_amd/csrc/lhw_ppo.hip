@@ -388,15 +388,19 @@ __global__ void __launch_bounds__(256) ppo_loss_kernel(int B, int Rcap, int A, i
                                                        float* __restrict__ dstd /* [B][Op] or NULL */, float* __restrict__ stats_part,
                                                        const float* __restrict__ imit_target /* [B][A] or NULL */,
                                                        const unsigned char* __restrict__ imit_mask /* [B][A] */, float imit_coeff,
-                                                       float imit_inv_count) {
+                                                       float imit_inv_count, int seqB) {
   int m = blockIdx.x * blockDim.x + threadIdx.x;
+  // row of sample m in the actor output buffer, and of its mirrored twin: FF minibatch: m and Rcap + m; recurrent minibatch
+  // (time-major, seqB columns per step, mirrored columns appended per step): t * 2 seqB + b and + seqB
+  size_t rn = (size_t)m, rm = (size_t)Rcap + m;
+  if (seqB > 0 && use_mirror) { rn = (size_t)(m / seqB) * (2 * (size_t)seqB) + (size_t)(m % seqB); rm = rn + seqB; }
   float s_actor = 0, s_critic = 0, s_mirror = 0, s_kl = 0, s_cf = 0, s_imit = 0;
   const float invB = 1.f / (float)B, invBA = 1.f / ((float)B * (float)A);
   __shared__ float red[NSTAT][4];
   if (m < B) {
     float lp = 0.f;
     for (int a = 0; a < A; a++) {
-      float d = (act[(size_t)m * A + a] - ya[(size_t)m * Op + a]) / stdv[a];
+      float d = (act[(size_t)m * A + a] - ya[rn * Op + a]) / stdv[a];
       lp += -0.5f * d * d - logf(stdv[a]) - 0.9189385332046727f;
     }
     float logr = lp - old_logp[m];
@@ -414,21 +418,21 @@ __global__ void __launch_bounds__(256) ppo_loss_kernel(int B, int Rcap, int A, i
     s_critic = e * e;
     dyc[(size_t)m * 4] = -2.f * e * invB;
     dyc[(size_t)m * 4 + 1] = 0.f; dyc[(size_t)m * 4 + 2] = 0.f; dyc[(size_t)m * 4 + 3] = 0.f;
-    if (use_mirror) for (int a = 0; a < Op; a++) dya[((size_t)Rcap + m) * Op + a] = 0.f;
+    if (use_mirror) for (int a = 0; a < Op; a++) dya[rm * Op + a] = 0.f;
     for (int a = 0; a < Op; a++) {
       float g = 0.f, gs = 0.f;
       if (a < A) {
-        float mu = ya[(size_t)m * Op + a], sd = stdv[a], x = act[(size_t)m * A + a];
+        float mu = ya[rn * Op + a], sd = stdv[a], x = act[(size_t)m * A + a];
         g = dlp * (x - mu) / (sd * sd);
         gs = dlp * ((x - mu) * (x - mu) / (sd * sd * sd) - 1.f / sd);
         if (use_mirror) {
           // mirror_actions[a] = sign[a] * mu_mir[src[a]]  (== mu_mir @ M_a, rl/envs/wrappers.py:49-51)
-          float mm = act_sign[a] * ya[((size_t)Rcap + m) * Op + act_src[a]];
+          float mm = act_sign[a] * ya[rm * Op + act_src[a]];
           float diff = mu - mm;
           s_mirror += diff * diff;
           g += mirror_coeff * 2.f * diff * invBA;
           // gradient wrt the mirrored-pass output it came from (act_src is a permutation: each slot written once)
-          dya[((size_t)Rcap + m) * Op + act_src[a]] = -mirror_coeff * 2.f * diff * invBA * act_sign[a];
+          dya[rm * Op + act_src[a]] = -mirror_coeff * 2.f * diff * invBA * act_sign[a];
         }
         if (imit_target && imit_mask[(size_t)m * A + a]) {
           float diff = mu - imit_target[(size_t)m * A + a];
@@ -436,7 +440,7 @@ __global__ void __launch_bounds__(256) ppo_loss_kernel(int B, int Rcap, int A, i
           g += imit_coeff * 2.f * diff * imit_inv_count;
         }
       }
-      dya[(size_t)m * Op + a] = g;
+      dya[rn * Op + a] = g;
       if (dstd) dstd[(size_t)m * Op + a] = gs;
     }
   }
@@ -751,7 +755,7 @@ extern "C" int lhw_ppo_grad(LhwPpo* p, const float* theta, float* grad, const fl
   hipLaunchKernelGGL(ppo_loss_kernel, dim3(nblk), dim3(256), 0, s, B, R, p->A, Op, p->ya, p->yc, p->mb_act, p->mb_logp,
                      p->mb_adv, p->mb_ret, theta + p->off_std, p->clip, p->mirror_coeff, mir, p->d_act_src, p->d_act_sign, p->dya,
                      p->dyc, p->learn_std ? p->dstd : (float*)nullptr, p->stats_part, p->imit_target, p->imit_mask, p->imit_coeff,
-                     p->imit_inv_count);
+                     p->imit_inv_count, 0);
   p->imit_target = nullptr; p->imit_mask = nullptr;   // armed for one call only
   hipLaunchKernelGGL(reduce_rows_kernel, dim3(1), dim3(64), 0, s, p->stats_part, nblk, NSTAT, stats_dev);
   if (p->learn_std) {
@@ -768,6 +772,22 @@ extern "C" int lhw_ppo_grad(LhwPpo* p, const float* theta, float* grad, const fl
   return LHW_OK;
 }
 
+// dual clip_grad_norm_ + Adam on the two parameter groups [0, na) and [off_critic, off_critic + nc) of a flat vector
+static void clip_and_adam(float* theta, float* grad, float* adam_m, float* adam_v, size_t na, size_t off_critic, size_t nc,
+                          int64_t step, float grad_scale, float* norm_part, float* stats, float grad_clip, float lr, float beta1,
+                          float beta2, float adam_eps, hipStream_t s) {
+  hipLaunchKernelGGL(sumsq_kernel, dim3(SUMSQ_BLOCKS), dim3(256), 0, s, grad, na, grad_scale, norm_part);
+  hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(64), 0, s, norm_part, SUMSQ_BLOCKS, stats + 8);
+  hipLaunchKernelGGL(sumsq_kernel, dim3(SUMSQ_BLOCKS), dim3(256), 0, s, grad + off_critic, nc, grad_scale, norm_part + SUMSQ_BLOCKS);
+  hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(64), 0, s, norm_part + SUMSQ_BLOCKS, SUMSQ_BLOCKS, stats + 9);
+  const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
+  hipLaunchKernelGGL(adam_kernel, dim3((na + 255) / 256), dim3(256), 0, s, theta, grad, adam_m, adam_v, na, grad_scale, stats + 8,
+                     grad_clip, lr, beta1, beta2, adam_eps, bc1, sqrtf(bc2));
+  hipLaunchKernelGGL(adam_kernel, dim3((nc + 255) / 256), dim3(256), 0, s, theta + off_critic, grad + off_critic,
+                     adam_m + off_critic, adam_v + off_critic, nc, grad_scale, stats + 9, grad_clip, lr, beta1, beta2, adam_eps, bc1,
+                     sqrtf(bc2));
+}
+
 // clip_grad_norm_ on the actor and critic parameter groups separately, then one Adam step each; zeroes grad.
 // grad_scale multiplies the gradient first (1/world_size after a sum all-reduce).  step is the 1-based Adam step count.
 extern "C" int lhw_ppo_apply(LhwPpo* p, float* theta, float* grad, float* adam_m, float* adam_v, int64_t step, float grad_scale,
@@ -776,18 +796,433 @@ extern "C" int lhw_ppo_apply(LhwPpo* p, float* theta, float* grad, float* adam_m
   HIPCHK(hipSetDevice(p->device));
   hipStream_t s = (hipStream_t)stream;
   const size_t na = p->learn_std ? p->off_std + p->A : p->off_std;  // actor group (+ stds if they are parameters)
-  const size_t nc = p->lc.total;
-  hipLaunchKernelGGL(sumsq_kernel, dim3(SUMSQ_BLOCKS), dim3(256), 0, s, grad, na, grad_scale, p->norm_part);
-  hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(64), 0, s, p->norm_part, SUMSQ_BLOCKS, p->stats + 8);
-  hipLaunchKernelGGL(sumsq_kernel, dim3(SUMSQ_BLOCKS), dim3(256), 0, s, grad + p->off_critic, nc, grad_scale, p->norm_part + SUMSQ_BLOCKS);
-  hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(64), 0, s, p->norm_part + SUMSQ_BLOCKS, SUMSQ_BLOCKS, p->stats + 9);
-  const float bc1 = 1.f - powf(p->beta1, (float)step), bc2 = 1.f - powf(p->beta2, (float)step);
-  hipLaunchKernelGGL(adam_kernel, dim3((na + 255) / 256), dim3(256), 0, s, theta, grad, adam_m, adam_v, na, grad_scale, p->stats + 8,
-                     p->grad_clip, p->lr, p->beta1, p->beta2, p->adam_eps, bc1, sqrtf(bc2));
-  hipLaunchKernelGGL(adam_kernel, dim3((nc + 255) / 256), dim3(256), 0, s, theta + p->off_critic, grad + p->off_critic,
-                     adam_m + p->off_critic, adam_v + p->off_critic, nc, grad_scale, p->stats + 9, p->grad_clip, p->lr, p->beta1,
-                     p->beta2, p->adam_eps, bc1, sqrtf(bc2));
+  clip_and_adam(theta, grad, adam_m, adam_v, na, p->off_critic, p->lc.total, step, grad_scale, p->norm_part, p->stats, p->grad_clip,
+                p->lr, p->beta1, p->beta2, p->adam_eps, s);
   if (!p->learn_std) HIPCHK(hipMemsetAsync(grad + p->off_std, 0, sizeof(float) * pad4(p->A), s));
+  HIPCHK(hipGetLastError());
+  return LHW_OK;
+}
+
+// =========================================================================================== recurrent (LSTM) PPO
+// Gaussian_LSTM_Actor / LSTM_V (reference rl/policies/actor.py:191-286, critic.py:52-112): two stacked LSTMCells and a
+// linear read-out per network; rollout = one cell step per control step with the hidden state reset at episode starts
+// (rl/workers/rollout_worker.py:134-137,174-177); update = back-propagation through time over whole trajectories
+// (rl/algos/ppo.py:512-533).  Where the reference pads a list of trajectories to a common length and masks the losses,
+// the device keeps the rollout's time-major layout: a minibatch is a set of env columns over all T steps, the hidden and
+// cell state are zeroed wherever an episode starts inside a column, and every (t, column) sample is valid -- the same
+// per-trajectory computation and the same loss mean, without padding.
+//
+// Per cell the input and recurrent weights are stored side by side, W = [W_ih | W_hh] ([4H][K], gate order i f g o as
+// in torch), so one MFMA GEMM over the concatenated input [x_t | h_{t-1}] gives the gate pre-activations; the two bias
+// vectors stay separate parameters (they receive the same gradient).
+struct LstmLayout {
+  int D, Dp, H, O, Op, K1;
+  size_t w1, bi1, bh1, w2, bi2, bh2, wo, bo, total;
+};
+static LstmLayout lstm_layout(int D, int H, int O) {
+  LstmLayout L;
+  L.D = D; L.Dp = pad4(D); L.H = H; L.O = O; L.Op = pad4(O); L.K1 = L.Dp + H;
+  size_t o = 0;
+  L.w1 = o; o += (size_t)4 * H * L.K1;
+  L.bi1 = o; o += 4 * H;
+  L.bh1 = o; o += 4 * H;
+  L.w2 = o; o += (size_t)4 * H * 2 * H;
+  L.bi2 = o; o += 4 * H;
+  L.bh2 = o; o += 4 * H;
+  L.wo = o; o += (size_t)L.Op * H;
+  L.bo = o; o += L.Op;
+  L.total = o;
+  return L;
+}
+
+struct SeqWs {  // activations of one network over a [T][Bt] minibatch (rows r = t * Bt + b)
+  float *xh1 = nullptr, *xh2 = nullptr;  // [R][K1] = [x_t | h1_{t-1}], [R][2H] = [h1_t | h2_{t-1}]
+  float *g1 = nullptr, *g2 = nullptr;    // [R][4H] activated gates (overwritten by d loss / d pre-activation in the backward pass)
+  float *c1 = nullptr, *c2 = nullptr;    // [R][H] cell states
+  float *h2 = nullptr, *y = nullptr;     // [R][H] top hidden state, [R][Op] read-out
+  float *dy = nullptr, *dh2 = nullptr;   // [R][Op], [R][H]
+  float *dx2 = nullptr, *dx1h = nullptr, *dcar1 = nullptr, *dcar2 = nullptr;  // per-step scratch [Bt][2H], [Bt][H], [Bt][H] x2
+  int Bt = 0;
+};
+
+struct LhwRnn {
+  int device, D, A, H, learn_std, T, Bmax, Nroll, use_mirror;
+  float clip, ent_coeff, mirror_coeff, grad_clip, lr, adam_eps, beta1, beta2;
+  LstmLayout la, lc;
+  size_t off_actor, off_std, off_critic, n_params;
+  int *d_obs_src = nullptr, *d_act_src = nullptr;
+  float *d_obs_sign = nullptr, *d_act_sign = nullptr;
+  // rollout: per network the concatenated step inputs hold the hidden state between calls, cells in rc
+  float *rxh1[2] = {nullptr, nullptr}, *rxh2[2] = {nullptr, nullptr}, *rc1[2] = {nullptr, nullptr}, *rc2[2] = {nullptr, nullptr};
+  float *rg = nullptr, *rh2 = nullptr, *ry = nullptr, *rcs = nullptr;  // step scratch: gates [N][4H], top hidden [N][H], read-out [N][Op], cells [N][H]
+  SeqWs wa, wc;
+  unsigned char* reset = nullptr;  // [T][Bmax]
+  float *mb_act = nullptr, *mb_logp = nullptr, *mb_adv = nullptr, *mb_ret = nullptr, *dstd = nullptr;
+  float *stats = nullptr, *stats_part = nullptr, *norm_part = nullptr, *part = nullptr;
+  std::vector<void*> allocs;
+};
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+
+// gates G [B][4H] (pre-activation, biases not yet added) -> activated in place; c, h of this step.
+// h goes to dest_a (always) and dest_b (zeroed for rows whose NEXT step starts an episode: the recurrent slot).
+__global__ void __launch_bounds__(256) lstm_cell_fwd_kernel(int B, int H, float* __restrict__ G, const float* __restrict__ bi,
+                                                            const float* __restrict__ bh, const float* __restrict__ c_prev,
+                                                            const unsigned char* __restrict__ reset_t, float* __restrict__ c_out,
+                                                            float* __restrict__ dest_a, int lda, float* __restrict__ dest_b, int ldb,
+                                                            const unsigned char* __restrict__ reset_next) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)B * H) return;
+  const int b = (int)(i / H), j = (int)(i - (size_t)b * H);
+  float* g = G + (size_t)b * 4 * H;
+  const float gi = sigmoidf_(g[j] + bi[j] + bh[j]);
+  const float gf = sigmoidf_(g[H + j] + bi[H + j] + bh[H + j]);
+  const float gg = tanhf(g[2 * H + j] + bi[2 * H + j] + bh[2 * H + j]);
+  const float go = sigmoidf_(g[3 * H + j] + bi[3 * H + j] + bh[3 * H + j]);
+  const float cp = (c_prev && !(reset_t && reset_t[b])) ? c_prev[(size_t)b * H + j] : 0.f;
+  const float c = gf * cp + gi * gg;
+  const float h = go * tanhf(c);
+  g[j] = gi; g[H + j] = gf; g[2 * H + j] = gg; g[3 * H + j] = go;
+  c_out[(size_t)b * H + j] = c;
+  dest_a[(size_t)b * lda + j] = h;
+  if (dest_b) dest_b[(size_t)b * ldb + j] = (reset_next && reset_next[b]) ? 0.f : h;
+}
+
+// backward of one cell step: G holds the activated gates and receives d loss / d pre-activation; dcar carries d loss / d c
+// to the previous step (zero across an episode start)
+__global__ void __launch_bounds__(256) lstm_cell_bwd_kernel(int B, int H, float* __restrict__ G, const float* __restrict__ c,
+                                                            const float* __restrict__ c_prev, const unsigned char* __restrict__ reset_t,
+                                                            const float* __restrict__ dh_a, int lda, const float* __restrict__ dh_b, int ldb,
+                                                            const unsigned char* __restrict__ reset_next, float* __restrict__ dcar) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)B * H) return;
+  const int b = (int)(i / H), j = (int)(i - (size_t)b * H);
+  float* g = G + (size_t)b * 4 * H;
+  const float gi = g[j], gf = g[H + j], gg = g[2 * H + j], go = g[3 * H + j];
+  const bool rst = reset_t && reset_t[b];
+  const float cp = (c_prev && !rst) ? c_prev[(size_t)b * H + j] : 0.f;
+  float dh = dh_a[(size_t)b * lda + j];
+  if (dh_b && !(reset_next && reset_next[b])) dh += dh_b[(size_t)b * ldb + j];
+  const float tc = tanhf(c[(size_t)b * H + j]);
+  const float dct = dh * go * (1.f - tc * tc) + dcar[(size_t)b * H + j];
+  dcar[(size_t)b * H + j] = rst ? 0.f : dct * gf;
+  g[j] = dct * gg * gi * (1.f - gi);
+  g[H + j] = dct * cp * gf * (1.f - gf);
+  g[2 * H + j] = dct * gi * (1.f - gg * gg);
+  g[3 * H + j] = dh * tc * go * (1.f - go);
+}
+
+// (obs - mean) / std written into the x part of a concatenated input buffer (row stride ld)
+__global__ void normalize_ld_kernel(const float* __restrict__ obs, int D, int Dp, size_t R, const float* __restrict__ mean,
+                                    const float* __restrict__ stdv, float* __restrict__ out, int ld) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= R * (size_t)Dp) return;
+  size_t r = i / Dp;
+  int j = (int)(i - r * Dp);
+  out[r * ld + j] = j < D ? (obs[r * D + j] - mean[j]) / stdv[j] : 0.f;
+}
+// zero the hidden / cell state of rows starting an episode
+__global__ void rnn_reset_kernel(int N, int H, const unsigned char* __restrict__ reset, float* __restrict__ h1, int ld1,
+                                 float* __restrict__ h2, int ld2, float* __restrict__ c1, float* __restrict__ c2) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)N * H) return;
+  const int b = (int)(i / H), j = (int)(i - (size_t)b * H);
+  if (reset[b]) { h1[(size_t)b * ld1 + j] = 0.f; h2[(size_t)b * ld2 + j] = 0.f; c1[i] = 0.f; c2[i] = 0.f; }
+}
+// sequence minibatch gather: columns idx[0..B) of the time-major rollout [T][N] -> rows (t, b) of the workspaces
+__global__ void seq_gather_kernel(const int* __restrict__ idx, int T, int N, int B, int Bt, int Dp, int K1, int A,
+                                  const float* __restrict__ xn, const float* __restrict__ xm, const float* __restrict__ act,
+                                  const float* __restrict__ logp, const float* __restrict__ adv, const float* __restrict__ ret,
+                                  const unsigned char* __restrict__ done, float* __restrict__ xa, float* __restrict__ xc,
+                                  float* __restrict__ mact, float* __restrict__ mlogp, float* __restrict__ madv,
+                                  float* __restrict__ mret, unsigned char* __restrict__ reset_a, unsigned char* __restrict__ reset_c) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)T * B * Dp) return;
+  const size_t m = i / Dp;
+  const int j = (int)(i - m * Dp), t = (int)(m / B), b = (int)(m - (size_t)t * B);
+  const size_t src = (size_t)t * N + idx[b];
+  const float v = xn[src * Dp + j];
+  xa[((size_t)t * Bt + b) * K1 + j] = v;
+  if (xm) xa[((size_t)t * Bt + B + b) * K1 + j] = xm[src * Dp + j];
+  xc[m * K1 + j] = v;
+  if (j < A) mact[m * A + j] = act[src * A + j];
+  if (j == 0) {
+    mlogp[m] = logp[src]; madv[m] = adv[src]; mret[m] = ret[src];
+    const unsigned char r = (t == 0 || done[(size_t)(t - 1) * N + idx[b]]) ? 1 : 0;   // an episode starts at step t of this column
+    reset_a[(size_t)t * Bt + b] = r;
+    if (xm) reset_a[(size_t)t * Bt + B + b] = r;
+    reset_c[m] = r;
+  }
+}
+
+static void lstm_seq_forward(const LstmLayout& L, const float* th, SeqWs& w, int T, const unsigned char* reset, hipStream_t s) {
+  const int Bt = w.Bt, H = L.H, K1 = L.K1;
+  const int nb = (int)(((size_t)Bt * H + 255) / 256);
+  // the recurrent slots of step 0 start from zero
+  (void)hipMemset2DAsync(w.xh1 + L.Dp, sizeof(float) * K1, 0, sizeof(float) * H, Bt, s);
+  (void)hipMemset2DAsync(w.xh2 + H, sizeof(float) * 2 * H, 0, sizeof(float) * H, Bt, s);
+  for (int t = 0; t < T; t++) {
+    const size_t r0 = (size_t)t * Bt;
+    const bool last = t + 1 == T;
+    GemmArgs g{};
+    g.A = w.xh1 + r0 * K1; g.lda = K1; g.B = th + L.w1; g.ldb = K1; g.C = w.g1 + r0 * 4 * H; g.ldc = 4 * H; g.M = Bt; g.N = 4 * H; g.K = K1;
+    launch_gemm<true, true>(g, s);
+    hipLaunchKernelGGL(lstm_cell_fwd_kernel, dim3(nb), dim3(256), 0, s, Bt, H, w.g1 + r0 * 4 * H, th + L.bi1, th + L.bh1,
+                       t ? w.c1 + (r0 - Bt) * H : (const float*)nullptr, reset + r0, w.c1 + r0 * H, w.xh2 + r0 * 2 * H, 2 * H,
+                       last ? (float*)nullptr : w.xh1 + (r0 + Bt) * K1 + L.Dp, K1, last ? (const unsigned char*)nullptr : reset + r0 + Bt);
+    g = GemmArgs{};
+    g.A = w.xh2 + r0 * 2 * H; g.lda = 2 * H; g.B = th + L.w2; g.ldb = 2 * H; g.C = w.g2 + r0 * 4 * H; g.ldc = 4 * H; g.M = Bt; g.N = 4 * H; g.K = 2 * H;
+    launch_gemm<true, true>(g, s);
+    hipLaunchKernelGGL(lstm_cell_fwd_kernel, dim3(nb), dim3(256), 0, s, Bt, H, w.g2 + r0 * 4 * H, th + L.bi2, th + L.bh2,
+                       t ? w.c2 + (r0 - Bt) * H : (const float*)nullptr, reset + r0, w.c2 + r0 * H, w.h2 + r0 * H, H,
+                       last ? (float*)nullptr : w.xh2 + (r0 + Bt) * 2 * H + H, 2 * H, last ? (const unsigned char*)nullptr : reset + r0 + Bt);
+  }
+  GemmArgs g{};
+  g.A = w.h2; g.lda = H; g.B = th + L.wo; g.ldb = H; g.C = w.y; g.ldc = L.Op; g.M = T * Bt; g.N = L.O; g.K = H; g.bias = th + L.bo;
+  launch_gemm<true, true>(g, s);
+}
+
+// BPTT given w.dy; accumulates the parameter gradients of this network into grad (same layout as theta)
+static void lstm_seq_backward(const LstmLayout& L, const float* th, float* grad, SeqWs& w, int T, const unsigned char* reset,
+                              float* part, int k_chunk, hipStream_t s) {
+  const int Bt = w.Bt, H = L.H, K1 = L.K1, R = T * Bt;
+  const int nb = (int)(((size_t)Bt * H + 255) / 256);
+  GemmArgs g{};
+  g.A = w.dy; g.lda = L.Op; g.B = th + L.wo; g.ldb = H; g.C = w.dh2; g.ldc = H; g.M = R; g.N = H; g.K = L.O;
+  launch_gemm<true, false>(g, s);
+  (void)hipMemsetAsync(w.dcar1, 0, sizeof(float) * Bt * H, s);
+  (void)hipMemsetAsync(w.dcar2, 0, sizeof(float) * Bt * H, s);
+  for (int t = T - 1; t >= 0; t--) {
+    const size_t r0 = (size_t)t * Bt;
+    const bool last = t + 1 == T;
+    const unsigned char* rnext = last ? nullptr : reset + r0 + Bt;
+    hipLaunchKernelGGL(lstm_cell_bwd_kernel, dim3(nb), dim3(256), 0, s, Bt, H, w.g2 + r0 * 4 * H, w.c2 + r0 * H,
+                       t ? w.c2 + (r0 - Bt) * H : (const float*)nullptr, reset + r0, w.dh2 + r0 * H, H,
+                       last ? (const float*)nullptr : w.dx2 + H, 2 * H, rnext, w.dcar2);
+    g = GemmArgs{};   // d [h1_t | h2_{t-1}] = dG2 W2
+    g.A = w.g2 + r0 * 4 * H; g.lda = 4 * H; g.B = th + L.w2; g.ldb = 2 * H; g.C = w.dx2; g.ldc = 2 * H; g.M = Bt; g.N = 2 * H; g.K = 4 * H;
+    launch_gemm<true, false>(g, s);
+    hipLaunchKernelGGL(lstm_cell_bwd_kernel, dim3(nb), dim3(256), 0, s, Bt, H, w.g1 + r0 * 4 * H, w.c1 + r0 * H,
+                       t ? w.c1 + (r0 - Bt) * H : (const float*)nullptr, reset + r0, w.dx2, 2 * H,
+                       last ? (const float*)nullptr : w.dx1h, H, rnext, w.dcar1);
+    g = GemmArgs{};   // d h1_{t-1} = dG1 W1[:, Dp:]
+    g.A = w.g1 + r0 * 4 * H; g.lda = 4 * H; g.B = th + L.w1 + L.Dp; g.ldb = K1; g.C = w.dx1h; g.ldc = H; g.M = Bt; g.N = H; g.K = 4 * H;
+    launch_gemm<true, false>(g, s);
+  }
+  // parameter gradients: contractions over all R = T * Bt rows at once
+  g = GemmArgs{};
+  g.A = w.g2; g.lda = 4 * H; g.B = w.xh2; g.ldb = 2 * H; g.C = grad + L.w2; g.ldc = 2 * H; g.M = 4 * H; g.N = 2 * H; g.K = R; g.part = part; g.k_chunk = k_chunk;
+  launch_gemm<false, false>(g, s);
+  colsum_det(w.g2, R, 4 * H, 4 * H, grad + L.bi2, part, s);
+  colsum_det(w.g2, R, 4 * H, 4 * H, grad + L.bh2, part, s);
+  g = GemmArgs{};
+  g.A = w.g1; g.lda = 4 * H; g.B = w.xh1; g.ldb = K1; g.C = grad + L.w1; g.ldc = K1; g.M = 4 * H; g.N = K1; g.K = R; g.part = part; g.k_chunk = k_chunk;
+  launch_gemm<false, false>(g, s);
+  colsum_det(w.g1, R, 4 * H, 4 * H, grad + L.bi1, part, s);
+  colsum_det(w.g1, R, 4 * H, 4 * H, grad + L.bh1, part, s);
+  g = GemmArgs{};
+  g.A = w.dy; g.lda = L.Op; g.B = w.h2; g.ldb = H; g.C = grad + L.wo; g.ldc = H; g.M = L.O; g.N = H; g.K = R; g.part = part; g.k_chunk = k_chunk;
+  launch_gemm<false, false>(g, s);
+  colsum_det(w.dy, R, L.Op, L.O, grad + L.bo, part, s);
+}
+
+extern "C" int lhw_rnn_destroy(LhwRnn* p) {
+  if (!p) return LHW_OK;
+  (void)hipSetDevice(p->device);
+  for (void* a : p->allocs) (void)hipFree(a);
+  delete p;
+  return LHW_OK;
+}
+
+// seq_len / seq_cols: capacity of a BPTT minibatch (time steps x env columns); rollout_rows: envs stepped per call
+extern "C" int lhw_rnn_create(const LhwPpoConfig* c, int32_t seq_len, int32_t seq_cols, int32_t rollout_rows, LhwRnn** out) {
+  if (!c || !out) return lhw_fail(LHW_ERR_ARG, "null argument");
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return lhw_fail(LHW_ERR_NO_DEVICE, "no HIP device visible: liblhw has no CPU fallback");
+  if (c->obs_dim <= 0 || c->act_dim <= 0 || c->act_dim > 32 || c->hidden <= 0 || c->hidden % 4 || seq_len <= 0 || seq_cols <= 0 || rollout_rows <= 0)
+    return lhw_fail(LHW_ERR_ARG, "bad recurrent PPO dimensions");
+  HIPCHK(hipSetDevice(c->device));
+  LhwRnn* p = new LhwRnn();
+  p->device = c->device; p->D = c->obs_dim; p->A = c->act_dim; p->H = c->hidden; p->learn_std = c->learn_std;
+  p->T = seq_len; p->Bmax = seq_cols; p->Nroll = rollout_rows;
+  p->clip = c->clip; p->ent_coeff = c->entropy_coeff; p->mirror_coeff = c->mirror_coeff; p->grad_clip = c->max_grad_norm;
+  p->lr = c->lr; p->adam_eps = c->eps; p->beta1 = 0.9f; p->beta2 = 0.999f;
+  p->use_mirror = c->mirror_obs_src != nullptr;
+  p->la = lstm_layout(p->D, p->H, p->A);
+  p->lc = lstm_layout(p->D, p->H, 1);
+  p->off_actor = 0; p->off_std = p->la.total; p->off_critic = p->off_std + pad4(p->A); p->n_params = p->off_critic + p->lc.total;
+  bool ok = true;
+  auto alloc = [&](auto** ptr, size_t n) {
+    void* d = nullptr;
+    if (!ok || hipMalloc(&d, sizeof(**ptr) * std::max<size_t>(n, 1)) != hipSuccess || hipMemset(d, 0, sizeof(**ptr) * std::max<size_t>(n, 1)) != hipSuccess) { ok = false; return; }
+    p->allocs.push_back(d);
+    *ptr = (decltype(*ptr))d;
+  };
+  const size_t H = p->H, K1 = p->la.K1, Op = p->la.Op, N = p->Nroll;
+  for (int n = 0; n < 2; n++) { alloc(&p->rxh1[n], N * K1); alloc(&p->rxh2[n], N * 2 * H); alloc(&p->rc1[n], N * H); alloc(&p->rc2[n], N * H); }
+  alloc(&p->rg, N * 4 * H); alloc(&p->rh2, N * H); alloc(&p->ry, N * Op); alloc(&p->rcs, N * H);
+  auto alloc_ws = [&](SeqWs& w, const LstmLayout& L, int Bt) {
+    const size_t R = (size_t)p->T * Bt;
+    w.Bt = Bt;
+    alloc(&w.xh1, R * L.K1); alloc(&w.xh2, R * 2 * H); alloc(&w.g1, R * 4 * H); alloc(&w.g2, R * 4 * H); alloc(&w.c1, R * H); alloc(&w.c2, R * H);
+    alloc(&w.h2, R * H); alloc(&w.y, R * L.Op); alloc(&w.dy, R * L.Op); alloc(&w.dh2, R * H);
+    alloc(&w.dx2, (size_t)Bt * 2 * H); alloc(&w.dx1h, (size_t)Bt * H); alloc(&w.dcar1, (size_t)Bt * H); alloc(&w.dcar2, (size_t)Bt * H);
+  };
+  alloc_ws(p->wa, p->la, p->use_mirror ? 2 * p->Bmax : p->Bmax);
+  alloc_ws(p->wc, p->lc, p->Bmax);
+  const size_t Rm = (size_t)p->T * p->Bmax;
+  alloc(&p->reset, 3 * Rm);   // actor rows (up to 2 Bmax per step) then critic rows
+  alloc(&p->mb_act, Rm * p->A); alloc(&p->mb_logp, Rm); alloc(&p->mb_adv, Rm); alloc(&p->mb_ret, Rm); alloc(&p->dstd, Rm * Op);
+  alloc(&p->stats, 16); alloc(&p->stats_part, ((Rm + 255) / 256) * NSTAT); alloc(&p->norm_part, 2 * SUMSQ_BLOCKS);
+  const size_t max_slices = (2 * Rm + 2047) / 2048;
+  alloc(&p->part, std::max<size_t>(max_slices * 4 * H * std::max<size_t>(K1, 2 * H), (size_t)COLSUM_CHUNKS * 4 * H));
+  if (ok && p->use_mirror) {
+    const size_t Dp = p->la.Dp;
+    std::vector<int> osrc(Dp, 0), asrc(p->A, 0);
+    std::vector<float> osgn(Dp, 0.f), asgn(p->A, 0.f);
+    for (int j = 0; j < p->D; j++) { osrc[j] = c->mirror_obs_src[j]; osgn[j] = c->mirror_obs_sign[j]; if (osrc[j] < 0 || osrc[j] >= p->D) ok = false; }
+    for (int j = 0; j < p->A; j++) { asrc[j] = c->mirror_act_src[j]; asgn[j] = c->mirror_act_sign[j]; if (asrc[j] < 0 || asrc[j] >= p->A) ok = false; }
+    alloc(&p->d_obs_src, Dp); alloc(&p->d_act_src, p->A); alloc(&p->d_obs_sign, Dp); alloc(&p->d_act_sign, p->A);
+    if (ok) {
+      (void)hipMemcpy(p->d_obs_src, osrc.data(), sizeof(int) * Dp, hipMemcpyHostToDevice);
+      (void)hipMemcpy(p->d_act_src, asrc.data(), sizeof(int) * p->A, hipMemcpyHostToDevice);
+      (void)hipMemcpy(p->d_obs_sign, osgn.data(), sizeof(float) * Dp, hipMemcpyHostToDevice);
+      (void)hipMemcpy(p->d_act_sign, asgn.data(), sizeof(float) * p->A, hipMemcpyHostToDevice);
+    }
+  }
+  if (!ok) { lhw_rnn_destroy(p); return lhw_fail(LHW_ERR_HIP, "recurrent PPO workspace allocation failed (T=%d cols=%d) or bad mirror table", seq_len, seq_cols); }
+  *out = p;
+  return LHW_OK;
+}
+
+extern "C" int64_t lhw_rnn_param_count(const LhwRnn* p) { return p ? (int64_t)p->n_params : LHW_ERR_ARG; }
+
+// offsets in the flat parameter vector: out[0..7] actor W1 (cat) b_ih1 b_hh1 W2 (cat) b_ih2 b_hh2 Wout bout; out[8] stds;
+// out[9..16] critic likewise; out[17] padded obs width Dp; out[18] padded actor read-out width Op
+extern "C" int lhw_rnn_layout(const LhwRnn* p, int64_t* out19) {
+  if (!p || !out19) return lhw_fail(LHW_ERR_ARG, "null argument");
+  const LstmLayout* Ls[2] = {&p->la, &p->lc};
+  const size_t off[2] = {p->off_actor, p->off_critic};
+  for (int n = 0; n < 2; n++) {
+    const LstmLayout& L = *Ls[n];
+    const size_t v[8] = {L.w1, L.bi1, L.bh1, L.w2, L.bi2, L.bh2, L.wo, L.bo};
+    for (int k = 0; k < 8; k++) out19[n * 9 + k] = (int64_t)(off[n] + v[k]);
+  }
+  out19[8] = (int64_t)p->off_std;
+  out19[17] = p->la.Dp; out19[18] = p->la.Op;
+  return LHW_OK;
+}
+
+// One rollout step for N rows.  reset (device, [N], may be NULL): rows that start an episode with this observation.
+// commit != 0 advances the stored hidden / cell state (the reference's policy(state) / critic(state) calls in
+// RolloutWorker.sample); commit == 0 evaluates without touching it (value of a terminal / final observation).
+extern "C" int lhw_rnn_forward(LhwRnn* p, const float* theta, const float* obs, int64_t N, const float* obs_mean, const float* obs_std,
+                               const uint8_t* reset, uint64_t seed, uint32_t env_id_base, uint32_t counter, int deterministic,
+                               int commit, float* mu, float* act, float* logp, float* value, void* stream) {
+  if (!p || !theta || !obs || N <= 0 || N > p->Nroll) return lhw_fail(LHW_ERR_ARG, "bad argument (N=%lld, capacity %d)", (long long)N, p ? p->Nroll : 0);
+  if (act && !logp) return lhw_fail(LHW_ERR_ARG, "logp required with act");
+  HIPCHK(hipSetDevice(p->device));
+  hipStream_t s = (hipStream_t)stream;
+  const int H = p->H, K1 = p->la.K1, Dp = p->la.Dp;
+  const int nb = (int)(((size_t)N * H + 255) / 256);
+  const bool want[2] = {act != nullptr || mu != nullptr, value != nullptr};
+  for (int n = 0; n < 2; n++) {
+    if (!want[n]) continue;
+    const LstmLayout& L = n ? p->lc : p->la;
+    const float* th = theta + (n ? p->off_critic : p->off_actor);
+    if (reset && commit)
+      hipLaunchKernelGGL(rnn_reset_kernel, dim3(nb), dim3(256), 0, s, (int)N, H, reset, p->rxh1[n] + Dp, K1, p->rxh2[n] + H, 2 * H, p->rc1[n], p->rc2[n]);
+    const size_t nn = (size_t)N * Dp;
+    hipLaunchKernelGGL(normalize_ld_kernel, dim3((nn + 255) / 256), dim3(256), 0, s, obs, p->D, Dp, (size_t)N, obs_mean, obs_std, p->rxh1[n], K1);
+    GemmArgs g{};
+    g.A = p->rxh1[n]; g.lda = K1; g.B = th + L.w1; g.ldb = K1; g.C = p->rg; g.ldc = 4 * H; g.M = (int)N; g.N = 4 * H; g.K = K1;
+    launch_gemm<true, true>(g, s);
+    hipLaunchKernelGGL(lstm_cell_fwd_kernel, dim3(nb), dim3(256), 0, s, (int)N, H, p->rg, th + L.bi1, th + L.bh1, (const float*)p->rc1[n],
+                       (const unsigned char*)nullptr, commit ? p->rc1[n] : p->rcs, p->rxh2[n], 2 * H, commit ? p->rxh1[n] + Dp : (float*)nullptr, K1,
+                       (const unsigned char*)nullptr);
+    g = GemmArgs{};
+    g.A = p->rxh2[n]; g.lda = 2 * H; g.B = th + L.w2; g.ldb = 2 * H; g.C = p->rg; g.ldc = 4 * H; g.M = (int)N; g.N = 4 * H; g.K = 2 * H;
+    launch_gemm<true, true>(g, s);
+    hipLaunchKernelGGL(lstm_cell_fwd_kernel, dim3(nb), dim3(256), 0, s, (int)N, H, p->rg, th + L.bi2, th + L.bh2, (const float*)p->rc2[n],
+                       (const unsigned char*)nullptr, commit ? p->rc2[n] : p->rcs, p->rh2, H, commit ? p->rxh2[n] + H : (float*)nullptr, 2 * H,
+                       (const unsigned char*)nullptr);
+    g = GemmArgs{};
+    g.A = p->rh2; g.lda = H; g.B = th + L.wo; g.ldb = H; g.C = p->ry; g.ldc = L.Op; g.M = (int)N; g.N = L.O; g.K = H; g.bias = th + L.bo;
+    launch_gemm<true, true>(g, s);
+    if (n == 0) {
+      if (mu) HIPCHK(hipMemcpy2DAsync(mu, sizeof(float) * p->A, p->ry, sizeof(float) * L.Op, sizeof(float) * p->A, N, hipMemcpyDeviceToDevice, s));
+      if (act)
+        hipLaunchKernelGGL(sample_kernel, dim3((N + 255) / 256), dim3(256), 0, s, p->ry, L.Op, p->A, (int)N, theta + p->off_std, seed, env_id_base,
+                           counter, deterministic, act, logp);
+    } else {
+      HIPCHK(hipMemcpy2DAsync(value, sizeof(float), p->ry, sizeof(float) * L.Op, sizeof(float), N, hipMemcpyDeviceToDevice, s));
+    }
+  }
+  HIPCHK(hipGetLastError());
+  return LHW_OK;
+}
+
+// BPTT over one minibatch of B env columns of the time-major rollout ([T][N] buffers; xn / xm = normalised (mirrored)
+// observations [T*N][Dp], done = LHW_DONE_* flags).  Accumulates into grad and stats_dev[0..5] like lhw_ppo_grad.
+extern "C" int lhw_rnn_grad(LhwRnn* p, const float* theta, float* grad, int32_t T, int32_t N, const float* xn, const float* xm,
+                            const float* act, const float* old_logp, const float* adv, const float* ret, const uint8_t* done,
+                            const int32_t* cols, int32_t B, float* stats_dev, void* stream) {
+  if (!p || !theta || !grad || !xn || !act || !old_logp || !adv || !ret || !done || !cols || !stats_dev) return lhw_fail(LHW_ERR_ARG, "null argument");
+  if (T <= 0 || T > p->T || B <= 0 || B > p->Bmax || N <= 0) return lhw_fail(LHW_ERR_ARG, "sequence minibatch %d x %d exceeds capacity %d x %d", T, B, p->T, p->Bmax);
+  const int mir = p->use_mirror && xm != nullptr;
+  HIPCHK(hipSetDevice(p->device));
+  hipStream_t s = (hipStream_t)stream;
+  const int Dp = p->la.Dp, K1 = p->la.K1, Op = p->la.Op;
+  const int Bt = mir ? 2 * B : B, R = T * B;
+  p->wa.Bt = Bt; p->wc.Bt = B;
+  unsigned char *reset_a = p->reset, *reset_c = p->reset + (size_t)2 * p->T * p->Bmax;
+  const size_t n = (size_t)R * Dp;
+  hipLaunchKernelGGL(seq_gather_kernel, dim3((n + 255) / 256), dim3(256), 0, s, cols, T, N, B, Bt, Dp, K1, p->A, xn, mir ? xm : (const float*)nullptr,
+                     act, old_logp, adv, ret, done, p->wa.xh1, p->wc.xh1, p->mb_act, p->mb_logp, p->mb_adv, p->mb_ret, reset_a, reset_c);
+  const float *th_a = theta + p->off_actor, *th_c = theta + p->off_critic;
+  lstm_seq_forward(p->la, th_a, p->wa, T, reset_a, s);
+  lstm_seq_forward(p->lc, th_c, p->wc, T, reset_c, s);
+  const int nblk = (R + 255) / 256;
+  // the loss kernel writes d loss / d read-out for the normal rows (and the mirrored rows); rows it does not own stay zero
+  HIPCHK(hipMemsetAsync(p->wa.dy, 0, sizeof(float) * (size_t)T * Bt * Op, s));
+  hipLaunchKernelGGL(ppo_loss_kernel, dim3(nblk), dim3(256), 0, s, R, 0, p->A, Op, p->wa.y, p->wc.y, p->mb_act, p->mb_logp, p->mb_adv,
+                     p->mb_ret, theta + p->off_std, p->clip, p->mirror_coeff, mir, p->d_act_src, p->d_act_sign, p->wa.dy, p->wc.dy,
+                     p->learn_std ? p->dstd : (float*)nullptr, p->stats_part, (const float*)nullptr, (const unsigned char*)nullptr, 0.f, 0.f,
+                     mir ? B : 0);
+  hipLaunchKernelGGL(reduce_rows_kernel, dim3(1), dim3(64), 0, s, p->stats_part, nblk, NSTAT, stats_dev);
+  if (p->learn_std) {
+    colsum_det(p->dstd, R, Op, p->A, grad + p->off_std, p->part, s);
+    hipLaunchKernelGGL(entropy_grad_kernel, dim3(1), dim3(64), 0, s, theta + p->off_std, p->A, p->ent_coeff, grad + p->off_std);
+  }
+  const int kc = 2048;
+  lstm_seq_backward(p->la, th_a, grad + p->off_actor, p->wa, T, reset_a, p->part, kc, s);
+  lstm_seq_backward(p->lc, th_c, grad + p->off_critic, p->wc, T, reset_c, p->part, kc, s);
+  HIPCHK(hipGetLastError());
+  return LHW_OK;
+}
+
+extern "C" int lhw_rnn_apply(LhwRnn* p, float* theta, float* grad, float* adam_m, float* adam_v, int64_t step, float grad_scale,
+                             void* stream) {
+  if (!p || !theta || !grad || !adam_m || !adam_v || step <= 0) return lhw_fail(LHW_ERR_ARG, "bad argument");
+  HIPCHK(hipSetDevice(p->device));
+  hipStream_t s = (hipStream_t)stream;
+  const size_t na = p->learn_std ? p->off_std + p->A : p->off_std;
+  clip_and_adam(theta, grad, adam_m, adam_v, na, p->off_critic, p->lc.total, step, grad_scale, p->norm_part, p->stats, p->grad_clip,
+                p->lr, p->beta1, p->beta2, p->adam_eps, s);
+  if (!p->learn_std) HIPCHK(hipMemsetAsync(grad + p->off_std, 0, sizeof(float) * pad4(p->A), s));
+  HIPCHK(hipGetLastError());
+  return LHW_OK;
+}
+
+extern "C" int lhw_rnn_normalize(LhwRnn* p, const float* obs, int64_t R, const float* obs_mean, const float* obs_std, float* xn,
+                                 float* xm, void* stream) {
+  if (!p || !obs || !xn || R <= 0) return lhw_fail(LHW_ERR_ARG, "bad argument");
+  if (xm && !p->use_mirror) return lhw_fail(LHW_ERR_ARG, "mirror output requested but no mirror tables configured");
+  HIPCHK(hipSetDevice(p->device));
+  size_t n = (size_t)R * p->la.Dp;
+  hipLaunchKernelGGL(normalize_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, obs, p->D, p->la.Dp, (size_t)R,
+                     obs_mean, obs_std, xn, xm, p->d_obs_src, p->d_obs_sign);
   HIPCHK(hipGetLastError());
   return LHW_OK;
 }

@@ -149,3 +149,99 @@ class OraclePPO:
         self.copt.step()
         return (actor_loss.item(), entropy_penalty.item(), critic_loss.item(), approx_kl.item(), mirror_loss.item(),
                 imitation_loss.item(), clip_fraction)
+
+
+# ----------------------------------------------------------------------------- recurrent (LSTM) branch
+def lstm_cell(x, h, c, w_ih, w_hh, b_ih, b_hh):
+    """torch.nn.LSTMCell arithmetic (gate order i, f, g, o)."""
+    gates = x @ w_ih.t() + b_ih + h @ w_hh.t() + b_hh
+    i, f, g, o = gates.chunk(4, dim=-1)
+    c2 = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(g)
+    return torch.sigmoid(o) * torch.tanh(c2), c2
+
+
+def lstm_net(x, reset, p):
+    """x [T, B, D] normalised inputs, reset [T, B] bool (episode starts at t), p = [w_ih1, w_hh1, b_ih1, b_hh1, w_ih2, w_hh2,
+    b_ih2, b_hh2, w_out, b_out] -> read-out [T, B, O].  Gaussian_LSTM_Actor._get_dist_params / LSTM_V.forward
+    (reference rl/policies/actor.py:233-262, critic.py:84-112) on env columns with in-column episode starts."""
+    T, B, _ = x.shape
+    H = p[1].shape[1]
+    h1 = c1 = h2 = c2 = torch.zeros(B, H)
+    ys = []
+    for t in range(T):
+        keep = (~reset[t]).float().unsqueeze(-1)
+        h1, c1, h2, c2 = h1 * keep, c1 * keep, h2 * keep, c2 * keep
+        h1, c1 = lstm_cell(x[t], h1, c1, *p[0:4])
+        h2, c2 = lstm_cell(h1, h2, c2, *p[4:8])
+        ys.append(h2 @ p[8].t() + p[9])
+    return torch.stack(ys)
+
+
+class OracleRecurrentPPO:
+    """PPO.update_actor_critic, recurrent branch (reference rl/algos/ppo.py:299-406 with mask, :512-533), stated on env
+    columns: every (t, column) entry is a valid sample, episode starts inside a column reset the state."""
+
+    def __init__(self, actor, critic, stds, obs_mean, obs_std, *, lr=3e-4, eps=1e-5, clip=0.2, mirror_coeff=0.4, max_grad_norm=0.5,
+                 mirror_obs=None, mirror_act=None):
+        f32 = lambda a: torch.tensor(np.asarray(a), dtype=torch.float32)
+        self.actor = [f32(a).requires_grad_() for a in actor]
+        self.critic = [f32(a).requires_grad_() for a in critic]
+        self.stds = f32(stds)
+        self.obs_mean, self.obs_std = f32(obs_mean), f32(obs_std)
+        self.clip, self.mir, self.gc = clip, mirror_coeff, max_grad_norm
+        self.aopt = torch.optim.Adam(self.actor, lr=lr, eps=eps)
+        self.copt = torch.optim.Adam(self.critic, lr=lr, eps=eps)
+        self.mirror_obs, self.mirror_act = mirror_obs, mirror_act
+
+    def mu(self, obs, reset):
+        return lstm_net((obs - self.obs_mean) / self.obs_std, reset, self.actor)
+
+    def value(self, obs, reset):
+        return lstm_net((obs - self.obs_mean) / self.obs_std, reset, self.critic)
+
+    def log_prob(self, obs, reset, act):
+        return torch.distributions.Normal(self.mu(obs, reset), self.stds).log_prob(act).sum(-1, keepdim=True)
+
+    def update(self, obs, reset, act, ret, adv, old_logp):
+        """obs [T,B,D], reset [T,B] bool, act [T,B,A], ret/adv/old_logp [T,B,1]."""
+        pdf = torch.distributions.Normal(self.mu(obs, reset), self.stds)
+        logp = pdf.log_prob(act).sum(-1, keepdim=True)
+        ratio = (logp - old_logp).exp()
+        actor_loss = -torch.min(ratio * adv, ratio.clamp(1.0 - self.clip, 1.0 + self.clip) * adv).mean()
+        critic_loss = (ret - self.value(obs, reset)).pow(2).mean()
+        if self.mirror_obs is not None:
+            src, sign = self.mirror_obs
+            mobs = obs[..., torch.as_tensor(src, dtype=torch.long)] * torch.as_tensor(sign)
+            mact = self.mu(mobs, reset)
+            asrc, asign = self.mirror_act
+            mact = mact[..., torch.as_tensor(asrc, dtype=torch.long)] * torch.as_tensor(asign)
+            mirror_loss = (pdf.mean - mact).pow(2).mean()
+        else:
+            mirror_loss = torch.zeros_like(actor_loss)
+        total = actor_loss + self.mir * mirror_loss + critic_loss
+        self.aopt.zero_grad()
+        self.copt.zero_grad()
+        total.backward()
+        torch.nn.utils.clip_grad_norm_(self.actor, self.gc)
+        torch.nn.utils.clip_grad_norm_(self.critic, self.gc)
+        self.aopt.step()
+        self.copt.step()
+        return actor_loss.item(), critic_loss.item(), mirror_loss.item()
+
+
+def trajectories_to_columns(lengths, T):
+    """Greedy packing of back-to-back trajectories into columns of exactly T steps: returns per column the list of
+    (start offset in the concatenated arrays, length); raises if the lengths do not tile."""
+    cols, cur, fill, off = [], [], 0, 0
+    for n in lengths:
+        if fill + n > T:
+            raise ValueError("trajectory lengths do not tile columns of length %d" % T)
+        cur.append((off, n))
+        fill += n
+        off += n
+        if fill == T:
+            cols.append(cur)
+            cur, fill = [], 0
+    if cur:
+        raise ValueError("last column is not full")
+    return cols

@@ -221,6 +221,84 @@ def gen_misc():
              mir_obs_step=_get_symmetry_matrix(JVRC_MIR_OBS[:29] + list(range(29, 39))))
 
 
+def gen_rppo(tag, mirror, lengths, seed, n_updates=2, H=32):
+    """Reference recurrent branch: Gaussian_LSTM_Actor / LSTM_V, PPO.update_actor_critic on a padded list of trajectories
+    with the mask of rl/algos/ppo.py:512-533.  With mirror=True all trajectories have equal length (the reference's mirror
+    term averages over padded positions too -- a quirk the padding-free device formulation has no counterpart for)."""
+    import copy
+    from torch.nn.utils.rnn import pad_sequence
+    from rl.algos.ppo import PPO
+    from rl.envs.wrappers import SymmetricEnv, _get_symmetry_matrix
+    from rl.policies.actor import Gaussian_LSTM_Actor
+    from rl.policies.critic import LSTM_V
+    torch.manual_seed(seed)
+    D, A = 37, 12
+    policy = Gaussian_LSTM_Actor(D, A, layers=(H, H), init_std=0.223, learn_std=False)
+    critic = LSTM_V(D, layers=(H, H))
+    rs = np.random.default_rng(seed)
+    obs_mean = rs.normal(size=D).astype(np.float32) * 0.1
+    obs_std = (0.5 + rs.uniform(size=D)).astype(np.float32)
+    policy.obs_mean = torch.tensor(obs_mean); policy.obs_std = torch.tensor(obs_std)
+    critic.obs_mean = policy.obs_mean; critic.obs_std = policy.obs_std
+    ppo = PPO.__new__(PPO)
+    ppo.policy, ppo.critic = policy, critic
+    ppo.old_policy = copy.deepcopy(policy)
+    ppo.clip, ppo.ent_coeff, ppo.mirror_coeff, ppo.imitate_coeff, ppo.grad_clip = 0.2, 0.0, 0.4, 0.3, 0.5
+    ppo.recurrent, ppo.imitation_projector, ppo.base_policy = True, None, None
+    ppo.actor_optimizer = torch.optim.Adam(policy.parameters(), lr=3e-4, eps=1e-5)
+    ppo.critic_optimizer = torch.optim.Adam(critic.parameters(), lr=3e-4, eps=1e-5)
+    sym = SymmetricEnv.__new__(SymmetricEnv)
+    sym.act_mirror_matrix = torch.tensor(_get_symmetry_matrix(JVRC_MIR_ACT), dtype=torch.float32)
+    sym.obs_mirror_matrix = torch.tensor(_get_symmetry_matrix(JVRC_MIR_OBS), dtype=torch.float32)
+    sym.clock_inds = JVRC_CLOCK
+    sym.env = types.SimpleNamespace(base_obs_len=D)
+
+    def weights(net, layers, outl):
+        w = []
+        for cell in layers:
+            w += [cell.weight_ih, cell.weight_hh, cell.bias_ih, cell.bias_hh]
+        w += [outl.weight, outl.bias]
+        return [x.detach().numpy().copy() for x in w]
+
+    out = dict(obs_mean=obs_mean, obs_std=obs_std, hidden=H, mirror=int(mirror), lengths=np.array(lengths))
+    for k, w in enumerate(weights(policy, policy.actor_layers, policy.network_out)):
+        out[f"a0_{k}"] = w
+    for k, w in enumerate(weights(critic, critic.critic_layers, critic.network_out)):
+        out[f"c0_{k}"] = w
+    out["stds0"] = policy.stds.detach().numpy().copy()
+    scal = []
+    for u in range(n_updates):
+        obs_l, act_l, ret_l, adv_l = [], [], [], []
+        for Lk in lengths:
+            o = torch.tensor(rs.normal(size=(Lk, D)).astype(np.float32))
+            ph = rs.uniform(0, 6.28, Lk)
+            o[:, 29] = torch.tensor(np.sin(ph).astype(np.float32) * 0.99)
+            o[:, 30] = torch.tensor(np.cos(ph).astype(np.float32) * 0.99)
+            obs_l.append(o)
+            ret_l.append(torch.tensor(rs.normal(size=(Lk, 1)).astype(np.float32)))
+            adv_l.append(torch.tensor(rs.normal(size=(Lk, 1)).astype(np.float32)))
+        with torch.no_grad():     # actions sampled around the old policy's means, trajectory by trajectory
+            for o in obs_l:
+                mu = ppo.old_policy(o.unsqueeze(1)).squeeze(1)
+                act_l.append(mu + 0.223 * torch.tensor(rs.normal(size=mu.shape).astype(np.float32)) * (1.5 if u else 1.0))
+        mask = [torch.ones_like(r) for r in ret_l]
+        ob, ab, rb, vb, mb = (pad_sequence(x, batch_first=False) for x in (obs_l, act_l, ret_l, adv_l, mask))
+        with torch.no_grad():     # what update_actor_critic recomputes internally with old_policy (ppo.py:305-306)
+            olp = ppo.old_policy.distribution(ob).log_prob(ab).sum(-1, keepdim=True)
+        out[f"old_logp_{u}"] = torch.cat([olp[:Lk, k] for k, Lk in enumerate(lengths)]).numpy()
+        res = ppo.update_actor_critic(ob, ab, rb, vb, mb, mirror_observation=sym.mirror_clock_observation if mirror else None,
+                                      mirror_action=sym.mirror_action if mirror else None)
+        scal.append([float(x) for x in res])
+        out[f"obs_{u}"], out[f"act_{u}"] = torch.cat(obs_l).numpy(), torch.cat(act_l).numpy()     # trajectories back to back
+        out[f"ret_{u}"], out[f"adv_{u}"] = torch.cat(ret_l).numpy(), torch.cat(adv_l).numpy()
+    for k, w in enumerate(weights(policy, policy.actor_layers, policy.network_out)):
+        out[f"a1_{k}"] = w
+    for k, w in enumerate(weights(critic, critic.critic_layers, critic.network_out)):
+        out[f"c1_{k}"] = w
+    out["scalars"] = np.array(scal)
+    np.savez_compressed(os.path.join(OUT, f"rppo_{tag}.npz"), **out)
+
+
 def gen_stepping():
     """Executes the reference's SteppingTask (tasks/stepping_task.py) against a scripted fake RobotInterface: reset for
     every walk mode / initial phase / curriculum iteration with the np.random draws forced to listed values, then a run
@@ -390,6 +468,10 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "stepping":     # regenerate only the stepping-task fixture
         gen_stepping()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "rppo":
+        gen_rppo("h32_padded", False, [6, 4, 2, 6, 3, 3], 21)
+        gen_rppo("h32_mirror", True, [5, 5, 5], 22)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "imitate":
         gen_ppo("h64_imitate", 64, 80, True, False, 2, 14, imitate=True)
         sys.exit(0)
@@ -403,5 +485,7 @@ if __name__ == "__main__":
     gen_ppo("h64_learnstd", 64, 70, False, True, 2, 12)
     gen_ppo("h256_mirror", 256, 128, True, False, 1, 13)
     gen_ppo("h64_imitate", 64, 80, True, False, 2, 14, imitate=True)
+    gen_rppo("h32_padded", False, [6, 4, 2, 6, 3, 3], 21)
+    gen_rppo("h32_mirror", True, [5, 5, 5], 22)
     gen_stepping()
     print("golden fixtures written to", OUT)

@@ -73,3 +73,48 @@ def test_update_with_imitation_matches_reference():
         assert res[5] > 0
     for k in range(6):
         np.testing.assert_allclose(orc.actor[k].detach().numpy(), g[f"a1_{k}"], rtol=0, atol=2e-6)
+
+
+def _rppo_case(g, u):
+    """Columns-with-resets view of update u of a recurrent fixture (trajectories stored back to back)."""
+    lengths = [int(x) for x in g["lengths"]]
+    T = max(lengths)
+    cols = po.trajectories_to_columns(lengths, T)
+    B = len(cols)
+
+    def pack(a):
+        out = np.zeros((T, B) + a.shape[1:], np.float32)
+        for b, segs in enumerate(cols):
+            t = 0
+            for off, n in segs:
+                out[t:t + n, b] = a[off:off + n]
+                t += n
+        return torch.tensor(out)
+    reset = np.zeros((T, B), bool)
+    for b, segs in enumerate(cols):
+        t = 0
+        for off, n in segs:
+            reset[t, b] = True
+            t += n
+    return (pack(g[f"obs_{u}"]), torch.tensor(reset), pack(g[f"act_{u}"]), pack(g[f"ret_{u}"]), pack(g[f"adv_{u}"]),
+            pack(g[f"old_logp_{u}"]))
+
+
+@pytest.mark.parametrize("tag", ["h32_padded", "h32_mirror"])
+def test_recurrent_update_matches_reference(tag):
+    """Reference Gaussian_LSTM_Actor / LSTM_V + recurrent update_actor_critic on a PADDED trajectory list vs the oracle's
+    padding-free columns with in-column resets: same losses, same weights after two Adam steps."""
+    g = np.load(os.path.join(G, f"rppo_{tag}.npz"))
+    mirror = bool(g["mirror"])
+    mo = po.mirror_tables(MIR_OBS, [29, 30]) if mirror else None
+    ma = po.mirror_tables(MIR_ACT) if mirror else None
+    orc = po.OracleRecurrentPPO([g[f"a0_{k}"] for k in range(10)], [g[f"c0_{k}"] for k in range(10)], g["stds0"], g["obs_mean"],
+                                g["obs_std"], mirror_obs=mo, mirror_act=ma)
+    for u in range(len(g["scalars"])):
+        obs, reset, act, ret, adv, old_logp = _rppo_case(g, u)
+        a_loss, c_loss, m_loss = orc.update(obs, reset, act, ret, adv, old_logp)
+        ref = g["scalars"][u]      # actor, entropy, critic, kl, mirror, imitation, clip fraction
+        np.testing.assert_allclose([a_loss, c_loss, m_loss], [ref[0], ref[2], ref[4]], rtol=3e-5, atol=2e-6)
+    for k in range(10):
+        np.testing.assert_allclose(orc.actor[k].detach().numpy(), g[f"a1_{k}"], rtol=0, atol=2e-6, err_msg=f"actor {k}")
+        np.testing.assert_allclose(orc.critic[k].detach().numpy(), g[f"c1_{k}"], rtol=0, atol=2e-6, err_msg=f"critic {k}")
