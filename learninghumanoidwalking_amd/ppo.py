@@ -94,6 +94,8 @@ class Rollout:
 
     def collect(self, deterministic=False):
         env, k, T = self.env, self.k, self.T
+        if getattr(k, "recurrent", False):
+            return self._collect_recurrent(deterministic)
         if not self.started:
             self.obs[0].copy_(env.reset())
             self.started = True
@@ -108,6 +110,24 @@ class Rollout:
         k.forward(self.obs[T], want_actor=False, value=self.vfinal)
 
 
+    def _collect_recurrent(self, deterministic):
+        """LSTM policies: every env starts a fresh episode at the start of the batch (the reference's worker begins each
+        sample() call with env.reset() and zero hidden state, rollout_worker.py:130-137), the hidden state advances with
+        every policy / critic call and is zeroed for envs whose episode just ended; terminal and final values are
+        evaluated without advancing it."""
+        env, k, T = self.env, self.k, self.T
+        self.obs[0].copy_(env.reset())
+        reset = torch.ones(self.N, dtype=torch.uint8, device=self.obs.device)
+        for t in range(T):
+            k.forward(self.obs[t], reset=reset, seed=self.seed, env_id_base=self.env_base, counter=self.counter,
+                      deterministic=deterministic, commit=True, mu=self.mu, act=self.act[t], logp=self.logp[t], value=self.val[t])
+            env.step(self.act[t], obs_out=self.obs[t + 1], term_obs_out=self.tob, rew_out=self.rew[t], done_out=self.done[t])
+            k.forward(self.tob, commit=False, want_actor=False, value=self.vterm[t])
+            reset = (self.done[t] != 0).to(torch.uint8)
+            self.counter += 1
+        k.forward(self.obs[T], commit=False, want_actor=False, value=self.vfinal)
+
+
 class PPO:
     def __init__(self, env_fn, args, seed=None):
         self.seed = seed
@@ -119,9 +139,9 @@ class PPO:
         self.n_proc = int(getattr(args, "num_envs", None) or args.num_procs)
         self.grad_clip, self.mirror_coeff = args.max_grad_norm, args.mirror_coeff
         self.eval_freq = args.eval_freq
-        self.recurrent = getattr(args, "recurrent", False)
-        if self.recurrent:
-            raise NotImplementedError("LSTM policies are outside the hot path built so far (SURVEY.md 8f n3)")
+        self.recurrent = bool(getattr(args, "recurrent", False))
+        if self.recurrent and getattr(args, "imitate", None):
+            raise NotImplementedError("--imitate together with --recurrent is not supported")
         self.imitate_coeff = float(getattr(args, "imitate_coeff", 0.3))
         self.batch_size = self.n_proc * self.max_traj_len
         self.total_steps = 0
@@ -141,13 +161,41 @@ class PPO:
         self.spec = spec
         obs_dim, act_dim = spec.obs_dim, spec.act_dim
         mirror = None if getattr(args, "no_mirror", False) else spec.mirror_tables()
-        self.kernels = PpoKernels(
-            obs_dim, act_dim, hidden=256, max_rows=max(self.n_proc, int(self.minibatch_size or self.batch_size)),
-            device=self.device, learn_std=args.learn_std, lr=self.lr, eps=self.eps, clip=self.clip,
-            entropy_coeff=self.ent_coeff, mirror_coeff=self.mirror_coeff, max_grad_norm=self.grad_clip,
-            mirror_obs=mirror[0] if mirror else None, mirror_act=mirror[1] if mirror else None)
         continued = getattr(args, "continued", None)
-        if continued:
+        self.obs_rms = None
+        if self.recurrent:
+            # LSTM actor / critic (ppo.py:84-86); a minibatch is `minibatch_size` whole env columns of the rollout
+            from .rnn_kernels import RnnKernels, reference_init_lstm
+            hidden = int(getattr(args, "lstm_hidden", 256))
+            cols = min(self.n_proc, int(self.minibatch_size or self.n_proc))
+            self.kernels = RnnKernels(
+                obs_dim, act_dim, hidden=hidden, seq_len=self.max_traj_len, seq_cols=cols, rollout_rows=self.n_proc, device=self.device,
+                learn_std=args.learn_std, lr=self.lr, eps=self.eps, clip=self.clip, entropy_coeff=self.ent_coeff,
+                mirror_coeff=self.mirror_coeff, max_grad_norm=self.grad_clip,
+                mirror_obs=mirror[0] if mirror else None, mirror_act=mirror[1] if mirror else None)
+            self.kernels.recurrent = True
+            if continued:
+                from .checkpoint import load_recurrent_checkpoint
+                cpath = Path(Path(continued).parent, "critic" + str(continued).split("actor")[1])
+                t, om, osd, _ = load_recurrent_checkpoint(continued, cpath)
+                t["stds"] = args.std_dev * torch.ones(act_dim)
+                self.kernels.set_tensors(t)
+                self.kernels.set_obs_norm(om.numpy(), osd.numpy())
+                print("Loaded (pre-trained) actor from: ", continued)
+                print("Loaded (pre-trained) critic from: ", cpath)
+            else:
+                cpu_state = torch.random.get_rng_state()
+                self.kernels.set_tensors(reference_init_lstm(obs_dim, act_dim, hidden, args.std_dev, generator_seed=seed if seed is not None else 0))
+                torch.random.set_rng_state(cpu_state)
+        else:
+            self.kernels = PpoKernels(
+                obs_dim, act_dim, hidden=256, max_rows=max(self.n_proc, int(self.minibatch_size or self.batch_size)),
+                device=self.device, learn_std=args.learn_std, lr=self.lr, eps=self.eps, clip=self.clip,
+                entropy_coeff=self.ent_coeff, mirror_coeff=self.mirror_coeff, max_grad_norm=self.grad_clip,
+                mirror_obs=mirror[0] if mirror else None, mirror_act=mirror[1] if mirror else None)
+        if self.recurrent:
+            pass
+        elif continued:
             # --continued actor_X.pt: load actor + sibling critic, re-initialise stds, keep the embedded obs
             # normalisation (reference rl/algos/ppo.py:69-82)
             from .checkpoint import load_reference_checkpoint
@@ -223,6 +271,8 @@ class PPO:
         """One optimiser step on an explicit minibatch (same 7-tuple as the reference, ppo.py:299-406).
         ``mask`` must be 1 (FF path).  The mirror functions are configured at construction; the
         arguments are accepted for signature compatibility."""
+        if self.recurrent:
+            raise NotImplementedError("explicit padded-trajectory minibatches are not exposed for the LSTM path; use optimize()")
         k = self.kernels
         obs = obs_batch.to(self.device, torch.float32).contiguous()
         B = obs.shape[0]
@@ -263,9 +313,38 @@ class PPO:
         scale = dist_utils.allreduce_grad_(self.kernels.grad)  # RCCL sum over xGMI: the only data-path collective
         self.kernels.apply(grad_scale=scale)
 
+    def _optimize_recurrent(self, itr: int):
+        """Recurrent branch of PPO.train (ppo.py:512-533): `epochs` passes over shuffled minibatches of whole trajectories
+        -- here `minibatch_size` env columns of the time-major rollout (each column = back-to-back trajectories, the LSTM
+        state is reset where one starts), last partial minibatch kept (drop_last=False) -- BPTT on each."""
+        k, ro = self.kernels, self.rollout
+        T, N = ro.T, ro.N
+        adv = self._adv.reshape(-1)
+        self._normalize_advantages(adv)
+        ret = self._ret.reshape(-1)
+        xn, xm = k.normalize(ro.obs[:T].reshape(T * N, -1))
+        act, logp = ro.act.reshape(T * N, -1), ro.logp.reshape(-1)
+        mb = min(int(self.minibatch_size or N), N, k.seq_cols)
+        k.stats.zero_()
+        n_updates = 0
+        for epoch in range(self.epochs):
+            g = torch.Generator(device=self.device)
+            g.manual_seed((self.seed if self.seed is not None else 0) + itr * self.epochs + epoch + 1000003 * self.rank)
+            perm = torch.randperm(N, generator=g, device=self.device, dtype=torch.int64).to(torch.int32)
+            for start in range(0, N, mb):
+                k.grad_columns(T, N, xn, xm, act, logp, adv, ret, ro.done, perm[start:start + mb].contiguous())
+                self._allreduce_and_apply()
+                n_updates += 1
+        s = (k.stats / max(1, n_updates)).cpu().numpy()
+        self.last_losses = dict(actor=float(s[0]), critic=float(s[1]), mirror=float(s[2]), kl=float(s[3]), clip_fraction=float(s[4]),
+                                imitation=0.0, entropy=self._entropy_penalty(), n_updates=n_updates)
+        return self.last_losses
+
     def optimize(self, itr: int):
         """The per-iteration update of PPO.train (ppo.py:484-566): advantage normalisation, then
         `epochs` passes of shuffled minibatches (drop_last).  Returns dict of mean losses."""
+        if self.recurrent:
+            return self._optimize_recurrent(itr)
         k, ro = self.kernels, self.rollout
         T, N = ro.T, ro.N
         n_samples = T * N
@@ -315,7 +394,9 @@ class PPO:
         pickles naming the reference's classes, so `run_experiment.py eval` / `--continued` of the reference load them."""
         if self.rank != 0:
             return
-        from .checkpoint import save_reference_checkpoint
+        from .checkpoint import save_recurrent_checkpoint, save_reference_checkpoint
+        if self.recurrent:
+            save_reference_checkpoint = save_recurrent_checkpoint    # Gaussian_LSTM_Actor / LSTM_V pickles
         t = self.kernels.get_tensors()
         om, osd = self.kernels.obs_mean.cpu(), self.kernels.obs_std.cpu()
         save_reference_checkpoint(t, om, osd, self.kernels.learn_std, self.save_path / f"actor_{itr}.pt", self.save_path / f"critic_{itr}.pt")

@@ -160,6 +160,23 @@ class RnnKernels:
         _lib.check(self._L.lhw_rnn_normalize(self._h, _p(obs), R, _p(self.obs_mean), _p(self.obs_std), _p(xn), _p(xm), self._stream()))
         return xn, xm
 
+    def gae(self, rew, val, done, vterm, vfinal, gamma, lam):
+        T, N = rew.shape
+        ret = torch.empty(T, N, dtype=torch.float32, device=self.device)
+        adv = torch.empty(T, N, dtype=torch.float32, device=self.device)
+        _lib.check(self._L.lhw_gae(T, N, _p(rew), _p(val), _p(done), _p(vterm), _p(vfinal), float(gamma), float(lam), _p(ret), _p(adv),
+                                   self._stream()))
+        return ret, adv
+
+    def moments(self, x):
+        if not hasattr(self, "_mom"):
+            self._mom = torch.zeros(2, dtype=torch.float64, device=self.device)
+        _lib.check(self._L.lhw_moments(_p(x), x.numel(), _p(self._mom), self._stream()))
+        return self._mom
+
+    def scale_shift(self, x, mean, inv):
+        _lib.check(self._L.lhw_scale_shift(_p(x), x.numel(), float(mean), float(inv), self._stream()))
+
     def grad_columns(self, T, N, xn, xm, act, old_logp, adv, ret, done, cols):
         """BPTT over columns ``cols`` (int32 device tensor) of the time-major [T][N] rollout."""
         _lib.check(self._L.lhw_rnn_grad(self._h, _p(self.theta), _p(self.grad), int(T), int(N), _p(xn), _p(xm), _p(act), _p(old_logp),
@@ -169,3 +186,31 @@ class RnnKernels:
         self.adam_step += 1
         _lib.check(self._L.lhw_rnn_apply(self._h, _p(self.theta), _p(self.grad), _p(self.adam_m), _p(self.adam_v), self.adam_step,
                                          float(grad_scale), self._stream()))
+
+
+def reference_init_lstm(obs_dim, act_dim, hidden=256, init_std=0.2, generator_seed=None):
+    """Initial weights with the RNG consumption of the reference's recurrent constructors (reference
+    rl/policies/actor.py:191-232, critic.py:52-66, base.py:5-22): per network two nn.LSTMCell (default uniform init, not
+    touched by normc_fn) and one nn.Linear read-out, then normc on the Linear (actor read-out x0.01); actor first."""
+    import torch.nn as nn
+    if generator_seed is not None:
+        torch.manual_seed(generator_seed)
+
+    def net(out_dim, scale_out):
+        cells = [nn.LSTMCell(obs_dim, hidden), nn.LSTMCell(hidden, hidden)]
+        lin = nn.Linear(hidden, out_dim)
+        lin.weight.data.normal_(0, 1)
+        lin.weight.data *= 1 / torch.sqrt(lin.weight.data.pow(2).sum(1, keepdim=True))
+        lin.bias.data.fill_(0)
+        if scale_out is not None:
+            lin.weight.data.mul_(scale_out)
+        return cells, lin
+
+    out = {}
+    for pre, (cells, lin) in (("a", net(act_dim, 0.01)), ("c", net(1, None))):
+        for k, cell in enumerate(cells, 1):
+            out[f"{pre}_wih{k}"], out[f"{pre}_whh{k}"] = cell.weight_ih.data.clone(), cell.weight_hh.data.clone()
+            out[f"{pre}_bih{k}"], out[f"{pre}_bhh{k}"] = cell.bias_ih.data.clone(), cell.bias_hh.data.clone()
+        out[f"{pre}_wout"], out[f"{pre}_bout"] = lin.weight.data.clone(), lin.bias.data.clone()
+    out["stds"] = init_std * torch.ones(act_dim)
+    return out

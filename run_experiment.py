@@ -5,8 +5,9 @@ on-device rollout + PPO of this repository.
     python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 run_experiment.py train --env jvrc_walk ...
 
 Differences from the reference, by design: no Ray (`--num-procs` is the number of on-device envs per GPU unless
-`--num-envs` is given); `--recurrent` and the `eval` sub-command (GL viewer on CPU MuJoCo) are not part of the path built
-here and raise; `--imitate` needs an env description with `imitation_projector()` (as in the reference).
+`--num-envs` is given); with `--recurrent` (LSTM actor / critic) `--minibatch-size` counts env columns = trajectories, as it
+counts trajectories in the reference; the `eval` sub-command (GL viewer on CPU MuJoCo) is not part of the path built here;
+`--imitate` needs an env description with `imitation_projector()` (as in the reference).
 """
 import argparse
 import os
