@@ -245,14 +245,14 @@ struct HumanoidEnv {
 #define U_EK (U_EMARGIN + NE)
 #define U_EB (U_EK + NE)
 #define U_EIMP (U_EB + NE)
-#define U_EFL (U_EIMP + NE)
 constexpr int cmax(int a, int b) { return a > b ? a : b; }
 
-template <int NE_T, int NC_T>
+template <int NE_T, int NC_T, bool PRM_T>
 struct LdsT {
   static constexpr int NE_ = NE_T, NC_ = NC_T;
-  // H slot: the nv x nv factor, or the six per-row parameter arrays parked there before the reference acceleration is formed
-  static constexpr int USIZE_ = cmax(cmax(U_END_A, U_END_B), NE_T * LDV + cmax(NV * LDV, 6 * NE_T));
+  static constexpr bool PRM_ = PRM_T;   // per-env model parameters are staged in LDS (else read from the model tables)
+  // H slot: the nv x nv factor, or the five per-row parameter arrays parked there before the reference acceleration is formed
+  static constexpr int USIZE_ = cmax(cmax(U_END_A, U_END_B), NE_T * LDV + cmax(NV * LDV, 5 * NE_T));
   double qpos[NQ], qvel[NV], ctrl[NU];
   double xpos[NB * 3];
   double rootmat[9], com[4], svel[18];   // root xmat; tree com; cvel of the three tracked bodies (root, right foot, left foot)
@@ -265,12 +265,25 @@ struct LdsT {
   double con_dist[NC_T], con_pos[NC_T * 3], con_frame[NC_T * 9], con_mu[NC_T], con_solref[NC_T * 2], con_solimp[NC_T * 5], con_margin[NC_T];
   int con_g1[NC_T], con_g2[NC_T], con_dim[NC_T], con_row[NC_T];
   double sq[NU], sv[NU], frc[NU];
-  double damp[NV], floss[NV], bmass[NB], bipos[NB * 3], xfrc[12];  // per-env parameters, loaded once per launch
+  // per-env parameters, loaded once per launch (one-element stubs when the task reads the shared model tables instead)
+  double damp[PRM_T ? NV : 1], floss[PRM_T ? NV : 1], bmass[PRM_T ? NB : 1], bipos[PRM_T ? NB * 3 : 1], xfrc[PRM_T ? 12 : 1];
   double U[USIZE_];
   int ncon, nefc, nlim, overflow;
 };
 
 #define SYNC() __syncthreads()
+template <class L> __device__ __forceinline__ double prm_damp(const HModel& m, const L& S, int d) {
+  if constexpr (L::PRM_) return S.damp[d]; else return m.dof_d[DDS * d + DD_DAMPING];
+}
+template <class L> __device__ __forceinline__ double prm_floss(const HModel& m, const L& S, int d) {
+  if constexpr (L::PRM_) return S.floss[d]; else return m.dof_d[DDS * d + DD_FLOSS];
+}
+template <class L> __device__ __forceinline__ double prm_mass(const HModel& m, const L& S, int b) {
+  if constexpr (L::PRM_) return S.bmass[b]; else return m.body_d[BDS * b + BD_MASS];
+}
+template <class L> __device__ __forceinline__ double prm_ipos(const HModel& m, const L& S, int b, int a) {
+  if constexpr (L::PRM_) return S.bipos[3 * b + a]; else return m.body_d[BDS * b + BD_IPOS + a];
+}
 
 // ------------------------------------------------------------------------------------------------ small math
 // Wavefront reductions on the DPP path (row_shr 1/2/4/8 inside each 16-lane row, then row_bcast 15/31 across rows:
@@ -511,7 +524,8 @@ __device__ void fwd_kinematics(const HModel& m, L& S, int lane) {
         }
       }
       double t[3];
-      mat_vec(t, R, &S.bipos[3 * b]);
+      const double bip[3] = {prm_ipos(m, S, b, 0), prm_ipos(m, S, b, 1), prm_ipos(m, S, b, 2)};
+      mat_vec(t, R, bip);
       for (int k = 0; k < 3; k++) { S.xpos[3 * b + k] = xp[k]; S.U[U_XIPOS + 3 * b + k] = xp[k] + t[k]; }
 #pragma unroll
       for (int k = 0; k < 9; k++) S.U[U_XMAT + 9 * b + k] = R[k];
@@ -550,7 +564,7 @@ template <class L>
 __device__ double fwd_com(const HModel& m, const HParams& p, L& S, int lane) {
   double ms = 0, mx = 0, my = 0, mz = 0;
   if (lane >= 1 && lane < m.nbody && m.body_i[BIS * (lane) + BI_ROOT] == 1) {
-    ms = S.bmass[lane];
+    ms = prm_mass(m, S, lane);
     mx = ms * S.U[U_XIPOS + 3 * lane]; my = ms * S.U[U_XIPOS + 3 * lane + 1]; mz = ms * S.U[U_XIPOS + 3 * lane + 2];
   }
   ms = wave_sum(ms); mx = wave_sum(mx); my = wave_sum(my); mz = wave_sum(mz);
@@ -558,7 +572,7 @@ __device__ double fwd_com(const HModel& m, const HParams& p, L& S, int lane) {
   if (lane == 0) { S.com[0] = com[0]; S.com[1] = com[1]; S.com[2] = com[2]; }
   if (lane >= 1 && lane < m.nbody) {
     const int b = lane;
-    const double mass = S.bmass[b];
+    const double mass = prm_mass(m, S, b);
     // static bodies (their own root) use their own com as reference; they never enter M or the bias force
     const bool dyn = m.body_i[BIS * (b) + BI_ROOT] == 1;
     double dif[3];
@@ -594,7 +608,7 @@ __device__ double fwd_com(const HModel& m, const HParams& p, L& S, int lane) {
   SYNC();
   // mj_xfrcAccumulate: Cartesian force / torque applied at the com of the perturbed bodies -> joint space
   double qapp = 0;
-  if (p.env_params && lane < m.nv) {
+  if (L::PRM_ && p.env_params && lane < m.nv) {
     for (int k = 0; k < p.n_pbody; k++) {
       const int pb = p.pbody[k];
       if (!(((unsigned)m.body_i[BIS * pb + BI_DOFMASK] >> lane) & 1u)) continue;
@@ -696,8 +710,9 @@ __device__ __forceinline__ void col_sphere_sphere(ConSink<L>& k, const double* p
 }
 // Box-box: separating-axis test over the 15 candidate axes (3 + 3 face normals, 9 edge cross products; ties go to the
 // faces of geom2, an edge axis must beat the best face by 1e-6), then either a face contact -- the incident face polygon
-// is clipped against the side planes of the reference face (Sutherland-Hodgman) and the vertices at or below the
-// reference face within `margin` become contacts, at most 4, deepest first -- or a single edge-edge contact at the
+// and the reference face rectangle are intersected (incident vertices inside the rectangle, rectangle corners inside the
+// incident face, edge x side crossings) and the vertices at or below the reference face within `margin` become
+// contacts, at most 4, deepest first -- or a single edge-edge contact at the
 // mid-point of the closest points of the two edges.  This is the classical SAT + clipping construction (as in ODE's
 // dBoxBox), NOT a restatement of MuJoCo's mjc_BoxBox, whose source could not be consulted: the two agree for face-face
 // resting contacts (what the stair terrain produces) and may differ in contact count / placement in edge cases
@@ -713,123 +728,185 @@ struct BoxRec {  // contacts of one box-box pair, kept between the counting and 
     }
   }
 };
+__device__ __forceinline__ double sel3(int i, double a0, double a1, double a2) { return i == 0 ? a0 : (i == 1 ? a1 : a2); }
+
+// Every array below is indexed by compile-time constants only (loops fully unrolled, run-time choices through sel3), so the
+// whole narrow phase lives in registers: the first version kept the clipped polygon in scratch memory and cost ~58 k
+// cycles per sub-step for a wave with feet on boxes.
 template <class L>
 __device__ __noinline__ void col_box_box(BoxRec& k, const HModel& m, const L& S, int g1, int g2, double margin) {
-  const double zero[3] = {0, 0, 0};
   double p1[3], p2[3], R1[9], R2[9], s1[3], s2[3];
+#pragma unroll
   for (int a = 0; a < 3; a++) { p1[a] = S.U[U_GPOS + 3 * g1 + a]; p2[a] = S.U[U_GPOS + 3 * g2 + a]; s1[a] = m.geom_d[GDS * (g1) + GD_SIZE + a]; s2[a] = m.geom_d[GDS * (g2) + GD_SIZE + a]; }
+#pragma unroll
   for (int a = 0; a < 9; a++) { R1[a] = S.U[U_GMAT + 9 * g1 + a]; R2[a] = S.U[U_GMAT + 9 * g2 + a]; }
-  double A[3][3], B[3][3], d[3] = {p2[0] - p1[0], p2[1] - p1[1], p2[2] - p1[2]};
+  double A[3][3], B[3][3];
+  const double d[3] = {p2[0] - p1[0], p2[1] - p1[1], p2[2] - p1[2]};
+#pragma unroll
   for (int i = 0; i < 3; i++)
+#pragma unroll
     for (int c = 0; c < 3; c++) { A[i][c] = R1[3 * c + i]; B[i][c] = R2[3 * c + i]; }
   double R[3][3], AR[3][3], ta[3], tb[3];
+#pragma unroll
   for (int i = 0; i < 3; i++) {
     ta[i] = dot3(d, A[i]); tb[i] = dot3(d, B[i]);
+#pragma unroll
     for (int j = 0; j < 3; j++) { R[i][j] = dot3(A[i], B[j]); AR[i][j] = fabs(R[i][j]) + 1e-12; }
   }
   double best = -1e300;
   int code = -1;
+  bool sep = false;
+#pragma unroll
   for (int i = 0; i < 3; i++) {
     const double s = fabs(ta[i]) - (s1[i] + s2[0] * AR[i][0] + s2[1] * AR[i][1] + s2[2] * AR[i][2]);
-    if (s > margin) return;
+    sep = sep || s > margin;
     if (s > best) { best = s; code = i; }
   }
+#pragma unroll
   for (int j = 0; j < 3; j++) {
     const double s = fabs(tb[j]) - (s2[j] + s1[0] * AR[0][j] + s1[1] * AR[1][j] + s1[2] * AR[2][j]);
-    if (s > margin) return;
+    sep = sep || s > margin;
     if (s > best - 1e-9) { if (s > best) best = s; code = 3 + j; }
   }
   double ebest = -1e300;
   int ecode = -1;
+#pragma unroll
   for (int i = 0; i < 3; i++)
+#pragma unroll
     for (int j = 0; j < 3; j++) {
       const double len2 = 1.0 - R[i][j] * R[i][j];
-      if (len2 < 1e-12) continue;
       const int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
       const double tl = ta[i2] * R[i1][j] - ta[i1] * R[i2][j];
       const double ra = s1[i1] * AR[i2][j] + s1[i2] * AR[i1][j], rb = s2[j1] * AR[i][j2] + s2[j2] * AR[i][j1];
-      const double s = (fabs(tl) - ra - rb) / sqrt(len2);
-      if (s > margin) return;
-      if (s > ebest) { ebest = s; ecode = 6 + 3 * i + j; }
+      if (len2 >= 1e-12) {
+        const double s = (fabs(tl) - ra - rb) / sqrt(len2);
+        sep = sep || s > margin;
+        if (s > ebest) { ebest = s; ecode = 6 + 3 * i + j; }
+      }
     }
+  if (sep) return;
   if (ecode >= 0 && ebest > best + 1e-6) {
     const int i = (ecode - 6) / 3, j = (ecode - 6) % 3;
+    const double Ai[3] = {sel3(i, A[0][0], A[1][0], A[2][0]), sel3(i, A[0][1], A[1][1], A[2][1]), sel3(i, A[0][2], A[1][2], A[2][2])};
+    const double Bj[3] = {sel3(j, B[0][0], B[1][0], B[2][0]), sel3(j, B[0][1], B[1][1], B[2][1]), sel3(j, B[0][2], B[1][2], B[2][2])};
     double n[3];
-    cross3(n, A[i], B[j]);
+    cross3(n, Ai, Bj);
     normalize3(n);
     if (dot3(n, d) < 0) { n[0] = -n[0]; n[1] = -n[1]; n[2] = -n[2]; }
     double pa[3] = {p1[0], p1[1], p1[2]}, pb[3] = {p2[0], p2[1], p2[2]};
+#pragma unroll
     for (int c = 0; c < 3; c++) {
       if (c != i) { const double sg = dot3(n, A[c]) > 0 ? 1.0 : -1.0; for (int a = 0; a < 3; a++) pa[a] += sg * s1[c] * A[c][a]; }
       if (c != j) { const double sg = dot3(n, B[c]) > 0 ? -1.0 : 1.0; for (int a = 0; a < 3; a++) pb[a] += sg * s2[c] * B[c][a]; }
     }
     const double w[3] = {pa[0] - pb[0], pa[1] - pb[1], pa[2] - pb[2]};
-    const double bq = R[i][j], dd = dot3(A[i], w), ee = dot3(B[j], w), den = 1.0 - bq * bq;
+    const double bq = sel3(i, sel3(j, R[0][0], R[0][1], R[0][2]), sel3(j, R[1][0], R[1][1], R[1][2]), sel3(j, R[2][0], R[2][1], R[2][2]));
+    const double dd = dot3(Ai, w), ee = dot3(Bj, w), den = 1.0 - bq * bq;
     const double al = (bq * ee - dd) / den, be = (ee - bq * dd) / den;
     double pos[3];
-    for (int a = 0; a < 3; a++) pos[a] = 0.5 * ((pa[a] + al * A[i][a]) + (pb[a] + be * B[j][a]));
-    k.emit(ebest, pos, n, zero);
+    for (int a = 0; a < 3; a++) pos[a] = 0.5 * ((pa[a] + al * Ai[a]) + (pb[a] + be * Bj[a]));
+    k.emit(ebest, pos, n, nullptr);
     return;
   }
   const bool refB = code >= 3;
   const int ax = refB ? code - 3 : code;
-  const double *pr = refB ? p2 : p1, *pc = refB ? p1 : p2, *sr = refB ? s2 : s1, *sc = refB ? s1 : s2;
-  double (*Ar)[3] = refB ? B : A;
-  double (*Ac)[3] = refB ? A : B;
-  double n[3] = {Ar[ax][0], Ar[ax][1], Ar[ax][2]};
+  double Ar[3][3], Ac[3][3], pr[3], pc[3], sr[3], sc[3];
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    pr[i] = refB ? p2[i] : p1[i]; pc[i] = refB ? p1[i] : p2[i]; sr[i] = refB ? s2[i] : s1[i]; sc[i] = refB ? s1[i] : s2[i];
+#pragma unroll
+    for (int c = 0; c < 3; c++) { Ar[i][c] = refB ? B[i][c] : A[i][c]; Ac[i][c] = refB ? A[i][c] : B[i][c]; }
+  }
+  double n[3] = {sel3(ax, Ar[0][0], Ar[1][0], Ar[2][0]), sel3(ax, Ar[0][1], Ar[1][1], Ar[2][1]), sel3(ax, Ar[0][2], Ar[1][2], Ar[2][2])};
   if (dot3(n, d) < 0) { n[0] = -n[0]; n[1] = -n[1]; n[2] = -n[2]; }
   const double nr[3] = {refB ? -n[0] : n[0], refB ? -n[1] : n[1], refB ? -n[2] : n[2]};
-  double fc[3];
-  for (int a = 0; a < 3; a++) fc[a] = pr[a] + nr[a] * sr[ax];
+  const double sr_ax = sel3(ax, sr[0], sr[1], sr[2]);
+  const double fc[3] = {pr[0] + nr[0] * sr_ax, pr[1] + nr[1] * sr_ax, pr[2] + nr[2] * sr_ax};
   int kc = 0;
   double bestdot = -1;
+#pragma unroll
   for (int c = 0; c < 3; c++) { const double v = fabs(dot3(nr, Ac[c])); if (v > bestdot) { bestdot = v; kc = c; } }
-  const double sgn = dot3(nr, Ac[kc]) > 0 ? -1.0 : 1.0;
-  const int ku = (kc + 1) % 3, kv = (kc + 2) % 3;
-  double poly[8][3], tmp[8][3];
-  int np = 4;
+  const int ku = (kc + 1) % 3, kv = (kc + 2) % 3, ru = (ax + 1) % 3, rv = (ax + 2) % 3;
+  double Akc[3], Aku[3], Akv[3], u[3], v[3];
+#pragma unroll
+  for (int a = 0; a < 3; a++) {
+    Akc[a] = sel3(kc, Ac[0][a], Ac[1][a], Ac[2][a]); Aku[a] = sel3(ku, Ac[0][a], Ac[1][a], Ac[2][a]); Akv[a] = sel3(kv, Ac[0][a], Ac[1][a], Ac[2][a]);
+    u[a] = sel3(ru, Ar[0][a], Ar[1][a], Ar[2][a]); v[a] = sel3(rv, Ar[0][a], Ar[1][a], Ar[2][a]);
+  }
+  const double sgn = dot3(nr, Akc) > 0 ? -1.0 : 1.0;
+  const double sckc = sel3(kc, sc[0], sc[1], sc[2]), scku = sel3(ku, sc[0], sc[1], sc[2]), sckv = sel3(kv, sc[0], sc[1], sc[2]);
+  const double ha = sel3(ru, sr[0], sr[1], sr[2]), hb = sel3(rv, sr[0], sr[1], sr[2]);
+  double P[4][3], px[4], py[4], pd[4];
+#pragma unroll
   for (int q = 0; q < 4; q++) {
     const double su = (q == 0 || q == 3) ? 1.0 : -1.0, sv = (q < 2) ? 1.0 : -1.0;
-    for (int a = 0; a < 3; a++) poly[q][a] = pc[a] + sgn * sc[kc] * Ac[kc][a] + su * sc[ku] * Ac[ku][a] + sv * sc[kv] * Ac[kv][a];
+    double w0[3];
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+      P[q][a] = pc[a] + sgn * sckc * Akc[a] + su * scku * Aku[a] + sv * sckv * Akv[a];
+      w0[a] = P[q][a] - fc[a];
+    }
+    px[q] = dot3(w0, u); py[q] = dot3(w0, v); pd[q] = dot3(w0, nr);
   }
-  const int ru = (ax + 1) % 3, rv = (ax + 2) % 3;
-  for (int pl = 0; pl < 4 && np > 0; pl++) {
-    const double* axis = (pl < 2) ? Ar[ru] : Ar[rv];
-    const double half = (pl < 2) ? sr[ru] : sr[rv], sg = (pl & 1) ? -1.0 : 1.0;
-    int nq = 0;
-    for (int q = 0; q < np; q++) {
-      const double *x0 = poly[q], *x1 = poly[(q + 1) % np];
-      const double w0[3] = {x0[0] - pr[0], x0[1] - pr[1], x0[2] - pr[2]}, w1[3] = {x1[0] - pr[0], x1[1] - pr[1], x1[2] - pr[2]};
-      const double e0 = sg * dot3(w0, axis) - half, e1 = sg * dot3(w1, axis) - half;
-      if (e0 <= 0) { if (nq < 8) { for (int a = 0; a < 3; a++) tmp[nq][a] = x0[a]; nq++; } }
-      if ((e0 <= 0) != (e1 <= 0)) {
-        const double tt = e0 / (e0 - e1);
-        if (nq < 8) { for (int a = 0; a < 3; a++) tmp[nq][a] = x0[a] + tt * (x1[a] - x0[a]); nq++; }
+  // candidates (i) incident vertices inside the rectangle, (ii) rectangle corners inside the incident parallelogram,
+  // (iii) incident edge x rectangle side crossings; the four deepest are kept by bubbling through a sorted 4-slot list
+  double bd[4] = {1e300, 1e300, 1e300, 1e300}, bp[4][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+  auto push = [&](double nd, double n0, double n1, double n2) {
+    if (nd <= margin) {
+#pragma unroll
+      for (int kk = 0; kk < 4; kk++)
+        if (nd < bd[kk]) {
+          double t = bd[kk]; bd[kk] = nd; nd = t;
+          t = bp[kk][0]; bp[kk][0] = n0; n0 = t;
+          t = bp[kk][1]; bp[kk][1] = n1; n1 = t;
+          t = bp[kk][2]; bp[kk][2] = n2; n2 = t;
+        }
+    }
+  };
+#pragma unroll
+  for (int q = 0; q < 4; q++)
+    if (fabs(px[q]) <= ha && fabs(py[q]) <= hb) push(pd[q], P[q][0], P[q][1], P[q][2]);
+  {
+    const double e1x = px[1] - px[0], e1y = py[1] - py[0], e2x = px[3] - px[0], e2y = py[3] - py[0];
+    const double det = e1x * e2y - e1y * e2x;
+    if (fabs(det) > 1e-14) {
+#pragma unroll
+      for (int c = 0; c < 4; c++) {
+        const double cx = (c == 0 || c == 3) ? ha : -ha, cy = (c < 2) ? hb : -hb;
+        const double al = ((cx - px[0]) * e2y - (cy - py[0]) * e2x) / det, be = (e1x * (cy - py[0]) - e1y * (cx - px[0])) / det;
+        if (al >= 0 && al <= 1 && be >= 0 && be <= 1) {
+          const double dep = pd[0] + al * (pd[1] - pd[0]) + be * (pd[3] - pd[0]);
+          push(dep, fc[0] + cx * u[0] + cy * v[0] + dep * nr[0], fc[1] + cx * u[1] + cy * v[1] + dep * nr[1],
+               fc[2] + cx * u[2] + cy * v[2] + dep * nr[2]);
+        }
       }
     }
-    np = nq;
-    for (int q = 0; q < np; q++) for (int a = 0; a < 3; a++) poly[q][a] = tmp[q][a];
   }
-  double dep[8];
-  int idx[8], cnt = 0;
-  for (int q = 0; q < np; q++) {
-    const double w0[3] = {poly[q][0] - fc[0], poly[q][1] - fc[1], poly[q][2] - fc[2]};
-    const double dq = dot3(w0, nr);
-    if (dq <= margin) { dep[cnt] = dq; idx[cnt] = q; cnt++; }
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    const int q1 = (q + 1) & 3;
+    const double dx = px[q1] - px[q], dy = py[q1] - py[q], dd = pd[q1] - pd[q];
+#pragma unroll
+    for (int sd = 0; sd < 4; sd++) {
+      double tt = 0, other = 0, lim = 0;
+      bool ok;
+      if (sd < 2) {
+        ok = dx != 0;
+        tt = ((sd == 0 ? ha : -ha) - px[q]) / dx; other = py[q] + tt * dy; lim = hb;
+      } else {
+        ok = dy != 0;
+        tt = ((sd == 2 ? hb : -hb) - py[q]) / dy; other = px[q] + tt * dx; lim = ha;
+      }
+      if (ok && tt > 0 && tt < 1 && fabs(other) < lim)
+        push(pd[q] + tt * dd, P[q][0] + tt * (P[q1][0] - P[q][0]), P[q][1] + tt * (P[q1][1] - P[q][1]), P[q][2] + tt * (P[q1][2] - P[q][2]));
+    }
   }
-  for (int a = 1; a < cnt; a++) {
-    const double dv = dep[a];
-    const int iv = idx[a];
-    int b = a - 1;
-    while (b >= 0 && dep[b] > dv) { dep[b + 1] = dep[b]; idx[b + 1] = idx[b]; b--; }
-    dep[b + 1] = dv; idx[b + 1] = iv;
-  }
-  if (cnt > 4) cnt = 4;
-  for (int q = 0; q < cnt; q++) {
-    double pos[3];
-    for (int a = 0; a < 3; a++) pos[a] = poly[idx[q]][a] - nr[a] * dep[q] * 0.5;
-    k.emit(dep[q], pos, n, zero);
-  }
+#pragma unroll
+  for (int q = 0; q < 4; q++)
+    if (bd[q] < 1e299) {
+      const double pos[3] = {bp[q][0] - nr[0] * bd[q] * 0.5, bp[q][1] - nr[1] * bd[q] * 0.5, bp[q][2] - nr[2] * bd[q] * 0.5};
+      k.emit(bd[q], pos, n, nullptr);
+    }
 }
 
 template <class L>
@@ -1036,7 +1113,7 @@ __device__ __forceinline__ void row_params(const HModel& m, const double* sr_in,
 template <class L>
 __device__ void fwd_constraints(const HModel& m, L& S, int lane) {
   // ---- frictionloss rows: lane = dof (mj_instantiateFriction); they come first
-  const double myfl = lane < m.nv ? S.floss[lane] : 0.0;
+  const double myfl = lane < m.nv ? prm_floss(m, S, lane) : 0.0;
   int nfr;
   const int fbase = wave_scan(myfl > 0 ? 1 : 0, &nfr) - (myfl > 0 ? 1 : 0);
   // ---- limits: lane = joint; rows ordered by joint, lower side first
@@ -1065,7 +1142,7 @@ __device__ void fwd_constraints(const HModel& m, L& S, int lane) {
   }
   const int nefc = wave_max_i(rend);
   for (int it = lane; it < nefc * LDV; it += 64) S.U[U_J + it] = 0;
-  if (lane < NE) S.U[U_EFL + lane] = 0;
+  if (lane < NE) S.dact[lane] = 0;   // frictionloss of each row is parked in dact until the Newton loop starts writing it
   SYNC();
   if (myfl > 0 && fbase < NE) {
     const int d = lane, r = fbase;
@@ -1074,7 +1151,7 @@ __device__ void fwd_constraints(const HModel& m, L& S, int lane) {
     row_params(m, sr, si, 0.0, 0.0, m.dof_d[DDS * d + DD_INVW], &K, &B, &imp, &R);
     S.U[U_J + r * LDV + d] = 1.0;
     S.U[U_EPOS + r] = 0; S.U[U_EMARGIN + r] = 0; S.efc_D[r] = 1 / R; S.U[U_EK + r] = K; S.U[U_EB + r] = B; S.U[U_EIMP + r] = imp;
-    S.U[U_EFL + r] = myfl;
+    S.dact[r] = myfl;
   }
   if (nl > 0) {
     const int j = lane, d = m.jnt_i[JIS * (j) + JI_DADR];
@@ -1274,7 +1351,7 @@ __device__ __forceinline__ void substep(const HModel& m, const HParams& p, L& S,
     double act = 0;
     for (int u = 0; u < m.nu; u++)
       if (m.act_i[AIS * (u) + AI_DOF] == lane) act += m.act_d[ADS * (u) + AD_GEAR] * S.frc[u];
-    fs = -S.damp[lane] * qv - bias + act + qapp;
+    fs = -prm_damp(m, S, lane) * qv - bias + act + qapp;
     S.vec[lane] = qv;
   }
   SYNC();
@@ -1297,7 +1374,7 @@ __device__ __forceinline__ void substep(const HModel& m, const HParams& p, L& S,
     if (isrow) {
       aref = -S.U[U_EB + lane] * jv0 - S.U[U_EK + lane] * S.U[U_EIMP + lane] * (S.U[U_EPOS + lane] - S.U[U_EMARGIN + lane]);
       D = S.efc_D[lane];
-      fl = S.U[U_EFL + lane];
+      fl = S.dact[lane];
     }
   }
   SYNC();
@@ -1424,7 +1501,7 @@ __device__ __forceinline__ void substep(const HModel& m, const HParams& p, L& S,
   if (eulerdamp) {
     for (int it = lane; it < NV * LDV; it += 64) S.U[U_H + it] = S.M[it];
     SYNC();
-    if (lane < nv) S.U[U_H + lane * LDV + lane] += h * S.damp[lane];
+    if (lane < nv) S.U[U_H + lane * LDV + lane] += h * prm_damp(m, S, lane);
     SYNC();
     anew = chol_solve_inplace(S.U + U_H, nv, lane, fs + fcon);
   }
@@ -1579,7 +1656,7 @@ __global__ void __launch_bounds__(64, 2) humanoid_kernel(HModel m, HParams p, HS
                                                       float* __restrict__ rew, unsigned char* __restrict__ done_out,
                                                       float* __restrict__ rew_terms, const unsigned char* __restrict__ mask,
                                                       double* __restrict__ xq, double* __restrict__ xv) {
-  using L = LdsT<(TASK == TASK_STEP ? 64 : 48), (TASK == TASK_STEP ? 16 : 12)>;
+  using L = LdsT<(TASK == TASK_STEP ? 64 : 48), (TASK == TASK_STEP ? 16 : 12), TASK != TASK_STEP>;
   __shared__ L S;
   const int env = blockIdx.x, lane = threadIdx.x;
   if (MODE == 1 && mask && !mask[env]) return;
@@ -1617,15 +1694,17 @@ __global__ void __launch_bounds__(64, 2) humanoid_kernel(HModel m, HParams p, HS
   double goal[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   if (TASK == TASK_STEP) { t1 = irec[RI_T1]; t2 = irec[RI_T2]; reached = irec[RI_REACHED]; frames = irec[RI_FRAMES]; nseq = irec[RI_NSEQ]; }
   // per-env model parameters (or the shared defaults) -> LDS, once per launch
-  if (lane < m.nv) {
-    S.damp[lane] = prm ? prm[P_DAMP + lane] : m.dof_d[DDS * lane + DD_DAMPING];
-    S.floss[lane] = prm ? prm[P_FLOSS + lane] : m.dof_d[DDS * lane + DD_FLOSS];
+  if constexpr (L::PRM_) {
+    if (lane < m.nv) {
+      S.damp[lane] = prm ? prm[P_DAMP + lane] : m.dof_d[DDS * lane + DD_DAMPING];
+      S.floss[lane] = prm ? prm[P_FLOSS + lane] : m.dof_d[DDS * lane + DD_FLOSS];
+    }
+    if (lane < m.nbody) {
+      S.bmass[lane] = prm ? prm[P_MASS + lane] : m.body_d[BDS * lane + BD_MASS];
+      for (int a = 0; a < 3; a++) S.bipos[3 * lane + a] = prm ? prm[P_IPOS + 3 * lane + a] : m.body_d[BDS * lane + BD_IPOS + a];
+    }
+    if (lane < 12) S.xfrc[lane] = prm ? prm[P_XFRC + lane] : 0.0;
   }
-  if (lane < m.nbody) {
-    S.bmass[lane] = prm ? prm[P_MASS + lane] : m.body_d[BDS * lane + BD_MASS];
-    for (int a = 0; a < 3; a++) S.bipos[3 * lane + a] = prm ? prm[P_IPOS + 3 * lane + a] : m.body_d[BDS * lane + BD_IPOS + a];
-  }
-  if (lane < 12) S.xfrc[lane] = prm ? prm[P_XFRC + lane] : 0.0;
   SYNC();
 
   bool do_reset = MODE == 1;

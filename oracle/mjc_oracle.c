@@ -548,9 +548,9 @@ static int capsuleCapsule(RawCon* c, const double* p1, const double* R1, const d
   return n;
 }
 
-/* Box-box: separating-axis test over the 15 candidate axes, then either a face contact (the incident face polygon is
- * clipped against the side planes of the reference face; vertices at or below the reference face within `margin` become
- * contacts, at most 4, deepest first) or a single edge-edge contact.  This is the classical SAT + clipping construction
+/* Box-box: separating-axis test over the 15 candidate axes, then either a face contact (the vertices of the intersection
+ * of the incident face with the reference face rectangle, at or below the reference face within `margin`, become contacts,
+ * at most 4, deepest first) or a single edge-edge contact.  This is the classical SAT + clipping construction
  * (as in ODE's dBoxBox); it is NOT a restatement of MuJoCo's mjc_BoxBox, whose source could not be consulted -- contact
  * points of the two agree for face-face resting contacts (the case the stair terrain produces) and may differ in count and
  * placement for edge cases.  The HIP kernel implements exactly this algorithm (csrc/lhw_humanoid.hip box_box). */
@@ -625,50 +625,79 @@ static int boxBox(RawCon* out, const double* p1, const double* R1, const double*
   for (int k = 0; k < 3; k++) { double v = fabs(dot3(nr, Ac[k])); if (v > bestdot) { bestdot = v; kc = k; } }
   double sgn = dot3(nr, Ac[kc]) > 0 ? -1.0 : 1.0;
   int ku = (kc + 1) % 3, kv = (kc + 2) % 3;
-  double poly[8][3], tmp[8][3];
-  int np = 4;
-  for (int q = 0; q < 4; q++) {
-    double su = (q == 0 || q == 3) ? 1.0 : -1.0, sv = (q < 2) ? 1.0 : -1.0;
-    for (int a = 0; a < 3; a++) poly[q][a] = pc[a] + sgn * sc[kc] * Ac[kc][a] + su * sc[ku] * Ac[ku][a] + sv * sc[kv] * Ac[kv][a];
-  }
+  /* incident face vertices (a cycle), in the reference-face frame: origin fc, axes u, v, outward normal nr */
   int ru = (ax + 1) % 3, rv = (ax + 2) % 3;
-  for (int pl = 0; pl < 4 && np > 0; pl++) { /* Sutherland-Hodgman against sign*(x-pr).axis <= half */
-    const double* axis = (pl < 2) ? Ar[ru] : Ar[rv];
-    double half = (pl < 2) ? sr[ru] : sr[rv], sg = (pl & 1) ? -1.0 : 1.0;
-    int nq = 0;
-    for (int q = 0; q < np; q++) {
-      const double *x0 = poly[q], *x1 = poly[(q + 1) % np];
-      double w0[3] = {x0[0] - pr[0], x0[1] - pr[1], x0[2] - pr[2]}, w1[3] = {x1[0] - pr[0], x1[1] - pr[1], x1[2] - pr[2]};
-      double e0 = sg * dot3(w0, axis) - half, e1 = sg * dot3(w1, axis) - half;
-      if (e0 <= 0) { if (nq < 8) { memcpy(tmp[nq], x0, 3 * sizeof(double)); nq++; } }
-      if ((e0 <= 0) != (e1 <= 0)) {
-        double tt = e0 / (e0 - e1);
-        if (nq < 8) { for (int a = 0; a < 3; a++) tmp[nq][a] = x0[a] + tt * (x1[a] - x0[a]); nq++; }
-      }
-    }
-    np = nq;
-    memcpy(poly, tmp, sizeof(double) * 3 * np);
-  }
-  /* depths; keep at most 4, deepest first (stable) */
-  double dep[8]; int idx[8], cnt = 0;
-  for (int q = 0; q < np; q++) {
-    double w0[3] = {poly[q][0] - fc[0], poly[q][1] - fc[1], poly[q][2] - fc[2]};
-    double dq = dot3(w0, nr);
-    if (dq <= margin) { dep[cnt] = dq; idx[cnt] = q; cnt++; }
-  }
-  for (int a = 1; a < cnt; a++) { /* insertion sort by depth */
-    double dv = dep[a]; int iv = idx[a], b = a - 1;
-    while (b >= 0 && dep[b] > dv) { dep[b + 1] = dep[b]; idx[b + 1] = idx[b]; b--; }
-    dep[b + 1] = dv; idx[b + 1] = iv;
-  }
-  if (cnt > 4) cnt = 4;
-  for (int q = 0; q < cnt; q++) {
-    out[q].dist = dep[q];
+  const double *u = Ar[ru], *v = Ar[rv];
+  double ha = sr[ru], hb = sr[rv];
+  double P[4][3], px[4], py[4], pd[4];
+  for (int q = 0; q < 4; q++) {
+    double su = (q == 0 || q == 3) ? 1.0 : -1.0, sv = (q < 2) ? 1.0 : -1.0, w0[3];
     for (int a = 0; a < 3; a++) {
-      out[q].frame[a] = n[a]; out[q].frame[3 + a] = 0;
-      out[q].pos[a] = poly[idx[q]][a] - nr[a] * dep[q] * 0.5;
+      P[q][a] = pc[a] + sgn * sc[kc] * Ac[kc][a] + su * sc[ku] * Ac[ku][a] + sv * sc[kv] * Ac[kv][a];
+      w0[a] = P[q][a] - fc[a];
+    }
+    px[q] = dot3(w0, u); py[q] = dot3(w0, v); pd[q] = dot3(w0, nr);
+  }
+  /* Candidate contact points = vertices of (incident face) n (reference face rectangle), enumerated in a fixed order:
+   * (i) incident vertices inside the rectangle, (ii) rectangle corners inside the incident parallelogram (lifted onto the
+   * incident plane), (iii) incident edge x rectangle side crossings.  The four deepest (depth <= margin) are kept by
+   * bubbling each candidate through a 4-slot list sorted by depth (strict <: earlier candidates win ties). */
+  double bd[4] = {1e300, 1e300, 1e300, 1e300}, bp[4][3] = {{0}};
+#define BB_PUSH(DEPTH, X0, X1, X2)                                              \
+  do {                                                                          \
+    double nd_ = (DEPTH), n0_ = (X0), n1_ = (X1), n2_ = (X2), t_;               \
+    if (nd_ <= margin)                                                          \
+      for (int k_ = 0; k_ < 4; k_++)                                            \
+        if (nd_ < bd[k_]) {                                                     \
+          t_ = bd[k_]; bd[k_] = nd_; nd_ = t_;                                  \
+          t_ = bp[k_][0]; bp[k_][0] = n0_; n0_ = t_;                            \
+          t_ = bp[k_][1]; bp[k_][1] = n1_; n1_ = t_;                            \
+          t_ = bp[k_][2]; bp[k_][2] = n2_; n2_ = t_;                            \
+        }                                                                       \
+  } while (0)
+  for (int q = 0; q < 4; q++)
+    if (fabs(px[q]) <= ha && fabs(py[q]) <= hb) BB_PUSH(pd[q], P[q][0], P[q][1], P[q][2]);
+  {
+    double e1x = px[1] - px[0], e1y = py[1] - py[0], e2x = px[3] - px[0], e2y = py[3] - py[0];
+    double det = e1x * e2y - e1y * e2x;
+    if (fabs(det) > 1e-14)
+      for (int c = 0; c < 4; c++) {
+        double cx = (c == 0 || c == 3) ? ha : -ha, cy = (c < 2) ? hb : -hb;
+        double al = ((cx - px[0]) * e2y - (cy - py[0]) * e2x) / det, be = (e1x * (cy - py[0]) - e1y * (cx - px[0])) / det;
+        if (al >= 0 && al <= 1 && be >= 0 && be <= 1) {
+          double dep = pd[0] + al * (pd[1] - pd[0]) + be * (pd[3] - pd[0]);
+          BB_PUSH(dep, fc[0] + cx * u[0] + cy * v[0] + dep * nr[0], fc[1] + cx * u[1] + cy * v[1] + dep * nr[1],
+                  fc[2] + cx * u[2] + cy * v[2] + dep * nr[2]);
+        }
+      }
+  }
+  for (int q = 0; q < 4; q++) {
+    int q1 = (q + 1) & 3;
+    double dx = px[q1] - px[q], dy = py[q1] - py[q], dd = pd[q1] - pd[q];
+    for (int sd = 0; sd < 4; sd++) {
+      double tt, other, lim;
+      if (sd < 2) {
+        if (dx == 0) continue;
+        tt = ((sd == 0 ? ha : -ha) - px[q]) / dx; other = py[q] + tt * dy; lim = hb;
+      } else {
+        if (dy == 0) continue;
+        tt = ((sd == 2 ? hb : -hb) - py[q]) / dy; other = px[q] + tt * dx; lim = ha;
+      }
+      if (tt > 0 && tt < 1 && fabs(other) < lim)
+        BB_PUSH(pd[q] + tt * dd, P[q][0] + tt * (P[q1][0] - P[q][0]), P[q][1] + tt * (P[q1][1] - P[q][1]), P[q][2] + tt * (P[q1][2] - P[q][2]));
     }
   }
+#undef BB_PUSH
+  int cnt = 0;
+  for (int q = 0; q < 4; q++)
+    if (bd[q] < 1e299) {
+      out[cnt].dist = bd[q];
+      for (int a = 0; a < 3; a++) {
+        out[cnt].frame[a] = n[a]; out[cnt].frame[3 + a] = 0;
+        out[cnt].pos[a] = bp[q][a] - nr[a] * bd[q] * 0.5;
+      }
+      cnt++;
+    }
   return cnt;
 }
 

@@ -140,3 +140,15 @@ def test_ppo_imitate_wiring(tmp_path):
     assert algo.last_losses["imitation"] > 0
     with pytest.raises(ValueError, match="imitation_projector"):
         PPO(CartpoleSpec, args(), seed=1)
+
+
+def test_run_experiment_train_recurrent(tmp_path):
+    cmd = [sys.executable, os.path.join(ROOT, "run_experiment.py"), "train", "--env", "cartpole", "--logdir", str(tmp_path),
+           "--n-itr", "2", "--num-envs", "64", "--max-traj-len", "20", "--minibatch-size", "32", "--eval-freq", "100",
+           "--recurrent", "--seed", "0"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "Sampling took" in out.stdout and "Optimizer took" in out.stdout
+    run = [d for d in os.listdir(tmp_path) if d.endswith("_cartpole")]
+    raw = open(os.path.join(tmp_path, run[0], "actor_0.pt"), "rb").read()
+    assert b"Gaussian_LSTM_Actor" in raw
