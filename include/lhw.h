@@ -191,6 +191,9 @@ int lhw_ppo_normalize(LhwPpo* ppo, const float* obs, int64_t R, const float* obs
 int lhw_ppo_forward(LhwPpo* ppo, const float* theta, const float* obs, int64_t N, const float* obs_mean,
                     const float* obs_std, uint64_t seed, uint32_t env_id_base, uint32_t counter, int deterministic,
                     float* mu, float* act, float* logp, float* value, void* stream);
+/* fp16 != 0: lhw_ppo_forward (rollout inference) rounds weights and activations to fp16 and multiplies on the fp16 MFMA with
+ * float32 accumulation (BASELINE config "fp16 actor/critic"); the update (lhw_ppo_grad) always uses float32 operands */
+int lhw_ppo_set_inference_dtype(LhwPpo* ppo, int fp16);
 /* time-major [T][N] GAE(lambda); done holds LHW_DONE_* flags, vterm the critic value of the terminal
  * observation, vfinal [N] the value of the observation after the last step */
 int lhw_gae(int32_t T, int32_t N, const float* rew, const float* val, const uint8_t* done, const float* vterm,

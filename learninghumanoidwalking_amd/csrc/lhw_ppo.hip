@@ -154,6 +154,72 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(GemmArgs g) {
   }
 }
 
+// Half-precision inference GEMM (BASELINE config "fp16 actor/critic"): C = A B^T (+ bias, ReLU) with A [M][K] and B [N][K]
+// read as float32, rounded to fp16 while they are staged into LDS, multiplied on the fp16 MFMA
+// (v_mfma_f32_32x32x8_f16) with float32 accumulation; bias / ReLU / output stay float32.  Forward (rollout) only: the
+// update keeps float32 operands like the reference.
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+#define HLD (BK + 4)
+__global__ void __launch_bounds__(256) gemm_f16_fwd_kernel(GemmArgs g) {
+  __shared__ _Float16 Ah[BM][HLD];
+  __shared__ _Float16 Bh[BN][HLD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave & 1, wn = wave >> 1;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  f32x16 acc;
+  for (int r = 0; r < 16; r++) acc[r] = 0.f;
+  float4 ra, rb;
+  auto load = [&](int k0) {
+    ra = make_float4(0.f, 0.f, 0.f, 0.f);
+    rb = ra;
+    const int k = k0 + (tid & 3) * 4;
+    const int row = m0 + (tid >> 2), col = n0 + (tid >> 2);
+    if (row < g.M && k < g.K) {
+      ra = *reinterpret_cast<const float4*>(g.A + (size_t)row * g.lda + k);
+      if (k + 1 >= g.K) ra.y = 0.f;
+      if (k + 2 >= g.K) ra.z = 0.f;
+      if (k + 3 >= g.K) ra.w = 0.f;
+    }
+    if (col < g.N && k < g.K) {
+      rb = *reinterpret_cast<const float4*>(g.B + (size_t)col * g.ldb + k);
+      if (k + 1 >= g.K) rb.y = 0.f;
+      if (k + 2 >= g.K) rb.z = 0.f;
+      if (k + 3 >= g.K) rb.w = 0.f;
+    }
+  };
+  load(0);
+  for (int k0 = 0; k0 < g.K; k0 += BK) {
+    __syncthreads();
+    {
+      const int row = tid >> 2, kq = (tid & 3) * 4;
+      f16x4 ha = {(_Float16)ra.x, (_Float16)ra.y, (_Float16)ra.z, (_Float16)ra.w};
+      f16x4 hb = {(_Float16)rb.x, (_Float16)rb.y, (_Float16)rb.z, (_Float16)rb.w};
+      *reinterpret_cast<f16x4*>(&Ah[row][kq]) = ha;
+      *reinterpret_cast<f16x4*>(&Bh[row][kq]) = hb;
+    }
+    __syncthreads();
+    if (k0 + BK < g.K) load(k0 + BK);
+    const int am = wm * 32 + (lane & 31), bn = wn * 32 + (lane & 31), kh = lane >> 5;
+#pragma unroll
+    for (int kk = 0; kk < BK / 8; kk++) {
+      const f16x4 a = *reinterpret_cast<const f16x4*>(&Ah[am][kk * 8 + kh * 4]);
+      const f16x4 b = *reinterpret_cast<const f16x4*>(&Bh[bn][kk * 8 + kh * 4]);
+      acc = __builtin_amdgcn_mfma_f32_32x32x8f16(a, b, acc, 0, 0, 0);
+    }
+  }
+  const int col = n0 + wn * 32 + (lane & 31);
+  const float bias = (g.bias && col < g.N) ? g.bias[col] : 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; r++) {
+    int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    if (row < g.M && col < g.N) {
+      float v = acc[r] + bias;
+      if (g.relu) v = fmaxf(v, 0.f);
+      g.C[(size_t)row * g.ldc + col] = v;
+    }
+  }
+}
+
 // out[row*ldc + col] += sum over slices (in slice order) of part[z][row*N + col]: deterministic split-K reduction
 __global__ void __launch_bounds__(256) reduce_slices_kernel(const float* __restrict__ part, int nslices, int M, int N, float* __restrict__ out, int ldc) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -226,6 +292,7 @@ struct LhwPpo {
   int device, D, A, H, learn_std, max_rows;  // max_rows: capacity of the minibatch workspace (rows per net)
   float clip, ent_coeff, mirror_coeff, grad_clip, lr, adam_eps, beta1, beta2;
   int use_mirror;
+  int infer_half = 0;     // rollout inference with fp16 operands (lhw_ppo_set_inference_dtype)
   MlpLayout la, lc;       // actor, critic
   size_t off_actor, off_std, off_critic, n_params;  // flat theta: [actor | stds(A, padded to 4) | critic]
   // mirror tables (device): obs_src[Dp], obs_sign[Dp], act_src[A], act_sign[A]
@@ -256,9 +323,26 @@ struct LhwPpo {
     if (e_ != hipSuccess) return lhw_fail(LHW_ERR_HIP, "%s failed: %s", #x, hipGetErrorString(e_)); \
   } while (0)
 
-// y = mlp(x) for R rows; keeps h1/h2 for the backward pass
+static void launch_gemm_f16(const GemmArgs& g, hipStream_t s) {
+  dim3 grid((g.M + BM - 1) / BM, (g.N + BN - 1) / BN, 1);
+  hipLaunchKernelGGL(gemm_f16_fwd_kernel, grid, dim3(256), 0, s, g);
+}
+
+// y = mlp(x) for R rows; keeps h1/h2 for the backward pass.  half != 0: fp16 operands (rollout inference only)
 static void mlp_forward(const MlpLayout& L, const float* theta, const float* x, int ldx, int R, float* h1, float* h2,
-                        float* y, hipStream_t s) {
+                        float* y, hipStream_t s, int half = 0) {
+  if (half) {
+    GemmArgs g{};
+    g.A = x; g.lda = ldx; g.B = theta + L.w1; g.ldb = L.Dp; g.C = h1; g.ldc = L.H; g.M = R; g.N = L.H; g.K = L.Dp; g.bias = theta + L.b1; g.relu = 1;
+    launch_gemm_f16(g, s);
+    g = GemmArgs{};
+    g.A = h1; g.lda = L.H; g.B = theta + L.w2; g.ldb = L.H; g.C = h2; g.ldc = L.H; g.M = R; g.N = L.H; g.K = L.H; g.bias = theta + L.b2; g.relu = 1;
+    launch_gemm_f16(g, s);
+    g = GemmArgs{};
+    g.A = h2; g.lda = L.H; g.B = theta + L.w3; g.ldb = L.H; g.C = y; g.ldc = L.Op; g.M = R; g.N = L.O; g.K = L.H; g.bias = theta + L.b3;
+    launch_gemm_f16(g, s);
+    return;
+  }
   GemmArgs g{};
   g.A = x; g.lda = ldx; g.B = theta + L.w1; g.ldb = L.Dp; g.C = h1; g.ldc = L.H; g.M = R; g.N = L.H; g.K = L.Dp;
   g.bias = theta + L.b1; g.relu = 1;
@@ -636,6 +720,12 @@ extern "C" int lhw_ppo_destroy(LhwPpo* p) {
   return LHW_OK;
 }
 
+extern "C" int lhw_ppo_set_inference_dtype(LhwPpo* p, int fp16) {
+  if (!p) return lhw_fail(LHW_ERR_ARG, "null ppo");
+  p->infer_half = fp16 ? 1 : 0;
+  return LHW_OK;
+}
+
 extern "C" int64_t lhw_ppo_param_count(const LhwPpo* p) { return p ? (int64_t)p->n_params : LHW_ERR_ARG; }
 
 // offsets (in floats) of each tensor inside the flat parameter vector:
@@ -678,7 +768,7 @@ extern "C" int lhw_ppo_forward(LhwPpo* p, const float* theta, const float* obs, 
   hipLaunchKernelGGL(normalize_kernel, dim3((n + 255) / 256), dim3(256), 0, s, obs, p->D, p->la.Dp, (size_t)N, obs_mean, obs_std,
                      p->xb, (float*)nullptr, (const int*)nullptr, (const float*)nullptr);
   if (act || mu) {
-    mlp_forward(p->la, theta + p->off_actor, p->xb, p->la.Dp, (int)N, p->h1a, p->h2a, p->ya, s);
+    mlp_forward(p->la, theta + p->off_actor, p->xb, p->la.Dp, (int)N, p->h1a, p->h2a, p->ya, s, p->infer_half);
     if (mu) HIPCHK(hipMemcpy2DAsync(mu, sizeof(float) * p->A, p->ya, sizeof(float) * p->la.Op, sizeof(float) * p->A, N, hipMemcpyDeviceToDevice, s));
     if (act) {
       if (!logp) return lhw_fail(LHW_ERR_ARG, "logp required with act");
@@ -687,7 +777,7 @@ extern "C" int lhw_ppo_forward(LhwPpo* p, const float* theta, const float* obs, 
     }
   }
   if (value) {
-    mlp_forward(p->lc, theta + p->off_critic, p->xb, p->la.Dp, (int)N, p->h1c, p->h2c, p->yc, s);
+    mlp_forward(p->lc, theta + p->off_critic, p->xb, p->la.Dp, (int)N, p->h1c, p->h2c, p->yc, s, p->infer_half);
     HIPCHK(hipMemcpy2DAsync(value, sizeof(float), p->yc, sizeof(float) * 4, sizeof(float), N, hipMemcpyDeviceToDevice, s));
   }
   HIPCHK(hipGetLastError());

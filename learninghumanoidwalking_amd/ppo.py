@@ -193,6 +193,10 @@ class PPO:
                 device=self.device, learn_std=args.learn_std, lr=self.lr, eps=self.eps, clip=self.clip,
                 entropy_coeff=self.ent_coeff, mirror_coeff=self.mirror_coeff, max_grad_norm=self.grad_clip,
                 mirror_obs=mirror[0] if mirror else None, mirror_act=mirror[1] if mirror else None)
+        if getattr(args, "infer_fp16", False):
+            if self.recurrent:
+                raise NotImplementedError("--infer-fp16 is implemented for the feed-forward policies")
+            self.kernels.set_inference_fp16(True)   # rollout inference on the fp16 MFMA; the update stays float32
         if self.recurrent:
             pass
         elif continued:

@@ -43,6 +43,7 @@ def _setup(L):
     L.lhw_scale_shift.argtypes = [vp, i64, f32, f32, vp]
     L.lhw_ppo_grad.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp]
     L.lhw_ppo_apply.argtypes = [vp, vp, vp, vp, vp, i64, f32, vp]
+    L.lhw_ppo_set_inference_dtype.argtypes = [vp, ctypes.c_int]
     _SETUP = True
 
 
@@ -134,6 +135,11 @@ class PpoKernels:
     def set_tensors(self, tensors: dict):
         for n, t in tensors.items():
             self._view(self.theta, n).copy_(torch.as_tensor(t, dtype=torch.float32).reshape(self._view(self.theta, n).shape))
+
+    def set_inference_fp16(self, on=True):
+        """Rollout inference (``forward``) with fp16 operands on the fp16 MFMA; the update stays float32."""
+        _lib.check(self._L.lhw_ppo_set_inference_dtype(self._h, int(bool(on))))
+        self.inference_fp16 = bool(on)
 
     def set_obs_norm(self, mean, std):
         self.obs_mean.copy_(torch.as_tensor(np.asarray(mean), dtype=torch.float32))

@@ -269,3 +269,39 @@ def test_imitation_gradient_against_oracle_with_a_dominant_coefficient():
     # the term did matter: weights differ from the no-imitation fixture by much more than the tolerance
     g0 = np.load(os.path.join(G, "ppo_h64_imitate.npz"))
     assert np.abs(t["a_w3"].numpy() - g0["a1_4"]).max() > 1e-4
+
+
+def test_fp16_inference_matches_half_rounded_reference():
+    """lhw_ppo_set_inference_dtype: rollout forward with fp16 operands on the fp16 MFMA == a torch computation whose weights
+    and layer inputs are rounded to fp16 (float32 accumulation); the float32 path is unchanged and close."""
+    from learninghumanoidwalking_amd.ppo_kernels import PpoKernels, reference_init
+    D, A, H, N = 35, 10, 256, 1000
+    k = PpoKernels(D, A, hidden=H, max_rows=1024)
+    t = reference_init(D, A, H, 0.223, generator_seed=2)
+    for n in ("a_b1", "a_b2", "a_b3", "c_b1", "c_b2", "c_b3"):
+        t[n] = t[n] + torch.randn_like(t[n]) * 0.05
+    k.set_tensors(t)
+    om, osd = torch.randn(D) * 0.1, torch.rand(D) + 0.5
+    k.set_obs_norm(om.numpy(), osd.numpy())
+    obs = torch.randn(N, D)
+    mu32, _, _, v32 = k.forward(obs.cuda(), deterministic=True)
+    mu32, v32 = mu32.cpu().clone(), v32.cpu().clone()
+    k.set_inference_fp16(True)
+    mu16, _, _, v16 = k.forward(obs.cuda(), deterministic=True)
+    mu16, v16 = mu16.cpu(), v16.cpu()
+    h = lambda x: x.half().float()
+
+    def net(p):
+        x = (obs - om) / osd
+        x = torch.relu(h(x) @ h(t[f"{p}_w1"]).t() + t[f"{p}_b1"])
+        x = torch.relu(h(x) @ h(t[f"{p}_w2"]).t() + t[f"{p}_b2"])
+        return h(x) @ h(t[f"{p}_w3"]).t() + t[f"{p}_b3"]
+    # float32 accumulation order differs from torch's, so a few hidden activations land on the neighbouring fp16 value
+    # (2^-11 relative) when they are rounded for the next layer: tolerance of a few fp16 ulps, far below the fp16-vs-fp32 gap
+    np.testing.assert_allclose(mu16.numpy(), net("a").numpy(), rtol=3e-3, atol=1e-4)
+    np.testing.assert_allclose(v16.numpy(), net("c").numpy()[:, 0], rtol=3e-3, atol=1e-3)
+    assert float(np.abs(mu16.numpy() - net("a").numpy()).mean()) < 2e-5
+    assert 1e-7 < float((mu16 - mu32).abs().max()) < 5e-3           # really a different precision, and still close
+    k.set_inference_fp16(False)
+    mu_again = k.forward(obs.cuda(), deterministic=True)[0].cpu()
+    assert torch.equal(mu_again, mu32)
