@@ -9,6 +9,9 @@ cd /tmp && export TMPDIR=/tmp
 python /root/repo/bench.py --steps 3 --warmup 1 2>/dev/null | tail -1 > $OUT/bench_jvrc_walk_1gpu.json
 python /root/repo/bench.py --env h1 --num-envs 8192 --steps 2 --warmup 1 2>/dev/null | tail -1 > $OUT/bench_h1_8192_1gpu.json
 python /root/repo/bench.py --env cartpole --steps 3 --warmup 1 2>/dev/null | tail -1 > $OUT/bench_cartpole_1gpu.json
+python /root/repo/bench.py --env jvrc_step --steps 2 --warmup 1 2>/dev/null | tail -1 > $OUT/bench_jvrc_step_1gpu.json
+python /root/repo/bench.py --env h1_walk --num-envs 8192 --steps 2 --warmup 1 2>/dev/null | tail -1 > $OUT/bench_h1_walk_8192_1gpu.json
+python /root/repo/bench.py --env h1 --num-envs 8192 --infer-fp16 --steps 2 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/bench_h1_8192_fp16infer_1gpu.json
 rm -rf /tmp/kt; timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -- python /root/repo/bench.py --steps 1 --warmup 1 --no-cpu-baseline > /tmp/kt.log 2>&1
 cp /tmp/kt/*/*kernel_stats.csv $OUT/jvrc_walk_kernel_stats.csv
 for C in FETCH_SIZE WRITE_SIZE; do
@@ -20,4 +23,8 @@ for C in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_
   python /root/repo/scripts/pmc_summary.py /tmp/pm | grep -E "kernel,|humanoid_kernel<0" >> $OUT/jvrc_walk_step_pmc_sq.csv
 done
 python /root/repo/scripts/jvrc_phase_profile.py 4096 > $OUT/jvrc_walk_phase_cycles.txt 2>/dev/null
+python /root/repo/scripts/jvrc_phase_profile.py 4096 jvrc_step 3 > $OUT/jvrc_step_phase_cycles.txt 2>/dev/null
+python /root/repo/scripts/jvrc_phase_profile.py 4096 jvrc_step 4 >> $OUT/jvrc_step_phase_cycles.txt 2>/dev/null
+# end-to-end sanity: 40 PPO iterations of jvrc_walk on the stand-in robot (reward / episode length trend)
+rm -rf /tmp/train_log; timeout 400 python /root/repo/run_experiment.py train --env jvrc_walk --num-envs 4096 --minibatch-size 32768 --n-itr 40 --eval-freq 1000 --logdir /tmp/train_log --seed 0 2>&1 | grep -E "Iteration|Mean Eprew|Mean Eplen|fps=|Sampling took|Optimizer took" > $OUT/train_jvrc_walk_40iters.log
 ls -la $OUT
