@@ -1,4 +1,5 @@
-// Wave-per-environment rigid-body + soft-contact stepper with the walking task fused in.
+// Wave-per-environment rigid-body + soft-contact stepper with the tasks fused in (humanoid_kernel<MODE, TASK>:
+// jvrc_walk, jvrc_step, h1, h1_walk).
 //
 // One 64-lane wavefront advances one humanoid by a whole control step per launch:
 //   frame_skip x { PD law -> forward dynamics -> constraint solve -> Euler }  then
@@ -6,22 +7,23 @@
 //   bookkeeping + reset of the reference's rollout worker.
 // It takes over RobotBase.step/_do_simulation (reference robots/robot_base.py:41-98),
 // RobotInterface.step_pd/set_motor_torque/step -> mujoco.mj_step (reference
-// envs/common/robot_interface.py:493-546), BaseHumanoidEnv.step/reset_model/get_obs (reference
-// envs/common/base_humanoid_env.py:177-276) and WalkingTask (reference tasks/walking_task.py:85-205,
-// tasks/rewards.py:9-194).
+// envs/common/robot_interface.py:493-546), BaseHumanoidEnv.step/reset_model/get_obs incl. observation / init noise
+// (reference envs/common/base_humanoid_env.py:177-338), domain randomisation (envs/common/domain_randomization.py:10-56),
+// WalkingTask (tasks/walking_task.py:85-205), SteppingTask (tasks/stepping_task.py:66-334), StandingTask
+// (tasks/standing_task.py:49-131) and tasks/rewards.py:9-194.
 //
 // Physics = the MuJoCo pipeline subset of SURVEY.md Appendix A, float64: kinematics, com-based
 // spatial quantities, CRBA (+armature), RNE bias, joint damping, motor actuation with ctrl/force
-// clamps, primitive collisions (plane-{sphere,capsule,box}, sphere-sphere, sphere-capsule,
-// capsule-capsule), joint-limit rows, pyramidal contact rows with MuJoCo's impedance / reference
-// acceleration / regulariser model, the primal Newton solver with exact line search and warm
-// start, Euler integration with implicit joint damping.
+// clamps, applied Cartesian wrenches, primitive collisions (plane-{sphere,capsule,box}, sphere-sphere, sphere-capsule,
+// capsule-capsule; box-box in the stepping-task kernels), frictionloss and joint-limit rows, pyramidal contact rows with
+// MuJoCo's impedance / reference acceleration / regulariser model, the primal Newton solver with exact line search and
+// warm start, Euler integration with implicit joint damping.
 //
 // Mapping onto CDNA4: the env's working set (body frames, spatial inertias, M, J, H ...) lives in
 // LDS for the whole launch; nv-vectors are held one element per lane (lane i <-> dof i) and
 // efc-vectors one row per lane, so mat-vec products are conflict-free LDS row/column sweeps and
 // reductions are wavefront shuffles; the only serial chains are the kinematic tree levels and the
-// Cholesky columns.  The persistent state is one contiguous 1.2 KB record per env, read and
+// Cholesky columns.  The persistent state is one contiguous 1.3 KB record per env, read and
 // written once per control step with lane-strided (coalesced) accesses.
 #include <hip/hip_runtime.h>
 
@@ -1650,7 +1652,7 @@ __device__ __forceinline__ void body_linvel(const L& S, int slot /* 0 root, 1 ri
   lin[0] = cv[3] - t[0]; lin[1] = cv[4] - t[1]; lin[2] = cv[5] - t[2];
 }
 
-template <int MODE, int TASK>  // MODE: 0 step, 1 reset(mask), 2 set_state, 3 get_state; TASK: TASK_WALK / TASK_STAND
+template <int MODE, int TASK>  // MODE: 0 step, 1 reset(mask), 2 set_state, 3 get_state; TASK: TASK_WALK / TASK_STAND / TASK_STEP / TASK_H1WALK
 __global__ void __launch_bounds__(64, 2) humanoid_kernel(HModel m, HParams p, HState st, const float* __restrict__ act,
                                                       float* __restrict__ obs, float* __restrict__ term_obs,
                                                       float* __restrict__ rew, unsigned char* __restrict__ done_out,
