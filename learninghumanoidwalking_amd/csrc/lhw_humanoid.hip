@@ -273,7 +273,17 @@ struct LdsT {
   int ncon, nefc, nlim, overflow;
 };
 
-#define SYNC() __syncthreads()
+// A workgroup is exactly one wavefront (every launch uses blockDim = 64), and a wave's LDS instructions execute in issue
+// order, so cross-lane hand-offs through LDS need no hardware barrier and no s_waitcnt: __syncthreads() would add a
+// workgroup-scope fence, i.e. s_waitcnt vmcnt(0) lgkmcnt(0) -- a full drain of outstanding global loads and scratch
+// (register-spill) stores -- ~60 times per sub-step.  A wavefront-scope fence pair plus the compiler-only wave barrier
+// keeps the compiler from moving LDS accesses across the hand-off and emits no instruction.
+#define SYNC()                                               \
+  do {                                                       \
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  \
+    __builtin_amdgcn_wave_barrier();                         \
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  \
+  } while (0)
 template <class L> __device__ __forceinline__ double prm_damp(const HModel& m, const L& S, int d) {
   if constexpr (L::PRM_) return S.damp[d]; else return m.dof_d[DDS * d + DD_DAMPING];
 }
