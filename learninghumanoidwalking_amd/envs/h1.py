@@ -22,6 +22,19 @@ LEG_JOINTS = ["left_hip_yaw", "left_hip_roll", "left_hip_pitch", "left_knee", "l
               "right_hip_yaw", "right_hip_roll", "right_hip_pitch", "right_knee", "right_ankle"]  # gen_xml.py:9-20
 
 
+def load_config(path):
+    """YAML config with an optional ``inherits: <file in the same directory>`` key (values of the child win)."""
+    with open(path) as f:
+        cfg = yaml.safe_load(f)
+    cfg.pop("timing", None)
+    parent = cfg.pop("inherits", None)
+    if parent:
+        base = load_config(os.path.join(os.path.dirname(os.path.abspath(path)), parent))
+        base.update(cfg)
+        cfg = base
+    return cfg
+
+
 @dataclass
 class H1Spec:
     yaml_path: str = H1_BASE_YAML
@@ -33,8 +46,7 @@ class H1Spec:
     cfg: dict = field(default_factory=dict)
 
     def __post_init__(self):
-        with open(self.yaml_path) as f:
-            self.cfg = yaml.safe_load(f)
+        self.cfg = load_config(self.yaml_path)
         c = self.cfg
         self.sim_dt, self.control_dt = float(c["sim_dt"]), float(c["control_dt"])
         if int(c.get("obs_history_len", 1)) != 1:
