@@ -404,6 +404,46 @@ __device__ __forceinline__ void inert_vec(double* r, const double* i, const doub
 // element i of x.  Left-looking Cholesky with row i held in lane i's registers: column step j needs row j of L, which is
 // read back from LDS with j independent broadcast loads (one latency exposure per step instead of one per product).
 // The loops are fully unrolled over the compile-time bound NV so the row stays in VGPRs.  A is overwritten by L.
+// Operand broadcast of the factorisation.  Measured alternative (LHW_CHOL_SWIZZLE=1): ds_swizzle (bit mode: and_mask 0,
+// or_mask J) moves the ~300 broadcasts per factorisation from the VALU to the LDS crossbar, but its latency is exposed in
+// the column chain: 9.5 k -> 12 k cycles per solve, 3.48 -> 3.6 ms per control step.  v_readlane + SGPR operand stays.
+#ifndef LHW_CHOL_SWIZZLE
+#define LHW_CHOL_SWIZZLE 0
+#endif
+template <int J>
+__device__ __forceinline__ double bcast_col(double v) {
+#if LHW_CHOL_SWIZZLE
+  return __hiloint2double(__builtin_amdgcn_ds_swizzle(__double2hiint(v), J << 5), __builtin_amdgcn_ds_swizzle(__double2loint(v), J << 5));
+#else
+  return bcast(v, J);
+#endif
+}
+// column J of the left-looking factorisation (rows in registers), then the next one
+template <int J>
+struct CholCol {
+  static __device__ __forceinline__ void run(double (&r)[NV], double (&invd)[NV], int lane) {
+    double s0 = r[J], s1 = 0.0;
+#pragma unroll
+    for (int p = 0; p + 1 < J; p += 2) {
+      s0 -= r[p] * bcast_col<J>(r[p]);
+      s1 -= r[p + 1] * bcast_col<J>(r[p + 1]);
+    }
+    if (J & 1) s0 -= r[J - 1] * bcast_col<J>(r[J - 1]);
+    const double s = s0 + s1;
+    const double piv = fmax(bcast(s, J), HMINVAL);
+    double id = __builtin_amdgcn_rsq(piv);
+    id = id * (1.5 - 0.5 * piv * id * id);
+    id = id * (1.5 - 0.5 * piv * id * id);
+    invd[J] = id;
+    r[J] = (lane == J) ? piv * id : s * id;
+    CholCol<J + 1>::run(r, invd, lane);
+  }
+};
+template <>
+struct CholCol<NV> {
+  static __device__ __forceinline__ void run(double (&)[NV], double (&)[NV], int) {}
+};
+
 __device__ double chol_solve_inplace(double* A, int n, int lane, double x) {
   // The matrix is treated as NV x NV: rows/columns >= n hold the identity (callers keep that padding in LDS), so the
   // whole routine is straight-line code without exec-mask juggling.  Lanes >= NV shadow row NV-1 and are ignored.
@@ -413,23 +453,7 @@ __device__ double chol_solve_inplace(double* A, int n, int lane, double x) {
 #pragma unroll
   for (int p = 0; p < NV; p++) r[p] = A[i * LDV + p];
   double invd[NV];
-#pragma unroll
-  for (int j = 0; j < NV; j++) {
-    double s0 = r[j], s1 = 0.0;
-#pragma unroll
-    for (int p = 0; p + 1 < j; p += 2) {
-      s0 -= r[p] * bcast(r[p], j);
-      s1 -= r[p + 1] * bcast(r[p + 1], j);
-    }
-    if (j & 1) s0 -= r[j - 1] * bcast(r[j - 1], j);
-    const double s = s0 + s1;
-    const double piv = fmax(bcast(s, j), HMINVAL);
-    double id = __builtin_amdgcn_rsq(piv);
-    id = id * (1.5 - 0.5 * piv * id * id);
-    id = id * (1.5 - 0.5 * piv * id * id);
-    invd[j] = id;
-    r[j] = (lane == j) ? piv * id : s * id;
-  }
+  CholCol<0>::run(r, invd, lane);
   // forward substitution L y = x : column sweep, l_ij from registers (lanes < j keep their value)
 #pragma unroll
   for (int j = 0; j < NV; j++) {
