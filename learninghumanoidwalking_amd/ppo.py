@@ -88,6 +88,7 @@ class Rollout:
         self.vterm = torch.zeros(T, N, dtype=torch.float32, device=dev)
         self.vfinal = torch.zeros(N, dtype=torch.float32, device=dev)
         self.tob = torch.zeros(N, D, dtype=torch.float32, device=dev)
+        self.tob_all = None      # [T][N][D] terminal observations of the feed-forward path (allocated on first use)
         self.counter = 0
         self.started = False
         self.env_base = getattr(env, "env_id_base", 0)
@@ -101,13 +102,25 @@ class Rollout:
             self.started = True
         else:
             self.obs[0].copy_(self.obs[T])
+        # Only the actor sits on the step-to-step dependency chain.  The critic's weights do not change during a rollout
+        # and it is feed-forward, so V(s_t), V(terminal obs) and V(s_T) are evaluated afterwards in large batches instead
+        # of two extra 3-GEMM passes per control step (same values, ~2000 fewer kernel launches per iteration).
+        if self.tob_all is None:
+            self.tob_all = torch.zeros(T, self.N, self.obs.shape[2], dtype=torch.float32, device=self.obs.device)
         for t in range(T):
             k.forward(self.obs[t], seed=self.seed, env_id_base=self.env_base, counter=self.counter,
-                      deterministic=deterministic, mu=self.mu, act=self.act[t], logp=self.logp[t], value=self.val[t])
-            env.step(self.act[t], obs_out=self.obs[t + 1], term_obs_out=self.tob, rew_out=self.rew[t], done_out=self.done[t])
-            k.forward(self.tob, want_actor=False, value=self.vterm[t])
+                      deterministic=deterministic, want_value=False, mu=self.mu, act=self.act[t], logp=self.logp[t])
+            env.step(self.act[t], obs_out=self.obs[t + 1], term_obs_out=self.tob_all[t], rew_out=self.rew[t], done_out=self.done[t])
             self.counter += 1
+        self._batched_values(self.obs[:T].reshape(T * self.N, -1), self.val.reshape(-1))
+        self._batched_values(self.tob_all.reshape(T * self.N, -1), self.vterm.reshape(-1))
         k.forward(self.obs[T], want_actor=False, value=self.vfinal)
+
+    def _batched_values(self, obs_flat, out_flat):
+        chunk = int(self.k.max_rows)
+        for a in range(0, obs_flat.shape[0], chunk):
+            b = min(a + chunk, obs_flat.shape[0])
+            self.k.forward(obs_flat[a:b], want_actor=False, value=out_flat[a:b])
 
 
     def _collect_recurrent(self, deterministic):
