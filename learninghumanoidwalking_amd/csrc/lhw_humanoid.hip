@@ -129,18 +129,20 @@ enum { LHW_STREAM_OBS = 4 };
 #define JI_LIMITED 1
 #define JI_QADR 2
 #define JI_DADR 3
-#define DDS 12  // dof_d: armature damping invweight0 frictionloss solref2 solimp5 pad
+#define DDS 12  // dof_d: armature damping invweight0 frictionloss solref2 solimp5 gear(of the dof's actuator)
 #define DD_ARMATURE 0
 #define DD_DAMPING 1
 #define DD_INVW 2
 #define DD_FLOSS 3
 #define DD_SOLREF 4
 #define DD_SOLIMP 6
-#define DIS 4   // dof_i: body joint kind(0 free-trans 1 free-rot 2 slide 3 hinge) prevmask
+#define DD_GEAR 11
+#define DIS 6   // dof_i: body joint kind(0 free-trans 1 free-rot 2 slide 3 hinge) prevmask actuator(-1 none) pad
 #define DI_BODY 0
 #define DI_JNT 1
 #define DI_KIND 2
 #define DI_PREVMASK 3
+#define DI_ACT 4
 #define GDS 28  // geom_d: pos3 R_local9 size3 friction3 solmix solref2 solimp5 margin gap
 #define GD_POS 0
 #define GD_RLOC 3
@@ -1385,8 +1387,8 @@ __device__ __forceinline__ void substep(const HModel& m, const HParams& p, L& S,
   if (lane < nv) {
     qv = S.qvel[lane];
     double act = 0;
-    for (int u = 0; u < m.nu; u++)
-      if (m.act_i[AIS * (u) + AI_DOF] == lane) act += m.act_d[ADS * (u) + AD_GEAR] * S.frc[u];
+    const int u = m.dof_i[DIS * lane + DI_ACT];   // at most one actuator per dof (checked at create)
+    if (u >= 0) act = m.dof_d[DDS * lane + DD_GEAR] * S.frc[u];
     fs = -prm_damp(m, S, lane) * qv - bias + act + qapp;
     S.vec[lane] = qv;
   }
@@ -2331,6 +2333,13 @@ int humanoid_create(HumanoidEnv** out, const std::vector<int32_t>& mi, const std
     di[DI_BODY] = bmap[IF(LHW_IF_DOF_BODYID)[d]]; di[DI_JNT] = j;
     di[DI_KIND] = jtype[j] == JT_FREE ? (kk < 3 ? 0 : 1) : (jtype[j] == JT_SLIDE ? 2 : 3);
     di[DI_PREVMASK] = (int)pmask[d];
+    di[DI_ACT] = -1;
+    for (int u = 0; u < nu; u++)
+      if (jdof[IF(LHW_IF_ACTUATOR_TRNID)[u]] == d) {
+        if (di[DI_ACT] >= 0) { humanoid_destroy(h); return lhw_fail(LHW_ERR_UNSUPPORTED, "more than one actuator on dof %d", d); }
+        di[DI_ACT] = u;
+        k[DD_GEAR] = DF(LHW_DF_ACTUATOR_GEAR)[u];
+      }
   }
   for (int g = 0; g < ng; g++) {
     double* k = &geom_d[(size_t)GDS * g];
