@@ -35,15 +35,14 @@
 #include "lhw_rng.h"
 
 #define NB 20   // bodies
-#define NV 18   // dofs
-#define LDV 19  // padded row length of nv x nv matrices and of J (odd => conflict-free 64-bit column sweeps)
+#define NVMAX 18   // dofs (capacity of the persistent records; the kernels use the per-task width NV = L::NV_)
+#define LDVMAX 19
 #define NQ 19
 #define NJ 14   // joints
 #define NG 32   // geoms
 #define NP 64   // collision candidate pairs (one per lane)
 // contacts kept per step (NC) and constraint rows (NE, one per lane) are per-task capacities: see LdsT
 #define NU 12   // actuators
-#define NTRI (NV * (NV + 1) / 2)
 #define HMINVAL 1e-15
 
 enum { JT_FREE = 0, JT_SLIDE = 2, JT_HINGE = 3 };
@@ -54,8 +53,8 @@ enum { WALK_CURVED = 0, WALK_STANDING = 1, WALK_BACKWARD = 2, WALK_LATERAL = 3, 
 // persistent record (doubles)
 #define R_QPOS 0
 #define R_QVEL (R_QPOS + NQ)
-#define R_WARM (R_QVEL + NV)
-#define R_SQ (R_WARM + NV)       // joint position of each actuator at the last forward pass (actuator_length / gear)
+#define R_WARM (R_QVEL + NVMAX)
+#define R_SQ (R_WARM + NVMAX)       // joint position of each actuator at the last forward pass (actuator_length / gear)
 #define R_SV (R_SQ + NU)         // joint velocity, likewise
 #define R_FRC (R_SV + NU)        // actuator_force of the last forward pass
 #define R_PREVPRED (R_FRC + NU)  // prev_prediction (action smoothing)
@@ -86,8 +85,8 @@ static_assert(R_EPRET < REC_D, "record too small");
 #define MAX_SEQ 20
 // per-env model parameters touched by dynamics randomisation / perturbation (domain_randomization.py:10-56)
 #define P_DAMP 0
-#define P_FLOSS (P_DAMP + NV)
-#define P_MASS (P_FLOSS + NV)
+#define P_FLOSS (P_DAMP + NVMAX)
+#define P_MASS (P_FLOSS + NVMAX)
 #define P_IPOS (P_MASS + NB)
 #define P_XFRC (P_IPOS + NB * 3)  // xfrc_applied of up to two perturbed bodies: force3 torque3 each
 #define PRM_D 128
@@ -242,6 +241,8 @@ struct HumanoidEnv {
 // stage C offsets depend on the row capacity of the task's LDS layout (template parameter L of every phase function)
 #define NE (L::NE_)
 #define NC (L::NC_)
+#define NV (L::NV_)    // dof width the kernel is compiled for (18 JVRC, 16 H1): sizes the Cholesky, the row products and the LDS matrices
+#define LDV (L::LDV_)  // padded row length of nv x nv matrices and of J (odd => conflict-free 64-bit column sweeps)
 #define U_J 0
 #define U_H (U_J + NE * LDV)
 #define U_EPOS (U_H)
@@ -251,9 +252,10 @@ struct HumanoidEnv {
 #define U_EIMP (U_EB + NE)
 constexpr int cmax(int a, int b) { return a > b ? a : b; }
 
-template <int NE_T, int NC_T, bool PRM_T>
+template <int NE_T, int NC_T, bool PRM_T, int NV_T>
 struct LdsT {
-  static constexpr int NE_ = NE_T, NC_ = NC_T;
+  typedef LdsT L;
+  static constexpr int NE_ = NE_T, NC_ = NC_T, NV_ = NV_T, LDV_ = NV_T + 1;
   static constexpr bool PRM_ = PRM_T;   // per-env model parameters are staged in LDS (else read from the model tables)
   // H slot: the nv x nv factor, or the five per-row parameter arrays parked there before the reference acceleration is formed
   static constexpr int USIZE_ = cmax(cmax(U_END_A, U_END_B), NE_T * LDV + cmax(NV * LDV, 5 * NE_T));
@@ -421,9 +423,9 @@ __device__ __forceinline__ double bcast_col(double v) {
 #endif
 }
 // column J of the left-looking factorisation (rows in registers), then the next one
-template <int J>
-struct CholCol {
-  static __device__ __forceinline__ void run(double (&r)[NV], double (&invd)[NV], int lane) {
+template <class L, int J>
+__device__ __forceinline__ void chol_col(double (&r)[NV], double (&invd)[NV], int lane) {
+  if constexpr (J < L::NV_) {
     double s0 = r[J], s1 = 0.0;
 #pragma unroll
     for (int p = 0; p + 1 < J; p += 2) {
@@ -438,14 +440,11 @@ struct CholCol {
     id = id * (1.5 - 0.5 * piv * id * id);
     invd[J] = id;
     r[J] = (lane == J) ? piv * id : s * id;
-    CholCol<J + 1>::run(r, invd, lane);
+    chol_col<L, J + 1>(r, invd, lane);
   }
-};
-template <>
-struct CholCol<NV> {
-  static __device__ __forceinline__ void run(double (&)[NV], double (&)[NV], int) {}
-};
+}
 
+template <class L>
 __device__ double chol_solve_inplace(double* A, int n, int lane, double x) {
   // The matrix is treated as NV x NV: rows/columns >= n hold the identity (callers keep that padding in LDS), so the
   // whole routine is straight-line code without exec-mask juggling.  Lanes >= NV shadow row NV-1 and are ignored.
@@ -455,7 +454,7 @@ __device__ double chol_solve_inplace(double* A, int n, int lane, double x) {
 #pragma unroll
   for (int p = 0; p < NV; p++) r[p] = A[i * LDV + p];
   double invd[NV];
-  CholCol<0>::run(r, invd, lane);
+  chol_col<L, 0>(r, invd, lane);
   // forward substitution L y = x : column sweep, l_ij from registers (lanes < j keep their value)
 #pragma unroll
   for (int j = 0; j < NV; j++) {
@@ -482,6 +481,7 @@ __device__ double chol_solve_inplace(double* A, int n, int lane, double x) {
 }
 
 // y_lane = sum_k row[k] * v[k] with the row in registers and v broadcast from LDS
+template <class L>
 __device__ __forceinline__ double row_dot(const double* row, const double* v, int n) {
   double a0 = 0, a1 = 0;
 #pragma unroll
@@ -1408,7 +1408,7 @@ __device__ __forceinline__ void substep(const HModel& m, const HParams& p, L& S,
   double aref = 0, D = 0, fl = 0;
   const bool isrow = lane < nefc;
   {
-    const double jv0 = row_dot(Jrow, S.vec, nv);
+    const double jv0 = row_dot<L>(Jrow, S.vec, nv);
     if (isrow) {
       aref = -S.U[U_EB + lane] * jv0 - S.U[U_EK + lane] * S.U[U_EIMP + lane] * (S.U[U_EPOS + lane] - S.U[U_EMARGIN + lane]);
       D = S.efc_D[lane];
@@ -1420,7 +1420,7 @@ __device__ __forceinline__ void substep(const HModel& m, const HParams& p, L& S,
   // factor M (copy in H), qacc_smooth
   for (int it = lane; it < NV * LDV; it += 64) S.U[U_H + it] = S.M[it];
   SYNC();
-  const double as = chol_solve_inplace(S.U + U_H, nv, lane, fs);
+  const double as = chol_solve_inplace<L>(S.U + U_H, nv, lane, fs);
   PROF_MARK(12);
 
   PROF_MARK(6);
@@ -1433,8 +1433,8 @@ __device__ __forceinline__ void substep(const HModel& m, const HParams& p, L& S,
       const double w = *warm;
       if (lane < nv) { S.vec[lane] = w; S.vec2[lane] = as; }
       SYNC();
-      const double jar = row_dot(Jrow, S.vec, nv) - aref, Ma = row_dot(Mrow, S.vec, nv);
-      const double jas = row_dot(Jrow, S.vec2, nv) - aref;
+      const double jar = row_dot<L>(Jrow, S.vec, nv) - aref, Ma = row_dot<L>(Mrow, S.vec, nv);
+      const double jas = row_dot<L>(Jrow, S.vec2, nv) - aref;
       double cw, cs0, tf, td;
       row_eval(isrow, fl, D, jar, &cw, &tf, &td);
       row_eval(isrow, fl, D, jas, &cs0, &tf, &td);
@@ -1448,7 +1448,7 @@ __device__ __forceinline__ void substep(const HModel& m, const HParams& p, L& S,
     for (int iter = 0; iter <= m.iterations; iter++) {
       if (lane < nv) S.vec[lane] = qacc;
       SYNC();
-      const double jar = row_dot(Jrow, S.vec, nv) - aref, Ma = row_dot(Mrow, S.vec, nv);
+      const double jar = row_dot<L>(Jrow, S.vec, nv) - aref, Ma = row_dot<L>(Mrow, S.vec, nv);
       double c, force, dactive;
       row_eval(isrow, fl, D, jar, &c, &force, &dactive);
       if (lane < nv) c += 0.5 * (Ma - fs) * (qacc - as);
@@ -1491,10 +1491,10 @@ __device__ __forceinline__ void substep(const HModel& m, const HParams& p, L& S,
         S.U[U_H + i * LDV + j] = h0 + h1;
       }
       SYNC();
-      const double search = -chol_solve_inplace(S.U + U_H, nv, lane, grad);
+      const double search = -chol_solve_inplace<L>(S.U + U_H, nv, lane, grad);
       if (lane < nv) S.vec2[lane] = search;
       SYNC();
-      const double jv = row_dot(Jrow, S.vec2, nv), Mv = row_dot(Mrow, S.vec2, nv);
+      const double jv = row_dot<L>(Jrow, S.vec2, nv), Mv = row_dot<L>(Mrow, S.vec2, nv);
       const double qg1 = wave_sum(lane < nv ? search * (Ma - fs) : 0.0);
       const double qg2 = wave_sum(lane < nv ? 0.5 * search * Mv : 0.0);
       // exact line search on the convex piecewise-quadratic: safeguarded Newton on its derivative
@@ -1541,7 +1541,7 @@ __device__ __forceinline__ void substep(const HModel& m, const HParams& p, L& S,
     SYNC();
     if (lane < nv) S.U[U_H + lane * LDV + lane] += h * prm_damp(m, S, lane);
     SYNC();
-    anew = chol_solve_inplace(S.U + U_H, nv, lane, fs + fcon);
+    anew = chol_solve_inplace<L>(S.U + U_H, nv, lane, fs + fcon);
   }
   PROF_MARK(13);
   if (lane < nv) S.qvel[lane] = qv + h * anew;
@@ -1694,7 +1694,8 @@ __global__ void __launch_bounds__(64, 2) humanoid_kernel(HModel m, HParams p, HS
                                                       float* __restrict__ rew, unsigned char* __restrict__ done_out,
                                                       float* __restrict__ rew_terms, const unsigned char* __restrict__ mask,
                                                       double* __restrict__ xq, double* __restrict__ xv) {
-  using L = LdsT<(TASK == TASK_STEP ? 64 : 48), (TASK == TASK_STEP ? 16 : 12), TASK != TASK_STEP>;
+  using L = LdsT<(TASK == TASK_STEP ? 64 : 48), (TASK == TASK_STEP ? 16 : 12), TASK != TASK_STEP,
+                 ((TASK == TASK_STAND || TASK == TASK_H1WALK) ? 16 : 18)>;
   __shared__ L S;
   const int env = blockIdx.x, lane = threadIdx.x;
   if (MODE == 1 && mask && !mask[env]) return;
@@ -2201,9 +2202,9 @@ int humanoid_create(HumanoidEnv** out, const std::vector<int32_t>& mi, const std
       return lhw_fail(LHW_ERR_UNSUPPORTED, "exactly one dynamic tree (rooted at body 1) plus static children of the world is supported");
   }
   const int nb = (int)bsrc.size();
-  if (nq > NQ || nv > NV || nu > NU || nb > NB || nj > NJ || ng > NG || np > NP || nb > 64 || np > 64)
+  if (nq > NQ || nv > NVMAX || nu > NU || nb > NB || nj > NJ || ng > NG || np > NP || nb > 64 || np > 64)
     return lhw_fail(LHW_ERR_MODEL, "model exceeds compiled limits (nq %d/%d nv %d/%d nu %d/%d nbody %d/%d njnt %d/%d ngeom %d/%d npair %d/%d)",
-                    nq, NQ, nv, NV, nu, NU, nb, NB, nj, NJ, ng, NG, np, NP);
+                    nq, NQ, nv, NVMAX, nu, NU, nb, NB, nj, NJ, ng, NG, np, NP);
   const bool stepping = cfg->task == LHW_TASK_JVRC_STEP, h1walk = cfg->task == LHW_TASK_H1_WALK;
   const bool walk = cfg->task == LHW_TASK_JVRC_WALK || stepping;             // JVRC robot + gait clock
   const bool stand = cfg->task == LHW_TASK_H1_STAND || h1walk;               // H1 robot: observation noise, domain randomisation
