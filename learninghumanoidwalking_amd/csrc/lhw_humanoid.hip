@@ -1365,7 +1365,10 @@ __device__ __forceinline__ void substep(const HModel& m, const HParams& p, L& S,
   PROF_MARK(5);
   fwd_constraints(m, S, lane);  // stage C: J over the dead stage-B region, row parameters in the H slot
   PROF_MARK(4);
-  const int nv = m.nv, nefc = S.nefc;
+  // the kernels are compiled for the dof count of their robot (humanoid_create checks m.nv == NV), so every `k < nv` below
+  // folds at compile time
+  constexpr int nv = NV;
+  const int nefc = S.nefc;
   // transmission + actuation (lane = actuator)
   if (lane < m.nu) {
     const int j = m.act_i[AIS * (lane) + AI_JNT];
