@@ -624,7 +624,7 @@ __device__ double fwd_com(const HModel& m, const HParams& p, L& S, int lane) {
     ci[5] -= mass * dif[1] * dif[2];
     ci[6] = mass * dif[0]; ci[7] = mass * dif[1]; ci[8] = mass * dif[2]; ci[9] = mass;
   }
-  if (lane < m.nv) {
+  if (lane < NV) {
     const int d = lane, j = m.dof_i[DIS * (d) + DI_JNT], b = m.dof_i[DIS * (d) + DI_BODY], kind = m.dof_i[DIS * (d) + DI_KIND];
     const int t = kind <= 1 ? JT_FREE : (kind == 2 ? JT_SLIDE : JT_HINGE), k = d - m.jnt_i[JIS * (j) + JI_DADR];
     double off[3], ax[3], c[6];
@@ -646,7 +646,7 @@ __device__ double fwd_com(const HModel& m, const HParams& p, L& S, int lane) {
   SYNC();
   // mj_xfrcAccumulate: Cartesian force / torque applied at the com of the perturbed bodies -> joint space
   double qapp = 0;
-  if (L::PRM_ && p.env_params && lane < m.nv) {
+  if (L::PRM_ && p.env_params && lane < NV) {
     for (int k = 0; k < p.n_pbody; k++) {
       const int pb = p.pbody[k];
       if (!(((unsigned)m.body_i[BIS * pb + BI_DOFMASK] >> lane) & 1u)) continue;
@@ -671,11 +671,11 @@ __device__ void fwd_crb(const HModel& m, L& S, int lane) {
   }
   for (int it = lane; it < NV * LDV; it += 64) {
     const int i = it / LDV, j = it - i * LDV;
-    S.M[it] = (i == j && i >= m.nv) ? 1.0 : 0.0;
+    S.M[it] = (i == j && i >= NV) ? 1.0 : 0.0;
   }
   SYNC();
   // vec scratch: buf_i = crb[body(i)] * cdof_i  kept in csub (6 per dof)
-  if (lane < m.nv) {
+  if (lane < NV) {
     double buf[6];
     inert_vec(buf, &S.U[U_CRB + 10 * m.dof_i[DIS * (lane) + DI_BODY]], &S.cdof[6 * lane]);
     for (int a = 0; a < 6; a++) S.U[U_CSUB + 6 * lane + a] = buf[a];
@@ -1151,7 +1151,7 @@ __device__ __forceinline__ void row_params(const HModel& m, const double* sr_in,
 template <class L>
 __device__ void fwd_constraints(const HModel& m, L& S, int lane) {
   // ---- frictionloss rows: lane = dof (mj_instantiateFriction); they come first
-  const double myfl = lane < m.nv ? prm_floss(m, S, lane) : 0.0;
+  const double myfl = lane < NV ? prm_floss(m, S, lane) : 0.0;
   int nfr;
   const int fbase = wave_scan(myfl > 0 ? 1 : 0, &nfr) - (myfl > 0 ? 1 : 0);
   // ---- limits: lane = joint; rows ordered by joint, lower side first
@@ -1208,8 +1208,8 @@ __device__ void fwd_constraints(const HModel& m, L& S, int lane) {
   }
   // contact Jacobians: item = (contact, dof)
   const int ncon = S.ncon;
-  for (int it = lane; it < ncon * m.nv; it += 64) {
-    const int c = it / m.nv, k = it - c * m.nv, r0 = S.con_row[c];
+  for (int it = lane; it < ncon * NV; it += 64) {
+    const int c = it / NV, k = it - c * NV, r0 = S.con_row[c];
     if (r0 < 0) continue;
     const int b1 = m.geom_i[GIS * (S.con_g1[c]) + GI_BODY], b2 = m.geom_i[GIS * (S.con_g2[c]) + GI_BODY];
     const unsigned bit = 1u << k;
@@ -1253,7 +1253,7 @@ __device__ void fwd_constraints(const HModel& m, L& S, int lane) {
 template <class L>
 __device__ double fwd_velocity(const HModel& m, L& S, int lane) {
   // velocity seen by dof j when its cdof_dot is formed: sum over dof_prevmask[j]
-  if (lane < m.nv) {
+  if (lane < NV) {
     const int j = lane;
     unsigned mask = (unsigned)m.dof_i[DIS * (j) + DI_PREVMASK];
     double v[6] = {0, 0, 0, 0, 0, 0};
@@ -1311,7 +1311,7 @@ __device__ double fwd_velocity(const HModel& m, L& S, int lane) {
   if (lane < 18) S.svel[lane] = S.U[U_CVEL + 6 * m.track_body[lane / 6] + lane % 6];
   SYNC();
   double bias = 0;
-  if (lane < m.nv) {
+  if (lane < NV) {
     const int b = m.dof_i[DIS * (lane) + DI_BODY];
     for (int a = 0; a < 6; a++) bias += S.cdof[6 * lane + a] * S.U[U_CSUB + 6 * b + a];
   }
@@ -1716,13 +1716,13 @@ __global__ void __launch_bounds__(64, 2) humanoid_kernel(HModel m, HParams p, HS
   PROF_BEGIN();
   if (MODE == 3) {
     if (lane < m.nq) xq[(size_t)env * m.nq + lane] = rec[R_QPOS + lane];
-    if (lane < m.nv) xv[(size_t)env * m.nv + lane] = rec[R_QVEL + lane];
+    if (lane < NV) xv[(size_t)env * NV + lane] = rec[R_QVEL + lane];
     return;
   }
   // ---- load the persistent record (lane-strided)
   double warm = 0, prevpred = 0, prevact = 0, prevtq = 0;
   if (lane < m.nq) S.qpos[lane] = rec[R_QPOS + lane];
-  if (lane < m.nv) { S.qvel[lane] = rec[R_QVEL + lane]; warm = rec[R_WARM + lane]; }
+  if (lane < NV) { S.qvel[lane] = rec[R_QVEL + lane]; warm = rec[R_WARM + lane]; }
   if (lane < m.nu) {
     S.sq[lane] = rec[R_SQ + lane]; S.sv[lane] = rec[R_SV + lane]; S.frc[lane] = rec[R_FRC + lane];
     prevpred = rec[R_PREVPRED + lane]; prevact = rec[R_PREVACT + lane]; prevtq = rec[R_PREVTQ + lane];
@@ -1737,7 +1737,7 @@ __global__ void __launch_bounds__(64, 2) humanoid_kernel(HModel m, HParams p, HS
   if (TASK == TASK_STEP) { t1 = irec[RI_T1]; t2 = irec[RI_T2]; reached = irec[RI_REACHED]; frames = irec[RI_FRAMES]; nseq = irec[RI_NSEQ]; }
   // per-env model parameters (or the shared defaults) -> LDS, once per launch
   if constexpr (L::PRM_) {
-    if (lane < m.nv) {
+    if (lane < NV) {
       S.damp[lane] = prm ? prm[P_DAMP + lane] : m.dof_d[DDS * lane + DD_DAMPING];
       S.floss[lane] = prm ? prm[P_FLOSS + lane] : m.dof_d[DDS * lane + DD_FLOSS];
     }
@@ -1752,7 +1752,7 @@ __global__ void __launch_bounds__(64, 2) humanoid_kernel(HModel m, HParams p, HS
   bool do_reset = MODE == 1;
   if (MODE == 2) {
     if (lane < m.nq) S.qpos[lane] = xq[(size_t)env * m.nq + lane];
-    if (lane < m.nv) S.qvel[lane] = xv[(size_t)env * m.nv + lane];
+    if (lane < NV) S.qvel[lane] = xv[(size_t)env * NV + lane];
     SYNC();
     substep<TASK == TASK_STEP>(m, p, S, lane, 0, &warm, sprof, ter);  // set_state: mj_forward with actuation disabled
   }
@@ -1971,13 +1971,13 @@ __global__ void __launch_bounds__(64, 2) humanoid_kernel(HModel m, HParams p, HS
     {
       bool bad = false;
       if (lane < m.nq) bad = !isfinite(S.qpos[lane]);
-      if (lane < m.nv) bad = bad || !isfinite(S.qvel[lane]) || !isfinite(S.qacc[lane]);
+      if (lane < NV) bad = bad || !isfinite(S.qvel[lane]) || !isfinite(S.qacc[lane]);
       if (__any(bad) || !isfinite(r_sum)) {
         terminated = true;
         r_sum = 0;
         for (int k = 0; k < 10; k++) terms[k] = 0;
         if (lane < m.nq) S.qpos[lane] = p.nominal_qpos[lane];
-        if (lane < m.nv) { S.qvel[lane] = 0; S.qacc[lane] = 0; }
+        if (lane < NV) { S.qvel[lane] = 0; S.qacc[lane] = 0; }
         if (lane < m.nu) { S.sq[lane] = p.action_offset[lane]; S.sv[lane] = 0; S.frc[lane] = 0; cur_tq = 0; }
         if (lane == 0) atomicAdd(&st.ep_stats[4], 1.0);
         SYNC();
@@ -2039,7 +2039,7 @@ __global__ void __launch_bounds__(64, 2) humanoid_kernel(HModel m, HParams p, HS
     // ---- MujocoEnv.reset + BaseHumanoidEnv.reset_model (mujoco_env.py:113-127, base_humanoid_env.py:247-276)
     SYNC();
     if (lane < m.nq) S.qpos[lane] = p.nominal_qpos[lane];
-    if (lane < m.nv) S.qvel[lane] = 0;
+    if (lane < NV) S.qvel[lane] = 0;
     if (lane < m.nu) S.ctrl[lane] = 0;
     warm = 0;
     if (H1R) {
@@ -2158,7 +2158,7 @@ __global__ void __launch_bounds__(64, 2) humanoid_kernel(HModel m, HParams p, HS
   // ---- store the record
   SYNC();
   if (lane < m.nq) rec[R_QPOS + lane] = S.qpos[lane];
-  if (lane < m.nv) { rec[R_QVEL + lane] = S.qvel[lane]; rec[R_WARM + lane] = warm; }
+  if (lane < NV) { rec[R_QVEL + lane] = S.qvel[lane]; rec[R_WARM + lane] = warm; }
   if (lane < m.nu) {
     rec[R_SQ + lane] = S.sq[lane]; rec[R_SV + lane] = S.sv[lane]; rec[R_FRC + lane] = S.frc[lane];
     rec[R_PREVPRED + lane] = prevpred; rec[R_PREVACT + lane] = prevact; rec[R_PREVTQ + lane] = prevtq;
