@@ -26,5 +26,5 @@ python /root/repo/scripts/jvrc_phase_profile.py 4096 > $OUT/jvrc_walk_phase_cycl
 python /root/repo/scripts/jvrc_phase_profile.py 4096 jvrc_step 3 > $OUT/jvrc_step_phase_cycles.txt 2>/dev/null
 python /root/repo/scripts/jvrc_phase_profile.py 4096 jvrc_step 4 >> $OUT/jvrc_step_phase_cycles.txt 2>/dev/null
 # end-to-end sanity: 100 PPO iterations of jvrc_walk on the stand-in robot (reward / episode length trend)
-rm -rf /tmp/train_log; timeout 600 python /root/repo/run_experiment.py train --env jvrc_walk --num-envs 4096 --minibatch-size 32768 --n-itr 100 --eval-freq 1000 --logdir /tmp/train_log --seed 0 2>&1 | grep -E "Iteration|Mean Eprew|Mean Eplen|fps=|Sampling took|Optimizer took" > $OUT/train_jvrc_walk_40iters.log
+rm -rf /tmp/train_log; timeout 600 python /root/repo/run_experiment.py train --env jvrc_walk --num-envs 4096 --minibatch-size 32768 --n-itr 100 --eval-freq 1000 --logdir /tmp/train_log --seed 0 2>&1 | grep -E "Iteration|Mean Eprew|Mean Eplen|fps=|Sampling took|Optimizer took" > $OUT/train_jvrc_walk_100iters.log
 ls -la $OUT
