@@ -142,6 +142,11 @@ int lhw_env_step(LhwEnv* env, const float* act_dev, float* obs_dev, float* term_
  * terrain box, floor_z [N], and istate [N][5] = t1 t2 target_reached target_reached_frames sequence_length. */
 int lhw_env_debug_step_record(LhwEnv* env, double* seq, double* floor_z, int32_t* istate);
 
+/* Same as lhw_env_step for the envs [first, first + count) only; all pointers are the FULL-batch arrays (the range indexes
+ * into them).  Lets the host pipeline independent groups of envs on separate HIP streams: without a batch-wide barrier per
+ * control step, the tail of one group's kernel overlaps the next group's (wave-per-env steppers only). */
+int lhw_env_step_range(LhwEnv* env, int32_t first, int32_t count, const float* act_dev, float* obs_dev, float* term_obs_dev,
+                       float* rew_dev, uint8_t* done_dev, float* rew_terms_dev, void* stream);
 /* Parity hooks; HOST pointers, synchronous.  qpos [N][nq], qvel [N][nv] float64. */
 int lhw_env_get_state(LhwEnv* env, double* qpos_host, double* qvel_host);
 int lhw_env_set_state(LhwEnv* env, const double* qpos_host, const double* qvel_host);
@@ -191,6 +196,11 @@ int lhw_ppo_normalize(LhwPpo* ppo, const float* obs, int64_t R, const float* obs
 int lhw_ppo_forward(LhwPpo* ppo, const float* theta, const float* obs, int64_t N, const float* obs_mean,
                     const float* obs_std, uint64_t seed, uint32_t env_id_base, uint32_t counter, int deterministic,
                     float* mu, float* act, float* logp, float* value, void* stream);
+/* lhw_ppo_forward on workspace rows [ws_row, ws_row + N): calls issued on different streams for disjoint env groups may run
+ * concurrently (env_id_base must be the global id of the group's first env) */
+int lhw_ppo_forward_at(LhwPpo* ppo, const float* theta, const float* obs, int64_t N, const float* obs_mean,
+                       const float* obs_std, uint64_t seed, uint32_t env_id_base, uint32_t counter, int deterministic,
+                       int64_t ws_row, float* mu, float* act, float* logp, float* value, void* stream);
 /* fp16 != 0: lhw_ppo_forward (rollout inference) rounds weights and activations to fp16 and multiplies on the fp16 MFMA with
  * float32 accumulation (BASELINE config "fp16 actor/critic"); the update (lhw_ppo_grad) always uses float32 operands */
 int lhw_ppo_set_inference_dtype(LhwPpo* ppo, int fp16);

@@ -73,6 +73,7 @@ def lib():
     L.lhw_env_set_iteration.argtypes = [vp, i64]
     L.lhw_env_pop_fault_stats.argtypes = [vp, ctypes.POINTER(i64), ctypes.POINTER(i64)]
     L.lhw_env_phase_cycles.argtypes = [vp, ctypes.c_int, vp]
+    L.lhw_env_step_range.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp, vp, vp]
     L.lhw_ppo_set_imitation.argtypes = [vp, vp, vp, ctypes.c_float, i64]
     L.lhw_env_debug_step_record.argtypes = [vp, vp, vp, vp]
     _LIB = L

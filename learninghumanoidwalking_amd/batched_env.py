@@ -113,6 +113,14 @@ class BatchedEnv:
                                         _ptr(self.rew_terms), _stream_ptr(self.device)))
         return obs, rew, done, tob
 
+    def step_range(self, first: int, count: int, act: torch.Tensor, obs: torch.Tensor, term_obs: torch.Tensor, rew: torch.Tensor,
+                   done: torch.Tensor):
+        """Advance envs [first, first + count) only, on the current stream.  All tensors are the FULL-batch buffers ([N, ...]);
+        independent groups issued on different streams overlap on the GPU (no batch-wide barrier per control step)."""
+        assert act.is_cuda and act.dtype == torch.float32 and act.is_contiguous() and act.numel() == self.n_envs * self.act_dim
+        _lib.check(self._L.lhw_env_step_range(self._h, int(first), int(count), _ptr(act), _ptr(obs), _ptr(term_obs), _ptr(rew),
+                                              _ptr(done), _ptr(self.rew_terms), _stream_ptr(self.device)))
+
     def get_state(self):
         qpos = np.zeros((self.n_envs, self.nq))
         qvel = np.zeros((self.n_envs, self.nv))

@@ -206,6 +206,17 @@ extern "C" int lhw_env_step(LhwEnv* e, const float* act_dev, float* obs_dev, flo
   return LHW_OK;
 }
 
+extern "C" int lhw_env_step_range(LhwEnv* e, int32_t first, int32_t count, const float* act_dev, float* obs_dev, float* term_obs_dev,
+                                  float* rew_dev, uint8_t* done_dev, float* rew_terms_dev, void* stream) {
+  if (!e || !act_dev || !obs_dev || !rew_dev || !done_dev) return lhw_fail(LHW_ERR_ARG, "null argument");
+  if (e->task == LHW_TASK_CARTPOLE) return lhw_fail(LHW_ERR_UNSUPPORTED, "lhw_env_step_range: the lane-per-env cartpole stepper advances whole batches");
+  HIPCHK(hipSetDevice(e->device));
+  if (humanoid_step_range(e->hum, first, count, act_dev, obs_dev, term_obs_dev, rew_dev, done_dev, rew_terms_dev, (hipStream_t)stream))
+    return lhw_fail(LHW_ERR_ARG, "env range [%d, %d) outside the batch", first, first + count);
+  HIPCHK(hipGetLastError());
+  return LHW_OK;
+}
+
 extern "C" int lhw_env_get_state(LhwEnv* e, double* qpos_host, double* qvel_host) {
   if (!e || !qpos_host || !qvel_host) return lhw_fail(LHW_ERR_ARG, "null argument");
   HIPCHK(hipSetDevice(e->device));

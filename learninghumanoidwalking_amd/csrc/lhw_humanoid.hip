@@ -178,6 +178,7 @@ struct HModel {
 
 struct HParams {
   int n_envs, frame_skip, max_traj_len, period, task;
+  int env_first, env_count;             // sub-range of envs this launch advances (lhw_env_step_range); blockIdx.x is relative to it
   int root_body, head_body, rfoot_body, lfoot_body;
   int env_params;                       // 1: damping / frictionloss / mass / ipos / xfrc come from the per-env record
   int dynrand_interval, perturb_interval, n_pbody, pbody[2];
@@ -1700,7 +1701,7 @@ __global__ void __launch_bounds__(64, 2) humanoid_kernel(HModel m, HParams p, HS
   using L = LdsT<(TASK == TASK_STEP ? 64 : 48), (TASK == TASK_STEP ? 16 : 12), TASK != TASK_STEP,
                  ((TASK == TASK_STAND || TASK == TASK_H1WALK) ? 16 : 18)>;
   __shared__ L S;
-  const int env = blockIdx.x, lane = threadIdx.x;
+  const int env = blockIdx.x + p.env_first, lane = threadIdx.x;
   if (MODE == 1 && mask && !mask[env]) return;
   double* rec = st.rec + (size_t)env * REC_D;
   double* prm = st.prm ? st.prm + (size_t)env * PRM_D : nullptr;
@@ -2478,13 +2479,17 @@ void humanoid_destroy(HumanoidEnv* h) {
   delete h;
 }
 
-#define LAUNCH(MODE, ...)                                                                                          \
+#define LAUNCH_RANGE(MODE, FIRST, COUNT, ...)                                                                      \
   do {                                                                                                             \
-    if (h->p.task == TASK_WALK) hipLaunchKernelGGL((humanoid_kernel<MODE, TASK_WALK>), dim3(h->p.n_envs), dim3(64), 0, s, h->m, h->p, h->st, __VA_ARGS__); \
-    else if (h->p.task == TASK_STEP) hipLaunchKernelGGL((humanoid_kernel<MODE, TASK_STEP>), dim3(h->p.n_envs), dim3(64), 0, s, h->m, h->p, h->st, __VA_ARGS__); \
-    else if (h->p.task == TASK_H1WALK) hipLaunchKernelGGL((humanoid_kernel<MODE, TASK_H1WALK>), dim3(h->p.n_envs), dim3(64), 0, s, h->m, h->p, h->st, __VA_ARGS__); \
-    else hipLaunchKernelGGL((humanoid_kernel<MODE, TASK_STAND>), dim3(h->p.n_envs), dim3(64), 0, s, h->m, h->p, h->st, __VA_ARGS__);                     \
+    HParams pp_ = h->p;                                                                                            \
+    pp_.env_first = (FIRST); pp_.env_count = (COUNT);                                                              \
+    const dim3 grid_(pp_.env_count);                                                                               \
+    if (pp_.task == TASK_WALK) hipLaunchKernelGGL((humanoid_kernel<MODE, TASK_WALK>), grid_, dim3(64), 0, s, h->m, pp_, h->st, __VA_ARGS__); \
+    else if (pp_.task == TASK_STEP) hipLaunchKernelGGL((humanoid_kernel<MODE, TASK_STEP>), grid_, dim3(64), 0, s, h->m, pp_, h->st, __VA_ARGS__); \
+    else if (pp_.task == TASK_H1WALK) hipLaunchKernelGGL((humanoid_kernel<MODE, TASK_H1WALK>), grid_, dim3(64), 0, s, h->m, pp_, h->st, __VA_ARGS__); \
+    else hipLaunchKernelGGL((humanoid_kernel<MODE, TASK_STAND>), grid_, dim3(64), 0, s, h->m, pp_, h->st, __VA_ARGS__);                     \
   } while (0)
+#define LAUNCH(MODE, ...) LAUNCH_RANGE(MODE, 0, h->p.n_envs, __VA_ARGS__)
 
 void humanoid_reset(HumanoidEnv* h, const uint8_t* mask, float* obs, hipStream_t s) {
   LAUNCH(1, (const float*)nullptr, obs, (float*)nullptr, (float*)nullptr, (unsigned char*)nullptr, (float*)nullptr, mask,
@@ -2493,6 +2498,13 @@ void humanoid_reset(HumanoidEnv* h, const uint8_t* mask, float* obs, hipStream_t
 void humanoid_step(HumanoidEnv* h, const float* act, float* obs, float* term_obs, float* rew, uint8_t* done, float* rew_terms,
                    hipStream_t s) {
   LAUNCH(0, act, obs, term_obs, rew, done, rew_terms, (const unsigned char*)nullptr, (double*)nullptr, (double*)nullptr);
+}
+// envs [first, first + count) only; the pointers are the full-batch arrays
+int humanoid_step_range(HumanoidEnv* h, int first, int count, const float* act, float* obs, float* term_obs, float* rew, uint8_t* done,
+                        float* rew_terms, hipStream_t s) {
+  if (first < 0 || count <= 0 || first + count > h->p.n_envs) return -1;
+  LAUNCH_RANGE(0, first, count, act, obs, term_obs, rew, done, rew_terms, (const unsigned char*)nullptr, (double*)nullptr, (double*)nullptr);
+  return 0;
 }
 void humanoid_get_state(HumanoidEnv* h, double* qpos, double* qvel, hipStream_t s) {
   LAUNCH(3, (const float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, (unsigned char*)nullptr, (float*)nullptr,

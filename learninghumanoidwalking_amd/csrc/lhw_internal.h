@@ -16,6 +16,8 @@ void humanoid_destroy(HumanoidEnv* h);
 void humanoid_reset(HumanoidEnv* h, const uint8_t* mask, float* obs, hipStream_t s);
 void humanoid_step(HumanoidEnv* h, const float* act, float* obs, float* term_obs, float* rew, uint8_t* done, float* rew_terms,
                    hipStream_t s);
+int humanoid_step_range(HumanoidEnv* h, int first, int count, const float* act, float* obs, float* term_obs, float* rew, uint8_t* done,
+                        float* rew_terms, hipStream_t s);
 void humanoid_get_state(HumanoidEnv* h, double* qpos, double* qvel, hipStream_t s);
 void humanoid_set_state(HumanoidEnv* h, const double* qpos, const double* qvel, hipStream_t s);
 double* humanoid_ep_stats(HumanoidEnv* h);

@@ -756,32 +756,48 @@ extern "C" int lhw_ppo_normalize(LhwPpo* p, const float* obs, int64_t R, const f
   return LHW_OK;
 }
 
+// ws_row: first row of the forward workspace to use (concurrent calls on different streams must use disjoint row ranges)
+static int ppo_forward_impl(LhwPpo* p, const float* theta, const float* obs, int64_t N, const float* obs_mean, const float* obs_std,
+                            uint64_t seed, uint32_t env_id_base, uint32_t counter, int deterministic, int64_t ws_row, float* mu,
+                            float* act, float* logp, float* value, void* stream) {
+  if (!p || !theta || !obs || N <= 0 || ws_row < 0 || ws_row + N > p->max_rows)
+    return lhw_fail(LHW_ERR_ARG, "bad argument (rows [%lld, %lld), capacity %d)", (long long)ws_row, (long long)(ws_row + N), p ? p->max_rows : 0);
+  HIPCHK(hipSetDevice(p->device));
+  hipStream_t s = (hipStream_t)stream;
+  const size_t Dp = p->la.Dp, H = p->H, Op = p->la.Op, r0 = (size_t)ws_row;
+  float *xb = p->xb + r0 * Dp, *h1a = p->h1a + r0 * H, *h2a = p->h2a + r0 * H, *ya = p->ya + r0 * Op;
+  float *h1c = p->h1c + r0 * H, *h2c = p->h2c + r0 * H, *yc = p->yc + r0 * 4;
+  size_t n = (size_t)N * Dp;
+  hipLaunchKernelGGL(normalize_kernel, dim3((n + 255) / 256), dim3(256), 0, s, obs, p->D, p->la.Dp, (size_t)N, obs_mean, obs_std,
+                     xb, (float*)nullptr, (const int*)nullptr, (const float*)nullptr);
+  if (act || mu) {
+    mlp_forward(p->la, theta + p->off_actor, xb, p->la.Dp, (int)N, h1a, h2a, ya, s, p->infer_half);
+    if (mu) HIPCHK(hipMemcpy2DAsync(mu, sizeof(float) * p->A, ya, sizeof(float) * p->la.Op, sizeof(float) * p->A, N, hipMemcpyDeviceToDevice, s));
+    if (act) {
+      if (!logp) return lhw_fail(LHW_ERR_ARG, "logp required with act");
+      hipLaunchKernelGGL(sample_kernel, dim3((N + 255) / 256), dim3(256), 0, s, ya, p->la.Op, p->A, (int)N, theta + p->off_std,
+                         seed, env_id_base, counter, deterministic, act, logp);
+    }
+  }
+  if (value) {
+    mlp_forward(p->lc, theta + p->off_critic, xb, p->la.Dp, (int)N, h1c, h2c, yc, s, p->infer_half);
+    HIPCHK(hipMemcpy2DAsync(value, sizeof(float), yc, sizeof(float) * 4, sizeof(float), N, hipMemcpyDeviceToDevice, s));
+  }
+  HIPCHK(hipGetLastError());
+  return LHW_OK;
+}
+
 // Rollout inference for N rows (N <= max_rows): normalise, actor + critic forward, sample.
 //   act/logp/mu may be NULL to run the critic only; value may be NULL to run the actor only.
 extern "C" int lhw_ppo_forward(LhwPpo* p, const float* theta, const float* obs, int64_t N, const float* obs_mean,
                                const float* obs_std, uint64_t seed, uint32_t env_id_base, uint32_t counter, int deterministic,
                                float* mu, float* act, float* logp, float* value, void* stream) {
-  if (!p || !theta || !obs || N <= 0 || N > p->max_rows) return lhw_fail(LHW_ERR_ARG, "bad argument (N=%lld, capacity %d)", (long long)N, p ? p->max_rows : 0);
-  HIPCHK(hipSetDevice(p->device));
-  hipStream_t s = (hipStream_t)stream;
-  size_t n = (size_t)N * p->la.Dp;
-  hipLaunchKernelGGL(normalize_kernel, dim3((n + 255) / 256), dim3(256), 0, s, obs, p->D, p->la.Dp, (size_t)N, obs_mean, obs_std,
-                     p->xb, (float*)nullptr, (const int*)nullptr, (const float*)nullptr);
-  if (act || mu) {
-    mlp_forward(p->la, theta + p->off_actor, p->xb, p->la.Dp, (int)N, p->h1a, p->h2a, p->ya, s, p->infer_half);
-    if (mu) HIPCHK(hipMemcpy2DAsync(mu, sizeof(float) * p->A, p->ya, sizeof(float) * p->la.Op, sizeof(float) * p->A, N, hipMemcpyDeviceToDevice, s));
-    if (act) {
-      if (!logp) return lhw_fail(LHW_ERR_ARG, "logp required with act");
-      hipLaunchKernelGGL(sample_kernel, dim3((N + 255) / 256), dim3(256), 0, s, p->ya, p->la.Op, p->A, (int)N, theta + p->off_std,
-                         seed, env_id_base, counter, deterministic, act, logp);
-    }
-  }
-  if (value) {
-    mlp_forward(p->lc, theta + p->off_critic, p->xb, p->la.Dp, (int)N, p->h1c, p->h2c, p->yc, s, p->infer_half);
-    HIPCHK(hipMemcpy2DAsync(value, sizeof(float), p->yc, sizeof(float) * 4, sizeof(float), N, hipMemcpyDeviceToDevice, s));
-  }
-  HIPCHK(hipGetLastError());
-  return LHW_OK;
+  return ppo_forward_impl(p, theta, obs, N, obs_mean, obs_std, seed, env_id_base, counter, deterministic, 0, mu, act, logp, value, stream);
+}
+extern "C" int lhw_ppo_forward_at(LhwPpo* p, const float* theta, const float* obs, int64_t N, const float* obs_mean,
+                                  const float* obs_std, uint64_t seed, uint32_t env_id_base, uint32_t counter, int deterministic,
+                                  int64_t ws_row, float* mu, float* act, float* logp, float* value, void* stream) {
+  return ppo_forward_impl(p, theta, obs, N, obs_mean, obs_std, seed, env_id_base, counter, deterministic, ws_row, mu, act, logp, value, stream);
 }
 
 extern "C" int lhw_gae(int32_t T, int32_t N, const float* rew, const float* val, const uint8_t* done, const float* vterm,

@@ -10,6 +10,7 @@ liblhw.so.  Only gradients cross GPUs (``torch.distributed`` all-reduce, RCCL ov
 from __future__ import annotations
 
 import datetime
+import os
 import sys
 import time
 from dataclasses import dataclass
@@ -89,6 +90,10 @@ class Rollout:
         self.vfinal = torch.zeros(N, dtype=torch.float32, device=dev)
         self.tob = torch.zeros(N, D, dtype=torch.float32, device=dev)
         self.tob_all = None      # [T][N][D] terminal observations of the feed-forward path (allocated on first use)
+        # number of independent env groups pipelined on separate streams (wave-per-env steppers; LHW_ROLLOUT_GROUPS overrides)
+        want = int(os.environ.get("LHW_ROLLOUT_GROUPS", "2" if (N >= 2048 and hasattr(env, "step_range") and env.task != 0) else "1"))
+        self.groups = max(1, min(want, N)) if env.task != 0 else 1
+        self.streams = None
         self.counter = 0
         self.started = False
         self.env_base = getattr(env, "env_id_base", 0)
@@ -107,11 +112,35 @@ class Rollout:
         # of two extra 3-GEMM passes per control step (same values, ~2000 fewer kernel launches per iteration).
         if self.tob_all is None:
             self.tob_all = torch.zeros(T, self.N, self.obs.shape[2], dtype=torch.float32, device=self.obs.device)
-        for t in range(T):
-            k.forward(self.obs[t], seed=self.seed, env_id_base=self.env_base, counter=self.counter,
-                      deterministic=deterministic, want_value=False, mu=self.mu, act=self.act[t], logp=self.logp[t])
-            env.step(self.act[t], obs_out=self.obs[t + 1], term_obs_out=self.tob_all[t], rew_out=self.rew[t], done_out=self.done[t])
-            self.counter += 1
+        G = self.groups
+        if G <= 1:
+            for t in range(T):
+                k.forward(self.obs[t], seed=self.seed, env_id_base=self.env_base, counter=self.counter,
+                          deterministic=deterministic, want_value=False, mu=self.mu, act=self.act[t], logp=self.logp[t])
+                env.step(self.act[t], obs_out=self.obs[t + 1], term_obs_out=self.tob_all[t], rew_out=self.rew[t], done_out=self.done[t])
+                self.counter += 1
+        else:
+            # Environments are independent, so the batch is advanced as G groups on their own HIP streams: a group's policy
+            # forward waits only for that group's control-step kernel.  Without the batch-wide barrier per control step the
+            # tail of one group's kernel (waves that drew more contacts / Newton iterations / a reset) overlaps the other
+            # group's work: 3.8 -> 2.9 ms per control step of 4096 envs with two groups.  Every value is unchanged (the RNG is
+            # keyed by global env id and step counter, not by launch order).
+            main = torch.cuda.current_stream(self.obs.device)
+            if self.streams is None:
+                self.streams = [torch.cuda.Stream(device=self.obs.device) for _ in range(G)]
+            bounds = [(g * self.N // G, (g + 1) * self.N // G) for g in range(G)]
+            for s in self.streams:
+                s.wait_stream(main)
+            for t in range(T):
+                for s, (a, b) in zip(self.streams, bounds):
+                    with torch.cuda.stream(s):
+                        k.forward(self.obs[t, a:b], seed=self.seed, env_id_base=self.env_base + a, counter=self.counter,
+                                  deterministic=deterministic, want_value=False, ws_row=a, mu=self.mu[a:b], act=self.act[t, a:b],
+                                  logp=self.logp[t, a:b])
+                        env.step_range(a, b - a, self.act[t], self.obs[t + 1], self.tob_all[t], self.rew[t], self.done[t])
+                self.counter += 1
+            for s in self.streams:
+                main.wait_stream(s)
         self._batched_values(self.obs[:T].reshape(T * self.N, -1), self.val.reshape(-1))
         self._batched_values(self.tob_all.reshape(T * self.N, -1), self.vterm.reshape(-1))
         k.forward(self.obs[T], want_actor=False, value=self.vfinal)

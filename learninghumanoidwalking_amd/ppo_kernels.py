@@ -44,6 +44,7 @@ def _setup(L):
     L.lhw_ppo_grad.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp]
     L.lhw_ppo_apply.argtypes = [vp, vp, vp, vp, vp, i64, f32, vp]
     L.lhw_ppo_set_inference_dtype.argtypes = [vp, ctypes.c_int]
+    L.lhw_ppo_forward_at.argtypes = [vp, vp, vp, i64, vp, vp, u64, u32, u32, ctypes.c_int, i64, vp, vp, vp, vp, vp]
     _SETUP = True
 
 
@@ -147,7 +148,7 @@ class PpoKernels:
 
     # ---- kernels
     def forward(self, obs, *, seed=0, env_id_base=0, counter=0, deterministic=False, want_actor=True, want_value=True,
-                mu=None, act=None, logp=None, value=None):
+                mu=None, act=None, logp=None, value=None, ws_row=0):
         N = obs.shape[0]
         dev = self.device
         if want_actor:
@@ -156,11 +157,11 @@ class PpoKernels:
             logp = torch.empty(N, dtype=torch.float32, device=dev) if logp is None else logp
         if want_value:
             value = torch.empty(N, dtype=torch.float32, device=dev) if value is None else value
-        _lib.check(self._L.lhw_ppo_forward(self._h, _p(self.theta), _p(obs), N, _p(self.obs_mean), _p(self.obs_std),
-                                           int(seed) & (2**64 - 1), int(env_id_base), int(counter), int(deterministic),
-                                           _p(mu) if want_actor else None, _p(act) if want_actor else None,
-                                           _p(logp) if want_actor else None, _p(value) if want_value else None,
-                                           self._stream()))
+        _lib.check(self._L.lhw_ppo_forward_at(self._h, _p(self.theta), _p(obs), N, _p(self.obs_mean), _p(self.obs_std),
+                                              int(seed) & (2**64 - 1), int(env_id_base), int(counter), int(deterministic), int(ws_row),
+                                              _p(mu) if want_actor else None, _p(act) if want_actor else None,
+                                              _p(logp) if want_actor else None, _p(value) if want_value else None,
+                                              self._stream()))
         return mu, act, logp, value
 
     def normalize(self, obs, want_mirror=None):
