@@ -218,6 +218,7 @@ def main():
                         aggregate=dict(wall_ms_per_control_step=wall_step_ms,
                                        achieved_gbs=bytes_per_env_step * N / (wall_step_ms * 1e-3) / 1e9,
                                        fp64_tflops=flops_per_env_step * N / (wall_step_ms * 1e-3) / 1e12,
+                                       fp64_frac=flops_per_env_step * N / (wall_step_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS,
                                        note="the batch is advanced as independent env groups on separate streams; their "
                                             "control-step kernels overlap, so a launch's duration includes the share of the GPU "
                                             "it cedes to the other group; the aggregate line divides the whole batch's work by the "
