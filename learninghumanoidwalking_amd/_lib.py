@@ -49,6 +49,40 @@ def build(force: bool = False, verbose: bool = False) -> str:
     return LIB_PATH
 
 
+def declare(L):
+    """Attach the argument types of include/lhw.h's entry points to a loaded library (entry points the library
+    does not export are skipped: the emulated test build has no PPO kernels)."""
+    vp, i32, i64 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64
+
+    def sig(name, argtypes=None, restype=None):
+        f = getattr(L, name, None)
+        if f is None:
+            return
+        if argtypes is not None:
+            f.argtypes = argtypes
+        if restype is not None:
+            f.restype = restype
+
+    sig("lhw_version", restype=ctypes.c_int)
+    sig("lhw_last_error", restype=ctypes.c_char_p)
+    sig("lhw_env_create", [vp, i64, vp, i64, ctypes.POINTER(LhwEnvConfig), ctypes.POINTER(vp)])
+    sig("lhw_env_destroy", [vp])
+    for f in ("lhw_env_obs_dim", "lhw_env_act_dim", "lhw_env_num_reward_terms", "lhw_env_nq", "lhw_env_nv"):
+        sig(f, [vp])
+    sig("lhw_env_reset", [vp, vp, vp, vp])
+    sig("lhw_env_step", [vp, vp, vp, vp, vp, vp, vp, vp])
+    sig("lhw_env_get_state", [vp, vp, vp])
+    sig("lhw_env_set_state", [vp, vp, vp])
+    sig("lhw_env_pop_episode_stats", [vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(i64)])
+    sig("lhw_env_set_iteration", [vp, i64])
+    sig("lhw_env_pop_fault_stats", [vp, ctypes.POINTER(i64), ctypes.POINTER(i64)])
+    sig("lhw_env_phase_cycles", [vp, ctypes.c_int, vp])
+    sig("lhw_env_step_range", [vp, i32, i32, vp, vp, vp, vp, vp, vp, vp])
+    sig("lhw_ppo_set_imitation", [vp, vp, vp, ctypes.c_float, i64])
+    sig("lhw_env_debug_step_record", [vp, vp, vp, vp])
+    return L
+
+
 def lib():
     global _LIB
     if _LIB is not None:
@@ -56,26 +90,7 @@ def lib():
     if not os.path.exists(LIB_PATH):
         raise LhwError(-5, f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                            "(there is no CPU fallback for the stepper / PPO kernels)")
-    L = ctypes.CDLL(LIB_PATH)
-    vp, i32, i64 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64
-    L.lhw_version.restype = ctypes.c_int
-    L.lhw_last_error.restype = ctypes.c_char_p
-    L.lhw_env_create.argtypes = [vp, i64, vp, i64, ctypes.POINTER(LhwEnvConfig), ctypes.POINTER(vp)]
-    L.lhw_env_destroy.argtypes = [vp]
-    for f in ("lhw_env_obs_dim", "lhw_env_act_dim", "lhw_env_num_reward_terms", "lhw_env_nq", "lhw_env_nv"):
-        getattr(L, f).argtypes = [vp]
-    L.lhw_env_reset.argtypes = [vp, vp, vp, vp]
-    L.lhw_env_step.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
-    L.lhw_env_get_state.argtypes = [vp, vp, vp]
-    L.lhw_env_set_state.argtypes = [vp, vp, vp]
-    L.lhw_env_pop_episode_stats.argtypes = [vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double),
-                                            ctypes.POINTER(i64)]
-    L.lhw_env_set_iteration.argtypes = [vp, i64]
-    L.lhw_env_pop_fault_stats.argtypes = [vp, ctypes.POINTER(i64), ctypes.POINTER(i64)]
-    L.lhw_env_phase_cycles.argtypes = [vp, ctypes.c_int, vp]
-    L.lhw_env_step_range.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp, vp, vp]
-    L.lhw_ppo_set_imitation.argtypes = [vp, vp, vp, ctypes.c_float, i64]
-    L.lhw_env_debug_step_record.argtypes = [vp, vp, vp, vp]
+    L = declare(ctypes.CDLL(LIB_PATH))
     _LIB = L
     return L
 

@@ -1,0 +1,167 @@
+// TEST INFRASTRUCTURE -- scheduler of the host-side SIMT emulator (see hip/hip_runtime.h in this directory).
+#include <hip/hip_runtime.h>
+
+namespace emu {
+Block* g_blk = nullptr;
+
+asm(R"(
+.text
+.globl emu_switch
+.type emu_switch,@function
+emu_switch:
+  pushq %rbp
+  pushq %rbx
+  pushq %r12
+  pushq %r13
+  pushq %r14
+  pushq %r15
+  movq %rsp, (%rdi)
+  movq %rsi, %rsp
+  popq %r15
+  popq %r14
+  popq %r13
+  popq %r12
+  popq %rbx
+  popq %rbp
+  ret
+.size emu_switch, .-emu_switch
+)");
+
+static const size_t STACK = 512 * 1024;
+
+static void trampoline() {
+  Block* b = g_blk;
+  b->body();
+  Lane& l = b->lanes[b->cur];
+  l.state = DONE;
+  emu_switch(&l.sp, b->main_sp);
+  abort();  // a finished fiber is never resumed
+}
+
+void block_here() {
+  Block* b = g_blk;
+  Lane& l = b->lanes[b->cur];
+  l.state = BLOCKED;
+  emu_switch(&l.sp, b->main_sp);
+}
+
+static bool at(const Block& b, int lane, int op) {
+  return lane >= 0 && lane < (int)b.lanes.size() && b.lanes[lane].state == BLOCKED && b.lanes[lane].op == op;
+}
+
+// source lane of a DPP control word for destination lane i (-1: no source)
+static int dpp_source(int ctrl, int i) {
+  const int row = i & ~15, k = i & 15;
+  if (ctrl >= 0x000 && ctrl <= 0x0ff) return (i & ~3) + ((ctrl >> (2 * (i & 3))) & 3);          // quad_perm
+  if (ctrl >= 0x101 && ctrl <= 0x10f) { const int n = ctrl & 15; return k + n < 16 ? i + n : -1; }  // row_shl
+  if (ctrl >= 0x111 && ctrl <= 0x11f) { const int n = ctrl & 15; return k >= n ? i - n : -1; }      // row_shr
+  if (ctrl >= 0x121 && ctrl <= 0x12f) { const int n = ctrl & 15; return row + ((k - n) & 15); }     // row_ror
+  if (ctrl == 0x130) return i < 63 ? i + 1 : -1;                                                   // wave_shl:1
+  if (ctrl == 0x138) return i > 0 ? i - 1 : -1;                                                    // wave_shr:1
+  if (ctrl == 0x140) return row + (15 - k);                                                        // row_mirror
+  if (ctrl == 0x141) return row + (k < 8 ? 7 - k : 23 - k);                                        // row_half_mirror
+  if (ctrl == 0x142) return row >= 16 ? row - 1 : -1;                                              // row_bcast:15
+  if (ctrl == 0x143) return i >= 32 ? 31 : -1;                                                     // row_bcast:31
+  fprintf(stderr, "emu: unsupported DPP control 0x%x\n", ctrl);
+  abort();
+}
+
+static void resolve(Block& b) {
+  const int n = (int)b.lanes.size();
+  // block barrier: only completes once every live lane of the workgroup waits at one
+  bool all_block_barrier = true;
+  for (int i = 0; i < n; i++)
+    if (b.lanes[i].state == BLOCKED && b.lanes[i].op != OP_BLOCK_BARRIER) all_block_barrier = false;
+  for (int w0 = 0; w0 < n; w0 += 64) {
+    const int wn = std::min(64, n - w0);
+    uint64_t ballot = 0;
+    for (int i = 0; i < wn; i++)
+      if (at(b, w0 + i, OP_BALLOT) && b.lanes[w0 + i].val) ballot |= 1ull << i;
+    for (int i = 0; i < wn; i++) {
+      Lane& l = b.lanes[w0 + i];
+      if (l.state != BLOCKED) continue;
+      switch (l.op) {
+        case OP_DPP: {
+          const bool wr = ((l.row_mask >> (i >> 4)) & 1) && ((l.bank_mask >> ((i & 15) >> 2)) & 1);
+          if (!wr) { l.res = l.old; break; }
+          const int s = dpp_source(l.ctrl, i);
+          const bool ok = s >= 0 && s < wn && at(b, w0 + s, OP_DPP) && b.lanes[w0 + s].ctrl == l.ctrl;
+          l.res = ok ? b.lanes[w0 + s].val : (l.bound ? 0u : l.old);
+          break;
+        }
+        case OP_READLANE: {
+          const int s = l.sel & 63;
+          l.res = at(b, w0 + s, OP_READLANE) ? b.lanes[w0 + s].val : 0xDEADBEEFu;  // an inactive lane's register: garbage
+          break;
+        }
+        case OP_BPERMUTE: {
+          const int s = l.sel & 63;
+          l.res = at(b, w0 + s, OP_BPERMUTE) ? b.lanes[w0 + s].val : 0u;
+          break;
+        }
+        case OP_SWIZZLE: {
+          int s;
+          if (l.ctrl & 0x8000) s = (i & ~3) + ((l.ctrl >> (2 * (i & 3))) & 3);   // quad-permute mode
+          else { const int a = l.ctrl & 31, o = (l.ctrl >> 5) & 31, x = (l.ctrl >> 10) & 31; s = (i & 32) | ((((i & 31) & a) | o) ^ x); }
+          l.res = at(b, w0 + s, OP_SWIZZLE) ? b.lanes[w0 + s].val : 0u;
+          break;
+        }
+        case OP_BALLOT: l.res64 = ballot; break;
+        default: break;
+      }
+    }
+  }
+  for (int i = 0; i < n; i++) {
+    Lane& l = b.lanes[i];
+    if (l.state != BLOCKED) continue;
+    if (l.op == OP_BLOCK_BARRIER && !all_block_barrier) continue;
+    l.state = RUNNABLE;
+    l.op = OP_NONE;
+  }
+}
+
+void run_block(Block& b) {
+  const int n = (int)b.lanes.size();
+  static const bool reverse = getenv("LHW_EMU_REVERSE") && atoi(getenv("LHW_EMU_REVERSE"));
+  Block* outer = g_blk;
+  g_blk = &b;
+  for (int i = 0; i < n; i++) {
+    Lane& l = b.lanes[i];
+    if (!l.stack) l.stack = (char*)malloc(STACK);
+    l.tid = dim3(i);
+    l.state = RUNNABLE;
+    l.op = OP_NONE;
+    uintptr_t top = ((uintptr_t)(l.stack + STACK)) & ~(uintptr_t)15;
+    void** sp = (void**)(top - 8);   // fake return slot: the trampoline starts with rsp == 8 (mod 16), as after a call
+    *sp = nullptr;
+    *--sp = (void*)&trampoline;
+    for (int k = 0; k < 6; k++) *--sp = nullptr;
+    l.sp = sp;
+  }
+  for (;;) {
+    bool ran = false, live = false;
+    for (int k = 0; k < n; k++) {
+      const int i = reverse ? n - 1 - k : k;
+      Lane& l = b.lanes[i];
+      if (l.state == RUNNABLE) {
+        b.cur = i;
+        emu_switch(&b.main_sp, l.sp);
+        ran = true;
+      }
+      if (l.state != DONE) live = true;
+    }
+    if (!live) break;
+    bool runnable = false;
+    for (int i = 0; i < n; i++) if (b.lanes[i].state == RUNNABLE) runnable = true;
+    if (!runnable) {
+      resolve(b);
+      bool any = false;
+      for (int i = 0; i < n; i++) if (b.lanes[i].state == RUNNABLE) any = true;
+      if (!any) { fprintf(stderr, "emu: deadlock (a lane left the kernel while others wait at __syncthreads?)\n"); abort(); }
+    }
+    (void)ran;
+  }
+  b.cur = -1;
+  g_blk = outer;
+}
+}  // namespace emu

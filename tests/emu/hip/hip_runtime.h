@@ -1,0 +1,181 @@
+// TEST INFRASTRUCTURE -- not part of the product.
+//
+// A host-side SIMT emulator that stands in for <hip/hip_runtime.h> so that the HIP sources of the
+// wave-per-env stepper (learninghumanoidwalking_amd/csrc/lhw_humanoid.hip, lhw_cartpole.hip, lhw_api.hip)
+// compile with g++ into tests/emu/_build/liblhw_emu.so and run on a CPU.  Only tests/ builds or loads it; the
+// product library liblhw.so is always compiled by hipcc for gfx950 and has no CPU path.
+//
+// Model: every thread of a workgroup is a fiber (own stack, hand-written x86-64 context switch).  A fiber runs until
+// it reaches a cross-lane primitive (DPP move, v_readlane, ds_swizzle, ballot, wave barrier, __syncthreads); when no
+// fiber of the workgroup is runnable any more, all blocked fibers exchange their operands and continue.  Lanes that
+// are not blocked at a matching primitive count as inactive (EXEC = 0) for that exchange, which is what the hardware
+// does for divergent code as long as the exchange stays inside the group of lanes that branch together -- exactly the
+// contract the stepper's sub-wave groups are written to.  LDS is a static object; fences are no-ops because a fiber
+// executes its program order sequentially; the wave barrier is a rendezvous, so an LDS hand-off that lacks a SYNC()
+// shows up as a wrong result here (set LHW_EMU_REVERSE=1 to run the lanes in the opposite order and catch
+// order-dependent hand-offs).
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <vector>
+
+#define __HIP_EMU__ 1
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline __attribute__((always_inline))
+#define __noinline__ __attribute__((noinline))
+#define __shared__ static
+#define __launch_bounds__(...)
+#ifndef __restrict__
+#define __restrict__ __restrict
+#endif
+
+struct dim3 {
+  unsigned x, y, z;
+  dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+typedef void* hipStream_t;
+typedef void* hipEvent_t;
+typedef int hipError_t;
+enum { hipSuccess = 0, hipErrorUnknown = 999 };
+enum hipMemcpyKind { hipMemcpyHostToHost, hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice, hipMemcpyDefault };
+
+static inline hipError_t hipMalloc(void** p, size_t n) { *p = calloc(1, n ? n : 1); return *p ? hipSuccess : hipErrorUnknown; }
+template <class T> static inline hipError_t hipMalloc(T** p, size_t n) { return hipMalloc((void**)p, n); }
+static inline hipError_t hipFree(void* p) { free(p); return hipSuccess; }
+static inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { memcpy(d, s, n); return hipSuccess; }
+static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { memcpy(d, s, n); return hipSuccess; }
+static inline hipError_t hipMemset(void* d, int v, size_t n) { memset(d, v, n); return hipSuccess; }
+static inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { memset(d, v, n); return hipSuccess; }
+static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
+static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+static inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
+static inline hipError_t hipSetDevice(int) { return hipSuccess; }
+static inline hipError_t hipGetLastError() { return hipSuccess; }
+static inline const char* hipGetErrorString(hipError_t) { return "emulated"; }
+template <class K> static inline hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int* n, K, int, size_t) { *n = 8; return hipSuccess; }
+
+namespace emu {
+enum { RUNNABLE = 0, BLOCKED = 1, DONE = 2 };
+enum { OP_NONE = 0, OP_WAVE_BARRIER, OP_BLOCK_BARRIER, OP_DPP, OP_READLANE, OP_SWIZZLE, OP_BALLOT, OP_PERMLANE32_SWAP, OP_BPERMUTE };
+struct Lane {
+  void* sp = nullptr;
+  char* stack = nullptr;
+  int state = DONE, op = OP_NONE;
+  int ctrl = 0, row_mask = 0, bank_mask = 0, bound = 0, sel = 0;
+  uint32_t val = 0, val2 = 0, old = 0, res = 0, res2 = 0;
+  uint64_t res64 = 0;
+  dim3 tid;
+};
+struct Block {
+  std::vector<Lane> lanes;
+  void* main_sp = nullptr;
+  int cur = -1;
+  dim3 bid, bdim, gdim;
+  std::function<void()> body;
+};
+extern Block* g_blk;
+extern "C" void emu_switch(void** from_sp, void* to_sp);
+void run_block(Block& b);
+void block_here();   // current lane yields to the scheduler (state/op already set)
+inline Lane& cur() { return g_blk->lanes[g_blk->cur]; }
+
+template <class K, class... A>
+void launch(K kernel, dim3 grid, dim3 block, A... args) {
+  Block b;
+  b.bdim = block; b.gdim = grid;
+  b.lanes.resize(block.x);
+  for (unsigned bx = 0; bx < grid.x; bx++) {
+    b.bid = dim3(bx);
+    b.body = [&]() { kernel(args...); };
+    run_block(b);
+  }
+  for (auto& l : b.lanes) free(l.stack);
+}
+}  // namespace emu
+
+#define threadIdx (emu::cur().tid)
+#define blockIdx (emu::g_blk->bid)
+#define blockDim (emu::g_blk->bdim)
+#define gridDim (emu::g_blk->gdim)
+#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) emu::launch(kernel, grid, block, ##__VA_ARGS__)
+
+// ---- cross-lane primitives
+static inline int emu_update_dpp(int old, int src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl) {
+  emu::Lane& l = emu::cur();
+  l.op = emu::OP_DPP; l.ctrl = ctrl; l.row_mask = row_mask; l.bank_mask = bank_mask; l.bound = bound_ctrl; l.old = (uint32_t)old; l.val = (uint32_t)src;
+  emu::block_here();
+  return (int)l.res;
+}
+static inline int emu_readlane(int v, int lane) {
+  emu::Lane& l = emu::cur();
+  l.op = emu::OP_READLANE; l.val = (uint32_t)v; l.sel = lane;
+  emu::block_here();
+  return (int)l.res;
+}
+static inline int emu_ds_swizzle(int v, int pattern) {
+  emu::Lane& l = emu::cur();
+  l.op = emu::OP_SWIZZLE; l.val = (uint32_t)v; l.ctrl = pattern;
+  emu::block_here();
+  return (int)l.res;
+}
+static inline int emu_ds_bpermute(int addr, int v) {
+  emu::Lane& l = emu::cur();
+  l.op = emu::OP_BPERMUTE; l.val = (uint32_t)v; l.sel = (addr >> 2) & 63;
+  emu::block_here();
+  return (int)l.res;
+}
+static inline unsigned long long emu_ballot(int pred) {
+  emu::Lane& l = emu::cur();
+  l.op = emu::OP_BALLOT; l.val = pred ? 1u : 0u;
+  emu::block_here();
+  return l.res64;
+}
+static inline void emu_wave_barrier() {
+  emu::cur().op = emu::OP_WAVE_BARRIER;
+  emu::block_here();
+}
+static inline void __syncthreads() {
+  emu::cur().op = emu::OP_BLOCK_BARRIER;
+  emu::block_here();
+}
+#define __builtin_amdgcn_update_dpp emu_update_dpp
+#define __builtin_amdgcn_readlane emu_readlane
+#define __builtin_amdgcn_ds_swizzle emu_ds_swizzle
+#define __builtin_amdgcn_ds_bpermute emu_ds_bpermute
+#define __builtin_amdgcn_wave_barrier emu_wave_barrier
+#define __builtin_amdgcn_fence(order, scope) ((void)0)
+#define __builtin_amdgcn_s_setprio(x) ((void)0)
+#define __builtin_amdgcn_sched_barrier(x) ((void)0)
+#define __builtin_amdgcn_rsq(x) (1.0 / sqrt((double)(x)))
+#define __builtin_amdgcn_rcp(x) (1.0 / (double)(x))
+static inline int __any(int p) { return emu_ballot(p) != 0; }
+static inline int __all(int p) { return emu_ballot(!p) == 0; }
+static inline unsigned long long __ballot(int p) { return emu_ballot(p); }
+
+// ---- scalar device functions
+static inline int __ffs(unsigned v) { return __builtin_ffs((int)v); }
+static inline int __ffsll(unsigned long long v) { return __builtin_ffsll((long long)v); }
+static inline int __popc(unsigned v) { return __builtin_popcount(v); }
+static inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
+static inline int __double2loint(double d) { uint64_t u; memcpy(&u, &d, 8); return (int)(uint32_t)u; }
+static inline int __double2hiint(double d) { uint64_t u; memcpy(&u, &d, 8); return (int)(uint32_t)(u >> 32); }
+static inline double __hiloint2double(int hi, int lo) { uint64_t u = ((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo; double d; memcpy(&d, &u, 8); return d; }
+static inline double __longlong_as_double(long long v) { double d; memcpy(&d, &v, 8); return d; }
+static inline long long __double_as_longlong(double d) { long long v; memcpy(&v, &d, 8); return v; }
+static inline long long clock64() { static long long c = 0; return c += 16; }
+static inline double atomicAdd(double* p, double v) { double o = *p; *p = o + v; return o; }
+static inline float atomicAdd(float* p, float v) { float o = *p; *p = o + v; return o; }
+static inline int atomicAdd(int* p, int v) { int o = *p; *p = o + v; return o; }
+static inline unsigned atomicAdd(unsigned* p, unsigned v) { unsigned o = *p; *p = o + v; return o; }
+static inline int atomicOr(int* p, int v) { int o = *p; *p = o | v; return o; }
+static inline int atomicMax(int* p, int v) { int o = *p; *p = o > v ? o : v; return o; }
+using std::isfinite;
+using std::max;
+using std::min;

@@ -1,0 +1,188 @@
+"""The HIP stepper SOURCES (csrc/lhw_humanoid.hip, lhw_cartpole.hip, lhw_api.hip), compiled for the host against the SIMT
+emulator in tests/emu and driven through the C ABI, versus the float64 CPU oracle.  This is the CPU (`-m "not gpu"`)
+twin of tests/test_{jvrc,h1,h1_walk,jvrc_step,cartpole}_gpu.py: it checks lane mappings, cross-lane reductions, LDS
+hand-offs and the sub-wave grouping of the kernels without a GPU.  The emulated library is test infrastructure only."""
+import numpy as np
+import pytest
+
+from tests import emu
+
+
+def _states(orc):
+    return np.array([o.sim.qpos.copy() for o in orc]), np.array([o.sim.qvel.copy() for o in orc])
+
+
+def _mk(spec_cls, orc_cls, n, seed, max_traj_len=0):
+    spec = spec_cls()
+    env = emu.make_emulated(spec, n, seed=seed, max_traj_len=max_traj_len)
+    orc = [orc_cls(spec, seed=seed, env_id=i, max_traj_len=max_traj_len) for i in range(n)]
+    return spec, env, orc
+
+
+def _run_tape(env, orc, tape, qtol=1e-12, vtol=1e-10, resync=3, otol=2e-6):
+    N = len(orc)
+    for t in range(tape.shape[0]):
+        obs, rew, done, _ = env.step(tape[t])
+        res = [o.step(tape[t, i]) for i, o in enumerate(orc)]
+        q, v = env.get_state()
+        oq, ov = _states(orc)
+        np.testing.assert_allclose(q, oq, rtol=0, atol=qtol, err_msg=f"qpos t={t}")
+        np.testing.assert_allclose(v, ov, rtol=0, atol=vtol, err_msg=f"qvel t={t}")
+        np.testing.assert_allclose(obs, np.array([r[0] for r in res]), rtol=1e-5, atol=otol, err_msg=f"obs t={t}")
+        np.testing.assert_allclose(rew, np.array([r[1] for r in res]), rtol=0, atol=2e-6, err_msg=f"rew t={t}")
+        terms = np.array([[r[3][k] for k in o.TERMS] for r, o in zip(res, orc)])
+        np.testing.assert_allclose(env.rew_terms, terms, rtol=0, atol=2e-6, err_msg=f"terms t={t}")
+        np.testing.assert_array_equal(done & 1, np.array([int(r[2]) for r in res], dtype=np.uint8), err_msg=f"done t={t}")
+        if t % resync == resync - 1:
+            env.set_state(oq, ov)
+            for o in orc:
+                o.set_state(o.sim.qpos.copy(), o.sim.qvel.copy())
+    over, div = env.pop_fault_stats()
+    assert over == 0 and div == 0
+
+
+def test_emulated_jvrc_walk_reset_and_tape():
+    from learninghumanoidwalking_amd.envs.jvrc_walk import JvrcWalkSpec
+    from oracle.env_jvrc_walk import OracleJvrcWalkEnv
+    spec, env, orc = _mk(JvrcWalkSpec, OracleJvrcWalkEnv, 3, seed=9)
+    obs = env.reset().copy()
+    ref = np.array([o.reset() for o in orc])
+    q, v = env.get_state()
+    oq, ov = _states(orc)
+    np.testing.assert_allclose(q, oq, rtol=0, atol=1e-13)
+    np.testing.assert_allclose(v, ov, rtol=0, atol=1e-11)
+    np.testing.assert_allclose(obs, ref, rtol=1e-6, atol=1e-6)
+    tape = (np.random.default_rng(1234).normal(size=(6, 3, 12)) * 0.223).astype(np.float32)
+    _run_tape(env, orc, tape)
+
+
+def test_emulated_jvrc_walk_contact_variety():
+    """fallen / tangled / limit-violating poses: every primitive narrow phase and both limit sides (as the GPU test)."""
+    from learninghumanoidwalking_amd.envs.jvrc_walk import JvrcWalkSpec
+    from oracle.env_jvrc_walk import OracleJvrcWalkEnv
+    N = 6
+    spec, env, orc = _mk(JvrcWalkSpec, OracleJvrcWalkEnv, N, seed=2)
+    env.reset()
+    for o in orc:
+        o.reset()
+    m = spec.model()
+    rs = np.random.default_rng(11)
+    q = np.tile(spec.nominal_pose, (N, 1))
+    v = rs.normal(size=(N, 18)) * 0.3
+    lo, hi = m.jnt_range[1:, 0], m.jnt_range[1:, 1]
+    q[0, 2] = 0.3
+    quat = rs.normal(size=4)
+    q[0, 3:7] = quat / np.linalg.norm(quat)
+    q[0, 7:] = rs.uniform(lo, hi)
+    q[1] = [0.0, 0.0, 0.0707, -0.003, 0.4379, -0.8595, 0.2636, -0.793, 0.1178, -0.2801, 0.1269, -0.1164, -0.9956, -1.8286,
+            0.3116, -0.2094, 1.6397, -0.3666, 0.8188]
+    q[1, 3:7] /= np.linalg.norm(q[1, 3:7])
+    v[1] = 0
+    q[2, 2] = 1.3
+    q[2, 8], q[2, 14], q[2, 9], q[2, 15] = 0.3, -0.3, 0.2, -0.2      # legs pushed through each other
+    q[3, 2] = 1.2
+    q[3, 7:] = np.where(rs.uniform(size=12) < 0.5, lo - rs.uniform(0.02, 0.2, 12), hi + rs.uniform(0.02, 0.2, 12))
+    env.set_state(q, v)
+    for i, o in enumerate(orc):
+        o.set_state(q[i], v[i])
+    act = (rs.normal(size=(2, N, 12)) * 0.2).astype(np.float32)
+    kinds = set()
+    for t in range(2):
+        obs, rew, done, _ = env.step(act[t])
+        res = [o.step(act[t, i]) for i, o in enumerate(orc)]
+        for o in orc:
+            for k in range(o.sim.ncon):
+                c = o.sim.contact(k)
+                kinds.add((int(m.geom_type[c["geom1"]]), int(m.geom_type[c["geom2"]])))
+            if o.sim.nefc > 4 * o.sim.ncon:
+                kinds.add("limit")
+        gq, gv = env.get_state()
+        oq, ov = _states(orc)
+        np.testing.assert_allclose(gq, oq, rtol=0, atol=1e-11, err_msg=f"qpos t={t}")
+        np.testing.assert_allclose(gv, ov, rtol=0, atol=1e-8, err_msg=f"qvel t={t}")
+        np.testing.assert_array_equal(done & 1, np.array([int(r[2]) for r in res], dtype=np.uint8))
+        env.set_state(oq, ov)
+        for o in orc:
+            o.set_state(o.sim.qpos.copy(), o.sim.qvel.copy())
+    assert {(0, 3), (0, 6), "limit"} <= kinds, kinds
+    assert env.pop_fault_stats() == (0, 0)
+
+
+def test_emulated_jvrc_walk_auto_reset():
+    from learninghumanoidwalking_amd.envs.jvrc_walk import JvrcWalkSpec
+    from oracle.env_jvrc_walk import OracleJvrcWalkEnv
+    N, T, L = 3, 14, 6
+    spec, env, orc = _mk(JvrcWalkSpec, OracleJvrcWalkEnv, N, seed=21, max_traj_len=L)
+    env.reset()
+    for o in orc:
+        o.reset()
+    tape = (np.random.default_rng(7).normal(size=(T, N, 12)) * 0.4).astype(np.float32)
+    seen = 0
+    for t in range(T):
+        obs, rew, done, tob = env.step(tape[t])
+        res = [o.step_auto(tape[t, i]) for i, o in enumerate(orc)]
+        flags = np.array([r[2] for r in res], dtype=np.uint8)
+        np.testing.assert_array_equal(done, flags, err_msg=f"flags t={t}")
+        np.testing.assert_allclose(obs, np.array([r[0] for r in res]), rtol=1e-4, atol=1e-4, err_msg=f"obs t={t}")
+        np.testing.assert_allclose(tob, np.array([r[3] for r in res]), rtol=1e-4, atol=1e-4, err_msg=f"term obs t={t}")
+        seen |= int(np.bitwise_or.reduce(flags))
+        oq, ov = _states(orc)
+        q, v = env.get_state()
+        np.testing.assert_allclose(q, oq, rtol=0, atol=1e-9, err_msg=f"qpos t={t}")
+    assert seen & 2
+    assert env.pop_episode_stats()[2] > 0
+
+
+def test_emulated_h1_and_h1_walk():
+    from learninghumanoidwalking_amd.envs.h1 import H1Spec
+    from learninghumanoidwalking_amd.envs.h1_walk import H1WalkSpec
+    from oracle.env_h1 import OracleH1Env
+    from oracle.env_h1_walk import OracleH1WalkEnv
+    for spec_cls, orc_cls, seed in ((H1Spec, OracleH1Env, 12), (H1WalkSpec, OracleH1WalkEnv, 4)):
+        spec, env, orc = _mk(spec_cls, orc_cls, 2, seed=seed)
+        obs = env.reset().copy()
+        ref = np.array([o.reset() for o in orc])
+        q, v = env.get_state()
+        oq, ov = _states(orc)
+        np.testing.assert_allclose(q, oq, rtol=0, atol=1e-13)
+        np.testing.assert_allclose(obs, ref, rtol=1e-6, atol=2e-6)
+        assert all(o.sim.nefc >= 10 for o in orc)            # frictionloss rows active
+        tape = (np.random.default_rng(5).normal(size=(4, 2, 10)) * 0.05).astype(np.float32)
+        _run_tape(env, orc, tape, otol=2e-5)
+
+
+def test_emulated_jvrc_step_forward_mode_on_boxes():
+    from learninghumanoidwalking_amd.envs.jvrc_step import JvrcStepSpec
+    from oracle.env_jvrc_step import OracleJvrcStepEnv
+    N = 4
+    spec, env, orc = _mk(JvrcStepSpec, OracleJvrcStepEnv, N, seed=12)
+    obs = env.reset().copy()
+    ref = np.array([o.reset() for o in orc])
+    np.testing.assert_allclose(obs, ref, rtol=1e-6, atol=1e-6)
+    assert any(o.mode == 4 for o in orc), [o.mode for o in orc]   # at least one env stands on the boxes (FORWARD mode)
+    seq, fz, ist = env.debug_step_record()
+    for i, o in enumerate(orc):
+        np.testing.assert_allclose(seq[i, :len(o.sequence), :4], np.asarray(o.sequence)[:, :4], rtol=0, atol=1e-12)
+    tape = (np.random.default_rng(3).normal(size=(3, N, 12)) * 0.1).astype(np.float32)
+    _run_tape(env, orc, tape)
+
+
+def test_emulated_cartpole():
+    from learninghumanoidwalking_amd.envs import CartpoleSpec
+    from oracle.env_cartpole import OracleCartpoleEnv
+    spec = CartpoleSpec()
+    N, T = 5, 40
+    env = emu.make_emulated(spec, N, seed=1)
+    orc = [OracleCartpoleEnv(spec.model(), seed=1, env_id=i) for i in range(N)]
+    env.reset()
+    for o in orc:
+        o.reset()
+    tape = np.random.default_rng(0).uniform(-1, 1, size=(T, N, 1)).astype(np.float32)
+    for t in range(T):
+        env.step(tape[t])
+        for i, o in enumerate(orc):
+            o.step(tape[t, i, 0])
+    q, v = env.get_state()
+    oq, ov = _states(orc)
+    np.testing.assert_allclose(q, oq, rtol=0, atol=1e-11)
+    np.testing.assert_allclose(v, ov, rtol=0, atol=1e-10)
