@@ -1,7 +1,12 @@
-// Wave-per-environment rigid-body + soft-contact stepper with the tasks fused in (humanoid_kernel<MODE, TASK>:
-// jvrc_walk, jvrc_step, h1, h1_walk).
+// Rigid-body + soft-contact stepper with the tasks fused in (humanoid_kernel<MODE, TASK, W>: jvrc_walk, jvrc_step, h1,
+// h1_walk).  An environment is advanced by a GROUP of W lanes: W = 32 packs two environments into one 64-lane wavefront
+// (the fast path of the walking / standing tasks: at most 8 contacts per env), W = 64 gives one environment the whole
+// wavefront (16 contacts; the stepping task, reset / state access, and the re-run of envs that exceeded the fast path's
+// contact capacity).  The two groups of a wave share the instruction stream and nothing else: every cross-lane operation
+// (DPP scans, v_readlane broadcasts, ballots) is group-local, so per-env control flow (Newton iterations, resets) is plain
+// SIMT divergence at group granularity.
 //
-// One 64-lane wavefront advances one humanoid by a whole control step per launch:
+// One group advances one humanoid by a whole control step per launch:
 //   frame_skip x { PD law -> forward dynamics -> constraint solve -> Euler }  then
 //   task state machine, rewards, termination, observation, and (optionally) the episode
 //   bookkeeping + reset of the reference's rollout worker.
@@ -19,12 +24,14 @@
 // MuJoCo's impedance / reference acceleration / regulariser model, the primal Newton solver with exact line search and
 // warm start, Euler integration with implicit joint damping.
 //
-// Mapping onto CDNA4: the env's working set (body frames, spatial inertias, M, J, H ...) lives in
-// LDS for the whole launch; nv-vectors are held one element per lane (lane i <-> dof i) and
-// efc-vectors one row per lane, so mat-vec products are conflict-free LDS row/column sweeps and
-// reductions are wavefront shuffles; the only serial chains are the kinematic tree levels and the
-// Cholesky columns.  The persistent state is one contiguous 1.3 KB record per env, read and
-// written once per control step with lane-strided (coalesced) accesses.
+// Mapping onto CDNA4: the env's working set (body frames, spatial inertias, contact Jacobian, Cholesky factor ...) lives
+// in LDS for the whole launch; nv-vectors are held one element per lane (lane i <-> dof i); the pyramid rows of contact c
+// sit in lanes 4c..4c+3 with their Jacobian row in registers, and frictionloss / joint-limit rows -- unit vectors -- are
+// scalars of their dof's lane (no Jacobian storage, no row lanes).  Mat-vec products are conflict-free LDS row / column
+// sweeps, reductions are DPP scans; H = M + J^T D J is accumulated one row per dof lane straight into the registers the
+// left-looking Cholesky works on, whose finished rows are published through LDS (one broadcast read per column step
+// instead of one v_readlane per element).  The persistent state is one contiguous 1.3 KB record per env, read and written
+// once per control step with lane-strided (coalesced) accesses.
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -40,8 +47,8 @@
 #define NQ 19
 #define NJ 14   // joints
 #define NG 32   // geoms
-#define NP 64   // collision candidate pairs (one per lane)
-// contacts kept per step (NC) and constraint rows (NE, one per lane) are per-task capacities: see LdsT
+#define NP 64   // collision candidate pairs (one per lane of the group: npair <= W is checked at create)
+// contacts kept per step (NC = W / 4) and contact rows (NE = 4 NC, one per lane) follow from the group width: see LdsT
 #define NU 12   // actuators
 #define HMINVAL 1e-15
 
@@ -179,6 +186,7 @@ struct HModel {
 struct HParams {
   int n_envs, frame_skip, max_traj_len, period, task;
   int env_first, env_count;             // sub-range of envs this launch advances (lhw_env_step_range); blockIdx.x is relative to it
+  int only_flagged;                     // 1: advance only the envs whose st.slow flag is set (re-run of fast-path overflows), clearing it
   int root_body, head_body, rfoot_body, lfoot_body;
   int env_params;                       // 1: damping / frictionloss / mass / ipos / xfrc come from the per-env record
   int dynrand_interval, perturb_interval, n_pbody, pbody[2];
@@ -198,9 +206,11 @@ struct HState {
   double* prm;     // [N][PRM_D] per-env model parameters (NULL unless the task randomises them)
   double* ter;     // [N][TER_D] stepping-task record (NULL for the other tasks)
   double* ep_stats;
+  unsigned char* slow;  // [N] set by the two-envs-per-wave kernel for an env that exceeded its contact capacity: nothing of that env
+                        // was written, and the one-env-per-wave kernel repeats its control step
   long long* prof; // optional [16] per-phase cycle counters accumulated by env 0 (NULL = off)
 };
-#define PROF_BEGIN() long long prof_t = (st_prof && lane == 0) ? (long long)clock64() : 0
+#define PROF_BEGIN() long long prof_t = (st_prof && lane == 0) ? (long long)clock64() : 0   // lane = lane within the group
 #define PROF_MARK(slot)                                                  \
   do {                                                                   \
     if (st_prof && lane == 0) {                                          \
@@ -216,73 +226,76 @@ struct HumanoidEnv {
   HState st;
   std::vector<void*> dev_allocs;
   int device;
+  bool fast;   // the model fits the two-envs-per-wave kernels (W = 32)
 };
 
 // ------------------------------------------------------------------------------------------------ LDS working set
-// Working set of one env.  Everything that is only live inside one stage of the sub-step shares the union region U:
-//   stage A  kinematics + collision : cinert(partial) xmat xipos xanchor xaxis xquat gpos gmat
-//   stage B  com / CRBA / RNE       : cinert crb cdofdot cvel cacc cfrc csub
-//   stage C  constraints + solve    : J, H (the efc row parameters sit in H until the reference acceleration is formed)
-// which keeps the block at ~19 KB so that 8 waves stay resident per CU.
-#define U_CINERT 0
-#define U_XMAT (U_CINERT + NB * 10)
-#define U_XIPOS (U_XMAT + NB * 9)
-#define U_XANCHOR (U_XIPOS + NB * 3)
-#define U_XAXIS (U_XANCHOR + NJ * 3)
-#define U_GPOS (U_XAXIS + NJ * 3)
-#define U_GMAT (U_GPOS + NG * 3)
-#define U_END_A (U_GMAT + NG * 9)
-#define U_CRB (U_CINERT + NB * 10)
-#define U_CDOFDOT (U_CRB + NB * 10)
-#define U_CVEL (U_CDOFDOT + NV * 6)
-#define U_CACC (U_CVEL + NB * 6)
-#define U_CFRC (U_CACC + NB * 6)
-#define U_CSUB (U_CFRC + NB * 6)
-#define U_END_B (U_CSUB + NB * 6)
-// stage C offsets depend on the row capacity of the task's LDS layout (template parameter L of every phase function)
-#define NE (L::NE_)
-#define NC (L::NC_)
-#define NV (L::NV_)    // dof width the kernel is compiled for (18 JVRC, 16 H1): sizes the Cholesky, the row products and the LDS matrices
-#define LDV (L::LDV_)  // padded row length of nv x nv matrices and of J (odd => conflict-free 64-bit column sweeps)
-#define U_J 0
-#define U_H (U_J + NE * LDV)
-#define U_EPOS (U_H)
-#define U_EMARGIN (U_EPOS + NE)
-#define U_EK (U_EMARGIN + NE)
-#define U_EB (U_EK + NE)
-#define U_EIMP (U_EB + NE)
+// Working set of ONE env (= one group of W lanes; a wave of the W = 32 kernels holds two of these).  Members that are
+// live across stages are plain fields; everything that is only live inside one stage of the sub-step shares the region U:
+//   cdof                              : com -> contact Jacobian
+//   cinert                            : kinematics (rotated inertia) -> RNE -> CRBA
+//   stage A  kinematics + collision   : xmat xipos xanchor xaxis gpos gmat            (over X)
+//   stage B1 velocity / RNE           : cdofdot cvel cacc=cfrc, subtree sums over cvel (over X)
+//   stage B2 CRBA                     : crb buf M                                     (over X; M goes to registers at once)
+//   stage C  constraints + solve      : J (over cinert and X), the published Cholesky rows L
+#define NE (L::NE_)      // contact rows = lanes of the group: rows 4c .. 4c+3 belong to contact c
+#define NC (L::NC_)      // contacts kept per sub-step
+#define NV (L::NV_)      // dof width the kernel is compiled for (18 JVRC, 16 H1): sizes the Cholesky, the row products, the LDS matrices
+#define LDV (L::LDV_)    // padded row length of M (odd => conflict-free 64-bit row loads)
+#define NGT (L::NG_)     // geom capacity of the task's layout
+#define U_CDOF (L::U_CDOF_)
+#define U_CINERT (L::U_CINERT_)
+#define U_XMAT (L::U_XMAT_)
+#define U_XIPOS (L::U_XIPOS_)
+#define U_XANCHOR (L::U_XANCHOR_)
+#define U_XAXIS (L::U_XAXIS_)
+#define U_GPOS (L::U_GPOS_)
+#define U_GMAT (L::U_GMAT_)
+#define U_CDOFDOT (L::U_CDOFDOT_)
+#define U_CVEL (L::U_CVEL_)
+#define U_CACC (L::U_CACC_)
+#define U_CFRC (L::U_CACC_)   // cfrc overwrites cacc body by body
+#define U_CSUB (L::U_CVEL_)   // subtree force sums overwrite cvel (the tracked velocities are copied out first)
+#define U_CRB (L::U_CRB_)
+#define U_BUF (L::U_BUF_)
+#define U_M (L::U_M_)
+#define U_J (L::U_J_)
+#define U_L (L::U_L_)
 constexpr int cmax(int a, int b) { return a > b ? a : b; }
 
-template <int NE_T, int NC_T, bool PRM_T, int NV_T>
+template <int W_T, bool PRM_T, int NV_T, int NG_T>
 struct LdsT {
   typedef LdsT L;
-  static constexpr int NE_ = NE_T, NC_ = NC_T, NV_ = NV_T, LDV_ = NV_T + 1;
+  static constexpr int W_ = W_T, NC_ = W_T / 4, NE_ = W_T, NV_ = NV_T, LDV_ = NV_T + 1, NG_ = NG_T;
   static constexpr bool PRM_ = PRM_T;   // per-env model parameters are staged in LDS (else read from the model tables)
-  // H slot: the nv x nv factor, or the five per-row parameter arrays parked there before the reference acceleration is formed
-  static constexpr int USIZE_ = cmax(cmax(U_END_A, U_END_B), NE_T * LDV + cmax(NV * LDV, 5 * NE_T));
-  double qpos[NQ], qvel[NV], ctrl[NU];
+  static constexpr int U_CDOF_ = 0, U_CINERT_ = U_CDOF_ + NV_T * 6, X_ = U_CINERT_ + NB * 10;
+  static constexpr int U_XMAT_ = X_, U_XIPOS_ = U_XMAT_ + NB * 9, U_XANCHOR_ = U_XIPOS_ + NB * 3, U_XAXIS_ = U_XANCHOR_ + NJ * 3,
+                       U_GPOS_ = U_XAXIS_ + NJ * 3, U_GMAT_ = U_GPOS_ + NG_T * 3, END_A_ = U_GMAT_ + NG_T * 9;
+  static constexpr int U_CDOFDOT_ = X_, U_CVEL_ = U_CDOFDOT_ + NV_T * 6, U_CACC_ = U_CVEL_ + NB * 6, END_B1_ = U_CACC_ + NB * 6;
+  static constexpr int U_CRB_ = X_, U_BUF_ = U_CRB_ + NB * 10, U_M_ = U_BUF_ + NV_T * 6, END_B2_ = U_M_ + NV_T * (NV_T + 1);
+  static constexpr int U_J_ = U_CINERT_, U_L_ = U_J_ + W_T * NV_T, END_C_ = U_L_ + NV_T * NV_T;   // J rows and L rows are NV long (16-byte aligned rows)
+  static constexpr int USIZE_ = cmax(cmax(END_A_, END_B1_), cmax(END_B2_, END_C_));
+  double qpos[NQ], qvel[NV_T], ctrl[NU];
   double xpos[NB * 3];
   double rootmat[9], com[4], svel[18];   // root xmat; tree com; cvel of the three tracked bodies (root, right foot, left foot)
   double spos[9], rootquat[4];           // world position of the tracked points (body origin + local offset); root xquat
-  double cdof[NV * 6];
-  double M[NV * LDV];
-  double vec[NV], vec2[NV], evec[NE_T], dact[NE_T];
-  double qacc[NV];
-  double efc_D[NE_T], efc_force[NE_T];
-  double con_dist[NC_T], con_pos[NC_T * 3], con_frame[NC_T * 9], con_mu[NC_T], con_solref[NC_T * 2], con_solimp[NC_T * 5], con_margin[NC_T];
-  int con_g1[NC_T], con_g2[NC_T], con_dim[NC_T], con_row[NC_T];
+  double vec[NV_T], vec2[NV_T], evec[W_T], dact[W_T], dg[NV_T];
+  double qacc[NV_T];
+  double efc_force[W_T];
+  double con_dist[NC_], con_pos[NC_ * 3], con_frame[NC_ * 9], con_mu[NC_], con_solref[NC_ * 2], con_solimp[NC_ * 5], con_margin[NC_];
+  int con_g1[NC_], con_g2[NC_], con_dim[NC_];
   double sq[NU], sv[NU], frc[NU];
   // per-env parameters, loaded once per launch (one-element stubs when the task reads the shared model tables instead)
-  double damp[PRM_T ? NV : 1], floss[PRM_T ? NV : 1], bmass[PRM_T ? NB : 1], bipos[PRM_T ? NB * 3 : 1], xfrc[PRM_T ? 12 : 1];
-  double U[USIZE_];
-  int ncon, nefc, nlim, overflow;
+  double damp[PRM_T ? NV_T : 1], floss[PRM_T ? NV_T : 1], bmass[PRM_T ? NB : 1], bipos[PRM_T ? NB * 3 : 1], xfrc[PRM_T ? 12 : 1];
+  alignas(16) double U[USIZE_];
+  int ncon, overflow;
 };
 
-// A workgroup is exactly one wavefront (every launch uses blockDim = 64), and a wave's LDS instructions execute in issue
-// order, so cross-lane hand-offs through LDS need no hardware barrier and no s_waitcnt: __syncthreads() would add a
-// workgroup-scope fence, i.e. s_waitcnt vmcnt(0) lgkmcnt(0) -- a full drain of outstanding global loads and scratch
-// (register-spill) stores -- ~60 times per sub-step.  A wavefront-scope fence pair plus the compiler-only wave barrier
-// keeps the compiler from moving LDS accesses across the hand-off and emits no instruction.
+// The lanes of a group belong to one wavefront, and a wave's LDS instructions execute in issue order, so cross-lane
+// hand-offs through LDS need no hardware barrier and no s_waitcnt: __syncthreads() would add a workgroup-scope fence, i.e.
+// s_waitcnt vmcnt(0) lgkmcnt(0) -- a full drain of outstanding global loads -- ~60 times per sub-step.  A wavefront-scope
+// fence pair plus the compiler-only wave barrier keeps the compiler from moving LDS accesses across the hand-off and emits
+// no instruction.
 #define SYNC()                                               \
   do {                                                       \
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  \
@@ -303,9 +316,10 @@ template <class L> __device__ __forceinline__ double prm_ipos(const HModel& m, c
 }
 
 // ------------------------------------------------------------------------------------------------ small math
-// Wavefront reductions on the DPP path (row_shr 1/2/4/8 inside each 16-lane row, then row_bcast 15/31 across rows:
-// an inclusive scan whose last lane holds the total) instead of ds_bpermute shuffles: ~20 VALU ops and no LDS
-// round trips per reduction.  gfx950 is GFX9-family, so row_bcast is available.
+// Group reductions on the DPP path (row_shr 1/2/4/8 inside each 16-lane row, then row_bcast 15 [and 31 for W = 64] across
+// rows: an inclusive scan whose last lane holds the total) instead of ds_bpermute shuffles: ~20 VALU ops and no LDS round
+// trips per reduction.  gfx950 is GFX9-family, so row_bcast is available.  With W = 32 the row_bcast:15 step (rows 1 and 3
+// only) completes the scan of both halves at once and the total sits in lane 31 / 63; nothing crosses the half boundary.
 template <int CTRL, int ROWMASK>
 __device__ __forceinline__ int dpp_i(int v, int ident) { return __builtin_amdgcn_update_dpp(ident, v, CTRL, ROWMASK, 0xf, false); }
 template <int CTRL, int ROWMASK>
@@ -314,33 +328,51 @@ __device__ __forceinline__ double dpp_d(double v, double ident) {
   int hi = dpp_i<CTRL, ROWMASK>(__double2hiint(v), __double2hiint(ident));
   return __hiloint2double(hi, lo);
 }
-__device__ __forceinline__ double bcast(double v, int src /* wave-uniform */) {
-  int lo = __builtin_amdgcn_readlane(__double2loint(v), src), hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
-  return __hiloint2double(hi, lo);
+// index of this lane's group inside the wavefront (0 for W = 64)
+template <int W> __device__ __forceinline__ int group_id() { return W == 64 ? 0 : (int)(threadIdx.x >> 5); }
+// value held by lane `src` (0 <= src < W, uniform) of the caller's group
+template <int W>
+__device__ __forceinline__ int gbcast_i(int v, int src) {
+  if constexpr (W == 64) return __builtin_amdgcn_readlane(v, src);
+  else {
+    const int a = __builtin_amdgcn_readlane(v, src), b = __builtin_amdgcn_readlane(v, src + 32);
+    return group_id<W>() ? b : a;
+  }
 }
-__device__ __forceinline__ double wave_sum(double v) {
+template <int W>
+__device__ __forceinline__ double gbcast(double v, int src) {
+  return __hiloint2double(gbcast_i<W>(__double2hiint(v), src), gbcast_i<W>(__double2loint(v), src));
+}
+template <int W>
+__device__ __forceinline__ double gsum(double v) {
   v += dpp_d<0x111, 0xf>(v, 0.0); v += dpp_d<0x112, 0xf>(v, 0.0); v += dpp_d<0x114, 0xf>(v, 0.0); v += dpp_d<0x118, 0xf>(v, 0.0);
-  v += dpp_d<0x142, 0xa>(v, 0.0); v += dpp_d<0x143, 0xc>(v, 0.0);
-  return bcast(v, 63);
+  v += dpp_d<0x142, 0xa>(v, 0.0);
+  if constexpr (W == 64) v += dpp_d<0x143, 0xc>(v, 0.0);
+  return gbcast<W>(v, W - 1);
 }
-__device__ __forceinline__ double wave_min(double v) {
+template <int W>
+__device__ __forceinline__ double gmin(double v) {
   const double inf = __longlong_as_double(0x7ff0000000000000ll);
   v = fmin(v, dpp_d<0x111, 0xf>(v, inf)); v = fmin(v, dpp_d<0x112, 0xf>(v, inf)); v = fmin(v, dpp_d<0x114, 0xf>(v, inf));
-  v = fmin(v, dpp_d<0x118, 0xf>(v, inf)); v = fmin(v, dpp_d<0x142, 0xa>(v, inf)); v = fmin(v, dpp_d<0x143, 0xc>(v, inf));
-  return bcast(v, 63);
+  v = fmin(v, dpp_d<0x118, 0xf>(v, inf)); v = fmin(v, dpp_d<0x142, 0xa>(v, inf));
+  if constexpr (W == 64) v = fmin(v, dpp_d<0x143, 0xc>(v, inf));
+  return gbcast<W>(v, W - 1);
 }
-// inclusive prefix sum across the wave; *total receives the wave total
-__device__ __forceinline__ int wave_scan(int v, int* total) {
+// inclusive prefix sum across the group; *total receives the group total
+template <int W>
+__device__ __forceinline__ int gscan(int v, int* total) {
   v += dpp_i<0x111, 0xf>(v, 0); v += dpp_i<0x112, 0xf>(v, 0); v += dpp_i<0x114, 0xf>(v, 0); v += dpp_i<0x118, 0xf>(v, 0);
-  v += dpp_i<0x142, 0xa>(v, 0); v += dpp_i<0x143, 0xc>(v, 0);
-  *total = __builtin_amdgcn_readlane(v, 63);
+  v += dpp_i<0x142, 0xa>(v, 0);
+  if constexpr (W == 64) v += dpp_i<0x143, 0xc>(v, 0);
+  *total = gbcast_i<W>(v, W - 1);
   return v;
 }
-__device__ __forceinline__ int wave_max_i(int v) {
-  const int lo = -2147483647 - 1;
-  v = max(v, dpp_i<0x111, 0xf>(v, lo)); v = max(v, dpp_i<0x112, 0xf>(v, lo)); v = max(v, dpp_i<0x114, 0xf>(v, lo));
-  v = max(v, dpp_i<0x118, 0xf>(v, lo)); v = max(v, dpp_i<0x142, 0xa>(v, lo)); v = max(v, dpp_i<0x143, 0xc>(v, lo));
-  return __builtin_amdgcn_readlane(v, 63);
+// does the predicate hold for any (active) lane of the caller's group
+template <int W>
+__device__ __forceinline__ bool gany(bool pred) {
+  const unsigned long long b = __ballot(pred);
+  if constexpr (W == 64) return b != 0;
+  else return ((b >> (32 * group_id<W>())) & 0xffffffffull) != 0;
 }
 __device__ __forceinline__ double dot3(const double* a, const double* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
 __device__ __forceinline__ void cross3(double* r, const double* a, const double* b) {
@@ -404,95 +436,80 @@ __device__ __forceinline__ void inert_vec(double* r, const double* i, const doub
   r[5] = i[7] * v[0] - i[6] * v[1] + i[9] * v[5];
 }
 
-// ------------------------------------------------------------------------------------------------ dense SPD solve, wave-parallel
-// x <- A^-1 x for the SPD matrix whose lower triangle is in LDS (n x n, leading dimension LDV); lane i owns row i and
-// element i of x.  Left-looking Cholesky with row i held in lane i's registers: column step j needs row j of L, which is
-// read back from LDS with j independent broadcast loads (one latency exposure per step instead of one per product).
-// The loops are fully unrolled over the compile-time bound NV so the row stays in VGPRs.  A is overwritten by L.
-// Operand broadcast of the factorisation.  Measured alternative (LHW_CHOL_SWIZZLE=1): ds_swizzle (bit mode: and_mask 0,
-// or_mask J) moves the ~300 broadcasts per factorisation from the VALU to the LDS crossbar, but its latency is exposed in
-// the column chain: 9.5 k -> 12 k cycles per solve, 3.48 -> 3.6 ms per control step.  v_readlane + SGPR operand stays.
-#ifndef LHW_CHOL_SWIZZLE
-#define LHW_CHOL_SWIZZLE 0
-#endif
-template <int J>
-__device__ __forceinline__ double bcast_col(double v) {
-#if LHW_CHOL_SWIZZLE
-  return __hiloint2double(__builtin_amdgcn_ds_swizzle(__double2hiint(v), J << 5), __builtin_amdgcn_ds_swizzle(__double2loint(v), J << 5));
-#else
-  return bcast(v, J);
-#endif
-}
-// column J of the left-looking factorisation (rows in registers), then the next one
+// ------------------------------------------------------------------------------------------------ dense SPD solve, group-parallel
+// x <- A^-1 x.  Lane i of the group holds the off-diagonal part of row i of the SPD matrix in registers (r[0..NV); the
+// diagonal entry of r is ignored) and element i of x; the diagonal is published in LDS (dg) by the caller-supplied scalar
+// `diag`.  Left-looking Cholesky: column step J needs row J of L, which lane J has published in the LDS array Lb
+// (row-major NV x NV, 16-byte aligned rows) during the previous steps: every lane fetches it with broadcast reads and
+// computes its own L[i][J] and -- redundantly, from the published diagonal -- the pivot, so nothing has to be broadcast
+// out of a register inside the column chain (one v_readlane pair per element in the first version of this kernel), and
+// the same published rows serve the transposed access of the backward substitution.  Lanes >= NV shadow row NV-1.
+// The loops are fully unrolled over the compile-time bound NV so the row stays in VGPRs.
 template <class L, int J>
-__device__ __forceinline__ void chol_col(double (&r)[NV], double (&invd)[NV], int lane) {
+__device__ __forceinline__ void chol_col(double (&r)[NV], double (&invd)[NV], double& myinvd, double* Lb, const double* dg, int lane) {
   if constexpr (J < L::NV_) {
-    double s0 = r[J], s1 = 0.0;
+    double s0 = r[J], s1 = 0.0, p0 = dg[J], p1 = 0.0;
 #pragma unroll
     for (int p = 0; p + 1 < J; p += 2) {
-      s0 -= r[p] * bcast_col<J>(r[p]);
-      s1 -= r[p + 1] * bcast_col<J>(r[p + 1]);
+      const double2 ab = *reinterpret_cast<const double2*>(&Lb[J * NV + p]);
+      s0 -= r[p] * ab.x; p0 -= ab.x * ab.x;
+      s1 -= r[p + 1] * ab.y; p1 -= ab.y * ab.y;
     }
-    if (J & 1) s0 -= r[J - 1] * bcast_col<J>(r[J - 1]);
-    const double s = s0 + s1;
-    const double piv = fmax(bcast(s, J), HMINVAL);
+    if (J & 1) { const double a = Lb[J * NV + J - 1]; s0 -= r[J - 1] * a; p0 -= a * a; }
+    const double piv = fmax(p0 + p1, HMINVAL);
     double id = __builtin_amdgcn_rsq(piv);
     id = id * (1.5 - 0.5 * piv * id * id);
     id = id * (1.5 - 0.5 * piv * id * id);
     invd[J] = id;
-    r[J] = (lane == J) ? piv * id : s * id;
-    chol_col<L, J + 1>(r, invd, lane);
+    const double lij = (lane == J) ? piv * id : (s0 + s1) * id;
+    r[J] = lij;
+    if (lane == J) myinvd = id;
+    if (lane < NV) Lb[lane * NV + J] = lij;   // lanes < J publish don't-care values into the upper triangle, which nothing reads
+    SYNC();
+    chol_col<L, J + 1>(r, invd, myinvd, Lb, dg, lane);
   }
 }
 
 template <class L>
-__device__ double chol_solve_inplace(double* A, int n, int lane, double x) {
-  // The matrix is treated as NV x NV: rows/columns >= n hold the identity (callers keep that padding in LDS), so the
-  // whole routine is straight-line code without exec-mask juggling.  Lanes >= NV shadow row NV-1 and are ignored.
-  (void)n;
-  double r[NV];
-  const int i = lane < NV ? lane : NV - 1;
-#pragma unroll
-  for (int p = 0; p < NV; p++) r[p] = A[i * LDV + p];
-  double invd[NV];
-  chol_col<L, 0>(r, invd, lane);
-  // forward substitution L y = x : column sweep, l_ij from registers (lanes < j keep their value)
+__device__ __forceinline__ double chol_solve(double (&r)[NV], double diag, double* Lb, double* dg, int lane, double x) {
+  constexpr int W = L::W_;
+  SYNC();
+  if (lane < NV) dg[lane] = diag;
+  SYNC();
+  double invd[NV], myinvd = 1.0;
+  chol_col<L, 0>(r, invd, myinvd, Lb, dg, lane);
+  // forward substitution L y = x as a column sweep: x_i -= L[i][j] y_j for i > j, with y_j = x_j / L[j][j] read from lane j
 #pragma unroll
   for (int j = 0; j < NV; j++) {
-    const double yj = bcast(x, j) * invd[j];
-    x = (lane == j) ? yj : ((lane > j) ? x - r[j] * yj : x);
+    const double c = (lane > j) ? r[j] * invd[j] : 0.0;
+    x -= c * gbcast<W>(x, j);
   }
-  // backward substitution L^T z = y needs column `lane` of L: one transposing pass through LDS (full rows, no predicates;
-  // the upper triangle receives don't-care values that nothing reads)
-  SYNC();
-  if (lane < NV) {
-#pragma unroll
-    for (int p = 0; p < NV; p++) A[lane * LDV + p] = r[p];
-  }
-  SYNC();
+  x *= myinvd;
+  // backward substitution L^T z = y needs column `lane` of L: the published rows, read transposed
+  const int cl = lane < NV ? lane : NV - 1;
   double col[NV];
 #pragma unroll
-  for (int j = 0; j < NV; j++) col[j] = A[j * LDV + i];
+  for (int j = 0; j < NV; j++) col[j] = Lb[j * NV + cl];
 #pragma unroll
   for (int j = NV - 1; j >= 0; j--) {
-    const double xj = bcast(x, j) * invd[j];
-    x = (lane == j) ? xj : ((lane < j) ? x - col[j] * xj : x);
+    const double c = (lane < j) ? col[j] * invd[j] : 0.0;
+    x -= c * gbcast<W>(x, j);
   }
-  return x;
+  return x * myinvd;
 }
 
 // y_lane = sum_k row[k] * v[k] with the row in registers and v broadcast from LDS
 template <class L>
-__device__ __forceinline__ double row_dot(const double* row, const double* v, int n) {
+__device__ __forceinline__ double row_dot(const double (&row)[NV], const double* v) {
   double a0 = 0, a1 = 0;
 #pragma unroll
   for (int k = 0; k < NV; k += 2) {
-    if (k < n) a0 += row[k] * v[k];
-    if (k + 1 < n) a1 += row[k + 1] * v[k + 1];
+    a0 += row[k] * v[k];
+    a1 += row[k + 1] * v[k + 1];
   }
   return a0 + a1;
 }
-
+// ------------------------------------------------------------------------------------------------ forward dynamics phases
 // ------------------------------------------------------------------------------------------------ forward dynamics phases
 // mj_kinematics with rotation matrices: each lane precombines its body's local transform R_loc = R_body * R_joint(q)
 // (off the serial chain), so a tree level costs one 3x3 product and four matrix-vector products.
@@ -606,7 +623,7 @@ __device__ double fwd_com(const HModel& m, const HParams& p, L& S, int lane) {
     ms = prm_mass(m, S, lane);
     mx = ms * S.U[U_XIPOS + 3 * lane]; my = ms * S.U[U_XIPOS + 3 * lane + 1]; mz = ms * S.U[U_XIPOS + 3 * lane + 2];
   }
-  ms = wave_sum(ms); mx = wave_sum(mx); my = wave_sum(my); mz = wave_sum(mz);
+  ms = gsum<L::W_>(ms); mx = gsum<L::W_>(mx); my = gsum<L::W_>(my); mz = gsum<L::W_>(mz);
   const double com[3] = {mx / ms, my / ms, mz / ms};
   if (lane == 0) { S.com[0] = com[0]; S.com[1] = com[1]; S.com[2] = com[2]; }
   if (lane >= 1 && lane < m.nbody) {
@@ -642,7 +659,7 @@ __device__ double fwd_com(const HModel& m, const HParams& p, L& S, int lane) {
       c[0] = ax[0]; c[1] = ax[1]; c[2] = ax[2];
       cross3(c + 3, ax, off);
     }
-    for (int a = 0; a < 6; a++) S.cdof[6 * d + a] = c[a];
+    for (int a = 0; a < 6; a++) S.U[U_CDOF + 6 * d + a] = c[a];
   }
   SYNC();
   // mj_xfrcAccumulate: Cartesian force / torque applied at the com of the perturbed bodies -> joint space
@@ -653,9 +670,9 @@ __device__ double fwd_com(const HModel& m, const HParams& p, L& S, int lane) {
       if (!(((unsigned)m.body_i[BIS * pb + BI_DOFMASK] >> lane) & 1u)) continue;
       double off[3], t[3];
       for (int a = 0; a < 3; a++) off[a] = S.U[U_XIPOS + 3 * pb + a] - com[a];
-      cross3(t, &S.cdof[6 * lane], off);
+      cross3(t, &S.U[U_CDOF + 6 * lane], off);
       for (int a = 0; a < 3; a++)
-        qapp += (S.cdof[6 * lane + 3 + a] + t[a]) * S.xfrc[6 * k + a] + S.cdof[6 * lane + a] * S.xfrc[6 * k + 3 + a];
+        qapp += (S.U[U_CDOF + 6 * lane + 3 + a] + t[a]) * S.xfrc[6 * k + a] + S.U[U_CDOF + 6 * lane + a] * S.xfrc[6 * k + 3 + a];
     }
   }
   return qapp;
@@ -664,35 +681,103 @@ __device__ double fwd_com(const HModel& m, const HParams& p, L& S, int lane) {
 // composite inertias + joint-space inertia M (mj_crb); lower triangle + mirrored upper
 template <class L>
 __device__ void fwd_crb(const HModel& m, L& S, int lane) {
-  for (int it = lane; it < m.nbody * 10; it += 64) {
+  for (int it = lane; it < m.nbody * 10; it += L::W_) {
     const int b = it / 10, k = it - 10 * b;
     double s = 0;
     if (b >= 1) for (int d = b; d < m.body_i[BIS * (b) + BI_SUBEND]; d++) s += S.U[U_CINERT + 10 * d + k];
     S.U[U_CRB + it] = s;
   }
-  for (int it = lane; it < NV * LDV; it += 64) {
-    const int i = it / LDV, j = it - i * LDV;
-    S.M[it] = (i == j && i >= NV) ? 1.0 : 0.0;
+  for (int it = lane; it < NV * LDV; it += L::W_) {
+    S.U[U_M + it] = 0.0;
   }
   SYNC();
-  // vec scratch: buf_i = crb[body(i)] * cdof_i  kept in csub (6 per dof)
+  // buf_i = crb[body(i)] * cdof_i (6 per dof)
   if (lane < NV) {
     double buf[6];
-    inert_vec(buf, &S.U[U_CRB + 10 * m.dof_i[DIS * (lane) + DI_BODY]], &S.cdof[6 * lane]);
-    for (int a = 0; a < 6; a++) S.U[U_CSUB + 6 * lane + a] = buf[a];
+    inert_vec(buf, &S.U[U_CRB + 10 * m.dof_i[DIS * (lane) + DI_BODY]], &S.U[U_CDOF + 6 * lane]);
+    for (int a = 0; a < 6; a++) S.U[U_BUF + 6 * lane + a] = buf[a];
   }
   SYNC();
-  for (int it = lane; it < m.nmpair; it += 64) {
+  for (int it = lane; it < m.nmpair; it += L::W_) {
     const int i = m.mpair[2 * (it) + 0], j = m.mpair[2 * (it) + 1];
     double s = 0;
-    for (int a = 0; a < 6; a++) s += S.cdof[6 * j + a] * S.U[U_CSUB + 6 * i + a];
+    for (int a = 0; a < 6; a++) s += S.U[U_CDOF + 6 * j + a] * S.U[U_BUF + 6 * i + a];
     if (i == j) s += m.dof_d[DDS * (i) + DD_ARMATURE];
-    S.M[i * LDV + j] = s;
-    S.M[j * LDV + i] = s;
+    S.U[U_M + i * LDV + j] = s;
+    S.U[U_M + j * LDV + i] = s;
   }
   SYNC();
 }
 
+// mj_fwdVelocity: cvel, cdof_dot, bias force (RNE, no acceleration), passive damping, constraint reference
+template <class L>
+__device__ double fwd_velocity(const HModel& m, L& S, int lane) {
+  // velocity seen by dof j when its cdof_dot is formed: sum over dof_prevmask[j]
+  if (lane < NV) {
+    const int j = lane;
+    unsigned mask = (unsigned)m.dof_i[DIS * (j) + DI_PREVMASK];
+    double v[6] = {0, 0, 0, 0, 0, 0};
+    const bool zero = mask == 0xFFFFFFFFu;  // translational dofs of a free joint: cdof_dot = 0
+    if (!zero)
+      while (mask) {
+        const int k = __ffs(mask) - 1;
+        mask &= mask - 1;
+        const double qv = S.qvel[k];
+        for (int a = 0; a < 6; a++) v[a] += S.U[U_CDOF + 6 * k + a] * qv;
+      }
+    double a3[3], b3[3], c3[3];
+    const double* cd = &S.U[U_CDOF + 6 * j];
+    cross3(a3, v, cd); cross3(b3, v, cd + 3); cross3(c3, v + 3, cd);
+    for (int a = 0; a < 3; a++) {
+      S.U[U_CDOFDOT + 6 * j + a] = zero ? 0.0 : a3[a];
+      S.U[U_CDOFDOT + 6 * j + 3 + a] = zero ? 0.0 : b3[a] + c3[a];
+    }
+  }
+  SYNC();
+  for (int it = lane; it < m.nbody * 6; it += L::W_) {
+    const int b = it / 6, a = it - 6 * b;
+    unsigned mask = (unsigned)m.body_i[BIS * (b) + BI_DOFMASK];
+    double cv = 0, ca = (a >= 3) ? -m.gravity[a - 3] : 0.0;
+    while (mask) {
+      const int k = __ffs(mask) - 1;
+      mask &= mask - 1;
+      const double qv = S.qvel[k];
+      cv += S.U[U_CDOF + 6 * k + a] * qv;
+      ca += S.U[U_CDOFDOT + 6 * k + a] * qv;
+    }
+    S.U[U_CVEL + it] = cv;
+    S.U[U_CACC + it] = ca;
+  }
+  SYNC();
+  if (lane >= 1 && lane < m.nbody) {
+    const int b = lane;
+    double t[6], t2[6], f[6];
+    inert_vec(t, &S.U[U_CINERT + 10 * b], &S.U[U_CACC + 6 * b]);
+    inert_vec(t2, &S.U[U_CINERT + 10 * b], &S.U[U_CVEL + 6 * b]);
+    const double* v = &S.U[U_CVEL + 6 * b];
+    double a3[3], b3[3], c3[3];
+    cross3(a3, v, t2); cross3(b3, v + 3, t2 + 3); cross3(c3, v, t2 + 3);
+    for (int a = 0; a < 3; a++) { f[a] = a3[a] + b3[a] + t[a]; f[3 + a] = c3[a] + t[3 + a]; }
+    for (int a = 0; a < 6; a++) S.U[U_CFRC + 6 * b + a] = f[a];
+  }
+  if (lane == 0) for (int a = 0; a < 6; a++) S.U[U_CFRC + a] = 0;
+  if (lane < 18) S.svel[lane] = S.U[U_CVEL + 6 * m.track_body[lane / 6] + lane % 6];
+  SYNC();
+  for (int it = lane; it < m.nbody * 6; it += L::W_) {   // subtree sums (they overwrite cvel, which is dead now)
+    const int b = it / 6, a = it - 6 * b;
+    double s = 0;
+    if (b >= 1) for (int d = b; d < m.body_i[BIS * (b) + BI_SUBEND]; d++) s += S.U[U_CFRC + 6 * d + a];
+    S.U[U_CSUB + it] = s;
+  }
+  SYNC();
+  double bias = 0;
+  if (lane < NV) {
+    const int b = m.dof_i[DIS * (lane) + DI_BODY];
+    for (int a = 0; a < 6; a++) bias += S.U[U_CDOF + 6 * lane + a] * S.U[U_CSUB + 6 * b + a];
+  }
+  SYNC();
+  return bias;
+}
 // ---- collision (engine_collision_primitive.c restated).  Two passes over the same narrow phase: pass 0 counts the
 // contacts of each candidate pair (lane = pair), a wave scan gives every pair its slot range in pair order, pass 1
 // recomputes and writes straight into the LDS contact arrays (no per-lane contact records in scratch).
@@ -1041,7 +1126,6 @@ __device__ void fwd_collision(const HModel& m, const HParams& p, L& S, int lane,
     for (int k = 0; k < 3; k++) S.U[U_GPOS + 3 * g + k] = wp[k];
     for (int k = 0; k < 9; k++) S.U[U_GMAT + 9 * g + k] = R[k];
   }
-  if (lane == 0) { S.overflow = 0; }
   SYNC();
   int g1 = 0, g2 = 0;
   double margin = 0;
@@ -1063,12 +1147,12 @@ __device__ void fwd_collision(const HModel& m, const HParams& p, L& S, int lane,
   if constexpr (BOXBOX) boxpair = have && m.geom_i[GIS * g1 + GI_TYPE] == G_BOX && m.geom_i[GIS * g2 + GI_TYPE] == G_BOX;
   if (have && !boxpair) collide_pair(k, m, S, g1, g2, margin);
   if constexpr (BOXBOX) {
-    if (__any(boxpair)) {
+    if (gany<L::W_>(boxpair)) {
       if (boxpair) { col_box_box(br, m, S, g1, g2, margin); k.n = br.cnt; }
     }
   }
   int total;
-  const int base = wave_scan(k.n, &total) - k.n;
+  const int base = gscan<L::W_>(k.n, &total) - k.n;
   k.base = base; k.n = 0; k.write = 1;
   if (have && !boxpair && base < NC) collide_pair(k, m, S, g1, g2, margin);
   if constexpr (BOXBOX) {
@@ -1077,7 +1161,7 @@ __device__ void fwd_collision(const HModel& m, const HParams& p, L& S, int lane,
       for (int q = 0; q < br.cnt; q++) k.emit(br.dist[q], &br.pos[3 * q], br.n, zero);
     }
   }
-  if (lane == 0) { S.ncon = min(total, NC); if (total > NC) S.overflow = 1; }
+  if (lane == 0) { S.ncon = min(total, NC); if (total > NC) S.overflow = 1; }   // sticky for the whole control step
   SYNC();
   // mj_contactParam (lane = contact): priority, else solmix-weighted mix; friction = max; condim = max
   if (lane < S.ncon) {
@@ -1147,179 +1231,6 @@ __device__ __forceinline__ void row_params(const HModel& m, const double* sr_in,
     *B = -sr1 / fmax(HMINVAL, s1);
   }
 }
-
-// mj_makeConstraint: joint-limit rows, then contact rows (pyramidal), with mj_makeImpedance's shared pyramid R
-template <class L>
-__device__ void fwd_constraints(const HModel& m, L& S, int lane) {
-  // ---- frictionloss rows: lane = dof (mj_instantiateFriction); they come first
-  const double myfl = lane < NV ? prm_floss(m, S, lane) : 0.0;
-  int nfr;
-  const int fbase = wave_scan(myfl > 0 ? 1 : 0, &nfr) - (myfl > 0 ? 1 : 0);
-  // ---- limits: lane = joint; rows ordered by joint, lower side first
-  int nl = 0, lo = 0, hi = 0;
-  double dlo = 0, dhi = 0;
-  if (lane < m.njnt && m.jnt_i[JIS * (lane) + JI_LIMITED] && (m.jnt_i[JIS * (lane) + JI_TYPE] == JT_HINGE || m.jnt_i[JIS * (lane) + JI_TYPE] == JT_SLIDE)) {
-    const double q = S.qpos[m.jnt_i[JIS * (lane) + JI_QADR]], mg = m.jnt_d[JDS * (lane) + JD_MARGIN];
-    dlo = q - m.jnt_d[JDS * (lane) + JD_RANGE]; dhi = m.jnt_d[JDS * (lane) + JD_RANGE + 1] - q;
-    lo = dlo < mg; hi = dhi < mg;
-    nl = lo + hi;
-  }
-  int nlim;
-  const int lbase = nfr + wave_scan(nl, &nlim) - nl;
-  nlim += nfr;  // rows that precede the contact rows
-  // ---- contacts: lane = contact; rows = 4 (condim 3), 1 (condim 1) or 0 (excluded)
-  int nr = 0;
-  if (lane < S.ncon) nr = S.con_dim[lane] == 3 ? 4 : (S.con_dim[lane] == 1 ? 1 : 0);
-  int crows;
-  const int cbase = nlim + wave_scan(nr, &crows) - nr;
-  int rend = nlim;
-  if (lane < S.ncon) {
-    const bool fits = nr > 0 && cbase + nr <= NE;
-    if (nr > 0 && !fits) S.overflow = 1;  // contacts whose rows do not fit are dropped (counted in ep_stats[3])
-    S.con_row[lane] = fits ? cbase : -1;
-    if (fits) rend = cbase + nr;
-  }
-  const int nefc = wave_max_i(rend);
-  for (int it = lane; it < nefc * LDV; it += 64) S.U[U_J + it] = 0;
-  if (lane < NE) S.dact[lane] = 0;   // frictionloss of each row is parked in dact until the Newton loop starts writing it
-  SYNC();
-  if (myfl > 0 && fbase < NE) {
-    const int d = lane, r = fbase;
-    double sr[2] = {m.dof_d[DDS * d + DD_SOLREF], m.dof_d[DDS * d + DD_SOLREF + 1]}, si[5], K, B, imp, R;
-    for (int a = 0; a < 5; a++) si[a] = m.dof_d[DDS * d + DD_SOLIMP + a];
-    row_params(m, sr, si, 0.0, 0.0, m.dof_d[DDS * d + DD_INVW], &K, &B, &imp, &R);
-    S.U[U_J + r * LDV + d] = 1.0;
-    S.U[U_EPOS + r] = 0; S.U[U_EMARGIN + r] = 0; S.efc_D[r] = 1 / R; S.U[U_EK + r] = K; S.U[U_EB + r] = B; S.U[U_EIMP + r] = imp;
-    S.dact[r] = myfl;
-  }
-  if (nl > 0) {
-    const int j = lane, d = m.jnt_i[JIS * (j) + JI_DADR];
-    int r = lbase;
-    double sr[2] = {m.jnt_d[JDS * (j) + JD_SOLREF], m.jnt_d[JDS * (j) + JD_SOLREF + 1]}, si[5];
-    for (int a = 0; a < 5; a++) si[a] = m.jnt_d[JDS * (j) + JD_SOLIMP + a];
-    for (int side = 0; side < 2; side++) {
-      if (!(side == 0 ? lo : hi) || r >= NE) continue;
-      const double dist = side == 0 ? dlo : dhi, mg = m.jnt_d[JDS * (j) + JD_MARGIN];
-      double K, B, imp, R;
-      row_params(m, sr, si, dist, mg, m.dof_d[DDS * (d) + DD_INVW], &K, &B, &imp, &R);
-      S.U[U_J + r * LDV + d] = side == 0 ? 1.0 : -1.0;
-      S.U[U_EPOS + r] = dist; S.U[U_EMARGIN + r] = mg; S.efc_D[r] = 1 / R; S.U[U_EK + r] = K; S.U[U_EB + r] = B; S.U[U_EIMP + r] = imp;
-      r++;
-    }
-  }
-  // contact Jacobians: item = (contact, dof)
-  const int ncon = S.ncon;
-  for (int it = lane; it < ncon * NV; it += 64) {
-    const int c = it / NV, k = it - c * NV, r0 = S.con_row[c];
-    if (r0 < 0) continue;
-    const int b1 = m.geom_i[GIS * (S.con_g1[c]) + GI_BODY], b2 = m.geom_i[GIS * (S.con_g2[c]) + GI_BODY];
-    const unsigned bit = 1u << k;
-    const bool in1 = ((unsigned)m.body_i[BIS * (b1) + BI_DOFMASK] & bit) != 0, in2 = ((unsigned)m.body_i[BIS * (b2) + BI_DOFMASK] & bit) != 0;
-    double d[3] = {0, 0, 0};
-    if (in1 != in2) {
-      double off[3], t[3];
-      for (int a = 0; a < 3; a++) off[a] = S.con_pos[3 * c + a] - S.com[a];
-      cross3(t, &S.cdof[6 * k], off);
-      const double sg = in2 ? 1.0 : -1.0;
-      for (int a = 0; a < 3; a++) d[a] = sg * (S.cdof[6 * k + 3 + a] + t[a]);
-    }
-    const double* f = &S.con_frame[9 * c];
-    const double jn = dot3(f, d);
-    if (S.con_dim[c] == 1) { S.U[U_J + r0 * LDV + k] = jn; continue; }
-    const double mu = S.con_mu[c], t1 = mu * dot3(f + 3, d), t2 = mu * dot3(f + 6, d);
-    S.U[U_J + (r0 + 0) * LDV + k] = jn + t1;
-    S.U[U_J + (r0 + 1) * LDV + k] = jn - t1;
-    S.U[U_J + (r0 + 2) * LDV + k] = jn + t2;
-    S.U[U_J + (r0 + 3) * LDV + k] = jn - t2;
-  }
-  // contact row parameters: item = (contact, edge)
-  for (int it = lane; it < ncon * 4; it += 64) {
-    const int c = it >> 2, e = it & 3, r0 = S.con_row[c];
-    if (r0 < 0 || (S.con_dim[c] == 1 && e > 0)) continue;
-    const int b1 = m.geom_i[GIS * (S.con_g1[c]) + GI_BODY], b2 = m.geom_i[GIS * (S.con_g2[c]) + GI_BODY];
-    const double tran = m.body_d[BDS * (b1) + BD_INVW] + m.body_d[BDS * (b2) + BD_INVW];
-    const double mu = S.con_mu[c];
-    double K, B, imp, R;
-    const double diag = S.con_dim[c] == 1 ? tran : tran + mu * mu * tran;
-    row_params(m, &S.con_solref[2 * c], &S.con_solimp[5 * c], S.con_dist[c], S.con_margin[c], diag, &K, &B, &imp, &R);
-    if (S.con_dim[c] == 3) R = fmax(HMINVAL, 2 * mu * mu * R);  // every pyramid edge shares 2 mu^2 R(first edge)
-    const int r = r0 + e;
-    S.U[U_EPOS + r] = S.con_dist[c]; S.U[U_EMARGIN + r] = S.con_margin[c]; S.efc_D[r] = 1 / R; S.U[U_EK + r] = K; S.U[U_EB + r] = B; S.U[U_EIMP + r] = imp;
-  }
-  if (lane == 0) { S.nefc = nefc; S.nlim = nlim; }
-  SYNC();
-}
-
-// mj_fwdVelocity: cvel, cdof_dot, bias force (RNE, no acceleration), passive damping, constraint reference
-template <class L>
-__device__ double fwd_velocity(const HModel& m, L& S, int lane) {
-  // velocity seen by dof j when its cdof_dot is formed: sum over dof_prevmask[j]
-  if (lane < NV) {
-    const int j = lane;
-    unsigned mask = (unsigned)m.dof_i[DIS * (j) + DI_PREVMASK];
-    double v[6] = {0, 0, 0, 0, 0, 0};
-    const bool zero = mask == 0xFFFFFFFFu;  // translational dofs of a free joint: cdof_dot = 0
-    if (!zero)
-      while (mask) {
-        const int k = __ffs(mask) - 1;
-        mask &= mask - 1;
-        const double qv = S.qvel[k];
-        for (int a = 0; a < 6; a++) v[a] += S.cdof[6 * k + a] * qv;
-      }
-    double a3[3], b3[3], c3[3];
-    const double* cd = &S.cdof[6 * j];
-    cross3(a3, v, cd); cross3(b3, v, cd + 3); cross3(c3, v + 3, cd);
-    for (int a = 0; a < 3; a++) {
-      S.U[U_CDOFDOT + 6 * j + a] = zero ? 0.0 : a3[a];
-      S.U[U_CDOFDOT + 6 * j + 3 + a] = zero ? 0.0 : b3[a] + c3[a];
-    }
-  }
-  SYNC();
-  for (int it = lane; it < m.nbody * 6; it += 64) {
-    const int b = it / 6, a = it - 6 * b;
-    unsigned mask = (unsigned)m.body_i[BIS * (b) + BI_DOFMASK];
-    double cv = 0, ca = (a >= 3) ? -m.gravity[a - 3] : 0.0;
-    while (mask) {
-      const int k = __ffs(mask) - 1;
-      mask &= mask - 1;
-      const double qv = S.qvel[k];
-      cv += S.cdof[6 * k + a] * qv;
-      ca += S.U[U_CDOFDOT + 6 * k + a] * qv;
-    }
-    S.U[U_CVEL + it] = cv;
-    S.U[U_CACC + it] = ca;
-  }
-  SYNC();
-  if (lane >= 1 && lane < m.nbody) {
-    const int b = lane;
-    double t[6], t2[6], f[6];
-    inert_vec(t, &S.U[U_CINERT + 10 * b], &S.U[U_CACC + 6 * b]);
-    inert_vec(t2, &S.U[U_CINERT + 10 * b], &S.U[U_CVEL + 6 * b]);
-    const double* v = &S.U[U_CVEL + 6 * b];
-    double a3[3], b3[3], c3[3];
-    cross3(a3, v, t2); cross3(b3, v + 3, t2 + 3); cross3(c3, v, t2 + 3);
-    for (int a = 0; a < 3; a++) { f[a] = a3[a] + b3[a] + t[a]; f[3 + a] = c3[a] + t[3 + a]; }
-    for (int a = 0; a < 6; a++) S.U[U_CFRC + 6 * b + a] = f[a];
-  }
-  if (lane == 0) for (int a = 0; a < 6; a++) S.U[U_CFRC + a] = 0;
-  SYNC();
-  for (int it = lane; it < m.nbody * 6; it += 64) {
-    const int b = it / 6, a = it - 6 * b;
-    double s = 0;
-    if (b >= 1) for (int d = b; d < m.body_i[BIS * (b) + BI_SUBEND]; d++) s += S.U[U_CFRC + 6 * d + a];
-    S.U[U_CSUB + it] = s;
-  }
-  if (lane < 18) S.svel[lane] = S.U[U_CVEL + 6 * m.track_body[lane / 6] + lane % 6];
-  SYNC();
-  double bias = 0;
-  if (lane < NV) {
-    const int b = m.dof_i[DIS * (lane) + DI_BODY];
-    for (int a = 0; a < 6; a++) bias += S.cdof[6 * lane + a] * S.U[U_CSUB + 6 * b + a];
-  }
-  SYNC();
-  return bias;
-}
-
 // mj_constraintUpdate for one row at residual x = J a - aref: limit / contact rows are one-sided quadratics, frictionloss
 // rows (fl > 0) are Huber: quadratic for |x| < R fl, linear beyond with |force| = fl.
 __device__ __forceinline__ void row_eval(bool valid, double fl, double D, double x, double* cost, double* force, double* dact) {
@@ -1350,26 +1261,116 @@ __device__ __forceinline__ void row_deriv(bool valid, double fl, double D, doubl
 
 // One mj_forward (+ Euler).  flags: bit0 actuation enabled, bit1 integrate.
 // On return S.qacc / S.efc_force / contacts / S.sq,sv,frc describe THIS forward pass (the "stale" fields of note S).
+//
+// Constraint rows.  MuJoCo orders them frictionloss dofs, joint limits, contacts.  Here the pyramid rows of contact c are
+// rows (= lanes) 4c .. 4c+3 with their Jacobian row in registers and in LDS, and the frictionloss / limit rows -- whose
+// Jacobians are +-unit vectors -- are three scalars slots of their dof's lane (0 frictionloss, 1 lower limit, 2 upper limit):
+// J x is the lane's own element, J^T f lands on the lane's own dof, J^T D J on its own diagonal entry.  Only the summation
+// order differs from the row order of the reference; every row is there.
 template <bool BOXBOX, class L>
 __device__ __forceinline__ void substep(const HModel& m, const HParams& p, L& S, int lane, int flags, double* warm /* lane-held */, long long* st_prof,
                                         const double* ter) {
+  constexpr int W = L::W_;
   PROF_BEGIN();
   fwd_kinematics<BOXBOX>(m, S, lane);
   PROF_MARK(0);
-  fwd_collision<BOXBOX>(m, p, S, lane, ter);   // stage A temporaries (geom frames) die here
+  fwd_collision<BOXBOX>(m, p, S, lane, ter);   // stage A temporaries (geom frames) die with fwd_com
   PROF_MARK(3);
   const double qapp = fwd_com(m, p, S, lane);
   PROF_MARK(1);
-  fwd_crb(m, S, lane);
-  PROF_MARK(2);
-  const double bias = fwd_velocity(m, S, lane);  // stage B temporaries die here
+  const double bias = fwd_velocity(m, S, lane);
   PROF_MARK(5);
-  fwd_constraints(m, S, lane);  // stage C: J over the dead stage-B region, row parameters in the H slot
+  fwd_crb(m, S, lane);
+  // row `lane` of M (lane = dof) stays in registers for every product of the solve; its LDS slot dies here
+  const int ld = lane < NV ? lane : NV - 1;
+  double Mrow[NV];
+#pragma unroll
+  for (int k = 0; k < NV; k++) Mrow[k] = S.U[U_M + ld * LDV + k];
+  const double mdiag = S.U[U_M + ld * LDV + ld];
+  SYNC();
+  PROF_MARK(2);
+  // ---- contact Jacobian, item = (contact, dof): rows 4c .. 4c+3 = Jn +- mu Jt1, Jn +- mu Jt2 (condim 1: row 4c = Jn)
+  const int ncon = S.ncon, nrow = 4 * ncon;
+  for (int it = lane; it < ncon * NV; it += W) {
+    const int c = it / NV, k = it - c * NV;
+    const int b1 = m.geom_i[GIS * (S.con_g1[c]) + GI_BODY], b2 = m.geom_i[GIS * (S.con_g2[c]) + GI_BODY];
+    const unsigned bit = 1u << k;
+    const bool in1 = ((unsigned)m.body_i[BIS * (b1) + BI_DOFMASK] & bit) != 0, in2 = ((unsigned)m.body_i[BIS * (b2) + BI_DOFMASK] & bit) != 0;
+    double d[3] = {0, 0, 0};
+    if (in1 != in2) {
+      double off[3], t[3];
+      for (int a = 0; a < 3; a++) off[a] = S.con_pos[3 * c + a] - S.com[a];
+      cross3(t, &S.U[U_CDOF + 6 * k], off);
+      const double sg = in2 ? 1.0 : -1.0;
+      for (int a = 0; a < 3; a++) d[a] = sg * (S.U[U_CDOF + 6 * k + 3 + a] + t[a]);
+    }
+    const double* f = &S.con_frame[9 * c];
+    const double jn = dot3(f, d);
+    const bool pyr = S.con_dim[c] != 1;
+    const double mu = S.con_mu[c], t1 = mu * dot3(f + 3, d), t2 = mu * dot3(f + 6, d);
+    double* Jc = &S.U[U_J + 4 * c * NV + k];
+    Jc[0] = pyr ? jn + t1 : jn;
+    Jc[NV] = pyr ? jn - t1 : 0.0;
+    Jc[2 * NV] = pyr ? jn + t2 : 0.0;
+    Jc[3 * NV] = pyr ? jn - t2 : 0.0;
+  }
+  SYNC();
+  // ---- contact rows (lane = row): Jacobian row -> registers, impedance / regulariser / reference acceleration
+  double Jrow[NV];
+  bool isrow = false;
+  double D = 0, aref = 0;
+  {
+    const bool have = lane < nrow;
+#pragma unroll
+    for (int k = 0; k < NV; k++) { const double v = S.U[U_J + lane * NV + k]; Jrow[k] = have ? v : 0.0; }
+    const int c = have ? (lane >> 2) : 0, e = lane & 3, dim = S.con_dim[c];
+    isrow = have && (dim == 3 || (dim == 1 && e == 0));
+    const double jv0 = row_dot<L>(Jrow, S.qvel);
+    if (isrow) {
+      const int b1 = m.geom_i[GIS * (S.con_g1[c]) + GI_BODY], b2 = m.geom_i[GIS * (S.con_g2[c]) + GI_BODY];
+      const double tran = m.body_d[BDS * (b1) + BD_INVW] + m.body_d[BDS * (b2) + BD_INVW];
+      const double mu = S.con_mu[c];
+      double K, B, imp, R;
+      const double diag = dim == 1 ? tran : tran + mu * mu * tran;
+      row_params(m, &S.con_solref[2 * c], &S.con_solimp[5 * c], S.con_dist[c], S.con_margin[c], diag, &K, &B, &imp, &R);
+      if (dim == 3) R = fmax(HMINVAL, 2 * mu * mu * R);  // every pyramid edge shares 2 mu^2 R(first edge)
+      D = 1 / R;
+      aref = -B * jv0 - K * imp * (S.con_dist[c] - S.con_margin[c]);
+    }
+  }
+  // ---- unit rows of dof `lane`: slot 0 frictionloss (Huber), 1 lower limit (J = +1), 2 upper limit (J = -1)
+  bool uon[3] = {false, false, false};
+  double uD[3] = {0, 0, 0}, uaref[3] = {0, 0, 0}, ufl = 0;
+  const double qv = lane < NV ? S.qvel[lane] : 0.0;
+  if (lane < NV) {
+    const int d = lane;
+    const double fl = prm_floss(m, S, d);
+    if (fl > 0) {
+      double sr[2] = {m.dof_d[DDS * d + DD_SOLREF], m.dof_d[DDS * d + DD_SOLREF + 1]}, si[5], K, B, imp, R;
+      for (int a = 0; a < 5; a++) si[a] = m.dof_d[DDS * d + DD_SOLIMP + a];
+      row_params(m, sr, si, 0.0, 0.0, m.dof_d[DDS * d + DD_INVW], &K, &B, &imp, &R);
+      uon[0] = true; uD[0] = 1 / R; uaref[0] = -B * qv; ufl = fl;
+    }
+    const int j = m.dof_i[DIS * d + DI_JNT];
+    if (m.dof_i[DIS * d + DI_KIND] >= 2 && m.jnt_i[JIS * j + JI_LIMITED]) {
+      const double q = S.qpos[m.jnt_i[JIS * j + JI_QADR]], mg = m.jnt_d[JDS * j + JD_MARGIN];
+      const double dlo = q - m.jnt_d[JDS * j + JD_RANGE], dhi = m.jnt_d[JDS * j + JD_RANGE + 1] - q;
+      if (dlo < mg || dhi < mg) {
+        double sr[2] = {m.jnt_d[JDS * j + JD_SOLREF], m.jnt_d[JDS * j + JD_SOLREF + 1]}, si[5], K, B, imp, R;
+        for (int a = 0; a < 5; a++) si[a] = m.jnt_d[JDS * j + JD_SOLIMP + a];
+        if (dlo < mg) {
+          row_params(m, sr, si, dlo, mg, m.dof_d[DDS * d + DD_INVW], &K, &B, &imp, &R);
+          uon[1] = true; uD[1] = 1 / R; uaref[1] = -B * qv - K * imp * (dlo - mg);
+        }
+        if (dhi < mg) {
+          row_params(m, sr, si, dhi, mg, m.dof_d[DDS * d + DD_INVW], &K, &B, &imp, &R);
+          uon[2] = true; uD[2] = 1 / R; uaref[2] = B * qv - K * imp * (dhi - mg);
+        }
+      }
+    }
+  }
+  const bool anyrow = gany<W>(isrow || uon[0] || uon[1] || uon[2]);
   PROF_MARK(4);
-  // the kernels are compiled for the dof count of their robot (humanoid_create checks m.nv == NV), so every `k < nv` below
-  // folds at compile time
-  constexpr int nv = NV;
-  const int nefc = S.nefc;
   // transmission + actuation (lane = actuator)
   if (lane < m.nu) {
     const int j = m.act_i[AIS * (lane) + AI_JNT];
@@ -1386,137 +1387,132 @@ __device__ __forceinline__ void substep(const HModel& m, const HParams& p, L& S,
     S.frc[lane] = f;
   }
   SYNC();
-  // qfrc_smooth (lane = dof) = passive - bias + actuator
-  double fs = 0, qv = 0;
-  if (lane < nv) {
-    qv = S.qvel[lane];
+  // qfrc_smooth (lane = dof) = passive - bias + actuator + applied
+  double fs = 0;
+  if (lane < NV) {
     double act = 0;
     const int u = m.dof_i[DIS * lane + DI_ACT];   // at most one actuator per dof (checked at create)
     if (u >= 0) act = m.dof_d[DDS * lane + DD_GEAR] * S.frc[u];
     fs = -prm_damp(m, S, lane) * qv - bias + act + qapp;
-    S.vec[lane] = qv;
   }
-  SYNC();
-  // rows of M (lane = dof) and J (lane = row) stay in registers for every product of the solve
-  double Mrow[NV], Jrow[NV];
-  {
-    const int im = lane < nv ? lane : 0, ij = lane < nefc ? lane : 0;
-#pragma unroll
-    for (int k = 0; k < NV; k++) {
-      Mrow[k] = (k < nv && lane < nv) ? S.M[im * LDV + k] : 0.0;
-      Jrow[k] = (k < nv && lane < nefc) ? S.U[U_J + ij * LDV + k] : 0.0;
-    }
-  }
-  // constraint reference: aref = -B (J qvel) - K imp (pos - margin)   (lane = row); consumes the row parameters
-  // parked in the H slot, which the factorisations below then overwrite
-  double aref = 0, D = 0, fl = 0;
-  const bool isrow = lane < nefc;
-  {
-    const double jv0 = row_dot<L>(Jrow, S.vec, nv);
-    if (isrow) {
-      aref = -S.U[U_EB + lane] * jv0 - S.U[U_EK + lane] * S.U[U_EIMP + lane] * (S.U[U_EPOS + lane] - S.U[U_EMARGIN + lane]);
-      D = S.efc_D[lane];
-      fl = S.dact[lane];
-    }
-  }
-  SYNC();
+  double* Lb = S.U + U_L;
   PROF_MARK(11);
-  // factor M (copy in H), qacc_smooth
-  for (int it = lane; it < NV * LDV; it += 64) S.U[U_H + it] = S.M[it];
-  SYNC();
-  const double as = chol_solve_inplace<L>(S.U + U_H, nv, lane, fs);
+  // qacc_smooth = M^-1 qfrc_smooth
+  double as;
+  {
+    double r[NV];
+#pragma unroll
+    for (int k = 0; k < NV; k++) r[k] = Mrow[k];
+    as = chol_solve<L>(r, mdiag, Lb, S.dg, lane, fs);
+  }
   PROF_MARK(12);
-
-  PROF_MARK(6);
   double qacc = as, fcon = 0;  // lane = dof
-  if (nefc > 0) {
+  if (anyrow) {
     // ------------------------------------------------------------ primal Newton (engine_solver.c)
-    const double scale = 1.0 / (m.meaninertia * (nv > 1 ? nv : 1));
+    // cost / force / active-D of this lane's rows at acceleration a (ja = J a of the contact row, a = own dof element)
+    auto eval_rows = [&](double ja, double a, double* cost, double* force, double* dactive, double* ufrc, double* udact) {
+      double c, f, da;
+      row_eval(isrow, 0.0, D, ja - aref, &c, force, dactive);
+      double cs = c, uf = 0, ud = 0;
+      row_eval(uon[0], ufl, uD[0], a - uaref[0], &c, &f, &da); cs += c; uf += f; ud += da;
+      row_eval(uon[1], 0.0, uD[1], a - uaref[1], &c, &f, &da); cs += c; uf += f; ud += da;
+      row_eval(uon[2], 0.0, uD[2], -a - uaref[2], &c, &f, &da); cs += c; uf -= f; ud += da;
+      *cost = cs; *ufrc = uf; *udact = ud;
+    };
+    const double scale = 1.0 / (m.meaninertia * (NV > 1 ? NV : 1));
     // warm start: cheaper of qacc_warmstart and qacc_smooth
     if (!(m.disableflags & (1 << 7))) {
       const double w = *warm;
-      if (lane < nv) { S.vec[lane] = w; S.vec2[lane] = as; }
       SYNC();
-      const double jar = row_dot<L>(Jrow, S.vec, nv) - aref, Ma = row_dot<L>(Mrow, S.vec, nv);
-      const double jas = row_dot<L>(Jrow, S.vec2, nv) - aref;
-      double cw, cs0, tf, td;
-      row_eval(isrow, fl, D, jar, &cw, &tf, &td);
-      row_eval(isrow, fl, D, jas, &cs0, &tf, &td);
-      if (lane < nv) cw += 0.5 * (Ma - fs) * (w - as);
-      cw = wave_sum(cw);
-      const double cs = wave_sum(cs0);
+      if (lane < NV) { S.vec[lane] = w; S.vec2[lane] = as; }
+      SYNC();
+      const double jw = row_dot<L>(Jrow, S.vec), Ma = row_dot<L>(Mrow, S.vec), js = row_dot<L>(Jrow, S.vec2);
+      double cw, cs0, tf, td, tu, tv;
+      eval_rows(jw, w, &cw, &tf, &td, &tu, &tv);
+      eval_rows(js, as, &cs0, &tf, &td, &tu, &tv);
+      if (lane < NV) cw += 0.5 * (Ma - fs) * (w - as);
+      cw = gsum<W>(cw);
+      const double cs = gsum<W>(cs0);
       qacc = (cw > cs) ? as : w;
-      SYNC();
     }
     double cost = 0, oldcost = 0;
     for (int iter = 0; iter <= m.iterations; iter++) {
-      if (lane < nv) S.vec[lane] = qacc;
       SYNC();
-      const double jar = row_dot<L>(Jrow, S.vec, nv) - aref, Ma = row_dot<L>(Mrow, S.vec, nv);
-      double c, force, dactive;
-      row_eval(isrow, fl, D, jar, &c, &force, &dactive);
-      if (lane < nv) c += 0.5 * (Ma - fs) * (qacc - as);
+      if (lane < NV) S.vec[lane] = qacc;
+      SYNC();
+      const double ja = row_dot<L>(Jrow, S.vec), Ma = row_dot<L>(Mrow, S.vec);
+      double c, force, dactive, ufrc, udact;
+      eval_rows(ja, qacc, &c, &force, &dactive, &ufrc, &udact);
+      if (lane < NV) c += 0.5 * (Ma - fs) * (qacc - as);
       oldcost = cost;
-      cost = wave_sum(c);
-      if (lane < NE) { S.evec[lane] = force; S.efc_force[lane] = force; S.dact[lane] = dactive; }
+      cost = gsum<W>(c);
+      S.evec[lane] = force; S.efc_force[lane] = force; S.dact[lane] = dactive;   // lane = contact row (NE == W)
       SYNC();
       double grad = 0;
       fcon = 0;
-      if (lane < nv) {
+      {
         double f0 = 0, f1 = 0, f2 = 0, f3 = 0;
-        int r = 0;
-        for (; r + 3 < nefc; r += 4) {
-          f0 += S.U[U_J + r * LDV + lane] * S.evec[r];
-          f1 += S.U[U_J + (r + 1) * LDV + lane] * S.evec[r + 1];
-          f2 += S.U[U_J + (r + 2) * LDV + lane] * S.evec[r + 2];
-          f3 += S.U[U_J + (r + 3) * LDV + lane] * S.evec[r + 3];
+        for (int r = 0; r < nrow; r += 4) {   // whole contacts: nrow is a multiple of 4
+          f0 += S.U[U_J + r * NV + ld] * S.evec[r];
+          f1 += S.U[U_J + (r + 1) * NV + ld] * S.evec[r + 1];
+          f2 += S.U[U_J + (r + 2) * NV + ld] * S.evec[r + 2];
+          f3 += S.U[U_J + (r + 3) * NV + ld] * S.evec[r + 3];
         }
-        for (; r < nefc; r++) f0 += S.U[U_J + r * LDV + lane] * S.evec[r];
-        fcon = (f0 + f1) + (f2 + f3);
-        grad = Ma - fs - fcon;
+        if (lane < NV) {
+          fcon = ((f0 + f1) + (f2 + f3)) + ufrc;
+          grad = Ma - fs - fcon;
+        }
       }
-      const double gn = sqrt(wave_sum(grad * grad));
+      const double gn = sqrt(gsum<W>(grad * grad));
       if (iter > 0) { if (scale * (oldcost - cost) < m.tolerance || scale * gn < m.tolerance) break; }
       else if (scale * gn < m.tolerance) break;
       if (iter == m.iterations) break;
-      // H = M + J^T D_active J  (lower triangle; lanes sweep the packed triangle)
-      for (int e = lane; e < nv * (nv + 1) / 2; e += 64) {
-        int i = (int)((sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
-        while ((i + 1) * (i + 2) / 2 <= e) i++;
-        while (i * (i + 1) / 2 > e) i--;
-        const int j = e - i * (i + 1) / 2;
-        double h0 = S.M[i * LDV + j], h1 = 0;
-        int r = 0;
-        for (; r + 1 < nefc; r += 2) {
-          h0 += S.dact[r] * S.U[U_J + r * LDV + i] * S.U[U_J + r * LDV + j];
-          h1 += S.dact[r + 1] * S.U[U_J + (r + 1) * LDV + i] * S.U[U_J + (r + 1) * LDV + j];
+      // H = M + J^T D_active J, row `lane` (lane = dof) accumulated in the registers the factorisation works on; the diagonal
+      // entry travels separately (hd)
+      double Hrow[NV], hd = mdiag + udact;
+#pragma unroll
+      for (int k = 0; k < NV; k++) Hrow[k] = Mrow[k];
+      for (int r = 0; r < nrow; r++) {
+        const double jl = S.U[U_J + r * NV + ld], cj = S.dact[r] * jl;
+        hd += cj * jl;
+#pragma unroll
+        for (int k = 0; k < NV; k += 2) {
+          const double2 ab = *reinterpret_cast<const double2*>(&S.U[U_J + r * NV + k]);
+          Hrow[k] += cj * ab.x;
+          Hrow[k + 1] += cj * ab.y;
         }
-        if (r < nefc) h0 += S.dact[r] * S.U[U_J + r * LDV + i] * S.U[U_J + r * LDV + j];
-        S.U[U_H + i * LDV + j] = h0 + h1;
       }
+      const double search = -chol_solve<L>(Hrow, hd, Lb, S.dg, lane, grad);
+      if (lane < NV) S.vec2[lane] = search;
       SYNC();
-      const double search = -chol_solve_inplace<L>(S.U + U_H, nv, lane, grad);
-      if (lane < nv) S.vec2[lane] = search;
-      SYNC();
-      const double jv = row_dot<L>(Jrow, S.vec2, nv), Mv = row_dot<L>(Mrow, S.vec2, nv);
-      const double qg1 = wave_sum(lane < nv ? search * (Ma - fs) : 0.0);
-      const double qg2 = wave_sum(lane < nv ? 0.5 * search * Mv : 0.0);
+      const double jv = row_dot<L>(Jrow, S.vec2), Mv = row_dot<L>(Mrow, S.vec2);
+      const double qg1 = gsum<W>(lane < NV ? search * (Ma - fs) : 0.0);
+      const double qg2 = gsum<W>(lane < NV ? 0.5 * search * Mv : 0.0);
       // exact line search on the convex piecewise-quadratic: safeguarded Newton on its derivative
+      const double x0 = ja - aref, xu0 = qacc - uaref[0], xu1 = qacc - uaref[1], xu2 = -qacc - uaref[2];
+      auto deriv_rows = [&](double a, double* d1, double* d2) {
+        double r1, r2, s1, s2;
+        row_deriv(isrow, 0.0, D, x0 + a * jv, jv, &r1, &r2);
+        row_deriv(uon[0], ufl, uD[0], xu0 + a * search, search, &s1, &s2); r1 += s1; r2 += s2;
+        row_deriv(uon[1], 0.0, uD[1], xu1 + a * search, search, &s1, &s2); r1 += s1; r2 += s2;
+        row_deriv(uon[2], 0.0, uD[2], xu2 - a * search, -search, &s1, &s2); r1 += s1; r2 += s2;
+        *d1 = r1; *d2 = r2;
+      };
       double alpha = 0;
       {
         double r1, r2;
-        row_deriv(isrow, fl, D, jar, jv, &r1, &r2);
-        double d1 = wave_sum(r1) + qg1;
-        double d2 = wave_sum(r2) + 2 * qg2;
+        deriv_rows(0.0, &r1, &r2);
+        double d1 = gsum<W>(r1) + qg1;
+        double d2 = gsum<W>(r2) + 2 * qg2;
         if (!(d1 >= 0 || d2 <= 0)) {
           const double d0 = fabs(d1);
           double lo = 0, hi = -1;
           for (int it = 0; it < 40; it++) {
             double a = alpha - d1 / d2;
             if (hi >= 0 && (a <= lo || a >= hi)) a = 0.5 * (lo + hi);
-            row_deriv(isrow, fl, D, jar + a * jv, jv, &r1, &r2);
-            d1 = wave_sum(r1) + 2 * a * qg2 + qg1;
-            d2 = wave_sum(r2) + 2 * qg2;
+            deriv_rows(a, &r1, &r2);
+            d1 = gsum<W>(r1) + 2 * a * qg2 + qg1;
+            d2 = gsum<W>(r2) + 2 * qg2;
             if (d1 < 0) lo = a; else hi = a;
             alpha = a;
             if (fabs(d1) <= 1e-14 * d0) break;
@@ -1526,12 +1522,12 @@ __device__ __forceinline__ void substep(const HModel& m, const HParams& p, L& S,
       }
       if (alpha == 0) break;
       qacc += alpha * search;
-      SYNC();
     }
-  } else if (lane < NE) {
+  } else {
     S.efc_force[lane] = 0;
   }
-  if (lane < nv) S.qacc[lane] = qacc;
+  SYNC();
+  if (lane < NV) S.qacc[lane] = qacc;
   *warm = qacc;  // mj_fwdConstraint: next warm start
   SYNC();
   PROF_MARK(7);
@@ -1541,14 +1537,14 @@ __device__ __forceinline__ void substep(const HModel& m, const HParams& p, L& S,
   const double h = m.timestep;
   const bool eulerdamp = !(m.disableflags & (1 << 14));
   if (eulerdamp) {
-    for (int it = lane; it < NV * LDV; it += 64) S.U[U_H + it] = S.M[it];
-    SYNC();
-    if (lane < nv) S.U[U_H + lane * LDV + lane] += h * prm_damp(m, S, lane);
-    SYNC();
-    anew = chol_solve_inplace<L>(S.U + U_H, nv, lane, fs + fcon);
+    double r[NV];
+#pragma unroll
+    for (int k = 0; k < NV; k++) r[k] = Mrow[k];
+    const double dm = lane < NV ? prm_damp(m, S, lane) : 0.0;
+    anew = chol_solve<L>(r, mdiag + h * dm, Lb, S.dg, lane, fs + fcon);
   }
   PROF_MARK(13);
-  if (lane < nv) S.qvel[lane] = qv + h * anew;
+  if (lane < NV) S.qvel[lane] = qv + h * anew;
   SYNC();
   if (lane < m.njnt) {
     const int j = lane, qa = m.jnt_i[JIS * (j) + JI_QADR], da = m.jnt_i[JIS * (j) + JI_DADR];
@@ -1568,7 +1564,6 @@ __device__ __forceinline__ void substep(const HModel& m, const HParams& p, L& S,
   SYNC();
   PROF_MARK(8);
 }
-
 // ------------------------------------------------------------------------------------------------ task layer
 __device__ __forceinline__ void sample_ref(const HParams& p, unsigned genv, unsigned stream, unsigned counter, unsigned slot0,
                                            int mode, double* ref) {
@@ -1641,20 +1636,20 @@ __device__ __forceinline__ void write_obs_walk_ext(const HParams& p, int lane, i
 template <class L>
 __device__ void write_obs_h1(const HModel& m, const HParams& p, L& S, int lane, unsigned genv, unsigned obs_count, float* o,
                              float* o2) {
-  if (lane < 35) {
+  for (int e = lane; e < 35; e += L::W_) {   // e = observation entry (35 > 32: the two-envs-per-wave groups take two passes)
     double v;
-    if (lane < 2) {
+    if (e < 2) {
       double r, pt;
       quat_roll_pitch(&S.qpos[3], &r, &pt);
-      v = lane == 0 ? r : pt;
-    } else if (lane < 5) v = S.qvel[3 + (lane - 2)];
-    else if (lane < 15) v = S.sq[lane - 5];
-    else if (lane < 25) v = S.sv[lane - 15];
-    else v = S.frc[lane - 25] * m.act_d[ADS * (lane - 25) + AD_GEAR];
-    const double sc = p.obs_noise[lane];
-    if (sc > 0) v += lhw_rng_uniform(p.seed, genv, LHW_STREAM_OBS, obs_count, lane, -sc, sc);
-    if (o) o[lane] = (float)v;
-    if (o2) o2[lane] = (float)v;
+      v = e == 0 ? r : pt;
+    } else if (e < 5) v = S.qvel[3 + (e - 2)];
+    else if (e < 15) v = S.sq[e - 5];
+    else if (e < 25) v = S.sv[e - 15];
+    else v = S.frc[e - 25] * m.act_d[ADS * (e - 25) + AD_GEAR];
+    const double sc = p.obs_noise[e];
+    if (sc > 0) v += lhw_rng_uniform(p.seed, genv, LHW_STREAM_OBS, obs_count, e, -sc, sc);
+    if (o) o[e] = (float)v;
+    if (o2) o2[e] = (float)v;
   }
 }
 
@@ -1692,17 +1687,22 @@ __device__ __forceinline__ void body_linvel(const L& S, int slot /* 0 root, 1 ri
   lin[0] = cv[3] - t[0]; lin[1] = cv[4] - t[1]; lin[2] = cv[5] - t[2];
 }
 
-template <int MODE, int TASK>  // MODE: 0 step, 1 reset(mask), 2 set_state, 3 get_state; TASK: TASK_WALK / TASK_STAND / TASK_STEP / TASK_H1WALK
+template <int MODE, int TASK, int W>  // MODE: 0 step, 1 reset(mask), 2 set_state, 3 get_state; TASK: TASK_WALK / TASK_STAND / TASK_STEP / TASK_H1WALK; W: lanes per env
 __global__ void __launch_bounds__(64, 2) humanoid_kernel(HModel m, HParams p, HState st, const float* __restrict__ act,
                                                       float* __restrict__ obs, float* __restrict__ term_obs,
                                                       float* __restrict__ rew, unsigned char* __restrict__ done_out,
                                                       float* __restrict__ rew_terms, const unsigned char* __restrict__ mask,
                                                       double* __restrict__ xq, double* __restrict__ xv) {
-  using L = LdsT<(TASK == TASK_STEP ? 64 : 48), (TASK == TASK_STEP ? 16 : 12), TASK != TASK_STEP,
-                 ((TASK == TASK_STAND || TASK == TASK_H1WALK) ? 16 : 18)>;
-  __shared__ L S;
-  const int env = blockIdx.x + p.env_first, lane = threadIdx.x;
+  using L = LdsT<W, TASK != TASK_STEP, ((TASK == TASK_STAND || TASK == TASK_H1WALK) ? 16 : 18), (TASK == TASK_STEP ? 32 : 16)>;
+  constexpr int G = 64 / W;   // envs per wavefront
+  __shared__ L SG[G];
+  L& S = SG[group_id<W>()];
+  const int lane = threadIdx.x & (W - 1);   // lane within the env's group: every `lane` below is group-relative
+  const int eidx = blockIdx.x * G + group_id<W>();
+  if (eidx >= p.env_count) return;
+  const int env = eidx + p.env_first;
   if (MODE == 1 && mask && !mask[env]) return;
+  if (MODE == 0 && p.only_flagged && !st.slow[env]) return;
   double* rec = st.rec + (size_t)env * REC_D;
   double* prm = st.prm ? st.prm + (size_t)env * PRM_D : nullptr;
   double* ter = (TASK == TASK_STEP) ? st.ter + (size_t)env * TER_D : nullptr;
@@ -1749,410 +1749,440 @@ __global__ void __launch_bounds__(64, 2) humanoid_kernel(HModel m, HParams p, HS
     if (lane < 12) S.xfrc[lane] = prm ? prm[P_XFRC + lane] : 0.0;
   }
   SYNC();
+  if (lane == 0) S.overflow = 0;
+  SYNC();
 
-  bool do_reset = MODE == 1;
+  // One loop, one sub-step call site.  Each env walks through its stages -- the frame_skip control sub-steps, then (if
+  // the episode ended) the reset's forward pass and three settle steps -- and the two envs of a wave share every
+  // sub-step they both still need; an env that is done simply leaves the loop (SIMT divergence at group granularity).
+  enum { ST_CONTROL = 0, ST_RESET, ST_SETTLE, ST_FORWARD, ST_LAST, ST_END };
+  int stage = MODE == 0 ? ST_CONTROL : (MODE == 1 ? ST_RESET : ST_FORWARD), kstep = 0;
+  bool committed = false;   // outputs / episode statistics of this control step have been written
   if (MODE == 2) {
     if (lane < m.nq) S.qpos[lane] = xq[(size_t)env * m.nq + lane];
     if (lane < NV) S.qvel[lane] = xv[(size_t)env * NV + lane];
     SYNC();
-    substep<TASK == TASK_STEP>(m, p, S, lane, 0, &warm, sprof, ter);  // set_state: mj_forward with actuation disabled
   }
-  if (MODE == 0) {
-    // ---- BaseHumanoidEnv.step: smoothing, offsets (base_humanoid_env.py:209-215); RobotBase.step (robot_base.py:64-98)
-    double target = 0, a_raw = 0;
-    if (lane < m.nu) {
-      a_raw = (double)act[(size_t)env * m.nu + lane];
-      target = p.action_smoothing * a_raw + (1 - p.action_smoothing) * prevpred + p.action_offset[lane];
-      if (!started) { prevact = target; prevtq = S.frc[lane] * m.act_d[ADS * (lane) + AD_GEAR]; }
-    }
-    for (int k = 0; k < p.frame_skip; k++) {
-      if (lane < m.nu) {
-        // step_pd on the transmission fields of the previous forward pass (note S); ctrl = tau / gear
-        const double tau = p.kp[lane] * (target - S.sq[lane]) + p.kd[lane] * (0.0 - S.sv[lane]);
-        S.ctrl[lane] = tau / m.act_d[ADS * (lane) + AD_GEAR];
-      }
-      SYNC();
-      substep<TASK == TASK_STEP>(m, p, S, lane, 3, &warm, sprof, ter);
-    }
-    PROF_MARK(9);  // control-step prologue (load, PD) is folded into slot 9 with the sub-step loop overheads
-    double r_sum = 0, terms[10], cur_tq = 0;
-    bool terminated = false;
-    if (lane < m.nu) cur_tq = S.frc[lane] * m.act_d[ADS * (lane) + AD_GEAR];
-    // self-collision scan of the contacts of the last forward pass (robot_interface.py:472-484)
-    bool self_collision;
-    {
-      int selfcol = 0;
-      if (lane < S.ncon) {
-        const int b1 = m.geom_i[GIS * (S.con_g1[lane]) + GI_BODY], b2 = m.geom_i[GIS * (S.con_g2[lane]) + GI_BODY];
-        selfcol = (m.body_i[BIS * (b1) + BI_ROOT] == p.root_body && m.body_i[BIS * (b2) + BI_ROOT] == p.root_body) ? 1 : 0;
-      }
-      self_collision = __any(selfcol);
-    }
-    // ground reaction forces and lowest foot-floor contact point (robot_interface.py:269-325): lane = contact
-    double grf_r = 0, grf_l = 0, cz = 1e300;
-    if (TASK != TASK_STAND) {
-      int anyfoot = 0;
-      if (lane < S.ncon) {
-        const int c = lane, b1 = m.geom_i[GIS * (S.con_g1[c]) + GI_BODY], b2 = m.geom_i[GIS * (S.con_g2[c]) + GI_BODY];
-        const bool floor1 = m.body_i[BIS * (b1) + BI_ROOT] != p.root_body;
-        double fn = 0;
-        const int r0 = S.con_row[c];
-        if (r0 >= 0) {
-          if (S.con_dim[c] == 3) {
-            const double f0 = S.efc_force[r0], f1 = S.efc_force[r0 + 1], f2 = S.efc_force[r0 + 2], f3 = S.efc_force[r0 + 3], mu = S.con_mu[c];
-            const double n = f0 + f1 + f2 + f3, t1f = mu * (f0 - f1), t2f = mu * (f2 - f3);
-            fn = sqrt(n * n + t1f * t1f + t2f * t2f);
-          } else fn = fabs(S.efc_force[r0]);
-        }
-        if (floor1 && b2 == p.rfoot_body) { grf_r = fn; cz = S.con_pos[3 * c + 2]; anyfoot = 1; }
-        if (floor1 && b2 == p.lfoot_body) { grf_l = fn; cz = S.con_pos[3 * c + 2]; anyfoot = 1; }
-      }
-      grf_r = wave_sum(grf_r); grf_l = wave_sum(grf_l); cz = wave_min(cz);
-      if (!__any(anyfoot)) cz = 0;
-    }
-    if (WALKT) {
-    // ---- WalkingTask.step (walking_task.py:149-170)
-    phase += 1;
-    if (phase >= p.period) phase = 0;
-    {
-      const bool dbl = p.clock_lut[0 * p.period + phase] == 1.0 && p.clock_lut[2 * p.period + phase] == 1.0;
-      if (lhw_rng_randint(p.seed, genv, LHW_STREAM_STEP, step_count, WS + 0, 100) == 0 && dbl) {
-        if (mode == MODE_INPLACE) mode = MODE_STANDING;
-        else if (mode == MODE_STANDING) mode = MODE_INPLACE;
-        sample_ref(p, genv, LHW_STREAM_STEP, step_count, WS + 1, mode, mode_ref);
-      }
-      if (lhw_rng_randint(p.seed, genv, LHW_STREAM_STEP, step_count, WS + 4, 200) == 0 && mode != MODE_STANDING) {
-        if (mode == MODE_FORWARD) mode = MODE_INPLACE;
-        else if (mode == MODE_INPLACE) mode = MODE_FORWARD;
-        sample_ref(p, genv, LHW_STREAM_STEP, step_count, WS + 5, mode, mode_ref);
-      }
-      if (!H1R) step_count++;   // h1_walk: the counter advances after the post-observation randomisation draws below
-    }
-    // ---- calc_reward (walking_task.py:85-147) on the fields of the last forward pass
-    // joint-space sums: lane = actuator / dof
-    double s_posture = 0, s_tq = 0, s_act = 0, s_rootacc = 0;
-    if (lane < m.nu) {
-      const double dq = p.neutral_pose[lane] - S.sq[lane];
-      s_posture = dq * dq;
-      s_tq = fabs(prevtq - cur_tq);
-      s_act = fabs(prevact - target);
-    }
-    if (lane >= 3 && lane < 6) s_rootacc = fabs(S.qvel[lane]);
-    if (lane < 3) s_rootacc = fabs(S.qacc[lane]);
-    s_posture = wave_sum(s_posture); s_tq = wave_sum(s_tq); s_act = wave_sum(s_act); s_rootacc = wave_sum(s_rootacc);
-    {
-      double lv[3], rv[3], rl[3], vloc[3];
-      body_linvel(S, 2, p.lfoot_body, lv); body_linvel(S, 1, p.rfoot_body, rv); body_linvel(S, 0, p.root_body, rl);
-      matT_vec(vloc, S.rootmat, rl);
-      double rf = p.clock_lut[0 * p.period + phase], rvc = p.clock_lut[1 * p.period + phase];
-      double lf = p.clock_lut[2 * p.period + phase], lvc = p.clock_lut[3 * p.period + phase];
-      if (mode == MODE_STANDING) { rf = 1; lf = 1; rvc = -1; lvc = -1; }
-      double yaw_ref = mode_ref[0], vx = mode_ref[1], vy = mode_ref[2];
-      if (mode == MODE_STANDING) { yaw_ref = 0; vx = 0; vy = 0; }
-      else if (mode == MODE_INPLACE) { vx = 0; vy = 0; }
-      else yaw_ref = 0;
-      const double gs = sqrt(vx * vx + vy * vy);
-      const double PI4 = 3.141592653589793 / 4;
-      const double maxf = m.totalmass * 9.8 * 0.5;
-      const double nl = fmin(grf_l, maxf) / maxf * 2 - 1, nr = fmin(grf_r, maxf) / maxf * 2 - 1;
-      terms[0] = 0.225 * ((tan(PI4 * lf * nl) + tan(PI4 * rf * nr)) / 2);
-      const double nlv = fmin(sqrt(dot3(lv, lv)), 0.2) / 0.2 * 2 - 1, nrv = fmin(sqrt(dot3(rv, rv)), 0.2) / 0.2 * 2 - 1;
-      terms[1] = 0.225 * ((tan(PI4 * lvc * nlv) + tan(PI4 * rvc * nrv)) / 2);
-      terms[2] = 0.050 * exp(-0.25 * s_rootacc);
-      double herr = fabs(S.xpos[3 * p.root_body + 2] - cz - p.goal_height);
-      if (herr < 0.01 + 0.05 * gs) herr = 0;
-      terms[3] = 0.050 * exp(-40 * herr * herr);
-      const double ex = vloc[0] - vx, ey = vloc[1] - vy, en = sqrt(ex * ex + ey * ey);
-      terms[4] = 0.150 * exp(-10 * (en * en));
-      const double ye = fabs(S.qvel[5] - yaw_ref);
-      terms[5] = 0.150 * exp(-10 * (ye * ye * ye));
-      const double hx = S.xpos[3 * p.head_body] - S.xpos[3 * p.root_body], hy = S.xpos[3 * p.head_body + 1] - S.xpos[3 * p.root_body + 1];
-      terms[6] = 0.050 * exp(-10 * sqrt(hx * hx + hy * hy));
-      terms[7] = 0.050 * exp(-sqrt(s_posture));
-      terms[8] = 0.025 * exp(-0.25 * (s_tq / (double)m.nu));
-      terms[9] = 0.025 * exp(-5 * s_act / (double)m.nu);
-      for (int k = 0; k < 10; k++) r_sum += terms[k];  // python sum() over the dict, left to right
-    }
-      const double z = S.qpos[2];
-      terminated = z < 0.6 || z > 1.4 || self_collision;  // walking_task.py:184-192
-    } else if (TASK == TASK_STEP) {
-      // ---- SteppingTask.step (stepping_task.py:211-243) on the stale site / body frames
-      phase += 1;
-      if (phase >= p.period) phase = 0;
-      const double lp[3] = {S.spos[6], S.spos[7], S.spos[8]}, rp[3] = {S.spos[3], S.spos[4], S.spos[5]};
-      const double rootp[3] = {S.xpos[3 * p.root_body], S.xpos[3 * p.root_body + 1], S.xpos[3 * p.root_body + 2]};
-      {
-        const double* tg = ter + T_SEQ + 6 * t1;
-        const double dl = sqrt((lp[0] - tg[0]) * (lp[0] - tg[0]) + (lp[1] - tg[1]) * (lp[1] - tg[1]) + (lp[2] - tg[2]) * (lp[2] - tg[2]));
-        const double dr = sqrt((rp[0] - tg[0]) * (rp[0] - tg[0]) + (rp[1] - tg[1]) * (rp[1] - tg[1]) + (rp[2] - tg[2]) * (rp[2] - tg[2]));
-        if (dl < p.target_radius || dr < p.target_radius) { reached = 1; frames += 1; }
-        else { reached = 0; frames = 0; }
-        if (reached && frames >= p.delay_frames) {  // update_target_steps
-          t1 = t2; t2 += 1;
-          if (t2 == nseq) t2 = nseq - 1;
-          reached = 0; frames = 0;
-        }
-      }
-      // update_goal_steps (stepping_task.py:184-202): the two targets in the root frame
-      if (mode != WALK_STANDING) {
-        for (int i = 0; i < 2; i++) {
-          const double* sq = ter + T_SEQ + 6 * (i ? t2 : t1);
-          const double dvec[3] = {sq[0] - rootp[0], sq[1] - rootp[1], sq[2] - rootp[2]};
-          double rel[3];
-          matT_vec(rel, S.rootmat, dvec);
-          const double M00 = S.rootmat[0] * sq[4] + S.rootmat[3] * sq[5], M10 = S.rootmat[1] * sq[4] + S.rootmat[4] * sq[5];
-          const double cy = sqrt(M00 * M00 + M10 * M10);
-          goal[i] = rel[0]; goal[2 + i] = rel[1]; goal[4 + i] = rel[2];
-          goal[6 + i] = cy > 4.0 * 2.220446049250313e-16 ? atan2(M10, M00) : 0.0;
-        }
-      }
-      step_count++;
-      // ---- calc_reward (stepping_task.py:81-123)
-      {
-        const double* tg = ter + T_SEQ + 6 * t1;
-        const double* tg2 = ter + T_SEQ + 6 * t2;
-        double lv[3], rv[3];
-        body_linvel(S, 2, p.lfoot_body, lv); body_linvel(S, 1, p.rfoot_body, rv);
-        double rf = p.clock_lut[0 * p.period + phase], rvc = p.clock_lut[1 * p.period + phase];
-        double lf = p.clock_lut[2 * p.period + phase], lvc = p.clock_lut[3 * p.period + phase];
-        if (mode == WALK_STANDING) { rf = 1; lf = 1; rvc = -1; lvc = -1; }
-        const double PI4 = 3.141592653589793 / 4;
-        const double maxf = m.totalmass * 9.8 * 0.5;
-        const double nl = fmin(grf_l, maxf) / maxf * 2 - 1, nr = fmin(grf_r, maxf) / maxf * 2 - 1;
-        terms[0] = 0.150 * ((tan(PI4 * lf * nl) + tan(PI4 * rf * nr)) / 2);
-        const double nlv = fmin(sqrt(dot3(lv, lv)), 0.2) / 0.2 * 2 - 1, nrv = fmin(sqrt(dot3(rv, rv)), 0.2) / 0.2 * 2 - 1;
-        terms[1] = 0.150 * ((tan(PI4 * lvc * nlv) + tan(PI4 * rvc * nrv)) / 2);
-        const double inner = cos(0.5 * tg[3]) * S.rootquat[0] + sin(0.5 * tg[3]) * S.rootquat[3];
-        terms[2] = 0.050 * exp(-(10 * (1 - inner * inner)));
-        double herr = fabs(rootp[2] - cz - p.goal_height);
-        if (herr < 0.01) herr = 0;
-        terms[3] = 0.050 * exp(-40 * herr * herr);
-        const double dl = sqrt((lp[0] - tg[0]) * (lp[0] - tg[0]) + (lp[1] - tg[1]) * (lp[1] - tg[1]) + (lp[2] - tg[2]) * (lp[2] - tg[2]));
-        const double dr = sqrt((rp[0] - tg[0]) * (rp[0] - tg[0]) + (rp[1] - tg[1]) * (rp[1] - tg[1]) + (rp[2] - tg[2]) * (rp[2] - tg[2]));
-        const double hit = reached ? exp(-fmin(dl, dr) / 0.25) : 0.0;
-        const double mx = (tg[0] + tg2[0]) / 2, my = (tg[1] + tg2[1]) / 2;
-        const double progress = exp(-sqrt((rootp[0] - mx) * (rootp[0] - mx) + (rootp[1] - my) * (rootp[1] - my)) / 2);
-        terms[4] = 0.450 * (0.8 * hit + 0.2 * progress);
-        const double hx = S.xpos[3 * p.head_body] - rootp[0], hy = S.xpos[3 * p.head_body + 1] - rootp[1], hn = sqrt(hx * hx + hy * hy);
-        terms[5] = 0.050 * exp(-10 * (hn * hn));
-        for (int k = 0; k < 6; k++) r_sum += terms[k];
-        for (int k = 6; k < 10; k++) terms[k] = 0;
-      }
-      terminated = (rootp[2] - fmin(lp[2], rp[2])) < 0.6 || self_collision;  // stepping_task.py:247-259
-    } else {
-      // ---- StandingTask.calc_reward / done (standing_task.py:49-131) on the fields of the last forward pass
-      double s_posture = 0, s_tau = 0;
-      if (lane < m.nu) {
-        const double dq = S.sq[lane] - p.neutral_pose[lane];
-        s_posture = dq * dq;
-        s_tau = cur_tq * cur_tq;
-      }
-      s_posture = wave_sum(s_posture); s_tau = wave_sum(s_tau);
-      double rl[3], vloc[3], dh[3], hloc[3];
-      body_linvel(S, 0, p.root_body, rl);
-      matT_vec(vloc, S.rootmat, rl);
-      for (int a = 0; a < 3; a++) dh[a] = S.xpos[3 * p.head_body + a] - S.xpos[3 * p.root_body + a];
-      matT_vec(hloc, S.rootmat, dh);      // torso position in the pelvis frame: inv(root_pose) . head_pose
-      const double fwd = sqrt(vloc[0] * vloc[0] + vloc[1] * vloc[1]), yaw = fabs(S.qvel[5]);
-      const double herr = fabs(S.xpos[3 * p.root_body + 2] - p.goal_height);
-      const double uerr = sqrt(hloc[0] * hloc[0] + hloc[1] * hloc[1]);
-      terms[0] = 0.3 * exp(-4 * (fwd * fwd));
-      terms[1] = 0.3 * exp(-4 * (yaw * yaw));
-      terms[2] = 0.1 * exp(-0.5 * (herr * herr));
-      terms[3] = 0.1 * exp(-40 * (uerr * uerr));
-      terms[4] = 0.1 * exp(-5e-5 * s_tau);
-      terms[5] = 0.1 * exp(-1 * s_posture);
-      for (int k = 0; k < 6; k++) r_sum += terms[k];
-      for (int k = 6; k < 10; k++) terms[k] = 0;
-      const double z = S.qpos[2];
-      terminated = z < 0.9 || z > 1.4 || self_collision;  // standing_task.py:111-131
-    }
-    // failure detection: a non-finite state ends the episode (counted in ep_stats[4]); outputs are sanitised so one
-    // diverged env cannot poison the batch (the reference has no equivalent: a NaN there propagates into the buffers)
-    {
-      bool bad = false;
-      if (lane < m.nq) bad = !isfinite(S.qpos[lane]);
-      if (lane < NV) bad = bad || !isfinite(S.qvel[lane]) || !isfinite(S.qacc[lane]);
-      if (__any(bad) || !isfinite(r_sum)) {
-        terminated = true;
-        r_sum = 0;
-        for (int k = 0; k < 10; k++) terms[k] = 0;
-        if (lane < m.nq) S.qpos[lane] = p.nominal_qpos[lane];
-        if (lane < NV) { S.qvel[lane] = 0; S.qacc[lane] = 0; }
-        if (lane < m.nu) { S.sq[lane] = p.action_offset[lane]; S.sv[lane] = 0; S.frc[lane] = 0; cur_tq = 0; }
-        if (lane == 0) atomicAdd(&st.ep_stats[4], 1.0);
-        SYNC();
-      }
-    }
-    prevact = target;
-    prevtq = cur_tq;
-    prevpred = a_raw;
-    started = 1;
-    traj_len += 1;
-    ep_ret += r_sum;
-    const bool truncated = p.max_traj_len > 0 && traj_len >= p.max_traj_len;
-    const int NT = WALKT ? 10 : 6;
-    if (TASK == TASK_WALK) {
-      write_obs(m, p, S, lane, phase, mode, mode_ref, obs + (size_t)env * OBS);
-      if (term_obs) write_obs(m, p, S, lane, phase, mode, mode_ref, term_obs + (size_t)env * OBS);
-    } else if (TASK == TASK_STEP) {
-      write_obs_step(m, p, S, lane, phase, goal, obs + (size_t)env * OBS);
-      if (term_obs) write_obs_step(m, p, S, lane, phase, goal, term_obs + (size_t)env * OBS);
-    } else {
-      write_obs_h1(m, p, S, lane, genv, obs_count, obs + (size_t)env * OBS, term_obs ? term_obs + (size_t)env * OBS : nullptr);
-      if (TASK == TASK_H1WALK) {
-        write_obs_walk_ext(p, lane, phase, mode, mode_ref, obs + (size_t)env * OBS + 35);
-        if (term_obs) write_obs_walk_ext(p, lane, phase, mode, mode_ref, term_obs + (size_t)env * OBS + 35);
-      }
-      obs_count++;
-      // post-observation randomisation draws (base_humanoid_env.py:221-225): slot 0 / 70 are the interval triggers
-      if (p.dynrand_interval > 0 && lhw_rng_randint(p.seed, genv, LHW_STREAM_STEP, step_count, 0, p.dynrand_interval) == 0)
-        randomize_dynamics(m, p, S, prm, lane, genv, LHW_STREAM_STEP, step_count, 1);
-      if (p.perturb_interval > 0 && lhw_rng_randint(p.seed, genv, LHW_STREAM_STEP, step_count, 70, p.perturb_interval) == 0) {
-        // apply_perturbation (domain_randomization.py:10-26): per body force / torque, then a coin flip that clears ALL
-        double xf[12];
-        for (int k = 0; k < 12; k++) xf[k] = S.xfrc[k];
-        for (int k = 0; k < p.n_pbody; k++) {
-          for (int a = 0; a < 3; a++) {
-            xf[6 * k + a] = lhw_rng_uniform(p.seed, genv, LHW_STREAM_STEP, step_count, 71 + 7 * k + a, -p.force_mag, p.force_mag);
-            xf[6 * k + 3 + a] = lhw_rng_uniform(p.seed, genv, LHW_STREAM_STEP, step_count, 74 + 7 * k + a, -p.torque_mag, p.torque_mag);
-          }
-          if (lhw_rng_randint(p.seed, genv, LHW_STREAM_STEP, step_count, 77 + 7 * k, 2) == 0)
-            for (int j = 0; j < 12; j++) xf[j] = 0;
+  // ---- BaseHumanoidEnv.step: smoothing, offsets (base_humanoid_env.py:209-215); RobotBase.step (robot_base.py:64-98)
+  double target = 0, a_raw = 0;
+  if (MODE == 0 && lane < m.nu) {
+    a_raw = (double)act[(size_t)env * m.nu + lane];
+    target = p.action_smoothing * a_raw + (1 - p.action_smoothing) * prevpred + p.action_offset[lane];
+    if (!started) { prevact = target; prevtq = S.frc[lane] * m.act_d[ADS * (lane) + AD_GEAR]; }
+  }
+  for (;;) {
+    int flags = 3;
+    if (stage == ST_CONTROL) {
+      if (kstep < p.frame_skip) {
+        if (lane < m.nu) {
+          // step_pd on the transmission fields of the previous forward pass (note S); ctrl = tau / gear
+          const double tau = p.kp[lane] * (target - S.sq[lane]) + p.kd[lane] * (0.0 - S.sv[lane]);
+          S.ctrl[lane] = tau / m.act_d[ADS * (lane) + AD_GEAR];
         }
         SYNC();
-        if (lane < 12) { S.xfrc[lane] = xf[lane]; prm[P_XFRC + lane] = xf[lane]; }
-      }
-      step_count++;
-    }
-    if (lane == 0) {
-      rew[env] = (float)r_sum;
-      done_out[env] = (terminated ? 1 : 0) | (truncated ? 2 : 0);
-      if (S.overflow) atomicAdd(&st.ep_stats[3], 1.0);
-      if (rew_terms) for (int k = 0; k < NT; k++) rew_terms[(size_t)env * NT + k] = (float)terms[k];
-    }
-    if (p.max_traj_len > 0 && (terminated || truncated)) {
-      if (lane == 0) { atomicAdd(&st.ep_stats[0], ep_ret); atomicAdd(&st.ep_stats[1], (double)traj_len); atomicAdd(&st.ep_stats[2], 1.0); }
-      do_reset = true;
-    }
-  }
-  if (do_reset) {
-    // ---- MujocoEnv.reset + BaseHumanoidEnv.reset_model (mujoco_env.py:113-127, base_humanoid_env.py:247-276)
-    SYNC();
-    if (lane < m.nq) S.qpos[lane] = p.nominal_qpos[lane];
-    if (lane < NV) S.qvel[lane] = 0;
-    if (lane < m.nu) S.ctrl[lane] = 0;
-    warm = 0;
-    if (H1R) {
-      // mj_resetData clears xfrc_applied; dynamics randomisation on reset (base_humanoid_env.py:254-255), slots 0..63
-      if (lane < 12) { S.xfrc[lane] = 0; prm[P_XFRC + lane] = 0; }
-      if (p.dynrand_interval > 0) randomize_dynamics(m, p, S, prm, lane, genv, LHW_STREAM_RESET, reset_count, 0);
-      SYNC();
-      if (p.init_noise > 0) {  // _apply_init_noise (base_humanoid_env.py:278-305): slot 64 root z, 65/66 roll/pitch, 67.. joints
-        const double cn = p.init_noise;
-        if (lane == 0) {
-          const double z0 = p.nominal_qpos[2];
-          S.qpos[2] = lhw_rng_uniform(p.seed, genv, LHW_STREAM_RESET, reset_count, 64, z0, z0 + 0.02);
-          const double ai = 0.5 * lhw_rng_uniform(p.seed, genv, LHW_STREAM_RESET, reset_count, 65, -cn, cn);
-          const double aj = 0.5 * lhw_rng_uniform(p.seed, genv, LHW_STREAM_RESET, reset_count, 66, -cn, cn);
-          const double ci = cos(ai), si = sin(ai), cj = cos(aj), sj = sin(aj);   // euler2quat(ai, aj, 0), static xyz
-          S.qpos[3] = cj * ci; S.qpos[4] = cj * si; S.qpos[5] = sj * ci; S.qpos[6] = -sj * si;
-        }
-        if (lane >= 7 && lane < m.nq) S.qpos[lane] += lhw_rng_uniform(p.seed, genv, LHW_STREAM_RESET, reset_count, 67 + (lane - 7), -cn, cn);
-      }
-    }
-    SYNC();
-    substep<TASK == TASK_STEP>(m, p, S, lane, 0, &warm, sprof, ter);                           // set_state: forward, actuation disabled
-    for (int k = 0; k < 3; k++) substep<TASK == TASK_STEP>(m, p, S, lane, 3, &warm, sprof, ter);  // three settle steps, ctrl = 0
-    if (WALKT) {
-      // WalkingTask.reset (walking_task.py:194-205): slot 0 mode, 1..3 mode_ref, 4 phase (+100 for h1_walk)
-      const double u = lhw_rng_u01(p.seed, genv, LHW_STREAM_RESET, reset_count, WS + 0);
-      mode = u < 0.6 ? MODE_STANDING : (u < 0.8 ? MODE_INPLACE : MODE_FORWARD);
-      sample_ref(p, genv, LHW_STREAM_RESET, reset_count, WS + 1, mode, mode_ref);
-      phase = lhw_rng_randint(p.seed, genv, LHW_STREAM_RESET, reset_count, WS + 4, p.period);
-    }
-    if (TASK == TASK_STEP) {
-      // ---- SteppingTask.reset (stepping_task.py:261-334); RNG slots: 0 phase, 1 mode, 2 mode-specific choice, 3 first-step
-      // offset, 4 number of flat steps.  Lane k builds target step k (running sums are replayed per lane so that every
-      // value is produced by the same sequence of additions as in the reference's loops).
-      for (int k = 0; k < 8; k++) goal[k] = 0;
-      reached = 0; frames = 0;
-      phase = lhw_rng_randint(p.seed, genv, LHW_STREAM_RESET, reset_count, 0, 2) == 0 ? 0 : p.period / 2;
-      const double u = lhw_rng_u01(p.seed, genv, LHW_STREAM_RESET, reset_count, 1);
-      mode = u < 0.15 ? WALK_CURVED : (u < 0.2 ? WALK_STANDING : (u < 0.4 ? WALK_BACKWARD : (u < 0.7 ? WALK_LATERAL : WALK_FORWARD)));
-      const int k = lane;
-      double sx = 0, sy = 0, sz = 0, sth = 0;
-      if (mode == WALK_CURVED) {
-        const double* row = p.plans + (size_t)lhw_rng_randint(p.seed, genv, LHW_STREAM_RESET, reset_count, 2, p.nplans) * (1 + MAX_SEQ * 3);
-        nseq = (int)row[0];
-        if (k < nseq) { sx = row[1 + 3 * k]; sy = row[2 + 3 * k]; sth = row[3 + 3 * k]; }
-      } else if (mode == WALK_LATERAL) {
-        const double sgn = lhw_rng_randint(p.seed, genv, LHW_STREAM_RESET, reset_count, 2, 2) == 0 ? -1.0 : 1.0;
-        nseq = 19;
-        double y = 0;
-        for (int i = 1; i <= k + 1 && i < 20; i++) {
-          if (i % 2) y += 0.4; else y -= (2.0 / 3.0) * 0.4;
-        }
-        sy = sgn * y;
+        kstep++;
       } else {
-        const int num_steps = mode == WALK_STANDING ? 1 : 20;
-        const double size = mode == WALK_BACKWARD ? -0.1 : 0.3, gap = 0.15;
-        double height = 0;
-        if (mode == WALK_FORWARD) {
-          const double hh = fmin(1.0, fmax(0.0, ((double)p.iteration - 3000.0) / 8000.0)) * 0.1;
-          height = lhw_rng_randint(p.seed, genv, LHW_STREAM_RESET, reset_count, 2, 2) == 0 ? -hh : hh;
-        }
-        const double uf = lhw_rng_uniform(p.seed, genv, LHW_STREAM_RESET, reset_count, 3, 0.095, 0.105);
-        const bool neg = (double)phase == 0.5 * (double)p.period;
-        const int cflat = 2 + (int)lhw_rng_randint(p.seed, genv, LHW_STREAM_RESET, reset_count, 4, 2);
-        nseq = num_steps == 1 ? 2 : 20;
-        if (k == 0) sy = neg ? -1 * uf : 1 * uf;
-        else {
-          double x = 0, y = neg ? -gap : gap, z = 0;
-          const int last = (k >= nseq - 1) ? num_steps - 2 : k;   // the final step replays the whole loop
-          for (int i = 1; i <= last; i++) {
-            x += size; y *= -1;
-            if (i > cflat) z += height;
+        bool do_reset = false;
+        PROF_MARK(9);  // control-step prologue (load, PD) is folded into slot 9 with the sub-step loop overheads
+        double r_sum = 0, terms[10], cur_tq = 0;
+        bool terminated = false;
+        if (lane < m.nu) cur_tq = S.frc[lane] * m.act_d[ADS * (lane) + AD_GEAR];
+        // self-collision scan of the contacts of the last forward pass (robot_interface.py:472-484)
+        bool self_collision;
+        {
+          int selfcol = 0;
+          if (lane < S.ncon) {
+            const int b1 = m.geom_i[GIS * (S.con_g1[lane]) + GI_BODY], b2 = m.geom_i[GIS * (S.con_g2[lane]) + GI_BODY];
+            selfcol = (m.body_i[BIS * (b1) + BI_ROOT] == p.root_body && m.body_i[BIS * (b2) + BI_ROOT] == p.root_body) ? 1 : 0;
           }
-          if (k >= nseq - 1) { sx = x + size; sy = -y; sz = z; }
-          else { sx = x; sy = y; sz = z; }
+          self_collision = gany<W>(selfcol);
         }
-      }
-      // transform_sequence (stepping_task.py:125-138): relative to the feet mid-point and the root yaw (stale frames)
-      const double mid0 = (S.xpos[3 * p.lfoot_body] + S.xpos[3 * p.rfoot_body]) / 2, mid1 = (S.xpos[3 * p.lfoot_body + 1] + S.xpos[3 * p.rfoot_body + 1]) / 2;
-      double yaw;
-      {
-        const double w = S.rootquat[0], x = S.rootquat[1], y = S.rootquat[2], z = S.rootquat[3];
-        const double Nq = w * w + x * x + y * y + z * z, sc = Nq > 2.220446049250313e-16 ? 2.0 / Nq : 0.0;
-        const double Y = y * sc, Z = z * sc;
-        const double M00 = 1.0 - (y * Y + z * Z), M10 = x * Y + w * Z, cy = sqrt(M00 * M00 + M10 * M10);
-        yaw = cy > 4.0 * 2.220446049250313e-16 ? atan2(M10, M00) : 0.0;
-      }
-      if (k < MAX_SEQ) {
-        double out[6] = {0.0, 0.0, -1.0, 0.0, 1.0, 0.0};
-        if (k < nseq) {
-          const double cyw = cos(yaw), syw = sin(yaw);
-          out[0] = mid0 + sx * cyw - sy * syw; out[1] = mid1 + sx * syw + sy * cyw; out[2] = sz; out[3] = yaw + sth;
-          out[4] = cos(out[3]); out[5] = sin(out[3]);
+        // ground reaction forces and lowest foot-floor contact point (robot_interface.py:269-325): lane = contact
+        double grf_r = 0, grf_l = 0, cz = 1e300;
+        if (TASK != TASK_STAND) {
+          int anyfoot = 0;
+          if (lane < S.ncon) {
+            const int c = lane, b1 = m.geom_i[GIS * (S.con_g1[c]) + GI_BODY], b2 = m.geom_i[GIS * (S.con_g2[c]) + GI_BODY];
+            const bool floor1 = m.body_i[BIS * (b1) + BI_ROOT] != p.root_body;
+            double fn = 0;
+            const int r0 = 4 * c;   // rows of contact c
+            if (S.con_dim[c] != 0) {
+              if (S.con_dim[c] == 3) {
+                const double f0 = S.efc_force[r0], f1 = S.efc_force[r0 + 1], f2 = S.efc_force[r0 + 2], f3 = S.efc_force[r0 + 3], mu = S.con_mu[c];
+                const double n = f0 + f1 + f2 + f3, t1f = mu * (f0 - f1), t2f = mu * (f2 - f3);
+                fn = sqrt(n * n + t1f * t1f + t2f * t2f);
+              } else fn = fabs(S.efc_force[r0]);
+            }
+            if (floor1 && b2 == p.rfoot_body) { grf_r = fn; cz = S.con_pos[3 * c + 2]; anyfoot = 1; }
+            if (floor1 && b2 == p.lfoot_body) { grf_l = fn; cz = S.con_pos[3 * c + 2]; anyfoot = 1; }
+          }
+          grf_r = gsum<W>(grf_r); grf_l = gsum<W>(grf_l); cz = gmin<W>(cz);
+          if (!gany<W>(anyfoot)) cz = 0;
         }
-        for (int a = 0; a < 6; a++) ter[T_SEQ + 6 * k + a] = out[a];
+        if (WALKT) {
+        // ---- WalkingTask.step (walking_task.py:149-170)
+        phase += 1;
+        if (phase >= p.period) phase = 0;
+        {
+          const bool dbl = p.clock_lut[0 * p.period + phase] == 1.0 && p.clock_lut[2 * p.period + phase] == 1.0;
+          if (lhw_rng_randint(p.seed, genv, LHW_STREAM_STEP, step_count, WS + 0, 100) == 0 && dbl) {
+            if (mode == MODE_INPLACE) mode = MODE_STANDING;
+            else if (mode == MODE_STANDING) mode = MODE_INPLACE;
+            sample_ref(p, genv, LHW_STREAM_STEP, step_count, WS + 1, mode, mode_ref);
+          }
+          if (lhw_rng_randint(p.seed, genv, LHW_STREAM_STEP, step_count, WS + 4, 200) == 0 && mode != MODE_STANDING) {
+            if (mode == MODE_FORWARD) mode = MODE_INPLACE;
+            else if (mode == MODE_INPLACE) mode = MODE_FORWARD;
+            sample_ref(p, genv, LHW_STREAM_STEP, step_count, WS + 5, mode, mode_ref);
+          }
+          if (!H1R) step_count++;   // h1_walk: the counter advances after the post-observation randomisation draws below
+        }
+        // ---- calc_reward (walking_task.py:85-147) on the fields of the last forward pass
+        // joint-space sums: lane = actuator / dof
+        double s_posture = 0, s_tq = 0, s_act = 0, s_rootacc = 0;
+        if (lane < m.nu) {
+          const double dq = p.neutral_pose[lane] - S.sq[lane];
+          s_posture = dq * dq;
+          s_tq = fabs(prevtq - cur_tq);
+          s_act = fabs(prevact - target);
+        }
+        if (lane >= 3 && lane < 6) s_rootacc = fabs(S.qvel[lane]);
+        if (lane < 3) s_rootacc = fabs(S.qacc[lane]);
+        s_posture = gsum<W>(s_posture); s_tq = gsum<W>(s_tq); s_act = gsum<W>(s_act); s_rootacc = gsum<W>(s_rootacc);
+        {
+          double lv[3], rv[3], rl[3], vloc[3];
+          body_linvel(S, 2, p.lfoot_body, lv); body_linvel(S, 1, p.rfoot_body, rv); body_linvel(S, 0, p.root_body, rl);
+          matT_vec(vloc, S.rootmat, rl);
+          double rf = p.clock_lut[0 * p.period + phase], rvc = p.clock_lut[1 * p.period + phase];
+          double lf = p.clock_lut[2 * p.period + phase], lvc = p.clock_lut[3 * p.period + phase];
+          if (mode == MODE_STANDING) { rf = 1; lf = 1; rvc = -1; lvc = -1; }
+          double yaw_ref = mode_ref[0], vx = mode_ref[1], vy = mode_ref[2];
+          if (mode == MODE_STANDING) { yaw_ref = 0; vx = 0; vy = 0; }
+          else if (mode == MODE_INPLACE) { vx = 0; vy = 0; }
+          else yaw_ref = 0;
+          const double gs = sqrt(vx * vx + vy * vy);
+          const double PI4 = 3.141592653589793 / 4;
+          const double maxf = m.totalmass * 9.8 * 0.5;
+          const double nl = fmin(grf_l, maxf) / maxf * 2 - 1, nr = fmin(grf_r, maxf) / maxf * 2 - 1;
+          terms[0] = 0.225 * ((tan(PI4 * lf * nl) + tan(PI4 * rf * nr)) / 2);
+          const double nlv = fmin(sqrt(dot3(lv, lv)), 0.2) / 0.2 * 2 - 1, nrv = fmin(sqrt(dot3(rv, rv)), 0.2) / 0.2 * 2 - 1;
+          terms[1] = 0.225 * ((tan(PI4 * lvc * nlv) + tan(PI4 * rvc * nrv)) / 2);
+          terms[2] = 0.050 * exp(-0.25 * s_rootacc);
+          double herr = fabs(S.xpos[3 * p.root_body + 2] - cz - p.goal_height);
+          if (herr < 0.01 + 0.05 * gs) herr = 0;
+          terms[3] = 0.050 * exp(-40 * herr * herr);
+          const double ex = vloc[0] - vx, ey = vloc[1] - vy, en = sqrt(ex * ex + ey * ey);
+          terms[4] = 0.150 * exp(-10 * (en * en));
+          const double ye = fabs(S.qvel[5] - yaw_ref);
+          terms[5] = 0.150 * exp(-10 * (ye * ye * ye));
+          const double hx = S.xpos[3 * p.head_body] - S.xpos[3 * p.root_body], hy = S.xpos[3 * p.head_body + 1] - S.xpos[3 * p.root_body + 1];
+          terms[6] = 0.050 * exp(-10 * sqrt(hx * hx + hy * hy));
+          terms[7] = 0.050 * exp(-sqrt(s_posture));
+          terms[8] = 0.025 * exp(-0.25 * (s_tq / (double)m.nu));
+          terms[9] = 0.025 * exp(-5 * s_act / (double)m.nu);
+          for (int k = 0; k < 10; k++) r_sum += terms[k];  // python sum() over the dict, left to right
+        }
+          const double z = S.qpos[2];
+          terminated = z < 0.6 || z > 1.4 || self_collision;  // walking_task.py:184-192
+        } else if (TASK == TASK_STEP) {
+          // ---- SteppingTask.step (stepping_task.py:211-243) on the stale site / body frames
+          phase += 1;
+          if (phase >= p.period) phase = 0;
+          const double lp[3] = {S.spos[6], S.spos[7], S.spos[8]}, rp[3] = {S.spos[3], S.spos[4], S.spos[5]};
+          const double rootp[3] = {S.xpos[3 * p.root_body], S.xpos[3 * p.root_body + 1], S.xpos[3 * p.root_body + 2]};
+          {
+            const double* tg = ter + T_SEQ + 6 * t1;
+            const double dl = sqrt((lp[0] - tg[0]) * (lp[0] - tg[0]) + (lp[1] - tg[1]) * (lp[1] - tg[1]) + (lp[2] - tg[2]) * (lp[2] - tg[2]));
+            const double dr = sqrt((rp[0] - tg[0]) * (rp[0] - tg[0]) + (rp[1] - tg[1]) * (rp[1] - tg[1]) + (rp[2] - tg[2]) * (rp[2] - tg[2]));
+            if (dl < p.target_radius || dr < p.target_radius) { reached = 1; frames += 1; }
+            else { reached = 0; frames = 0; }
+            if (reached && frames >= p.delay_frames) {  // update_target_steps
+              t1 = t2; t2 += 1;
+              if (t2 == nseq) t2 = nseq - 1;
+              reached = 0; frames = 0;
+            }
+          }
+          // update_goal_steps (stepping_task.py:184-202): the two targets in the root frame
+          if (mode != WALK_STANDING) {
+            for (int i = 0; i < 2; i++) {
+              const double* sq = ter + T_SEQ + 6 * (i ? t2 : t1);
+              const double dvec[3] = {sq[0] - rootp[0], sq[1] - rootp[1], sq[2] - rootp[2]};
+              double rel[3];
+              matT_vec(rel, S.rootmat, dvec);
+              const double M00 = S.rootmat[0] * sq[4] + S.rootmat[3] * sq[5], M10 = S.rootmat[1] * sq[4] + S.rootmat[4] * sq[5];
+              const double cy = sqrt(M00 * M00 + M10 * M10);
+              goal[i] = rel[0]; goal[2 + i] = rel[1]; goal[4 + i] = rel[2];
+              goal[6 + i] = cy > 4.0 * 2.220446049250313e-16 ? atan2(M10, M00) : 0.0;
+            }
+          }
+          step_count++;
+          // ---- calc_reward (stepping_task.py:81-123)
+          {
+            const double* tg = ter + T_SEQ + 6 * t1;
+            const double* tg2 = ter + T_SEQ + 6 * t2;
+            double lv[3], rv[3];
+            body_linvel(S, 2, p.lfoot_body, lv); body_linvel(S, 1, p.rfoot_body, rv);
+            double rf = p.clock_lut[0 * p.period + phase], rvc = p.clock_lut[1 * p.period + phase];
+            double lf = p.clock_lut[2 * p.period + phase], lvc = p.clock_lut[3 * p.period + phase];
+            if (mode == WALK_STANDING) { rf = 1; lf = 1; rvc = -1; lvc = -1; }
+            const double PI4 = 3.141592653589793 / 4;
+            const double maxf = m.totalmass * 9.8 * 0.5;
+            const double nl = fmin(grf_l, maxf) / maxf * 2 - 1, nr = fmin(grf_r, maxf) / maxf * 2 - 1;
+            terms[0] = 0.150 * ((tan(PI4 * lf * nl) + tan(PI4 * rf * nr)) / 2);
+            const double nlv = fmin(sqrt(dot3(lv, lv)), 0.2) / 0.2 * 2 - 1, nrv = fmin(sqrt(dot3(rv, rv)), 0.2) / 0.2 * 2 - 1;
+            terms[1] = 0.150 * ((tan(PI4 * lvc * nlv) + tan(PI4 * rvc * nrv)) / 2);
+            const double inner = cos(0.5 * tg[3]) * S.rootquat[0] + sin(0.5 * tg[3]) * S.rootquat[3];
+            terms[2] = 0.050 * exp(-(10 * (1 - inner * inner)));
+            double herr = fabs(rootp[2] - cz - p.goal_height);
+            if (herr < 0.01) herr = 0;
+            terms[3] = 0.050 * exp(-40 * herr * herr);
+            const double dl = sqrt((lp[0] - tg[0]) * (lp[0] - tg[0]) + (lp[1] - tg[1]) * (lp[1] - tg[1]) + (lp[2] - tg[2]) * (lp[2] - tg[2]));
+            const double dr = sqrt((rp[0] - tg[0]) * (rp[0] - tg[0]) + (rp[1] - tg[1]) * (rp[1] - tg[1]) + (rp[2] - tg[2]) * (rp[2] - tg[2]));
+            const double hit = reached ? exp(-fmin(dl, dr) / 0.25) : 0.0;
+            const double mx = (tg[0] + tg2[0]) / 2, my = (tg[1] + tg2[1]) / 2;
+            const double progress = exp(-sqrt((rootp[0] - mx) * (rootp[0] - mx) + (rootp[1] - my) * (rootp[1] - my)) / 2);
+            terms[4] = 0.450 * (0.8 * hit + 0.2 * progress);
+            const double hx = S.xpos[3 * p.head_body] - rootp[0], hy = S.xpos[3 * p.head_body + 1] - rootp[1], hn = sqrt(hx * hx + hy * hy);
+            terms[5] = 0.050 * exp(-10 * (hn * hn));
+            for (int k = 0; k < 6; k++) r_sum += terms[k];
+            for (int k = 6; k < 10; k++) terms[k] = 0;
+          }
+          terminated = (rootp[2] - fmin(lp[2], rp[2])) < 0.6 || self_collision;  // stepping_task.py:247-259
+        } else {
+          // ---- StandingTask.calc_reward / done (standing_task.py:49-131) on the fields of the last forward pass
+          double s_posture = 0, s_tau = 0;
+          if (lane < m.nu) {
+            const double dq = S.sq[lane] - p.neutral_pose[lane];
+            s_posture = dq * dq;
+            s_tau = cur_tq * cur_tq;
+          }
+          s_posture = gsum<W>(s_posture); s_tau = gsum<W>(s_tau);
+          double rl[3], vloc[3], dh[3], hloc[3];
+          body_linvel(S, 0, p.root_body, rl);
+          matT_vec(vloc, S.rootmat, rl);
+          for (int a = 0; a < 3; a++) dh[a] = S.xpos[3 * p.head_body + a] - S.xpos[3 * p.root_body + a];
+          matT_vec(hloc, S.rootmat, dh);      // torso position in the pelvis frame: inv(root_pose) . head_pose
+          const double fwd = sqrt(vloc[0] * vloc[0] + vloc[1] * vloc[1]), yaw = fabs(S.qvel[5]);
+          const double herr = fabs(S.xpos[3 * p.root_body + 2] - p.goal_height);
+          const double uerr = sqrt(hloc[0] * hloc[0] + hloc[1] * hloc[1]);
+          terms[0] = 0.3 * exp(-4 * (fwd * fwd));
+          terms[1] = 0.3 * exp(-4 * (yaw * yaw));
+          terms[2] = 0.1 * exp(-0.5 * (herr * herr));
+          terms[3] = 0.1 * exp(-40 * (uerr * uerr));
+          terms[4] = 0.1 * exp(-5e-5 * s_tau);
+          terms[5] = 0.1 * exp(-1 * s_posture);
+          for (int k = 0; k < 6; k++) r_sum += terms[k];
+          for (int k = 6; k < 10; k++) terms[k] = 0;
+          const double z = S.qpos[2];
+          terminated = z < 0.9 || z > 1.4 || self_collision;  // standing_task.py:111-131
+        }
+        // failure detection: a non-finite state ends the episode (counted in ep_stats[4]); outputs are sanitised so one
+        // diverged env cannot poison the batch (the reference has no equivalent: a NaN there propagates into the buffers)
+        {
+          bool bad = false;
+          if (lane < m.nq) bad = !isfinite(S.qpos[lane]);
+          if (lane < NV) bad = bad || !isfinite(S.qvel[lane]) || !isfinite(S.qacc[lane]);
+          if (gany<W>(bad) || !isfinite(r_sum)) {
+            terminated = true;
+            r_sum = 0;
+            for (int k = 0; k < 10; k++) terms[k] = 0;
+            if (lane < m.nq) S.qpos[lane] = p.nominal_qpos[lane];
+            if (lane < NV) { S.qvel[lane] = 0; S.qacc[lane] = 0; }
+            if (lane < m.nu) { S.sq[lane] = p.action_offset[lane]; S.sv[lane] = 0; S.frc[lane] = 0; cur_tq = 0; }
+            if (lane == 0) atomicAdd(&st.ep_stats[4], 1.0);
+            SYNC();
+          }
+        }
+        prevact = target;
+        prevtq = cur_tq;
+        prevpred = a_raw;
+        started = 1;
+        traj_len += 1;
+        ep_ret += r_sum;
+        const bool truncated = p.max_traj_len > 0 && traj_len >= p.max_traj_len;
+        const int NT = WALKT ? 10 : 6;
+        if (TASK == TASK_WALK) {
+          write_obs(m, p, S, lane, phase, mode, mode_ref, obs + (size_t)env * OBS);
+          if (term_obs) write_obs(m, p, S, lane, phase, mode, mode_ref, term_obs + (size_t)env * OBS);
+        } else if (TASK == TASK_STEP) {
+          write_obs_step(m, p, S, lane, phase, goal, obs + (size_t)env * OBS);
+          if (term_obs) write_obs_step(m, p, S, lane, phase, goal, term_obs + (size_t)env * OBS);
+        } else {
+          write_obs_h1(m, p, S, lane, genv, obs_count, obs + (size_t)env * OBS, term_obs ? term_obs + (size_t)env * OBS : nullptr);
+          if (TASK == TASK_H1WALK) {
+            write_obs_walk_ext(p, lane, phase, mode, mode_ref, obs + (size_t)env * OBS + 35);
+            if (term_obs) write_obs_walk_ext(p, lane, phase, mode, mode_ref, term_obs + (size_t)env * OBS + 35);
+          }
+          obs_count++;
+          // post-observation randomisation draws (base_humanoid_env.py:221-225): slot 0 / 70 are the interval triggers
+          if (p.dynrand_interval > 0 && lhw_rng_randint(p.seed, genv, LHW_STREAM_STEP, step_count, 0, p.dynrand_interval) == 0)
+            randomize_dynamics(m, p, S, prm, lane, genv, LHW_STREAM_STEP, step_count, 1);
+          if (p.perturb_interval > 0 && lhw_rng_randint(p.seed, genv, LHW_STREAM_STEP, step_count, 70, p.perturb_interval) == 0) {
+            // apply_perturbation (domain_randomization.py:10-26): per body force / torque, then a coin flip that clears ALL
+            double xf[12];
+            for (int k = 0; k < 12; k++) xf[k] = S.xfrc[k];
+            for (int k = 0; k < p.n_pbody; k++) {
+              for (int a = 0; a < 3; a++) {
+                xf[6 * k + a] = lhw_rng_uniform(p.seed, genv, LHW_STREAM_STEP, step_count, 71 + 7 * k + a, -p.force_mag, p.force_mag);
+                xf[6 * k + 3 + a] = lhw_rng_uniform(p.seed, genv, LHW_STREAM_STEP, step_count, 74 + 7 * k + a, -p.torque_mag, p.torque_mag);
+              }
+              if (lhw_rng_randint(p.seed, genv, LHW_STREAM_STEP, step_count, 77 + 7 * k, 2) == 0)
+                for (int j = 0; j < 12; j++) xf[j] = 0;
+            }
+            SYNC();
+            if (lane < 12) { S.xfrc[lane] = xf[lane]; prm[P_XFRC + lane] = xf[lane]; }
+          }
+          step_count++;
+        }
+        if (lane == 0) {
+          rew[env] = (float)r_sum;
+          done_out[env] = (terminated ? 1 : 0) | (truncated ? 2 : 0);
+          if (S.overflow) atomicAdd(&st.ep_stats[3], 1.0);
+          if (rew_terms) for (int k = 0; k < NT; k++) rew_terms[(size_t)env * NT + k] = (float)terms[k];
+        }
+        if (p.max_traj_len > 0 && (terminated || truncated)) {
+          if (lane == 0) { atomicAdd(&st.ep_stats[0], ep_ret); atomicAdd(&st.ep_stats[1], (double)traj_len); atomicAdd(&st.ep_stats[2], 1.0); }
+          do_reset = true;
+        }
+        committed = true;
+        stage = do_reset ? ST_RESET : ST_END;
       }
-      if (lane == 0) ter[T_FLOOR] = mode == WALK_FORWARD ? -2.0 : 0.0;   // stepping_task.py:330-334
-      t1 = 0; t2 = 1;                                                   // update_target_steps from t1 = t2 = 0
-      if (t2 == nseq) t2 = nseq - 1;
+    } else if (stage == ST_SETTLE) {
+      if (kstep < 3) kstep++;   // three settle steps, ctrl = 0
+      else {
+        if (WALKT) {
+          // WalkingTask.reset (walking_task.py:194-205): slot 0 mode, 1..3 mode_ref, 4 phase (+100 for h1_walk)
+          const double u = lhw_rng_u01(p.seed, genv, LHW_STREAM_RESET, reset_count, WS + 0);
+          mode = u < 0.6 ? MODE_STANDING : (u < 0.8 ? MODE_INPLACE : MODE_FORWARD);
+          sample_ref(p, genv, LHW_STREAM_RESET, reset_count, WS + 1, mode, mode_ref);
+          phase = lhw_rng_randint(p.seed, genv, LHW_STREAM_RESET, reset_count, WS + 4, p.period);
+        }
+        if (TASK == TASK_STEP) {
+          // ---- SteppingTask.reset (stepping_task.py:261-334); RNG slots: 0 phase, 1 mode, 2 mode-specific choice, 3 first-step
+          // offset, 4 number of flat steps.  Lane k builds target step k (running sums are replayed per lane so that every
+          // value is produced by the same sequence of additions as in the reference's loops).
+          for (int k = 0; k < 8; k++) goal[k] = 0;
+          reached = 0; frames = 0;
+          phase = lhw_rng_randint(p.seed, genv, LHW_STREAM_RESET, reset_count, 0, 2) == 0 ? 0 : p.period / 2;
+          const double u = lhw_rng_u01(p.seed, genv, LHW_STREAM_RESET, reset_count, 1);
+          mode = u < 0.15 ? WALK_CURVED : (u < 0.2 ? WALK_STANDING : (u < 0.4 ? WALK_BACKWARD : (u < 0.7 ? WALK_LATERAL : WALK_FORWARD)));
+          const int k = lane;
+          double sx = 0, sy = 0, sz = 0, sth = 0;
+          if (mode == WALK_CURVED) {
+            const double* row = p.plans + (size_t)lhw_rng_randint(p.seed, genv, LHW_STREAM_RESET, reset_count, 2, p.nplans) * (1 + MAX_SEQ * 3);
+            nseq = (int)row[0];
+            if (k < nseq) { sx = row[1 + 3 * k]; sy = row[2 + 3 * k]; sth = row[3 + 3 * k]; }
+          } else if (mode == WALK_LATERAL) {
+            const double sgn = lhw_rng_randint(p.seed, genv, LHW_STREAM_RESET, reset_count, 2, 2) == 0 ? -1.0 : 1.0;
+            nseq = 19;
+            double y = 0;
+            for (int i = 1; i <= k + 1 && i < 20; i++) {
+              if (i % 2) y += 0.4; else y -= (2.0 / 3.0) * 0.4;
+            }
+            sy = sgn * y;
+          } else {
+            const int num_steps = mode == WALK_STANDING ? 1 : 20;
+            const double size = mode == WALK_BACKWARD ? -0.1 : 0.3, gap = 0.15;
+            double height = 0;
+            if (mode == WALK_FORWARD) {
+              const double hh = fmin(1.0, fmax(0.0, ((double)p.iteration - 3000.0) / 8000.0)) * 0.1;
+              height = lhw_rng_randint(p.seed, genv, LHW_STREAM_RESET, reset_count, 2, 2) == 0 ? -hh : hh;
+            }
+            const double uf = lhw_rng_uniform(p.seed, genv, LHW_STREAM_RESET, reset_count, 3, 0.095, 0.105);
+            const bool neg = (double)phase == 0.5 * (double)p.period;
+            const int cflat = 2 + (int)lhw_rng_randint(p.seed, genv, LHW_STREAM_RESET, reset_count, 4, 2);
+            nseq = num_steps == 1 ? 2 : 20;
+            if (k == 0) sy = neg ? -1 * uf : 1 * uf;
+            else {
+              double x = 0, y = neg ? -gap : gap, z = 0;
+              const int last = (k >= nseq - 1) ? num_steps - 2 : k;   // the final step replays the whole loop
+              for (int i = 1; i <= last; i++) {
+                x += size; y *= -1;
+                if (i > cflat) z += height;
+              }
+              if (k >= nseq - 1) { sx = x + size; sy = -y; sz = z; }
+              else { sx = x; sy = y; sz = z; }
+            }
+          }
+          // transform_sequence (stepping_task.py:125-138): relative to the feet mid-point and the root yaw (stale frames)
+          const double mid0 = (S.xpos[3 * p.lfoot_body] + S.xpos[3 * p.rfoot_body]) / 2, mid1 = (S.xpos[3 * p.lfoot_body + 1] + S.xpos[3 * p.rfoot_body + 1]) / 2;
+          double yaw;
+          {
+            const double w = S.rootquat[0], x = S.rootquat[1], y = S.rootquat[2], z = S.rootquat[3];
+            const double Nq = w * w + x * x + y * y + z * z, sc = Nq > 2.220446049250313e-16 ? 2.0 / Nq : 0.0;
+            const double Y = y * sc, Z = z * sc;
+            const double M00 = 1.0 - (y * Y + z * Z), M10 = x * Y + w * Z, cy = sqrt(M00 * M00 + M10 * M10);
+            yaw = cy > 4.0 * 2.220446049250313e-16 ? atan2(M10, M00) : 0.0;
+          }
+          if (k < MAX_SEQ) {
+            double out[6] = {0.0, 0.0, -1.0, 0.0, 1.0, 0.0};
+            if (k < nseq) {
+              const double cyw = cos(yaw), syw = sin(yaw);
+              out[0] = mid0 + sx * cyw - sy * syw; out[1] = mid1 + sx * syw + sy * cyw; out[2] = sz; out[3] = yaw + sth;
+              out[4] = cos(out[3]); out[5] = sin(out[3]);
+            }
+            for (int a = 0; a < 6; a++) ter[T_SEQ + 6 * k + a] = out[a];
+          }
+          if (lane == 0) ter[T_FLOOR] = mode == WALK_FORWARD ? -2.0 : 0.0;   // stepping_task.py:330-334
+          t1 = 0; t2 = 1;                                                   // update_target_steps from t1 = t2 = 0
+          if (t2 == nseq) t2 = nseq - 1;
+        }
+        reset_count++;
+        traj_len = 0;
+        ep_ret = 0;
+        prevpred = 0;
+        if (TASK == TASK_WALK) {
+          if (obs) write_obs(m, p, S, lane, phase, mode, mode_ref, obs + (size_t)env * OBS);
+        } else if (TASK == TASK_STEP) {
+          if (obs) write_obs_step(m, p, S, lane, phase, goal, obs + (size_t)env * OBS);
+        } else {
+          write_obs_h1(m, p, S, lane, genv, obs_count, obs ? obs + (size_t)env * OBS : nullptr, nullptr);  // the counter advances either way
+          if (TASK == TASK_H1WALK && obs) write_obs_walk_ext(p, lane, phase, mode, mode_ref, obs + (size_t)env * OBS + 35);
+          obs_count++;
+        }
+        stage = ST_END;
+      }
     }
-    reset_count++;
-    traj_len = 0;
-    ep_ret = 0;
-    prevpred = 0;
-    if (TASK == TASK_WALK) {
-      if (obs) write_obs(m, p, S, lane, phase, mode, mode_ref, obs + (size_t)env * OBS);
-    } else if (TASK == TASK_STEP) {
-      if (obs) write_obs_step(m, p, S, lane, phase, goal, obs + (size_t)env * OBS);
-    } else {
-      write_obs_h1(m, p, S, lane, genv, obs_count, obs ? obs + (size_t)env * OBS : nullptr, nullptr);  // the counter advances either way
-      if (TASK == TASK_H1WALK && obs) write_obs_walk_ext(p, lane, phase, mode, mode_ref, obs + (size_t)env * OBS + 35);
-      obs_count++;
+    if (stage == ST_RESET) {   // (an env whose episode just ended enters here in the same pass)
+      // ---- MujocoEnv.reset + BaseHumanoidEnv.reset_model (mujoco_env.py:113-127, base_humanoid_env.py:247-276)
+      SYNC();
+      if (lane < m.nq) S.qpos[lane] = p.nominal_qpos[lane];
+      if (lane < NV) S.qvel[lane] = 0;
+      if (lane < m.nu) S.ctrl[lane] = 0;
+      warm = 0;
+      if (H1R) {
+        // mj_resetData clears xfrc_applied; dynamics randomisation on reset (base_humanoid_env.py:254-255), slots 0..63
+        if (lane < 12) { S.xfrc[lane] = 0; prm[P_XFRC + lane] = 0; }
+        if (p.dynrand_interval > 0) randomize_dynamics(m, p, S, prm, lane, genv, LHW_STREAM_RESET, reset_count, 0);
+        SYNC();
+        if (p.init_noise > 0) {  // _apply_init_noise (base_humanoid_env.py:278-305): slot 64 root z, 65/66 roll/pitch, 67.. joints
+          const double cn = p.init_noise;
+          if (lane == 0) {
+            const double z0 = p.nominal_qpos[2];
+            S.qpos[2] = lhw_rng_uniform(p.seed, genv, LHW_STREAM_RESET, reset_count, 64, z0, z0 + 0.02);
+            const double ai = 0.5 * lhw_rng_uniform(p.seed, genv, LHW_STREAM_RESET, reset_count, 65, -cn, cn);
+            const double aj = 0.5 * lhw_rng_uniform(p.seed, genv, LHW_STREAM_RESET, reset_count, 66, -cn, cn);
+            const double ci = cos(ai), si = sin(ai), cj = cos(aj), sj = sin(aj);   // euler2quat(ai, aj, 0), static xyz
+            S.qpos[3] = cj * ci; S.qpos[4] = cj * si; S.qpos[5] = sj * ci; S.qpos[6] = -sj * si;
+          }
+          if (lane >= 7 && lane < m.nq) S.qpos[lane] += lhw_rng_uniform(p.seed, genv, LHW_STREAM_RESET, reset_count, 67 + (lane - 7), -cn, cn);
+        }
+      }
+      SYNC();
+      flags = 0;   // set_state: forward pass with actuation disabled
+      stage = ST_SETTLE; kstep = 0;
+    } else if (stage == ST_FORWARD) {
+      flags = 0;   // lhw_env_set_state: mj_forward with actuation disabled
+      stage = ST_LAST;
+    }
+    if (stage == ST_END) break;
+    substep<TASK == TASK_STEP>(m, p, S, lane, flags, &warm, sprof, ter);
+    if (stage == ST_LAST) break;
+    // two envs per wave: an env that needs more contacts than this layout holds is handed to the one-env-per-wave kernel
+    // untouched (nothing of it has been written yet); once its outputs are out, it can only truncate like that kernel does
+    if (W == 32 && MODE == 0 && !committed && S.overflow) {
+      if (lane == 0) st.slow[env] = 1;
+      return;
     }
   }
   PROF_MARK(10);
@@ -2165,6 +2195,7 @@ __global__ void __launch_bounds__(64, 2) humanoid_kernel(HModel m, HParams p, HS
     rec[R_PREVPRED + lane] = prevpred; rec[R_PREVACT + lane] = prevact; rec[R_PREVTQ + lane] = prevtq;
   }
   if (lane == 0) {
+    if (MODE == 0 && p.only_flagged) st.slow[env] = 0;
     rec[R_MODEREF] = mode_ref[0]; rec[R_MODEREF + 1] = mode_ref[1]; rec[R_MODEREF + 2] = mode_ref[2];
     rec[R_EPRET] = ep_ret;
     irec[RI_PHASE] = phase; irec[RI_MODE] = mode; irec[RI_TRAJ] = traj_len; irec[RI_STARTED] = started;
@@ -2259,6 +2290,8 @@ int humanoid_create(HumanoidEnv** out, const std::vector<int32_t>& mi, const std
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return lhw_fail(LHW_ERR_NO_DEVICE, "no HIP device");
   HumanoidEnv* h = new HumanoidEnv();
   h->device = cfg->device;
+  // two envs per wave (W = 32) where the model fits half a wavefront; the stepping task needs the 16-contact layout throughout
+  h->fast = !stepping && np <= 32 && ng <= 16 && nj <= 32 && !getenv("LHW_ONE_ENV_PER_WAVE");
   HModel& m = h->m;
   memset(&m, 0, sizeof m);
   m.nq = nq; m.nv = nv; m.nu = nu; m.nbody = nb; m.njnt = nj; m.ngeom = ng; m.npair = np;
@@ -2459,7 +2492,10 @@ int humanoid_create(HumanoidEnv** out, const std::vector<int32_t>& mi, const std
     h->st.ter = const_cast<double*>(to_dev<double>(h, all.data(), all.size()));
     ok = ok && h->st.ter != nullptr;
   }
-  void *rec = nullptr, *irec = nullptr, *eps = nullptr;
+  void *rec = nullptr, *irec = nullptr, *eps = nullptr, *slow = nullptr;
+  ok = ok && hipMalloc(&slow, N) == hipSuccess && hipMemset(slow, 0, N) == hipSuccess;
+  if (slow) h->dev_allocs.push_back(slow);
+  h->st.slow = (unsigned char*)slow;
   ok = ok && hipMalloc(&rec, sizeof(double) * REC_D * N) == hipSuccess && hipMemset(rec, 0, sizeof(double) * REC_D * N) == hipSuccess &&
        hipMalloc(&irec, sizeof(int) * REC_I * N) == hipSuccess && hipMemset(irec, 0, sizeof(int) * REC_I * N) == hipSuccess &&
        hipMalloc(&eps, sizeof(double) * 8) == hipSuccess && hipMemset(eps, 0, sizeof(double) * 8) == hipSuccess;
@@ -2479,17 +2515,29 @@ void humanoid_destroy(HumanoidEnv* h) {
   delete h;
 }
 
-#define LAUNCH_RANGE(MODE, FIRST, COUNT, ...)                                                                      \
+#define LAUNCH_RANGE(MODE, WIDTH, FLAGGED, FIRST, COUNT, ...)                                                       \
   do {                                                                                                             \
     HParams pp_ = h->p;                                                                                            \
-    pp_.env_first = (FIRST); pp_.env_count = (COUNT);                                                              \
-    const dim3 grid_(pp_.env_count);                                                                               \
-    if (pp_.task == TASK_WALK) hipLaunchKernelGGL((humanoid_kernel<MODE, TASK_WALK>), grid_, dim3(64), 0, s, h->m, pp_, h->st, __VA_ARGS__); \
-    else if (pp_.task == TASK_STEP) hipLaunchKernelGGL((humanoid_kernel<MODE, TASK_STEP>), grid_, dim3(64), 0, s, h->m, pp_, h->st, __VA_ARGS__); \
-    else if (pp_.task == TASK_H1WALK) hipLaunchKernelGGL((humanoid_kernel<MODE, TASK_H1WALK>), grid_, dim3(64), 0, s, h->m, pp_, h->st, __VA_ARGS__); \
-    else hipLaunchKernelGGL((humanoid_kernel<MODE, TASK_STAND>), grid_, dim3(64), 0, s, h->m, pp_, h->st, __VA_ARGS__);                     \
+    pp_.env_first = (FIRST); pp_.env_count = (COUNT); pp_.only_flagged = (FLAGGED);                                \
+    const dim3 grid_((pp_.env_count + (64 / WIDTH) - 1) / (64 / WIDTH));                                           \
+    if (pp_.task == TASK_WALK) hipLaunchKernelGGL((humanoid_kernel<MODE, TASK_WALK, WIDTH>), grid_, dim3(64), 0, s, h->m, pp_, h->st, __VA_ARGS__); \
+    else if (pp_.task == TASK_STEP) hipLaunchKernelGGL((humanoid_kernel<MODE, TASK_STEP, 64>), grid_, dim3(64), 0, s, h->m, pp_, h->st, __VA_ARGS__); \
+    else if (pp_.task == TASK_H1WALK) hipLaunchKernelGGL((humanoid_kernel<MODE, TASK_H1WALK, WIDTH>), grid_, dim3(64), 0, s, h->m, pp_, h->st, __VA_ARGS__); \
+    else hipLaunchKernelGGL((humanoid_kernel<MODE, TASK_STAND, WIDTH>), grid_, dim3(64), 0, s, h->m, pp_, h->st, __VA_ARGS__);                     \
   } while (0)
-#define LAUNCH(MODE, ...) LAUNCH_RANGE(MODE, 0, h->p.n_envs, __VA_ARGS__)
+#define LAUNCH(MODE, ...) LAUNCH_RANGE(MODE, 64, 0, 0, h->p.n_envs, __VA_ARGS__)
+// One control step of envs [first, first + count): two envs per wave where the model allows it, followed by the one-env-per-wave
+// kernel over the same range for the envs that flagged themselves (more than 8 contacts); that launch finds nothing to do on
+// most steps and its waves exit on their first load.
+#define LAUNCH_STEP(FIRST, COUNT, ...)                                                       \
+  do {                                                                                       \
+    if (h->fast) {                                                                           \
+      LAUNCH_RANGE(0, 32, 0, FIRST, COUNT, __VA_ARGS__);                                     \
+      LAUNCH_RANGE(0, 64, 1, FIRST, COUNT, __VA_ARGS__);                                     \
+    } else {                                                                                 \
+      LAUNCH_RANGE(0, 64, 0, FIRST, COUNT, __VA_ARGS__);                                     \
+    }                                                                                        \
+  } while (0)
 
 void humanoid_reset(HumanoidEnv* h, const uint8_t* mask, float* obs, hipStream_t s) {
   LAUNCH(1, (const float*)nullptr, obs, (float*)nullptr, (float*)nullptr, (unsigned char*)nullptr, (float*)nullptr, mask,
@@ -2497,13 +2545,13 @@ void humanoid_reset(HumanoidEnv* h, const uint8_t* mask, float* obs, hipStream_t
 }
 void humanoid_step(HumanoidEnv* h, const float* act, float* obs, float* term_obs, float* rew, uint8_t* done, float* rew_terms,
                    hipStream_t s) {
-  LAUNCH(0, act, obs, term_obs, rew, done, rew_terms, (const unsigned char*)nullptr, (double*)nullptr, (double*)nullptr);
+  LAUNCH_STEP(0, h->p.n_envs, act, obs, term_obs, rew, done, rew_terms, (const unsigned char*)nullptr, (double*)nullptr, (double*)nullptr);
 }
 // envs [first, first + count) only; the pointers are the full-batch arrays
 int humanoid_step_range(HumanoidEnv* h, int first, int count, const float* act, float* obs, float* term_obs, float* rew, uint8_t* done,
                         float* rew_terms, hipStream_t s) {
   if (first < 0 || count <= 0 || first + count > h->p.n_envs) return -1;
-  LAUNCH_RANGE(0, first, count, act, obs, term_obs, rew, done, rew_terms, (const unsigned char*)nullptr, (double*)nullptr, (double*)nullptr);
+  LAUNCH_STEP(first, count, act, obs, term_obs, rew, done, rew_terms, (const unsigned char*)nullptr, (double*)nullptr, (double*)nullptr);
   return 0;
 }
 void humanoid_get_state(HumanoidEnv* h, double* qpos, double* qvel, hipStream_t s) {
@@ -2517,7 +2565,7 @@ void humanoid_set_state(HumanoidEnv* h, const double* qpos, const double* qvel, 
 double* humanoid_ep_stats(HumanoidEnv* h) { return h->st.ep_stats; }
 int humanoid_occupancy() {
   int nb = -1;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, humanoid_kernel<0, TASK_WALK>, 64, 0) != hipSuccess) return -1;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, humanoid_kernel<0, TASK_WALK, 32>, 64, 0) != hipSuccess) return -1;
   return nb;
 }
 int humanoid_profile(HumanoidEnv* h, int enable, long long* out16) {

@@ -179,3 +179,6 @@ static inline int atomicMax(int* p, int v) { int o = *p; *p = o > v ? o : v; ret
 using std::isfinite;
 using std::max;
 using std::min;
+struct alignas(16) double2 { double x, y; };
+struct alignas(8) float2 { float x, y; };
+struct alignas(16) float4 { float x, y, z, w; };
