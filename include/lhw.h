@@ -157,6 +157,10 @@ int lhw_env_pop_episode_stats(LhwEnv* env, double* ret_sum, double* len_sum, int
  * dropped because more than the compiled-in cap were active, and control steps in which an env's state became
  * non-finite (the env is flagged terminated, its outputs are zeroed, and it is reset like any finished episode). */
 int lhw_env_pop_fault_stats(LhwEnv* env, int64_t* contact_overflow, int64_t* diverged);
+/* Control steps since the last call that the two-envs-per-wave kernels handed to the one-env-per-wave kernel because an
+ * env touched more contacts than their layout holds (8); such a step costs roughly three ordinary ones.  Diagnostic of the
+ * rollout, no reference counterpart (host pointer, synchronous, resets the counter). */
+int lhw_env_pop_rerun_count(LhwEnv* env, int64_t* reruns);
 int lhw_env_set_iteration(LhwEnv* env, int64_t iteration);
 /* Diagnostic: shader-clock cycles env 0 spent in each phase of the wave-per-env stepper since the last call
  * (slots: 0 kinematics, 1 com/cdof, 2 CRBA, 3 collision, 4 constraint rows, 5 velocity/RNE, 6 smooth solve,

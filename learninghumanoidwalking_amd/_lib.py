@@ -76,6 +76,7 @@ def declare(L):
     sig("lhw_env_pop_episode_stats", [vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(i64)])
     sig("lhw_env_set_iteration", [vp, i64])
     sig("lhw_env_pop_fault_stats", [vp, ctypes.POINTER(i64), ctypes.POINTER(i64)])
+    sig("lhw_env_pop_rerun_count", [vp, ctypes.POINTER(i64)])
     sig("lhw_env_phase_cycles", [vp, ctypes.c_int, vp])
     sig("lhw_env_step_range", [vp, i32, i32, vp, vp, vp, vp, vp, vp, vp])
     sig("lhw_ppo_set_imitation", [vp, vp, vp, ctypes.c_float, i64])

@@ -149,6 +149,12 @@ class BatchedEnv:
         _lib.check(self._L.lhw_env_pop_fault_stats(self._h, ctypes.byref(a), ctypes.byref(b)))
         return a.value, b.value
 
+    def pop_rerun_count(self):
+        """Control steps since the last call that needed the one-env-per-wave re-run (more than 8 contacts)."""
+        a = ctypes.c_int64()
+        _lib.check(self._L.lhw_env_pop_rerun_count(self._h, ctypes.byref(a)))
+        return a.value
+
     def debug_step_record(self):
         """Stepping task test hook: (sequence [N,20,6] = x y z theta cos sin, floor_z [N], istate [N,5] = t1 t2 reached frames nseq)."""
         seq = np.zeros((self.n_envs, 20, 6))

@@ -282,6 +282,19 @@ extern "C" int lhw_env_pop_fault_stats(LhwEnv* e, int64_t* contact_overflow, int
   return LHW_OK;
 }
 
+extern "C" int lhw_env_pop_rerun_count(LhwEnv* e, int64_t* reruns) {
+  if (!e) return lhw_fail(LHW_ERR_ARG, "null env");
+  if (reruns) *reruns = 0;
+  if (!e->hum) return LHW_OK;
+  HIPCHK(hipSetDevice(e->device));
+  double h = 0;
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpy(&h, humanoid_ep_stats(e->hum) + 5, sizeof h, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemset(humanoid_ep_stats(e->hum) + 5, 0, sizeof h));
+  if (reruns) *reruns = (int64_t)h;
+  return LHW_OK;
+}
+
 extern "C" int lhw_env_debug_step_record(LhwEnv* e, double* seq, double* floor_z, int32_t* istate) {
   if (!e || !e->hum || e->task != LHW_TASK_JVRC_STEP) return lhw_fail(LHW_ERR_ARG, "step record: not a stepping-task env");
   if (humanoid_step_record(e->hum, seq, floor_z, istate)) return lhw_fail(LHW_ERR_HIP, "step record copy failed");

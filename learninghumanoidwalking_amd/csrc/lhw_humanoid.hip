@@ -241,8 +241,6 @@ struct HumanoidEnv {
 #define NE (L::NE_)      // contact rows = lanes of the group: rows 4c .. 4c+3 belong to contact c
 #define NC (L::NC_)      // contacts kept per sub-step
 #define NV (L::NV_)      // dof width the kernel is compiled for (18 JVRC, 16 H1): sizes the Cholesky, the row products, the LDS matrices
-#define LDV (L::LDV_)    // padded row length of M (odd => conflict-free 64-bit row loads)
-#define NGT (L::NG_)     // geom capacity of the task's layout
 #define U_CDOF (L::U_CDOF_)
 #define U_CINERT (L::U_CINERT_)
 #define U_XMAT (L::U_XMAT_)
@@ -259,37 +257,79 @@ struct HumanoidEnv {
 #define U_CRB (L::U_CRB_)
 #define U_BUF (L::U_BUF_)
 #define U_M (L::U_M_)
+#define U_CDIST (L::U_CDIST_)
+#define U_CMARGIN (L::U_CMARGIN_)
+#define U_CSOLREF (L::U_CSOLREF_)
+#define U_CSOLIMP (L::U_CSOLIMP_)
+#define U_CFRAME (L::U_CFRAME_)
 #define U_J (L::U_J_)
 #define U_L (L::U_L_)
+#define U_VEC (L::U_VEC_)
+#define U_VEC2 (L::U_VEC2_)
+#define U_DG (L::U_DG_)
+#define U_EVEC (L::U_EVEC_)
+#define U_DACT (L::U_DACT_)
+#define TRI(i, j) ((i) * ((i) + 1) / 2 + (j))   // packed lower triangle, row-major (i >= j)
 constexpr int cmax(int a, int b) { return a > b ? a : b; }
+constexpr int even(int a) { return (a + 1) & ~1; }
 
-template <int W_T, bool PRM_T, int NV_T, int NG_T>
+// The layout is a template of the group width (contact / row capacity), the dof width, the geom and body capacities and the
+// task features that need extra state, so that the two-envs-per-wave kernels of the walking / standing tasks stay within
+// 10 KB per env: eight wavefronts = all 4096 envs of the headline batch are resident at once on the 256 CUs.
+template <int W_T, bool PRM_T, int NV_T, int NG_T, int NB_T, bool STEP_T>
 struct LdsT {
   typedef LdsT L;
-  static constexpr int W_ = W_T, NC_ = W_T / 4, NE_ = W_T, NV_ = NV_T, LDV_ = NV_T + 1, NG_ = NG_T;
+  static constexpr int W_ = W_T, NC_ = W_T / 4, NE_ = W_T, NV_ = NV_T, NG_ = NG_T, NB_ = NB_T, TRI_ = NV_T * (NV_T + 1) / 2;
   static constexpr bool PRM_ = PRM_T;   // per-env model parameters are staged in LDS (else read from the model tables)
-  static constexpr int U_CDOF_ = 0, U_CINERT_ = U_CDOF_ + NV_T * 6, X_ = U_CINERT_ + NB * 10;
-  static constexpr int U_XMAT_ = X_, U_XIPOS_ = U_XMAT_ + NB * 9, U_XANCHOR_ = U_XIPOS_ + NB * 3, U_XAXIS_ = U_XANCHOR_ + NJ * 3,
+  static constexpr int U_CDOF_ = 0, U_CINERT_ = U_CDOF_ + NV_T * 6, X_ = U_CINERT_ + NB_T * 10;
+  static constexpr int U_XMAT_ = X_, U_XIPOS_ = U_XMAT_ + NB_T * 9, U_XANCHOR_ = U_XIPOS_ + NB_T * 3, U_XAXIS_ = U_XANCHOR_ + NJ * 3,
                        U_GPOS_ = U_XAXIS_ + NJ * 3, U_GMAT_ = U_GPOS_ + NG_T * 3, END_A_ = U_GMAT_ + NG_T * 9;
-  static constexpr int U_CDOFDOT_ = X_, U_CVEL_ = U_CDOFDOT_ + NV_T * 6, U_CACC_ = U_CVEL_ + NB * 6, END_B1_ = U_CACC_ + NB * 6;
-  static constexpr int U_CRB_ = X_, U_BUF_ = U_CRB_ + NB * 10, U_M_ = U_BUF_ + NV_T * 6, END_B2_ = U_M_ + NV_T * (NV_T + 1);
-  static constexpr int U_J_ = U_CINERT_, U_L_ = U_J_ + W_T * NV_T, END_C_ = U_L_ + NV_T * NV_T;   // J rows and L rows are NV long (16-byte aligned rows)
-  static constexpr int USIZE_ = cmax(cmax(END_A_, END_B1_), cmax(END_B2_, END_C_));
+  static constexpr int U_CDOFDOT_ = X_, U_CVEL_ = U_CDOFDOT_ + NV_T * 6, U_CACC_ = U_CVEL_ + NB_T * 6, END_B1_ = U_CACC_ + NB_T * 6;
+  static constexpr int U_CRB_ = X_, U_BUF_ = U_CRB_ + NB_T * 10, U_M_ = U_BUF_ + NV_T * 6, END_B2_ = U_M_ + TRI_;
+  // contact records that only feed the Jacobian / row parameters: written by the collision stage, live across stage B,
+  // dead once the rows are built (the solver's vectors and the Cholesky rows then reuse the space)
+  static constexpr int U_J_ = U_CINERT_, U_L_ = U_J_ + W_T * NV_T;
+  static constexpr int U_CDIST_ = even(cmax(cmax(cmax(END_A_, END_B1_), END_B2_), U_L_)), U_CMARGIN_ = U_CDIST_ + NC_, U_CSOLREF_ = U_CMARGIN_ + NC_,
+                       U_CSOLIMP_ = U_CSOLREF_ + 2 * NC_, U_CFRAME_ = U_CSOLIMP_ + 5 * NC_, END_CON_ = U_CFRAME_ + 9 * NC_;   // (beyond J: they feed its rows)
+  static constexpr int U_VEC_ = even(U_L_ + TRI_), U_VEC2_ = U_VEC_ + NV_T, U_DG_ = U_VEC2_ + NV_T,
+                       U_EVEC_ = U_DG_ + NV_T, U_DACT_ = U_EVEC_ + W_T, END_C_ = U_DACT_ + W_T;   // J rows are NV long (16-byte aligned)
+  static constexpr int USIZE_ = even(cmax(END_CON_, END_C_));
   double qpos[NQ], qvel[NV_T], ctrl[NU];
-  double xpos[NB * 3];
+  double xpos[NB_T * 3];
   double rootmat[9], com[4], svel[18];   // root xmat; tree com; cvel of the three tracked bodies (root, right foot, left foot)
-  double spos[9], rootquat[4];           // world position of the tracked points (body origin + local offset); root xquat
-  double vec[NV_T], vec2[NV_T], evec[W_T], dact[W_T], dg[NV_T];
+  double spos[STEP_T ? 9 : 1], rootquat[STEP_T ? 4 : 1];   // stepping task: world position of the tracked points (body origin + local offset); root xquat
   double qacc[NV_T];
   double efc_force[W_T];
-  double con_dist[NC_], con_pos[NC_ * 3], con_frame[NC_ * 9], con_mu[NC_], con_solref[NC_ * 2], con_solimp[NC_ * 5], con_margin[NC_];
+  double con_pos[NC_ * 3], con_mu[NC_];
   int con_g1[NC_], con_g2[NC_], con_dim[NC_];
   double sq[NU], sv[NU], frc[NU];
   // per-env parameters, loaded once per launch (one-element stubs when the task reads the shared model tables instead)
-  double damp[PRM_T ? NV_T : 1], floss[PRM_T ? NV_T : 1], bmass[PRM_T ? NB : 1], bipos[PRM_T ? NB * 3 : 1], xfrc[PRM_T ? 12 : 1];
+  double damp[PRM_T ? NV_T : 1], floss[PRM_T ? NV_T : 1], bmass[PRM_T ? NB_T : 1], bipos[PRM_T ? NB_T * 3 : 1], xfrc[PRM_T ? 12 : 1];
   alignas(16) double U[USIZE_];
+  // episode / task context of the env (home of these values during the launch: nothing of it is held in registers across a sub-step)
+  double cmode_ref[3], cep_ret;
+  int ci[12];
   int ncon, overflow;
 };
+enum { CI_PHASE = 0, CI_MODE, CI_TRAJ, CI_STARTED, CI_STEPCNT, CI_RESETCNT, CI_OBSCNT, CI_T1, CI_T2, CI_REACHED, CI_FRAMES, CI_NSEQ };
+#define CTX_LOAD()                                                                                                     \
+  double mode_ref[3] = {S.cmode_ref[0], S.cmode_ref[1], S.cmode_ref[2]};                                               \
+  double ep_ret = S.cep_ret;                                                                                           \
+  int phase = S.ci[CI_PHASE], mode = S.ci[CI_MODE], traj_len = S.ci[CI_TRAJ], started = S.ci[CI_STARTED];              \
+  unsigned step_count = (unsigned)S.ci[CI_STEPCNT], reset_count = (unsigned)S.ci[CI_RESETCNT], obs_count = (unsigned)S.ci[CI_OBSCNT]; \
+  int t1 = S.ci[CI_T1], t2 = S.ci[CI_T2], reached = S.ci[CI_REACHED], frames = S.ci[CI_FRAMES], nseq = S.ci[CI_NSEQ];  \
+  double goal[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define CTX_STORE()                                                                                                    \
+  do {                                                                                                                 \
+    SYNC();                                                                                                            \
+    if (lane == 0) {                                                                                                   \
+      S.cmode_ref[0] = mode_ref[0]; S.cmode_ref[1] = mode_ref[1]; S.cmode_ref[2] = mode_ref[2]; S.cep_ret = ep_ret;    \
+      S.ci[CI_PHASE] = phase; S.ci[CI_MODE] = mode; S.ci[CI_TRAJ] = traj_len; S.ci[CI_STARTED] = started;              \
+      S.ci[CI_STEPCNT] = (int)step_count; S.ci[CI_RESETCNT] = (int)reset_count; S.ci[CI_OBSCNT] = (int)obs_count;      \
+      S.ci[CI_T1] = t1; S.ci[CI_T2] = t2; S.ci[CI_REACHED] = reached; S.ci[CI_FRAMES] = frames; S.ci[CI_NSEQ] = nseq;  \
+    }                                                                                                                  \
+    SYNC();                                                                                                            \
+  } while (0)
 
 // The lanes of a group belong to one wavefront, and a wave's LDS instructions execute in issue order, so cross-lane
 // hand-offs through LDS need no hardware barrier and no s_waitcnt: __syncthreads() would add a workgroup-scope fence, i.e.
@@ -438,12 +478,12 @@ __device__ __forceinline__ void inert_vec(double* r, const double* i, const doub
 
 // ------------------------------------------------------------------------------------------------ dense SPD solve, group-parallel
 // x <- A^-1 x.  Lane i of the group holds the off-diagonal part of row i of the SPD matrix in registers (r[0..NV); the
-// diagonal entry of r is ignored) and element i of x; the diagonal is published in LDS (dg) by the caller-supplied scalar
-// `diag`.  Left-looking Cholesky: column step J needs row J of L, which lane J has published in the LDS array Lb
-// (row-major NV x NV, 16-byte aligned rows) during the previous steps: every lane fetches it with broadcast reads and
-// computes its own L[i][J] and -- redundantly, from the published diagonal -- the pivot, so nothing has to be broadcast
-// out of a register inside the column chain (one v_readlane pair per element in the first version of this kernel), and
-// the same published rows serve the transposed access of the backward substitution.  Lanes >= NV shadow row NV-1.
+// diagonal entry of r is ignored) and element i of x; the diagonal is published in LDS (dg) from the caller-supplied scalar
+// `diag`.  Left-looking Cholesky: column step J needs row J of L, which lane J has published in the LDS array Lb (packed
+// lower triangle, row-major) during the previous steps: every lane fetches it with broadcast reads and computes its own
+// L[i][J] and -- redundantly, from the published diagonal -- the pivot, so nothing has to be broadcast out of a register
+// inside the column chain (one v_readlane pair per element in the first version of this kernel), and the same published
+// rows serve the transposed access of the backward substitution.  Lanes >= NV shadow row NV-1.
 // The loops are fully unrolled over the compile-time bound NV so the row stays in VGPRs.
 template <class L, int J>
 __device__ __forceinline__ void chol_col(double (&r)[NV], double (&invd)[NV], double& myinvd, double* Lb, const double* dg, int lane) {
@@ -451,11 +491,11 @@ __device__ __forceinline__ void chol_col(double (&r)[NV], double (&invd)[NV], do
     double s0 = r[J], s1 = 0.0, p0 = dg[J], p1 = 0.0;
 #pragma unroll
     for (int p = 0; p + 1 < J; p += 2) {
-      const double2 ab = *reinterpret_cast<const double2*>(&Lb[J * NV + p]);
-      s0 -= r[p] * ab.x; p0 -= ab.x * ab.x;
-      s1 -= r[p + 1] * ab.y; p1 -= ab.y * ab.y;
+      const double a = Lb[TRI(J, p)], b = Lb[TRI(J, p + 1)];
+      s0 -= r[p] * a; p0 -= a * a;
+      s1 -= r[p + 1] * b; p1 -= b * b;
     }
-    if (J & 1) { const double a = Lb[J * NV + J - 1]; s0 -= r[J - 1] * a; p0 -= a * a; }
+    if (J & 1) { const double a = Lb[TRI(J, J - 1)]; s0 -= r[J - 1] * a; p0 -= a * a; }
     const double piv = fmax(p0 + p1, HMINVAL);
     double id = __builtin_amdgcn_rsq(piv);
     id = id * (1.5 - 0.5 * piv * id * id);
@@ -464,7 +504,7 @@ __device__ __forceinline__ void chol_col(double (&r)[NV], double (&invd)[NV], do
     const double lij = (lane == J) ? piv * id : (s0 + s1) * id;
     r[J] = lij;
     if (lane == J) myinvd = id;
-    if (lane < NV) Lb[lane * NV + J] = lij;   // lanes < J publish don't-care values into the upper triangle, which nothing reads
+    if (lane >= J && lane < NV) Lb[TRI(lane, J)] = lij;
     SYNC();
     chol_col<L, J + 1>(r, invd, myinvd, Lb, dg, lane);
   }
@@ -489,7 +529,7 @@ __device__ __forceinline__ double chol_solve(double (&r)[NV], double diag, doubl
   const int cl = lane < NV ? lane : NV - 1;
   double col[NV];
 #pragma unroll
-  for (int j = 0; j < NV; j++) col[j] = Lb[j * NV + cl];
+  for (int j = 0; j < NV; j++) col[j] = Lb[TRI(j, (cl < j ? cl : j))];   // (entries with j < lane are never used)
 #pragma unroll
   for (int j = NV - 1; j >= 0; j--) {
     const double c = (lane < j) ? col[j] * invd[j] : 0.0;
@@ -555,7 +595,7 @@ __device__ void fwd_kinematics(const HModel& m, L& S, int lane) {
       if (jt == JT_FREE) {
         double q[4] = {S.qpos[qa + 3], S.qpos[qa + 4], S.qpos[qa + 5], S.qpos[qa + 6]};
         normalize4(q);
-        for (int k = 0; k < 4; k++) { S.qpos[qa + 3 + k] = q[k]; if (STEPT) S.rootquat[k] = q[k]; }
+        for (int k = 0; k < 4; k++) { S.qpos[qa + 3 + k] = q[k]; if constexpr (STEPT) S.rootquat[k] = q[k]; }
         quat2mat(R, q);
         for (int k = 0; k < 3; k++) { xp[k] = S.qpos[qa + k]; S.U[U_XANCHOR + 3 * ja + k] = xp[k]; S.U[U_XAXIS + 3 * ja + k] = kd[BD_JAXIS + k]; }
       } else {
@@ -604,7 +644,7 @@ __device__ void fwd_kinematics(const HModel& m, L& S, int lane) {
     ci[5] = Ri[3] * I0 * Ri[6] + Ri[4] * I1 * Ri[7] + Ri[5] * I2 * Ri[8];
   }
   if (lane < 9) S.rootmat[lane] = S.U[U_XMAT + 9 * 1 + lane];
-  if (STEPT && lane < 3) {  // tracked points (foot force sites): body origin + R * local offset, lane = point
+  if constexpr (STEPT) if (lane < 3) {  // tracked points (foot force sites): body origin + R * local offset, lane = point
     const int tb = lane == 0 ? m.track_body[0] : (lane == 1 ? m.track_body[1] : m.track_body[2]);
     const double off[3] = {lane == 0 ? m.track_off[0] : (lane == 1 ? m.track_off[3] : m.track_off[6]),
                            lane == 0 ? m.track_off[1] : (lane == 1 ? m.track_off[4] : m.track_off[7]),
@@ -687,9 +727,7 @@ __device__ void fwd_crb(const HModel& m, L& S, int lane) {
     if (b >= 1) for (int d = b; d < m.body_i[BIS * (b) + BI_SUBEND]; d++) s += S.U[U_CINERT + 10 * d + k];
     S.U[U_CRB + it] = s;
   }
-  for (int it = lane; it < NV * LDV; it += L::W_) {
-    S.U[U_M + it] = 0.0;
-  }
+  for (int it = lane; it < L::TRI_; it += L::W_) S.U[U_M + it] = 0.0;   // packed lower triangle
   SYNC();
   // buf_i = crb[body(i)] * cdof_i (6 per dof)
   if (lane < NV) {
@@ -703,8 +741,7 @@ __device__ void fwd_crb(const HModel& m, L& S, int lane) {
     double s = 0;
     for (int a = 0; a < 6; a++) s += S.U[U_CDOF + 6 * j + a] * S.U[U_BUF + 6 * i + a];
     if (i == j) s += m.dof_d[DDS * (i) + DD_ARMATURE];
-    S.U[U_M + i * LDV + j] = s;
-    S.U[U_M + j * LDV + i] = s;
+    S.U[U_M + TRI(i, j)] = s;   // j is an ancestor dof of i or i itself: j <= i
   }
   SYNC();
 }
@@ -790,7 +827,7 @@ struct ConSink {
       const int c = base + n;
       if (c < NC) {
         L& Z = *S;
-        Z.con_dist[c] = dist;
+        Z.U[U_CDIST + c] = dist;
         double f[9];
         for (int a = 0; a < 3; a++) { Z.con_pos[3 * c + a] = pos[a]; f[a] = nrm[a]; f[3 + a] = tan[a]; }
         // mju_makeFrame
@@ -803,7 +840,7 @@ struct ConSink {
         for (int a = 0; a < 3; a++) f[3 + a] -= tt * f[a];
         normalize3(f + 3);
         cross3(f + 6, f, f + 3);
-        for (int a = 0; a < 9; a++) Z.con_frame[9 * c + a] = f[a];
+        for (int a = 0; a < 9; a++) Z.U[U_CFRAME + 9 * c + a] = f[a];
         Z.con_g1[c] = g1; Z.con_g2[c] = g2;
       }
     }
@@ -1190,11 +1227,11 @@ __device__ void fwd_collision(const HModel& m, const HParams& p, L& S, int lane,
       for (int a = 0; a < 5; a++) si[a] = mix * m.geom_d[GDS * (g1) + GD_SOLIMP + a] + (1 - mix) * m.geom_d[GDS * (g2) + GD_SOLIMP + a];
       mu = fmax(m.geom_d[GDS * (g1) + GD_FRICTION], m.geom_d[GDS * (g2) + GD_FRICTION]);
     }
-    S.con_margin[c] = incm;
-    S.con_dim[c] = (S.con_dist[c] >= incm) ? 0 : dim;  // 0: excluded from the constraint set (gap)
+    S.U[U_CMARGIN + c] = incm;
+    S.con_dim[c] = (S.U[U_CDIST + c] >= incm) ? 0 : dim;  // 0: excluded from the constraint set (gap)
     S.con_mu[c] = mu;
-    S.con_solref[2 * c] = sr[0]; S.con_solref[2 * c + 1] = sr[1];
-    for (int a = 0; a < 5; a++) S.con_solimp[5 * c + a] = si[a];
+    S.U[U_CSOLREF + 2 * c] = sr[0]; S.U[U_CSOLREF + 2 * c + 1] = sr[1];
+    for (int a = 0; a < 5; a++) S.U[U_CSOLIMP + 5 * c + a] = si[a];
   }
   SYNC();
 }
@@ -1285,8 +1322,8 @@ __device__ __forceinline__ void substep(const HModel& m, const HParams& p, L& S,
   const int ld = lane < NV ? lane : NV - 1;
   double Mrow[NV];
 #pragma unroll
-  for (int k = 0; k < NV; k++) Mrow[k] = S.U[U_M + ld * LDV + k];
-  const double mdiag = S.U[U_M + ld * LDV + ld];
+  for (int k = 0; k < NV; k++) Mrow[k] = S.U[U_M + (k <= ld ? TRI(ld, k) : TRI(k, ld))];
+  const double mdiag = S.U[U_M + TRI(ld, ld)];
   SYNC();
   PROF_MARK(2);
   // ---- contact Jacobian, item = (contact, dof): rows 4c .. 4c+3 = Jn +- mu Jt1, Jn +- mu Jt2 (condim 1: row 4c = Jn)
@@ -1304,7 +1341,7 @@ __device__ __forceinline__ void substep(const HModel& m, const HParams& p, L& S,
       const double sg = in2 ? 1.0 : -1.0;
       for (int a = 0; a < 3; a++) d[a] = sg * (S.U[U_CDOF + 6 * k + 3 + a] + t[a]);
     }
-    const double* f = &S.con_frame[9 * c];
+    const double* f = &S.U[U_CFRAME + 9 * c];
     const double jn = dot3(f, d);
     const bool pyr = S.con_dim[c] != 1;
     const double mu = S.con_mu[c], t1 = mu * dot3(f + 3, d), t2 = mu * dot3(f + 6, d);
@@ -1316,26 +1353,35 @@ __device__ __forceinline__ void substep(const HModel& m, const HParams& p, L& S,
   }
   SYNC();
   // ---- contact rows (lane = row): Jacobian row -> registers, impedance / regulariser / reference acceleration
-  double Jrow[NV];
+  // (the row is re-read from LDS for each product instead of being held across the factorisations: 36 VGPRs that the
+  // Cholesky needs more)
+  auto jrow_dot = [&](const double* v) {
+    double Jrow[NV];
+#pragma unroll
+    for (int k = 0; k < NV; k += 2) {
+      const double2 ab = *reinterpret_cast<const double2*>(&S.U[U_J + lane * NV + k]);
+      Jrow[k] = ab.x; Jrow[k + 1] = ab.y;
+    }
+    const double d = row_dot<L>(Jrow, v);
+    return lane < nrow ? d : 0.0;   // rows beyond the last contact are not initialised
+  };
   bool isrow = false;
   double D = 0, aref = 0;
   {
     const bool have = lane < nrow;
-#pragma unroll
-    for (int k = 0; k < NV; k++) { const double v = S.U[U_J + lane * NV + k]; Jrow[k] = have ? v : 0.0; }
     const int c = have ? (lane >> 2) : 0, e = lane & 3, dim = S.con_dim[c];
     isrow = have && (dim == 3 || (dim == 1 && e == 0));
-    const double jv0 = row_dot<L>(Jrow, S.qvel);
+    const double jv0 = jrow_dot(S.qvel);
     if (isrow) {
       const int b1 = m.geom_i[GIS * (S.con_g1[c]) + GI_BODY], b2 = m.geom_i[GIS * (S.con_g2[c]) + GI_BODY];
       const double tran = m.body_d[BDS * (b1) + BD_INVW] + m.body_d[BDS * (b2) + BD_INVW];
       const double mu = S.con_mu[c];
       double K, B, imp, R;
       const double diag = dim == 1 ? tran : tran + mu * mu * tran;
-      row_params(m, &S.con_solref[2 * c], &S.con_solimp[5 * c], S.con_dist[c], S.con_margin[c], diag, &K, &B, &imp, &R);
+      row_params(m, &S.U[U_CSOLREF + 2 * c], &S.U[U_CSOLIMP + 5 * c], S.U[U_CDIST + c], S.U[U_CMARGIN + c], diag, &K, &B, &imp, &R);
       if (dim == 3) R = fmax(HMINVAL, 2 * mu * mu * R);  // every pyramid edge shares 2 mu^2 R(first edge)
       D = 1 / R;
-      aref = -B * jv0 - K * imp * (S.con_dist[c] - S.con_margin[c]);
+      aref = -B * jv0 - K * imp * (S.U[U_CDIST + c] - S.U[U_CMARGIN + c]);
     }
   }
   // ---- unit rows of dof `lane`: slot 0 frictionloss (Huber), 1 lower limit (J = +1), 2 upper limit (J = -1)
@@ -1403,7 +1449,7 @@ __device__ __forceinline__ void substep(const HModel& m, const HParams& p, L& S,
     double r[NV];
 #pragma unroll
     for (int k = 0; k < NV; k++) r[k] = Mrow[k];
-    as = chol_solve<L>(r, mdiag, Lb, S.dg, lane, fs);
+    as = chol_solve<L>(r, mdiag, Lb, S.U + U_DG, lane, fs);
   }
   PROF_MARK(12);
   double qacc = as, fcon = 0;  // lane = dof
@@ -1424,9 +1470,9 @@ __device__ __forceinline__ void substep(const HModel& m, const HParams& p, L& S,
     if (!(m.disableflags & (1 << 7))) {
       const double w = *warm;
       SYNC();
-      if (lane < NV) { S.vec[lane] = w; S.vec2[lane] = as; }
+      if (lane < NV) { S.U[U_VEC + lane] = w; S.U[U_VEC2 + lane] = as; }
       SYNC();
-      const double jw = row_dot<L>(Jrow, S.vec), Ma = row_dot<L>(Mrow, S.vec), js = row_dot<L>(Jrow, S.vec2);
+      const double jw = jrow_dot(S.U + U_VEC), Ma = row_dot<L>(Mrow, S.U + U_VEC), js = jrow_dot(S.U + U_VEC2);
       double cw, cs0, tf, td, tu, tv;
       eval_rows(jw, w, &cw, &tf, &td, &tu, &tv);
       eval_rows(js, as, &cs0, &tf, &td, &tu, &tv);
@@ -1438,25 +1484,25 @@ __device__ __forceinline__ void substep(const HModel& m, const HParams& p, L& S,
     double cost = 0, oldcost = 0;
     for (int iter = 0; iter <= m.iterations; iter++) {
       SYNC();
-      if (lane < NV) S.vec[lane] = qacc;
+      if (lane < NV) S.U[U_VEC + lane] = qacc;
       SYNC();
-      const double ja = row_dot<L>(Jrow, S.vec), Ma = row_dot<L>(Mrow, S.vec);
+      const double ja = jrow_dot(S.U + U_VEC), Ma = row_dot<L>(Mrow, S.U + U_VEC);
       double c, force, dactive, ufrc, udact;
       eval_rows(ja, qacc, &c, &force, &dactive, &ufrc, &udact);
       if (lane < NV) c += 0.5 * (Ma - fs) * (qacc - as);
       oldcost = cost;
       cost = gsum<W>(c);
-      S.evec[lane] = force; S.efc_force[lane] = force; S.dact[lane] = dactive;   // lane = contact row (NE == W)
+      S.U[U_EVEC + lane] = force; S.efc_force[lane] = force; S.U[U_DACT + lane] = dactive;   // lane = contact row (NE == W)
       SYNC();
       double grad = 0;
       fcon = 0;
       {
         double f0 = 0, f1 = 0, f2 = 0, f3 = 0;
         for (int r = 0; r < nrow; r += 4) {   // whole contacts: nrow is a multiple of 4
-          f0 += S.U[U_J + r * NV + ld] * S.evec[r];
-          f1 += S.U[U_J + (r + 1) * NV + ld] * S.evec[r + 1];
-          f2 += S.U[U_J + (r + 2) * NV + ld] * S.evec[r + 2];
-          f3 += S.U[U_J + (r + 3) * NV + ld] * S.evec[r + 3];
+          f0 += S.U[U_J + r * NV + ld] * S.U[U_EVEC + r];
+          f1 += S.U[U_J + (r + 1) * NV + ld] * S.U[U_EVEC + r + 1];
+          f2 += S.U[U_J + (r + 2) * NV + ld] * S.U[U_EVEC + r + 2];
+          f3 += S.U[U_J + (r + 3) * NV + ld] * S.U[U_EVEC + r + 3];
         }
         if (lane < NV) {
           fcon = ((f0 + f1) + (f2 + f3)) + ufrc;
@@ -1473,7 +1519,7 @@ __device__ __forceinline__ void substep(const HModel& m, const HParams& p, L& S,
 #pragma unroll
       for (int k = 0; k < NV; k++) Hrow[k] = Mrow[k];
       for (int r = 0; r < nrow; r++) {
-        const double jl = S.U[U_J + r * NV + ld], cj = S.dact[r] * jl;
+        const double jl = S.U[U_J + r * NV + ld], cj = S.U[U_DACT + r] * jl;
         hd += cj * jl;
 #pragma unroll
         for (int k = 0; k < NV; k += 2) {
@@ -1482,10 +1528,10 @@ __device__ __forceinline__ void substep(const HModel& m, const HParams& p, L& S,
           Hrow[k + 1] += cj * ab.y;
         }
       }
-      const double search = -chol_solve<L>(Hrow, hd, Lb, S.dg, lane, grad);
-      if (lane < NV) S.vec2[lane] = search;
+      const double search = -chol_solve<L>(Hrow, hd, Lb, S.U + U_DG, lane, grad);
+      if (lane < NV) S.U[U_VEC2 + lane] = search;
       SYNC();
-      const double jv = row_dot<L>(Jrow, S.vec2), Mv = row_dot<L>(Mrow, S.vec2);
+      const double jv = jrow_dot(S.U + U_VEC2), Mv = row_dot<L>(Mrow, S.U + U_VEC2);
       const double qg1 = gsum<W>(lane < NV ? search * (Ma - fs) : 0.0);
       const double qg2 = gsum<W>(lane < NV ? 0.5 * search * Mv : 0.0);
       // exact line search on the convex piecewise-quadratic: safeguarded Newton on its derivative
@@ -1541,7 +1587,7 @@ __device__ __forceinline__ void substep(const HModel& m, const HParams& p, L& S,
 #pragma unroll
     for (int k = 0; k < NV; k++) r[k] = Mrow[k];
     const double dm = lane < NV ? prm_damp(m, S, lane) : 0.0;
-    anew = chol_solve<L>(r, mdiag + h * dm, Lb, S.dg, lane, fs + fcon);
+    anew = chol_solve<L>(r, mdiag + h * dm, Lb, S.U + U_DG, lane, fs + fcon);
   }
   PROF_MARK(13);
   if (lane < NV) S.qvel[lane] = qv + h * anew;
@@ -1693,7 +1739,10 @@ __global__ void __launch_bounds__(64, 2) humanoid_kernel(HModel m, HParams p, HS
                                                       float* __restrict__ rew, unsigned char* __restrict__ done_out,
                                                       float* __restrict__ rew_terms, const unsigned char* __restrict__ mask,
                                                       double* __restrict__ xq, double* __restrict__ xv) {
-  using L = LdsT<W, TASK != TASK_STEP, ((TASK == TASK_STAND || TASK == TASK_H1WALK) ? 16 : 18), (TASK == TASK_STEP ? 32 : 16)>;
+  // H1 tasks: 16 dofs, per-env model parameters (domain randomisation); stepping task: 32 geoms, foot sites; the
+  // two-envs-per-wave layouts are sized for the robots' own body counts (JVRC 18, H1 15; humanoid_create checks)
+  using L = LdsT<W, (TASK == TASK_STAND || TASK == TASK_H1WALK), ((TASK == TASK_STAND || TASK == TASK_H1WALK) ? 16 : 18),
+                 ((TASK == TASK_STEP || W == 64) ? NG : 16), (W == 64 ? NB : ((TASK == TASK_STAND || TASK == TASK_H1WALK) ? 15 : 18)), TASK == TASK_STEP>;
   constexpr int G = 64 / W;   // envs per wavefront
   __shared__ L SG[G];
   L& S = SG[group_id<W>()];
@@ -1720,22 +1769,25 @@ __global__ void __launch_bounds__(64, 2) humanoid_kernel(HModel m, HParams p, HS
     if (lane < NV) xv[(size_t)env * NV + lane] = rec[R_QVEL + lane];
     return;
   }
-  // ---- load the persistent record (lane-strided)
-  double warm = 0, prevpred = 0, prevact = 0, prevtq = 0;
+  // ---- load the persistent record (lane-strided); the episode / task context goes to its LDS home
+  double warm = 0;
   if (lane < m.nq) S.qpos[lane] = rec[R_QPOS + lane];
   if (lane < NV) { S.qvel[lane] = rec[R_QVEL + lane]; warm = rec[R_WARM + lane]; }
   if (lane < m.nu) {
     S.sq[lane] = rec[R_SQ + lane]; S.sv[lane] = rec[R_SV + lane]; S.frc[lane] = rec[R_FRC + lane];
-    prevpred = rec[R_PREVPRED + lane]; prevact = rec[R_PREVACT + lane]; prevtq = rec[R_PREVTQ + lane];
     S.ctrl[lane] = 0;
   }
-  double mode_ref[3] = {rec[R_MODEREF], rec[R_MODEREF + 1], rec[R_MODEREF + 2]};
-  double ep_ret = rec[R_EPRET];
-  int phase = irec[RI_PHASE], mode = irec[RI_MODE], traj_len = irec[RI_TRAJ], started = irec[RI_STARTED];
-  unsigned step_count = (unsigned)irec[RI_STEPCNT], reset_count = (unsigned)irec[RI_RESETCNT], obs_count = (unsigned)irec[RI_OBSCNT];
-  int t1 = 0, t2 = 0, reached = 0, frames = 0, nseq = 2;
-  double goal[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  if (TASK == TASK_STEP) { t1 = irec[RI_T1]; t2 = irec[RI_T2]; reached = irec[RI_REACHED]; frames = irec[RI_FRAMES]; nseq = irec[RI_NSEQ]; }
+  if (lane < 3) S.cmode_ref[lane] = rec[R_MODEREF + lane];
+  if (lane == 3) S.cep_ret = rec[R_EPRET];
+  if (lane < 12) {
+    // CI_* order: phase mode traj started stepcnt resetcnt obscnt t1 t2 reached frames nseq
+    const int src = lane == CI_PHASE ? RI_PHASE : lane == CI_MODE ? RI_MODE : lane == CI_TRAJ ? RI_TRAJ : lane == CI_STARTED ? RI_STARTED
+                  : lane == CI_STEPCNT ? RI_STEPCNT : lane == CI_RESETCNT ? RI_RESETCNT : lane == CI_OBSCNT ? RI_OBSCNT : lane == CI_T1 ? RI_T1
+                  : lane == CI_T2 ? RI_T2 : lane == CI_REACHED ? RI_REACHED : lane == CI_FRAMES ? RI_FRAMES : RI_NSEQ;
+    int v = irec[src];
+    if (TASK != TASK_STEP && lane >= CI_T1) v = lane == CI_NSEQ ? 2 : 0;
+    S.ci[lane] = v;
+  }
   // per-env model parameters (or the shared defaults) -> LDS, once per launch
   if constexpr (L::PRM_) {
     if (lane < NV) {
@@ -1764,12 +1816,9 @@ __global__ void __launch_bounds__(64, 2) humanoid_kernel(HModel m, HParams p, HS
     SYNC();
   }
   // ---- BaseHumanoidEnv.step: smoothing, offsets (base_humanoid_env.py:209-215); RobotBase.step (robot_base.py:64-98)
-  double target = 0, a_raw = 0;
-  if (MODE == 0 && lane < m.nu) {
-    a_raw = (double)act[(size_t)env * m.nu + lane];
-    target = p.action_smoothing * a_raw + (1 - p.action_smoothing) * prevpred + p.action_offset[lane];
-    if (!started) { prevact = target; prevtq = S.frc[lane] * m.act_d[ADS * (lane) + AD_GEAR]; }
-  }
+  double target = 0;
+  if (MODE == 0 && lane < m.nu)
+    target = p.action_smoothing * (double)act[(size_t)env * m.nu + lane] + (1 - p.action_smoothing) * rec[R_PREVPRED + lane] + p.action_offset[lane];
   for (;;) {
     int flags = 3;
     if (stage == ST_CONTROL) {
@@ -1783,6 +1832,15 @@ __global__ void __launch_bounds__(64, 2) humanoid_kernel(HModel m, HParams p, HS
         kstep++;
       } else {
         bool do_reset = false;
+        CTX_LOAD();
+        double a_raw = 0, prevact = 0, prevtq = 0, prevpred = 0;
+        if (lane < m.nu) {
+          a_raw = (double)act[(size_t)env * m.nu + lane];
+          prevact = rec[R_PREVACT + lane]; prevtq = rec[R_PREVTQ + lane];
+          // prev_action / prev_torque are initialised once, on the first step ever (robot_base.py:82-85), from the fields of
+          // the forward pass that preceded this control step (the record still holds them)
+          if (!started) { prevact = target; prevtq = rec[R_FRC + lane] * m.act_d[ADS * (lane) + AD_GEAR]; }
+        }
         PROF_MARK(9);  // control-step prologue (load, PD) is folded into slot 9 with the sub-step loop overheads
         double r_sum = 0, terms[10], cur_tq = 0;
         bool terminated = false;
@@ -2044,12 +2102,16 @@ __global__ void __launch_bounds__(64, 2) humanoid_kernel(HModel m, HParams p, HS
           if (lane == 0) { atomicAdd(&st.ep_stats[0], ep_ret); atomicAdd(&st.ep_stats[1], (double)traj_len); atomicAdd(&st.ep_stats[2], 1.0); }
           do_reset = true;
         }
+        if (lane < m.nu) { rec[R_PREVPRED + lane] = prevpred; rec[R_PREVACT + lane] = prevact; rec[R_PREVTQ + lane] = prevtq; }
+        CTX_STORE();
         committed = true;
         stage = do_reset ? ST_RESET : ST_END;
       }
     } else if (stage == ST_SETTLE) {
       if (kstep < 3) kstep++;   // three settle steps, ctrl = 0
       else {
+        CTX_LOAD();
+        double prevpred = 0;
         if (WALKT) {
           // WalkingTask.reset (walking_task.py:194-205): slot 0 mode, 1..3 mode_ref, 4 phase (+100 for h1_walk)
           const double u = lhw_rng_u01(p.seed, genv, LHW_STREAM_RESET, reset_count, WS + 0);
@@ -2140,10 +2202,13 @@ __global__ void __launch_bounds__(64, 2) humanoid_kernel(HModel m, HParams p, HS
           if (TASK == TASK_H1WALK && obs) write_obs_walk_ext(p, lane, phase, mode, mode_ref, obs + (size_t)env * OBS + 35);
           obs_count++;
         }
+        if (lane < m.nu) rec[R_PREVPRED + lane] = prevpred;
+        CTX_STORE();
         stage = ST_END;
       }
     }
-    if (stage == ST_RESET) {   // (an env whose episode just ended enters here in the same pass)
+    if (stage == ST_RESET) {
+      const unsigned reset_count = (unsigned)S.ci[CI_RESETCNT];   // (an env whose episode just ended enters here in the same pass)
       // ---- MujocoEnv.reset + BaseHumanoidEnv.reset_model (mujoco_env.py:113-127, base_humanoid_env.py:247-276)
       SYNC();
       if (lane < m.nq) S.qpos[lane] = p.nominal_qpos[lane];
@@ -2190,18 +2255,16 @@ __global__ void __launch_bounds__(64, 2) humanoid_kernel(HModel m, HParams p, HS
   SYNC();
   if (lane < m.nq) rec[R_QPOS + lane] = S.qpos[lane];
   if (lane < NV) { rec[R_QVEL + lane] = S.qvel[lane]; rec[R_WARM + lane] = warm; }
-  if (lane < m.nu) {
-    rec[R_SQ + lane] = S.sq[lane]; rec[R_SV + lane] = S.sv[lane]; rec[R_FRC + lane] = S.frc[lane];
-    rec[R_PREVPRED + lane] = prevpred; rec[R_PREVACT + lane] = prevact; rec[R_PREVTQ + lane] = prevtq;
+  if (lane < m.nu) { rec[R_SQ + lane] = S.sq[lane]; rec[R_SV + lane] = S.sv[lane]; rec[R_FRC + lane] = S.frc[lane]; }
+  if (lane < 3) rec[R_MODEREF + lane] = S.cmode_ref[lane];
+  if (lane == 3) rec[R_EPRET] = S.cep_ret;
+  if (lane < (TASK == TASK_STEP ? 12 : 7)) {
+    const int dst = lane == CI_PHASE ? RI_PHASE : lane == CI_MODE ? RI_MODE : lane == CI_TRAJ ? RI_TRAJ : lane == CI_STARTED ? RI_STARTED
+                  : lane == CI_STEPCNT ? RI_STEPCNT : lane == CI_RESETCNT ? RI_RESETCNT : lane == CI_OBSCNT ? RI_OBSCNT : lane == CI_T1 ? RI_T1
+                  : lane == CI_T2 ? RI_T2 : lane == CI_REACHED ? RI_REACHED : lane == CI_FRAMES ? RI_FRAMES : RI_NSEQ;
+    irec[dst] = S.ci[lane];
   }
-  if (lane == 0) {
-    if (MODE == 0 && p.only_flagged) st.slow[env] = 0;
-    rec[R_MODEREF] = mode_ref[0]; rec[R_MODEREF + 1] = mode_ref[1]; rec[R_MODEREF + 2] = mode_ref[2];
-    rec[R_EPRET] = ep_ret;
-    irec[RI_PHASE] = phase; irec[RI_MODE] = mode; irec[RI_TRAJ] = traj_len; irec[RI_STARTED] = started;
-    irec[RI_STEPCNT] = (int)step_count; irec[RI_RESETCNT] = (int)reset_count; irec[RI_OBSCNT] = (int)obs_count;
-    if (TASK == TASK_STEP) { irec[RI_T1] = t1; irec[RI_T2] = t2; irec[RI_REACHED] = reached; irec[RI_FRAMES] = frames; irec[RI_NSEQ] = nseq; }
-  }
+  if (lane == 0 && MODE == 0 && p.only_flagged) { st.slow[env] = 0; atomicAdd(&st.ep_stats[5], 1.0); }
 }
 
 // ------------------------------------------------------------------------------------------------ host side
@@ -2291,7 +2354,7 @@ int humanoid_create(HumanoidEnv** out, const std::vector<int32_t>& mi, const std
   HumanoidEnv* h = new HumanoidEnv();
   h->device = cfg->device;
   // two envs per wave (W = 32) where the model fits half a wavefront; the stepping task needs the 16-contact layout throughout
-  h->fast = !stepping && np <= 32 && ng <= 16 && nj <= 32 && !getenv("LHW_ONE_ENV_PER_WAVE");
+  h->fast = !stepping && np <= 32 && ng <= 16 && nj <= 32 && nb <= (stand ? 15 : 18) && !getenv("LHW_ONE_ENV_PER_WAVE");
   HModel& m = h->m;
   memset(&m, 0, sizeof m);
   m.nq = nq; m.nv = nv; m.nu = nu; m.nbody = nb; m.njnt = nj; m.ngeom = ng; m.npair = np;

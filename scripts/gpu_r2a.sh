@@ -1,7 +1,7 @@
 #!/bin/bash
 # round-2 GPU pass A: parity of the group-width-generic stepper on hardware + first timings
 set -u
-OUT=/root/repo/gpurun_out/r2a
+OUT=/root/repo/gpurun_out/r2b
 mkdir -p $OUT
 cd /root/repo
 python -m pytest tests -m gpu -x -q > $OUT/pytest.log 2>&1; echo "pytest rc $?" >> $OUT/pytest.log
@@ -14,7 +14,7 @@ python scripts/jvrc_phase_profile.py 4096 > $OUT/phase_fast.txt 2>&1
 LHW_ONE_ENV_PER_WAVE=1 python scripts/jvrc_phase_profile.py 4096 > $OUT/phase_w64.txt 2>&1
 python - <<'PY' > $OUT/summary.txt
 import json,glob
-for f in sorted(glob.glob('/root/repo/gpurun_out/r2a/bench_*.json')):
+for f in sorted(glob.glob('/root/repo/gpurun_out/r2b/bench_*.json')):
     try:
         d=json.load(open(f)); r=d['roofline']
         print(f.split('/')[-1], 'value %.0f'%d['value'], 'sample_s %.3f opt_s %.3f'%(d['sample_s_per_iter'], d['optimize_s_per_iter']), 'launch_ms %.3f wall_ms/step %.3f'%(r['avg_launch_ms'], r['aggregate']['wall_ms_per_control_step']))

@@ -17,3 +17,8 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def have_reference():
     return os.path.isdir(os.path.join(REFERENCE, "rl"))
+
+
+if os.environ.get("LHW_EMU") == "1":   # debugging aid: replay the -m gpu stepper tests on the host-side SIMT emulator
+    from tests import emu as _emu
+    _emu.install_as_backend()

@@ -140,6 +140,11 @@ class EmuBatchedEnv:
         self._check(self._L.lhw_env_pop_fault_stats(self._h, ctypes.byref(a), ctypes.byref(b)))
         return a.value, b.value
 
+    def pop_rerun_count(self):
+        a = ctypes.c_int64()
+        self._check(self._L.lhw_env_pop_rerun_count(self._h, ctypes.byref(a)))
+        return a.value
+
     def pop_episode_stats(self):
         r, l, c = ctypes.c_double(), ctypes.c_double(), ctypes.c_int64()
         self._check(self._L.lhw_env_pop_episode_stats(self._h, ctypes.byref(r), ctypes.byref(l), ctypes.byref(c)))
@@ -173,3 +178,47 @@ def make_emulated(spec, n_envs, **kw):
     k = captured["k"]
     k.pop("device", None)
     return EmuBatchedEnv(captured["model"], captured["task"], captured["n"], **k)
+
+
+class TorchEmuBatchedEnv(EmuBatchedEnv):
+    """EmuBatchedEnv with the torch-tensor surface of BatchedEnv (CPU tensors sharing the numpy buffers), so that the
+    `-m gpu` stepper tests can be replayed on the emulator: `LHW_EMU=1 python -m pytest tests/test_jvrc_gpu.py -m gpu`."""
+
+    def __init__(self, model, task, n_envs, **kw):
+        import torch
+        kw.pop("device", None)
+        super().__init__(model, task, n_envs, **kw)
+        self._np = dict(obs=self.obs, term_obs=self.term_obs, rew=self.rew, done=self.done, rew_terms=self.rew_terms)
+        for k, v in self._np.items():
+            setattr(self, k, torch.from_numpy(v))
+        self.device = torch.device("cpu")
+
+    def reset(self, mask=None):
+        mp = None
+        if mask is not None:
+            mask = np.ascontiguousarray(mask.numpy() if hasattr(mask, "numpy") else mask, np.uint8)
+            mp = mask.ctypes.data
+        self._check(self._L.lhw_env_reset(self._h, mp, self._np["obs"].ctypes.data, None))
+        return self.obs
+
+    def step(self, act, obs_out=None, term_obs_out=None, rew_out=None, done_out=None):
+        a = np.ascontiguousarray(act.numpy() if hasattr(act, "numpy") else act, np.float32).reshape(self.n_envs, self.act_dim)
+        n = self._np
+        self._check(self._L.lhw_env_step(self._h, a.ctypes.data, n["obs"].ctypes.data, n["term_obs"].ctypes.data, n["rew"].ctypes.data,
+                                         n["done"].ctypes.data, n["rew_terms"].ctypes.data, None))
+        return self.obs, self.rew, self.done, self.term_obs
+
+
+def install_as_backend():
+    """Route BatchedEnv to the emulator and make `.cuda()` a no-op (debugging aid for replaying GPU tests on a CPU)."""
+    import torch
+    import learninghumanoidwalking_amd.batched_env as be
+    import learninghumanoidwalking_amd.envs as envs_pkg
+    import importlib, pkgutil
+    be.BatchedEnv = TorchEmuBatchedEnv
+    for mi in pkgutil.iter_modules(envs_pkg.__path__):
+        mod = importlib.import_module(f"{envs_pkg.__name__}.{mi.name}")
+        if hasattr(mod, "BatchedEnv"):
+            mod.BatchedEnv = TorchEmuBatchedEnv
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    torch.cuda.is_available = lambda: True
