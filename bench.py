@@ -180,6 +180,10 @@ def main():
     for i in range(args.warmup):
         algo.iterate(i)
     barrier()
+    if hasattr(env, "pop_fault_stats"):
+        env.pop_fault_stats()
+    if hasattr(env, "pop_rerun_count"):
+        env.pop_rerun_count()
     timing["on"] = rank == 0
     t0 = time.time()
     sample_t = opt_t = 0.0
@@ -189,6 +193,8 @@ def main():
         opt_t += ot
     barrier()
     elapsed = time.time() - t0
+    faults = env.pop_fault_stats() if hasattr(env, "pop_fault_stats") else (0, 0)
+    reruns = env.pop_rerun_count() if hasattr(env, "pop_rerun_count") else 0
     tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -241,7 +247,11 @@ def main():
                         mirror=not args.no_mirror and spec.mirror_tables() is not None,
                         frame_skip=spec.frame_skip, sim_dt=spec.sim_dt, control_dt=spec.control_dt),
             ppo_iters_per_s=K / elapsed, sample_s_per_iter=sample_t / K, optimize_s_per_iter=opt_t / K,
-            optimizer_steps_per_iter=L.get("n_updates"), roofline=roofline)
+            optimizer_steps_per_iter=L.get("n_updates"), roofline=roofline,
+            stepper_counters=dict(contact_overflow_steps=int(faults[0]), diverged_env_steps=int(faults[1]), one_env_per_wave_reruns=int(reruns),
+                                  env_steps=int(N * T * K),
+                                  note="rank 0, timed iterations: control steps that dropped contacts beyond the 16-contact layout / whose state "
+                                       "went non-finite / that the two-envs-per-wave kernel handed to the one-env-per-wave kernel (> 8 contacts)"))
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = run_cpu_baseline(env_name)
         print(json.dumps(out))

@@ -9,7 +9,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
-LIB_PATH = os.path.join(_HERE, "liblhw.so")
+LIB_PATH = os.environ.get("LHW_LIB") or os.path.join(_HERE, "liblhw.so")   # LHW_LIB: kernel-variant experiments (scripts/)
 _LIB = None
 
 

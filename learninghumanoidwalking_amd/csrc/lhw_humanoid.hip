@@ -187,6 +187,7 @@ struct HParams {
   int n_envs, frame_skip, max_traj_len, period, task;
   int env_first, env_count;             // sub-range of envs this launch advances (lhw_env_step_range); blockIdx.x is relative to it
   int only_flagged;                     // 1: advance only the envs whose st.slow flag is set (re-run of fast-path overflows), clearing it
+  int reset_template;                   // >= 0: record index of the template env whose freshly reset state every auto-reset copies (-1: resets are computed)
   int root_body, head_body, rfoot_body, lfoot_body;
   int env_params;                       // 1: damping / frictionloss / mass / ipos / xfrc come from the per-env record
   int dynrand_interval, perturb_interval, n_pbody, pbody[2];
@@ -485,17 +486,36 @@ __device__ __forceinline__ void inert_vec(double* r, const double* i, const doub
 // inside the column chain (one v_readlane pair per element in the first version of this kernel), and the same published
 // rows serve the transposed access of the backward substitution.  Lanes >= NV shadow row NV-1.
 // The loops are fully unrolled over the compile-time bound NV so the row stays in VGPRs.
+// Column step J.  `cur` holds row J of L up to column J-2, prefetched from LDS during the previous step; the one element
+// that step J-1 has only just produced, L[J][J-1], comes straight out of lane J's registers (v_readlane), so no LDS round
+// trip sits on the column-to-column dependency chain; the reads issued here are the prefetch of row J+1.
+#ifndef LHW_CHOL_PREFETCH
+#define LHW_CHOL_PREFETCH 1
+#endif
 template <class L, int J>
-__device__ __forceinline__ void chol_col(double (&r)[NV], double (&invd)[NV], double& myinvd, double* Lb, const double* dg, int lane) {
+__device__ __forceinline__ void chol_col(double (&r)[NV], double (&invd)[NV], double& myinvd, const double (&cur)[NV], double dgj,
+                                         double* Lb, const double* dg, int lane) {
   if constexpr (J < L::NV_) {
-    double s0 = r[J], s1 = 0.0, p0 = dg[J], p1 = 0.0;
+    constexpr int W = L::W_;
+    double nxt[NV], dgn = 0.0;
+#if LHW_CHOL_PREFETCH
+    if constexpr (J + 1 < L::NV_) {
 #pragma unroll
-    for (int p = 0; p + 1 < J; p += 2) {
-      const double a = Lb[TRI(J, p)], b = Lb[TRI(J, p + 1)];
-      s0 -= r[p] * a; p0 -= a * a;
-      s1 -= r[p + 1] * b; p1 -= b * b;
+      for (int p = 0; p < J; p++) nxt[p] = Lb[TRI(J + 1, p)];
+      dgn = dg[J + 1];
     }
-    if (J & 1) { const double a = Lb[TRI(J, J - 1)]; s0 -= r[J - 1] * a; p0 -= a * a; }
+#endif
+    double s0 = r[J], s1 = 0.0, p0 = dgj, p1 = 0.0;
+#pragma unroll
+    for (int p = 0; p + 1 <= J - 2; p += 2) {   // pairs (p, p+1) of the prefetched columns 0 .. J-2
+      s0 -= r[p] * cur[p]; p0 -= cur[p] * cur[p];
+      s1 -= r[p + 1] * cur[p + 1]; p1 -= cur[p + 1] * cur[p + 1];
+    }
+    if constexpr (J >= 2 && ((J - 1) & 1)) { s1 -= r[J - 2] * cur[J - 2]; p1 -= cur[J - 2] * cur[J - 2]; }   // odd count of prefetched columns
+    if constexpr (J >= 1) {
+      const double last = gbcast<W>(r[J - 1], J);
+      s0 -= r[J - 1] * last; p0 -= last * last;
+    }
     const double piv = fmax(p0 + p1, HMINVAL);
     double id = __builtin_amdgcn_rsq(piv);
     id = id * (1.5 - 0.5 * piv * id * id);
@@ -506,7 +526,14 @@ __device__ __forceinline__ void chol_col(double (&r)[NV], double (&invd)[NV], do
     if (lane == J) myinvd = id;
     if (lane >= J && lane < NV) Lb[TRI(lane, J)] = lij;
     SYNC();
-    chol_col<L, J + 1>(r, invd, myinvd, Lb, dg, lane);
+#if !LHW_CHOL_PREFETCH
+    if constexpr (J + 1 < L::NV_) {
+#pragma unroll
+      for (int p = 0; p < J; p++) nxt[p] = Lb[TRI(J + 1, p)];
+      dgn = dg[J + 1];
+    }
+#endif
+    chol_col<L, J + 1>(r, invd, myinvd, nxt, dgn, Lb, dg, lane);
   }
 }
 
@@ -516,8 +543,8 @@ __device__ __forceinline__ double chol_solve(double (&r)[NV], double diag, doubl
   SYNC();
   if (lane < NV) dg[lane] = diag;
   SYNC();
-  double invd[NV], myinvd = 1.0;
-  chol_col<L, 0>(r, invd, myinvd, Lb, dg, lane);
+  double invd[NV], myinvd = 1.0, cur0[NV];
+  chol_col<L, 0>(r, invd, myinvd, cur0, dg[0], Lb, dg, lane);
   // forward substitution L y = x as a column sweep: x_i -= L[i][j] y_j for i > j, with y_j = x_j / L[j][j] read from lane j
 #pragma unroll
   for (int j = 0; j < NV; j++) {
@@ -1483,6 +1510,7 @@ __device__ __forceinline__ void substep(const HModel& m, const HParams& p, L& S,
     }
     double cost = 0, oldcost = 0;
     for (int iter = 0; iter <= m.iterations; iter++) {
+      if (st_prof && lane == 0) st_prof[6] += 1;    // diagnostic: Newton passes (cost evaluations) of env 0
       SYNC();
       if (lane < NV) S.U[U_VEC + lane] = qacc;
       SYNC();
@@ -1554,6 +1582,7 @@ __device__ __forceinline__ void substep(const HModel& m, const HParams& p, L& S,
           const double d0 = fabs(d1);
           double lo = 0, hi = -1;
           for (int it = 0; it < 40; it++) {
+            if (st_prof && lane == 0) st_prof[14] += 1;   // diagnostic: line-search passes of env 0
             double a = alpha - d1 / d2;
             if (hi >= 0 && (a <= lo || a >= hi)) a = 0.5 * (lo + hi);
             deriv_rows(a, &r1, &r2);
@@ -2207,8 +2236,22 @@ __global__ void __launch_bounds__(64, 2) humanoid_kernel(HModel m, HParams p, HS
         stage = ST_END;
       }
     }
-    if (stage == ST_RESET) {
-      const unsigned reset_count = (unsigned)S.ci[CI_RESETCNT];   // (an env whose episode just ended enters here in the same pass)
+    if (TASK == TASK_WALK && MODE == 0 && stage == ST_RESET && p.reset_template >= 0) {
+      // jvrc_walk: the physical state of a freshly reset env -- nominal pose, zero velocity, one forward pass, three settle
+      // steps (base_humanoid_env.py:247-276) -- does not depend on the env or on any random draw, so it was computed once,
+      // by this same code, for the template record at creation; an episode end copies it instead of holding its wave (and,
+      // with every wave of the batch resident at once, the whole launch) for four more sub-steps.
+      const double* tr = st.rec + (size_t)p.reset_template * REC_D;
+      SYNC();
+      if (lane < m.nq) S.qpos[lane] = tr[R_QPOS + lane];
+      if (lane < NV) { S.qvel[lane] = tr[R_QVEL + lane]; warm = tr[R_WARM + lane]; }
+      if (lane < m.nu) { S.sq[lane] = tr[R_SQ + lane]; S.sv[lane] = tr[R_SV + lane]; S.frc[lane] = tr[R_FRC + lane]; S.ctrl[lane] = 0; }
+      SYNC();
+      stage = ST_SETTLE; kstep = 3;
+      continue;
+    }
+    if (stage == ST_RESET) {   // (an env whose episode just ended enters here in the same pass)
+      const unsigned reset_count = (unsigned)S.ci[CI_RESETCNT];
       // ---- MujocoEnv.reset + BaseHumanoidEnv.reset_model (mujoco_env.py:113-127, base_humanoid_env.py:247-276)
       SYNC();
       if (lane < m.nq) S.qpos[lane] = p.nominal_qpos[lane];
@@ -2556,11 +2599,12 @@ int humanoid_create(HumanoidEnv** out, const std::vector<int32_t>& mi, const std
     ok = ok && h->st.ter != nullptr;
   }
   void *rec = nullptr, *irec = nullptr, *eps = nullptr, *slow = nullptr;
-  ok = ok && hipMalloc(&slow, N) == hipSuccess && hipMemset(slow, 0, N) == hipSuccess;
+  ok = ok && hipMalloc(&slow, N + 1) == hipSuccess && hipMemset(slow, 0, N + 1) == hipSuccess;
   if (slow) h->dev_allocs.push_back(slow);
   h->st.slow = (unsigned char*)slow;
-  ok = ok && hipMalloc(&rec, sizeof(double) * REC_D * N) == hipSuccess && hipMemset(rec, 0, sizeof(double) * REC_D * N) == hipSuccess &&
-       hipMalloc(&irec, sizeof(int) * REC_I * N) == hipSuccess && hipMemset(irec, 0, sizeof(int) * REC_I * N) == hipSuccess &&
+  // (one record more than envs: the reset template of the jvrc_walk kernels)
+  ok = ok && hipMalloc(&rec, sizeof(double) * REC_D * (N + 1)) == hipSuccess && hipMemset(rec, 0, sizeof(double) * REC_D * (N + 1)) == hipSuccess &&
+       hipMalloc(&irec, sizeof(int) * REC_I * (N + 1)) == hipSuccess && hipMemset(irec, 0, sizeof(int) * REC_I * (N + 1)) == hipSuccess &&
        hipMalloc(&eps, sizeof(double) * 8) == hipSuccess && hipMemset(eps, 0, sizeof(double) * 8) == hipSuccess;
   if (rec) h->dev_allocs.push_back(rec);
   if (irec) h->dev_allocs.push_back(irec);
@@ -2568,6 +2612,17 @@ int humanoid_create(HumanoidEnv** out, const std::vector<int32_t>& mi, const std
   h->st.rec = (double*)rec; h->st.irec = (int*)irec; h->st.ep_stats = (double*)eps; h->st.prof = nullptr;
   if (!ok) { humanoid_destroy(h); return lhw_fail(LHW_ERR_HIP, "humanoid_create: device allocation failed or bad body ids"); }
   *obs_dim = stepping ? 39 : (walk ? 37 : (h1walk ? 43 : 35)); *act_dim = nu; *n_terms = ((walk && !stepping) || h1walk) ? 10 : 6;
+  p.reset_template = -1;
+  if (p.task == TASK_WALK && !getenv("LHW_NO_RESET_TEMPLATE")) {
+    // reset the template record (index N) once with the ordinary reset kernel; auto-resets copy its state from then on
+    HParams pp = p;
+    pp.env_first = (int)N; pp.env_count = 1; pp.only_flagged = 0;
+    hipLaunchKernelGGL((humanoid_kernel<1, TASK_WALK, 64>), dim3(1), dim3(64), 0, 0, h->m, pp, h->st, (const float*)nullptr, (float*)nullptr,
+                       (float*)nullptr, (float*)nullptr, (unsigned char*)nullptr, (float*)nullptr, (const unsigned char*)nullptr, (double*)nullptr,
+                       (double*)nullptr);
+    if (hipDeviceSynchronize() != hipSuccess) { humanoid_destroy(h); return lhw_fail(LHW_ERR_HIP, "humanoid_create: reset template launch failed"); }
+    p.reset_template = (int)N;
+  }
   *out = h;
   return LHW_OK;
 }

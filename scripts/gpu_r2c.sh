@@ -1,7 +1,7 @@
 #!/bin/bash
 # round-2 GPU pass C: grouping of the rollout, instruction-mix counters of the two-envs-per-wave kernel
 set -u
-OUT=/root/repo/gpurun_out/r2c
+OUT=/root/repo/gpurun_out/r2f
 mkdir -p $OUT
 cd /root/repo
 python -m pytest tests -m gpu -x -q > $OUT/pytest.log 2>&1; echo "pytest rc $?" >> $OUT/pytest.log
@@ -20,7 +20,7 @@ done
 cd /root/repo
 python - <<'PY' > $OUT/summary.txt
 import json,glob
-for f in sorted(glob.glob('/root/repo/gpurun_out/r2c/bench_*.json')):
+for f in sorted(glob.glob('/root/repo/gpurun_out/r2f/bench_*.json')):
     try:
         d=json.load(open(f)); r=d['roofline']
         print(f.split('/')[-1], 'value %.0f'%d['value'], 'sample_s %.3f opt_s %.3f'%(d['sample_s_per_iter'], d['optimize_s_per_iter']), 'launch_ms %.3f wall_ms/step %.3f'%(r['avg_launch_ms'], r['aggregate']['wall_ms_per_control_step']))

@@ -12,14 +12,20 @@ env.reset()
 if name == "jvrc_step":
     _, fz, _ = env.debug_step_record()
     print(f"jvrc_step seed {seed}: env 0 {'stands on the boxes (FORWARD mode)' if fz[0] != 0 else 'stands on the floor'}; {int((fz != 0).sum())}/{N} envs on boxes")
-act = torch.randn(N, 12, device="cuda") * 0.1
-for _ in range(3): env.step(act)
+# "policy" regime of an untrained actor: zero-mean actions with the exploration std (0.223), redrawn every control step
+# (LHW_PROFILE_STD overrides; 0.1 with a fixed draw was the quasi-static regime of round 1)
+std = float(os.environ.get("LHW_PROFILE_STD", "0.223"))
+gen = torch.Generator(device="cuda"); gen.manual_seed(0)
+def draw(): return torch.randn(N, 12, device="cuda", generator=gen) * std
+for _ in range(30): env.step(draw())
 env.phase_cycles(True)
-steps = 10
+steps = 20
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+acts = [draw() for _ in range(steps)]
+torch.cuda.synchronize()
 e0.record()
-for _ in range(steps): env.step(act)
+for a in acts: env.step(a)
 e1.record(); torch.cuda.synchronize()
 c = env.phase_cycles(True)
 from learninghumanoidwalking_amd import _lib
@@ -29,3 +35,4 @@ tot = c[:11].sum()
 print(f"N={N} ms/step {e0.elapsed_time(e1)/steps:.3f}  env0 cycles/control-step {tot/steps:.0f}  per sub-step {tot/steps/25:.0f}")
 for n, v in zip(names, c[:11]): print(f"  {n:14s} {v/steps/25:9.0f} cyc/substep  {100*v/tot:5.1f}%")
 print("  detail slots 11..15:", (c[11:16]/steps/25).astype(int))
+print(f"  newton passes per sub-step (env 0): {c[6]/steps/25:.2f}   line-search passes per sub-step: {c[14]/steps/25:.2f}")

@@ -160,6 +160,7 @@ static inline int __all(int p) { return emu_ballot(!p) == 0; }
 static inline unsigned long long __ballot(int p) { return emu_ballot(p); }
 
 // ---- scalar device functions
+static inline int __clz(int v) { return v ? __builtin_clz((unsigned)v) : 32; }
 static inline int __ffs(unsigned v) { return __builtin_ffs((int)v); }
 static inline int __ffsll(unsigned long long v) { return __builtin_ffsll((long long)v); }
 static inline int __popc(unsigned v) { return __builtin_popcount(v); }
