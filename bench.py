@@ -24,22 +24,23 @@ MFMA_F32_PEAK_TFLOPS = 157.3  # f32-input MFMA peak (= f32 vector peak)
 FP64_VALU_PEAK_TFLOPS = 78.6
 
 
-def pmc_traffic_per_launch(kernel_substr):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc summaries (profiles/), applying
-    the gfx950 correction of MI355X_MICROARCH.md (FETCH_SIZE under-reports coalesced reads by 2x; WRITE_SIZE uncalibrated).
-    Returns (bytes or None, note)."""
+def static_pmc_traffic(kernel_substr):
+    """HBM bytes per launch of the dominant kernel from the COMMITTED rocprofv3 --pmc summaries (profiles/), with the gfx950
+    correction of MI355X_MICROARCH.md (FETCH_SIZE under-reports coalesced reads by 2x; WRITE_SIZE uncalibrated).  Static: it
+    is NOT measured by this run (the counters need their own rocprofv3 passes, scripts/collect_profiles.sh)."""
     import csv
     vals = {}
     for name in ("fetch_size", "write_size"):
-        path = os.path.join(ROOT, "profiles", f"r01_jvrc_walk_step_pmc_{name}.csv")
+        path = os.path.join(ROOT, "profiles", f"r02_jvrc_walk_step_pmc_{name}.csv")
         if not os.path.exists(path):
-            return None, "no PMC summary committed"
+            return None
         for row in csv.DictReader(open(path)):
             if kernel_substr in row["kernel"]:
                 vals[name] = float(row["mean"]) * 1024.0
     if len(vals) != 2:
-        return None, "kernel not found in the PMC summaries"
-    return 2.0 * vals["fetch_size"] + vals["write_size"], "profiles/r01_jvrc_walk_step_pmc_{fetch,write}_size.csv: 2*FETCH_SIZE + WRITE_SIZE"
+        return None
+    return dict(bytes_per_launch=2.0 * vals["fetch_size"] + vals["write_size"], envs_per_launch=4096,
+                source="profiles/r02_jvrc_walk_step_pmc_{fetch,write}_size.csv: 2*FETCH_SIZE + WRITE_SIZE, whole-batch launches")
 
 
 def cpu_baseline_worker(a):
@@ -87,8 +88,8 @@ def run_cpu_baseline(env_name, target_seconds=15.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--env", default=os.environ.get("LHW_BENCH_ENV", "auto"))
     ap.add_argument("--num-envs", type=int, default=4096, help="envs per GPU")
     ap.add_argument("--traj-len", type=int, default=400, help="control steps per env per iteration (max_traj_len)")
@@ -177,6 +178,22 @@ def main():
             return r
 
         env.step_range = timed_range
+    if getattr(algo.rollout, "persistent", False):
+        orig_rollout = env.rollout
+
+        def timed_rollout(T, *a, **k):
+            if not timing["on"]:
+                return orig_rollout(T, *a, **k)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()                      # the rollout kernel is launched on the current stream
+            r = orig_rollout(T, *a, **k)
+            e1.record()
+            step_events.append((e0, e1))
+            launch_envs["n"] = args.num_envs
+            launch_envs["steps"] = int(T)
+            return r
+
+        env.rollout = timed_rollout
     for i in range(args.warmup):
         algo.iterate(i)
     barrier()
@@ -187,14 +204,31 @@ def main():
     timing["on"] = rank == 0
     t0 = time.time()
     sample_t = opt_t = 0.0
+    iter_s = []
     for i in range(args.steps):
         _, st, ot = algo.iterate(args.warmup + i)
         sample_t += st
         opt_t += ot
+        iter_s.append(st + ot)
     barrier()
     elapsed = time.time() - t0
     faults = env.pop_fault_stats() if hasattr(env, "pop_fault_stats") else (0, 0)
     reruns = env.pop_rerun_count() if hasattr(env, "pop_rerun_count") else 0
+    # calibration of the dominant kernel outside the timed region (rank 0): whole-batch launches, one at a time, nothing
+    # else on the GPU -- the duration rocprofv3 --kernel-trace reports for an isolated launch
+    isolated_ms = None
+    timing["on"] = False
+    if rank == 0 and hasattr(env, "step_range"):
+        ro = algo.rollout
+        evs = []
+        for t in range(min(20, ro.T)):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            orig_step(ro.act[t])
+            e1.record()
+            evs.append((e0, e1))
+        torch.cuda.synchronize()
+        isolated_ms = float(np.median([a.elapsed_time(b) for a, b in evs]))
     tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -209,32 +243,40 @@ def main():
         spec = algo.spec
         bytes_per_env_step = spec.algorithmic_bytes_per_env_step()
         flops_per_env_step = spec.algorithmic_flops_per_env_step()
-        NL = launch_envs["n"]                      # envs per control-step launch (N / rollout groups)
+        NL = launch_envs["n"]                      # envs per launch (N / rollout groups)
+        TL = launch_envs.get("steps", 1)           # control steps per launch (T for the persistent rollout kernel, else 1)
+        persistent = TL > 1
         groups = max(1, N // NL)
-        achieved_gbs = bytes_per_env_step * NL / (avg_step_ms * 1e-3) / 1e9
+        achieved_gbs = bytes_per_env_step * NL * TL / (avg_step_ms * 1e-3) / 1e9
+        achieved_tf = flops_per_env_step * NL * TL / (avg_step_ms * 1e-3) / 1e12
         wall_step_ms = sample_t / K / T * 1e3     # wall time per control step of all N envs, policy inference included
-        traffic, traffic_note = (pmc_traffic_per_launch("humanoid_kernel<0, 1>") if env_name == "jvrc_walk" and N == 4096
-                                 else (None, "PMC summary exists for jvrc_walk @ 4096 envs only"))
-        if traffic is not None and NL != N:      # the PMC pass measured whole-batch launches: scale to the envs of one launch
-            traffic, traffic_note = traffic * NL / N, traffic_note + f" (4096-env launch, scaled to {NL} envs)"
-        roofline = dict(bound="hbm", kernel=spec.step_kernel_name, achieved=achieved_gbs, peak=HBM_PEAK_GBS, unit="GB/s",
-                        frac=achieved_gbs / HBM_PEAK_GBS, traffic=traffic, traffic_source=traffic_note,
-                        algorithmic_bytes_per_launch=bytes_per_env_step * NL, avg_launch_ms=avg_step_ms, launches=len(step_ms),
-                        envs_per_launch=NL, concurrent_launches=groups,
-                        aggregate=dict(wall_ms_per_control_step=wall_step_ms,
-                                       achieved_gbs=bytes_per_env_step * N / (wall_step_ms * 1e-3) / 1e9,
-                                       fp64_tflops=flops_per_env_step * N / (wall_step_ms * 1e-3) / 1e12,
-                                       fp64_frac=flops_per_env_step * N / (wall_step_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS,
-                                       note="the batch is advanced as independent env groups on separate streams; their "
-                                            "control-step kernels overlap, so a launch's duration includes the share of the GPU "
-                                            "it cedes to the other group; the aggregate line divides the whole batch's work by the "
-                                            "wall time per control step"),
-                        algorithmic_bytes_per_env_step=bytes_per_env_step,
-                        note="the fused control-step kernel touches each env's state once per control step, so it is "
-                             "bound by on-chip fp64 latency/VALU issue, not HBM (SURVEY.md 8d); fp64 VALU fraction below",
-                        valu_fp64=dict(achieved_tflops=flops_per_env_step * NL / (avg_step_ms * 1e-3) / 1e12,
-                                       peak_tflops=FP64_VALU_PEAK_TFLOPS,
-                                       frac=flops_per_env_step * NL / (avg_step_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS))
+        static = static_pmc_traffic(spec.step_kernel_name.split("<")[0]) if env_name == "jvrc_walk" else None
+        # The fused control-step kernel touches each env's state once per control step (3 KB): by design it is not HBM-bound
+        #  but bound by fp64 vector issue + on-chip latency, so the primary roofline is the fp64 VALU one.
+        roofline = dict(
+            bound="valu_fp64", kernel=(spec.step_kernel_name.replace("humanoid_kernel<0, ", "humanoid_rollout_kernel<") if persistent else spec.step_kernel_name), achieved=achieved_tf, peak=FP64_VALU_PEAK_TFLOPS, unit="TFLOP/s",
+            frac=achieved_tf / FP64_VALU_PEAK_TFLOPS, traffic=None,
+            traffic_note="HBM bytes are not measured by this run (PMC counters need separate rocprofv3 passes); see traffic_static",
+            traffic_static=static,
+            algorithmic_flops_per_launch=flops_per_env_step * NL * TL, algorithmic_bytes_per_launch=bytes_per_env_step * NL * TL,
+            algorithmic_flops_per_env_step=flops_per_env_step, algorithmic_bytes_per_env_step=bytes_per_env_step,
+            avg_launch_ms=avg_step_ms, launches=len(step_ms), envs_per_launch=NL, control_steps_per_launch=TL, concurrent_launches=groups,
+            launch_note=("HIP events on the launch stream around lhw_env_rollout over the timed region: ONE launch per PPO iteration advances "
+                         "every env by T control steps (stepper + in-kernel float32 actor, whose FLOPs are not counted here); "
+                         "`isolated` is the launch-per-step kernel on the same batch, for comparison") if persistent else
+                        ("HIP events on the launch stream around lhw_env_step_range over the timed region: the two-envs-per-wave kernel "
+                        "plus the (normally empty) one-env-per-wave re-run launch behind it; with concurrent_launches > 1 the groups' "
+                        "kernels overlap, so a launch's span includes the share of the GPU it cedes to the other group"),
+            isolated=None if isolated_ms is None else dict(
+                launch_ms=isolated_ms, envs_per_launch=N, fp64_tflops=flops_per_env_step * N / (isolated_ms * 1e-3) / 1e12,
+                fp64_frac=flops_per_env_step * N / (isolated_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS,
+                note="median of 20 whole-batch launches issued one at a time after the timed region (no overlap)"),
+            aggregate=dict(wall_ms_per_control_step=wall_step_ms,
+                           fp64_tflops=flops_per_env_step * N / (wall_step_ms * 1e-3) / 1e12,
+                           fp64_frac=flops_per_env_step * N / (wall_step_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS,
+                           note="whole batch's algorithmic FLOPs / wall time per control step of the rollout (policy inference included)"),
+            hbm=dict(bound="hbm", achieved=achieved_gbs, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved_gbs / HBM_PEAK_GBS,
+                     note="secondary: algorithmic bytes / launch span; ~3e-4 of peak by construction"))
         L = algo.last_losses
         upd_flops = algo.kernels_update_flops_per_sample_epoch() * N * T * args.epochs if hasattr(algo, "kernels_update_flops_per_sample_epoch") else None
         out = dict(
@@ -247,6 +289,7 @@ def main():
                         mirror=not args.no_mirror and spec.mirror_tables() is not None,
                         frame_skip=spec.frame_skip, sim_dt=spec.sim_dt, control_dt=spec.control_dt),
             ppo_iters_per_s=K / elapsed, sample_s_per_iter=sample_t / K, optimize_s_per_iter=opt_t / K,
+            median_iter_s=float(np.median(iter_s)), iter_s=[round(x, 4) for x in iter_s],
             optimizer_steps_per_iter=L.get("n_updates"), roofline=roofline,
             stepper_counters=dict(contact_overflow_steps=int(faults[0]), diverged_env_steps=int(faults[1]), one_env_per_wave_reruns=int(reruns),
                                   env_steps=int(N * T * K),

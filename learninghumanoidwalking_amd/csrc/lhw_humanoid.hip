@@ -39,6 +39,7 @@
 #include <vector>
 
 #include "lhw_internal.h"
+#include "lhw_policy.h"
 #include "lhw_rng.h"
 
 #define NB 20   // bodies
@@ -210,6 +211,7 @@ struct HState {
   unsigned char* slow;  // [N] set by the two-envs-per-wave kernel for an env that exceeded its contact capacity: nothing of that env
                         // was written, and the one-env-per-wave kernel repeats its control step
   long long* prof; // optional [16] per-phase cycle counters accumulated by env 0 (NULL = off)
+  long long* wave_cyc;  // optional [N] shader-clock cycles the env's group spent in the last control-step launch (NULL = off)
 };
 #define PROF_BEGIN() long long prof_t = (st_prof && lane == 0) ? (long long)clock64() : 0   // lane = lane within the group
 #define PROF_MARK(slot)                                                  \
@@ -310,6 +312,12 @@ struct LdsT {
   // episode / task context of the env (home of these values during the launch: nothing of it is held in registers across a sub-step)
   double cmode_ref[3], cep_ret;
   int ci[12];
+  // Float32 staging that is only live BETWEEN sub-steps, in the tail of the (then dead) stage region: the action of this
+  // control step when it comes from the in-kernel policy (read before the first sub-step) and the env's current observation
+  // (written after the last sub-step, copied out to the obs / terminal-obs buffers or consumed by the in-kernel policy).
+  static constexpr int OBSF_ = USIZE_ - 24, ACTF_ = OBSF_ - (NU + 1) / 2;
+  __device__ __forceinline__ float* obsf() { return reinterpret_cast<float*>(U + OBSF_); }
+  __device__ __forceinline__ float* actf() { return reinterpret_cast<float*>(U + ACTF_); }
   int ncon, overflow;
 };
 enum { CI_PHASE = 0, CI_MODE, CI_TRAJ, CI_STARTED, CI_STEPCNT, CI_RESETCNT, CI_OBSCNT, CI_T1, CI_T2, CI_REACHED, CI_FRAMES, CI_NSEQ };
@@ -1762,25 +1770,24 @@ __device__ __forceinline__ void body_linvel(const L& S, int slot /* 0 root, 1 ri
   lin[0] = cv[3] - t[0]; lin[1] = cv[4] - t[1]; lin[2] = cv[5] - t[2];
 }
 
-template <int MODE, int TASK, int W>  // MODE: 0 step, 1 reset(mask), 2 set_state, 3 get_state; TASK: TASK_WALK / TASK_STAND / TASK_STEP / TASK_H1WALK; W: lanes per env
-__global__ void __launch_bounds__(64, 2) humanoid_kernel(HModel m, HParams p, HState st, const float* __restrict__ act,
-                                                      float* __restrict__ obs, float* __restrict__ term_obs,
-                                                      float* __restrict__ rew, unsigned char* __restrict__ done_out,
-                                                      float* __restrict__ rew_terms, const unsigned char* __restrict__ mask,
-                                                      double* __restrict__ xq, double* __restrict__ xv) {
-  // H1 tasks: 16 dofs, per-env model parameters (domain randomisation); stepping task: 32 geoms, foot sites; the
-  // two-envs-per-wave layouts are sized for the robots' own body counts (JVRC 18, H1 15; humanoid_create checks)
-  using L = LdsT<W, (TASK == TASK_STAND || TASK == TASK_H1WALK), ((TASK == TASK_STAND || TASK == TASK_H1WALK) ? 16 : 18),
-                 ((TASK == TASK_STEP || W == 64) ? NG : 16), (W == 64 ? NB : ((TASK == TASK_STAND || TASK == TASK_H1WALK) ? 15 : 18)), TASK == TASK_STEP>;
-  constexpr int G = 64 / W;   // envs per wavefront
-  __shared__ L SG[G];
-  L& S = SG[group_id<W>()];
-  const int lane = threadIdx.x & (W - 1);   // lane within the env's group: every `lane` below is group-relative
-  const int eidx = blockIdx.x * G + group_id<W>();
-  if (eidx >= p.env_count) return;
-  const int env = eidx + p.env_first;
-  if (MODE == 1 && mask && !mask[env]) return;
-  if (MODE == 0 && p.only_flagged && !st.slow[env]) return;
+// Layout of a task's kernels at group width W.  H1 tasks: 16 dofs, per-env model parameters (domain randomisation); stepping
+// task: 32 geoms, foot sites; the two-envs-per-wave layouts are sized for the robots' own body counts (JVRC 18, H1 15;
+// humanoid_create checks).
+template <int TASK, int W>
+struct LayoutOf {
+  typedef LdsT<W, (TASK == TASK_STAND || TASK == TASK_H1WALK), ((TASK == TASK_STAND || TASK == TASK_H1WALK) ? 16 : 18),
+               ((TASK == TASK_STEP || W == 64) ? NG : 16), (W == 64 ? NB : ((TASK == TASK_STAND || TASK == TASK_H1WALK) ? 15 : 18)), TASK == TASK_STEP> type;
+};
+
+// One control step (MODE 0), reset (1), set_state (2) or get_state (3) of env `env` by the group of W lanes that calls it
+// (`lane` = lane within the group, S = the group's LDS working set).  Returns true iff the env exceeded the contact capacity
+// of the two-envs-per-wave layout before anything of this control step was written: the caller repeats the step with W = 64.
+template <int MODE, int TASK, int W>
+__device__ __forceinline__ bool control_step(const HModel& m, const HParams& p, const HState& st, typename LayoutOf<TASK, W>::type& S, const int env,
+                                             const int lane, const float* __restrict__ act, float* __restrict__ obs, float* __restrict__ term_obs,
+                                             float* __restrict__ rew, unsigned char* __restrict__ done_out, float* __restrict__ rew_terms,
+                                             double* __restrict__ xq, double* __restrict__ xv) {
+  using L = typename LayoutOf<TASK, W>::type;
   double* rec = st.rec + (size_t)env * REC_D;
   double* prm = st.prm ? st.prm + (size_t)env * PRM_D : nullptr;
   double* ter = (TASK == TASK_STEP) ? st.ter + (size_t)env * TER_D : nullptr;
@@ -1793,10 +1800,11 @@ __global__ void __launch_bounds__(64, 2) humanoid_kernel(HModel m, HParams p, HS
   long long* sprof = (env == 0) ? st.prof : nullptr;
   long long* st_prof = sprof;
   PROF_BEGIN();
+  const long long t_launch = (MODE == 0 && st.wave_cyc) ? (long long)clock64() : 0;
   if (MODE == 3) {
     if (lane < m.nq) xq[(size_t)env * m.nq + lane] = rec[R_QPOS + lane];
     if (lane < NV) xv[(size_t)env * NV + lane] = rec[R_QVEL + lane];
-    return;
+    return false;
   }
   // ---- load the persistent record (lane-strided); the episode / task context goes to its LDS home
   double warm = 0;
@@ -1845,9 +1853,11 @@ __global__ void __launch_bounds__(64, 2) humanoid_kernel(HModel m, HParams p, HS
     SYNC();
   }
   // ---- BaseHumanoidEnv.step: smoothing, offsets (base_humanoid_env.py:209-215); RobotBase.step (robot_base.py:64-98)
-  double target = 0;
-  if (MODE == 0 && lane < m.nu)
-    target = p.action_smoothing * (double)act[(size_t)env * m.nu + lane] + (1 - p.action_smoothing) * rec[R_PREVPRED + lane] + p.action_offset[lane];
+  double target = 0, a_in = 0;   // (the raw action stays in a register: its LDS staging is overwritten by the first sub-step)
+  if (MODE == 0 && lane < m.nu) {
+    a_in = (double)(act ? act[(size_t)env * m.nu + lane] : S.actf()[lane]);
+    target = p.action_smoothing * a_in + (1 - p.action_smoothing) * rec[R_PREVPRED + lane] + p.action_offset[lane];
+  }
   for (;;) {
     int flags = 3;
     if (stage == ST_CONTROL) {
@@ -1864,7 +1874,7 @@ __global__ void __launch_bounds__(64, 2) humanoid_kernel(HModel m, HParams p, HS
         CTX_LOAD();
         double a_raw = 0, prevact = 0, prevtq = 0, prevpred = 0;
         if (lane < m.nu) {
-          a_raw = (double)act[(size_t)env * m.nu + lane];
+          a_raw = a_in;
           prevact = rec[R_PREVACT + lane]; prevtq = rec[R_PREVTQ + lane];
           // prev_action / prev_torque are initialised once, on the first step ever (robot_base.py:82-85), from the fields of
           // the forward pass that preceded this control step (the record still holds them)
@@ -2088,18 +2098,21 @@ __global__ void __launch_bounds__(64, 2) humanoid_kernel(HModel m, HParams p, HS
         ep_ret += r_sum;
         const bool truncated = p.max_traj_len > 0 && traj_len >= p.max_traj_len;
         const int NT = WALKT ? 10 : 6;
-        if (TASK == TASK_WALK) {
-          write_obs(m, p, S, lane, phase, mode, mode_ref, obs + (size_t)env * OBS);
-          if (term_obs) write_obs(m, p, S, lane, phase, mode, mode_ref, term_obs + (size_t)env * OBS);
-        } else if (TASK == TASK_STEP) {
-          write_obs_step(m, p, S, lane, phase, goal, obs + (size_t)env * OBS);
-          if (term_obs) write_obs_step(m, p, S, lane, phase, goal, term_obs + (size_t)env * OBS);
-        } else {
-          write_obs_h1(m, p, S, lane, genv, obs_count, obs + (size_t)env * OBS, term_obs ? term_obs + (size_t)env * OBS : nullptr);
-          if (TASK == TASK_H1WALK) {
-            write_obs_walk_ext(p, lane, phase, mode, mode_ref, obs + (size_t)env * OBS + 35);
-            if (term_obs) write_obs_walk_ext(p, lane, phase, mode, mode_ref, term_obs + (size_t)env * OBS + 35);
-          }
+        // the observation is formed in LDS (the persistent rollout kernel feeds it to the policy from there) and copied out
+        SYNC();
+        if (TASK == TASK_WALK) write_obs(m, p, S, lane, phase, mode, mode_ref, S.obsf());
+        else if (TASK == TASK_STEP) write_obs_step(m, p, S, lane, phase, goal, S.obsf());
+        else {
+          write_obs_h1(m, p, S, lane, genv, obs_count, S.obsf(), nullptr);
+          if (TASK == TASK_H1WALK) write_obs_walk_ext(p, lane, phase, mode, mode_ref, S.obsf() + 35);
+        }
+        SYNC();
+        for (int e = lane; e < OBS; e += W) {
+          const float ov = S.obsf()[e];
+          obs[(size_t)env * OBS + e] = ov;
+          if (term_obs) term_obs[(size_t)env * OBS + e] = ov;
+        }
+        if (TASK != TASK_WALK && TASK != TASK_STEP) {
           obs_count++;
           // post-observation randomisation draws (base_humanoid_env.py:221-225): slot 0 / 70 are the interval triggers
           if (p.dynrand_interval > 0 && lhw_rng_randint(p.seed, genv, LHW_STREAM_STEP, step_count, 0, p.dynrand_interval) == 0)
@@ -2222,15 +2235,16 @@ __global__ void __launch_bounds__(64, 2) humanoid_kernel(HModel m, HParams p, HS
         traj_len = 0;
         ep_ret = 0;
         prevpred = 0;
-        if (TASK == TASK_WALK) {
-          if (obs) write_obs(m, p, S, lane, phase, mode, mode_ref, obs + (size_t)env * OBS);
-        } else if (TASK == TASK_STEP) {
-          if (obs) write_obs_step(m, p, S, lane, phase, goal, obs + (size_t)env * OBS);
-        } else {
-          write_obs_h1(m, p, S, lane, genv, obs_count, obs ? obs + (size_t)env * OBS : nullptr, nullptr);  // the counter advances either way
-          if (TASK == TASK_H1WALK && obs) write_obs_walk_ext(p, lane, phase, mode, mode_ref, obs + (size_t)env * OBS + 35);
+        SYNC();
+        if (TASK == TASK_WALK) write_obs(m, p, S, lane, phase, mode, mode_ref, S.obsf());
+        else if (TASK == TASK_STEP) write_obs_step(m, p, S, lane, phase, goal, S.obsf());
+        else {
+          write_obs_h1(m, p, S, lane, genv, obs_count, S.obsf(), nullptr);  // the counter advances whether or not the caller wants the observation
+          if (TASK == TASK_H1WALK) write_obs_walk_ext(p, lane, phase, mode, mode_ref, S.obsf() + 35);
           obs_count++;
         }
+        SYNC();
+        if (obs) for (int e = lane; e < OBS; e += W) obs[(size_t)env * OBS + e] = S.obsf()[e];
         if (lane < m.nu) rec[R_PREVPRED + lane] = prevpred;
         CTX_STORE();
         stage = ST_END;
@@ -2290,7 +2304,7 @@ __global__ void __launch_bounds__(64, 2) humanoid_kernel(HModel m, HParams p, HS
     // untouched (nothing of it has been written yet); once its outputs are out, it can only truncate like that kernel does
     if (W == 32 && MODE == 0 && !committed && S.overflow) {
       if (lane == 0) st.slow[env] = 1;
-      return;
+      return true;
     }
   }
   PROF_MARK(10);
@@ -2308,6 +2322,147 @@ __global__ void __launch_bounds__(64, 2) humanoid_kernel(HModel m, HParams p, HS
     irec[dst] = S.ci[lane];
   }
   if (lane == 0 && MODE == 0 && p.only_flagged) { st.slow[env] = 0; atomicAdd(&st.ep_stats[5], 1.0); }
+  if (MODE == 0 && st.wave_cyc && lane == 0) st.wave_cyc[env] = (long long)clock64() - t_launch;
+  return false;
+}
+
+template <int MODE, int TASK, int W>  // MODE: 0 step, 1 reset(mask), 2 set_state, 3 get_state; TASK: TASK_WALK / TASK_STAND / TASK_STEP / TASK_H1WALK; W: lanes per env
+__global__ void __launch_bounds__(64, 2) humanoid_kernel(HModel m, HParams p, HState st, const float* __restrict__ act,
+                                                      float* __restrict__ obs, float* __restrict__ term_obs,
+                                                      float* __restrict__ rew, unsigned char* __restrict__ done_out,
+                                                      float* __restrict__ rew_terms, const unsigned char* __restrict__ mask,
+                                                      double* __restrict__ xq, double* __restrict__ xv) {
+  using L = typename LayoutOf<TASK, W>::type;
+  constexpr int G = 64 / W;   // envs per wavefront
+  __shared__ L SG[G];
+  const int lane = threadIdx.x & (W - 1);   // lane within the env's group
+  const int eidx = blockIdx.x * G + group_id<W>();
+  if (eidx >= p.env_count) return;
+  const int env = eidx + p.env_first;
+  if (MODE == 1 && mask && !mask[env]) return;
+  if (MODE == 0 && p.only_flagged && !st.slow[env]) return;
+  control_step<MODE, TASK, W>(m, p, st, SG[group_id<W>()], env, lane, act, obs, term_obs, rew, done_out, rew_terms, xq, xv);
+}
+
+// ------------------------------------------------------------------------------------------------ persistent rollout
+// A whole rollout -- T control steps of every env, policy inference included -- as ONE launch (lhw_env_rollout).  A wave
+// keeps its two envs for all T steps: actor forward for both (float32, the weights streamed from L2: 308 KB per step and
+// wave), action sampling, control step, next observation straight from LDS.  There is no kernel boundary and no batch-wide
+// barrier per control step any more, so a wave that needs more Newton iterations (or the re-run of an env with more than 8
+// contacts) in one step is not waited for by the other 2047: per-step launches last as long as their slowest wave -- 1.4x
+// the mean in the early-training regime -- whereas the sum over 400 steps differs little between waves.
+//
+// The actor is evaluated exactly like the GEMM path: x = (obs - mean) / std, each unit an fmaf chain over k in ascending order
+// (what v_mfma_f32_32x32x2_f32 computes), bias added afterwards, ReLU; the Gaussian head is the shared lhw_policy_sample.
+// Lane l owns hidden units 4l .. 4l+3 of BOTH envs, so a weight is fetched once (one 16-byte load per k from the k-major
+// copies w1t / w2t) and used twice; activations cross lanes through LDS (the sub-step's stage region, idle between steps).
+
+template <int TASK>
+__global__ void __launch_bounds__(64, 2) humanoid_rollout_kernel(HModel m, HParams p, HState st, RolloutArgs ra) {
+  using L32 = typename LayoutOf<TASK, 32>::type;
+  using L64 = typename LayoutOf<TASK, 64>::type;
+  union Shared { L32 g[2]; L64 one; };
+  __shared__ Shared sh;
+  const int tid = threadIdx.x, gid = tid >> 5, l32 = tid & 31;
+  const int N = p.n_envs;
+  const int e0 = 2 * (int)blockIdx.x + p.env_first;
+  const bool have = 2 * (int)blockIdx.x + gid < p.env_count;   // (the last wave of an odd batch holds one env)
+  const int env = have ? e0 + gid : e0;
+  const int D = ra.D, Dp = ra.Dp, H = ra.H, A = ra.A;
+  float* xs = reinterpret_cast<float*>(sh.g[0].U);   // [2][Dp] normalised observations
+  float* h1s = xs + 2 * Dp;                           // [2][H]
+  float* h2s = h1s + 2 * H;                           // [2][H]
+  float* lps = reinterpret_cast<float*>(sh.g[1].U);   // [2][A] log-density terms
+  // the observation the rollout starts from (reset observation or the last one of the previous batch)
+  for (int k = l32; k < D; k += 32) sh.g[gid].obsf()[k] = ra.obs[(size_t)env * D + k];
+  SYNC();
+  for (int t = 0; t < ra.T; t++) {
+    // ---------------------------------------------------------------- actor forward of both envs (whole wave)
+    for (int idx = tid; idx < 2 * Dp; idx += 64) {
+      const int e = idx / Dp, k = idx - e * Dp;
+      xs[idx] = k < D ? (sh.g[e].obsf()[k] - ra.obs_mean[k]) / ra.obs_std[k] : 0.f;
+    }
+    SYNC();
+    {
+      float a0[4] = {0.f, 0.f, 0.f, 0.f}, a1[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
+      for (int k = 0; k < Dp; k++) {
+        const float4 w = *reinterpret_cast<const float4*>(ra.w1t + (size_t)k * H + 4 * tid);
+        const float x0 = xs[k], x1 = xs[Dp + k];
+        a0[0] = fmaf(x0, w.x, a0[0]); a0[1] = fmaf(x0, w.y, a0[1]); a0[2] = fmaf(x0, w.z, a0[2]); a0[3] = fmaf(x0, w.w, a0[3]);
+        a1[0] = fmaf(x1, w.x, a1[0]); a1[1] = fmaf(x1, w.y, a1[1]); a1[2] = fmaf(x1, w.z, a1[2]); a1[3] = fmaf(x1, w.w, a1[3]);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const float b = ra.b1[4 * tid + q];
+        h1s[4 * tid + q] = fmaxf(a0[q] + b, 0.f);
+        h1s[H + 4 * tid + q] = fmaxf(a1[q] + b, 0.f);
+      }
+    }
+    SYNC();
+    {
+      float a0[4] = {0.f, 0.f, 0.f, 0.f}, a1[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
+      for (int k = 0; k < H; k++) {
+        const float4 w = *reinterpret_cast<const float4*>(ra.w2t + (size_t)k * H + 4 * tid);
+        const float x0 = h1s[k], x1 = h1s[H + k];
+        a0[0] = fmaf(x0, w.x, a0[0]); a0[1] = fmaf(x0, w.y, a0[1]); a0[2] = fmaf(x0, w.z, a0[2]); a0[3] = fmaf(x0, w.w, a0[3]);
+        a1[0] = fmaf(x1, w.x, a1[0]); a1[1] = fmaf(x1, w.y, a1[1]); a1[2] = fmaf(x1, w.z, a1[2]); a1[3] = fmaf(x1, w.w, a1[3]);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const float b = ra.b2[4 * tid + q];
+        h2s[4 * tid + q] = fmaxf(a0[q] + b, 0.f);
+        h2s[H + 4 * tid + q] = fmaxf(a1[q] + b, 0.f);
+      }
+    }
+    SYNC();
+    if (tid < 2 * A) {   // lane = (env of the wave, action component): mean, sample, log-density term
+      const int e = tid / A, a = tid - e * A;
+      float acc = 0.f;
+#pragma unroll 8
+      for (int k = 0; k < H; k++) acc = fmaf(h2s[e * H + k], ra.w3[(size_t)a * H + k], acc);
+      const float mu = acc + ra.b3[a];
+      float term;
+      const float x = lhw_policy_sample(mu, ra.stds[a], ra.seed, ra.env_id_base + (unsigned)(e0 + e), ra.counter0 + (unsigned)t, a,
+                                        ra.deterministic, &term);
+      sh.g[e].actf()[a] = x;
+      lps[e * A + a] = term;
+      if (e == 0 || 2 * (int)blockIdx.x + 1 < p.env_count) ra.act[((size_t)t * N + e0 + e) * A + a] = x;
+    }
+    SYNC();
+    if (tid < 2 && (tid == 0 || 2 * (int)blockIdx.x + 1 < p.env_count)) {
+      float lp = 0.f;
+      for (int a = 0; a < A; a++) lp += lps[tid * A + a];
+      ra.logp[(size_t)t * N + e0 + tid] = lp;
+    }
+    SYNC();
+    // ---------------------------------------------------------------- control step of both envs (two groups of 32 lanes)
+    float* obs_t1 = ra.obs + (size_t)(t + 1) * N * D;
+    float* tob_t = ra.tob + (size_t)t * N * D;
+    float* rew_t = ra.rew + (size_t)t * N;
+    unsigned char* done_t = ra.done + (size_t)t * N;
+    float* terms_t = (t == ra.T - 1) ? ra.rew_terms : nullptr;
+    bool handed = false;
+    if (have) handed = control_step<0, TASK, 32>(m, p, st, sh.g[gid], env, l32, nullptr, obs_t1, tob_t, rew_t, done_t, terms_t, nullptr, nullptr);
+    __syncthreads();   // the two groups ran divergently; the policy below is a whole-wave computation (one-wave workgroup: free)
+    const unsigned long long hb = __ballot(handed);
+    if (hb) {
+      // An env touched more than 8 contacts: the whole wave repeats its control step with the one-env-per-wave layout (the
+      // W = 32 step wrote nothing of it).  The LDS of both groups is overwritten; everything persistent is in the records.
+      __threadfence();   // this step's actions were written by other lanes of this wave
+      const float* act_t = ra.act + (size_t)t * N * A;
+      for (int e = 0; e < 2; e++) {
+        if (!((hb >> (32 * e)) & 1ull)) continue;
+        control_step<0, TASK, 64>(m, p, st, sh.one, e0 + e, tid, act_t, obs_t1, tob_t, rew_t, done_t, terms_t, nullptr, nullptr);
+        if (tid == 0) { st.slow[e0 + e] = 0; atomicAdd(&st.ep_stats[5], 1.0); }
+      }
+      __threadfence();
+      SYNC();
+      if (have) for (int k = l32; k < D; k += 32) sh.g[gid].obsf()[k] = obs_t1[(size_t)env * D + k];
+      SYNC();
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ host side
@@ -2609,7 +2764,7 @@ int humanoid_create(HumanoidEnv** out, const std::vector<int32_t>& mi, const std
   if (rec) h->dev_allocs.push_back(rec);
   if (irec) h->dev_allocs.push_back(irec);
   if (eps) h->dev_allocs.push_back(eps);
-  h->st.rec = (double*)rec; h->st.irec = (int*)irec; h->st.ep_stats = (double*)eps; h->st.prof = nullptr;
+  h->st.rec = (double*)rec; h->st.irec = (int*)irec; h->st.ep_stats = (double*)eps; h->st.prof = nullptr; h->st.wave_cyc = nullptr;
   if (!ok) { humanoid_destroy(h); return lhw_fail(LHW_ERR_HIP, "humanoid_create: device allocation failed or bad body ids"); }
   *obs_dim = stepping ? 39 : (walk ? 37 : (h1walk ? 43 : 35)); *act_dim = nu; *n_terms = ((walk && !stepping) || h1walk) ? 10 : 6;
   p.reset_template = -1;
@@ -2680,11 +2835,39 @@ void humanoid_set_state(HumanoidEnv* h, const double* qpos, const double* qvel, 
   LAUNCH(2, (const float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, (unsigned char*)nullptr, (float*)nullptr,
          (const unsigned char*)nullptr, const_cast<double*>(qpos), const_cast<double*>(qvel));
 }
+// whole-batch persistent rollout; 0 = launched, 1 = this env has no two-envs-per-wave kernels (caller steps it launch by launch)
+int humanoid_supports_rollout(HumanoidEnv* h) { return h->fast ? 1 : 0; }
+int humanoid_rollout(HumanoidEnv* h, const RolloutArgs& ra, hipStream_t s) {
+  if (!h->fast) return 1;
+  HParams pp = h->p;
+  pp.env_first = 0; pp.env_count = pp.n_envs; pp.only_flagged = 0;
+  const dim3 grid((pp.n_envs + 1) / 2);
+  if (pp.task == TASK_WALK) hipLaunchKernelGGL((humanoid_rollout_kernel<TASK_WALK>), grid, dim3(64), 0, s, h->m, pp, h->st, ra);
+  else if (pp.task == TASK_H1WALK) hipLaunchKernelGGL((humanoid_rollout_kernel<TASK_H1WALK>), grid, dim3(64), 0, s, h->m, pp, h->st, ra);
+  else if (pp.task == TASK_STAND) hipLaunchKernelGGL((humanoid_rollout_kernel<TASK_STAND>), grid, dim3(64), 0, s, h->m, pp, h->st, ra);
+  else return 1;
+  return 0;
+}
 double* humanoid_ep_stats(HumanoidEnv* h) { return h->st.ep_stats; }
 int humanoid_occupancy() {
   int nb = -1;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, humanoid_kernel<0, TASK_WALK, 32>, 64, 0) != hipSuccess) return -1;
   return nb;
+}
+// diagnostic: per-env duration of the last control-step launch (load balance across wavefronts)
+int humanoid_wave_cycles(HumanoidEnv* h, long long* out) {
+  const size_t N = h->p.n_envs;
+  if (!h->st.wave_cyc) {
+    void* d = nullptr;
+    if (hipMalloc(&d, (N + 1) * sizeof(long long)) != hipSuccess) return -1;
+    (void)hipMemset(d, 0, (N + 1) * sizeof(long long));
+    h->dev_allocs.push_back(d);
+    h->st.wave_cyc = (long long*)d;
+    return 0;
+  }
+  if (!out) return 0;
+  if (hipDeviceSynchronize() != hipSuccess) return -1;
+  return hipMemcpy(out, h->st.wave_cyc, N * sizeof(long long), hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
 }
 int humanoid_profile(HumanoidEnv* h, int enable, long long* out16) {
   if (enable && !h->st.prof) {
@@ -2703,6 +2886,22 @@ int humanoid_profile(HumanoidEnv* h, int enable, long long* out16) {
 }
 // curriculum input of the stepping task (stair height, stepping_task.py:305); the other tasks ignore it
 void humanoid_set_iteration(HumanoidEnv* h, int64_t it) { h->p.iteration = (int)std::min<int64_t>(it, 1 << 30); }
+// sq / sv / frc of the persistent records (fields of the last forward pass) -> host, torque = force * gear
+int humanoid_actuator_state(HumanoidEnv* h, double* pos, double* vel, double* tq) {
+  const size_t N = h->p.n_envs;
+  const int nu = h->m.nu;
+  std::vector<double> rec(N * REC_D), act_d((size_t)nu * ADS);
+  if (hipDeviceSynchronize() != hipSuccess) return -1;
+  if (hipMemcpy(rec.data(), h->st.rec, rec.size() * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  if (hipMemcpy(act_d.data(), h->m.act_d, act_d.size() * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  for (size_t n = 0; n < N; n++)
+    for (int u = 0; u < nu; u++) {
+      if (pos) pos[n * nu + u] = rec[n * REC_D + R_SQ + u];
+      if (vel) vel[n * nu + u] = rec[n * REC_D + R_SV + u];
+      if (tq) tq[n * nu + u] = rec[n * REC_D + R_FRC + u] * act_d[(size_t)ADS * u + AD_GEAR];
+    }
+  return 0;
+}
 int humanoid_step_record(HumanoidEnv* h, double* seq, double* floor_z, int32_t* istate) {
   if (!h->st.ter) return -1;
   const size_t N = h->p.n_envs;

@@ -17,12 +17,15 @@
 // (backward-weight, where the contraction runs over the minibatch).
 #include <hip/hip_runtime.h>
 
+#include <mutex>
+
 #include <cmath>
 #include <cstring>
 #include <vector>
 
 #include "../../include/lhw.h"
 #include "lhw_internal.h"
+#include "lhw_policy.h"
 #include "lhw_rng.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -313,7 +316,6 @@ struct LhwPpo {
   const unsigned char* imit_mask = nullptr;
   float imit_coeff = 0.f, imit_inv_count = 0.f;
   float *norm_part = nullptr;  // [2][SUMSQ_BLOCKS]
-  double *mom_part = nullptr;  // [MOM_BLOCKS][2]
   int max_slices = 0;
 };
 
@@ -439,17 +441,9 @@ __global__ void sample_kernel(const float* __restrict__ mu, int ldmu, int A, int
   if (n >= N) return;
   float lp = 0.f;
   for (int a = 0; a < A; a++) {
-    float m = mu[(size_t)n * ldmu + a], sd = stdv[a], x = m;
-    if (!deterministic) {
-      // Box-Muller on two counter-based uniforms (the reference samples torch.distributions.Normal, actor.py:180)
-      double u1 = lhw_rng_u01(seed, env_base + n, LHW_STREAM_POLICY, counter, 2 * a);
-      double u2 = lhw_rng_u01(seed, env_base + n, LHW_STREAM_POLICY, counter, 2 * a + 1);
-      float z = (float)(sqrt(-2.0 * log(1.0 - u1)) * cos(6.283185307179586 * u2));
-      x = m + sd * z;
-    }
-    act[(size_t)n * A + a] = x;
-    float d = (x - m) / sd;
-    lp += -0.5f * d * d - logf(sd) - 0.9189385332046727f;
+    float term;
+    act[(size_t)n * A + a] = lhw_policy_sample(mu[(size_t)n * ldmu + a], stdv[a], seed, env_base + n, counter, a, deterministic, &term);
+    lp += term;
   }
   logp[n] = lp;
 }
@@ -680,8 +674,7 @@ extern "C" int lhw_ppo_create(const LhwPpoConfig* c, LhwPpo** out) {
             alloc(&p->mb_ret, R) && alloc(&p->stats, 16) && alloc(&p->dstd, R * Op) && alloc(&p->stats_part, ((R + 255) / 256) * NSTAT) &&
             alloc(&p->norm_part, 2 * SUMSQ_BLOCKS);
   p->max_slices = (int)((R + 511) / 512);
-  ok = ok && alloc(&p->part, std::max<size_t>((size_t)p->max_slices * H * std::max<size_t>(H, Dp), (size_t)COLSUM_CHUNKS * H)) &&
-       hipMalloc(&p->mom_part, sizeof(double) * 2 * MOM_BLOCKS) == hipSuccess;
+  ok = ok && alloc(&p->part, std::max<size_t>((size_t)p->max_slices * H * std::max<size_t>(H, Dp), (size_t)COLSUM_CHUNKS * H));
   if (ok && p->use_mirror) {
     std::vector<int> osrc(Dp, 0), asrc(p->A, 0);
     std::vector<float> osgn(Dp, 0.f), asgn(p->A, 0.f);
@@ -715,7 +708,6 @@ extern "C" int lhw_ppo_destroy(LhwPpo* p) {
   for (float* b : bufs) if (b) (void)hipFree(b);
   if (p->d_obs_src) (void)hipFree(p->d_obs_src);
   if (p->d_act_src) (void)hipFree(p->d_act_src);
-  if (p->mom_part) (void)hipFree(p->mom_part);
   delete p;
   return LHW_OK;
 }
@@ -800,9 +792,22 @@ extern "C" int lhw_ppo_forward_at(LhwPpo* p, const float* theta, const float* ob
   return ppo_forward_impl(p, theta, obs, N, obs_mean, obs_std, seed, env_id_base, counter, deterministic, ws_row, mu, act, logp, value, stream);
 }
 
+#define LHW_MAX_DEVICES 64
+// device that owns a device pointer; makes it current (the handle-free entry points below have no LhwPpo to ask)
+static int device_of(const void* ptr, int* dev) {
+  hipPointerAttribute_t at;
+  if (hipPointerGetAttributes(&at, ptr) != hipSuccess) return lhw_fail(LHW_ERR_ARG, "not a device pointer");
+  if (at.device < 0 || at.device >= LHW_MAX_DEVICES) return lhw_fail(LHW_ERR_ARG, "device %d out of range", at.device);
+  if (hipSetDevice(at.device) != hipSuccess) return lhw_fail(LHW_ERR_HIP, "hipSetDevice(%d) failed", at.device);
+  *dev = at.device;
+  return 0;
+}
+
 extern "C" int lhw_gae(int32_t T, int32_t N, const float* rew, const float* val, const uint8_t* done, const float* vterm,
                        const float* vfinal, double gamma, double lam, float* ret, float* adv, void* stream) {
   if (T <= 0 || N <= 0 || !rew || !val || !done || !vterm || !vfinal || !ret || !adv) return lhw_fail(LHW_ERR_ARG, "bad argument");
+  int dev = 0;
+  if (device_of(rew, &dev)) return LHW_ERR_HIP;
   hipLaunchKernelGGL(gae_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, T, N, rew, val, done, vterm, vfinal,
                      gamma, lam, ret, adv);
   HIPCHK(hipGetLastError());
@@ -812,8 +817,18 @@ extern "C" int lhw_gae(int32_t T, int32_t N, const float* rew, const float* val,
 // sum and sum of squares (float64) of x[0..n): the caller all-reduces them across GPUs, then calls lhw_scale_shift
 extern "C" int lhw_moments(const float* x, int64_t n, double* out2_dev, void* stream) {
   if (!x || !out2_dev || n <= 0) return lhw_fail(LHW_ERR_ARG, "bad argument");
-  static thread_local double* scratch = nullptr;  // per-thread, per-process partial buffer (device of the first call)
-  if (!scratch) HIPCHK(hipMalloc(&scratch, sizeof(double) * 2 * MOM_BLOCKS));
+  // handle-free entry point: run on the device that owns x, with that device's own partial-sum buffer (kept for the
+  // process lifetime; one per device, so a process driving several GPUs never hands a kernel a foreign-device pointer)
+  int dev = 0;
+  if (device_of(x, &dev)) return LHW_ERR_HIP;
+  static double* scratch_of[LHW_MAX_DEVICES] = {nullptr};
+  static std::mutex mu;
+  double* scratch;
+  {
+    std::lock_guard<std::mutex> lock(mu);
+    if (!scratch_of[dev]) HIPCHK(hipMalloc(&scratch_of[dev], sizeof(double) * 2 * MOM_BLOCKS));
+    scratch = scratch_of[dev];
+  }
   hipLaunchKernelGGL(moments_kernel, dim3(MOM_BLOCKS), dim3(256), 0, (hipStream_t)stream, x, (size_t)n, scratch);
   hipLaunchKernelGGL(moments_final_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, scratch, MOM_BLOCKS, out2_dev);
   HIPCHK(hipGetLastError());
@@ -821,6 +836,8 @@ extern "C" int lhw_moments(const float* x, int64_t n, double* out2_dev, void* st
 }
 extern "C" int lhw_scale_shift(float* x, int64_t n, float mean, float inv_scale, void* stream) {
   if (!x || n <= 0) return lhw_fail(LHW_ERR_ARG, "bad argument");
+  int dev = 0;
+  if (device_of(x, &dev)) return LHW_ERR_HIP;
   hipLaunchKernelGGL(scale_shift_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, (size_t)n, mean, inv_scale);
   HIPCHK(hipGetLastError());
   return LHW_OK;

@@ -16,6 +16,41 @@ from .jvrc_step import JvrcStepSpec
 from .jvrc_walk import JvrcWalkSpec
 
 
+class _InterfaceView:
+    """Read-only subset of the reference's RobotInterface (envs/common/robot_interface.py:60-185) over the device state
+    of the single env: what tests and evaluation scripts query after reset()/step().  Mutators (set_pd_gains,
+    set_motor_torque, step ...) are the kernel's business and are not offered."""
+
+    def __init__(self, owner):
+        self._o = owner
+
+    def nq(self): return self._o._env.nq
+    def nv(self): return self._o._env.nv
+    def nu(self): return self._o.spec.act_dim
+    def sim_dt(self): return self._o.spec.sim_dt
+    def get_robot_mass(self): return float(self._o.spec.model().totalmass)
+    def get_qpos(self): return self._o._env.get_state()[0][0].copy()
+    def get_qvel(self): return self._o._env.get_state()[1][0].copy()
+    def get_gear_ratios(self): return np.asarray(self._o.spec.model().actuator_gear, dtype=float).copy()
+    def get_motor_names(self): return list(self._o.spec.model().actuator_names)
+    def get_act_joint_positions(self): return self._o._env.get_actuator_state()[0][0]
+    def get_act_joint_velocities(self): return self._o._env.get_actuator_state()[1][0]
+    def get_act_joint_torques(self): return self._o._env.get_actuator_state()[2][0]
+
+
+class _DataView:
+    """`env.data.qpos` / `.qvel` as read-only snapshots (the reference exposes mjData)."""
+
+    def __init__(self, owner):
+        self._o = owner
+
+    @property
+    def qpos(self): return self._o._env.get_state()[0][0].copy()
+
+    @property
+    def qvel(self): return self._o._env.get_state()[1][0].copy()
+
+
 class _SingleEnv:
     TERMS: list = []
 
@@ -28,6 +63,12 @@ class _SingleEnv:
         if spec.obs_mean is not None:
             self.obs_mean, self.obs_std = np.asarray(spec.obs_mean), np.asarray(spec.obs_std)
         self.robot = SimpleNamespace(iteration_count=np.inf)
+        # reference attribute names (tests/test_environments.py:232-246): the task runs inside the kernel, so `task` only
+        # describes it; `interface` / `data` are read-only views of the device state, `model` is the compiled model
+        self.task = SimpleNamespace(name=type(spec).__name__.replace("Spec", ""), reward_terms=list(self.TERMS))
+        self.model = spec.model()
+        self.interface = _InterfaceView(self)      # (the get_act_joint_* getters raise for cartpole: its kernel keeps no such fields)
+        self.data = _DataView(self)
         self._mask = torch.ones(1, dtype=torch.uint8, device=self._env.device)
         self._act = torch.zeros(1, spec.act_dim, dtype=torch.float32, device=self._env.device)
 

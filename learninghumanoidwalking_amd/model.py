@@ -249,12 +249,11 @@ def generate_header() -> str:
     return "\n".join(out)
 
 
-def pack_from_mjmodel(m) -> tuple[np.ndarray, np.ndarray]:
-    """Fill the blobs from a real ``mujoco.MjModel`` (reference-side binding).
-
-    Not exercised in this container (mujoco is not installed); see INTEGRATION.md.
-    Collision candidates are rebuilt with the same static filter as our compiler.
-    """
+def model_from_mjmodel(m) -> Model:
+    """Build a `Model` from a real ``mujoco.MjModel`` (reference-side binding; scripts/pin_vs_mujoco.py runs the CPU oracle on
+    it next to ``mj_step``).  Not exercised in this container (mujoco is not installed); see INTEGRATION.md.
+    Collision candidates are rebuilt with the same static filter as our compiler."""
+    import mujoco  # noqa: F401  (only to fail early with a clear message)
     from . import mjcf  # local import: mjcf depends on this module
 
     mod = Model(
@@ -267,17 +266,20 @@ def pack_from_mjmodel(m) -> tuple[np.ndarray, np.ndarray]:
         o_margin=float(m.opt.o_margin),
     )
     a = mod.arrays
-    for name, _, width, sym in FIELDS:
+    for name, kind, width, sym in FIELDS:
         if name.startswith("pair_"):
             continue
         if name == "actuator_trnid":
-            a[name] = np.asarray(m.actuator_trnid)[:, 0].copy()
+            v = np.asarray(m.actuator_trnid)[:, 0]
         elif name == "actuator_gear":
-            a[name] = np.asarray(m.actuator_gear)[:, 0].copy()
-        elif name == "dof_jntid":
-            a[name] = np.asarray(m.dof_jntid).copy()
+            v = np.asarray(m.actuator_gear)[:, 0]
         else:
-            a[name] = np.asarray(getattr(m, name)).copy()
+            v = np.asarray(getattr(m, name))
+        a[name] = np.ascontiguousarray(v, dtype=np.int32 if kind == "i" else np.float64).copy()
+    for kind, names, count in (("body", mod.body_names, m.nbody), ("joint", mod.jnt_names, m.njnt), ("geom", mod.geom_names, m.ngeom),
+                               ("actuator", mod.actuator_names, m.nu), ("site", mod.site_names, m.nsite)):
+        acc = getattr(m, kind)
+        names.extend((acc(i).name or f"{kind}{i}") for i in range(count))
     excludes = set()
     for k in range(m.nexclude):
         sig = int(m.exclude_signature[k])
@@ -285,7 +287,12 @@ def pack_from_mjmodel(m) -> tuple[np.ndarray, np.ndarray]:
     g1, g2 = mjcf.build_pairs(mod, excludes)
     a["pair_geom1"], a["pair_geom2"] = g1, g2
     mod.npair = len(g1)
-    return mod.pack()
+    return mod
+
+
+def pack_from_mjmodel(m) -> tuple[np.ndarray, np.ndarray]:
+    """LHWM blobs of a real ``mujoco.MjModel`` (what `lhw_env_create` takes)."""
+    return model_from_mjmodel(m).pack()
 
 
 if __name__ == "__main__":

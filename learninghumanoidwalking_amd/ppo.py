@@ -37,6 +37,25 @@ class BatchData:
     ep_rewards: torch.Tensor
 
 
+class _AdamView:
+    """`actor_optimizer` / `critic_optimizer` of the reference (torch.optim.Adam over the two networks, ppo.py:128-129) as a
+    read-only view: one fused Adam kernel updates the flat parameter vector, its moments live in PpoKernels.adam_m / adam_v."""
+
+    def __init__(self, kernels, names, lr, eps):
+        self._k, self._names = kernels, names
+        self.defaults = dict(lr=lr, betas=(0.9, 0.999), eps=eps, weight_decay=0)
+        self.param_groups = [dict(self.defaults, params=list(names))]
+
+    def state_dict(self):
+        k = self._k
+        state = {n: dict(step=int(k.adam_step), exp_avg=k._view(k.adam_m, n).detach().cpu().clone(),
+                         exp_avg_sq=k._view(k.adam_v, n).detach().cpu().clone()) for n in self._names if hasattr(k, "_view")}
+        return dict(state=state, param_groups=[dict(self.defaults, params=list(self._names))])
+
+    def zero_grad(self):      # gradients are zeroed by the apply kernel after every optimiser step
+        pass
+
+
 class RunningMeanStd:
     """Chan parallel mean/variance (reference rl/envs/normalize.py:4-61)."""
 
@@ -94,6 +113,11 @@ class Rollout:
         want = int(os.environ.get("LHW_ROLLOUT_GROUPS", "2" if (N >= 2048 and hasattr(env, "step_range") and env.task != 0) else "1"))
         self.groups = max(1, min(want, N)) if env.task != 0 else 1
         self.streams = None
+        # One launch per rollout with the actor evaluated inside the stepper (lhw_env_rollout) where the env offers it and the
+        # policy is the float32 feed-forward 256-256 actor; LHW_ROLLOUT_PERSISTENT=0 forces the launch-per-step paths.
+        self.persistent = (os.environ.get("LHW_ROLLOUT_PERSISTENT", "1") != "0" and getattr(env, "supports_rollout", False)
+                           and not getattr(kernels, "recurrent", False) and not getattr(kernels, "inference_fp16", False)
+                           and getattr(kernels, "hidden", 0) == 256)
         self.counter = 0
         self.started = False
         self.env_base = getattr(env, "env_id_base", 0)
@@ -113,7 +137,11 @@ class Rollout:
         if self.tob_all is None:
             self.tob_all = torch.zeros(T, self.N, self.obs.shape[2], dtype=torch.float32, device=self.obs.device)
         G = self.groups
-        if G <= 1:
+        if self.persistent:
+            env.rollout(T, self._actor_for_rollout(), self.obs, self.act, self.logp, self.rew, self.tob_all, self.done,
+                        seed=self.seed, env_id_base=self.env_base, counter0=self.counter, deterministic=deterministic)
+            self.counter += T
+        elif G <= 1:
             for t in range(T):
                 k.forward(self.obs[t], seed=self.seed, env_id_base=self.env_base, counter=self.counter,
                           deterministic=deterministic, want_value=False, mu=self.mu, act=self.act[t], logp=self.logp[t])
@@ -145,6 +173,18 @@ class Rollout:
         self._batched_values(self.tob_all.reshape(T * self.N, -1), self.vterm.reshape(-1))
         k.forward(self.obs[T], want_actor=False, value=self.vfinal)
 
+    def _actor_for_rollout(self):
+        """The actor's tensors in the layout lhw_env_rollout streams them in: layers 1 and 2 k-major (one 16-byte load per k
+        and lane covers four hidden units), rows of w1t beyond the observation length zero."""
+        k = self.k
+        D, H, A = k.obs_dim, k.hidden, k.act_dim
+        v = lambda n: k._view(k.theta, n)
+        w1t = torch.zeros((D + 3) // 4 * 4, H, dtype=torch.float32, device=k.theta.device)
+        w1t[:D].copy_(v("a_w1").t())
+        return dict(w1t=w1t, b1=v("a_b1").contiguous(), w2t=v("a_w2").t().contiguous(), b2=v("a_b2").contiguous(),
+                    w3=v("a_w3").contiguous(), b3=v("a_b3").contiguous(), stds=v("stds").contiguous(),
+                    obs_mean=k.obs_mean, obs_std=k.obs_std)
+
     def _batched_values(self, obs_flat, out_flat):
         chunk = int(self.k.max_rows)
         for a in range(0, obs_flat.shape[0], chunk):
@@ -153,13 +193,20 @@ class Rollout:
 
 
     def _collect_recurrent(self, deterministic):
-        """LSTM policies: every env starts a fresh episode at the start of the batch (the reference's worker begins each
-        sample() call with env.reset() and zero hidden state, rollout_worker.py:130-137), the hidden state advances with
-        every policy / critic call and is zeroed for envs whose episode just ended; terminal and final values are
-        evaluated without advancing it."""
+        """LSTM policies.  As in the reference's worker (rollout_worker.py:130-190: `current_state` / hidden state are only
+        initialised when they are None), episodes AND the LSTM hidden / cell state are carried from one batch to the next:
+        the envs are reset once, before the first batch; afterwards a batch starts from the last observation of the previous
+        one with the hidden state the previous batch left, zeroed only for envs whose episode ended on its last step.  The
+        hidden state advances with every policy / critic call; terminal and final values are evaluated without advancing it.
+        (The update, like the reference's, restarts every stored trajectory -- here every env column -- from a zero state.)"""
         env, k, T = self.env, self.k, self.T
-        self.obs[0].copy_(env.reset())
-        reset = torch.ones(self.N, dtype=torch.uint8, device=self.obs.device)
+        if not self.started:
+            self.obs[0].copy_(env.reset())
+            self._rec_reset = torch.ones(self.N, dtype=torch.uint8, device=self.obs.device)
+            self.started = True
+        else:
+            self.obs[0].copy_(self.obs[T])
+        reset = self._rec_reset
         for t in range(T):
             k.forward(self.obs[t], reset=reset, seed=self.seed, env_id_base=self.env_base, counter=self.counter,
                       deterministic=deterministic, commit=True, mu=self.mu, act=self.act[t], logp=self.logp[t], value=self.val[t])
@@ -167,6 +214,7 @@ class Rollout:
             k.forward(self.tob, commit=False, want_actor=False, value=self.vterm[t])
             reset = (self.done[t] != 0).to(torch.uint8)
             self.counter += 1
+        self._rec_reset = reset
         k.forward(self.obs[T], commit=False, want_actor=False, value=self.vfinal)
 
 
@@ -189,11 +237,12 @@ class PPO:
         self.total_steps = 0
         self.iteration_count = 0
         self.save_path = Path(args.logdir)
-        self.save_path.mkdir(parents=True, exist_ok=True)
         self.best_metric = -np.inf
         d = _dist()
         self.rank = d.get_rank() if d else 0
         self.world = d.get_world_size() if d else 1
+        if self.rank == 0:
+            self.save_path.mkdir(parents=True, exist_ok=True)
         dev_index = getattr(args, "device_index", None)
         if dev_index is None:
             dev_index = torch.cuda.current_device() if torch.cuda.is_available() else 0
@@ -223,12 +272,10 @@ class PPO:
                 t["stds"] = args.std_dev * torch.ones(act_dim)
                 self.kernels.set_tensors(t)
                 self.kernels.set_obs_norm(om.numpy(), osd.numpy())
-                print("Loaded (pre-trained) actor from: ", continued)
-                print("Loaded (pre-trained) critic from: ", cpath)
+                self._log("Loaded (pre-trained) actor from: " + str(continued))
+                self._log("Loaded (pre-trained) critic from: " + str(cpath))
             else:
-                cpu_state = torch.random.get_rng_state()
-                self.kernels.set_tensors(reference_init_lstm(obs_dim, act_dim, hidden, args.std_dev, generator_seed=seed if seed is not None else 0))
-                torch.random.set_rng_state(cpu_state)
+                self.kernels.set_tensors(reference_init_lstm(obs_dim, act_dim, hidden, args.std_dev, generator_seed=self._init_seed(seed)))
         else:
             self.kernels = PpoKernels(
                 obs_dim, act_dim, hidden=256, max_rows=max(self.n_proc, int(self.minibatch_size or self.batch_size)),
@@ -251,24 +298,21 @@ class PPO:
             self.kernels.set_tensors(t)
             self.kernels.set_obs_norm(om.numpy(), osd.numpy())
             self.obs_rms = None
-            print("Loaded (pre-trained) actor from: ", continued)
-            print("Loaded (pre-trained) critic from: ", cpath)
+            self._log("Loaded (pre-trained) actor from: " + str(continued))
+            self._log("Loaded (pre-trained) critic from: " + str(cpath))
         else:
             # identical initial weights on every rank: the reference's init path under a fixed torch seed
-            gen_seed = seed if seed is not None else 0
-            cpu_state = torch.random.get_rng_state()
-            self.kernels.set_tensors(reference_init(obs_dim, act_dim, 256, args.std_dev, generator_seed=gen_seed))
-            torch.random.set_rng_state(cpu_state)
+            self.kernels.set_tensors(reference_init(obs_dim, act_dim, 256, args.std_dev, generator_seed=self._init_seed(seed)))
         if continued:
             pass
         elif spec.obs_mean is not None:
             self.obs_rms = None
             self.kernels.set_obs_norm(spec.obs_mean, spec.obs_std)
-            print("Using fixed observation normalization from environment.")
+            self._log("Using fixed observation normalization from environment.")
         else:
             self.obs_rms = RunningMeanStd(shape=(obs_dim,))
             self.kernels.set_obs_norm(self.obs_rms.mean, self.obs_rms.std)
-            print("Using running observation normalization (will update during training).")
+            self._log("Using running observation normalization (will update during training).")
         env_seed = (seed if seed is not None else int(time.time())) & 0x7FFFFFFF
         self.env_seed = env_seed
         self.env = spec.make_batched(self.n_proc, seed=env_seed, device=self.device, max_traj_len=self.max_traj_len,
@@ -288,6 +332,12 @@ class PPO:
             self.imitation_projector = projector
         self.policy = self.kernels  # attribute names the reference's tests look for
         self.critic = self.kernels
+        # The reference deep-copies the actor into old_policy every iteration only to evaluate the behaviour log-probs; here
+        # they are stored by the rollout (and recomputed in float32 for the fp16-inference mode), so old_policy is the policy.
+        self.old_policy = self.kernels
+        names = list(getattr(self.kernels, "TENSORS", []))
+        self.actor_optimizer = _AdamView(self.kernels, [n for n in names if n.startswith("a_") or n == "stds"], self.lr, self.eps)
+        self.critic_optimizer = _AdamView(self.kernels, [n for n in names if n.startswith("c_")], self.lr, self.eps)
         self.last_losses = {}
 
     # ------------------------------------------------------------------ sampling
@@ -302,8 +352,20 @@ class PPO:
         self._ep_stats = (rs, ls, cnt)
         return BatchData(states=ro.obs[:T].reshape(T * N, -1), actions=ro.act.reshape(T * N, -1),
                          rewards=ro.rew.reshape(T * N, 1), values=ro.val.reshape(T * N, 1), returns=ret.reshape(T * N, 1),
-                         dones=ro.done.reshape(T * N, 1), traj_idx=torch.zeros(0),
+                         dones=ro.done.reshape(T * N, 1), traj_idx=self._traj_idx(ro.done),
                          ep_lens=torch.tensor([ls / cnt] if cnt else []), ep_rewards=torch.tensor([rs / cnt] if cnt else []))
+
+    @staticmethod
+    def _traj_idx(done):
+        """Trajectory boundaries like PPOBuffer.traj_idx (rl/storage/rollout_storage.py:24-51: [0, end of 1st trajectory, ...,
+        number of samples]) for the ENV-MAJOR order of the batch -- sample (env n, step t) at n * T + t, i.e.
+        `states.view(T, N, -1).transpose(0, 1)`: one env's T steps are contiguous there, and a trajectory ends where that env's
+        episode ended or the buffer filled.  (The tensors of BatchData themselves are time-major, [T][N] flattened.)"""
+        T, N = done.shape
+        ends = (done.t() != 0)                      # [N][T]
+        ends[:, T - 1] = True
+        idx = torch.nonzero(ends.reshape(-1)).reshape(-1) + 1
+        return torch.cat([torch.zeros(1, dtype=idx.dtype, device=idx.device), idx])
 
     # ------------------------------------------------------------------ update
     def _normalize_advantages(self, adv_flat):
@@ -401,15 +463,18 @@ class PPO:
         xn, xm = k.normalize(raw_obs)
         act = ro.act.reshape(n_samples, -1)
         logp = ro.logp.reshape(-1)
+        if getattr(k, "inference_fp16", False):
+            # The rollout's log-probs came out of the fp16-operand forward; the update evaluates the policy in float32, so
+            # ratio != 1 on the very first minibatch from precision noise alone (amplified by 1 / std^2).  The reference
+            # evaluates old_policy and policy in the same precision (ppo.py:305-309): recompute the old log-probs once per
+            # iteration with the float32 actor, before any weight changes.
+            logp = self._float32_log_probs(raw_obs, act)
         mb = int(self.minibatch_size or n_samples)
         mb = min(mb, n_samples)
         k.stats.zero_()
         n_updates = 0
         for epoch in range(self.epochs):
-            g = torch.Generator(device=self.device)
-            base = self.seed if self.seed is not None else 0
-            g.manual_seed(base + itr * self.epochs + epoch + 1000003 * self.rank)
-            perm = torch.randperm(n_samples, generator=g, device=self.device, dtype=torch.int64).to(torch.int32)
+            perm = self._minibatch_perm(itr, epoch, n_samples)
             for start in range(0, n_samples - mb + 1, mb):
                 mb_idx = perm[start:start + mb]
                 imit = self._imitation_term(raw_obs.index_select(0, mb_idx.long())) if self.imitation_projector is not None else None
@@ -420,6 +485,29 @@ class PPO:
         self.last_losses = dict(actor=float(s[0]), critic=float(s[1]), mirror=float(s[2]), kl=float(s[3]),
                                 clip_fraction=float(s[4]), imitation=float(s[5]), entropy=self._entropy_penalty(), n_updates=n_updates)
         return self.last_losses
+
+    def _minibatch_perm(self, itr, epoch, n_samples, rank=None):
+        """Shuffle of this rank's samples for one epoch (per-rank shuffles: statistically, not bitwise, the reference's global
+        randperm, ppo.py:487-490); a pure function of (seed, iteration, epoch, rank)."""
+        g = torch.Generator(device=self.device)
+        base = self.seed if self.seed is not None else 0
+        g.manual_seed(base + itr * self.epochs + epoch + 1000003 * (self.rank if rank is None else rank))
+        return torch.randperm(n_samples, generator=g, device=self.device, dtype=torch.int64).to(torch.int32)
+
+    def _float32_log_probs(self, obs_flat, act_flat):
+        k = self.kernels
+        sd = k.get_tensors()["stds"].to(self.device)
+        out = torch.empty(obs_flat.shape[0], dtype=torch.float32, device=self.device)
+        k.set_inference_fp16(False)
+        try:
+            chunk = int(k.max_rows)
+            for a in range(0, obs_flat.shape[0], chunk):
+                b = min(a + chunk, obs_flat.shape[0])
+                mu, _, _, _ = k.forward(obs_flat[a:b], deterministic=True, want_value=False)
+                out[a:b] = torch.distributions.Normal(mu, sd).log_prob(act_flat[a:b]).sum(-1)
+        finally:
+            k.set_inference_fp16(True)
+        return out
 
     def iterate(self, itr: int):
         """One PPO iteration: rollout + GAE + update.  Returns (n_samples_local, sample_time, optimize_time)."""
@@ -463,24 +551,40 @@ class PPO:
         return mean_r, mean_l
 
     # ------------------------------------------------------------------ training loop
+    def _init_seed(self, seed):
+        """Seed of the weight initialisation: the run's seed, or -- like the reference without --seed -- a fresh random one
+        (rank 0's under torch.distributed, so that every rank starts from the same weights)."""
+        if seed is not None:
+            return int(seed)
+        s = [int.from_bytes(os.urandom(4), "little")]
+        d = _dist()
+        if d:
+            d.broadcast_object_list(s, src=0)
+        return s[0]
+
+    def _log(self, msg):
+        """progress lines of PPO.train (reference rl/algos/ppo.py:459-566) -- rank 0 only under torch.distributed"""
+        if self.rank == 0:
+            print(msg)
+
     def train(self, env_fn, n_itr):
         train_start = time.time()
         k = self.kernels
         if self.obs_rms is not None:
-            print("Warming up observation normalization...")
+            self._log("Warming up observation normalization...")
             for i in range(5):  # ppo.py:442-457
                 batch = self.sample_parallel_with_workers()
                 mean, var, n = dist_utils.global_batch_moments(batch.states)  # == update on the concatenated batch
                 self.obs_rms.update_from_moments(mean.cpu().numpy(), var.cpu().numpy(), n)
-                print(f"  Warmup batch {i + 1}: {int(n)} samples, obs_rms count: {self.obs_rms.count:.0f}")
+                self._log(f"  Warmup batch {i + 1}: {int(n)} samples, obs_rms count: {self.obs_rms.count:.0f}")
             k.set_obs_norm(self.obs_rms.mean, self.obs_rms.std)
-            print(f"Normalization initialized with {self.obs_rms.count:.0f} samples")
+            self._log(f"Normalization initialized with {self.obs_rms.count:.0f} samples")
         for itr in range(n_itr):
-            print(f"********** Iteration {itr} ************")
+            self._log(f"********** Iteration {itr} ************")
             batch, sample_time, optimize_time = self.iterate(itr)
             num_samples = batch.states.shape[0] * self.world
-            print(f"Sampling took {sample_time:.2f}s for {num_samples} steps.")
-            print(f"Optimizer took: {optimize_time:.2f}s")
+            self._log(f"Sampling took {sample_time:.2f}s for {num_samples} steps.")
+            self._log(f"Optimizer took: {optimize_time:.2f}s")
             self.total_steps += num_samples
             L = self.last_losses
             rs, ls, cnt = self._ep_stats
@@ -506,10 +610,10 @@ class PPO:
             fps = self.total_steps / total_time
             iter_avg = total_time / (itr + 1)
             eta = round((n_itr - itr) * iter_avg)
-            print(f"Total time elapsed: {total_time:.2f}s. Total steps: {self.total_steps} "
-                  f"(fps={fps:.2f}. iter-avg={iter_avg:.2f}s. ETA={datetime.timedelta(seconds=eta)})")
+            self._log(f"Total time elapsed: {total_time:.2f}s. Total steps: {self.total_steps} "
+                      f"(fps={fps:.2f}. iter-avg={iter_avg:.2f}s. ETA={datetime.timedelta(seconds=eta)})")
             if itr == 0 or (itr + 1) % self.eval_freq == 0:
                 t0 = time.time()
                 mean_r, mean_l = self.evaluate(itr)
-                print("====EVALUATE EPISODE====")
-                print(f"(Episode length:{mean_l:.3f}. Reward:{mean_r:.3f}. Time taken:{time.time() - t0:.2f}s)")
+                self._log("====EVALUATE EPISODE====")
+                self._log(f"(Episode length:{mean_l:.3f}. Reward:{mean_r:.3f}. Time taken:{time.time() - t0:.2f}s)")

@@ -213,8 +213,16 @@ def reference_init(obs_dim, act_dim, hidden=256, init_std=0.223, generator_seed=
     actor mean layer x0.01 -- so that the same torch seed gives the reference's initial weights."""
     import torch.nn as nn
 
-    if generator_seed is not None:
-        torch.manual_seed(generator_seed)
+    # the draws come from the CPU default generator, seeded here and restored afterwards; the CUDA generators are left alone
+    # (torch.manual_seed would reseed them too)
+    with torch.random.fork_rng(devices=[]):
+        if generator_seed is not None:
+            torch.default_generator.manual_seed(int(generator_seed))
+        return _reference_init_draw(obs_dim, act_dim, hidden, init_std)
+
+
+def _reference_init_draw(obs_dim, act_dim, hidden, init_std):
+    import torch.nn as nn
 
     def net(out_dim, scale_out):
         layers = [nn.Linear(obs_dim, hidden), nn.Linear(hidden, hidden), nn.Linear(hidden, out_dim)]

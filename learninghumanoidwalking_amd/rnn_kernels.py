@@ -193,8 +193,16 @@ def reference_init_lstm(obs_dim, act_dim, hidden=256, init_std=0.2, generator_se
     rl/policies/actor.py:191-232, critic.py:52-66, base.py:5-22): per network two nn.LSTMCell (default uniform init, not
     touched by normc_fn) and one nn.Linear read-out, then normc on the Linear (actor read-out x0.01); actor first."""
     import torch.nn as nn
-    if generator_seed is not None:
-        torch.manual_seed(generator_seed)
+    # the draws come from the CPU default generator, seeded here and restored afterwards; the CUDA generators are left alone
+    # (torch.manual_seed would reseed them too)
+    with torch.random.fork_rng(devices=[]):
+        if generator_seed is not None:
+            torch.default_generator.manual_seed(int(generator_seed))
+        return _reference_init_lstm_draw(obs_dim, act_dim, hidden, init_std)
+
+
+def _reference_init_lstm_draw(obs_dim, act_dim, hidden, init_std):
+    import torch.nn as nn
 
     def net(out_dim, scale_out):
         cells = [nn.LSTMCell(obs_dim, hidden), nn.LSTMCell(hidden, hidden)]

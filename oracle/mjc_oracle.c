@@ -1283,10 +1283,33 @@ double* orc_field(OData* d, const char* name) {
   F(qpos) F(qvel) F(ctrl) F(xfrc_applied) F(qacc_warmstart) F(xpos) F(xquat) F(xmat) F(xipos) F(ximat) F(geom_xpos)
   F(geom_xmat) F(site_xpos) F(site_xmat) F(subtree_com) F(cvel) F(M) F(qfrc_bias) F(qfrc_passive) F(qfrc_actuator)
   F(qfrc_smooth) F(qacc_smooth) F(qfrc_constraint) F(qacc) F(actuator_length) F(actuator_velocity) F(actuator_force)
-  F(efc_J) F(efc_pos) F(efc_force) F(efc_aref) F(efc_D) F(efc_R)
+  F(efc_J) F(efc_pos) F(efc_force) F(efc_aref) F(efc_D) F(efc_R) F(efc_frictionloss)
 #undef F
   return NULL;
 }
+/* Independent cross-check of the primal Newton solver (tests/test_oracle_crosscheck.py): projected Gauss-Seidel on the DUAL
+ * of the same regularised problem,  min_f 1/2 f^T (A + R) f + f^T b,  A = J M^-1 J^T,  b = J qacc_smooth - aref,
+ * f_i >= 0 for limit / contact rows, |f_i| <= frictionloss_i for frictionloss rows (the formulation MuJoCo's PGS option
+ * uses; strictly convex, so its optimum is the Newton optimum).  AR is the dense n x n matrix A + diag(R), caller-built.
+ * Returns the number of sweeps done; stops when the largest force change of a sweep is below tol. */
+int orc_dual_pgs(int n, const double* AR, const double* b, const double* floss, const int* is_friction, double* f, int max_sweeps, double tol) {
+  int sweep = 0;
+  for (; sweep < max_sweeps; sweep++) {
+    double change = 0;
+    for (int i = 0; i < n; i++) {
+      double res = b[i];
+      for (int k = 0; k < n; k++) res += AR[(size_t)i * n + k] * f[k];
+      double fi = f[i] - res / AR[(size_t)i * n + i];
+      if (is_friction[i]) { if (fi > floss[i]) fi = floss[i]; else if (fi < -floss[i]) fi = -floss[i]; }
+      else if (fi < 0) fi = 0;
+      if (fabs(fi - f[i]) > change) change = fabs(fi - f[i]);
+      f[i] = fi;
+    }
+    if (change < tol) { sweep++; break; }
+  }
+  return sweep;
+}
+int orc_efc_type(const OData* d, int r) { return (r >= 0 && r < d->nefc) ? d->efc_type[r] : -1; }
 int orc_ncon(const OData* d) { return d->ncon; }
 int orc_nefc(const OData* d) { return d->nefc; }
 int orc_niter(const OData* d) { return d->solver_niter; }

@@ -44,6 +44,11 @@ def lib():
             getattr(L, f).restype = ctypes.c_int
         L.orc_time.argtypes = [ctypes.c_void_p]
         L.orc_time.restype = ctypes.c_double
+        L.orc_efc_type.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        L.orc_efc_type.restype = ctypes.c_int
+        L.orc_dual_pgs.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                   ctypes.c_int, ctypes.c_double]
+        L.orc_dual_pgs.restype = ctypes.c_int
         L.orc_contact.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
         L.orc_contact_force.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
         L.orc_object_velocity.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
@@ -106,6 +111,10 @@ class OracleSim:
         width = self.model.nv if name == "efc_J" else 1
         a = np.ctypeslib.as_array(p, shape=(n * width,)).copy()
         return a.reshape(n, width) if width > 1 else a
+
+    def efc_types(self):
+        """Row kinds in efc order: 0 frictionloss, 1 joint limit, 2 contact (pyramid edge)."""
+        return np.array([self._L.orc_efc_type(self._d, r) for r in range(self.nefc)], dtype=np.int32)
 
     @property
     def ncon(self):

@@ -70,8 +70,10 @@ def run_experiment(args):
     rank = dist.get_rank() if world > 1 else 0
     if args.env not in ENVIRONMENTS:
         raise SystemExit(f"unknown --env {args.env!r}; available: {sorted(ENVIRONMENTS)}")
-    timestamp = datetime.now().strftime("%y-%m-%d-%H-%M-%S-%f")[:-3]
-    args.logdir = Path(args.logdir) / f"{timestamp}_{args.env}"
+    stamp = [datetime.now().strftime("%y-%m-%d-%H-%M-%S-%f")[:-3]]
+    if world > 1:
+        dist.broadcast_object_list(stamp, src=0)     # one log directory per run, named by rank 0's clock
+    args.logdir = Path(args.logdir) / f"{stamp[0]}_{args.env}"
     args.device_index = local_rank
     Spec = ENVIRONMENTS[args.env]
     env_fn = partial(Spec, yaml_path=args.yaml) if (args.yaml and args.env != "cartpole") else Spec

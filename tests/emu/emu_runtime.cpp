@@ -27,7 +27,7 @@ emu_switch:
 .size emu_switch, .-emu_switch
 )");
 
-static const size_t STACK = 512 * 1024;
+static const size_t STACK = 1024 * 1024;
 
 static void trampoline() {
   Block* b = g_blk;

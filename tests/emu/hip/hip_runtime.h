@@ -155,6 +155,8 @@ static inline void __syncthreads() {
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
 #define __builtin_amdgcn_rsq(x) (1.0 / sqrt((double)(x)))
 #define __builtin_amdgcn_rcp(x) (1.0 / (double)(x))
+static inline void __threadfence() {}
+static inline void __threadfence_block() {}
 static inline int __any(int p) { return emu_ballot(p) != 0; }
 static inline int __all(int p) { return emu_ballot(!p) == 0; }
 static inline unsigned long long __ballot(int p) { return emu_ballot(p); }

@@ -49,8 +49,8 @@ def test_action_tape_resynchronised_with_dynrand_and_perturbation():
         res = [o.step(tape[t, i]) for i, o in enumerate(orc)]
         q, v = env.get_state()
         oq, ov = _states(orc)
-        np.testing.assert_allclose(q, oq, rtol=0, atol=1e-8, err_msg=f"qpos t={t}")
-        np.testing.assert_allclose(v, ov, rtol=0, atol=1e-7, err_msg=f"qvel t={t}")
+        np.testing.assert_allclose(q, oq, rtol=0, atol=1e-12, err_msg=f"qpos t={t}")
+        np.testing.assert_allclose(v, ov, rtol=0, atol=1e-10, err_msg=f"qvel t={t}")
         np.testing.assert_allclose(obs.cpu().numpy(), np.array([r[0] for r in res]), rtol=1e-5, atol=2e-5, err_msg=f"obs t={t}")
         np.testing.assert_allclose(rew.cpu().numpy(), np.array([r[1] for r in res]), rtol=0, atol=2e-6, err_msg=f"rew t={t}")
         terms = np.array([[r[3][k] for k in o.TERMS] for r, o in zip(res, orc)])

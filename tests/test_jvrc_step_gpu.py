@@ -56,7 +56,7 @@ def test_reset_sequences_terrain_and_obs():
 
 def test_action_tape_resynchronised_on_boxes():
     """Random-action tape, 120 control steps, re-synchronised every 5 steps; robots that fall are put back on the terrain
-    with an x offset so that feet straddle two boxes.  Positions 1e-8, velocities 1e-7, float32 outputs 2e-6, identical
+    with an x offset so that feet straddle two boxes.  Positions 1e-12, velocities 1e-10 (measured ~1e-14), float32 outputs 2e-6, identical
     termination flags and target bookkeeping."""
     import torch
     N, T = 8, 120
@@ -79,8 +79,8 @@ def test_action_tape_resynchronised_on_boxes():
             two_box += len(boxes) > 1
         q, v = env.get_state()
         oq, ov = _states(orc)
-        np.testing.assert_allclose(q, oq, rtol=0, atol=1e-8, err_msg=f"qpos t={t}")
-        np.testing.assert_allclose(v, ov, rtol=0, atol=1e-7, err_msg=f"qvel t={t}")
+        np.testing.assert_allclose(q, oq, rtol=0, atol=1e-12, err_msg=f"qpos t={t}")
+        np.testing.assert_allclose(v, ov, rtol=0, atol=1e-10, err_msg=f"qvel t={t}")
         np.testing.assert_allclose(obs.cpu().numpy(), np.array([r[0] for r in res]), rtol=1e-5, atol=2e-6, err_msg=f"obs t={t}")
         np.testing.assert_allclose(rew.cpu().numpy(), np.array([r[1] for r in res]), rtol=0, atol=2e-6, err_msg=f"rew t={t}")
         terms = np.array([[r[3][k] for k in o.TERMS] for r, o in zip(res, orc)])
@@ -162,15 +162,15 @@ def test_box_box_contact_variety():
     for t in range(4):
         obs, rew, done, _ = env.step(torch.from_numpy(act[t]).cuda())
         res = [o.step(act[t, i]) for i, o in enumerate(orc)]
-        keep = np.array([o.sim.ncon <= 16 for o in orc])
+        assert max(o.sim.ncon for o in orc) <= 16     # no env excluded: all of them fit the 16-contact layout
         for o in orc:
             ncon_box += sum(1 for k in range(o.sim.ncon) if m.geom_type[o.sim.contact(k)["geom1"]] == 6)
         gq, gv = env.get_state()
         oq, ov = _states(orc)
-        np.testing.assert_allclose(gq[keep], oq[keep], rtol=0, atol=1e-8, err_msg=f"qpos t={t}")
-        np.testing.assert_allclose(gv[keep], ov[keep], rtol=0, atol=1e-6, err_msg=f"qvel t={t}")
+        np.testing.assert_allclose(gq, oq, rtol=0, atol=1e-11, err_msg=f"qpos t={t}")
+        np.testing.assert_allclose(gv, ov, rtol=0, atol=1e-8, err_msg=f"qvel t={t}")
         env.set_state(oq, ov)
         for o in orc:
             o.set_state(o.sim.qpos.copy(), o.sim.qvel.copy())
     assert ncon_box > 20, ncon_box
-    assert keep.sum() >= N - 2
+    assert env.pop_fault_stats() == (0, 0)
