@@ -187,6 +187,15 @@ int lhw_env_pop_fault_stats(LhwEnv* env, int64_t* contact_overflow, int64_t* div
  * env touched more contacts than their layout holds (8); such a step costs roughly three ordinary ones.  Diagnostic of the
  * rollout, no reference counterpart (host pointer, synchronous, resets the counter). */
 int lhw_env_pop_rerun_count(LhwEnv* env, int64_t* reruns);
+/* Test / tuning hook for the update's GEMM kernel (no reference counterpart): C = op(A) op(B) on device buffers.
+ * a_kc: A stored [M][K] (else [K][M]); b_kc: B stored [N][K] (else [K][N]); wt: 0 = automatic tile choice, 1 = 64x64, 2 = 128x128
+ * block tiles; optional epilogue bias[n], ReLU, mask (v = mask[m][n] > 0 ? v : 0).  With `part` (split-K scratch,
+ * [ceil(K / k_chunk)][M*N] floats) the partial products are reduced in slice order and ADDED to C, as the weight-gradient GEMMs
+ * of lhw_ppo_grad do; `colsum` ([slices][M] scratch, A stored [K][M] only) also ADDS sum_k A[k][m] to colsum_out[m] (the bias
+ * gradient fused into the same pass).  Leading dimensions must be multiples of 4 floats (16-byte rows). */
+int lhw_debug_gemm(int32_t a_kc, int32_t b_kc, int32_t wt, int32_t M, int32_t N, int32_t K, const float* A, int32_t lda, const float* B,
+                   int32_t ldb, float* C, int32_t ldc, const float* bias, int32_t relu, const float* mask, int32_t ldmask,
+                   int32_t k_chunk, float* part, float* colsum, float* colsum_out, void* stream);
 /* Diagnostic (load balance): the first call arms the recording; later calls return, per env, the shader-clock cycles its
  * wavefront group spent in the most recent control-step launch.  HOST pointer [N] int64, synchronous; humanoid tasks only. */
 int lhw_env_debug_wave_cycles(LhwEnv* env, int64_t* cycles_host);

@@ -45,114 +45,152 @@ struct GemmArgs {
   const float* mask; int ldmask;  // *= (mask[m][n] > 0)
   float* part;              // split-K: slice z stores its partial product at part + z*M*N (row-major, ld N); reduced in slice order afterwards
   int k_chunk;              // K range per blockIdx.z
+  float* colsum;            // (A stored [K][M] only) slice z also stores sum_k A[k][m] at colsum + z*M: the bias gradient of a dW GEMM
+  int tiles_m, tiles_n, slices;   // filled in by launch_gemm
 };
 
+// C = op(A) op(B) on v_mfma_f32_32x32x2_f32.  Block = 4 waves (2 x 2), each wave owns WT x WT MFMA tiles of 32 x 32:
+// block tile 64 x 64 (WT = 1) or 128 x 128 (WT = 2; one LDS operand read per MFMA instead of two).  K advances in steps of
+// BK = 16 through double-buffered LDS tiles: the global loads of step k+1 are in flight while step k is multiplied and there
+// is one barrier per step.
 // A_KC: A is stored [M][K] (K contiguous); else A is stored [K][M] (M contiguous) i.e. we multiply by its transpose.
 // B_KC: B is stored [N][K] (K contiguous); else B is stored [K][N].
-template <bool A_KC, bool B_KC>
+template <bool A_KC, bool B_KC, int WT>
 __global__ void __launch_bounds__(256) gemm_f32_kernel(GemmArgs g) {
-  __shared__ float As[BK][LDS_LD];
-  __shared__ float Bs[BK][LDS_LD];
+  constexpr int TM = 64 * WT, LD = TM + 4;
+  __shared__ float As[2][BK][LD];
+  __shared__ float Bs[2][BK][LD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave & 1, wn = wave >> 1;
-  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
-  const int kbeg = blockIdx.z * g.k_chunk;
+  // XCD-aware block order.  Workgroups are dealt round-robin to the 8 XCDs, each with its own L2, so XCD x takes the contiguous
+  // range [x * per, (x + 1) * per) of the order (n tile fastest, then m tile, then k slice): the blocks that share an A tile
+  // (forward / activation-gradient GEMMs: the n tiles of one m tile) or a k slice of both operands (weight-gradient GEMMs: all
+  // tiles of the slice) run back to back on ONE L2 instead of being spread over all eight.
+  const int per = (int)gridDim.x >> 3, v = ((int)blockIdx.x & 7) * per + ((int)blockIdx.x >> 3);
+  if (v >= g.tiles_m * g.tiles_n * g.slices) return;
+  const int tn = v % g.tiles_n, tm = (v / g.tiles_n) % g.tiles_m, bz = v / (g.tiles_n * g.tiles_m);
+  const int m0 = tm * TM, n0 = tn * TM;
+  const int kbeg = bz * g.k_chunk;
   const int kend = min(g.K, kbeg + g.k_chunk);
-  f32x16 acc;
-  for (int r = 0; r < 16; r++) acc[r] = 0.f;
+  f32x16 acc[WT][WT];
+#pragma unroll
+  for (int i = 0; i < WT; i++)
+#pragma unroll
+    for (int j = 0; j < WT; j++)
+      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
 
-  float4 ra, rb;
-  auto load_a = [&](int k0) {
-    ra = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (A_KC) {
-      int row = m0 + (tid >> 2), k = k0 + (tid & 3) * 4;
-      if (row < g.M && k < kend) {
-        ra = *reinterpret_cast<const float4*>(g.A + (size_t)row * g.lda + k);
-        if (k + 1 >= kend) ra.y = 0.f;
-        if (k + 2 >= kend) ra.z = 0.f;
-        if (k + 3 >= kend) ra.w = 0.f;
-      }
-    } else {
-      int k = k0 + (tid >> 4), m = m0 + (tid & 15) * 4;
-      if (k < kend && m < g.M) {
-        ra = *reinterpret_cast<const float4*>(g.A + (size_t)k * g.lda + m);
-        if (m + 1 >= g.M) ra.y = 0.f;
-        if (m + 2 >= g.M) ra.z = 0.f;
-        if (m + 3 >= g.M) ra.w = 0.f;
-      }
-    }
-  };
-  auto load_b = [&](int k0) {
-    rb = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (B_KC) {
-      int row = n0 + (tid >> 2), k = k0 + (tid & 3) * 4;
-      if (row < g.N && k < kend) {
-        rb = *reinterpret_cast<const float4*>(g.B + (size_t)row * g.ldb + k);
-        if (k + 1 >= kend) rb.y = 0.f;
-        if (k + 2 >= kend) rb.z = 0.f;
-        if (k + 3 >= kend) rb.w = 0.f;
-      }
-    } else {
-      int k = k0 + (tid >> 4), n = n0 + (tid & 15) * 4;
-      if (k < kend && n < g.N) {
-        rb = *reinterpret_cast<const float4*>(g.B + (size_t)k * g.ldb + n);
-        if (n + 1 >= g.N) rb.y = 0.f;
-        if (n + 2 >= g.N) rb.z = 0.f;
-        if (n + 3 >= g.N) rb.w = 0.f;
+  // operand staging: KC layout -> 4 / WT threads per row, each 4 * WT consecutive k; else 16 threads per k, each 4 * WT rows
+  float4 ra[WT], rb[WT];
+  auto load_tile = [&](float4 (&r)[WT], const float* __restrict__ P, int ld, bool kc, int x0, int X, int k0) {
+#pragma unroll
+    for (int q = 0; q < WT; q++) {
+      r[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (kc) {
+        const int row = x0 + tid / (4 / WT), k = k0 + (tid % (4 / WT)) * 4 * WT + 4 * q;
+        if (row < X && k < kend) {
+          r[q] = *reinterpret_cast<const float4*>(P + (size_t)row * ld + k);
+          if (k + 1 >= kend) r[q].y = 0.f;
+          if (k + 2 >= kend) r[q].z = 0.f;
+          if (k + 3 >= kend) r[q].w = 0.f;
+        }
+      } else {
+        const int k = k0 + (tid >> 4), x = x0 + (tid & 15) * 4 * WT + 4 * q;
+        if (k < kend && x < X) {
+          r[q] = *reinterpret_cast<const float4*>(P + (size_t)k * ld + x);
+          if (x + 1 >= X) r[q].y = 0.f;
+          if (x + 2 >= X) r[q].z = 0.f;
+          if (x + 3 >= X) r[q].w = 0.f;
+        }
       }
     }
   };
-  auto store_tiles = [&]() {
-    if (A_KC) {
-      int row = tid >> 2, kq = (tid & 3) * 4;
-      As[kq + 0][row] = ra.x; As[kq + 1][row] = ra.y; As[kq + 2][row] = ra.z; As[kq + 3][row] = ra.w;
-    } else {
-      int k = tid >> 4, mq = (tid & 15) * 4;
-      *reinterpret_cast<float4*>(&As[k][mq]) = ra;
-    }
-    if (B_KC) {
-      int row = tid >> 2, kq = (tid & 3) * 4;
-      Bs[kq + 0][row] = rb.x; Bs[kq + 1][row] = rb.y; Bs[kq + 2][row] = rb.z; Bs[kq + 3][row] = rb.w;
-    } else {
-      int k = tid >> 4, nq = (tid & 15) * 4;
-      *reinterpret_cast<float4*>(&Bs[k][nq]) = rb;
+  auto store_tile = [&](float (&T)[BK][LD], const float4 (&r)[WT], bool kc) {
+#pragma unroll
+    for (int q = 0; q < WT; q++) {
+      if (kc) {
+        const int row = tid / (4 / WT), kq = (tid % (4 / WT)) * 4 * WT + 4 * q;
+        T[kq + 0][row] = r[q].x; T[kq + 1][row] = r[q].y; T[kq + 2][row] = r[q].z; T[kq + 3][row] = r[q].w;
+      } else {
+        const int k = tid >> 4, xq = (tid & 15) * 4 * WT + 4 * q;
+        *reinterpret_cast<float4*>(&T[k][xq]) = r[q];
+      }
     }
   };
 
+  const bool want_colsum = !A_KC && g.colsum != nullptr && tn == 0;
+  float cs = 0.f;   // thread (m = tid % TM, k group = tid / TM): running sum of its A-tile entries
+  int cur = 0;
   if (kbeg < kend) {
-    load_a(kbeg);
-    load_b(kbeg);
+    load_tile(ra, g.A, g.lda, A_KC, m0, g.M, kbeg);
+    load_tile(rb, g.B, g.ldb, B_KC, n0, g.N, kbeg);
+    store_tile(As[0], ra, A_KC);
+    store_tile(Bs[0], rb, B_KC);
   }
+  __syncthreads();
   for (int k0 = kbeg; k0 < kend; k0 += BK) {
-    __syncthreads();
-    store_tiles();
-    __syncthreads();
-    if (k0 + BK < kend) {
-      load_a(k0 + BK);
-      load_b(k0 + BK);
+    const bool more = k0 + BK < kend;
+    if (more) {
+      load_tile(ra, g.A, g.lda, A_KC, m0, g.M, k0 + BK);
+      load_tile(rb, g.B, g.ldb, B_KC, n0, g.N, k0 + BK);
     }
-    const int am = wm * 32 + (lane & 31), bn = wn * 32 + (lane & 31), kh = lane >> 5;
+    const int l31 = lane & 31, kh = lane >> 5;
 #pragma unroll
     for (int kk = 0; kk < BK / 2; kk++) {
-      float a = As[kk * 2 + kh][am];
-      float b = Bs[kk * 2 + kh][bn];
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+      float a[WT], b[WT];
+#pragma unroll
+      for (int i = 0; i < WT; i++) a[i] = As[cur][kk * 2 + kh][(wm * WT + i) * 32 + l31];
+#pragma unroll
+      for (int j = 0; j < WT; j++) b[j] = Bs[cur][kk * 2 + kh][(wn * WT + j) * 32 + l31];
+#pragma unroll
+      for (int i = 0; i < WT; i++)
+#pragma unroll
+        for (int j = 0; j < WT; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
     }
+    if (want_colsum) {
+      constexpr int KG = BK * TM / 256;   // k rows per thread
+      const int m = tid % TM, kg = tid / TM;
+#pragma unroll
+      for (int q = 0; q < KG; q++) cs += As[cur][kg * KG + q][m];
+    }
+    if (more) {
+      store_tile(As[cur ^ 1], ra, A_KC);
+      store_tile(Bs[cur ^ 1], rb, B_KC);
+    }
+    __syncthreads();
+    cur ^= 1;
   }
 
   // epilogue; C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-  const int col = n0 + wn * 32 + (lane & 31);
-  const float bias = (g.bias && col < g.N) ? g.bias[col] : 0.f;
-  float* part = g.part ? g.part + (size_t)blockIdx.z * g.M * g.N : nullptr;
+  float* part = g.part ? g.part + (size_t)bz * g.M * g.N : nullptr;
 #pragma unroll
-  for (int r = 0; r < 16; r++) {
-    int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-    if (row < g.M && col < g.N) {
-      float v = acc[r] + bias;
-      if (g.relu) v = fmaxf(v, 0.f);
-      if (g.mask) v = g.mask[(size_t)row * g.ldmask + col] > 0.f ? v : 0.f;
-      if (part) part[(size_t)row * g.N + col] = v;
-      else g.C[(size_t)row * g.ldc + col] = v;
+  for (int j = 0; j < WT; j++) {
+    const int col = n0 + (wn * WT + j) * 32 + (lane & 31);
+    const float bias = (g.bias && col < g.N) ? g.bias[col] : 0.f;
+#pragma unroll
+    for (int i = 0; i < WT; i++) {
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int row = m0 + (wm * WT + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (row < g.M && col < g.N) {
+          float v = acc[i][j][r] + bias;
+          if (g.relu) v = fmaxf(v, 0.f);
+          if (g.mask) v = g.mask[(size_t)row * g.ldmask + col] > 0.f ? v : 0.f;
+          if (part) part[(size_t)row * g.N + col] = v;
+          else g.C[(size_t)row * g.ldc + col] = v;
+        }
+      }
+    }
+  }
+  if (want_colsum) {   // combine the k groups in a fixed order (the tiles are idle now: the loop ended with a barrier)
+    constexpr int NG = 256 / TM;
+    float* red = &As[0][0][0];
+    red[tid] = cs;
+    __syncthreads();
+    if (tid < TM && m0 + tid < g.M) {
+      float s = red[tid];
+#pragma unroll
+      for (int q = 1; q < NG; q++) s += red[q * TM + tid];
+      g.colsum[(size_t)bz * g.M + m0 + tid] = s;
     }
   }
 }
@@ -255,16 +293,65 @@ __global__ void __launch_bounds__(256) colsum_final_kernel(const float* __restri
   out[c] += s;
 }
 
+// Ordered reduction of split-K partials that were left in place by a series of GEMMs (the weight / bias gradients of one
+// minibatch): one launch adds every segment's slices, in slice order, to its destination.
+#define MAX_SEGS 16
+struct Seg { const float* part; float* dst; int nslices, count, N, ldc; };   // partial z at part + z*count; element i -> dst[(i/N)*ldc + i%N]
+struct SegList { Seg s[MAX_SEGS]; int first[MAX_SEGS + 1]; int n; };
+__global__ void __launch_bounds__(256) reduce_segments_kernel(SegList L) {
+  // block = 64 consecutive elements of one segment x 4 slice ranges; the four partial sums are combined in a fixed order
+  __shared__ float red[4][64];
+  const int e0 = blockIdx.x * 64;
+  int k = 0;
+  while (e0 >= L.first[k + 1]) k++;
+  const Seg sg = L.s[k];
+  const int e = e0 - L.first[k] + (threadIdx.x & 63), q = threadIdx.x >> 6;
+  const int per = (sg.nslices + 3) >> 2, z0 = q * per, z1 = min(sg.nslices, z0 + per);
+  float s = 0.f;
+  if (e < sg.count) {
+#pragma unroll 8
+    for (int z = z0; z < z1; z++) s += sg.part[(size_t)z * sg.count + e];
+  }
+  red[q][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (q == 0 && e < sg.count) {
+    const int t = threadIdx.x;
+    const float tot = (red[0][t] + red[1][t]) + (red[2][t] + red[3][t]);
+    const int row = e / sg.N, col = e - row * sg.N;
+    sg.dst[(size_t)row * sg.ldc + col] += tot;
+  }
+}
+static void seg_add(SegList& L, const float* part, float* dst, int nslices, int M, int N, int ldc) {
+  Seg& s = L.s[L.n];
+  s.part = part; s.dst = dst; s.nslices = nslices; s.count = M * N; s.N = N; s.ldc = ldc;
+  if (L.n == 0) L.first[0] = 0;
+  L.first[L.n + 1] = L.first[L.n] + (M * N + 63) / 64 * 64;   // (a block never straddles two segments)
+  L.n++;
+}
+static void launch_reduce_segments(const SegList& L, hipStream_t s) {
+  if (L.n == 0) return;
+  hipLaunchKernelGGL(reduce_segments_kernel, dim3(L.first[L.n] / 64), dim3(256), 0, s, L);
+}
+
+// defer != 0: split-K partials (and the fused column sums) stay in g.part / g.colsum for a later reduce_segments launch
 template <bool A_KC, bool B_KC>
-static void launch_gemm(const GemmArgs& g, hipStream_t s) {
+static void launch_gemm(const GemmArgs& g, hipStream_t s, int defer = 0, int wt = 0) {
   GemmArgs a = g;
   if (a.k_chunk <= 0) a.k_chunk = a.K;
   a.k_chunk = ((a.k_chunk + BK - 1) / BK) * BK;
-  dim3 grid((a.M + BM - 1) / BM, (a.N + BN - 1) / BN, (a.K + a.k_chunk - 1) / a.k_chunk);
-  hipLaunchKernelGGL((gemm_f32_kernel<A_KC, B_KC>), grid, dim3(256), 0, s, a);
-  if (a.part) {  // ordered reduction of the split-K slices into the (accumulating) destination
+  const int nz = (a.K + a.k_chunk - 1) / a.k_chunk;
+  static const int env_wt = getenv("LHW_GEMM_WT") ? atoi(getenv("LHW_GEMM_WT")) : 0;   // tuning aid: 1 / 2 forces the tile size
+  const int force_wt = wt ? wt : env_wt;
+  // 128 x 128 tiles when both dimensions fill them and the grid still covers the chip
+  const bool big = force_wt ? force_wt == 2 : (a.M >= 128 && a.N >= 128 && (size_t)((a.M + 127) / 128) * ((a.N + 127) / 128) * nz >= 256);
+  const int tile = big ? 128 : 64;
+  a.tiles_m = (a.M + tile - 1) / tile; a.tiles_n = (a.N + tile - 1) / tile; a.slices = nz;
+  const dim3 grid(8 * (((size_t)a.tiles_m * a.tiles_n * nz + 7) / 8));
+  if (big) hipLaunchKernelGGL((gemm_f32_kernel<A_KC, B_KC, 2>), grid, dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((gemm_f32_kernel<A_KC, B_KC, 1>), grid, dim3(256), 0, s, a);
+  if (a.part && !defer) {  // ordered reduction of the split-K slices into the (accumulating) destination
     const int n = a.M * a.N;
-    hipLaunchKernelGGL(reduce_slices_kernel, dim3((n + 255) / 256), dim3(256), 0, s, a.part, (int)grid.z, a.M, a.N, a.C, a.ldc);
+    hipLaunchKernelGGL(reduce_slices_kernel, dim3((n + 255) / 256), dim3(256), 0, s, a.part, nz, a.M, a.N, a.C, a.ldc);
   }
 }
 
@@ -316,7 +403,13 @@ struct LhwPpo {
   const unsigned char* imit_mask = nullptr;
   float imit_coeff = 0.f, imit_inv_count = 0.f;
   float *norm_part = nullptr;  // [2][SUMSQ_BLOCKS]
+  float *bwd_part = nullptr;   // split-K partials of the weight / bias gradients: actor (two passes), then critic
   int max_slices = 0;
+  // the critic's forward / backward chain runs on its own stream beside the actor's (they share only the gathered inputs and
+  // the loss kernel): the load / multiply / store phases of one network's GEMMs overlap the other's
+  hipStream_t side = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  int two_streams = 1;
 };
 
 #define HIPCHK(x)                                                                                   \
@@ -359,42 +452,74 @@ static void mlp_forward(const MlpLayout& L, const float* theta, const float* x, 
   launch_gemm<true, true>(g, s);
 }
 
-// accumulates parameter gradients of one MLP given dy [R][Op]; every reduction runs in a fixed order (same seed ->
-// bitwise identical weights, the property the reference's tests/test_determinism.py checks)
 static void colsum_det(const float* X, int rows, int ld, int ncols, float* out, float* scratch /* [COLSUM_CHUNKS][ncols] */, hipStream_t s) {
   hipLaunchKernelGGL(colsum_det_kernel, dim3((ncols + 63) / 64, COLSUM_CHUNKS), dim3(256), 0, s, X, rows, ld, ncols, scratch);
   hipLaunchKernelGGL(colsum_final_kernel, dim3((ncols + 255) / 256), dim3(256), 0, s, scratch, ncols, out);
 }
-static void mlp_backward(const MlpLayout& L, const float* theta, float* grad, const float* x, int ldx, int R, const float* h1,
-                         const float* h2, const float* dy, float* dh2, float* dh1, int k_chunk, float* part, hipStream_t s) {
+// Split-K partial regions of one network's parameter gradients ([slices][count] each), reduced by one reduce_segments launch.
+// The K dimension of a weight-gradient GEMM is the minibatch: it is cut into slices so that every GEMM puts ~1000 blocks on the
+// chip -- 512-row slices for the 256 x 256 layer (16 output tiles), 128-row slices for the skinny first / last layers (4 tiles),
+// whose blocks would otherwise sit through 32 dependent load -> multiply steps with nothing else resident to hide them.
+#define KC_WIDE 512
+#define KC_SKINNY 128
+struct BwdParts { float *w3, *w2, *w1, *b3, *b2, *b1; };
+struct BwdSlices { int w3 = 0, w2 = 0, w1 = 0; };
+static inline int nsl(int rows, int kc) { return (rows + kc - 1) / kc; }
+static size_t bwd_parts_floats(const MlpLayout& L, size_t rows, int passes) {
+  const size_t ss = (size_t)passes * (nsl((int)rows, KC_SKINNY) + 1), sw = (size_t)passes * (nsl((int)rows, KC_WIDE) + 1);
+  return ss * ((size_t)L.Op * L.H + L.Op) + sw * ((size_t)L.H * L.H + L.H) + ss * ((size_t)L.H * L.Dp + L.H);
+}
+static BwdParts bwd_parts_carve(const MlpLayout& L, size_t rows, int passes, float* base) {
+  const size_t ss = (size_t)passes * (nsl((int)rows, KC_SKINNY) + 1), sw = (size_t)passes * (nsl((int)rows, KC_WIDE) + 1);
+  BwdParts P;
+  P.w3 = base; base += ss * L.Op * L.H;
+  P.b3 = base; base += ss * L.Op;
+  P.w2 = base; base += sw * L.H * L.H;
+  P.b2 = base; base += sw * L.H;
+  P.w1 = base; base += ss * L.H * L.Dp;
+  P.b1 = base;
+  return P;
+}
+// Back-propagation through one MLP for R rows given dy [R][Op].  The weight-gradient GEMMs (K = R) leave their partial products
+// -- and, from the same operand tiles, the bias gradients' partial column sums -- in P behind the z slices an earlier pass
+// wrote; mlp_backward_segments then lists them for the ordered reduction into grad.  Every reduction runs in a fixed order
+// (same seed -> bitwise identical weights, the property the reference's tests/test_determinism.py checks).
+static void mlp_backward(const MlpLayout& L, const float* theta, const float* x, int ldx, int R, const float* h1, const float* h2,
+                         const float* dy, float* dh2, float* dh1, const BwdParts& P, BwdSlices& z, hipStream_t s) {
   GemmArgs g{};
-  // dW3 [O][H] += dy^T h2 ; db3 += colsum(dy)
-  g.A = dy; g.lda = L.Op; g.B = h2; g.ldb = L.H; g.C = grad + L.w3; g.ldc = L.H; g.M = L.O; g.N = L.H; g.K = R;
-  g.part = part; g.k_chunk = k_chunk;
-  launch_gemm<false, false>(g, s);
-  colsum_det(dy, R, L.Op, L.O, grad + L.b3, part, s);
-  // dh2 = (dy W3) * (h2 > 0) ; db2 += colsum(dh2)
+  // dW3 [O][H] = dy^T h2 ; db3 = colsum(dy)
+  g.A = dy; g.lda = L.Op; g.B = h2; g.ldb = L.H; g.M = L.O; g.N = L.H; g.K = R;
+  g.part = P.w3 + (size_t)z.w3 * L.O * L.H; g.colsum = P.b3 + (size_t)z.w3 * L.O; g.k_chunk = KC_SKINNY;
+  launch_gemm<false, false>(g, s, 1);
+  // dh2 = (dy W3) * (h2 > 0)
   g = GemmArgs{};
   g.A = dy; g.lda = L.Op; g.B = theta + L.w3; g.ldb = L.H; g.C = dh2; g.ldc = L.H; g.M = R; g.N = L.H; g.K = L.O;
   g.mask = h2; g.ldmask = L.H;
   launch_gemm<true, false>(g, s);
-  colsum_det(dh2, R, L.H, L.H, grad + L.b2, part, s);
-  // dW2 += dh2^T h1
+  // dW2 = dh2^T h1 ; db2 = colsum(dh2)
   g = GemmArgs{};
-  g.A = dh2; g.lda = L.H; g.B = h1; g.ldb = L.H; g.C = grad + L.w2; g.ldc = L.H; g.M = L.H; g.N = L.H; g.K = R;
-  g.part = part; g.k_chunk = k_chunk;
-  launch_gemm<false, false>(g, s);
-  // dh1 = (dh2 W2) * (h1 > 0) ; db1 += colsum(dh1)
+  g.A = dh2; g.lda = L.H; g.B = h1; g.ldb = L.H; g.M = L.H; g.N = L.H; g.K = R;
+  g.part = P.w2 + (size_t)z.w2 * L.H * L.H; g.colsum = P.b2 + (size_t)z.w2 * L.H; g.k_chunk = KC_WIDE;
+  launch_gemm<false, false>(g, s, 1);
+  // dh1 = (dh2 W2) * (h1 > 0)
   g = GemmArgs{};
   g.A = dh2; g.lda = L.H; g.B = theta + L.w2; g.ldb = L.H; g.C = dh1; g.ldc = L.H; g.M = R; g.N = L.H; g.K = L.H;
   g.mask = h1; g.ldmask = L.H;
   launch_gemm<true, false>(g, s);
-  colsum_det(dh1, R, L.H, L.H, grad + L.b1, part, s);
-  // dW1 [H][Dp] += dh1^T x
+  // dW1 [H][Dp] = dh1^T x ; db1 = colsum(dh1)
   g = GemmArgs{};
-  g.A = dh1; g.lda = L.H; g.B = x; g.ldb = ldx; g.C = grad + L.w1; g.ldc = L.Dp; g.M = L.H; g.N = L.Dp; g.K = R;
-  g.part = part; g.k_chunk = k_chunk;
-  launch_gemm<false, false>(g, s);
+  g.A = dh1; g.lda = L.H; g.B = x; g.ldb = ldx; g.M = L.H; g.N = L.Dp; g.K = R;
+  g.part = P.w1 + (size_t)z.w1 * L.H * L.Dp; g.colsum = P.b1 + (size_t)z.w1 * L.H; g.k_chunk = KC_SKINNY;
+  launch_gemm<false, false>(g, s, 1);
+  z.w3 += nsl(R, KC_SKINNY); z.w2 += nsl(R, KC_WIDE); z.w1 += nsl(R, KC_SKINNY);
+}
+static void mlp_backward_segments(SegList& S, const MlpLayout& L, float* grad, const BwdParts& P, const BwdSlices& z) {
+  seg_add(S, P.w3, grad + L.w3, z.w3, L.O, L.H, L.H);
+  seg_add(S, P.b3, grad + L.b3, z.w3, L.O, 1, 1);
+  seg_add(S, P.w2, grad + L.w2, z.w2, L.H, L.H, L.H);
+  seg_add(S, P.b2, grad + L.b2, z.w2, L.H, 1, 1);
+  seg_add(S, P.w1, grad + L.w1, z.w1, L.H, L.Dp, L.Dp);
+  seg_add(S, P.b1, grad + L.b1, z.w1, L.H, 1, 1);
 }
 
 // ------------------------------------------------------------------------------------------- elementwise kernels
@@ -645,6 +770,33 @@ __global__ void scale_shift_kernel(float* __restrict__ x, size_t n, float mean, 
 }
 
 // ------------------------------------------------------------------------------------------- C ABI
+// Test / tuning hook: one GEMM of the update path on caller-provided device buffers (see include/lhw.h).
+extern "C" int lhw_debug_gemm(int32_t a_kc, int32_t b_kc, int32_t wt, int32_t M, int32_t N, int32_t K, const float* A, int32_t lda,
+                              const float* B, int32_t ldb, float* C, int32_t ldc, const float* bias, int32_t relu, const float* mask,
+                              int32_t ldmask, int32_t k_chunk, float* part, float* colsum, float* colsum_out, void* stream) {
+  if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || (lda | ldb | ldc) & 3) return lhw_fail(LHW_ERR_ARG, "lhw_debug_gemm: bad argument");
+  if ((colsum && (a_kc || !part || !colsum_out)) || (k_chunk > 0 && k_chunk < K && !part)) return lhw_fail(LHW_ERR_ARG, "lhw_debug_gemm: split-K needs part; colsum needs A stored [K][M]");
+  hipStream_t s = (hipStream_t)stream;
+  GemmArgs g{};
+  g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.bias = bias; g.relu = relu;
+  g.mask = mask; g.ldmask = ldmask; g.part = part; g.k_chunk = k_chunk; g.colsum = colsum;
+  const int defer = part != nullptr;
+  if (a_kc && b_kc) launch_gemm<true, true>(g, s, defer, wt);
+  else if (a_kc && !b_kc) launch_gemm<true, false>(g, s, defer, wt);
+  else if (!a_kc && !b_kc) launch_gemm<false, false>(g, s, defer, wt);
+  else return lhw_fail(LHW_ERR_UNSUPPORTED, "lhw_debug_gemm: A [K][M] with B [N][K] is not used by the update");
+  if (part) {   // the deferred path of the update: partials (and column sums) reduced by one launch, accumulating into C / colsum_out
+    const int kc = ((std::max(1, k_chunk > 0 ? k_chunk : K) + BK - 1) / BK) * BK;
+    SegList S;
+    S.n = 0;
+    seg_add(S, part, C, (K + kc - 1) / kc, M, N, ldc);
+    if (colsum) seg_add(S, colsum, colsum_out, (K + kc - 1) / kc, M, 1, 1);
+    launch_reduce_segments(S, s);
+  }
+  HIPCHK(hipGetLastError());
+  return LHW_OK;
+}
+
 extern "C" int lhw_ppo_create(const LhwPpoConfig* c, LhwPpo** out) {
   if (!c || !out) return lhw_fail(LHW_ERR_ARG, "null argument");
   *out = nullptr;
@@ -675,6 +827,7 @@ extern "C" int lhw_ppo_create(const LhwPpoConfig* c, LhwPpo** out) {
             alloc(&p->norm_part, 2 * SUMSQ_BLOCKS);
   p->max_slices = (int)((R + 511) / 512);
   ok = ok && alloc(&p->part, std::max<size_t>((size_t)p->max_slices * H * std::max<size_t>(H, Dp), (size_t)COLSUM_CHUNKS * H));
+  ok = ok && alloc(&p->bwd_part, bwd_parts_floats(p->la, R, 2) + bwd_parts_floats(p->lc, R, 1));
   if (ok && p->use_mirror) {
     std::vector<int> osrc(Dp, 0), asrc(p->A, 0);
     std::vector<float> osgn(Dp, 0.f), asgn(p->A, 0.f);
@@ -691,6 +844,10 @@ extern "C" int lhw_ppo_create(const LhwPpoConfig* c, LhwPpo** out) {
       (void)hipMemcpy(p->d_act_sign, asgn.data(), sizeof(float) * p->A, hipMemcpyHostToDevice);
     }
   }
+  p->two_streams = !(getenv("LHW_PPO_TWO_STREAMS") && atoi(getenv("LHW_PPO_TWO_STREAMS")) == 0);
+  ok = ok && hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking) == hipSuccess &&
+       hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming) == hipSuccess &&
+       hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming) == hipSuccess;
   if (!ok) {
     lhw_ppo_destroy(p);
     return lhw_fail(LHW_ERR_HIP, "PPO workspace allocation failed (max_rows=%d) or bad mirror table", c->max_rows);
@@ -704,10 +861,13 @@ extern "C" int lhw_ppo_destroy(LhwPpo* p) {
   (void)hipSetDevice(p->device);
   float* bufs[] = {p->xb, p->h1a, p->h2a, p->ya, p->h1c, p->h2c, p->yc, p->dya, p->dh2a, p->dh1a, p->dyc, p->dh2c, p->dh1c,
                    p->mb_act, p->mb_logp, p->mb_adv, p->mb_ret, p->stats, p->d_obs_sign, p->d_act_sign, p->part, p->dstd, p->stats_part,
-                   p->norm_part};
+                   p->norm_part, p->bwd_part};
   for (float* b : bufs) if (b) (void)hipFree(b);
   if (p->d_obs_src) (void)hipFree(p->d_obs_src);
   if (p->d_act_src) (void)hipFree(p->d_act_src);
+  if (p->side) { (void)hipStreamSynchronize(p->side); (void)hipStreamDestroy(p->side); }
+  if (p->ev_fork) (void)hipEventDestroy(p->ev_fork);
+  if (p->ev_join) (void)hipEventDestroy(p->ev_join);
   delete p;
   return LHW_OK;
 }
@@ -869,11 +1029,20 @@ extern "C" int lhw_ppo_grad(LhwPpo* p, const float* theta, float* grad, const fl
                      adv, ret, p->xb, p->mb_act, p->mb_logp, p->mb_adv, p->mb_ret);
   const float* th_a = theta + p->off_actor;
   const float* th_c = theta + p->off_critic;
+  hipStream_t sc = p->two_streams ? p->side : s;   // the critic's chain
+  auto fork = [&]() { if (sc != s) { (void)hipEventRecord(p->ev_fork, s); (void)hipStreamWaitEvent(sc, p->ev_fork, 0); } };
+  auto join = [&]() { if (sc != s) { (void)hipEventRecord(p->ev_join, sc); (void)hipStreamWaitEvent(s, p->ev_join, 0); } };
   // forward: rows [0,B) and, if mirroring, rows [R, R+B)
-  mlp_forward(p->la, th_a, p->xb, Dp, B, p->h1a, p->h2a, p->ya, s);
-  if (mir)
-    mlp_forward(p->la, th_a, p->xb + (size_t)R * Dp, Dp, B, p->h1a + (size_t)R * p->H, p->h2a + (size_t)R * p->H, p->ya + (size_t)R * Op, s);
-  mlp_forward(p->lc, th_c, p->xb, Dp, B, p->h1c, p->h2c, p->yc, s);
+  fork();
+  mlp_forward(p->lc, th_c, p->xb, Dp, B, p->h1c, p->h2c, p->yc, sc);
+  if (mir && B == R) {
+    mlp_forward(p->la, th_a, p->xb, Dp, 2 * B, p->h1a, p->h2a, p->ya, s);   // mirrored rows follow without a gap
+  } else {
+    mlp_forward(p->la, th_a, p->xb, Dp, B, p->h1a, p->h2a, p->ya, s);
+    if (mir)
+      mlp_forward(p->la, th_a, p->xb + (size_t)R * Dp, Dp, B, p->h1a + (size_t)R * p->H, p->h2a + (size_t)R * p->H, p->ya + (size_t)R * Op, s);
+  }
+  join();
   const int nblk = (B + 255) / 256;
   hipLaunchKernelGGL(ppo_loss_kernel, dim3(nblk), dim3(256), 0, s, B, R, p->A, Op, p->ya, p->yc, p->mb_act, p->mb_logp,
                      p->mb_adv, p->mb_ret, theta + p->off_std, p->clip, p->mirror_coeff, mir, p->d_act_src, p->d_act_sign, p->dya,
@@ -885,12 +1054,26 @@ extern "C" int lhw_ppo_grad(LhwPpo* p, const float* theta, float* grad, const fl
     colsum_det(p->dstd, B, Op, p->A, grad + p->off_std, p->part, s);
     hipLaunchKernelGGL(entropy_grad_kernel, dim3(1), dim3(64), 0, s, theta + p->off_std, p->A, p->ent_coeff, grad + p->off_std);
   }
-  const int kc = 512;
-  mlp_backward(p->la, th_a, grad + p->off_actor, p->xb, Dp, B, p->h1a, p->h2a, p->dya, p->dh2a, p->dh1a, kc, p->part, s);
-  if (mir)
-    mlp_backward(p->la, th_a, grad + p->off_actor, p->xb + (size_t)R * Dp, Dp, B, p->h1a + (size_t)R * p->H, p->h2a + (size_t)R * p->H,
-                 p->dya + (size_t)R * Op, p->dh2a + (size_t)R * p->H, p->dh1a + (size_t)R * p->H, kc, p->part, s);
-  mlp_backward(p->lc, th_c, grad + p->off_critic, p->xb, Dp, B, p->h1c, p->h2c, p->dyc, p->dh2c, p->dh1c, kc, p->part, s);
+  const BwdParts Pa = bwd_parts_carve(p->la, R, 2, p->bwd_part);
+  const BwdParts Pc = bwd_parts_carve(p->lc, R, 1, p->bwd_part + bwd_parts_floats(p->la, R, 2));
+  BwdSlices za, zc;
+  fork();
+  mlp_backward(p->lc, th_c, p->xb, Dp, B, p->h1c, p->h2c, p->dyc, p->dh2c, p->dh1c, Pc, zc, sc);
+  if (mir && B == R) {
+    // the mirrored rows follow the normal ones without a gap: one pass over 2B rows
+    mlp_backward(p->la, th_a, p->xb, Dp, 2 * B, p->h1a, p->h2a, p->dya, p->dh2a, p->dh1a, Pa, za, s);
+  } else {
+    mlp_backward(p->la, th_a, p->xb, Dp, B, p->h1a, p->h2a, p->dya, p->dh2a, p->dh1a, Pa, za, s);
+    if (mir)
+      mlp_backward(p->la, th_a, p->xb + (size_t)R * Dp, Dp, B, p->h1a + (size_t)R * p->H, p->h2a + (size_t)R * p->H,
+                   p->dya + (size_t)R * Op, p->dh2a + (size_t)R * p->H, p->dh1a + (size_t)R * p->H, Pa, za, s);
+  }
+  join();
+  SegList S;
+  S.n = 0;
+  mlp_backward_segments(S, p->la, grad + p->off_actor, Pa, za);
+  mlp_backward_segments(S, p->lc, grad + p->off_critic, Pc, zc);
+  launch_reduce_segments(S, s);
   HIPCHK(hipGetLastError());
   return LHW_OK;
 }

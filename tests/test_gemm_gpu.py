@@ -1,0 +1,76 @@
+"""The update path's float32 MFMA GEMM kernel (lhw_debug_gemm -> gemm_f32_kernel, csrc/lhw_ppo.hip) against torch float64 on the
+shapes lhw_ppo_grad issues -- both block-tile sizes, every operand layout, ragged edges (K not a multiple of 16, M / N not a
+multiple of the tile), the fused epilogues (bias + ReLU, ReLU-derivative mask) and the split-K path with the bias gradient's
+column sums taken from the same operand tiles."""
+import ctypes
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _gemm(a_kc, b_kc, wt, M, N, K, A, B, C, bias=None, relu=0, mask=None, k_chunk=0, part=None, colsum=None, colsum_out=None):
+    from learninghumanoidwalking_amd import _lib
+    L = _lib.lib()
+    _lib.check(L.lhw_debug_gemm(int(a_kc), int(b_kc), wt, M, N, K, _p(A), A.stride(0), _p(B), B.stride(0), _p(C), C.stride(0), _p(bias), relu,
+                                _p(mask), mask.stride(0) if mask is not None else 0, k_chunk, _p(part), _p(colsum), _p(colsum_out), None))
+
+
+@pytest.mark.parametrize("wt", [1, 2])
+@pytest.mark.parametrize("M,N,K", [(1000, 256, 40), (4099, 256, 256), (777, 12, 256), (130, 130, 20)])
+def test_forward_layout_bias_relu(wt, M, N, K):
+    import torch
+    g = torch.Generator(device="cuda").manual_seed(M + N + K)
+    A = torch.randn(M, K, device="cuda", generator=g)
+    W = torch.randn(N, K, device="cuda", generator=g) / K ** 0.5
+    b = torch.randn(N, device="cuda", generator=g)
+    C = torch.full((M, (N + 3) // 4 * 4), 7.0, device="cuda")
+    _gemm(True, True, wt, M, N, K, A, W, C, bias=b, relu=1)
+    ref = torch.relu(A.double() @ W.double().t() + b.double())
+    assert (C[:, :N].double() - ref).abs().max().item() < 2e-5
+    assert (C[:, N:] == 7.0).all()
+
+
+@pytest.mark.parametrize("wt", [1, 2])
+@pytest.mark.parametrize("M,N,K", [(3000, 256, 12), (2049, 256, 256)])
+def test_backward_activation_layout_with_mask(wt, M, N, K):
+    import torch
+    g = torch.Generator(device="cuda").manual_seed(N + K)
+    dY = torch.randn(M, K, device="cuda", generator=g)
+    W = torch.randn(K, N, device="cuda", generator=g) / K ** 0.5      # stored [K][N]
+    h = torch.randn(M, N, device="cuda", generator=g)
+    C = torch.zeros(M, N, device="cuda")
+    _gemm(True, False, wt, M, N, K, dY, W, C, mask=h)
+    ref = (dY.double() @ W.double()) * (h > 0)
+    assert (C.double() - ref).abs().max().item() < 2e-5
+
+
+@pytest.mark.parametrize("wt", [1, 2])
+@pytest.mark.parametrize("M,N,K,kc", [(256, 256, 5000, 512), (12, 256, 4097, 512), (256, 40, 3000, 512), (1, 256, 2000, 256)])
+def test_weight_gradient_split_k_with_fused_bias_gradient(wt, M, N, K, kc):
+    import torch
+    g = torch.Generator(device="cuda").manual_seed(M * 7 + N)
+    Mp = (M + 3) // 4 * 4
+    dY = torch.randn(K, Mp, device="cuda", generator=g)          # A stored [K][M]
+    X = torch.randn(K, N, device="cuda", generator=g)
+    nz = (K + kc - 1) // kc
+    part = torch.full((nz, M * N), float("nan"), device="cuda")
+    cpart = torch.full((nz, M), float("nan"), device="cuda")
+    C0 = torch.randn(M, N, device="cuda", generator=g)
+    b0 = torch.randn(M, device="cuda", generator=g)
+    C, bsum = C0.clone(), b0.clone()
+    _gemm(False, False, wt, M, N, K, dY, X, C, k_chunk=kc, part=part, colsum=cpart, colsum_out=bsum)
+    ref = C0.double() + dY[:, :M].double().t() @ X.double()
+    refb = b0.double() + dY[:, :M].double().sum(0)
+    scale = K ** 0.5
+    assert (C.double() - ref).abs().max().item() < 2e-5 * scale
+    assert (bsum.double() - refb).abs().max().item() < 2e-5 * scale
+    # deterministic: a second run gives the same bits
+    C2, b2 = C0.clone(), b0.clone()
+    _gemm(False, False, wt, M, N, K, dY, X, C2, k_chunk=kc, part=part, colsum=cpart, colsum_out=b2)
+    assert torch.equal(C, C2) and torch.equal(bsum, b2)
