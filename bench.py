@@ -24,14 +24,14 @@ MFMA_F32_PEAK_TFLOPS = 157.3  # f32-input MFMA peak (= f32 vector peak)
 FP64_VALU_PEAK_TFLOPS = 78.6
 
 
-def static_pmc_traffic(kernel_substr):
+def static_pmc_traffic(kernel_substr, stem="step"):
     """HBM bytes per launch of the dominant kernel from the COMMITTED rocprofv3 --pmc summaries (profiles/), with the gfx950
     correction of MI355X_MICROARCH.md (FETCH_SIZE under-reports coalesced reads by 2x; WRITE_SIZE uncalibrated).  Static: it
     is NOT measured by this run (the counters need their own rocprofv3 passes, scripts/collect_profiles.sh)."""
     import csv
     vals = {}
     for name in ("fetch_size", "write_size"):
-        path = os.path.join(ROOT, "profiles", f"r02_jvrc_walk_step_pmc_{name}.csv")
+        path = os.path.join(ROOT, "profiles", f"r02_jvrc_walk_{stem}_pmc_{name}.csv")
         if not os.path.exists(path):
             return None
         for row in csv.DictReader(open(path)):
@@ -40,7 +40,9 @@ def static_pmc_traffic(kernel_substr):
     if len(vals) != 2:
         return None
     return dict(bytes_per_launch=2.0 * vals["fetch_size"] + vals["write_size"], envs_per_launch=4096,
-                source="profiles/r02_jvrc_walk_step_pmc_{fetch,write}_size.csv: 2*FETCH_SIZE + WRITE_SIZE, whole-batch launches")
+                control_steps_per_launch=400 if stem == "rollout" else 1,
+                source=f"profiles/r02_jvrc_walk_{stem}_pmc_{{fetch,write}}_size.csv: 2*FETCH_SIZE + WRITE_SIZE, whole-batch launches"
+                       + (" of 400 control steps" if stem == "rollout" else ""))
 
 
 def cpu_baseline_worker(a):
@@ -250,7 +252,9 @@ def main():
         achieved_gbs = bytes_per_env_step * NL * TL / (avg_step_ms * 1e-3) / 1e9
         achieved_tf = flops_per_env_step * NL * TL / (avg_step_ms * 1e-3) / 1e12
         wall_step_ms = sample_t / K / T * 1e3     # wall time per control step of all N envs, policy inference included
-        static = static_pmc_traffic(spec.step_kernel_name.split("<")[0]) if env_name == "jvrc_walk" else None
+        static = None
+        if env_name == "jvrc_walk":
+            static = static_pmc_traffic("humanoid_rollout_kernel", "rollout") if persistent else static_pmc_traffic(spec.step_kernel_name.split("<")[0])
         # The fused control-step kernel touches each env's state once per control step (3 KB): by design it is not HBM-bound
         #  but bound by fp64 vector issue + on-chip latency, so the primary roofline is the fp64 VALU one.
         roofline = dict(

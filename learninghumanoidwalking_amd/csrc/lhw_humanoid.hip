@@ -340,6 +340,18 @@ enum { CI_PHASE = 0, CI_MODE, CI_TRAJ, CI_STARTED, CI_STEPCNT, CI_RESETCNT, CI_O
     SYNC();                                                                                                            \
   } while (0)
 
+// 0, produced where the optimiser cannot see it (and cannot move it out of a loop)
+__host__ __device__ __forceinline__ int opaque_zero() {
+#if defined(__HIP_DEVICE_COMPILE__)
+  int z;
+  asm volatile("v_mov_b32 %0, 0" : "=v"(z));
+  return z;
+#else
+  static volatile int z = 0;   // (host pass / SIMT emulator)
+  return z;
+#endif
+}
+
 // The lanes of a group belong to one wavefront, and a wave's LDS instructions execute in issue order, so cross-lane
 // hand-offs through LDS need no hardware barrier and no s_waitcnt: __syncthreads() would add a workgroup-scope fence, i.e.
 // s_waitcnt vmcnt(0) lgkmcnt(0) -- a full drain of outstanding global loads -- ~60 times per sub-step.  A wavefront-scope
@@ -2298,7 +2310,17 @@ __device__ __forceinline__ bool control_step(const HModel& m, const HParams& p, 
       stage = ST_LAST;
     }
     if (stage == ST_END) break;
-    substep<TASK == TASK_STEP>(m, p, S, lane, flags, &warm, sprof, ter);
+#ifndef LHW_NO_OPAQUE_LANE
+    // The lane index goes through a value the compiler cannot see through (opaque_zero()).  Everything a lane
+    // reads from the model tables in a sub-step is indexed by it and invariant across the 25 sub-steps; left alone, the
+    // compiler hoists those ~100 loads out of the loop and -- with the registers full -- parks them in scratch, from where
+    // every sub-step reloads them: ~300 scratch loads per sub-step against an 11 MB-per-XCD footprint that misses L2
+    // (FETCH_SIZE 708 MB per launch), instead of loads from tables that all waves share and that stay in L1 / L2.
+    const int lane_s = lane + opaque_zero();
+#else
+    const int lane_s = lane;
+#endif
+    substep<TASK == TASK_STEP>(m, p, S, lane_s, flags, &warm, sprof, ter);
     if (stage == ST_LAST) break;
     // two envs per wave: an env that needs more contacts than this layout holds is handed to the one-env-per-wave kernel
     // untouched (nothing of it has been written yet); once its outputs are out, it can only truncate like that kernel does

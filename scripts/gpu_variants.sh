@@ -1,13 +1,11 @@
 #!/bin/bash
-# time stepper variants (learninghumanoidwalking_amd/variants/liblhw_*.so) with the phase profiler, same box
+# time stepper variants (learninghumanoidwalking_amd/variants/liblhw_*.so) against the in-tree library, same box, interleaved
 OUT=/root/repo/gpurun_out/var
 mkdir -p $OUT
 cd /root/repo
 for rep in 1 2; do
-for f in learninghumanoidwalking_amd/variants/liblhw_*.so; do
-  v=$(basename $f .so)
-  LHW_LIB=/root/repo/$f python scripts/jvrc_phase_profile.py 4096 > $OUT/${v}.txt 2>&1
-  echo "$v $(grep 'ms/step' $OUT/${v}.txt)"
-  if [ $rep = 1 ]; then grep -E "kinematics|com/|crba|velocity|newton|collision|constraints|euler|detail" $OUT/${v}.txt | tr '\n' ' ' | sed 's/cyc\/substep//g; s/  */ /g'; echo; fi
+for f in default learninghumanoidwalking_amd/variants/liblhw_*.so; do
+  if [ $f = default ]; then unset LHW_LIB; v=default; else export LHW_LIB=/root/repo/$f; v=$(basename $f .so); fi
+  python bench.py --steps 3 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); r=d['roofline']; print('$v', 'value %.0f sample %.3f opt %.3f launch_ms %.2f iso %.3f' % (d['value'], d['sample_s_per_iter'], d['optimize_s_per_iter'], r['avg_launch_ms'], r['isolated']['launch_ms']))"
 done
 done
