@@ -254,11 +254,11 @@ def main():
         wall_step_ms = sample_t / K / T * 1e3     # wall time per control step of all N envs, policy inference included
         static = None
         if env_name == "jvrc_walk":
-            static = static_pmc_traffic("humanoid_rollout_kernel", "rollout") if persistent else static_pmc_traffic(spec.step_kernel_name.split("<")[0])
+            static = static_pmc_traffic("humanoid_rollout_kernel", "rollout") if persistent else static_pmc_traffic(spec.step_kernel_name)
         # The fused control-step kernel touches each env's state once per control step (3 KB): by design it is not HBM-bound
         #  but bound by fp64 vector issue + on-chip latency, so the primary roofline is the fp64 VALU one.
         roofline = dict(
-            bound="valu_fp64", kernel=(spec.step_kernel_name.replace("humanoid_kernel<0, ", "humanoid_rollout_kernel<") if persistent else spec.step_kernel_name), achieved=achieved_tf, peak=FP64_VALU_PEAK_TFLOPS, unit="TFLOP/s",
+            bound="valu_fp64", kernel=(spec.step_kernel_name.replace("humanoid_kernel<0, ", "humanoid_rollout_kernel<").replace(", 32>", ">") if persistent else spec.step_kernel_name), achieved=achieved_tf, peak=FP64_VALU_PEAK_TFLOPS, unit="TFLOP/s",
             frac=achieved_tf / FP64_VALU_PEAK_TFLOPS, traffic=None,
             traffic_note="HBM bytes are not measured by this run (PMC counters need separate rocprofv3 passes); see traffic_static",
             traffic_static=static,

@@ -168,6 +168,10 @@ typedef struct LhwRolloutArgs {
 } LhwRolloutArgs;
 /* 1 if lhw_env_rollout is available for this env (a humanoid task whose model fits the two-envs-per-wave kernels), else 0. */
 int lhw_env_supports_rollout(LhwEnv* env);
+/* 1 if a rollout launch keeps all envs of this batch resident on the GPU at once (occupancy x CUs x 2 envs per wave >= N): the
+ * regime in which the one-launch rollout is at least as fast as launch-per-step.  Larger batches run, but as successive
+ * generations of waves; stepping them launch by launch is faster (measured: h1 @ 8192 envs, 2.45 s vs 1.91 s per 400 steps). */
+int lhw_env_rollout_is_resident(LhwEnv* env);
 int lhw_env_rollout(LhwEnv* env, const LhwRolloutArgs* args, void* stream);
 /* Parity hooks; HOST pointers, synchronous.  qpos [N][nq], qvel [N][nv] float64. */
 int lhw_env_get_state(LhwEnv* env, double* qpos_host, double* qvel_host);

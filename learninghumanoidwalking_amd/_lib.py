@@ -89,6 +89,7 @@ def declare(L):
     sig("lhw_env_debug_wave_cycles", [vp, vp])
     sig("lhw_env_rollout", [vp, ctypes.POINTER(LhwRolloutArgs), vp])
     sig("lhw_env_supports_rollout", [vp])
+    sig("lhw_env_rollout_is_resident", [vp])
     sig("lhw_debug_gemm", [i32, i32, i32, i32, i32, i32, vp, i32, vp, i32, vp, i32, vp, i32, vp, i32, i32, vp, vp, vp, vp])
     sig("lhw_env_phase_cycles", [vp, ctypes.c_int, vp])
     sig("lhw_env_step_range", [vp, i32, i32, vp, vp, vp, vp, vp, vp, vp])

@@ -126,6 +126,11 @@ class BatchedEnv:
         """lhw_env_rollout (a whole rollout with the actor evaluated inside the stepper's launch) is available for this env."""
         return bool(self._L.lhw_env_supports_rollout(self._h))
 
+    @property
+    def rollout_is_resident(self) -> bool:
+        """One rollout launch keeps every env of this batch on the GPU at once (the regime the one-launch rollout is meant for)."""
+        return bool(self._L.lhw_env_rollout_is_resident(self._h))
+
     def rollout(self, T: int, policy: dict, obs: torch.Tensor, act: torch.Tensor, logp: torch.Tensor, rew: torch.Tensor,
                 term_obs: torch.Tensor, done: torch.Tensor, *, seed=0, env_id_base=0, counter0=0, deterministic=False):
         """T control steps of every env as ONE launch on the current stream, the feed-forward actor evaluated in the kernel.

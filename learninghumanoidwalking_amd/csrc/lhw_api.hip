@@ -219,6 +219,12 @@ extern "C" int lhw_env_step_range(LhwEnv* e, int32_t first, int32_t count, const
 
 extern "C" int lhw_env_supports_rollout(LhwEnv* e) { return e && e->hum && humanoid_supports_rollout(e->hum) ? 1 : 0; }
 
+extern "C" int lhw_env_rollout_is_resident(LhwEnv* e) {
+  if (!e || !e->hum) return 0;
+  if (hipSetDevice(e->device) != hipSuccess) return 0;
+  return humanoid_rollout_resident(e->hum);
+}
+
 extern "C" int lhw_env_rollout(LhwEnv* e, const LhwRolloutArgs* a, void* stream) {
   if (!e || !a) return lhw_fail(LHW_ERR_ARG, "null argument");
   if (!e->hum) return lhw_fail(LHW_ERR_UNSUPPORTED, "lhw_env_rollout: humanoid tasks only");

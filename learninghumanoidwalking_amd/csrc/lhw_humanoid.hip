@@ -1117,6 +1117,50 @@ __device__ __noinline__ void col_box_box(BoxRec& k, const HModel& m, const L& S,
     }
 }
 
+// Sphere-box (mjc_SphereBox): the centre, in the box frame, clamped to the box; outside, the contact is along
+// (centre - clamped point); inside, the sphere leaves through the nearest face.  Normal from the sphere to the box, position
+// midway between the two surfaces.  Returns false beyond the margin.  (same operation order as sphereBox in the CPU checker, mjc_oracle.c)
+__device__ __forceinline__ bool sphere_box_raw(const double* p1, double r, const double* p2, const double* R2, const double* size, double margin,
+                                               double* dist_out, double* pos, double* nrm) {
+  const double d[3] = {p1[0] - p2[0], p1[1] - p2[1], p1[2] - p2[2]};
+  double ctr[3], cl[3], v[3], nl[3], pl[3];
+  for (int a = 0; a < 3; a++) ctr[a] = R2[a] * d[0] + R2[3 + a] * d[1] + R2[6 + a] * d[2];   // R2^T d
+  for (int a = 0; a < 3; a++) { cl[a] = ctr[a] > size[a] ? size[a] : (ctr[a] < -size[a] ? -size[a] : ctr[a]); v[a] = ctr[a] - cl[a]; }
+  const double dist = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+  double pen;
+  if (dist > HMINVAL) {
+    pen = dist - r;
+    if (pen > margin) return false;
+    for (int a = 0; a < 3; a++) { nl[a] = v[a] / dist; pl[a] = cl[a] + nl[a] * (0.5 * pen); }
+  } else {
+    int kf = 0;
+    double depth = size[0] - fabs(ctr[0]);
+    for (int a = 1; a < 3; a++) if (size[a] - fabs(ctr[a]) < depth) { depth = size[a] - fabs(ctr[a]); kf = a; }
+    const double ck = kf == 0 ? ctr[0] : (kf == 1 ? ctr[1] : ctr[2]), sk = kf == 0 ? size[0] : (kf == 1 ? size[1] : size[2]);
+    const double sg = ck >= 0 ? 1.0 : -1.0;
+    pen = -depth - r;
+    if (pen > margin) return false;
+    for (int a = 0; a < 3; a++) { nl[a] = a == kf ? sg : 0.0; pl[a] = a == kf ? sg * sk : ctr[a]; }
+    for (int a = 0; a < 3; a++) pl[a] += nl[a] * (0.5 * pen);
+  }
+  double nw[3], pw[3];
+  mat_vec(nw, R2, nl);
+  mat_vec(pw, R2, pl);
+  *dist_out = pen;
+  for (int a = 0; a < 3; a++) { nrm[a] = -nw[a]; pos[a] = p2[a] + pw[a]; }
+  return true;
+}
+// half the slope of the squared distance from c0 + t al (box frame) to the box: nondecreasing in t
+__device__ __forceinline__ double seg_box_slope(const double* c0, const double* al, const double* size, double t) {
+  double g = 0;
+  for (int a = 0; a < 3; a++) {
+    const double x = c0[a] + t * al[a];
+    if (x > size[a]) g += al[a] * (x - size[a]);
+    else if (x < -size[a]) g += al[a] * (x + size[a]);
+  }
+  return g;
+}
+
 template <class L>
 __device__ void collide_pair(ConSink<L>& k, const HModel& m, const L& S, int g1, int g2, double margin) {
   const double zero[3] = {0, 0, 0};
@@ -1149,6 +1193,53 @@ __device__ void collide_pair(ConSink<L>& k, const HModel& m, const L& S, int g1,
     const double x = fmin(s2[1], fmax(-s2[1], dot3(ax, vec)));
     double q[3] = {p2[0] + ax[0] * x, p2[1] + ax[1] * x, p2[2] + ax[2] * x};
     col_sphere_sphere(k, p1, s1[0], q, s2[0], margin);
+  } else if (t1 == G_SPHERE && t2 == G_BOX) {
+    double dist, pos[3], nrm[3];
+    if (sphere_box_raw(p1, s1[0], p2, R2, s2, margin, &dist, pos, nrm)) k.emit(dist, pos, nrm, zero);
+  } else if (t1 == G_CAPSULE && t2 == G_BOX) {
+    // same construction as capsuleBox in the CPU checker, mjc_oracle.c (not MuJoCo's mjc_CapsuleBox case analysis): both ends if both touch; else the interval
+    // [tlo, thi] of segment points nearest to the box (two bisections on the monotone slope), plus a touching end
+    const double ax[3] = {R1[2], R1[5], R1[8]}, h = s1[1], d[3] = {p1[0] - p2[0], p1[1] - p2[1], p1[2] - p2[2]};
+    const double TOL = 1e-9, FLAT = 1e-12;
+    double c0[3], al[3];
+    for (int a = 0; a < 3; a++) {
+      c0[a] = R2[a] * d[0] + R2[3 + a] * d[1] + R2[6 + a] * d[2];
+      al[a] = R2[a] * ax[0] + R2[3 + a] * ax[1] + R2[6 + a] * ax[2];
+    }
+    double q[3], dm, pm[3], nm[3], dp, pp[3], np_[3];
+    for (int a = 0; a < 3; a++) q[a] = p1[a] - ax[a] * h;
+    const bool gm = sphere_box_raw(q, s1[0], p2, R2, s2, margin, &dm, pm, nm);
+    for (int a = 0; a < 3; a++) q[a] = p1[a] + ax[a] * h;
+    const bool gp = sphere_box_raw(q, s1[0], p2, R2, s2, margin, &dp, pp, np_);
+    if (gm && gp) { k.emit(dm, pm, nm, zero); k.emit(dp, pp, np_, zero); }
+    else {
+      const double sm = seg_box_slope(c0, al, s2, -h), sp = seg_box_slope(c0, al, s2, h);
+      double tlo, thi;
+      if (sm >= -FLAT) tlo = -h;
+      else if (sp < -FLAT) tlo = h;
+      else {
+        double lo = -h, hi = h;
+        for (int it = 0; it < 60; it++) { const double mid = 0.5 * (lo + hi); if (seg_box_slope(c0, al, s2, mid) >= -FLAT) hi = mid; else lo = mid; }
+        tlo = hi;
+      }
+      if (sp <= FLAT) thi = h;
+      else if (sm > FLAT) thi = -h;
+      else {
+        double lo = -h, hi = h;
+        for (int it = 0; it < 60; it++) { const double mid = 0.5 * (lo + hi); if (seg_box_slope(c0, al, s2, mid) <= FLAT) lo = mid; else hi = mid; }
+        thi = lo;
+      }
+      const int n0 = k.n;
+      double ds, ps[3], ns[3];
+      for (int a = 0; a < 3; a++) q[a] = p1[a] + ax[a] * tlo;
+      if (sphere_box_raw(q, s1[0], p2, R2, s2, margin, &ds, ps, ns)) k.emit(ds, ps, ns, zero);
+      if (thi > tlo + TOL) {
+        for (int a = 0; a < 3; a++) q[a] = p1[a] + ax[a] * thi;
+        if (sphere_box_raw(q, s1[0], p2, R2, s2, margin, &ds, ps, ns)) k.emit(ds, ps, ns, zero);
+      } else thi = tlo;
+      if (k.n - n0 < 2 && gm && tlo > -h + TOL) k.emit(dm, pm, nm, zero);
+      if (k.n - n0 < 2 && gp && thi < h - TOL) k.emit(dp, pp, np_, zero);
+    }
   } else if (t1 == G_CAPSULE && t2 == G_CAPSULE) {
     double a1[3] = {R1[2], R1[5], R1[8]}, a2[3] = {R2[2], R2[5], R2[8]}, dif[3] = {p1[0] - p2[0], p1[1] - p2[1], p1[2] - p2[2]};
     const double ma = dot3(a1, a1), mb = -dot3(a1, a2), mc = dot3(a2, a2), u = -dot3(a1, dif), v = dot3(a2, dif);
@@ -1217,7 +1308,7 @@ __device__ void fwd_collision(const HModel& m, const HParams& p, L& S, int lane,
   if (have) {
     g1 = m.pair_i[2 * (lane) + 0]; g2 = m.pair_i[2 * (lane) + 1];
     margin = fmax(m.geom_d[GDS * (g1) + GD_MARGIN], m.geom_d[GDS * (g2) + GD_MARGIN]);
-    // boxes only collide while the floor is lowered (KNOWN DEVIATION, DESIGN.md section 6: coplanar floor + box contacts
+    // boxes only collide while the floor is lowered (KNOWN DEVIATION, DESIGN.md sections 2 and 7: coplanar floor + box contacts
     // of the reference would need more constraint rows than a wave has lanes)
     if (BOXBOX && ter && ter[T_FLOOR] == 0.0 && ((g1 >= p.box_geom0 && g1 < p.box_geom0 + p.nbox) || (g2 >= p.box_geom0 && g2 < p.box_geom0 + p.nbox)))
       have = false;
@@ -2859,6 +2950,21 @@ void humanoid_set_state(HumanoidEnv* h, const double* qpos, const double* qvel, 
 }
 // whole-batch persistent rollout; 0 = launched, 1 = this env has no two-envs-per-wave kernels (caller steps it launch by launch)
 int humanoid_supports_rollout(HumanoidEnv* h) { return h->fast ? 1 : 0; }
+// 1 if one rollout launch keeps every env resident (a wave per two envs, all waves on the chip at once): only then does the
+// persistent kernel beat launch-per-step -- a second generation of waves would start after the first has run all T steps,
+// whereas per-step launches refill the slots every control step.
+int humanoid_rollout_resident(HumanoidEnv* h) {
+  if (!h->fast) return 0;
+  int nb = 0, dev = 0;
+  hipDeviceProp_t prop;
+  hipError_t e = hipSuccess;
+  if (h->p.task == TASK_WALK) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, humanoid_rollout_kernel<TASK_WALK>, 64, 0);
+  else if (h->p.task == TASK_H1WALK) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, humanoid_rollout_kernel<TASK_H1WALK>, 64, 0);
+  else if (h->p.task == TASK_STAND) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, humanoid_rollout_kernel<TASK_STAND>, 64, 0);
+  else return 0;
+  if (e != hipSuccess || hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+  return (long long)(h->p.n_envs + 1) / 2 <= (long long)nb * prop.multiProcessorCount ? 1 : 0;
+}
 int humanoid_rollout(HumanoidEnv* h, const RolloutArgs& ra, hipStream_t s) {
   if (!h->fast) return 1;
   HParams pp = h->p;

@@ -32,6 +32,7 @@ int humanoid_step_range(HumanoidEnv* h, int first, int count, const float* act, 
 void humanoid_get_state(HumanoidEnv* h, double* qpos, double* qvel, hipStream_t s);
 void humanoid_set_state(HumanoidEnv* h, const double* qpos, const double* qvel, hipStream_t s);
 int humanoid_supports_rollout(HumanoidEnv* h);
+int humanoid_rollout_resident(HumanoidEnv* h);
 int humanoid_rollout(HumanoidEnv* h, const RolloutArgs& ra, hipStream_t s);
 double* humanoid_ep_stats(HumanoidEnv* h);
 void humanoid_set_iteration(HumanoidEnv* h, int64_t it);

@@ -342,8 +342,10 @@ static void launch_gemm(const GemmArgs& g, hipStream_t s, int defer = 0, int wt 
   const int nz = (a.K + a.k_chunk - 1) / a.k_chunk;
   static const int env_wt = getenv("LHW_GEMM_WT") ? atoi(getenv("LHW_GEMM_WT")) : 0;   // tuning aid: 1 / 2 forces the tile size
   const int force_wt = wt ? wt : env_wt;
-  // 128 x 128 tiles when both dimensions fill them and the grid still covers the chip
-  const bool big = force_wt ? force_wt == 2 : (a.M >= 128 && a.N >= 128 && (size_t)((a.M + 127) / 128) * ((a.N + 127) / 128) * nz >= 256);
+  // 64 x 64 block tiles by default: on every shape of the update they beat the 128 x 128 variant (profiles/r02_ppo_gemm_shapes.txt:
+  // at K = 256 a block's whole K loop is 16 steps, so more, smaller blocks hide the load / store phases better than fewer
+  // LDS reads per MFMA help); wt = 2 (LHW_GEMM_WT=2) keeps the large tile selectable for other shapes
+  const bool big = force_wt == 2;
   const int tile = big ? 128 : 64;
   a.tiles_m = (a.M + tile - 1) / tile; a.tiles_n = (a.N + tile - 1) / tile; a.slices = nz;
   const dim3 grid(8 * (((size_t)a.tiles_m * a.tiles_n * nz + 7) / 8));

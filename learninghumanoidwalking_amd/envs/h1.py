@@ -42,7 +42,7 @@ class H1Spec:
     name: str = "h1"
     obs_dim: int = 35
     act_dim: int = 10
-    step_kernel_name: str = "humanoid_kernel<0, 2>"     # rocprof name of the control-step kernel (MODE 0, TASK_STAND)
+    step_kernel_name: str = "humanoid_kernel<0, 2, 32>"     # rocprof name of the control-step kernel (MODE 0, TASK_STAND)
     cfg: dict = field(default_factory=dict)
 
     def __post_init__(self):

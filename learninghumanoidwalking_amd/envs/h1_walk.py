@@ -27,7 +27,7 @@ class H1WalkSpec(H1Spec):
     yaml_path: str = H1_WALK_YAML
     name: str = "h1_walk"
     obs_dim: int = 43
-    step_kernel_name: str = "humanoid_kernel<0, 4>"
+    step_kernel_name: str = "humanoid_kernel<0, 4, 32>"
 
     def __post_init__(self):
         super().__post_init__()

@@ -64,7 +64,7 @@ class JvrcWalkSpec:
     name: str = "jvrc_walk"
     obs_dim: int = 37
     act_dim: int = 12
-    step_kernel_name: str = "humanoid_kernel<0, 1>"     # rocprof name of the control-step kernel (MODE 0, TASK_WALK)
+    step_kernel_name: str = "humanoid_kernel<0, 1, 32>"     # rocprof name of the control-step kernel (MODE 0, TASK_WALK)
     cfg: dict = field(default_factory=dict)
 
     def __post_init__(self):

@@ -35,6 +35,7 @@ _INERT_TAGS = {"camera", "light", "sensor", "keyframe", "custom", "visual", "ass
 SUPPORTED_PAIRS = {
     (GEOM_PLANE, GEOM_SPHERE), (GEOM_PLANE, GEOM_CAPSULE), (GEOM_PLANE, GEOM_BOX),
     (GEOM_SPHERE, GEOM_SPHERE), (GEOM_SPHERE, GEOM_CAPSULE), (GEOM_CAPSULE, GEOM_CAPSULE), (GEOM_BOX, GEOM_BOX),
+    (GEOM_SPHERE, GEOM_BOX), (GEOM_CAPSULE, GEOM_BOX),
 }
 
 _DEF_SOLREF = (0.02, 1.0)

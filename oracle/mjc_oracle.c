@@ -548,6 +548,95 @@ static int capsuleCapsule(RawCon* c, const double* p1, const double* R1, const d
   return n;
 }
 
+/* Sphere-box (MuJoCo: mjc_SphereBox, engine_collision_box.c) [MJ-recall]: the sphere centre in the box frame is clamped to the
+ * box; outside, the contact is along (centre - clamped point); inside, the sphere leaves through the nearest face.  The
+ * normal points from geom1 (the sphere) to geom2 (the box); the position is midway between the two surfaces. */
+static int sphereBox(RawCon* c, const double* p1, double r, const double* p2, const double* R2, const double* size, double margin) {
+  double d[3] = {p1[0] - p2[0], p1[1] - p2[1], p1[2] - p2[2]}, ctr[3], cl[3], v[3], nl[3], pl[3];
+  mulMatTVec3(ctr, R2, d);
+  for (int k = 0; k < 3; k++) { cl[k] = ctr[k] > size[k] ? size[k] : (ctr[k] < -size[k] ? -size[k] : ctr[k]); v[k] = ctr[k] - cl[k]; }
+  double dist = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]), pen;
+  if (dist > MINVAL) {
+    pen = dist - r;
+    if (pen > margin) return 0;
+    for (int k = 0; k < 3; k++) { nl[k] = v[k] / dist; pl[k] = cl[k] + nl[k] * (0.5 * pen); }
+  } else {
+    int kf = 0;
+    double depth = size[0] - fabs(ctr[0]);
+    for (int k = 1; k < 3; k++) if (size[k] - fabs(ctr[k]) < depth) { depth = size[k] - fabs(ctr[k]); kf = k; }
+    const double sg = ctr[kf] >= 0 ? 1.0 : -1.0;
+    pen = -depth - r;
+    if (pen > margin) return 0;
+    for (int k = 0; k < 3; k++) { nl[k] = 0; pl[k] = ctr[k]; }
+    nl[kf] = sg; pl[kf] = sg * size[kf];
+    for (int k = 0; k < 3; k++) pl[k] += nl[k] * (0.5 * pen);
+  }
+  double nw[3], pw[3];
+  mulMatVec3(nw, R2, nl);
+  mulMatVec3(pw, R2, pl);
+  c->dist = pen;
+  for (int k = 0; k < 3; k++) { c->frame[k] = -nw[k]; c->frame[3 + k] = 0; c->pos[k] = p2[k] + pw[k]; }
+  return 1;
+}
+/* d/dt of the squared distance from the point c0 + t al (box frame) to the box, halved: nondecreasing in t (the distance to
+ * a convex set along a line is convex) */
+static double segBoxSlope(const double* c0, const double* al, const double* size, double t) {
+  double g = 0;
+  for (int k = 0; k < 3; k++) {
+    const double x = c0[k] + t * al[k];
+    if (x > size[k]) g += al[k] * (x - size[k]);
+    else if (x < -size[k]) g += al[k] * (x + size[k]);
+  }
+  return g;
+}
+/* Capsule-box.  NOT a restatement of MuJoCo's mjc_CapsuleBox (a long case analysis whose source could not be consulted).
+ * The squared distance from a point of the capsule's segment to the box is convex along the segment; its minimisers form an
+ * interval [t_lo, t_hi], found by two bisections (60 halvings each = to the last bit) on the monotone slope.  Contacts are
+ * sphere-box contacts: if both segment ends touch, the two ends (a capsule lying on a face rests on its ends, as in MuJoCo);
+ * otherwise at t_lo, at t_hi if it is a different point (the capsule leaves a face over an edge), and at a touching end that
+ * is not one of those points.  At most 2 contacts.  The HIP kernel implements exactly this (csrc/lhw_humanoid.hip). */
+#define CAPBOX_TOL 1e-9    /* two segment parameters closer than this are one point */
+#define CAPBOX_FLAT 1e-12  /* |slope| below this counts as zero (a segment parallel to a face up to rounding) */
+static int capsuleBox(RawCon* c, const double* p1, const double* R1, const double* s1, const double* p2, const double* R2, const double* s2, double margin) {
+  const double axis[3] = {R1[2], R1[5], R1[8]}, h = s1[1];
+  double d[3] = {p1[0] - p2[0], p1[1] - p2[1], p1[2] - p2[2]}, c0[3], al[3];
+  mulMatTVec3(c0, R2, d);
+  mulMatTVec3(al, R2, axis);
+  RawCon em, ep;
+  double q[3];
+  for (int k = 0; k < 3; k++) q[k] = p1[k] - axis[k] * h;
+  const int gm = sphereBox(&em, q, s1[0], p2, R2, s2, margin);
+  for (int k = 0; k < 3; k++) q[k] = p1[k] + axis[k] * h;
+  const int gp = sphereBox(&ep, q, s1[0], p2, R2, s2, margin);
+  if (gm && gp) { c[0] = em; c[1] = ep; return 2; }
+  const double sm = segBoxSlope(c0, al, s2, -h), sp = segBoxSlope(c0, al, s2, h);
+  double tlo, thi;
+  if (sm >= -CAPBOX_FLAT) tlo = -h;
+  else if (sp < -CAPBOX_FLAT) tlo = h;
+  else {
+    double lo = -h, hi = h;
+    for (int it = 0; it < 60; it++) { const double mid = 0.5 * (lo + hi); if (segBoxSlope(c0, al, s2, mid) >= -CAPBOX_FLAT) hi = mid; else lo = mid; }
+    tlo = hi;
+  }
+  if (sp <= CAPBOX_FLAT) thi = h;
+  else if (sm > CAPBOX_FLAT) thi = -h;
+  else {
+    double lo = -h, hi = h;
+    for (int it = 0; it < 60; it++) { const double mid = 0.5 * (lo + hi); if (segBoxSlope(c0, al, s2, mid) <= CAPBOX_FLAT) lo = mid; else hi = mid; }
+    thi = lo;
+  }
+  int n = 0;
+  for (int k = 0; k < 3; k++) q[k] = p1[k] + axis[k] * tlo;
+  n += sphereBox(c + n, q, s1[0], p2, R2, s2, margin);
+  if (thi > tlo + CAPBOX_TOL) {
+    for (int k = 0; k < 3; k++) q[k] = p1[k] + axis[k] * thi;
+    n += sphereBox(c + n, q, s1[0], p2, R2, s2, margin);
+  } else thi = tlo;
+  if (n < 2 && gm && tlo > -h + CAPBOX_TOL) c[n++] = em;
+  if (n < 2 && gp && thi < h - CAPBOX_TOL) c[n++] = ep;
+  return n;
+}
+
 /* Box-box: separating-axis test over the 15 candidate axes, then either a face contact (the vertices of the intersection
  * of the incident face with the reference face rectangle, at or below the reference face within `margin`, become contacts,
  * at most 4, deepest first) or a single edge-edge contact.  This is the classical SAT + clipping construction
@@ -724,6 +813,8 @@ static void collision(OData* d) {
     else if (t1 == GEOM_SPHERE && t2 == GEOM_SPHERE) n = sphereSphereRaw(rc, p1, s1[0], p2, s2[0], margin);
     else if (t1 == GEOM_SPHERE && t2 == GEOM_CAPSULE) n = sphereCapsule(rc, p1, s1[0], p2, R2, s2, margin);
     else if (t1 == GEOM_CAPSULE && t2 == GEOM_CAPSULE) n = capsuleCapsule(rc, p1, R1, s1, p2, R2, s2, margin);
+    else if (t1 == GEOM_SPHERE && t2 == GEOM_BOX) n = sphereBox(rc, p1, s1[0], p2, R2, s2, margin);
+    else if (t1 == GEOM_CAPSULE && t2 == GEOM_BOX) n = capsuleBox(rc, p1, R1, s1, p2, R2, s2, margin);
     else if (t1 == GEOM_BOX && t2 == GEOM_BOX) n = boxBox(rc, p1, R1, s1, p2, R2, s2, margin);
     for (int i = 0; i < n; i++) {
       if (d->ncon >= MAXCON) { d->warning_contactfull = 1; return; }

@@ -2,6 +2,7 @@
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+os.environ["LHW_ROLLOUT_PERSISTENT"] = "2"
 from learninghumanoidwalking_amd.envs.jvrc_walk import JvrcWalkSpec
 from learninghumanoidwalking_amd.ppo import Rollout
 from learninghumanoidwalking_amd.ppo_kernels import PpoKernels, reference_init

@@ -60,6 +60,9 @@ static inline hipError_t hipSetDevice(int) { return hipSuccess; }
 static inline hipError_t hipGetLastError() { return hipSuccess; }
 static inline const char* hipGetErrorString(hipError_t) { return "emulated"; }
 template <class K> static inline hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int* n, K, int, size_t) { *n = 8; return hipSuccess; }
+struct hipDeviceProp_t { int multiProcessorCount = 256; };
+static inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
+static inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) { *p = hipDeviceProp_t(); return hipSuccess; }
 
 namespace emu {
 enum { RUNNABLE = 0, BLOCKED = 1, DONE = 2 };

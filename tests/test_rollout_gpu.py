@@ -26,8 +26,9 @@ def _kernels(spec, N, seed):
 
 
 @pytest.mark.parametrize("task,N,T,mtl", [("jvrc_walk", 67, 24, 9), ("h1", 33, 12, 5), ("h1_walk", 18, 12, 0)])
-def test_persistent_rollout_equals_stepwise(task, N, T, mtl):
+def test_persistent_rollout_equals_stepwise(task, N, T, mtl, monkeypatch):
     import torch
+    monkeypatch.setenv("LHW_ROLLOUT_PERSISTENT", "1")     # (the one-launch rollout is opt-in)
     from learninghumanoidwalking_amd.envs.h1 import H1Spec
     from learninghumanoidwalking_amd.envs.h1_walk import H1WalkSpec
     from learninghumanoidwalking_amd.envs.jvrc_walk import JvrcWalkSpec
