@@ -81,9 +81,12 @@ def test_unsupported_features_raise():
         mjcf.compile_string(base % ("ball", "sphere"))
     with pytest.raises(mjcf.MjcfError):
         mjcf.compile_string(base % ("hinge", "mesh"))
-    with pytest.raises(mjcf.MjcfError):   # box-capsule has no narrow phase
+    with pytest.raises(mjcf.MjcfError):   # cylinders have no narrow phase (box-capsule / box-sphere do since round 2)
         mjcf.compile_string("<mujoco><worldbody><body><freejoint/><geom type='box' size='.1 .1 .1'/></body>"
+                            "<body pos='1 0 0'><freejoint/><geom type='cylinder' size='.1 .1'/></body></worldbody></mujoco>")
+    m = mjcf.compile_string("<mujoco><worldbody><body><freejoint/><geom type='box' size='.1 .1 .1'/></body>"
                             "<body pos='1 0 0'><freejoint/><geom type='capsule' size='.1 .1'/></body></worldbody></mujoco>")
+    assert m.npair == 1 and m.geom_type[m.pair_geom1[0]] == 3 and m.geom_type[m.pair_geom2[0]] == 6   # capsule before box
 
 
 def test_euler_and_fromto_orientation():
