@@ -99,7 +99,8 @@ def main():
     ap.add_argument("--epochs", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-mirror", action="store_true")
-    ap.add_argument("--infer-fp16", action="store_true", help="rollout inference with fp16 operands (BASELINE config 5); update stays f32")
+    ap.add_argument("--infer-fp16", action="store_true", help="rollout inference with fp16 operands; update stays f32")
+    ap.add_argument("--fp16", action="store_true", help="BASELINE config 5: fp16 actor / critic (inference and every GEMM of the update with fp16 operands, f32 accumulation / master weights / Adam)")
     args = ap.parse_args()
 
     import numpy as np
@@ -134,7 +135,7 @@ def main():
         gamma=0.99, lam=0.95, lr=3e-4, eps=1e-5, entropy_coeff=0.0, clip=0.2, minibatch_size=args.minibatch_size,
         epochs=args.epochs, max_traj_len=args.traj_len, num_procs=args.num_envs, num_envs=args.num_envs, max_grad_norm=0.5,
         mirror_coeff=0.4, eval_freq=10**9, recurrent=False, imitate=None, imitate_coeff=0.3, learn_std=False,
-        std_dev=0.223, no_mirror=args.no_mirror, infer_fp16=args.infer_fp16, continued=None, logdir=os.path.join("/tmp", f"lhw_bench_{os.getpid()}"),
+        std_dev=0.223, no_mirror=args.no_mirror, infer_fp16=args.infer_fp16, fp16=args.fp16, continued=None, logdir=os.path.join("/tmp", f"lhw_bench_{os.getpid()}"),
         device_index=local_rank)
     algo = PPO(spec_cls, ppo_args, seed=0)
     if algo.obs_rms is not None:  # cartpole path: frozen running normalisation after a short warm-up (ppo.py:442-457)
@@ -286,7 +287,7 @@ def main():
         out = dict(
             metric="env-steps/s (whole job): on-device rollout + GAE + PPO update", value=value, unit="env-steps/s",
             n_gpus=world, steps=K, warmup=args.warmup, ms_per_step=elapsed / K * 1e3, higher_is_better=True, scaling="weak",
-            vs_baseline=None, dtype="f64 physics / f32 networks" + (" (fp16-operand rollout inference)" if args.infer_fp16 else ""), data="synthetic",
+            vs_baseline=None, dtype="f64 physics / " + ("fp16-operand networks, f32 accumulate + master weights" if args.fp16 else "f32 networks" + (" (fp16-operand rollout inference)" if args.infer_fp16 else "")), data="synthetic",
             config=dict(workload=f"{env_name} @ {N} envs/GPU, T={T} control steps/iter, {args.epochs} epochs, "
                                  f"minibatch {args.minibatch_size}/GPU" + (" (JVRC stand-in model)" if env_name.startswith("jvrc") else " (H1 stand-in model)" if env_name.startswith("h1") else ""),
                         envs_per_gpu=N, traj_len=T, epochs=args.epochs, minibatch_per_gpu=args.minibatch_size,

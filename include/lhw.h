@@ -193,7 +193,8 @@ int lhw_env_pop_fault_stats(LhwEnv* env, int64_t* contact_overflow, int64_t* div
 int lhw_env_pop_rerun_count(LhwEnv* env, int64_t* reruns);
 /* Test / tuning hook for the update's GEMM kernel (no reference counterpart): C = op(A) op(B) on device buffers.
  * a_kc: A stored [M][K] (else [K][M]); b_kc: B stored [N][K] (else [K][N]); wt: 0 = automatic tile choice, 1 = 64x64, 2 = 128x128
- * block tiles; optional epilogue bias[n], ReLU, mask (v = mask[m][n] > 0 ? v : 0).  With `part` (split-K scratch,
+ * block tiles, 16 = fp16 operands (64x64 tiles, fp16 MFMA); optional epilogue bias[n], ReLU, mask (v = mask[m][n] > 0 ? v : 0).
+ * With `part` (split-K scratch,
  * [ceil(K / k_chunk)][M*N] floats) the partial products are reduced in slice order and ADDED to C, as the weight-gradient GEMMs
  * of lhw_ppo_grad do; `colsum` ([slices][M] scratch, A stored [K][M] only) also ADDS sum_k A[k][m] to colsum_out[m] (the bias
  * gradient fused into the same pass).  Leading dimensions must be multiples of 4 floats (16-byte rows). */
@@ -250,6 +251,10 @@ int lhw_ppo_forward_at(LhwPpo* ppo, const float* theta, const float* obs, int64_
 /* fp16 != 0: lhw_ppo_forward (rollout inference) rounds weights and activations to fp16 and multiplies on the fp16 MFMA with
  * float32 accumulation (BASELINE config "fp16 actor/critic"); the update (lhw_ppo_grad) always uses float32 operands */
 int lhw_ppo_set_inference_dtype(LhwPpo* ppo, int fp16);
+/* fp16 != 0: every GEMM of lhw_ppo_grad (forward, activation gradients, weight gradients) rounds both operands to fp16 and
+ * runs on the fp16 MFMA with float32 accumulation -- BASELINE config 5 "fp16 actor/critic": fp16 weights and activations per
+ * GEMM, float32 master weights, loss, gradient accumulation and Adam.  The reference has no counterpart (it trains in float32). */
+int lhw_ppo_set_update_dtype(LhwPpo* ppo, int fp16);
 /* time-major [T][N] GAE(lambda); done holds LHW_DONE_* flags, vterm the critic value of the terminal
  * observation, vfinal [N] the value of the observation after the last step */
 int lhw_gae(int32_t T, int32_t N, const float* rew, const float* val, const uint8_t* done, const float* vterm,

@@ -2656,9 +2656,17 @@ int humanoid_create(HumanoidEnv** out, const std::vector<int32_t>& mi, const std
     if (cd != 1 && cd != 3) return lhw_fail(LHW_ERR_UNSUPPORTED, "condim %d", cd);
   }
   if (mi[LHW_IH_CONE] != 0) return lhw_fail(LHW_ERR_UNSUPPORTED, "only the pyramidal cone is implemented");
-  for (int q = 0; q < np; q++)
-    if (!stepping && IF(LHW_IF_GEOM_TYPE)[IF(LHW_IF_PAIR_GEOM1)[q]] == G_BOX && IF(LHW_IF_GEOM_TYPE)[IF(LHW_IF_PAIR_GEOM2)[q]] == G_BOX)
+  for (int q = 0; q < np; q++) {
+    const int t1 = IF(LHW_IF_GEOM_TYPE)[IF(LHW_IF_PAIR_GEOM1)[q]], t2 = IF(LHW_IF_GEOM_TYPE)[IF(LHW_IF_PAIR_GEOM2)[q]];
+    if (!stepping && t1 == G_BOX && t2 == G_BOX)
       return lhw_fail(LHW_ERR_UNSUPPORTED, "box-box pairs are only compiled into the stepping-task kernels");
+    // narrow phases that exist (geom1 type <= geom2 type, as MuJoCo orders a pair): a model packed straight from an mjModel
+    // (pack_from_mjmodel) does not pass through mjcf.build_pairs, which refuses the others
+    const bool ok = (t1 == G_PLANE && (t2 == G_SPHERE || t2 == G_CAPSULE || t2 == G_BOX)) ||
+                    (t1 == G_SPHERE && (t2 == G_SPHERE || t2 == G_CAPSULE || t2 == G_BOX)) ||
+                    (t1 == G_CAPSULE && (t2 == G_CAPSULE || t2 == G_BOX)) || (t1 == G_BOX && t2 == G_BOX);
+    if (!ok) return lhw_fail(LHW_ERR_UNSUPPORTED, "collision pair %d: no narrow phase for geom types %d / %d (plane, sphere, capsule, box only)", q, t1, t2);
+  }
 
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return lhw_fail(LHW_ERR_NO_DEVICE, "no HIP device");

@@ -195,69 +195,112 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(GemmArgs g) {
   }
 }
 
-// Half-precision inference GEMM (BASELINE config "fp16 actor/critic"): C = A B^T (+ bias, ReLU) with A [M][K] and B [N][K]
-// read as float32, rounded to fp16 while they are staged into LDS, multiplied on the fp16 MFMA
-// (v_mfma_f32_32x32x8_f16) with float32 accumulation; bias / ReLU / output stay float32.  Forward (rollout) only: the
-// update keeps float32 operands like the reference.
+// Half-precision GEMM (BASELINE config "fp16 actor/critic"): the same tiling, block order, epilogues, split-K and fused column
+// sums as gemm_f32_kernel, with both operands read as float32, rounded to fp16 while they are staged into LDS ([row][k] tiles,
+// k contiguous) and multiplied on the fp16 MFMA (v_mfma_f32_32x32x8_f16) with float32 accumulation; bias / ReLU / mask / outputs
+// and the split-K partials stay float32.  Used by the rollout inference (lhw_ppo_set_inference_dtype) and, with
+// lhw_ppo_set_update_dtype, by every GEMM of the update (weights, activations and back-propagated gradients rounded to fp16
+// per GEMM; float32 master weights, loss, Adam).
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 #define HLD (BK + 4)
-__global__ void __launch_bounds__(256) gemm_f16_fwd_kernel(GemmArgs g) {
-  __shared__ _Float16 Ah[BM][HLD];
-  __shared__ _Float16 Bh[BN][HLD];
+template <bool A_KC, bool B_KC>
+__global__ void __launch_bounds__(256) gemm_f16_kernel(GemmArgs g) {
+  __shared__ _Float16 Ah[2][BM][HLD];
+  __shared__ _Float16 Bh[2][BN][HLD];
+  __shared__ float red[256];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave & 1, wn = wave >> 1;
-  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  const int per = (int)gridDim.x >> 3, v = ((int)blockIdx.x & 7) * per + ((int)blockIdx.x >> 3);   // XCD-aware order (gemm_f32_kernel)
+  if (v >= g.tiles_m * g.tiles_n * g.slices) return;
+  const int tn = v % g.tiles_n, tm = (v / g.tiles_n) % g.tiles_m, bz = v / (g.tiles_n * g.tiles_m);
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int kbeg = bz * g.k_chunk;
+  const int kend = min(g.K, kbeg + g.k_chunk);
   f32x16 acc;
   for (int r = 0; r < 16; r++) acc[r] = 0.f;
   float4 ra, rb;
-  auto load = [&](int k0) {
-    ra = make_float4(0.f, 0.f, 0.f, 0.f);
-    rb = ra;
-    const int k = k0 + (tid & 3) * 4;
-    const int row = m0 + (tid >> 2), col = n0 + (tid >> 2);
-    if (row < g.M && k < g.K) {
-      ra = *reinterpret_cast<const float4*>(g.A + (size_t)row * g.lda + k);
-      if (k + 1 >= g.K) ra.y = 0.f;
-      if (k + 2 >= g.K) ra.z = 0.f;
-      if (k + 3 >= g.K) ra.w = 0.f;
-    }
-    if (col < g.N && k < g.K) {
-      rb = *reinterpret_cast<const float4*>(g.B + (size_t)col * g.ldb + k);
-      if (k + 1 >= g.K) rb.y = 0.f;
-      if (k + 2 >= g.K) rb.z = 0.f;
-      if (k + 3 >= g.K) rb.w = 0.f;
+  auto load_tile = [&](float4& r, const float* __restrict__ P, int ld, bool kc, int x0, int X, int k0) {
+    r = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (kc) {
+      const int row = x0 + (tid >> 2), k = k0 + (tid & 3) * 4;
+      if (row < X && k < kend) {
+        r = *reinterpret_cast<const float4*>(P + (size_t)row * ld + k);
+        if (k + 1 >= kend) r.y = 0.f;
+        if (k + 2 >= kend) r.z = 0.f;
+        if (k + 3 >= kend) r.w = 0.f;
+      }
+    } else {
+      const int k = k0 + (tid >> 4), x = x0 + (tid & 15) * 4;
+      if (k < kend && x < X) {
+        r = *reinterpret_cast<const float4*>(P + (size_t)k * ld + x);
+        if (x + 1 >= X) r.y = 0.f;
+        if (x + 2 >= X) r.z = 0.f;
+        if (x + 3 >= X) r.w = 0.f;
+      }
     }
   };
-  load(0);
-  for (int k0 = 0; k0 < g.K; k0 += BK) {
-    __syncthreads();
-    {
-      const int row = tid >> 2, kq = (tid & 3) * 4;
-      f16x4 ha = {(_Float16)ra.x, (_Float16)ra.y, (_Float16)ra.z, (_Float16)ra.w};
-      f16x4 hb = {(_Float16)rb.x, (_Float16)rb.y, (_Float16)rb.z, (_Float16)rb.w};
-      *reinterpret_cast<f16x4*>(&Ah[row][kq]) = ha;
-      *reinterpret_cast<f16x4*>(&Bh[row][kq]) = hb;
+  auto store_tile = [&](_Float16 (&T)[BM][HLD], const float4& r, bool kc) {
+    if (kc) {
+      const f16x4 hv = {(_Float16)r.x, (_Float16)r.y, (_Float16)r.z, (_Float16)r.w};
+      *reinterpret_cast<f16x4*>(&T[tid >> 2][(tid & 3) * 4]) = hv;
+    } else {
+      const int k = tid >> 4, xq = (tid & 15) * 4;
+      T[xq + 0][k] = (_Float16)r.x; T[xq + 1][k] = (_Float16)r.y; T[xq + 2][k] = (_Float16)r.z; T[xq + 3][k] = (_Float16)r.w;
     }
-    __syncthreads();
-    if (k0 + BK < g.K) load(k0 + BK);
+  };
+  const bool want_colsum = !A_KC && g.colsum != nullptr && tn == 0;
+  float cs = 0.f;
+  int cur = 0;
+  if (kbeg < kend) {
+    load_tile(ra, g.A, g.lda, A_KC, m0, g.M, kbeg);
+    load_tile(rb, g.B, g.ldb, B_KC, n0, g.N, kbeg);
+    store_tile(Ah[0], ra, A_KC);
+    store_tile(Bh[0], rb, B_KC);
+  }
+  __syncthreads();
+  for (int k0 = kbeg; k0 < kend; k0 += BK) {
+    const bool more = k0 + BK < kend;
+    if (more) {
+      load_tile(ra, g.A, g.lda, A_KC, m0, g.M, k0 + BK);
+      load_tile(rb, g.B, g.ldb, B_KC, n0, g.N, k0 + BK);
+    }
     const int am = wm * 32 + (lane & 31), bn = wn * 32 + (lane & 31), kh = lane >> 5;
 #pragma unroll
     for (int kk = 0; kk < BK / 8; kk++) {
-      const f16x4 a = *reinterpret_cast<const f16x4*>(&Ah[am][kk * 8 + kh * 4]);
-      const f16x4 b = *reinterpret_cast<const f16x4*>(&Bh[bn][kk * 8 + kh * 4]);
+      const f16x4 a = *reinterpret_cast<const f16x4*>(&Ah[cur][am][kk * 8 + kh * 4]);
+      const f16x4 b = *reinterpret_cast<const f16x4*>(&Bh[cur][bn][kk * 8 + kh * 4]);
       acc = __builtin_amdgcn_mfma_f32_32x32x8f16(a, b, acc, 0, 0, 0);
     }
+    if (want_colsum) {   // thread (m = tid % 64, k group = tid / 64): the rounded entries it would also have multiplied
+      const int m = tid & 63, kg = tid >> 6;
+#pragma unroll
+      for (int q = 0; q < 4; q++) cs += (float)Ah[cur][m][kg * 4 + q];
+    }
+    if (more) {
+      store_tile(Ah[cur ^ 1], ra, A_KC);
+      store_tile(Bh[cur ^ 1], rb, B_KC);
+    }
+    __syncthreads();
+    cur ^= 1;
   }
   const int col = n0 + wn * 32 + (lane & 31);
   const float bias = (g.bias && col < g.N) ? g.bias[col] : 0.f;
+  float* part = g.part ? g.part + (size_t)bz * g.M * g.N : nullptr;
 #pragma unroll
   for (int r = 0; r < 16; r++) {
-    int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
     if (row < g.M && col < g.N) {
-      float v = acc[r] + bias;
-      if (g.relu) v = fmaxf(v, 0.f);
-      g.C[(size_t)row * g.ldc + col] = v;
+      float v2 = acc[r] + bias;
+      if (g.relu) v2 = fmaxf(v2, 0.f);
+      if (g.mask) v2 = g.mask[(size_t)row * g.ldmask + col] > 0.f ? v2 : 0.f;
+      if (part) part[(size_t)row * g.N + col] = v2;
+      else g.C[(size_t)row * g.ldc + col] = v2;
     }
+  }
+  if (want_colsum) {
+    red[tid] = cs;
+    __syncthreads();
+    if (tid < 64 && m0 + tid < g.M) g.colsum[(size_t)bz * g.M + m0 + tid] = ((red[tid] + red[64 + tid]) + red[128 + tid]) + red[192 + tid];
   }
 }
 
@@ -335,7 +378,7 @@ static void launch_reduce_segments(const SegList& L, hipStream_t s) {
 
 // defer != 0: split-K partials (and the fused column sums) stay in g.part / g.colsum for a later reduce_segments launch
 template <bool A_KC, bool B_KC>
-static void launch_gemm(const GemmArgs& g, hipStream_t s, int defer = 0, int wt = 0) {
+static void launch_gemm(const GemmArgs& g, hipStream_t s, int defer = 0, int wt = 0, int half = 0) {
   GemmArgs a = g;
   if (a.k_chunk <= 0) a.k_chunk = a.K;
   a.k_chunk = ((a.k_chunk + BK - 1) / BK) * BK;
@@ -346,10 +389,11 @@ static void launch_gemm(const GemmArgs& g, hipStream_t s, int defer = 0, int wt 
   // at K = 256 a block's whole K loop is 16 steps, so more, smaller blocks hide the load / store phases better than fewer
   // LDS reads per MFMA help); wt = 2 (LHW_GEMM_WT=2) keeps the large tile selectable for other shapes
   const bool big = force_wt == 2;
-  const int tile = big ? 128 : 64;
+  const int tile = (big && !half) ? 128 : 64;
   a.tiles_m = (a.M + tile - 1) / tile; a.tiles_n = (a.N + tile - 1) / tile; a.slices = nz;
   const dim3 grid(8 * (((size_t)a.tiles_m * a.tiles_n * nz + 7) / 8));
-  if (big) hipLaunchKernelGGL((gemm_f32_kernel<A_KC, B_KC, 2>), grid, dim3(256), 0, s, a);
+  if (half) hipLaunchKernelGGL((gemm_f16_kernel<A_KC, B_KC>), grid, dim3(256), 0, s, a);
+  else if (big) hipLaunchKernelGGL((gemm_f32_kernel<A_KC, B_KC, 2>), grid, dim3(256), 0, s, a);
   else hipLaunchKernelGGL((gemm_f32_kernel<A_KC, B_KC, 1>), grid, dim3(256), 0, s, a);
   if (a.part && !defer) {  // ordered reduction of the split-K slices into the (accumulating) destination
     const int n = a.M * a.N;
@@ -385,6 +429,7 @@ struct LhwPpo {
   float clip, ent_coeff, mirror_coeff, grad_clip, lr, adam_eps, beta1, beta2;
   int use_mirror;
   int infer_half = 0;     // rollout inference with fp16 operands (lhw_ppo_set_inference_dtype)
+  int update_half = 0;    // every GEMM of the update with fp16 operands (lhw_ppo_set_update_dtype)
   MlpLayout la, lc;       // actor, critic
   size_t off_actor, off_std, off_critic, n_params;  // flat theta: [actor | stds(A, padded to 4) | critic]
   // mirror tables (device): obs_src[Dp], obs_sign[Dp], act_src[A], act_sign[A]
@@ -420,38 +465,21 @@ struct LhwPpo {
     if (e_ != hipSuccess) return lhw_fail(LHW_ERR_HIP, "%s failed: %s", #x, hipGetErrorString(e_)); \
   } while (0)
 
-static void launch_gemm_f16(const GemmArgs& g, hipStream_t s) {
-  dim3 grid((g.M + BM - 1) / BM, (g.N + BN - 1) / BN, 1);
-  hipLaunchKernelGGL(gemm_f16_fwd_kernel, grid, dim3(256), 0, s, g);
-}
-
 // y = mlp(x) for R rows; keeps h1/h2 for the backward pass.  half != 0: fp16 operands (rollout inference only)
 static void mlp_forward(const MlpLayout& L, const float* theta, const float* x, int ldx, int R, float* h1, float* h2,
                         float* y, hipStream_t s, int half = 0) {
-  if (half) {
-    GemmArgs g{};
-    g.A = x; g.lda = ldx; g.B = theta + L.w1; g.ldb = L.Dp; g.C = h1; g.ldc = L.H; g.M = R; g.N = L.H; g.K = L.Dp; g.bias = theta + L.b1; g.relu = 1;
-    launch_gemm_f16(g, s);
-    g = GemmArgs{};
-    g.A = h1; g.lda = L.H; g.B = theta + L.w2; g.ldb = L.H; g.C = h2; g.ldc = L.H; g.M = R; g.N = L.H; g.K = L.H; g.bias = theta + L.b2; g.relu = 1;
-    launch_gemm_f16(g, s);
-    g = GemmArgs{};
-    g.A = h2; g.lda = L.H; g.B = theta + L.w3; g.ldb = L.H; g.C = y; g.ldc = L.Op; g.M = R; g.N = L.O; g.K = L.H; g.bias = theta + L.b3;
-    launch_gemm_f16(g, s);
-    return;
-  }
   GemmArgs g{};
   g.A = x; g.lda = ldx; g.B = theta + L.w1; g.ldb = L.Dp; g.C = h1; g.ldc = L.H; g.M = R; g.N = L.H; g.K = L.Dp;
   g.bias = theta + L.b1; g.relu = 1;
-  launch_gemm<true, true>(g, s);
+  launch_gemm<true, true>(g, s, 0, 0, half);
   g = GemmArgs{};
   g.A = h1; g.lda = L.H; g.B = theta + L.w2; g.ldb = L.H; g.C = h2; g.ldc = L.H; g.M = R; g.N = L.H; g.K = L.H;
   g.bias = theta + L.b2; g.relu = 1;
-  launch_gemm<true, true>(g, s);
+  launch_gemm<true, true>(g, s, 0, 0, half);
   g = GemmArgs{};
   g.A = h2; g.lda = L.H; g.B = theta + L.w3; g.ldb = L.H; g.C = y; g.ldc = L.Op; g.M = R; g.N = L.O; g.K = L.H;
   g.bias = theta + L.b3;
-  launch_gemm<true, true>(g, s);
+  launch_gemm<true, true>(g, s, 0, 0, half);
 }
 
 static void colsum_det(const float* X, int rows, int ld, int ncols, float* out, float* scratch /* [COLSUM_CHUNKS][ncols] */, hipStream_t s) {
@@ -487,32 +515,32 @@ static BwdParts bwd_parts_carve(const MlpLayout& L, size_t rows, int passes, flo
 // wrote; mlp_backward_segments then lists them for the ordered reduction into grad.  Every reduction runs in a fixed order
 // (same seed -> bitwise identical weights, the property the reference's tests/test_determinism.py checks).
 static void mlp_backward(const MlpLayout& L, const float* theta, const float* x, int ldx, int R, const float* h1, const float* h2,
-                         const float* dy, float* dh2, float* dh1, const BwdParts& P, BwdSlices& z, hipStream_t s) {
+                         const float* dy, float* dh2, float* dh1, const BwdParts& P, BwdSlices& z, hipStream_t s, int half = 0) {
   GemmArgs g{};
   // dW3 [O][H] = dy^T h2 ; db3 = colsum(dy)
   g.A = dy; g.lda = L.Op; g.B = h2; g.ldb = L.H; g.M = L.O; g.N = L.H; g.K = R;
   g.part = P.w3 + (size_t)z.w3 * L.O * L.H; g.colsum = P.b3 + (size_t)z.w3 * L.O; g.k_chunk = KC_SKINNY;
-  launch_gemm<false, false>(g, s, 1);
+  launch_gemm<false, false>(g, s, 1, 0, half);
   // dh2 = (dy W3) * (h2 > 0)
   g = GemmArgs{};
   g.A = dy; g.lda = L.Op; g.B = theta + L.w3; g.ldb = L.H; g.C = dh2; g.ldc = L.H; g.M = R; g.N = L.H; g.K = L.O;
   g.mask = h2; g.ldmask = L.H;
-  launch_gemm<true, false>(g, s);
+  launch_gemm<true, false>(g, s, 0, 0, half);
   // dW2 = dh2^T h1 ; db2 = colsum(dh2)
   g = GemmArgs{};
   g.A = dh2; g.lda = L.H; g.B = h1; g.ldb = L.H; g.M = L.H; g.N = L.H; g.K = R;
   g.part = P.w2 + (size_t)z.w2 * L.H * L.H; g.colsum = P.b2 + (size_t)z.w2 * L.H; g.k_chunk = KC_WIDE;
-  launch_gemm<false, false>(g, s, 1);
+  launch_gemm<false, false>(g, s, 1, 0, half);
   // dh1 = (dh2 W2) * (h1 > 0)
   g = GemmArgs{};
   g.A = dh2; g.lda = L.H; g.B = theta + L.w2; g.ldb = L.H; g.C = dh1; g.ldc = L.H; g.M = R; g.N = L.H; g.K = L.H;
   g.mask = h1; g.ldmask = L.H;
-  launch_gemm<true, false>(g, s);
+  launch_gemm<true, false>(g, s, 0, 0, half);
   // dW1 [H][Dp] = dh1^T x ; db1 = colsum(dh1)
   g = GemmArgs{};
   g.A = dh1; g.lda = L.H; g.B = x; g.ldb = ldx; g.M = L.H; g.N = L.Dp; g.K = R;
   g.part = P.w1 + (size_t)z.w1 * L.H * L.Dp; g.colsum = P.b1 + (size_t)z.w1 * L.H; g.k_chunk = KC_SKINNY;
-  launch_gemm<false, false>(g, s, 1);
+  launch_gemm<false, false>(g, s, 1, 0, half);
   z.w3 += nsl(R, KC_SKINNY); z.w2 += nsl(R, KC_WIDE); z.w1 += nsl(R, KC_SKINNY);
 }
 static void mlp_backward_segments(SegList& S, const MlpLayout& L, float* grad, const BwdParts& P, const BwdSlices& z) {
@@ -782,10 +810,11 @@ extern "C" int lhw_debug_gemm(int32_t a_kc, int32_t b_kc, int32_t wt, int32_t M,
   GemmArgs g{};
   g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.bias = bias; g.relu = relu;
   g.mask = mask; g.ldmask = ldmask; g.part = part; g.k_chunk = k_chunk; g.colsum = colsum;
-  const int defer = part != nullptr;
-  if (a_kc && b_kc) launch_gemm<true, true>(g, s, defer, wt);
-  else if (a_kc && !b_kc) launch_gemm<true, false>(g, s, defer, wt);
-  else if (!a_kc && !b_kc) launch_gemm<false, false>(g, s, defer, wt);
+  const int defer = part != nullptr, half = wt == 16;   // wt = 16: fp16 operands on the fp16 MFMA
+  if (half) wt = 1;
+  if (a_kc && b_kc) launch_gemm<true, true>(g, s, defer, wt, half);
+  else if (a_kc && !b_kc) launch_gemm<true, false>(g, s, defer, wt, half);
+  else if (!a_kc && !b_kc) launch_gemm<false, false>(g, s, defer, wt, half);
   else return lhw_fail(LHW_ERR_UNSUPPORTED, "lhw_debug_gemm: A [K][M] with B [N][K] is not used by the update");
   if (part) {   // the deferred path of the update: partials (and column sums) reduced by one launch, accumulating into C / colsum_out
     const int kc = ((std::max(1, k_chunk > 0 ? k_chunk : K) + BK - 1) / BK) * BK;
@@ -877,6 +906,12 @@ extern "C" int lhw_ppo_destroy(LhwPpo* p) {
 extern "C" int lhw_ppo_set_inference_dtype(LhwPpo* p, int fp16) {
   if (!p) return lhw_fail(LHW_ERR_ARG, "null ppo");
   p->infer_half = fp16 ? 1 : 0;
+  return LHW_OK;
+}
+
+extern "C" int lhw_ppo_set_update_dtype(LhwPpo* p, int fp16) {
+  if (!p) return lhw_fail(LHW_ERR_ARG, "null ppo");
+  p->update_half = fp16 ? 1 : 0;
   return LHW_OK;
 }
 
@@ -1036,13 +1071,13 @@ extern "C" int lhw_ppo_grad(LhwPpo* p, const float* theta, float* grad, const fl
   auto join = [&]() { if (sc != s) { (void)hipEventRecord(p->ev_join, sc); (void)hipStreamWaitEvent(s, p->ev_join, 0); } };
   // forward: rows [0,B) and, if mirroring, rows [R, R+B)
   fork();
-  mlp_forward(p->lc, th_c, p->xb, Dp, B, p->h1c, p->h2c, p->yc, sc);
+  mlp_forward(p->lc, th_c, p->xb, Dp, B, p->h1c, p->h2c, p->yc, sc, p->update_half);
   if (mir && B == R) {
-    mlp_forward(p->la, th_a, p->xb, Dp, 2 * B, p->h1a, p->h2a, p->ya, s);   // mirrored rows follow without a gap
+    mlp_forward(p->la, th_a, p->xb, Dp, 2 * B, p->h1a, p->h2a, p->ya, s, p->update_half);   // mirrored rows follow without a gap
   } else {
-    mlp_forward(p->la, th_a, p->xb, Dp, B, p->h1a, p->h2a, p->ya, s);
+    mlp_forward(p->la, th_a, p->xb, Dp, B, p->h1a, p->h2a, p->ya, s, p->update_half);
     if (mir)
-      mlp_forward(p->la, th_a, p->xb + (size_t)R * Dp, Dp, B, p->h1a + (size_t)R * p->H, p->h2a + (size_t)R * p->H, p->ya + (size_t)R * Op, s);
+      mlp_forward(p->la, th_a, p->xb + (size_t)R * Dp, Dp, B, p->h1a + (size_t)R * p->H, p->h2a + (size_t)R * p->H, p->ya + (size_t)R * Op, s, p->update_half);
   }
   join();
   const int nblk = (B + 255) / 256;
@@ -1060,15 +1095,15 @@ extern "C" int lhw_ppo_grad(LhwPpo* p, const float* theta, float* grad, const fl
   const BwdParts Pc = bwd_parts_carve(p->lc, R, 1, p->bwd_part + bwd_parts_floats(p->la, R, 2));
   BwdSlices za, zc;
   fork();
-  mlp_backward(p->lc, th_c, p->xb, Dp, B, p->h1c, p->h2c, p->dyc, p->dh2c, p->dh1c, Pc, zc, sc);
+  mlp_backward(p->lc, th_c, p->xb, Dp, B, p->h1c, p->h2c, p->dyc, p->dh2c, p->dh1c, Pc, zc, sc, p->update_half);
   if (mir && B == R) {
     // the mirrored rows follow the normal ones without a gap: one pass over 2B rows
-    mlp_backward(p->la, th_a, p->xb, Dp, 2 * B, p->h1a, p->h2a, p->dya, p->dh2a, p->dh1a, Pa, za, s);
+    mlp_backward(p->la, th_a, p->xb, Dp, 2 * B, p->h1a, p->h2a, p->dya, p->dh2a, p->dh1a, Pa, za, s, p->update_half);
   } else {
-    mlp_backward(p->la, th_a, p->xb, Dp, B, p->h1a, p->h2a, p->dya, p->dh2a, p->dh1a, Pa, za, s);
+    mlp_backward(p->la, th_a, p->xb, Dp, B, p->h1a, p->h2a, p->dya, p->dh2a, p->dh1a, Pa, za, s, p->update_half);
     if (mir)
       mlp_backward(p->la, th_a, p->xb + (size_t)R * Dp, Dp, B, p->h1a + (size_t)R * p->H, p->h2a + (size_t)R * p->H,
-                   p->dya + (size_t)R * Op, p->dh2a + (size_t)R * p->H, p->dh1a + (size_t)R * p->H, Pa, za, s);
+                   p->dya + (size_t)R * Op, p->dh2a + (size_t)R * p->H, p->dh1a + (size_t)R * p->H, Pa, za, s, p->update_half);
   }
   join();
   SegList S;

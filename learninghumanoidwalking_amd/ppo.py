@@ -290,6 +290,13 @@ class PPO:
             if self.recurrent:
                 raise NotImplementedError("--infer-fp16 is implemented for the feed-forward policies")
             self.kernels.set_inference_fp16(True)   # rollout inference on the fp16 MFMA; the update stays float32
+        if getattr(args, "fp16", False):
+            # BASELINE config 5: fp16 actor / critic -- inference AND every GEMM of the update with fp16 operands (float32
+            # accumulation, master weights, loss and Adam)
+            if self.recurrent:
+                raise NotImplementedError("--fp16 is implemented for the feed-forward policies")
+            self.kernels.set_inference_fp16(True)
+            self.kernels.set_update_fp16(True)
         if self.recurrent:
             pass
         elif continued:

@@ -44,6 +44,7 @@ def _setup(L):
     L.lhw_ppo_grad.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp]
     L.lhw_ppo_apply.argtypes = [vp, vp, vp, vp, vp, i64, f32, vp]
     L.lhw_ppo_set_inference_dtype.argtypes = [vp, ctypes.c_int]
+    L.lhw_ppo_set_update_dtype.argtypes = [vp, ctypes.c_int]
     L.lhw_ppo_forward_at.argtypes = [vp, vp, vp, i64, vp, vp, u64, u32, u32, ctypes.c_int, i64, vp, vp, vp, vp, vp]
     _SETUP = True
 
@@ -141,6 +142,12 @@ class PpoKernels:
         """Rollout inference (``forward``) with fp16 operands on the fp16 MFMA; the update stays float32."""
         _lib.check(self._L.lhw_ppo_set_inference_dtype(self._h, int(bool(on))))
         self.inference_fp16 = bool(on)
+
+    def set_update_fp16(self, on=True):
+        """Every GEMM of the update (``grad_minibatch``) with fp16 operands on the fp16 MFMA, float32 accumulation; master
+        weights, loss and Adam stay float32 (BASELINE config 5, together with ``set_inference_fp16``)."""
+        _lib.check(self._L.lhw_ppo_set_update_dtype(self._h, int(bool(on))))
+        self.update_fp16 = bool(on)
 
     def set_obs_norm(self, mean, std):
         self.obs_mean.copy_(torch.as_tensor(np.asarray(mean), dtype=torch.float32))

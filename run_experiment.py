@@ -46,6 +46,7 @@ def build_parser():
     p.add_argument("--recurrent", action="store_true")
     p.add_argument("--imitate", type=str, default=None)
     p.add_argument("--infer-fp16", action="store_true", help="rollout inference with fp16 operands (update stays float32)")
+    p.add_argument("--fp16", action="store_true", help="fp16 actor / critic: inference and all GEMMs of the update with fp16 operands, float32 accumulation / master weights / Adam")
     p.add_argument("--imitate-coeff", type=float, default=0.3)
     p.add_argument("--yaml", type=str, default=None)
     p.add_argument("--device", type=str, default="auto", choices=["auto", "cpu", "cuda"])

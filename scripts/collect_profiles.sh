@@ -13,7 +13,7 @@ python $B --env h1 --num-envs 8192 --steps 2 --warmup 1 2>/dev/null | tail -1 > 
 python $B --env cartpole --steps 3 --warmup 1 2>/dev/null | tail -1 > $OUT/bench_cartpole_1gpu.json
 python $B --env jvrc_step --steps 2 --warmup 1 2>/dev/null | tail -1 > $OUT/bench_jvrc_step_1gpu.json
 python $B --env h1_walk --num-envs 8192 --steps 2 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/bench_h1_walk_8192_1gpu.json
-python $B --env h1 --num-envs 8192 --infer-fp16 --steps 2 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/bench_h1_8192_fp16infer_1gpu.json
+python $B --env h1 --num-envs 8192 --fp16 --steps 2 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/bench_h1_8192_fp16_1gpu.json
 # per-kernel durations of the default bench command (the control-step kernel's average must agree with the bench line's HIP events)
 rm -rf /tmp/kt; timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -- python $B --no-cpu-baseline > $OUT/kt.log 2>&1
 cp /tmp/kt/*/*kernel_stats.csv $OUT/jvrc_walk_kernel_stats.csv

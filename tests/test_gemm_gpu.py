@@ -74,3 +74,44 @@ def test_weight_gradient_split_k_with_fused_bias_gradient(wt, M, N, K, kc):
     C2, b2 = C0.clone(), b0.clone()
     _gemm(False, False, wt, M, N, K, dY, X, C2, k_chunk=kc, part=part, colsum=cpart, colsum_out=b2)
     assert torch.equal(C, C2) and torch.equal(bsum, b2)
+
+
+@pytest.mark.parametrize("layout,M,N,K", [("fwd", 1000, 256, 40), ("fwd", 777, 12, 256), ("bwd", 2049, 256, 256), ("bwd", 3000, 256, 12),
+                                          ("dw", 256, 256, 5000), ("dw", 12, 256, 4097), ("dw", 256, 40, 3000)])
+def test_fp16_operand_mode_equals_half_rounded_operands(layout, M, N, K):
+    """wt = 16: both operands rounded to fp16 while staged, fp16 MFMA, float32 accumulate -- every layout of the update."""
+    import torch
+    g = torch.Generator(device="cuda").manual_seed(M + 3 * N + K)
+    h = lambda x: x.half().double()
+    if layout == "fwd":
+        A = torch.randn(M, (K + 3) // 4 * 4, device="cuda", generator=g)[:, :K]
+        A = torch.nn.functional.pad(A, (0, (-K) % 4)).contiguous()
+        W = torch.randn(N, A.shape[1], device="cuda", generator=g) / K ** 0.5
+        if K % 4:
+            A[:, K:] = 0
+        b = torch.randn(N, device="cuda", generator=g)
+        C = torch.zeros(M, (N + 3) // 4 * 4, device="cuda")
+        _gemm(True, True, 16, M, N, K, A, W, C, bias=b, relu=1)
+        ref = torch.relu(h(A[:, :K]) @ h(W[:, :K]).t() + b.double())
+        assert (C[:, :N].double() - ref).abs().max().item() < 1e-4
+    elif layout == "bwd":
+        dY = torch.randn(M, K, device="cuda", generator=g)
+        W = torch.randn(K, N, device="cuda", generator=g) / K ** 0.5
+        msk = torch.randn(M, N, device="cuda", generator=g)
+        C = torch.zeros(M, N, device="cuda")
+        _gemm(True, False, 16, M, N, K, dY, W, C, mask=msk)
+        ref = (h(dY) @ h(W)) * (msk > 0)
+        assert (C.double() - ref).abs().max().item() < 1e-4
+    else:
+        Mp = (M + 3) // 4 * 4
+        dY = torch.randn(K, Mp, device="cuda", generator=g)
+        X = torch.randn(K, N, device="cuda", generator=g)
+        kc = 512
+        nz = (K + kc - 1) // kc
+        part = torch.full((nz, M * N), float("nan"), device="cuda")
+        cpart = torch.full((nz, M), float("nan"), device="cuda")
+        C = torch.zeros(M, N, device="cuda"); bsum = torch.zeros(M, device="cuda")
+        _gemm(False, False, 16, M, N, K, dY, X, C, k_chunk=kc, part=part, colsum=cpart, colsum_out=bsum)
+        ref = h(dY[:, :M]).t() @ h(X)
+        assert (C.double() - ref).abs().max().item() < 2e-5 * K ** 0.5 * 4
+        assert (bsum.double() - h(dY[:, :M]).sum(0)).abs().max().item() < 2e-5 * K ** 0.5 * 4

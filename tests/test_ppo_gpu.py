@@ -305,3 +305,68 @@ def test_fp16_inference_matches_half_rounded_reference():
     k.set_inference_fp16(False)
     mu_again = k.forward(obs.cuda(), deterministic=True)[0].cpu()
     assert torch.equal(mu_again, mu32)
+
+
+def test_fp16_update_matches_half_rounded_reference():
+    """lhw_ppo_set_update_dtype (BASELINE config 5): every GEMM of the update rounds both operands to fp16 and accumulates in
+    float32 -- forward, activation gradients, weight gradients (bias gradients are sums of the rounded output gradients);
+    loss, master weights and Adam are float32.  Pinned to a torch computation with exactly that rounding (a custom autograd
+    linear layer under the oracle's update); the float32 path is a different, nearby result."""
+    from oracle import ppo_oracle as po
+    g = np.load(os.path.join(G, "ppo_h64_mirror.npz"))
+    h = lambda x: x.half().float()
+
+    class HalfLinear(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x, W, b):
+            ctx.save_for_backward(x, W)
+            return h(x) @ h(W).t() + b
+
+        @staticmethod
+        def backward(ctx, gy):
+            x, W = ctx.saved_tensors
+            gh = h(gy)
+            return gh @ h(W), gh.t() @ h(x), gh.sum(0)
+
+    def half_mlp(x, W1, b1, W2, b2, W3, b3):
+        x = torch.relu(HalfLinear.apply(x, W1, b1))
+        x = torch.relu(HalfLinear.apply(x, W2, b2))
+        return HalfLinear.apply(x, W3, b3)
+
+    def run(fp16):
+        k = _kernels(g, 64, True, False)
+        k.set_tensors({f"a_{n}": g[f"a0_{i}"] for i, n in enumerate(NAMES)})
+        k.set_tensors({f"c_{n}": g[f"c0_{i}"] for i, n in enumerate(NAMES)})
+        k.set_tensors({"stds": g["stds0"]})
+        k.set_update_fp16(fp16)
+        scal = _run_updates(k, g)
+        return scal, k.get_tensors()
+
+    s16, t16 = run(True)
+    s32, t32 = run(False)
+    orc = po.OraclePPO([g[f"a0_{i}"] for i in range(6)], [g[f"c0_{i}"] for i in range(6)], g["stds0"], g["obs_mean"], g["obs_std"],
+                       mirror_obs=po.mirror_tables(MIR_OBS, [29, 30]), mirror_act=po.mirror_tables(MIR_ACT))
+    saved = po.mlp
+    po.mlp = half_mlp
+    try:
+        ref = []
+        for u in range(len(g["scalars"])):
+            c = lambda n: torch.tensor(g[f"{n}_{u}"])
+            ref.append(orc.update(c("obs"), c("act"), c("ret"), c("adv"), c("old_logp")))
+    finally:
+        po.mlp = saved
+    ref = np.array(ref)
+    np.testing.assert_allclose(s16[:, 0], ref[:, 0], rtol=2e-3, atol=2e-5)   # actor loss
+    np.testing.assert_allclose(s16[:, 1], ref[:, 2], rtol=2e-3, atol=2e-5)   # critic loss
+    np.testing.assert_allclose(s16[:, 2], ref[:, 4], rtol=5e-3, atol=2e-6)   # mirror loss
+    worst16 = worst32 = 0.0
+    for i, n in enumerate(NAMES):
+        for net, params in (("a", orc.actor), ("c", orc.critic)):
+            want = params[i].detach().numpy()
+            worst16 = max(worst16, float(np.abs(t16[f"{net}_{n}"].numpy() - want).max()))
+            worst32 = max(worst32, float(np.abs(t32[f"{net}_{n}"].numpy() - want).max()))
+    # two Adam steps of lr 3e-4: a wrong gradient sign moves a weight by 1.2e-3.  Summation order inside a GEMM flips a few
+    # fp16 roundings of the next layer's inputs, hence looser than the float32 fixture test (3e-6), far tighter than a wrong term
+    assert worst16 < 6e-5, worst16
+    assert worst32 > 1e-7, "the float32 update should differ from the half-rounded reference"
+    print(f"fp16 update vs half-rounded torch reference: worst |dw| {worst16:.2e} (float32 update vs the same reference {worst32:.2e})")

@@ -81,3 +81,20 @@ def test_sphere_box_and_capsule_box_on_the_gpu(tmp_path):
     env = spec.make_batched(len(POSES), seed=3, device=0)
     env.reset()
     _run(spec, env, lambda a: env.step(torch.from_numpy(a).cuda()), env.get_state, env.set_state)
+
+
+@pytest.mark.gpu
+def test_create_refuses_pairs_without_a_narrow_phase():
+    """A model that reaches lhw_env_create without passing mjcf.build_pairs (pack_from_mjmodel) is checked there."""
+    from learninghumanoidwalking_amd import _lib
+    spec = JvrcWalkSpec()
+    m = spec.model()
+    g = int(m.pair_geom2[0])
+    old = int(m.arrays["geom_type"][g])
+    m.arrays["geom_type"][g] = 5          # mjGEOM_CYLINDER
+    try:
+        with pytest.raises(_lib.LhwError) as err:
+            spec.make_batched(2, seed=0, device=0)
+        assert "narrow phase" in str(err.value)
+    finally:
+        m.arrays["geom_type"][g] = old
