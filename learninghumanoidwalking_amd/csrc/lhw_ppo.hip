@@ -589,18 +589,26 @@ __global__ void gather_kernel(const int* __restrict__ idx, int B, int Rcap, int 
 }
 
 // rollout sampling: act = mu + std * N(0,1) (or mu), logp of the sampled action under (mu, std)
-__global__ void sample_kernel(const float* __restrict__ mu, int ldmu, int A, int N, const float* __restrict__ stdv,
-                              uint64_t seed, uint32_t env_base, uint32_t counter, int deterministic,
-                              float* __restrict__ act, float* __restrict__ logp) {
-  int n = blockIdx.x * blockDim.x + threadIdx.x;
-  if (n >= N) return;
-  float lp = 0.f;
-  for (int a = 0; a < A; a++) {
+// One (row, action component) per lane, 32 lanes per row (act_dim <= 32): the Box-Muller draw is ~400 instructions of float64
+// transcendentals per component, so a thread per row (12 draws in sequence, 8 blocks for a 2048-row group) left this kernel
+// latency-bound at 15 us on the rollout's critical path.  The log-density terms are summed by the row's first lane in
+// component order, as the in-kernel policy of the rollout kernel does (bit-identical log-probabilities).
+__global__ void __launch_bounds__(256) sample_kernel(const float* __restrict__ mu, int ldmu, int A, int N, const float* __restrict__ stdv,
+                                                     uint64_t seed, uint32_t env_base, uint32_t counter, int deterministic,
+                                                     float* __restrict__ act, float* __restrict__ logp) {
+  __shared__ float terms[8][32];
+  const int r = threadIdx.x >> 5, a = threadIdx.x & 31, n = blockIdx.x * 8 + r;
+  if (n < N && a < A) {
     float term;
     act[(size_t)n * A + a] = lhw_policy_sample(mu[(size_t)n * ldmu + a], stdv[a], seed, env_base + n, counter, a, deterministic, &term);
-    lp += term;
+    terms[r][a] = term;
   }
-  logp[n] = lp;
+  __syncthreads();
+  if (n < N && a == 0) {
+    float lp = 0.f;
+    for (int k = 0; k < A; k++) lp += terms[r][k];
+    logp[n] = lp;
+  }
 }
 
 // PPO losses and their gradients wrt network outputs (reference rl/algos/ppo.py:302-384, FF path, mask = 1).
@@ -964,7 +972,7 @@ static int ppo_forward_impl(LhwPpo* p, const float* theta, const float* obs, int
     if (mu) HIPCHK(hipMemcpy2DAsync(mu, sizeof(float) * p->A, ya, sizeof(float) * p->la.Op, sizeof(float) * p->A, N, hipMemcpyDeviceToDevice, s));
     if (act) {
       if (!logp) return lhw_fail(LHW_ERR_ARG, "logp required with act");
-      hipLaunchKernelGGL(sample_kernel, dim3((N + 255) / 256), dim3(256), 0, s, ya, p->la.Op, p->A, (int)N, theta + p->off_std,
+      hipLaunchKernelGGL(sample_kernel, dim3((N + 7) / 8), dim3(256), 0, s, ya, p->la.Op, p->A, (int)N, theta + p->off_std,
                          seed, env_id_base, counter, deterministic, act, logp);
     }
   }
@@ -1496,7 +1504,7 @@ extern "C" int lhw_rnn_forward(LhwRnn* p, const float* theta, const float* obs, 
     if (n == 0) {
       if (mu) HIPCHK(hipMemcpy2DAsync(mu, sizeof(float) * p->A, p->ry, sizeof(float) * L.Op, sizeof(float) * p->A, N, hipMemcpyDeviceToDevice, s));
       if (act)
-        hipLaunchKernelGGL(sample_kernel, dim3((N + 255) / 256), dim3(256), 0, s, p->ry, L.Op, p->A, (int)N, theta + p->off_std, seed, env_id_base,
+        hipLaunchKernelGGL(sample_kernel, dim3((N + 7) / 8), dim3(256), 0, s, p->ry, L.Op, p->A, (int)N, theta + p->off_std, seed, env_id_base,
                            counter, deterministic, act, logp);
     } else {
       HIPCHK(hipMemcpy2DAsync(value, sizeof(float), p->ry, sizeof(float) * L.Op, sizeof(float), N, hipMemcpyDeviceToDevice, s));

@@ -148,7 +148,7 @@ class Rollout:
         elif G <= 1:
             for t in range(T):
                 k.forward(self.obs[t], seed=self.seed, env_id_base=self.env_base, counter=self.counter,
-                          deterministic=deterministic, want_value=False, mu=self.mu, act=self.act[t], logp=self.logp[t])
+                          deterministic=deterministic, want_value=False, want_mu=False, act=self.act[t], logp=self.logp[t])
                 env.step(self.act[t], obs_out=self.obs[t + 1], term_obs_out=self.tob_all[t], rew_out=self.rew[t], done_out=self.done[t])
                 self.counter += 1
         else:
@@ -167,7 +167,7 @@ class Rollout:
                 for s, (a, b) in zip(self.streams, bounds):
                     with torch.cuda.stream(s):
                         k.forward(self.obs[t, a:b], seed=self.seed, env_id_base=self.env_base + a, counter=self.counter,
-                                  deterministic=deterministic, want_value=False, ws_row=a, mu=self.mu[a:b], act=self.act[t, a:b],
+                                  deterministic=deterministic, want_value=False, want_mu=False, ws_row=a, act=self.act[t, a:b],
                                   logp=self.logp[t, a:b])
                         env.step_range(a, b - a, self.act[t], self.obs[t + 1], self.tob_all[t], self.rew[t], self.done[t])
                 self.counter += 1

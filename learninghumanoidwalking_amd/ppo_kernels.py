@@ -155,18 +155,21 @@ class PpoKernels:
 
     # ---- kernels
     def forward(self, obs, *, seed=0, env_id_base=0, counter=0, deterministic=False, want_actor=True, want_value=True,
-                mu=None, act=None, logp=None, value=None, ws_row=0):
+                mu=None, act=None, logp=None, value=None, ws_row=0, want_mu=True):
         N = obs.shape[0]
         dev = self.device
         if want_actor:
-            mu = torch.empty(N, self.act_dim, dtype=torch.float32, device=dev) if mu is None else mu
+            if want_mu:      # (the rollout needs only the sampled action and its log-density: one strided copy less per step)
+                mu = torch.empty(N, self.act_dim, dtype=torch.float32, device=dev) if mu is None else mu
+            else:
+                mu = None
             act = torch.empty(N, self.act_dim, dtype=torch.float32, device=dev) if act is None else act
             logp = torch.empty(N, dtype=torch.float32, device=dev) if logp is None else logp
         if want_value:
             value = torch.empty(N, dtype=torch.float32, device=dev) if value is None else value
         _lib.check(self._L.lhw_ppo_forward_at(self._h, _p(self.theta), _p(obs), N, _p(self.obs_mean), _p(self.obs_std),
                                               int(seed) & (2**64 - 1), int(env_id_base), int(counter), int(deterministic), int(ws_row),
-                                              _p(mu) if want_actor else None, _p(act) if want_actor else None,
+                                              _p(mu) if (want_actor and mu is not None) else None, _p(act) if want_actor else None,
                                               _p(logp) if want_actor else None, _p(value) if want_value else None,
                                               self._stream()))
         return mu, act, logp, value
