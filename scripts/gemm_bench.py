@@ -17,7 +17,7 @@ x = torch.randn(B, Dp, device=dev); h = torch.randn(B, H, device=dev); h2 = torc
 W1 = torch.randn(H, Dp, device=dev); W2 = torch.randn(H, H, device=dev); W3 = torch.randn(Op, H, device=dev); b = torch.randn(H, device=dev)
 out = torch.zeros(B, H, device=dev); outy = torch.zeros(B, Op, device=dev)
 nz = (B + 511) // 512
-part = torch.zeros(nz * H * H, device=dev); cpart = torch.zeros(4 * nz * H, device=dev); dW = torch.zeros(H, H, device=dev); db = torch.zeros(H, device=dev)
+part = torch.zeros(nz * H * H, device=dev); part2 = torch.zeros(2 * nz * H * H, device=dev); cpart = torch.zeros(4 * nz * H, device=dev); dW = torch.zeros(H, H, device=dev); db = torch.zeros(H, device=dev)
 dW1 = torch.zeros(H, Dp, device=dev); dW3 = torch.zeros(Op, H, device=dev)
 cases = [
     ("L1  fwd  [B,40]x[256,40]^T", 2.0 * B * H * Dp, lambda wt: L.lhw_debug_gemm(1, 1, wt, B, H, Dp, p(x), Dp, p(W1), Dp, p(out), H, p(b), 1, None, 0, 0, None, None, None, None)),
@@ -26,6 +26,8 @@ cases = [
     ("dh2 bwd  [B,12]x[12,256] mask", 2.0 * B * H * Op, lambda wt: L.lhw_debug_gemm(1, 0, wt, B, H, Op, p(y), Op, p(W3), H, p(out), H, None, 0, p(h2), H, 0, None, None, None, None)),
     ("dh1 bwd  [B,256]x[256,256] mask", 2.0 * B * H * H, lambda wt: L.lhw_debug_gemm(1, 0, wt, B, H, H, p(h), H, p(W2), H, p(out), H, None, 0, p(h2), H, 0, None, None, None, None)),
     ("dW2      [B,256]^T x [B,256] +colsum", 2.0 * B * H * H, lambda wt: L.lhw_debug_gemm(0, 0, wt, H, H, B, p(h), H, p(h2), H, p(dW), H, None, 0, None, 0, 512, p(part), p(cpart), p(db), None)),
+    ("dW2 kc256  +colsum", 2.0 * B * H * H, lambda wt: L.lhw_debug_gemm(0, 0, wt, H, H, B, p(h), H, p(h2), H, p(dW), H, None, 0, None, 0, 256, p(part2), p(cpart), p(db), None)),
+    ("dW2 kc1024 +colsum", 2.0 * B * H * H, lambda wt: L.lhw_debug_gemm(0, 0, wt, H, H, B, p(h), H, p(h2), H, p(dW), H, None, 0, None, 0, 1024, p(part), p(cpart), p(db), None)),
     ("dW1      [B,256]^T x [B,40] +colsum", 2.0 * B * H * Dp, lambda wt: L.lhw_debug_gemm(0, 0, wt, H, Dp, B, p(h), H, p(x), Dp, p(dW1), Dp, None, 0, None, 0, KS, p(part), p(cpart), p(db), None)),
     ("dW3      [B,12]^T x [B,256] +colsum", 2.0 * B * H * Op, lambda wt: L.lhw_debug_gemm(0, 0, wt, Op, H, B, p(y), Op, p(h), H, p(dW3), H, None, 0, None, 0, KS, p(part), p(cpart), p(db), None)),
 ]
