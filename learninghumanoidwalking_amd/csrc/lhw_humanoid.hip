@@ -1832,8 +1832,14 @@ __device__ void write_obs_h1(const HModel& m, const HParams& p, L& S, int lane, 
     else if (e < 15) v = S.sq[e - 5];
     else if (e < 25) v = S.sv[e - 15];
     else v = S.frc[e - 25] * m.act_d[ADS * (e - 25) + AD_GEAR];
+    // observation noise (base_humanoid_env.py:307-338): scale > 0 uniform in [-scale, scale]; scale < 0 Gaussian with standard
+    // deviation -scale (Box-Muller on the slots e and 64 + e of the observation stream)
     const double sc = p.obs_noise[e];
     if (sc > 0) v += lhw_rng_uniform(p.seed, genv, LHW_STREAM_OBS, obs_count, e, -sc, sc);
+    else if (sc < 0) {
+      const double u1 = lhw_rng_u01(p.seed, genv, LHW_STREAM_OBS, obs_count, e), u2 = lhw_rng_u01(p.seed, genv, LHW_STREAM_OBS, obs_count, 64 + e);
+      v += -sc * (sqrt(-2.0 * log(1.0 - u1)) * cos(6.283185307179586 * u2));
+    }
     if (o) o[e] = (float)v;
     if (o2) o2[e] = (float)v;
   }

@@ -60,13 +60,16 @@ class H1Spec:
         self.init_noise_deg = float(c.get("init_noise") or 0.0)
         on = c.get("observation_noise") or {}
         self.obs_noise_enabled = bool(on.get("enabled", False))
-        if self.obs_noise_enabled and on.get("type", "uniform") != "uniform":
-            raise NotImplementedError("only uniform observation noise is implemented")
+        self.obs_noise_type = str(on.get("type", "uniform"))
+        if self.obs_noise_enabled and self.obs_noise_type not in ("uniform", "gaussian"):
+            raise ValueError("Observation noise type must be 'uniform' or 'gaussian'")     # base_humanoid_env.py:328
         sc, mult = on.get("scales", {}), float(on.get("multiplier", 1.0))
         # per-observation-entry noise half-widths (base_humanoid_env.py:307-338; groups h1_base.py:107-113)
         self.obs_noise_scale = np.concatenate([
             np.full(2, sc.get("root_orient", 0.0)), np.full(3, sc.get("root_ang_vel", 0.0)), np.full(10, sc.get("motor_pos", 0.0)),
             np.full(10, sc.get("motor_vel", 0.0)), np.full(10, sc.get("motor_tau", 0.0))]) * mult * float(self.obs_noise_enabled)
+        # the kernel reads the type from the sign: scale > 0 uniform in [-scale, scale], scale < 0 Gaussian with std -scale
+        self.obs_noise_param = -self.obs_noise_scale if self.obs_noise_type == "gaussian" else self.obs_noise_scale
         pc = c.get("perturbation") or {}
         self.perturb_interval = int(pc["interval"] / self.control_dt) if pc.get("enable") else 0   # base_humanoid_env.py:86-92
         self.perturb_bodies = list(pc.get("bodies", []))
@@ -117,7 +120,7 @@ class H1Spec:
     def task_params(self):
         """LHW_TP_* layout for LHW_TASK_H1_STAND."""
         return np.concatenate([[0.98, np.deg2rad(self.init_noise_deg), self.force_magnitude, self.torque_magnitude],
-                               self.obs_noise_scale])
+                               self.obs_noise_param])
 
     def task_iparams(self):
         m = self.model()

@@ -95,7 +95,12 @@ class OracleH1Env:
         r, p, _ = quat2euler_sxyz(q[3:7])
         state = np.concatenate([[r], [p], v[3:6], self._act_pos(), self._act_vel(), self._act_torque()])
         sc = self.spec.obs_noise_scale
-        if self.spec.obs_noise_enabled:
+        if self.spec.obs_noise_enabled and getattr(self.spec, "obs_noise_type", "uniform") == "gaussian":
+            # base_humanoid_env.py:326-327: randn(n) * scale; Box-Muller on slots k and 64 + k of the observation stream
+            u = lambda slot: rng.u01(self.seed, self.env_id, STREAM_OBS, self.obs_count, slot)
+            z = np.array([np.sqrt(-2.0 * np.log(1.0 - u(k))) * np.cos(6.283185307179586 * u(64 + k)) for k in range(35)])
+            state = state + sc * z
+        elif self.spec.obs_noise_enabled:
             noise = np.array([rng.uniform(self.seed, self.env_id, STREAM_OBS, self.obs_count, k, -sc[k], sc[k]) for k in range(35)])
             state = state + noise
         self.obs_count += 1
