@@ -474,7 +474,8 @@ class PPO:
         xn, xm = k.normalize(raw_obs)
         act = ro.act.reshape(n_samples, -1)
         logp = ro.logp.reshape(-1)
-        if getattr(k, "inference_fp16", False):
+        if getattr(k, "inference_fp16", False) and not getattr(k, "update_fp16", False):
+            # (with --fp16 the update evaluates the policy with the same fp16-operand GEMMs as the rollout: nothing to do)
             # The rollout's log-probs came out of the fp16-operand forward; the update evaluates the policy in float32, so
             # ratio != 1 on the very first minibatch from precision noise alone (amplified by 1 / std^2).  The reference
             # evaluates old_policy and policy in the same precision (ppo.py:305-309): recompute the old log-probs once per
