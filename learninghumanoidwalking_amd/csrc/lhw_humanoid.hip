@@ -180,6 +180,7 @@ struct HModel {
   double timestep, gravity[3], tolerance, meaninertia, totalmass;
   const double *body_d, *jnt_d, *dof_d, *geom_d, *act_d;
   const int *body_i, *jnt_i, *dof_i, *geom_i, *act_i, *pair_i, *mpair;
+  int has_primbox;     // some collision pair is sphere-box or capsule-box (collide_primbox)
   int track_body[3];  // bodies whose spatial velocity must survive the sub-step (the task reads them afterwards)
   double track_off[9];  // local offset of the tracked point on each of them (foot force sites for the stepping task)
 };
@@ -1161,42 +1162,20 @@ __device__ __forceinline__ double seg_box_slope(const double* c0, const double* 
   return g;
 }
 
+// Sphere-box and capsule-box pairs.  Kept out of collide_pair and called only under the model-wide flag m.has_primbox (a
+// scalar branch): models without such pairs -- the stand-ins -- must not pay for this code (inside collide_pair's dispatch
+// chain the compiler speculated parts of it for every pair: +8 % VALU instructions per sub-step).
 template <class L>
-__device__ void collide_pair(ConSink<L>& k, const HModel& m, const L& S, int g1, int g2, double margin) {
+__device__ void collide_primbox(ConSink<L>& k, const HModel& m, const L& S, int g1, int g2, double margin) {
   const double zero[3] = {0, 0, 0};
-  const int t1 = m.geom_i[GIS * (g1) + GI_TYPE], t2 = m.geom_i[GIS * (g2) + GI_TYPE];
+  const int t1 = m.geom_i[GIS * (g1) + GI_TYPE];
   double p1[3], p2[3], R1[9], R2[9], s1[3], s2[3];
   for (int a = 0; a < 3; a++) { p1[a] = S.U[U_GPOS + 3 * g1 + a]; p2[a] = S.U[U_GPOS + 3 * g2 + a]; s1[a] = m.geom_d[GDS * (g1) + GD_SIZE + a]; s2[a] = m.geom_d[GDS * (g2) + GD_SIZE + a]; }
   for (int a = 0; a < 9; a++) { R1[a] = S.U[U_GMAT + 9 * g1 + a]; R2[a] = S.U[U_GMAT + 9 * g2 + a]; }
-  if (t1 == G_PLANE && t2 == G_SPHERE) col_plane_sphere(k, p1, R1, p2, s2[0], margin, zero);
-  else if (t1 == G_PLANE && t2 == G_CAPSULE) {
-    double ax[3] = {R2[2], R2[5], R2[8]}, e[3];
-    for (int s = 1; s >= -1; s -= 2) {
-      for (int a = 0; a < 3; a++) e[a] = p2[a] + s * ax[a] * s2[1];
-      col_plane_sphere(k, p1, R1, e, s2[0], margin, ax);  // tangent aligned with the capsule axis
-    }
-  } else if (t1 == G_PLANE && t2 == G_BOX) {
-    double nn[3] = {R1[2], R1[5], R1[8]}, dif[3] = {p2[0] - p1[0], p2[1] - p1[1], p2[2] - p1[2]};
-    const double dist = dot3(dif, nn);
-    const int n0 = k.n;
-    for (int i = 0; i < 8 && k.n - n0 < 4; i++) {
-      double v[3] = {(i & 1 ? s2[0] : -s2[0]), (i & 2 ? s2[1] : -s2[1]), (i & 4 ? s2[2] : -s2[2])}, corner[3], pos[3];
-      mat_vec(corner, R2, v);
-      const double ld = dot3(nn, corner);
-      if (dist + ld > margin || ld > 0) continue;
-      for (int a = 0; a < 3; a++) pos[a] = corner[a] + p2[a] - nn[a] * (dist + ld) * 0.5;
-      k.emit(dist + ld, pos, nn, zero);
-    }
-  } else if (t1 == G_SPHERE && t2 == G_SPHERE) col_sphere_sphere(k, p1, s1[0], p2, s2[0], margin);
-  else if (t1 == G_SPHERE && t2 == G_CAPSULE) {
-    double ax[3] = {R2[2], R2[5], R2[8]}, vec[3] = {p1[0] - p2[0], p1[1] - p2[1], p1[2] - p2[2]};
-    const double x = fmin(s2[1], fmax(-s2[1], dot3(ax, vec)));
-    double q[3] = {p2[0] + ax[0] * x, p2[1] + ax[1] * x, p2[2] + ax[2] * x};
-    col_sphere_sphere(k, p1, s1[0], q, s2[0], margin);
-  } else if (t1 == G_SPHERE && t2 == G_BOX) {
+  if (t1 == G_SPHERE) {
     double dist, pos[3], nrm[3];
     if (sphere_box_raw(p1, s1[0], p2, R2, s2, margin, &dist, pos, nrm)) k.emit(dist, pos, nrm, zero);
-  } else if (t1 == G_CAPSULE && t2 == G_BOX) {
+  } else {
     // same construction as capsuleBox in the CPU checker, mjc_oracle.c (not MuJoCo's mjc_CapsuleBox case analysis): both ends if both touch; else the interval
     // [tlo, thi] of segment points nearest to the box (two bisections on the monotone slope), plus a touching end
     const double ax[3] = {R1[2], R1[5], R1[8]}, h = s1[1], d[3] = {p1[0] - p2[0], p1[1] - p2[1], p1[2] - p2[2]};
@@ -1240,6 +1219,41 @@ __device__ void collide_pair(ConSink<L>& k, const HModel& m, const L& S, int g1,
       if (k.n - n0 < 2 && gm && tlo > -h + TOL) k.emit(dm, pm, nm, zero);
       if (k.n - n0 < 2 && gp && thi < h - TOL) k.emit(dp, pp, np_, zero);
     }
+  }
+}
+
+template <class L>
+__device__ void collide_pair(ConSink<L>& k, const HModel& m, const L& S, int g1, int g2, double margin) {
+  const double zero[3] = {0, 0, 0};
+  const int t1 = m.geom_i[GIS * (g1) + GI_TYPE], t2 = m.geom_i[GIS * (g2) + GI_TYPE];
+  double p1[3], p2[3], R1[9], R2[9], s1[3], s2[3];
+  for (int a = 0; a < 3; a++) { p1[a] = S.U[U_GPOS + 3 * g1 + a]; p2[a] = S.U[U_GPOS + 3 * g2 + a]; s1[a] = m.geom_d[GDS * (g1) + GD_SIZE + a]; s2[a] = m.geom_d[GDS * (g2) + GD_SIZE + a]; }
+  for (int a = 0; a < 9; a++) { R1[a] = S.U[U_GMAT + 9 * g1 + a]; R2[a] = S.U[U_GMAT + 9 * g2 + a]; }
+  if (t1 == G_PLANE && t2 == G_SPHERE) col_plane_sphere(k, p1, R1, p2, s2[0], margin, zero);
+  else if (t1 == G_PLANE && t2 == G_CAPSULE) {
+    double ax[3] = {R2[2], R2[5], R2[8]}, e[3];
+    for (int s = 1; s >= -1; s -= 2) {
+      for (int a = 0; a < 3; a++) e[a] = p2[a] + s * ax[a] * s2[1];
+      col_plane_sphere(k, p1, R1, e, s2[0], margin, ax);  // tangent aligned with the capsule axis
+    }
+  } else if (t1 == G_PLANE && t2 == G_BOX) {
+    double nn[3] = {R1[2], R1[5], R1[8]}, dif[3] = {p2[0] - p1[0], p2[1] - p1[1], p2[2] - p1[2]};
+    const double dist = dot3(dif, nn);
+    const int n0 = k.n;
+    for (int i = 0; i < 8 && k.n - n0 < 4; i++) {
+      double v[3] = {(i & 1 ? s2[0] : -s2[0]), (i & 2 ? s2[1] : -s2[1]), (i & 4 ? s2[2] : -s2[2])}, corner[3], pos[3];
+      mat_vec(corner, R2, v);
+      const double ld = dot3(nn, corner);
+      if (dist + ld > margin || ld > 0) continue;
+      for (int a = 0; a < 3; a++) pos[a] = corner[a] + p2[a] - nn[a] * (dist + ld) * 0.5;
+      k.emit(dist + ld, pos, nn, zero);
+    }
+  } else if (t1 == G_SPHERE && t2 == G_SPHERE) col_sphere_sphere(k, p1, s1[0], p2, s2[0], margin);
+  else if (t1 == G_SPHERE && t2 == G_CAPSULE) {
+    double ax[3] = {R2[2], R2[5], R2[8]}, vec[3] = {p1[0] - p2[0], p1[1] - p2[1], p1[2] - p2[2]};
+    const double x = fmin(s2[1], fmax(-s2[1], dot3(ax, vec)));
+    double q[3] = {p2[0] + ax[0] * x, p2[1] + ax[1] * x, p2[2] + ax[2] * x};
+    col_sphere_sphere(k, p1, s1[0], q, s2[0], margin);
   } else if (t1 == G_CAPSULE && t2 == G_CAPSULE) {
     double a1[3] = {R1[2], R1[5], R1[8]}, a2[3] = {R2[2], R2[5], R2[8]}, dif[3] = {p1[0] - p2[0], p1[1] - p2[1], p1[2] - p2[2]};
     const double ma = dot3(a1, a1), mb = -dot3(a1, a2), mc = dot3(a2, a2), u = -dot3(a1, dif), v = dot3(a2, dif);
@@ -1320,7 +1334,13 @@ __device__ void fwd_collision(const HModel& m, const HParams& p, L& S, int lane,
   br.cnt = 0;
   bool boxpair = false;
   if constexpr (BOXBOX) boxpair = have && m.geom_i[GIS * g1 + GI_TYPE] == G_BOX && m.geom_i[GIS * g2 + GI_TYPE] == G_BOX;
-  if (have && !boxpair) collide_pair(k, m, S, g1, g2, margin);
+  bool primbox = false;
+  if (m.has_primbox && have) {
+    const int ta = m.geom_i[GIS * g1 + GI_TYPE], tb = m.geom_i[GIS * g2 + GI_TYPE];
+    primbox = tb == G_BOX && (ta == G_SPHERE || ta == G_CAPSULE);
+  }
+  if (have && !boxpair && !primbox) collide_pair(k, m, S, g1, g2, margin);
+  if (m.has_primbox) { if (primbox) collide_primbox(k, m, S, g1, g2, margin); }
   if constexpr (BOXBOX) {
     if (gany<L::W_>(boxpair)) {
       if (boxpair) { col_box_box(br, m, S, g1, g2, margin); k.n = br.cnt; }
@@ -1329,7 +1349,8 @@ __device__ void fwd_collision(const HModel& m, const HParams& p, L& S, int lane,
   int total;
   const int base = gscan<L::W_>(k.n, &total) - k.n;
   k.base = base; k.n = 0; k.write = 1;
-  if (have && !boxpair && base < NC) collide_pair(k, m, S, g1, g2, margin);
+  if (have && !boxpair && !primbox && base < NC) collide_pair(k, m, S, g1, g2, margin);
+  if (m.has_primbox) { if (primbox && base < NC) collide_primbox(k, m, S, g1, g2, margin); }
   if constexpr (BOXBOX) {
     if (boxpair && base < NC) {
       const double zero[3] = {0, 0, 0};
@@ -2662,6 +2683,7 @@ int humanoid_create(HumanoidEnv** out, const std::vector<int32_t>& mi, const std
     if (cd != 1 && cd != 3) return lhw_fail(LHW_ERR_UNSUPPORTED, "condim %d", cd);
   }
   if (mi[LHW_IH_CONE] != 0) return lhw_fail(LHW_ERR_UNSUPPORTED, "only the pyramidal cone is implemented");
+  int primbox_pairs = 0;
   for (int q = 0; q < np; q++) {
     const int t1 = IF(LHW_IF_GEOM_TYPE)[IF(LHW_IF_PAIR_GEOM1)[q]], t2 = IF(LHW_IF_GEOM_TYPE)[IF(LHW_IF_PAIR_GEOM2)[q]];
     if (!stepping && t1 == G_BOX && t2 == G_BOX)
@@ -2671,6 +2693,7 @@ int humanoid_create(HumanoidEnv** out, const std::vector<int32_t>& mi, const std
     const bool ok = (t1 == G_PLANE && (t2 == G_SPHERE || t2 == G_CAPSULE || t2 == G_BOX)) ||
                     (t1 == G_SPHERE && (t2 == G_SPHERE || t2 == G_CAPSULE || t2 == G_BOX)) ||
                     (t1 == G_CAPSULE && (t2 == G_CAPSULE || t2 == G_BOX)) || (t1 == G_BOX && t2 == G_BOX);
+    if (t2 == G_BOX && (t1 == G_SPHERE || t1 == G_CAPSULE)) primbox_pairs++;
     if (!ok) return lhw_fail(LHW_ERR_UNSUPPORTED, "collision pair %d: no narrow phase for geom types %d / %d (plane, sphere, capsule, box only)", q, t1, t2);
   }
 
@@ -2803,6 +2826,7 @@ int humanoid_create(HumanoidEnv** out, const std::vector<int32_t>& mi, const std
     ai[AI_DOF] = jdof[j]; ai[AI_JNT] = j; ai[AI_CTRLLIMITED] = IF(LHW_IF_ACTUATOR_CTRLLIMITED)[u]; ai[AI_FORCELIMITED] = IF(LHW_IF_ACTUATOR_FORCELIMITED)[u];
   }
   m.nlevel = nlevel; m.nmpair = (int)mp.size() / 2;
+  m.has_primbox = primbox_pairs > 0;
   auto BID = [&](int f) { const int b = cfg->task_iparams[f]; return (b >= 0 && b < nbm) ? bmap[b] : -1; };
   m.track_body[0] = BID(LHW_TI_ROOT_BODY); m.track_body[1] = BID(LHW_TI_RFOOT_BODY); m.track_body[2] = BID(LHW_TI_LFOOT_BODY);
   ok = ok && (m.body_d = to_dev<double>(h, body_d.data(), body_d.size())) && (m.jnt_d = to_dev<double>(h, jnt_d.data(), jnt_d.size())) &&
