@@ -69,7 +69,7 @@ class OracleSim:
         m = model
         self._shapes = dict(
             qpos=(m.nq,), qvel=(m.nv,), ctrl=(m.nu,), xfrc_applied=(m.nbody, 6), qacc_warmstart=(m.nv,),
-            xpos=(m.nbody, 3), xquat=(m.nbody, 4), xmat=(m.nbody, 9), xipos=(m.nbody, 3), geom_xpos=(m.ngeom, 3),
+            xpos=(m.nbody, 3), xquat=(m.nbody, 4), xmat=(m.nbody, 9), xipos=(m.nbody, 3), ximat=(m.nbody, 9), geom_xpos=(m.ngeom, 3),
             geom_xmat=(m.ngeom, 9), site_xpos=(m.nsite, 3), site_xmat=(m.nsite, 9), subtree_com=(m.nbody, 3),
             cvel=(m.nbody, 6), M=(m.nv, m.nv), qfrc_bias=(m.nv,), qfrc_passive=(m.nv,), qfrc_actuator=(m.nv,),
             qfrc_smooth=(m.nv,), qacc_smooth=(m.nv,), qfrc_constraint=(m.nv,), qacc=(m.nv,),
