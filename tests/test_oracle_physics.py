@@ -104,3 +104,54 @@ def test_contact_force_decode_and_friction_pyramid():
     assert s.qvel[0] < v0                              # friction decelerates the slide
     # each pyramid edge force is non-negative (unilateral rows)
     assert (s.efc("efc_force") >= 0).all()
+
+
+def _impedance(r, solimp):
+    d0, dw, width, mid, power = solimp
+    x = min(1.0, abs(r) / width)
+    y = (x ** power) / (mid ** (power - 1)) if x <= mid else 1 - ((1 - x) ** power) / ((1 - mid) ** (power - 1))
+    return d0 + y * (dw - d0)
+
+
+def test_scalar_constraints_interpolate_between_unforced_and_reference_acceleration():
+    """MuJoCo's documented soft-constraint law for a single scalar constraint whose regulariser is built from the exact
+    inverse inertia: a1 = d * aref + (1 - d) * a0, with aref = -b v - k r, b = 2 / (dmax * timeconst),
+    k = d(r) / (dmax^2 * timeconst^2 * dampratio^2) and the impedance d = d(|r|) from solimp (Computation chapter, "Solver
+    parameters").  Checked on a frictionless sphere pressed into a plane (condim 1) and on a pendulum beyond its joint
+    limit: it pins reference acceleration, stiffness / damping, impedance curve and the R = (1 - d) / d * A scaling."""
+    solref, solimp = (0.02, 1.0), (0.9, 0.95, 0.001, 0.5, 2.0)
+    k0 = 1.0 / (solimp[1] ** 2 * solref[0] ** 2 * solref[1] ** 2)     # stiffness = d(r) * k0
+    b = 2.0 / (solimp[1] * solref[0])
+    xml = """<mujoco><option timestep="0.001"/><worldbody>
+      <geom name="floor" type="plane" size="0 0 1" condim="1"/>
+      <body pos="0 0 0.1"><freejoint/><geom type="sphere" size="0.1" mass="2" condim="1"/></body>
+    </worldbody></mujoco>"""
+    m = mjcf.compile_string(xml)
+    s = OracleSim(m)
+    for r, v in ((-0.0005, 0.0), (-0.0002, -0.3), (-0.0009, 0.2), (-0.003, 0.05)):
+        s.reset_data()
+        s.qpos[:] = [0, 0, 0.1 + r, 1, 0, 0, 0]
+        s.qvel[:] = [0, 0, v, 0, 0, 0]
+        s.forward(False)
+        assert s.ncon == 1 and s.nefc == 1
+        d = _impedance(r, solimp)
+        want = max(d * (-b * v - d * k0 * r) + (1 - d) * (-9.81), -9.81)     # unilateral: it can only push up
+        assert abs(s.qacc[2] - want) < 1e-9 * (1 + abs(want)), (r, v, s.qacc[2], want)
+    # hinge pendulum past its upper limit (range in radians), limit row: r = range_hi - q < 0
+    xml = """<mujoco><compiler angle="radian"/><option timestep="0.001" gravity="0 0 -9.81"/><worldbody>
+      <body><joint name="j" type="hinge" axis="0 1 0" limited="true" range="-0.5 0.5"/>
+        <geom type="capsule" fromto="0 0 0 0 0 -0.5" size="0.02" mass="1.5"/></body>
+    </worldbody></mujoco>"""
+    m = mjcf.compile_string(xml)
+    s = OracleSim(m)
+    for q, v in ((0.5004, 0.0), (0.5008, 0.4), (0.5002, -0.2)):
+        s.reset_data()
+        s.qpos[:] = [q]; s.qvel[:] = [v]
+        s.forward(False)
+        assert s.nefc == 1
+        a0 = float(s.qacc_smooth[0])
+        r = 0.5 - q                                                # distance to the limit (negative: violated)
+        d = _impedance(r, solimp)
+        # the limit row is J = -1 on the joint (it pushes q down): constraint-space quantities are a = -qacc, v_c = -v
+        want_c = max(d * (-b * (-v) - d * k0 * r) + (1 - d) * (-a0), -a0)
+        assert abs(-s.qacc[0] - want_c) < 1e-9 * (1 + abs(want_c)), (q, v, s.qacc[0], want_c)
