@@ -155,3 +155,32 @@ def test_scalar_constraints_interpolate_between_unforced_and_reference_accelerat
         # the limit row is J = -1 on the joint (it pushes q down): constraint-space quantities are a = -qacc, v_c = -v
         want_c = max(d * (-b * (-v) - d * k0 * r) + (1 - d) * (-a0), -a0)
         assert abs(-s.qacc[0] - want_c) < 1e-9 * (1 + abs(want_c)), (q, v, s.qacc[0], want_c)
+
+
+def test_frictionloss_row_quadratic_zone_and_saturation():
+    """Dry joint friction (MuJoCo: a constraint with reference acceleration -b v, Huber cost, force bounded by frictionloss):
+    inside the quadratic zone the documented scalar law a1 = d aref + (1 - d) a0 holds with d = solimp[0] (position 0);
+    beyond it the force saturates at exactly +-frictionloss opposing the motion."""
+    xml = """<mujoco><compiler angle="radian"/><option timestep="0.001"/><worldbody>
+      <body><joint name="j" type="hinge" axis="0 1 0" frictionloss="0.3" armature="0.02"/>
+        <geom type="capsule" fromto="0 0 0 0 0 -0.5" size="0.02" mass="1.5"/></body>
+    </worldbody></mujoco>"""
+    m = mjcf.compile_string(xml)
+    s = OracleSim(m)
+    solref, solimp = (0.02, 1.0), (0.9, 0.95, 0.001, 0.5, 2.0)
+    b, d = 2.0 / (solimp[1] * solref[0]), solimp[0]
+    for q, v in ((0.005, 1e-4), (-0.004, -2e-4), (0.01, 0.0)):     # slow and near the bottom: quadratic zone
+        s.reset_data()
+        s.qpos[:] = [q]; s.qvel[:] = [v]
+        s.forward(False)
+        assert s.nefc == 1
+        a0, M = float(s.qacc_smooth[0]), float(np.array(s.M)[0, 0])
+        want = d * (-b * v) + (1 - d) * a0
+        assert abs(M * (want - a0)) < 0.3, "test case meant to stay inside the friction bound"
+        assert abs(s.qacc[0] - want) < 1e-9 * (1 + abs(want)), (q, v, s.qacc[0], want)
+    for q, v in ((0.3, 2.0), (0.1, -3.0)):                           # fast: saturated, the force opposes the velocity
+        s.reset_data()
+        s.qpos[:] = [q]; s.qvel[:] = [v]
+        s.forward(False)
+        a0, M = float(s.qacc_smooth[0]), float(np.array(s.M)[0, 0])
+        assert abs(s.qacc[0] - (a0 - np.sign(v) * 0.3 / M)) < 1e-9 * (1 + abs(a0))
