@@ -257,3 +257,45 @@ def test_contact_parameter_mixing(case):
     d = _impedance(r, solimp)
     want = max(d * (-b * v - d * k0 * r) + (1 - d) * (-9.81), -9.81)
     assert abs(s.qacc[2] - want) < 1e-9 * (1 + abs(want)), (case, s.qacc[2], want)
+
+
+def test_euler_treats_joint_damping_implicitly():
+    """mj_Euler with damping (the default integrator's "implicit in velocity" treatment of joint damping): for a single hinge
+    without gravity, I v' = -c v is advanced by backward Euler, v1 = v0 / (1 + h c / I), however stiff h c / I is; with the
+    eulerdamp flag disabled it is the explicit v1 = v0 (1 - h c / I)."""
+    for flags, c in (("", 0.5), ("", 50.0), ('<flag eulerdamp="disable"/>', 0.5)):
+        xml = f"""<mujoco><compiler angle="radian"/><option timestep="0.002" gravity="0 0 0">{flags}</option><worldbody>
+          <body><joint name="j" type="hinge" axis="0 1 0" damping="{c}" armature="0.01"/>
+            <geom type="capsule" fromto="0 0 0 0 0 -0.5" size="0.02" mass="1.5"/></body>
+        </worldbody></mujoco>"""
+        m = mjcf.compile_string(xml)
+        s = OracleSim(m)
+        s.qvel[:] = [1.7]
+        s.forward(False)
+        I = float(np.array(s.M)[0, 0])
+        s.step()
+        want = 1.7 / (1 + 0.002 * c / I) if not flags else 1.7 * (1 - 0.002 * c / I)
+        assert abs(s.qvel[0] - want) < 1e-12, (flags, c, s.qvel[0], want)
+
+
+def test_free_joint_velocity_conventions():
+    """Documented free-joint convention: qvel = (linear velocity in the WORLD frame, angular velocity in the BODY frame);
+    positions integrate as x += h v and q <- q * exp(h w / 2) (right multiplication)."""
+    xml = """<mujoco><option timestep="0.01" gravity="0 0 0"/><worldbody>
+      <body pos="0 0 1"><freejoint/><geom type="sphere" size="0.1" mass="1"/></body></worldbody></mujoco>"""
+    m = mjcf.compile_string(xml)
+    s = OracleSim(m)
+    q0 = np.array([0.3, -0.5, 0.2, 0.77])
+    q0 /= np.linalg.norm(q0)
+    v, w = np.array([0.4, -0.2, 0.1]), np.array([0.9, -1.3, 0.6])
+    s.qpos[:] = [0.1, 0.2, 1.0, *q0]
+    s.qvel[:] = [*v, *w]
+    s.step()
+    np.testing.assert_allclose(s.qpos[:3], np.array([0.1, 0.2, 1.0]) + 0.01 * v, atol=1e-15)
+    R0, R1 = mjcf.quat2mat(q0), mjcf.quat2mat(np.array(s.qpos[3:7]))
+    ang = np.linalg.norm(w) * 0.01
+    k = w / np.linalg.norm(w)
+    K = np.array([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
+    E = np.eye(3) + np.sin(ang) * K + (1 - np.cos(ang)) * K @ K
+    np.testing.assert_allclose(R1, R0 @ E, atol=1e-14)                # body-frame angular velocity
+    assert np.abs(R1 - E @ R0).max() > 1e-4                           # (and not the world-frame reading)
