@@ -237,3 +237,32 @@ def test_emulated_frictionless_contacts(tmp_path):
     assert all(o.sim.ncon >= 4 and o.sim.nefc == o.sim.ncon for o in orc)      # one row per contact
     tape = (np.random.default_rng(2).normal(size=(4, n, 12)) * 0.2).astype(np.float32)
     _run_tape(env, orc, tape)
+
+
+def test_emulated_contact_parameter_conventions(tmp_path):
+    """The kernel's row parameters under the conventions the stand-in models never exercise: negative solref (direct stiffness /
+    damping), a solimp power other than 2 (the general pow() branch), geom margins, solmix-weighted mixing on one foot and
+    priority-based selection on the other -- the oracle's handling of each is pinned to MuJoCo's documented formulas in
+    tests/test_oracle_physics.py."""
+    from learninghumanoidwalking_amd.envs.jvrc_walk import JVRC_STANDIN_XML, JvrcWalkSpec
+    from oracle.env_jvrc_walk import OracleJvrcWalkEnv
+    xml = open(JVRC_STANDIN_XML).read()
+    floor = '<geom name="floor" type="plane" size="0 0 0.25" contype="1" conaffinity="0"/>'
+    rfoot = '<geom name="R_ANKLE_P_S-foot" type="box" size="0.1 0.05 0.01" pos="0.029 0 -0.09778" contype="0" conaffinity="1"/>'
+    lfoot = '<geom name="L_ANKLE_P_S-foot" type="box" size="0.1 0.05 0.01" pos="0.029 0 -0.09778" contype="0" conaffinity="1"/>'
+    assert floor in xml and rfoot in xml and lfoot in xml
+    xml = xml.replace(floor, floor[:-2] + ' solref="-9000 -350" solimp="0.8 0.97 0.002 0.3 3" margin="0.002" solmix="3"/>')
+    xml = xml.replace(rfoot, rfoot[:-2] + ' solref="0.015 1.1" solimp="0.85 0.96 0.0015 0.4 2.5" solmix="1"/>')
+    xml = xml.replace(lfoot, lfoot[:-2] + ' solref="0.03 0.9" solimp="0.9 0.99 0.001 0.5 1" priority="2"/>')
+    path = tmp_path / "jvrc_params.xml"
+    path.write_text(xml)
+    spec = JvrcWalkSpec(xml_path=str(path))
+    n = 2
+    env = emu.make_emulated(spec, n, seed=8)
+    orc = [OracleJvrcWalkEnv(spec, seed=8, env_id=i) for i in range(n)]
+    obs = env.reset().copy()
+    ref = np.array([o.reset() for o in orc])
+    np.testing.assert_allclose(obs, ref, rtol=1e-6, atol=2e-6)
+    assert all(o.sim.ncon >= 4 for o in orc)
+    tape = (np.random.default_rng(3).normal(size=(4, n, 12)) * 0.2).astype(np.float32)
+    _run_tape(env, orc, tape)
