@@ -111,3 +111,14 @@ def test_h1_standin_structure():
     assert len(spec.rand_bodies()) == 11 and len(spec.rand_dofs()) == 10
     np.testing.assert_allclose(spec.obs_noise_scale, [0.05] * 5 + [0.02] * 10 + [0.05] * 10 + [5.0] * 10)
     assert len(spec.task_iparams()) == 30 and len(spec.task_params()) == 39
+
+
+def test_invweight0_closed_forms():
+    """mj_setConst: for a free rigid body body_invweight0 = (1 / m, 1 / I) and the six dof_invweight0 repeat them; a body
+    welded to the world has zero inverse weight."""
+    m = mjcf.compile_string("<mujoco><worldbody><body pos='0 0 1'><freejoint/><geom type='sphere' size='0.1' mass='2'/></body>"
+                            "<body pos='1 0 0'><geom type='box' size='.1 .1 .1'/></body></worldbody></mujoco>")
+    I = 0.4 * 2 * 0.1 ** 2
+    np.testing.assert_allclose(m.body_invweight0[1], [0.5, 1 / I], rtol=1e-12)
+    np.testing.assert_allclose(m.dof_invweight0, [0.5] * 3 + [1 / I] * 3, rtol=1e-12)
+    np.testing.assert_allclose(m.body_invweight0[2], [0, 0], atol=0)
