@@ -266,3 +266,25 @@ def test_emulated_contact_parameter_conventions(tmp_path):
     assert all(o.sim.ncon >= 4 for o in orc)
     tape = (np.random.default_rng(3).normal(size=(4, n, 12)) * 0.2).astype(np.float32)
     _run_tape(env, orc, tape)
+
+
+def test_emulated_disable_flags(tmp_path):
+    """<flag eulerdamp / refsafe / warmstart = "disable">: the three mjOption disable flags the kernel honours (explicit joint
+    damping in the integrator, no clamp of solref's time constant, cold-started Newton) -- never set by the shipped models."""
+    from learninghumanoidwalking_amd.envs.jvrc_walk import JVRC_STANDIN_XML, JvrcWalkSpec
+    from oracle.env_jvrc_walk import OracleJvrcWalkEnv
+    xml = open(JVRC_STANDIN_XML).read()
+    opt = '<option timestep="0.001"/>'
+    assert opt in xml
+    path = tmp_path / "jvrc_flags.xml"
+    path.write_text(xml.replace(opt, '<option timestep="0.001"><flag eulerdamp="disable" refsafe="disable" warmstart="disable"/></option>'))
+    spec = JvrcWalkSpec(xml_path=str(path))
+    assert spec.model().disableflags != 0
+    n = 2
+    env = emu.make_emulated(spec, n, seed=9)
+    orc = [OracleJvrcWalkEnv(spec, seed=9, env_id=i) for i in range(n)]
+    obs = env.reset().copy()
+    ref = np.array([o.reset() for o in orc])
+    np.testing.assert_allclose(obs, ref, rtol=1e-6, atol=2e-6)
+    tape = (np.random.default_rng(4).normal(size=(4, n, 12)) * 0.2).astype(np.float32)
+    _run_tape(env, orc, tape)
