@@ -1574,7 +1574,10 @@ __device__ __forceinline__ void substep(const HModel& m, const HParams& p, L& S,
       }
     }
   }
-  const bool anyrow = gany<W>(isrow || uon[0] || uon[1] || uon[2]);
+  // (most sub-steps of a walking robot have no joint at a limit and no dry friction: the per-dof unit rows are then skipped as
+  // a whole in every cost / derivative evaluation of the solver)
+  const bool anyunit = gany<W>(uon[0] || uon[1] || uon[2]);
+  const bool anyrow = gany<W>(isrow) || anyunit;
   PROF_MARK(4);
   // transmission + actuation (lane = actuator)
   if (lane < m.nu) {
@@ -1619,9 +1622,11 @@ __device__ __forceinline__ void substep(const HModel& m, const HParams& p, L& S,
       double c, f, da;
       row_eval(isrow, 0.0, D, ja - aref, &c, force, dactive);
       double cs = c, uf = 0, ud = 0;
-      row_eval(uon[0], ufl, uD[0], a - uaref[0], &c, &f, &da); cs += c; uf += f; ud += da;
-      row_eval(uon[1], 0.0, uD[1], a - uaref[1], &c, &f, &da); cs += c; uf += f; ud += da;
-      row_eval(uon[2], 0.0, uD[2], -a - uaref[2], &c, &f, &da); cs += c; uf -= f; ud += da;
+      if (anyunit) {
+        row_eval(uon[0], ufl, uD[0], a - uaref[0], &c, &f, &da); cs += c; uf += f; ud += da;
+        row_eval(uon[1], 0.0, uD[1], a - uaref[1], &c, &f, &da); cs += c; uf += f; ud += da;
+        row_eval(uon[2], 0.0, uD[2], -a - uaref[2], &c, &f, &da); cs += c; uf -= f; ud += da;
+      }
       *cost = cs; *ufrc = uf; *udact = ud;
     };
     const double scale = 1.0 / (m.meaninertia * (NV > 1 ? NV : 1));
@@ -1699,9 +1704,11 @@ __device__ __forceinline__ void substep(const HModel& m, const HParams& p, L& S,
       auto deriv_rows = [&](double a, double* d1, double* d2) {
         double r1, r2, s1, s2;
         row_deriv(isrow, 0.0, D, x0 + a * jv, jv, &r1, &r2);
-        row_deriv(uon[0], ufl, uD[0], xu0 + a * search, search, &s1, &s2); r1 += s1; r2 += s2;
-        row_deriv(uon[1], 0.0, uD[1], xu1 + a * search, search, &s1, &s2); r1 += s1; r2 += s2;
-        row_deriv(uon[2], 0.0, uD[2], xu2 - a * search, -search, &s1, &s2); r1 += s1; r2 += s2;
+        if (anyunit) {
+          row_deriv(uon[0], ufl, uD[0], xu0 + a * search, search, &s1, &s2); r1 += s1; r2 += s2;
+          row_deriv(uon[1], 0.0, uD[1], xu1 + a * search, search, &s1, &s2); r1 += s1; r2 += s2;
+          row_deriv(uon[2], 0.0, uD[2], xu2 - a * search, -search, &s1, &s2); r1 += s1; r2 += s2;
+        }
         *d1 = r1; *d2 = r2;
       };
       double alpha = 0;
