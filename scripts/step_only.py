@@ -7,7 +7,12 @@ N = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 spec = JvrcWalkSpec()
 if len(sys.argv) > 3:      # sub-steps per control step (default 25): the difference of two runs isolates the per-sub-step counters
-    spec.frame_skip = int(sys.argv[3])
+    FS = int(sys.argv[3])
+
+    class _Spec(JvrcWalkSpec):
+        frame_skip = property(lambda self: FS)
+
+    spec = _Spec()
 env = spec.make_batched(N, seed=1, device=0, max_traj_len=400)
 env.reset()
 act = torch.randn(N, 12, device="cuda") * 0.1
