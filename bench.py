@@ -29,20 +29,19 @@ def static_pmc_traffic(kernel_substr, stem="step"):
     correction of MI355X_MICROARCH.md (FETCH_SIZE under-reports coalesced reads by 2x; WRITE_SIZE uncalibrated).  Static: it
     is NOT measured by this run (the counters need their own rocprofv3 passes, scripts/collect_profiles.sh)."""
     import csv
-    vals = {}
-    for name in ("fetch_size", "write_size"):
-        path = os.path.join(ROOT, "profiles", f"r02_jvrc_walk_{stem}_pmc_{name}.csv")
-        if not os.path.exists(path):
-            return None
-        for row in csv.DictReader(open(path)):
-            if kernel_substr in row["kernel"]:
-                vals[name] = float(row["mean"]) * 1024.0
-    if len(vals) != 2:
-        return None
-    return dict(bytes_per_launch=2.0 * vals["fetch_size"] + vals["write_size"], envs_per_launch=4096,
-                control_steps_per_launch=400 if stem == "rollout" else 1,
-                source=f"profiles/r02_jvrc_walk_{stem}_pmc_{{fetch,write}}_size.csv: 2*FETCH_SIZE + WRITE_SIZE, whole-batch launches"
-                       + (" of 400 control steps" if stem == "rollout" else ""))
+    for rnd in ("r03", "r02"):          # newest committed round first
+        vals = {}
+        for name in ("fetch_size", "write_size"):
+            path = os.path.join(ROOT, "profiles", f"{rnd}_jvrc_walk_{stem}_pmc_{name}.csv")
+            if not os.path.exists(path):
+                break
+            for row in csv.DictReader(open(path)):
+                if kernel_substr in row["kernel"]:
+                    vals[name] = float(row["mean"]) * 1024.0
+        if len(vals) == 2:
+            return dict(bytes_per_launch=2.0 * vals["fetch_size"] + vals["write_size"], envs_per_launch=4096, control_steps_per_launch=1,
+                        source=f"profiles/{rnd}_jvrc_walk_{stem}_pmc_{{fetch,write}}_size.csv: 2*FETCH_SIZE + WRITE_SIZE, whole-batch launches")
+    return None
 
 
 def cpu_baseline_worker(a):
@@ -181,22 +180,6 @@ def main():
             return r
 
         env.step_range = timed_range
-    if getattr(algo.rollout, "persistent", False):
-        orig_rollout = env.rollout
-
-        def timed_rollout(T, *a, **k):
-            if not timing["on"]:
-                return orig_rollout(T, *a, **k)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()                      # the rollout kernel is launched on the current stream
-            r = orig_rollout(T, *a, **k)
-            e1.record()
-            step_events.append((e0, e1))
-            launch_envs["n"] = args.num_envs
-            launch_envs["steps"] = int(T)
-            return r
-
-        env.rollout = timed_rollout
     for i in range(args.warmup):
         algo.iterate(i)
     barrier()
@@ -247,35 +230,32 @@ def main():
         bytes_per_env_step = spec.algorithmic_bytes_per_env_step()
         flops_per_env_step = spec.algorithmic_flops_per_env_step()
         NL = launch_envs["n"]                      # envs per launch (N / rollout groups)
-        TL = launch_envs.get("steps", 1)           # control steps per launch (T for the persistent rollout kernel, else 1)
-        persistent = TL > 1
         groups = max(1, N // NL)
-        achieved_gbs = bytes_per_env_step * NL * TL / (avg_step_ms * 1e-3) / 1e9
-        achieved_tf = flops_per_env_step * NL * TL / (avg_step_ms * 1e-3) / 1e12
+        achieved_gbs = bytes_per_env_step * NL / (avg_step_ms * 1e-3) / 1e9
+        overlapped_tf = flops_per_env_step * NL / (avg_step_ms * 1e-3) / 1e12
         wall_step_ms = sample_t / K / T * 1e3     # wall time per control step of all N envs, policy inference included
-        static = None
-        if env_name == "jvrc_walk":
-            static = static_pmc_traffic("humanoid_rollout_kernel", "rollout") if persistent else static_pmc_traffic(spec.step_kernel_name)
+        static = static_pmc_traffic(spec.step_kernel_name) if env_name == "jvrc_walk" else None
         # The fused control-step kernel touches each env's state once per control step (3 KB): by design it is not HBM-bound
         #  but bound by fp64 vector issue + on-chip latency, so the primary roofline is the fp64 VALU one.
+        # `achieved` / `frac` are those of an ISOLATED whole-batch launch (what an isolated rocprofv3 dispatch shows); the
+        # rollout itself runs `concurrent_launches` half-batch launches side by side, whose per-launch spans are in `overlapped`.
+        iso_tf = None if isolated_ms is None else flops_per_env_step * N / (isolated_ms * 1e-3) / 1e12
         roofline = dict(
-            bound="valu_fp64", kernel=(spec.step_kernel_name.replace("humanoid_kernel<0, ", "humanoid_rollout_kernel<").replace(", 32>", ">") if persistent else spec.step_kernel_name), achieved=achieved_tf, peak=FP64_VALU_PEAK_TFLOPS, unit="TFLOP/s",
-            frac=achieved_tf / FP64_VALU_PEAK_TFLOPS, traffic=None,
+            bound="valu_fp64", kernel=spec.step_kernel_name, achieved=iso_tf if iso_tf is not None else overlapped_tf,
+            peak=FP64_VALU_PEAK_TFLOPS, unit="TFLOP/s",
+            frac=(iso_tf if iso_tf is not None else overlapped_tf) / FP64_VALU_PEAK_TFLOPS, traffic=None,
             traffic_note="HBM bytes are not measured by this run (PMC counters need separate rocprofv3 passes); see traffic_static",
             traffic_static=static,
-            algorithmic_flops_per_launch=flops_per_env_step * NL * TL, algorithmic_bytes_per_launch=bytes_per_env_step * NL * TL,
+            algorithmic_flops_per_launch=flops_per_env_step * N, algorithmic_bytes_per_launch=bytes_per_env_step * N,
             algorithmic_flops_per_env_step=flops_per_env_step, algorithmic_bytes_per_env_step=bytes_per_env_step,
-            avg_launch_ms=avg_step_ms, launches=len(step_ms), envs_per_launch=NL, control_steps_per_launch=TL, concurrent_launches=groups,
-            launch_note=("HIP events on the launch stream around lhw_env_rollout over the timed region: ONE launch per PPO iteration advances "
-                         "every env by T control steps (stepper + in-kernel float32 actor, whose FLOPs are not counted here); "
-                         "`isolated` is the launch-per-step kernel on the same batch, for comparison") if persistent else
-                        ("HIP events on the launch stream around lhw_env_step_range over the timed region: the two-envs-per-wave kernel "
-                        "plus the (normally empty) one-env-per-wave re-run launch behind it; with concurrent_launches > 1 the groups' "
-                        "kernels overlap, so a launch's span includes the share of the GPU it cedes to the other group"),
-            isolated=None if isolated_ms is None else dict(
-                launch_ms=isolated_ms, envs_per_launch=N, fp64_tflops=flops_per_env_step * N / (isolated_ms * 1e-3) / 1e12,
-                fp64_frac=flops_per_env_step * N / (isolated_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS,
-                note="median of 20 whole-batch launches issued one at a time after the timed region (no overlap)"),
+            avg_launch_ms=isolated_ms if isolated_ms is not None else avg_step_ms, envs_per_launch=N if isolated_ms is not None else NL,
+            launch_note="median of 20 whole-batch control-step launches issued one at a time after the timed region, HIP events on the "
+                        "launch stream (no overlap): the duration rocprofv3 --kernel-trace reports for an isolated dispatch",
+            overlapped=dict(avg_launch_ms=avg_step_ms, launches=len(step_ms), envs_per_launch=NL, concurrent_launches=groups,
+                            fp64_tflops=overlapped_tf, fp64_frac=overlapped_tf / FP64_VALU_PEAK_TFLOPS,
+                            note="HIP events on the launch stream around lhw_env_step_range over the timed region: the two-envs-per-wave "
+                                 "kernel plus the (normally empty) one-env-per-wave re-run launch behind it; with concurrent_launches > 1 "
+                                 "the groups' kernels overlap, so a launch's span includes the share of the GPU it cedes to the other group"),
             aggregate=dict(wall_ms_per_control_step=wall_step_ms,
                            fp64_tflops=flops_per_env_step * N / (wall_step_ms * 1e-3) / 1e12,
                            fp64_frac=flops_per_env_step * N / (wall_step_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS,

@@ -147,32 +147,6 @@ int lhw_env_debug_step_record(LhwEnv* env, double* seq, double* floor_z, int32_t
  * control step, the tail of one group's kernel overlaps the next group's (wave-per-env steppers only). */
 int lhw_env_step_range(LhwEnv* env, int32_t first, int32_t count, const float* act_dev, float* obs_dev, float* term_obs_dev,
                        float* rew_dev, uint8_t* done_dev, float* rew_terms_dev, void* stream);
-/* A whole rollout in one launch: T control steps of every env with the actor evaluated inside the kernel (what
- * RolloutWorker.sample does per worker, rl/workers/rollout_worker.py:97-199, minus the critic, which the caller evaluates in
- * large batches afterwards).  A wavefront keeps its two envs for all T steps, so no step waits for the slowest env of the batch.
- * All pointers are DEVICE pointers.  Time-major buffers: obs [T+1][N][D] (obs[0] = the observations the rollout starts from,
- * filled by the caller; obs[t+1] is written by step t), act [T][N][A], logp / rew [T][N], tob [T][N][D] terminal observations,
- * done [T][N] flags as in lhw_env_step.  Actor weights in float32: w1t [Dp][H] and w2t [H][H] are K-MAJOR copies (w1t[k][j] =
- * W1[j][k], rows k >= D zero), w3 [A][H] row-major, biases, stds [A], obs_mean / obs_std [D]; H must be 256 and Dp <= 48.
- * Actions are mu + std * N(0,1) from the counter-based generator keyed (seed, env_id_base + env, step counter counter0 + t)
- * -- bit-identical to lhw_ppo_forward + lhw_env_step called step by step.  Returns LHW_ERR_UNSUPPORTED for tasks without
- * two-envs-per-wave kernels (cartpole, jvrc_step): step those launch by launch. */
-typedef struct LhwRolloutArgs {
-  int32_t T, D, Dp, H, A, deterministic;
-  uint32_t counter0, env_id_base;
-  uint64_t seed;
-  const float *w1t, *b1, *w2t, *b2, *w3, *b3, *stds, *obs_mean, *obs_std;
-  float *obs, *act, *logp, *rew, *tob;
-  uint8_t* done;
-  float* rew_terms;
-} LhwRolloutArgs;
-/* 1 if lhw_env_rollout is available for this env (a humanoid task whose model fits the two-envs-per-wave kernels), else 0. */
-int lhw_env_supports_rollout(LhwEnv* env);
-/* 1 if a rollout launch keeps all envs of this batch resident on the GPU at once (occupancy x CUs x 2 envs per wave >= N): the
- * regime in which the one-launch rollout is at least as fast as launch-per-step.  Larger batches run, but as successive
- * generations of waves; stepping them launch by launch is faster (measured: h1 @ 8192 envs, 2.45 s vs 1.91 s per 400 steps). */
-int lhw_env_rollout_is_resident(LhwEnv* env);
-int lhw_env_rollout(LhwEnv* env, const LhwRolloutArgs* args, void* stream);
 /* Parity hooks; HOST pointers, synchronous.  qpos [N][nq], qvel [N][nv] float64. */
 int lhw_env_get_state(LhwEnv* env, double* qpos_host, double* qvel_host);
 int lhw_env_set_state(LhwEnv* env, const double* qpos_host, const double* qvel_host);

@@ -31,14 +31,6 @@ class LhwEnvConfig(ctypes.Structure):
     ]
 
 
-class LhwRolloutArgs(ctypes.Structure):
-    """include/lhw.h: LhwRolloutArgs (device pointers)"""
-    _fields_ = [("T", ctypes.c_int32), ("D", ctypes.c_int32), ("Dp", ctypes.c_int32), ("H", ctypes.c_int32), ("A", ctypes.c_int32),
-                ("deterministic", ctypes.c_int32), ("counter0", ctypes.c_uint32), ("env_id_base", ctypes.c_uint32), ("seed", ctypes.c_uint64)] + [
-        (n, ctypes.c_void_p) for n in ("w1t", "b1", "w2t", "b2", "w3", "b3", "stds", "obs_mean", "obs_std", "obs", "act", "logp", "rew", "tob",
-                                       "done", "rew_terms")]
-
-
 def sources():
     return sorted(glob.glob(os.path.join(_HERE, "csrc", "*.hip")))
 
@@ -87,9 +79,6 @@ def declare(L):
     sig("lhw_env_pop_rerun_count", [vp, ctypes.POINTER(i64)])
     sig("lhw_env_get_actuator_state", [vp, vp, vp, vp])
     sig("lhw_env_debug_wave_cycles", [vp, vp])
-    sig("lhw_env_rollout", [vp, ctypes.POINTER(LhwRolloutArgs), vp])
-    sig("lhw_env_supports_rollout", [vp])
-    sig("lhw_env_rollout_is_resident", [vp])
     sig("lhw_debug_gemm", [i32, i32, i32, i32, i32, i32, vp, i32, vp, i32, vp, i32, vp, i32, vp, i32, i32, vp, vp, vp, vp])
     sig("lhw_env_phase_cycles", [vp, ctypes.c_int, vp])
     sig("lhw_env_step_range", [vp, i32, i32, vp, vp, vp, vp, vp, vp, vp])

@@ -121,38 +121,6 @@ class BatchedEnv:
         _lib.check(self._L.lhw_env_step_range(self._h, int(first), int(count), _ptr(act), _ptr(obs), _ptr(term_obs), _ptr(rew),
                                               _ptr(done), _ptr(self.rew_terms), _stream_ptr(self.device)))
 
-    @property
-    def supports_rollout(self) -> bool:
-        """lhw_env_rollout (a whole rollout with the actor evaluated inside the stepper's launch) is available for this env."""
-        return bool(self._L.lhw_env_supports_rollout(self._h))
-
-    @property
-    def rollout_is_resident(self) -> bool:
-        """One rollout launch keeps every env of this batch on the GPU at once (the regime the one-launch rollout is meant for)."""
-        return bool(self._L.lhw_env_rollout_is_resident(self._h))
-
-    def rollout(self, T: int, policy: dict, obs: torch.Tensor, act: torch.Tensor, logp: torch.Tensor, rew: torch.Tensor,
-                term_obs: torch.Tensor, done: torch.Tensor, *, seed=0, env_id_base=0, counter0=0, deterministic=False):
-        """T control steps of every env as ONE launch on the current stream, the feed-forward actor evaluated in the kernel.
-        `policy`: contiguous float32 device tensors w1t [Dp][H] (k-major, rows D..Dp zero), b1 [H], w2t [H][H] (k-major), b2,
-        w3 [A][H], b3 [A], stds [A], obs_mean [D], obs_std [D].  obs [T+1][N][D] holds the current observation in obs[0];
-        act [T][N][A], logp / rew [T][N], term_obs [T][N][D], done [T][N] uint8 are filled time-major."""
-        N, D, A = self.n_envs, self.obs_dim, self.act_dim
-        a = _lib.LhwRolloutArgs()
-        a.T, a.D, a.Dp, a.H, a.A = int(T), D, int(policy["w1t"].shape[0]), int(policy["w1t"].shape[1]), A
-        a.deterministic, a.counter0, a.env_id_base, a.seed = int(deterministic), int(counter0) & 0xffffffff, int(env_id_base), int(seed) & (2**64 - 1)
-        for name in ("w1t", "b1", "w2t", "b2", "w3", "b3", "stds", "obs_mean", "obs_std"):
-            t = policy[name]
-            assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous(), name
-            setattr(a, name, _ptr(t))
-        for name, t, shape, dt in (("obs", obs, (T + 1, N, D), torch.float32), ("act", act, (T, N, A), torch.float32),
-                                   ("logp", logp, (T, N), torch.float32), ("rew", rew, (T, N), torch.float32),
-                                   ("tob", term_obs, (T, N, D), torch.float32), ("done", done, (T, N), torch.uint8)):
-            assert t.is_cuda and t.dtype == dt and t.is_contiguous() and tuple(t.shape) == shape, name
-            setattr(a, name, _ptr(t))
-        a.rew_terms = _ptr(self.rew_terms)
-        _lib.check(self._L.lhw_env_rollout(self._h, ctypes.byref(a), _stream_ptr(self.device)))
-
     def get_state(self):
         qpos = np.zeros((self.n_envs, self.nq))
         qvel = np.zeros((self.n_envs, self.nv))

@@ -217,33 +217,6 @@ extern "C" int lhw_env_step_range(LhwEnv* e, int32_t first, int32_t count, const
   return LHW_OK;
 }
 
-extern "C" int lhw_env_supports_rollout(LhwEnv* e) { return e && e->hum && humanoid_supports_rollout(e->hum) ? 1 : 0; }
-
-extern "C" int lhw_env_rollout_is_resident(LhwEnv* e) {
-  if (!e || !e->hum) return 0;
-  if (hipSetDevice(e->device) != hipSuccess) return 0;
-  return humanoid_rollout_resident(e->hum);
-}
-
-extern "C" int lhw_env_rollout(LhwEnv* e, const LhwRolloutArgs* a, void* stream) {
-  if (!e || !a) return lhw_fail(LHW_ERR_ARG, "null argument");
-  if (!e->hum) return lhw_fail(LHW_ERR_UNSUPPORTED, "lhw_env_rollout: humanoid tasks only");
-  if (a->T <= 0 || a->D != e->obs_dim || a->A != e->act_dim || a->H != 256 || a->Dp < a->D || a->Dp > 48 || 2 * a->A > 64)
-    return lhw_fail(LHW_ERR_ARG, "lhw_env_rollout: bad dimensions (T %d D %d/%d A %d/%d H %d Dp %d)", a->T, a->D, e->obs_dim, a->A, e->act_dim, a->H, a->Dp);
-  if (!a->w1t || !a->b1 || !a->w2t || !a->b2 || !a->w3 || !a->b3 || !a->stds || !a->obs_mean || !a->obs_std || !a->obs || !a->act || !a->logp ||
-      !a->rew || !a->tob || !a->done)
-    return lhw_fail(LHW_ERR_ARG, "lhw_env_rollout: null buffer");
-  HIPCHK(hipSetDevice(e->device));
-  RolloutArgs r{};
-  r.T = a->T; r.D = a->D; r.Dp = a->Dp; r.H = a->H; r.A = a->A; r.deterministic = a->deterministic;
-  r.counter0 = a->counter0; r.env_id_base = a->env_id_base; r.seed = a->seed;
-  r.w1t = a->w1t; r.b1 = a->b1; r.w2t = a->w2t; r.b2 = a->b2; r.w3 = a->w3; r.b3 = a->b3; r.stds = a->stds; r.obs_mean = a->obs_mean; r.obs_std = a->obs_std;
-  r.obs = a->obs; r.act = a->act; r.logp = a->logp; r.rew = a->rew; r.tob = a->tob; r.done = a->done; r.rew_terms = a->rew_terms;
-  if (humanoid_rollout(e->hum, r, (hipStream_t)stream)) return lhw_fail(LHW_ERR_UNSUPPORTED, "lhw_env_rollout: this env has no two-envs-per-wave kernels");
-  HIPCHK(hipGetLastError());
-  return LHW_OK;
-}
-
 extern "C" int lhw_env_get_state(LhwEnv* e, double* qpos_host, double* qvel_host) {
   if (!e || !qpos_host || !qvel_host) return lhw_fail(LHW_ERR_ARG, "null argument");
   HIPCHK(hipSetDevice(e->device));

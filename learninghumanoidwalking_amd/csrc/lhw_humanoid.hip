@@ -39,7 +39,6 @@
 #include <vector>
 
 #include "lhw_internal.h"
-#include "lhw_policy.h"
 #include "lhw_rng.h"
 
 #define NB 20   // bodies
@@ -313,12 +312,10 @@ struct LdsT {
   // episode / task context of the env (home of these values during the launch: nothing of it is held in registers across a sub-step)
   double cmode_ref[3], cep_ret;
   int ci[12];
-  // Float32 staging that is only live BETWEEN sub-steps, in the tail of the (then dead) stage region: the action of this
-  // control step when it comes from the in-kernel policy (read before the first sub-step) and the env's current observation
-  // (written after the last sub-step, copied out to the obs / terminal-obs buffers or consumed by the in-kernel policy).
-  static constexpr int OBSF_ = USIZE_ - 24, ACTF_ = OBSF_ - (NU + 1) / 2;
+  // Float32 staging that is only live BETWEEN sub-steps, in the tail of the (then dead) stage region: the env's current
+  // observation (written after the last sub-step, copied out to the obs / terminal-obs buffers).
+  static constexpr int OBSF_ = USIZE_ - 24;
   __device__ __forceinline__ float* obsf() { return reinterpret_cast<float*>(U + OBSF_); }
-  __device__ __forceinline__ float* actf() { return reinterpret_cast<float*>(U + ACTF_); }
   int ncon, overflow;
 };
 enum { CI_PHASE = 0, CI_MODE, CI_TRAJ, CI_STARTED, CI_STEPCNT, CI_RESETCNT, CI_OBSCNT, CI_T1, CI_T2, CI_REACHED, CI_FRAMES, CI_NSEQ };
@@ -1992,7 +1989,7 @@ __device__ __forceinline__ bool control_step(const HModel& m, const HParams& p, 
   // ---- BaseHumanoidEnv.step: smoothing, offsets (base_humanoid_env.py:209-215); RobotBase.step (robot_base.py:64-98)
   double target = 0, a_in = 0;   // (the raw action stays in a register: its LDS staging is overwritten by the first sub-step)
   if (MODE == 0 && lane < m.nu) {
-    a_in = (double)(act ? act[(size_t)env * m.nu + lane] : S.actf()[lane]);
+    a_in = (double)act[(size_t)env * m.nu + lane];
     target = p.action_smoothing * a_in + (1 - p.action_smoothing) * rec[R_PREVPRED + lane] + p.action_offset[lane];
   }
   for (;;) {
@@ -2235,7 +2232,7 @@ __device__ __forceinline__ bool control_step(const HModel& m, const HParams& p, 
         ep_ret += r_sum;
         const bool truncated = p.max_traj_len > 0 && traj_len >= p.max_traj_len;
         const int NT = WALKT ? 10 : 6;
-        // the observation is formed in LDS (the persistent rollout kernel feeds it to the policy from there) and copied out
+        // the observation is formed in LDS and copied out
         SYNC();
         if (TASK == TASK_WALK) write_obs(m, p, S, lane, phase, mode, mode_ref, S.obsf());
         else if (TASK == TASK_STEP) write_obs_step(m, p, S, lane, phase, goal, S.obsf());
@@ -2489,127 +2486,6 @@ __global__ void __launch_bounds__(64, 2) humanoid_kernel(HModel m, HParams p, HS
   if (MODE == 1 && mask && !mask[env]) return;
   if (MODE == 0 && p.only_flagged && !st.slow[env]) return;
   control_step<MODE, TASK, W>(m, p, st, SG[group_id<W>()], env, lane, act, obs, term_obs, rew, done_out, rew_terms, xq, xv);
-}
-
-// ------------------------------------------------------------------------------------------------ persistent rollout
-// A whole rollout -- T control steps of every env, policy inference included -- as ONE launch (lhw_env_rollout).  A wave
-// keeps its two envs for all T steps: actor forward for both (float32, the weights streamed from L2: 308 KB per step and
-// wave), action sampling, control step, next observation straight from LDS.  There is no kernel boundary and no batch-wide
-// barrier per control step any more, so a wave that needs more Newton iterations (or the re-run of an env with more than 8
-// contacts) in one step is not waited for by the other 2047: per-step launches last as long as their slowest wave -- 1.4x
-// the mean in the early-training regime -- whereas the sum over 400 steps differs little between waves.
-//
-// The actor is evaluated exactly like the GEMM path: x = (obs - mean) / std, each unit an fmaf chain over k in ascending order
-// (what v_mfma_f32_32x32x2_f32 computes), bias added afterwards, ReLU; the Gaussian head is the shared lhw_policy_sample.
-// Lane l owns hidden units 4l .. 4l+3 of BOTH envs, so a weight is fetched once (one 16-byte load per k from the k-major
-// copies w1t / w2t) and used twice; activations cross lanes through LDS (the sub-step's stage region, idle between steps).
-
-template <int TASK>
-__global__ void __launch_bounds__(64, 2) humanoid_rollout_kernel(HModel m, HParams p, HState st, RolloutArgs ra) {
-  using L32 = typename LayoutOf<TASK, 32>::type;
-  using L64 = typename LayoutOf<TASK, 64>::type;
-  union Shared { L32 g[2]; L64 one; };
-  __shared__ Shared sh;
-  const int tid = threadIdx.x, gid = tid >> 5, l32 = tid & 31;
-  const int N = p.n_envs;
-  const int e0 = 2 * (int)blockIdx.x + p.env_first;
-  const bool have = 2 * (int)blockIdx.x + gid < p.env_count;   // (the last wave of an odd batch holds one env)
-  const int env = have ? e0 + gid : e0;
-  const int D = ra.D, Dp = ra.Dp, H = ra.H, A = ra.A;
-  float* xs = reinterpret_cast<float*>(sh.g[0].U);   // [2][Dp] normalised observations
-  float* h1s = xs + 2 * Dp;                           // [2][H]
-  float* h2s = h1s + 2 * H;                           // [2][H]
-  float* lps = reinterpret_cast<float*>(sh.g[1].U);   // [2][A] log-density terms
-  // the observation the rollout starts from (reset observation or the last one of the previous batch)
-  for (int k = l32; k < D; k += 32) sh.g[gid].obsf()[k] = ra.obs[(size_t)env * D + k];
-  SYNC();
-  for (int t = 0; t < ra.T; t++) {
-    // ---------------------------------------------------------------- actor forward of both envs (whole wave)
-    for (int idx = tid; idx < 2 * Dp; idx += 64) {
-      const int e = idx / Dp, k = idx - e * Dp;
-      xs[idx] = k < D ? (sh.g[e].obsf()[k] - ra.obs_mean[k]) / ra.obs_std[k] : 0.f;
-    }
-    SYNC();
-    {
-      float a0[4] = {0.f, 0.f, 0.f, 0.f}, a1[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 8
-      for (int k = 0; k < Dp; k++) {
-        const float4 w = *reinterpret_cast<const float4*>(ra.w1t + (size_t)k * H + 4 * tid);
-        const float x0 = xs[k], x1 = xs[Dp + k];
-        a0[0] = fmaf(x0, w.x, a0[0]); a0[1] = fmaf(x0, w.y, a0[1]); a0[2] = fmaf(x0, w.z, a0[2]); a0[3] = fmaf(x0, w.w, a0[3]);
-        a1[0] = fmaf(x1, w.x, a1[0]); a1[1] = fmaf(x1, w.y, a1[1]); a1[2] = fmaf(x1, w.z, a1[2]); a1[3] = fmaf(x1, w.w, a1[3]);
-      }
-#pragma unroll
-      for (int q = 0; q < 4; q++) {
-        const float b = ra.b1[4 * tid + q];
-        h1s[4 * tid + q] = fmaxf(a0[q] + b, 0.f);
-        h1s[H + 4 * tid + q] = fmaxf(a1[q] + b, 0.f);
-      }
-    }
-    SYNC();
-    {
-      float a0[4] = {0.f, 0.f, 0.f, 0.f}, a1[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 8
-      for (int k = 0; k < H; k++) {
-        const float4 w = *reinterpret_cast<const float4*>(ra.w2t + (size_t)k * H + 4 * tid);
-        const float x0 = h1s[k], x1 = h1s[H + k];
-        a0[0] = fmaf(x0, w.x, a0[0]); a0[1] = fmaf(x0, w.y, a0[1]); a0[2] = fmaf(x0, w.z, a0[2]); a0[3] = fmaf(x0, w.w, a0[3]);
-        a1[0] = fmaf(x1, w.x, a1[0]); a1[1] = fmaf(x1, w.y, a1[1]); a1[2] = fmaf(x1, w.z, a1[2]); a1[3] = fmaf(x1, w.w, a1[3]);
-      }
-#pragma unroll
-      for (int q = 0; q < 4; q++) {
-        const float b = ra.b2[4 * tid + q];
-        h2s[4 * tid + q] = fmaxf(a0[q] + b, 0.f);
-        h2s[H + 4 * tid + q] = fmaxf(a1[q] + b, 0.f);
-      }
-    }
-    SYNC();
-    if (tid < 2 * A) {   // lane = (env of the wave, action component): mean, sample, log-density term
-      const int e = tid / A, a = tid - e * A;
-      float acc = 0.f;
-#pragma unroll 8
-      for (int k = 0; k < H; k++) acc = fmaf(h2s[e * H + k], ra.w3[(size_t)a * H + k], acc);
-      const float mu = acc + ra.b3[a];
-      float term;
-      const float x = lhw_policy_sample(mu, ra.stds[a], ra.seed, ra.env_id_base + (unsigned)(e0 + e), ra.counter0 + (unsigned)t, a,
-                                        ra.deterministic, &term);
-      sh.g[e].actf()[a] = x;
-      lps[e * A + a] = term;
-      if (e == 0 || 2 * (int)blockIdx.x + 1 < p.env_count) ra.act[((size_t)t * N + e0 + e) * A + a] = x;
-    }
-    SYNC();
-    if (tid < 2 && (tid == 0 || 2 * (int)blockIdx.x + 1 < p.env_count)) {
-      float lp = 0.f;
-      for (int a = 0; a < A; a++) lp += lps[tid * A + a];
-      ra.logp[(size_t)t * N + e0 + tid] = lp;
-    }
-    SYNC();
-    // ---------------------------------------------------------------- control step of both envs (two groups of 32 lanes)
-    float* obs_t1 = ra.obs + (size_t)(t + 1) * N * D;
-    float* tob_t = ra.tob + (size_t)t * N * D;
-    float* rew_t = ra.rew + (size_t)t * N;
-    unsigned char* done_t = ra.done + (size_t)t * N;
-    float* terms_t = (t == ra.T - 1) ? ra.rew_terms : nullptr;
-    bool handed = false;
-    if (have) handed = control_step<0, TASK, 32>(m, p, st, sh.g[gid], env, l32, nullptr, obs_t1, tob_t, rew_t, done_t, terms_t, nullptr, nullptr);
-    __syncthreads();   // the two groups ran divergently; the policy below is a whole-wave computation (one-wave workgroup: free)
-    const unsigned long long hb = __ballot(handed);
-    if (hb) {
-      // An env touched more than 8 contacts: the whole wave repeats its control step with the one-env-per-wave layout (the
-      // W = 32 step wrote nothing of it).  The LDS of both groups is overwritten; everything persistent is in the records.
-      __threadfence();   // this step's actions were written by other lanes of this wave
-      const float* act_t = ra.act + (size_t)t * N * A;
-      for (int e = 0; e < 2; e++) {
-        if (!((hb >> (32 * e)) & 1ull)) continue;
-        control_step<0, TASK, 64>(m, p, st, sh.one, e0 + e, tid, act_t, obs_t1, tob_t, rew_t, done_t, terms_t, nullptr, nullptr);
-        if (tid == 0) { st.slow[e0 + e] = 0; atomicAdd(&st.ep_stats[5], 1.0); }
-      }
-      __threadfence();
-      SYNC();
-      if (have) for (int k = l32; k < D; k += 32) sh.g[gid].obsf()[k] = obs_t1[(size_t)env * D + k];
-      SYNC();
-    }
-  }
 }
 
 // ------------------------------------------------------------------------------------------------ host side
@@ -2946,15 +2822,22 @@ void humanoid_destroy(HumanoidEnv* h) {
   delete h;
 }
 
+// (LHW_ONLY_WALK: development builds that compile the jvrc_walk kernels only -- a third of the compile time)
+#ifdef LHW_ONLY_WALK
+#define LAUNCH_OTHER_TASKS(MODE, WIDTH, ...)
+#else
+#define LAUNCH_OTHER_TASKS(MODE, WIDTH, ...)                                                                        \
+    else if (pp_.task == TASK_STEP) hipLaunchKernelGGL((humanoid_kernel<MODE, TASK_STEP, 64>), grid_, dim3(64), 0, s, h->m, pp_, h->st, __VA_ARGS__); \
+    else if (pp_.task == TASK_H1WALK) hipLaunchKernelGGL((humanoid_kernel<MODE, TASK_H1WALK, WIDTH>), grid_, dim3(64), 0, s, h->m, pp_, h->st, __VA_ARGS__); \
+    else hipLaunchKernelGGL((humanoid_kernel<MODE, TASK_STAND, WIDTH>), grid_, dim3(64), 0, s, h->m, pp_, h->st, __VA_ARGS__);
+#endif
 #define LAUNCH_RANGE(MODE, WIDTH, FLAGGED, FIRST, COUNT, ...)                                                       \
   do {                                                                                                             \
     HParams pp_ = h->p;                                                                                            \
     pp_.env_first = (FIRST); pp_.env_count = (COUNT); pp_.only_flagged = (FLAGGED);                                \
     const dim3 grid_((pp_.env_count + (64 / WIDTH) - 1) / (64 / WIDTH));                                           \
     if (pp_.task == TASK_WALK) hipLaunchKernelGGL((humanoid_kernel<MODE, TASK_WALK, WIDTH>), grid_, dim3(64), 0, s, h->m, pp_, h->st, __VA_ARGS__); \
-    else if (pp_.task == TASK_STEP) hipLaunchKernelGGL((humanoid_kernel<MODE, TASK_STEP, 64>), grid_, dim3(64), 0, s, h->m, pp_, h->st, __VA_ARGS__); \
-    else if (pp_.task == TASK_H1WALK) hipLaunchKernelGGL((humanoid_kernel<MODE, TASK_H1WALK, WIDTH>), grid_, dim3(64), 0, s, h->m, pp_, h->st, __VA_ARGS__); \
-    else hipLaunchKernelGGL((humanoid_kernel<MODE, TASK_STAND, WIDTH>), grid_, dim3(64), 0, s, h->m, pp_, h->st, __VA_ARGS__);                     \
+    LAUNCH_OTHER_TASKS(MODE, WIDTH, __VA_ARGS__)                                                                   \
   } while (0)
 #define LAUNCH(MODE, ...) LAUNCH_RANGE(MODE, 64, 0, 0, h->p.n_envs, __VA_ARGS__)
 // One control step of envs [first, first + count): two envs per wave where the model allows it, followed by the one-env-per-wave
@@ -2992,34 +2875,6 @@ void humanoid_get_state(HumanoidEnv* h, double* qpos, double* qvel, hipStream_t 
 void humanoid_set_state(HumanoidEnv* h, const double* qpos, const double* qvel, hipStream_t s) {
   LAUNCH(2, (const float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, (unsigned char*)nullptr, (float*)nullptr,
          (const unsigned char*)nullptr, const_cast<double*>(qpos), const_cast<double*>(qvel));
-}
-// whole-batch persistent rollout; 0 = launched, 1 = this env has no two-envs-per-wave kernels (caller steps it launch by launch)
-int humanoid_supports_rollout(HumanoidEnv* h) { return h->fast ? 1 : 0; }
-// 1 if one rollout launch keeps every env resident (a wave per two envs, all waves on the chip at once): only then does the
-// persistent kernel beat launch-per-step -- a second generation of waves would start after the first has run all T steps,
-// whereas per-step launches refill the slots every control step.
-int humanoid_rollout_resident(HumanoidEnv* h) {
-  if (!h->fast) return 0;
-  int nb = 0, dev = 0;
-  hipDeviceProp_t prop;
-  hipError_t e = hipSuccess;
-  if (h->p.task == TASK_WALK) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, humanoid_rollout_kernel<TASK_WALK>, 64, 0);
-  else if (h->p.task == TASK_H1WALK) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, humanoid_rollout_kernel<TASK_H1WALK>, 64, 0);
-  else if (h->p.task == TASK_STAND) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, humanoid_rollout_kernel<TASK_STAND>, 64, 0);
-  else return 0;
-  if (e != hipSuccess || hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
-  return (long long)(h->p.n_envs + 1) / 2 <= (long long)nb * prop.multiProcessorCount ? 1 : 0;
-}
-int humanoid_rollout(HumanoidEnv* h, const RolloutArgs& ra, hipStream_t s) {
-  if (!h->fast) return 1;
-  HParams pp = h->p;
-  pp.env_first = 0; pp.env_count = pp.n_envs; pp.only_flagged = 0;
-  const dim3 grid((pp.n_envs + 1) / 2);
-  if (pp.task == TASK_WALK) hipLaunchKernelGGL((humanoid_rollout_kernel<TASK_WALK>), grid, dim3(64), 0, s, h->m, pp, h->st, ra);
-  else if (pp.task == TASK_H1WALK) hipLaunchKernelGGL((humanoid_rollout_kernel<TASK_H1WALK>), grid, dim3(64), 0, s, h->m, pp, h->st, ra);
-  else if (pp.task == TASK_STAND) hipLaunchKernelGGL((humanoid_rollout_kernel<TASK_STAND>), grid, dim3(64), 0, s, h->m, pp, h->st, ra);
-  else return 1;
-  return 0;
 }
 double* humanoid_ep_stats(HumanoidEnv* h) { return h->st.ep_stats; }
 int humanoid_occupancy() {

@@ -113,15 +113,6 @@ class Rollout:
         want = int(os.environ.get("LHW_ROLLOUT_GROUPS", "2" if (N >= 2048 and hasattr(env, "step_range") and env.task != 0) else "1"))
         self.groups = max(1, min(want, N)) if env.task != 0 else 1
         self.streams = None
-        # One launch per rollout with the actor evaluated inside the stepper (lhw_env_rollout), for envs that offer it, the
-        # float32 feed-forward 256-256 actor and batches that are resident as a whole.  Opt-in (LHW_ROLLOUT_PERSISTENT=1; =2
-        # at any batch size): bit-identical to the launch-per-step rollout, but at present 7 % slower than the two-group
-        # launch-per-step pipeline below (1.19 s vs 1.12 s per 4096 x 400 rollout of jvrc_walk).
-        want = os.environ.get("LHW_ROLLOUT_PERSISTENT", "0")
-        self.persistent = (want != "0" and getattr(env, "supports_rollout", False)
-                           and (want == "2" or getattr(env, "rollout_is_resident", False))
-                           and not getattr(kernels, "recurrent", False) and not getattr(kernels, "inference_fp16", False)
-                           and getattr(kernels, "hidden", 0) == 256)
         self.counter = 0
         self.started = False
         self.env_base = getattr(env, "env_id_base", 0)
@@ -141,11 +132,7 @@ class Rollout:
         if self.tob_all is None:
             self.tob_all = torch.zeros(T, self.N, self.obs.shape[2], dtype=torch.float32, device=self.obs.device)
         G = self.groups
-        if self.persistent:
-            env.rollout(T, self._actor_for_rollout(), self.obs, self.act, self.logp, self.rew, self.tob_all, self.done,
-                        seed=self.seed, env_id_base=self.env_base, counter0=self.counter, deterministic=deterministic)
-            self.counter += T
-        elif G <= 1:
+        if G <= 1:
             for t in range(T):
                 k.forward(self.obs[t], seed=self.seed, env_id_base=self.env_base, counter=self.counter,
                           deterministic=deterministic, want_value=False, want_mu=False, act=self.act[t], logp=self.logp[t])
@@ -176,18 +163,6 @@ class Rollout:
         self._batched_values(self.obs[:T].reshape(T * self.N, -1), self.val.reshape(-1))
         self._batched_values(self.tob_all.reshape(T * self.N, -1), self.vterm.reshape(-1))
         k.forward(self.obs[T], want_actor=False, value=self.vfinal)
-
-    def _actor_for_rollout(self):
-        """The actor's tensors in the layout lhw_env_rollout streams them in: layers 1 and 2 k-major (one 16-byte load per k
-        and lane covers four hidden units), rows of w1t beyond the observation length zero."""
-        k = self.k
-        D, H, A = k.obs_dim, k.hidden, k.act_dim
-        v = lambda n: k._view(k.theta, n)
-        w1t = torch.zeros((D + 3) // 4 * 4, H, dtype=torch.float32, device=k.theta.device)
-        w1t[:D].copy_(v("a_w1").t())
-        return dict(w1t=w1t, b1=v("a_b1").contiguous(), w2t=v("a_w2").t().contiguous(), b2=v("a_b2").contiguous(),
-                    w3=v("a_w3").contiguous(), b3=v("a_b3").contiguous(), stds=v("stds").contiguous(),
-                    obs_mean=k.obs_mean, obs_std=k.obs_std)
 
     def _batched_values(self, obs_flat, out_flat):
         chunk = int(self.k.max_rows)

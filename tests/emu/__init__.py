@@ -140,29 +140,6 @@ class EmuBatchedEnv:
         self._check(self._L.lhw_env_pop_fault_stats(self._h, ctypes.byref(a), ctypes.byref(b)))
         return a.value, b.value
 
-    def rollout(self, T, weights, obs_mean, obs_std, obs0, seed=0, env_id_base=0, counter0=0, deterministic=False):
-        """lhw_env_rollout on numpy buffers.  weights: a_w1 [H][D], a_b1, a_w2, a_b2, a_w3 [A][H], a_b3, stds.  Returns a dict
-        of the time-major buffers."""
-        from learninghumanoidwalking_amd import _lib as product
-        N, D, A = self.n_envs, self.obs_dim, self.act_dim
-        H = weights["a_w1"].shape[0]
-        Dp = (D + 3) // 4 * 4
-        f = lambda x: np.ascontiguousarray(x, np.float32)
-        w1t = np.zeros((Dp, H), np.float32); w1t[:D] = weights["a_w1"].T
-        keep = dict(w1t=w1t, b1=f(weights["a_b1"]), w2t=f(weights["a_w2"].T), b2=f(weights["a_b2"]), w3=f(weights["a_w3"]), b3=f(weights["a_b3"]),
-                    stds=f(weights["stds"]), obs_mean=f(obs_mean), obs_std=f(obs_std),
-                    obs=np.zeros((T + 1, N, D), np.float32), act=np.zeros((T, N, A), np.float32), logp=np.zeros((T, N), np.float32),
-                    rew=np.zeros((T, N), np.float32), tob=np.zeros((T, N, D), np.float32), done=np.zeros((T, N), np.uint8),
-                    rew_terms=np.zeros((N, self.n_terms), np.float32))
-        keep["obs"][0] = obs0
-        a = product.LhwRolloutArgs()
-        a.T, a.D, a.Dp, a.H, a.A, a.deterministic = T, D, Dp, H, A, int(deterministic)
-        a.counter0, a.env_id_base, a.seed = counter0, env_id_base, seed
-        for k, v in keep.items():
-            setattr(a, k, v.ctypes.data)
-        self._check(self._L.lhw_env_rollout(self._h, ctypes.byref(a), None))
-        return keep
-
     def get_actuator_state(self):
         out = [np.zeros((self.n_envs, self.act_dim)) for _ in range(3)]
         self._check(self._L.lhw_env_get_actuator_state(self._h, out[0].ctypes.data, out[1].ctypes.data, out[2].ctypes.data))
