@@ -180,6 +180,8 @@ struct HModel {
   const double *body_d, *jnt_d, *dof_d, *geom_d, *act_d;
   const int *body_i, *jnt_i, *dof_i, *geom_i, *act_i, *pair_i, *mpair;
   int has_primbox;     // some collision pair is sphere-box or capsule-box (collide_primbox)
+  int chain2;          // free root + two serial chains of (nv - 6) / 2 dofs each: the chain solver applies
+  const int* chain_idx;  // [32][NR + 1]: for each lane of the chain layout, offsets into the packed M of its row (+ diagonal); TRI = zero
   int track_body[3];  // bodies whose spatial velocity must survive the sub-step (the task reads them afterwards)
   double track_off[9];  // local offset of the tracked point on each of them (foot force sites for the stepping task)
 };
@@ -288,7 +290,7 @@ struct LdsT {
   static constexpr int U_XMAT_ = X_, U_XIPOS_ = U_XMAT_ + NB_T * 9, U_XANCHOR_ = U_XIPOS_ + NB_T * 3, U_XAXIS_ = U_XANCHOR_ + NJ * 3,
                        U_GPOS_ = U_XAXIS_ + NJ * 3, U_GMAT_ = U_GPOS_ + NG_T * 3, END_A_ = U_GMAT_ + NG_T * 9;
   static constexpr int U_CDOFDOT_ = X_, U_CVEL_ = U_CDOFDOT_ + NV_T * 6, U_CACC_ = U_CVEL_ + NB_T * 6, END_B1_ = U_CACC_ + NB_T * 6;
-  static constexpr int U_CRB_ = X_, U_BUF_ = U_CRB_ + NB_T * 10, U_M_ = U_BUF_ + NV_T * 6, END_B2_ = U_M_ + TRI_;
+  static constexpr int U_CRB_ = X_, U_BUF_ = U_CRB_ + NB_T * 10, U_M_ = U_BUF_ + NV_T * 6, END_B2_ = U_M_ + TRI_ + 1;   // (M is followed by one zero: chain_idx)
   // contact records that only feed the Jacobian / row parameters: written by the collision stage, live across stage B,
   // dead once the rows are built (the solver's vectors and the Cholesky rows then reuse the space)
   static constexpr int U_J_ = U_CINERT_, U_L_ = U_J_ + W_T * NV_T;
@@ -361,6 +363,13 @@ __host__ __device__ __forceinline__ int opaque_zero() {
     __builtin_amdgcn_wave_barrier();                         \
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  \
   } while (0)
+// Reconvergence point after a lane-divergent region that contains cross-lane operations (the hardware reconverges by
+// itself; the SIMT emulator of tests/emu needs to be told, its lanes being free-running fibers)
+#if defined(__HIP_EMU__)
+#define GROUP_SYNC(W) emu_group_sync(W)
+#else
+#define GROUP_SYNC(W) ((void)0)
+#endif
 template <class L> __device__ __forceinline__ double prm_damp(const HModel& m, const L& S, int d) {
   if constexpr (L::PRM_) return S.damp[d]; else return m.dof_d[DDS * d + DD_DAMPING];
 }
@@ -495,94 +504,7 @@ __device__ __forceinline__ void inert_vec(double* r, const double* i, const doub
   r[5] = i[7] * v[0] - i[6] * v[1] + i[9] * v[5];
 }
 
-// ------------------------------------------------------------------------------------------------ dense SPD solve, group-parallel
-// x <- A^-1 x.  Lane i of the group holds the off-diagonal part of row i of the SPD matrix in registers (r[0..NV); the
-// diagonal entry of r is ignored) and element i of x; the diagonal is published in LDS (dg) from the caller-supplied scalar
-// `diag`.  Left-looking Cholesky: column step J needs row J of L, which lane J has published in the LDS array Lb (packed
-// lower triangle, row-major) during the previous steps: every lane fetches it with broadcast reads and computes its own
-// L[i][J] and -- redundantly, from the published diagonal -- the pivot, so nothing has to be broadcast out of a register
-// inside the column chain (one v_readlane pair per element in the first version of this kernel), and the same published
-// rows serve the transposed access of the backward substitution.  Lanes >= NV shadow row NV-1.
-// The loops are fully unrolled over the compile-time bound NV so the row stays in VGPRs.
-// Column step J.  `cur` holds row J of L up to column J-2, prefetched from LDS during the previous step; the one element
-// that step J-1 has only just produced, L[J][J-1], comes straight out of lane J's registers (v_readlane), so no LDS round
-// trip sits on the column-to-column dependency chain; the reads issued here are the prefetch of row J+1.
-#ifndef LHW_CHOL_PREFETCH
-#define LHW_CHOL_PREFETCH 1
-#endif
-template <class L, int J>
-__device__ __forceinline__ void chol_col(double (&r)[NV], double (&invd)[NV], double& myinvd, const double (&cur)[NV], double dgj,
-                                         double* Lb, const double* dg, int lane) {
-  if constexpr (J < L::NV_) {
-    constexpr int W = L::W_;
-    double nxt[NV], dgn = 0.0;
-#if LHW_CHOL_PREFETCH
-    if constexpr (J + 1 < L::NV_) {
-#pragma unroll
-      for (int p = 0; p < J; p++) nxt[p] = Lb[TRI(J + 1, p)];
-      dgn = dg[J + 1];
-    }
-#endif
-    double s0 = r[J], s1 = 0.0, p0 = dgj, p1 = 0.0;
-#pragma unroll
-    for (int p = 0; p + 1 <= J - 2; p += 2) {   // pairs (p, p+1) of the prefetched columns 0 .. J-2
-      s0 -= r[p] * cur[p]; p0 -= cur[p] * cur[p];
-      s1 -= r[p + 1] * cur[p + 1]; p1 -= cur[p + 1] * cur[p + 1];
-    }
-    if constexpr (J >= 2 && ((J - 1) & 1)) { s1 -= r[J - 2] * cur[J - 2]; p1 -= cur[J - 2] * cur[J - 2]; }   // odd count of prefetched columns
-    if constexpr (J >= 1) {
-      const double last = gbcast<W>(r[J - 1], J);
-      s0 -= r[J - 1] * last; p0 -= last * last;
-    }
-    const double piv = fmax(p0 + p1, HMINVAL);
-    double id = __builtin_amdgcn_rsq(piv);
-    id = id * (1.5 - 0.5 * piv * id * id);
-    id = id * (1.5 - 0.5 * piv * id * id);
-    invd[J] = id;
-    const double lij = (lane == J) ? piv * id : (s0 + s1) * id;
-    r[J] = lij;
-    if (lane == J) myinvd = id;
-    if (lane >= J && lane < NV) Lb[TRI(lane, J)] = lij;
-    SYNC();
-#if !LHW_CHOL_PREFETCH
-    if constexpr (J + 1 < L::NV_) {
-#pragma unroll
-      for (int p = 0; p < J; p++) nxt[p] = Lb[TRI(J + 1, p)];
-      dgn = dg[J + 1];
-    }
-#endif
-    chol_col<L, J + 1>(r, invd, myinvd, nxt, dgn, Lb, dg, lane);
-  }
-}
-
-template <class L>
-__device__ __forceinline__ double chol_solve(double (&r)[NV], double diag, double* Lb, double* dg, int lane, double x) {
-  constexpr int W = L::W_;
-  SYNC();
-  if (lane < NV) dg[lane] = diag;
-  SYNC();
-  double invd[NV], myinvd = 1.0, cur0[NV];
-  chol_col<L, 0>(r, invd, myinvd, cur0, dg[0], Lb, dg, lane);
-  // forward substitution L y = x as a column sweep: x_i -= L[i][j] y_j for i > j, with y_j = x_j / L[j][j] read from lane j
-#pragma unroll
-  for (int j = 0; j < NV; j++) {
-    const double c = (lane > j) ? r[j] * invd[j] : 0.0;
-    x -= c * gbcast<W>(x, j);
-  }
-  x *= myinvd;
-  // backward substitution L^T z = y needs column `lane` of L: the published rows, read transposed
-  const int cl = lane < NV ? lane : NV - 1;
-  double col[NV];
-#pragma unroll
-  for (int j = 0; j < NV; j++) col[j] = Lb[TRI(j, (cl < j ? cl : j))];   // (entries with j < lane are never used)
-#pragma unroll
-  for (int j = NV - 1; j >= 0; j--) {
-    const double c = (lane < j) ? col[j] * invd[j] : 0.0;
-    x -= c * gbcast<W>(x, j);
-  }
-  return x * myinvd;
-}
-
+// ------------------------------------------------------------------------------------------------ row products
 // y_lane = sum_k row[k] * v[k] with the row in registers and v broadcast from LDS
 template <class L>
 __device__ __forceinline__ double row_dot(const double (&row)[NV], const double* v) {
@@ -594,7 +516,94 @@ __device__ __forceinline__ double row_dot(const double (&row)[NV], const double*
   }
   return a0 + a1;
 }
-// ------------------------------------------------------------------------------------------------ forward dynamics phases
+// ------------------------------------------------------------------------------------------------ chain-structured SPD solve
+// Both robots are a free root (dofs 0..5) carrying two serial chains of NCH dofs each (the legs): M, M + h D and the Newton
+// Hessian M + J^T D J are block-structured [root | chain A | chain B] with no A-B block, unless a contact couples the two legs
+// (then the dense solver above is used for that sub-step).  The chain solver lays one HALF of the env on each 16-lane DPP row:
+//   row position p = 0..5   root dof p          (held by BOTH rows of the env: "copy A" and "copy B")
+//   row position p = 6..6+NCH-1   dof p-6 of the row's chain
+// so that "the value held by the lane of dof e of my half" is ONE instruction (v_mov_b64_dpp row_newbcast:e) instead of the
+// four v_readlane + two v_cndmask of a 32-lane-group broadcast, and the two chains are eliminated in lockstep: a reverse
+// (leaf-to-root) L^T D L factorisation -- the order in which this structure has no fill-in, as in MuJoCo's mj_factorM --
+// takes 6 + NCH column steps of at most 5 + NCH updates instead of NV steps of NV.  The root-root block is split between the
+// two copies (their Schur complements add up: one v_permlane16_swap exchange per value after the chain columns).
+// Lane p holds row p of its half's matrix [[Krr_h, C_h^T], [C_h, T_h]] as R[0 .. NR) (full symmetric row; R[p] itself is
+// never read), its diagonal entry in dg, and element p of the right-hand side.
+#define NCH ((L::NV_ - 6) / 2)
+#define NR (6 + NCH)
+template <int SRC>
+__device__ __forceinline__ double rbc(double v) {   // value held by lane SRC of the caller's 16-lane row
+  const long long lv = __double_as_longlong(v);
+  return __longlong_as_double(__builtin_amdgcn_update_dpp(lv, lv, 0x150 + SRC, 0xf, 0xf, false));
+}
+// v(this lane) + v(lane ^ 16): the same sum (row 0 + row 1 of the pair, in this order) in both rows
+__device__ __forceinline__ double xhalf_sum(double v) {
+  const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+  const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+  const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+  return __hiloint2double((int)b[0], (int)a[0]) + __hiloint2double((int)b[1], (int)a[1]);
+}
+__device__ __forceinline__ double rcp_f64(double d) {
+  double x = __builtin_amdgcn_rcp(d);
+  x = fma(fma(-d, x, 1.0), x, x);
+  x = fma(fma(-d, x, 1.0), x, x);
+  return x;
+}
+// column step K of the factorisation with the right-hand side carried along (x <- L^-T x on the fly)
+template <class L, int K>
+__device__ __forceinline__ void chain_col(double (&R)[NR], double& dg, double& x, int p) {
+  const double inv = rcp_f64(rbc<K>(dg));
+  const double f = (p < K) ? R[K] * inv : 0.0;   // L[K][p]
+  dg = fma(-f, R[K], dg);
+  x = fma(-f, rbc<K>(x), x);
+#pragma unroll
+  for (int e = 0; e < K; e++) R[e] = fma(-f, rbc<K>(R[e]), R[e]);
+}
+template <class L, int K, int KEND>
+__device__ __forceinline__ void chain_cols(double (&R)[NR], double& dg, double& x, int p) {
+  if constexpr (K >= KEND) {
+    chain_col<L, K>(R, dg, x, p);
+    chain_cols<L, K - 1, KEND>(R, dg, x, p);
+  }
+}
+template <class L, int E>
+__device__ __forceinline__ void chain_fwd(const double (&Lr)[NR], double& x) {
+  if constexpr (E < NR) {
+    x = fma(-Lr[E], rbc<E>(x), x);
+    chain_fwd<L, E + 1>(Lr, x);
+  }
+}
+// acc += sum_e Mrow[e] * (x held by the lane of row position e)
+template <class L, int E>
+__device__ __forceinline__ void chain_mrow(const double (&Mr)[NR], double x, double& acc) {
+  if constexpr (E < NR) {
+    acc = fma(Mr[E], rbc<E>(x), acc);
+    chain_mrow<L, E + 1>(Mr, x, acc);
+  }
+}
+// x <- K^-1 x.  R, dg: this lane's row / diagonal (copy B of the root: zero; destroyed); rootb: this lane is a root dof's copy B.
+// Root elements of x must be identical in the two copies on entry, and are on return.
+template <class L>
+__device__ __forceinline__ double chain_solve(double (&R)[NR], double dg, double x, int p, bool rootb) {
+  if (rootb) x = 0.0;
+  chain_cols<L, NR - 1, 6>(R, dg, x, p);
+  if (p < 6) {   // Schur complements of the two chains add up on the root block
+#pragma unroll
+    for (int e = 0; e < 6; e++) R[e] = xhalf_sum(R[e]);
+    dg = xhalf_sum(dg);
+    x = xhalf_sum(x);
+  }
+  GROUP_SYNC(L::W_);
+  chain_cols<L, 5, 0>(R, dg, x, p);
+  const double myinv = rcp_f64(dg);   // (every lane's dg is frozen once its own column has been eliminated)
+  x *= myinv;
+  double Lr[NR];
+#pragma unroll
+  for (int e = 0; e < NR; e++) Lr[e] = (e < p) ? R[e] * myinv : 0.0;   // row p of the unit factor
+  chain_fwd<L, 0>(Lr, x);
+  return x;
+}
+
 // ------------------------------------------------------------------------------------------------ forward dynamics phases
 // mj_kinematics with rotation matrices: each lane precombines its body's local transform R_loc = R_body * R_joint(q)
 // (off the serial chain), so a tree level costs one 3x3 product and four matrix-vector products.
@@ -702,7 +711,7 @@ __device__ void fwd_kinematics(const HModel& m, L& S, int lane) {
 
 // subtree com of the (single) dynamic tree rooted at body 1, cinert, cdof  (mj_comPos)
 template <class L>
-__device__ double fwd_com(const HModel& m, const HParams& p, L& S, int lane) {
+__device__ double fwd_com(const HModel& m, const HParams& p, L& S, int lane, int dq /* dof whose applied force this lane returns (-1: none) */) {
   double ms = 0, mx = 0, my = 0, mz = 0;
   if (lane >= 1 && lane < m.nbody && m.body_i[BIS * (lane) + BI_ROOT] == 1) {
     ms = prm_mass(m, S, lane);
@@ -749,15 +758,15 @@ __device__ double fwd_com(const HModel& m, const HParams& p, L& S, int lane) {
   SYNC();
   // mj_xfrcAccumulate: Cartesian force / torque applied at the com of the perturbed bodies -> joint space
   double qapp = 0;
-  if (L::PRM_ && p.env_params && lane < NV) {
+  if (L::PRM_ && p.env_params && dq >= 0) {
     for (int k = 0; k < p.n_pbody; k++) {
       const int pb = p.pbody[k];
-      if (!(((unsigned)m.body_i[BIS * pb + BI_DOFMASK] >> lane) & 1u)) continue;
+      if (!(((unsigned)m.body_i[BIS * pb + BI_DOFMASK] >> dq) & 1u)) continue;
       double off[3], t[3];
       for (int a = 0; a < 3; a++) off[a] = S.U[U_XIPOS + 3 * pb + a] - com[a];
-      cross3(t, &S.U[U_CDOF + 6 * lane], off);
+      cross3(t, &S.U[U_CDOF + 6 * dq], off);
       for (int a = 0; a < 3; a++)
-        qapp += (S.U[U_CDOF + 6 * lane + 3 + a] + t[a]) * S.xfrc[6 * k + a] + S.U[U_CDOF + 6 * lane + a] * S.xfrc[6 * k + 3 + a];
+        qapp += (S.U[U_CDOF + 6 * dq + 3 + a] + t[a]) * S.xfrc[6 * k + a] + S.U[U_CDOF + 6 * dq + a] * S.xfrc[6 * k + 3 + a];
     }
   }
   return qapp;
@@ -772,7 +781,7 @@ __device__ void fwd_crb(const HModel& m, L& S, int lane) {
     if (b >= 1) for (int d = b; d < m.body_i[BIS * (b) + BI_SUBEND]; d++) s += S.U[U_CINERT + 10 * d + k];
     S.U[U_CRB + it] = s;
   }
-  for (int it = lane; it < L::TRI_; it += L::W_) S.U[U_M + it] = 0.0;   // packed lower triangle
+  for (int it = lane; it <= L::TRI_; it += L::W_) S.U[U_M + it] = 0.0;   // packed lower triangle, then the zero the chain solver's row gather points at
   SYNC();
   // buf_i = crb[body(i)] * cdof_i (6 per dof)
   if (lane < NV) {
@@ -793,7 +802,7 @@ __device__ void fwd_crb(const HModel& m, L& S, int lane) {
 
 // mj_fwdVelocity: cvel, cdof_dot, bias force (RNE, no acceleration), passive damping, constraint reference
 template <class L>
-__device__ double fwd_velocity(const HModel& m, L& S, int lane) {
+__device__ double fwd_velocity(const HModel& m, L& S, int lane, int dq /* dof whose bias force this lane returns (-1: none) */) {
   // velocity seen by dof j when its cdof_dot is formed: sum over dof_prevmask[j]
   if (lane < NV) {
     const int j = lane;
@@ -853,9 +862,9 @@ __device__ double fwd_velocity(const HModel& m, L& S, int lane) {
   }
   SYNC();
   double bias = 0;
-  if (lane < NV) {
-    const int b = m.dof_i[DIS * (lane) + DI_BODY];
-    for (int a = 0; a < 6; a++) bias += S.U[U_CDOF + 6 * lane + a] * S.U[U_CSUB + 6 * b + a];
+  if (dq >= 0) {
+    const int b = m.dof_i[DIS * (dq) + DI_BODY];
+    for (int a = 0; a < 6; a++) bias += S.U[U_CDOF + 6 * dq + a] * S.U[U_CSUB + 6 * b + a];
   }
   SYNC();
   return bias;
@@ -1344,10 +1353,11 @@ __device__ void fwd_collision(const HModel& m, const HParams& p, L& S, int lane,
     }
   }
   int total;
+  const int mine = k.n;   // (pairs without a contact skip the writing pass: most of them, most of the time)
   const int base = gscan<L::W_>(k.n, &total) - k.n;
   k.base = base; k.n = 0; k.write = 1;
-  if (have && !boxpair && !primbox && base < NC) collide_pair(k, m, S, g1, g2, margin);
-  if (m.has_primbox) { if (primbox && base < NC) collide_primbox(k, m, S, g1, g2, margin); }
+  if (have && !boxpair && !primbox && mine > 0 && base < NC) collide_pair(k, m, S, g1, g2, margin);
+  if (m.has_primbox) { if (primbox && mine > 0 && base < NC) collide_primbox(k, m, S, g1, g2, margin); }
   if constexpr (BOXBOX) {
     if (boxpair && base < NC) {
       const double zero[3] = {0, 0, 0};
@@ -1452,36 +1462,90 @@ __device__ __forceinline__ void row_deriv(bool valid, double fl, double D, doubl
   *d1 = a; *d2 = b;
 }
 
-// One mj_forward (+ Euler).  flags: bit0 actuation enabled, bit1 integrate.
-// On return S.qacc / S.efc_force / contacts / S.sq,sv,frc describe THIS forward pass (the "stale" fields of note S).
-//
-// Constraint rows.  MuJoCo orders them frictionloss dofs, joint limits, contacts.  Here the pyramid rows of contact c are
-// rows (= lanes) 4c .. 4c+3 with their Jacobian row in registers and in LDS, and the frictionloss / limit rows -- whose
-// Jacobians are +-unit vectors -- are three scalars slots of their dof's lane (0 frictionloss, 1 lower limit, 2 upper limit):
-// J x is the lane's own element, J^T f lands on the lane's own dof, J^T D J on its own diagonal entry.  Only the summation
-// order differs from the row order of the reference; every row is there.
-template <bool BOXBOX, class L>
-__device__ __forceinline__ void substep(const HModel& m, const HParams& p, L& S, int lane, int flags, double* warm /* lane-held */, long long* st_prof,
-                                        const double* ter) {
+// K^-1 x for a Hessian whose contacts couple the two chains (no block structure left): a plain left-looking Cholesky on the
+// packed lower triangle in LDS (the U_L region, which the chain solver leaves idle), one dof per lane, rolled loops.  Slow
+// (~2 k instructions) and small: it runs in the few sub-steps with leg-leg contacts and must not cost the hot path registers.
+// Hrow / hd: the chain-layout row of M + J^T D J (root + own-chain columns) as assembled for chain_solve.
+template <class L>
+__device__ __forceinline__ double dense_lds_solve(L& S, const double (&Hrow)[NR], double hd, double x, int dof, bool prim, int coff, int nrow) {
+  double* A = S.U + U_L;
+  double* xs = S.U + U_DG;
+  const int d = dof >= 0 ? dof : 0;
+  SYNC();
+  if (prim) {
+#pragma unroll
+    for (int e = 0; e < NR; e++) {
+      const int c = e < 6 ? e : coff + e - 6;
+      if (c < d) A[TRI(d, c)] = Hrow[e];
+    }
+    A[TRI(d, d)] = hd;
+    if (d >= 6 + NCH)   // chain B rows: the chain A columns carry the coupling J^T D J only
+      for (int c = 6; c < 6 + NCH; c++) {
+        double s = 0;
+        for (int r = 0; r < nrow; r++) s += S.U[U_DACT + r] * S.U[U_J + r * NV + d] * S.U[U_J + r * NV + c];
+        A[TRI(d, c)] = s;
+      }
+  }
+  SYNC();
+  for (int j = 0; j < NV; j++) {
+    double s = 0;
+    const bool act = prim && d >= j;
+    if (act) {
+      s = A[TRI(d, j)];
+      for (int k = 0; k < j; k++) s -= A[TRI(d, k)] * A[TRI(j, k)];
+    }
+    SYNC();
+    if (act && d == j) A[TRI(j, j)] = sqrt(fmax(s, HMINVAL));
+    SYNC();
+    if (act && d > j) A[TRI(d, j)] = s / A[TRI(j, j)];
+    SYNC();
+  }
+  for (int j = 0; j < NV; j++) {
+    if (prim && d == j) { x = x / A[TRI(j, j)]; xs[j] = x; }
+    SYNC();
+    if (prim && d > j) x -= A[TRI(d, j)] * xs[j];
+  }
+  for (int j = NV - 1; j >= 0; j--) {
+    if (prim && d == j) { x = x / A[TRI(j, j)]; xs[j] = x; }
+    SYNC();
+    if (prim && d < j) x -= A[TRI(j, d)] * xs[j];
+  }
+  SYNC();
+  return dof >= 0 ? xs[d] : 0.0;
+}
+
+// Everything of the sub-step behind the joint-space inertia: constraint rows, smooth acceleration, Newton, Euler.
+// Dofs sit in the half-env-per-DPP-row layout of the chain solver: a root dof is held by two lanes, `prim` marks the one that
+// counts in sums over dofs and writes the dof's results.  `cross`: some contact couples the two chains (group-uniform).
+template <class L>
+__device__ __forceinline__ void solve_tail(const HModel& m, const HParams& p, L& S, const int lane, const int flags, long long* st_prof,
+                                           const int dof, const bool prim, const bool cross, const double qapp, const double bias) {
   constexpr int W = L::W_;
   PROF_BEGIN();
-  fwd_kinematics<BOXBOX>(m, S, lane);
-  PROF_MARK(0);
-  fwd_collision<BOXBOX>(m, p, S, lane, ter);   // stage A temporaries (geom frames) die with fwd_com
-  PROF_MARK(3);
-  const double qapp = fwd_com(m, p, S, lane);
-  PROF_MARK(1);
-  const double bias = fwd_velocity(m, S, lane);
-  PROF_MARK(5);
-  fwd_crb(m, S, lane);
-  // row `lane` of M (lane = dof) stays in registers for every product of the solve; its LDS slot dies here
-  const int ld = lane < NV ? lane : NV - 1;
-  double Mrow[NV];
+  const int dd = dof >= 0 ? dof : 0;   // (lanes without a dof shadow dof 0; nothing of theirs is used)
+  const int cp = lane & 15;            // chain layout: position in the 16-lane row
+  const bool rootb = dof >= 0 && !prim;
+  const int coff = 6 + ((lane >> 4) & 1) * NCH;   // first dof of this row's chain
+  // row of M of this lane's dof stays in registers for every product of the solve; its LDS slot dies here
+  double Mrow[NR];
+  double mdiag;
+  {
+    const int* ix = m.chain_idx + (lane & 31) * (NR + 1);   // offsets into the packed M (TRI_: the zero behind it, for entries outside the lane's block row)
 #pragma unroll
-  for (int k = 0; k < NV; k++) Mrow[k] = S.U[U_M + (k <= ld ? TRI(ld, k) : TRI(k, ld))];
-  const double mdiag = S.U[U_M + TRI(ld, ld)];
+    for (int e = 0; e < NR; e++) Mrow[e] = S.U[U_M + ix[e]];
+    mdiag = S.U[U_M + ix[NR]];
+  }
   SYNC();
-  PROF_MARK(2);
+  // M x for the dof vector x held one element per dof lane
+  auto mprod = [&](double x) {
+    double acc = 0;
+    chain_mrow<L, 0>(Mrow, x, acc);
+    if (cp < 6) acc = xhalf_sum(acc);   // root rows: the two copies hold the coupling to one chain each
+    GROUP_SYNC(W);
+    return acc;
+  };
+  // K^-1 x for K = M + diag(extra) (+ J^T D J accumulated by the caller into Krow / kd)
+  auto spd_solve = [&](double (&Krow)[NR], double kd, double x) { return chain_solve<L>(Krow, rootb ? 0.0 : kd, x, cp, rootb); };
   // ---- contact Jacobian, item = (contact, dof): rows 4c .. 4c+3 = Jn +- mu Jt1, Jn +- mu Jt2 (condim 1: row 4c = Jn)
   const int ncon = S.ncon, nrow = 4 * ncon;
   for (int it = lane; it < ncon * NV; it += W) {
@@ -1540,12 +1604,12 @@ __device__ __forceinline__ void substep(const HModel& m, const HParams& p, L& S,
       aref = -B * jv0 - K * imp * (S.U[U_CDIST + c] - S.U[U_CMARGIN + c]);
     }
   }
-  // ---- unit rows of dof `lane`: slot 0 frictionloss (Huber), 1 lower limit (J = +1), 2 upper limit (J = -1)
+  // ---- unit rows of this lane's dof: slot 0 frictionloss (Huber), 1 lower limit (J = +1), 2 upper limit (J = -1)
   bool uon[3] = {false, false, false};
   double uD[3] = {0, 0, 0}, uaref[3] = {0, 0, 0}, ufl = 0;
-  const double qv = lane < NV ? S.qvel[lane] : 0.0;
-  if (lane < NV) {
-    const int d = lane;
+  const double qv = dof >= 0 ? S.qvel[dd] : 0.0;
+  if (dof >= 0) {
+    const int d = dof;
     const double fl = prm_floss(m, S, d);
     if (fl > 0) {
       double sr[2] = {m.dof_d[DDS * d + DD_SOLREF], m.dof_d[DDS * d + DD_SOLREF + 1]}, si[5], K, B, imp, R;
@@ -1592,26 +1656,25 @@ __device__ __forceinline__ void substep(const HModel& m, const HParams& p, L& S,
     S.frc[lane] = f;
   }
   SYNC();
-  // qfrc_smooth (lane = dof) = passive - bias + actuator + applied
+  // qfrc_smooth of this lane's dof = passive - bias + actuator + applied
   double fs = 0;
-  if (lane < NV) {
+  if (dof >= 0) {
     double act = 0;
-    const int u = m.dof_i[DIS * lane + DI_ACT];   // at most one actuator per dof (checked at create)
-    if (u >= 0) act = m.dof_d[DDS * lane + DD_GEAR] * S.frc[u];
-    fs = -prm_damp(m, S, lane) * qv - bias + act + qapp;
+    const int u = m.dof_i[DIS * dd + DI_ACT];   // at most one actuator per dof (checked at create)
+    if (u >= 0) act = m.dof_d[DDS * dd + DD_GEAR] * S.frc[u];
+    fs = -prm_damp(m, S, dd) * qv - bias + act + qapp;
   }
-  double* Lb = S.U + U_L;
   PROF_MARK(11);
   // qacc_smooth = M^-1 qfrc_smooth
   double as;
   {
-    double r[NV];
+    double r[NR];
 #pragma unroll
-    for (int k = 0; k < NV; k++) r[k] = Mrow[k];
-    as = chol_solve<L>(r, mdiag, Lb, S.U + U_DG, lane, fs);
+    for (int k = 0; k < NR; k++) r[k] = Mrow[k];
+    as = spd_solve(r, mdiag, fs);
   }
   PROF_MARK(12);
-  double qacc = as, fcon = 0;  // lane = dof
+  double qacc = as, fcon = 0;  // element of this lane's dof
   if (anyrow) {
     // ------------------------------------------------------------ primal Newton (engine_solver.c)
     // cost / force / active-D of this lane's rows at acceleration a (ja = J a of the contact row, a = own dof element)
@@ -1620,24 +1683,26 @@ __device__ __forceinline__ void substep(const HModel& m, const HParams& p, L& S,
       row_eval(isrow, 0.0, D, ja - aref, &c, force, dactive);
       double cs = c, uf = 0, ud = 0;
       if (anyunit) {
-        row_eval(uon[0], ufl, uD[0], a - uaref[0], &c, &f, &da); cs += c; uf += f; ud += da;
-        row_eval(uon[1], 0.0, uD[1], a - uaref[1], &c, &f, &da); cs += c; uf += f; ud += da;
-        row_eval(uon[2], 0.0, uD[2], -a - uaref[2], &c, &f, &da); cs += c; uf -= f; ud += da;
+        double cu = 0;
+        row_eval(uon[0], ufl, uD[0], a - uaref[0], &c, &f, &da); cu += c; uf += f; ud += da;
+        row_eval(uon[1], 0.0, uD[1], a - uaref[1], &c, &f, &da); cu += c; uf += f; ud += da;
+        row_eval(uon[2], 0.0, uD[2], -a - uaref[2], &c, &f, &da); cu += c; uf -= f; ud += da;
+        if (prim) cs += cu;   // (the unit rows of a root dof count once)
       }
       *cost = cs; *ufrc = uf; *udact = ud;
     };
     const double scale = 1.0 / (m.meaninertia * (NV > 1 ? NV : 1));
     // warm start: cheaper of qacc_warmstart and qacc_smooth
     if (!(m.disableflags & (1 << 7))) {
-      const double w = *warm;
+      const double w = dof >= 0 ? S.qacc[dd] : 0.0;   // qacc of the previous forward pass = qacc_warmstart
       SYNC();
-      if (lane < NV) { S.U[U_VEC + lane] = w; S.U[U_VEC2 + lane] = as; }
+      if (prim) { S.U[U_VEC + dd] = w; S.U[U_VEC2 + dd] = as; }
       SYNC();
-      const double jw = jrow_dot(S.U + U_VEC), Ma = row_dot<L>(Mrow, S.U + U_VEC), js = jrow_dot(S.U + U_VEC2);
+      const double jw = jrow_dot(S.U + U_VEC), Ma = mprod(w), js = jrow_dot(S.U + U_VEC2);
       double cw, cs0, tf, td, tu, tv;
       eval_rows(jw, w, &cw, &tf, &td, &tu, &tv);
       eval_rows(js, as, &cs0, &tf, &td, &tu, &tv);
-      if (lane < NV) cw += 0.5 * (Ma - fs) * (w - as);
+      if (prim) cw += 0.5 * (Ma - fs) * (w - as);
       cw = gsum<W>(cw);
       const double cs = gsum<W>(cs0);
       qacc = (cw > cs) ? as : w;
@@ -1646,12 +1711,12 @@ __device__ __forceinline__ void substep(const HModel& m, const HParams& p, L& S,
     for (int iter = 0; iter <= m.iterations; iter++) {
       if (st_prof && lane == 0) st_prof[6] += 1;    // diagnostic: Newton passes (cost evaluations) of env 0
       SYNC();
-      if (lane < NV) S.U[U_VEC + lane] = qacc;
+      if (prim) S.U[U_VEC + dd] = qacc;
       SYNC();
-      const double ja = jrow_dot(S.U + U_VEC), Ma = row_dot<L>(Mrow, S.U + U_VEC);
+      const double ja = jrow_dot(S.U + U_VEC), Ma = mprod(qacc);
       double c, force, dactive, ufrc, udact;
       eval_rows(ja, qacc, &c, &force, &dactive, &ufrc, &udact);
-      if (lane < NV) c += 0.5 * (Ma - fs) * (qacc - as);
+      if (prim) c += 0.5 * (Ma - fs) * (qacc - as);
       oldcost = cost;
       cost = gsum<W>(c);
       S.U[U_EVEC + lane] = force; S.efc_force[lane] = force; S.U[U_DACT + lane] = dactive;   // lane = contact row (NE == W)
@@ -1661,47 +1726,64 @@ __device__ __forceinline__ void substep(const HModel& m, const HParams& p, L& S,
       {
         double f0 = 0, f1 = 0, f2 = 0, f3 = 0;
         for (int r = 0; r < nrow; r += 4) {   // whole contacts: nrow is a multiple of 4
-          f0 += S.U[U_J + r * NV + ld] * S.U[U_EVEC + r];
-          f1 += S.U[U_J + (r + 1) * NV + ld] * S.U[U_EVEC + r + 1];
-          f2 += S.U[U_J + (r + 2) * NV + ld] * S.U[U_EVEC + r + 2];
-          f3 += S.U[U_J + (r + 3) * NV + ld] * S.U[U_EVEC + r + 3];
+          f0 += S.U[U_J + r * NV + dd] * S.U[U_EVEC + r];
+          f1 += S.U[U_J + (r + 1) * NV + dd] * S.U[U_EVEC + r + 1];
+          f2 += S.U[U_J + (r + 2) * NV + dd] * S.U[U_EVEC + r + 2];
+          f3 += S.U[U_J + (r + 3) * NV + dd] * S.U[U_EVEC + r + 3];
         }
-        if (lane < NV) {
+        if (dof >= 0) {
           fcon = ((f0 + f1) + (f2 + f3)) + ufrc;
           grad = Ma - fs - fcon;
         }
       }
-      const double gn = sqrt(gsum<W>(grad * grad));
+      const double gn = sqrt(gsum<W>(prim ? grad * grad : 0.0));
       if (iter > 0) { if (scale * (oldcost - cost) < m.tolerance || scale * gn < m.tolerance) break; }
       else if (scale * gn < m.tolerance) break;
       if (iter == m.iterations) break;
-      // H = M + J^T D_active J, row `lane` (lane = dof) accumulated in the registers the factorisation works on; the diagonal
+      // H = M + J^T D_active J, row of this lane's dof accumulated in the registers the factorisation works on; the diagonal
       // entry travels separately (hd)
-      double Hrow[NV], hd = mdiag + udact;
+      double Hrow[NR], hd = mdiag + udact;
 #pragma unroll
-      for (int k = 0; k < NV; k++) Hrow[k] = Mrow[k];
-      for (int r = 0; r < nrow; r++) {
-        const double jl = S.U[U_J + r * NV + ld], cj = S.U[U_DACT + r] * jl;
-        hd += cj * jl;
+      for (int k = 0; k < NR; k++) Hrow[k] = Mrow[k];
+      {
+        for (int r = 0; r < nrow; r++) {
+          const double jl = S.U[U_J + r * NV + dd], cj = S.U[U_DACT + r] * jl;
+          hd += cj * jl;
 #pragma unroll
-        for (int k = 0; k < NV; k += 2) {
-          const double2 ab = *reinterpret_cast<const double2*>(&S.U[U_J + r * NV + k]);
-          Hrow[k] += cj * ab.x;
-          Hrow[k + 1] += cj * ab.y;
+          for (int k = 0; k < 6; k += 2) {
+            const double2 ab = *reinterpret_cast<const double2*>(&S.U[U_J + r * NV + k]);
+            Hrow[k] += cj * ab.x;
+            Hrow[k + 1] += cj * ab.y;
+          }
+          if constexpr (NCH % 2 == 0) {
+#pragma unroll
+            for (int k = 0; k < NCH; k += 2) {
+              const double2 ab = *reinterpret_cast<const double2*>(&S.U[U_J + r * NV + coff + k]);
+              Hrow[6 + k] += cj * ab.x;
+              Hrow[6 + k + 1] += cj * ab.y;
+            }
+          } else {
+#pragma unroll
+            for (int k = 0; k < NCH; k++) Hrow[6 + k] += cj * S.U[U_J + r * NV + coff + k];
+          }
+        }
+        if (rootb) {   // the root-root block lives in copy A
+#pragma unroll
+          for (int k = 0; k < 6; k++) Hrow[k] = 0.0;
         }
       }
-      const double search = -chol_solve<L>(Hrow, hd, Lb, S.U + U_DG, lane, grad);
-      if (lane < NV) S.U[U_VEC2 + lane] = search;
+      const double search = cross ? -dense_lds_solve<L>(S, Hrow, hd, grad, dof, prim, coff, nrow) : -spd_solve(Hrow, hd, grad);
+      if (prim) S.U[U_VEC2 + dd] = search;
       SYNC();
-      const double jv = jrow_dot(S.U + U_VEC2), Mv = row_dot<L>(Mrow, S.U + U_VEC2);
-      const double qg1 = gsum<W>(lane < NV ? search * (Ma - fs) : 0.0);
-      const double qg2 = gsum<W>(lane < NV ? 0.5 * search * Mv : 0.0);
+      const double jv = jrow_dot(S.U + U_VEC2), Mv = mprod(search);
+      const double qg1 = gsum<W>(prim ? search * (Ma - fs) : 0.0);
+      const double qg2 = gsum<W>(prim ? 0.5 * search * Mv : 0.0);
       // exact line search on the convex piecewise-quadratic: safeguarded Newton on its derivative
       const double x0 = ja - aref, xu0 = qacc - uaref[0], xu1 = qacc - uaref[1], xu2 = -qacc - uaref[2];
       auto deriv_rows = [&](double a, double* d1, double* d2) {
         double r1, r2, s1, s2;
         row_deriv(isrow, 0.0, D, x0 + a * jv, jv, &r1, &r2);
-        if (anyunit) {
+        if (anyunit && prim) {
           row_deriv(uon[0], ufl, uD[0], xu0 + a * search, search, &s1, &s2); r1 += s1; r2 += s2;
           row_deriv(uon[1], 0.0, uD[1], xu1 + a * search, search, &s1, &s2); r1 += s1; r2 += s2;
           row_deriv(uon[2], 0.0, uD[2], xu2 - a * search, -search, &s1, &s2); r1 += s1; r2 += s2;
@@ -1738,8 +1820,7 @@ __device__ __forceinline__ void substep(const HModel& m, const HParams& p, L& S,
     S.efc_force[lane] = 0;
   }
   SYNC();
-  if (lane < NV) S.qacc[lane] = qacc;
-  *warm = qacc;  // mj_fwdConstraint: next warm start
+  if (prim) S.qacc[dd] = qacc;   // mj_fwdConstraint: also the next warm start
   SYNC();
   PROF_MARK(7);
   if (!(flags & 2)) return;
@@ -1748,14 +1829,14 @@ __device__ __forceinline__ void substep(const HModel& m, const HParams& p, L& S,
   const double h = m.timestep;
   const bool eulerdamp = !(m.disableflags & (1 << 14));
   if (eulerdamp) {
-    double r[NV];
+    double r[NR];
 #pragma unroll
-    for (int k = 0; k < NV; k++) r[k] = Mrow[k];
-    const double dm = lane < NV ? prm_damp(m, S, lane) : 0.0;
-    anew = chol_solve<L>(r, mdiag + h * dm, Lb, S.U + U_DG, lane, fs + fcon);
+    for (int k = 0; k < NR; k++) r[k] = Mrow[k];
+    const double dm = dof >= 0 ? prm_damp(m, S, dd) : 0.0;
+    anew = spd_solve(r, mdiag + h * dm, fs + fcon);
   }
   PROF_MARK(13);
-  if (lane < NV) S.qvel[lane] = qv + h * anew;
+  if (prim) S.qvel[dd] = qv + h * anew;
   SYNC();
   if (lane < m.njnt) {
     const int j = lane, qa = m.jnt_i[JIS * (j) + JI_QADR], da = m.jnt_i[JIS * (j) + JI_DADR];
@@ -1774,6 +1855,46 @@ __device__ __forceinline__ void substep(const HModel& m, const HParams& p, L& S,
   }
   SYNC();
   PROF_MARK(8);
+}
+
+// One mj_forward (+ Euler).  flags: bit0 actuation enabled, bit1 integrate.
+// On return S.qacc / S.efc_force / contacts / S.sq,sv,frc describe THIS forward pass (the "stale" fields of note S); S.qacc of
+// the previous pass is the warm start of this one.
+//
+// Constraint rows.  MuJoCo orders them frictionloss dofs, joint limits, contacts.  Here the pyramid rows of contact c are
+// rows (= lanes) 4c .. 4c+3 with their Jacobian row in LDS, and the frictionloss / limit rows -- whose
+// Jacobians are +-unit vectors -- are three scalars slots of their dof's lane (0 frictionloss, 1 lower limit, 2 upper limit):
+// J x is the lane's own element, J^T f lands on the lane's own dof, J^T D J on its own diagonal entry.  Only the summation
+// order differs from the row order of the reference; every row is there.
+template <bool BOXBOX, class L>
+__device__ __forceinline__ void substep(const HModel& m, const HParams& p, L& S, int lane, int flags, long long* st_prof, const double* ter) {
+  constexpr int W = L::W_;
+  PROF_BEGIN();
+  fwd_kinematics<BOXBOX>(m, S, lane);
+  PROF_MARK(0);
+  fwd_collision<BOXBOX>(m, p, S, lane, ter);   // stage A temporaries (geom frames) die with fwd_com
+  PROF_MARK(3);
+  // The chain solver needs the [root | chain A | chain B] block structure of M (checked at create).  A contact between bodies
+  // of the two chains couples them in the Newton Hessian (rare: it is a self-collision, i.e. the last control step of an
+  // episode): those Hessians are factorised by the looped dense Cholesky in LDS instead (dense_lds_solve).
+  bool cross = false;
+  if (lane < S.ncon && S.con_dim[lane] != 0) {
+    const unsigned m1 = (unsigned)m.body_i[BIS * m.geom_i[GIS * S.con_g1[lane] + GI_BODY] + BI_DOFMASK];
+    const unsigned m2 = (unsigned)m.body_i[BIS * m.geom_i[GIS * S.con_g2[lane] + GI_BODY] + BI_DOFMASK];
+    const unsigned ca = ((1u << NCH) - 1u) << 6, cb = ca << NCH;
+    cross = ((m1 & ca) && (m2 & cb)) || ((m1 & cb) && (m2 & ca));
+  }
+  cross = gany<W>(cross);
+  const int cp = lane & 15, hh = (lane >> 4) & 1;
+  const int dof = (lane < 32 && cp < NR) ? (cp < 6 ? cp : 6 + hh * NCH + (cp - 6)) : -1;
+  const bool prim = dof >= 0 && (cp >= 6 || hh == 0);
+  const double qapp = fwd_com(m, p, S, lane, dof);
+  PROF_MARK(1);
+  const double bias = fwd_velocity(m, S, lane, dof);
+  PROF_MARK(5);
+  fwd_crb(m, S, lane);
+  PROF_MARK(2);
+  solve_tail(m, p, S, lane, flags, st_prof, dof, prim, cross, qapp, bias);
 }
 // ------------------------------------------------------------------------------------------------ task layer
 __device__ __forceinline__ void sample_ref(const HParams& p, unsigned genv, unsigned stream, unsigned counter, unsigned slot0,
@@ -1941,9 +2062,9 @@ __device__ __forceinline__ bool control_step(const HModel& m, const HParams& p, 
     return false;
   }
   // ---- load the persistent record (lane-strided); the episode / task context goes to its LDS home
-  double warm = 0;
   if (lane < m.nq) S.qpos[lane] = rec[R_QPOS + lane];
-  if (lane < NV) { S.qvel[lane] = rec[R_QVEL + lane]; warm = rec[R_WARM + lane]; }
+  if (lane < NV) { S.qvel[lane] = rec[R_QVEL + lane]; S.qacc[lane] = rec[R_WARM + lane]; }   // qacc of the last pass = warm start
+
   if (lane < m.nu) {
     S.sq[lane] = rec[R_SQ + lane]; S.sv[lane] = rec[R_SV + lane]; S.frc[lane] = rec[R_FRC + lane];
     S.ctrl[lane] = 0;
@@ -2392,7 +2513,7 @@ __device__ __forceinline__ bool control_step(const HModel& m, const HParams& p, 
       const double* tr = st.rec + (size_t)p.reset_template * REC_D;
       SYNC();
       if (lane < m.nq) S.qpos[lane] = tr[R_QPOS + lane];
-      if (lane < NV) { S.qvel[lane] = tr[R_QVEL + lane]; warm = tr[R_WARM + lane]; }
+      if (lane < NV) { S.qvel[lane] = tr[R_QVEL + lane]; S.qacc[lane] = tr[R_WARM + lane]; }
       if (lane < m.nu) { S.sq[lane] = tr[R_SQ + lane]; S.sv[lane] = tr[R_SV + lane]; S.frc[lane] = tr[R_FRC + lane]; S.ctrl[lane] = 0; }
       SYNC();
       stage = ST_SETTLE; kstep = 3;
@@ -2405,7 +2526,7 @@ __device__ __forceinline__ bool control_step(const HModel& m, const HParams& p, 
       if (lane < m.nq) S.qpos[lane] = p.nominal_qpos[lane];
       if (lane < NV) S.qvel[lane] = 0;
       if (lane < m.nu) S.ctrl[lane] = 0;
-      warm = 0;
+      if (lane < NV) S.qacc[lane] = 0;   // mj_resetData clears qacc_warmstart
       if (H1R) {
         // mj_resetData clears xfrc_applied; dynamics randomisation on reset (base_humanoid_env.py:254-255), slots 0..63
         if (lane < 12) { S.xfrc[lane] = 0; prm[P_XFRC + lane] = 0; }
@@ -2442,7 +2563,7 @@ __device__ __forceinline__ bool control_step(const HModel& m, const HParams& p, 
 #else
     const int lane_s = lane;
 #endif
-    substep<TASK == TASK_STEP>(m, p, S, lane_s, flags, &warm, sprof, ter);
+    substep<TASK == TASK_STEP>(m, p, S, lane_s, flags, sprof, ter);
     if (stage == ST_LAST) break;
     // two envs per wave: an env that needs more contacts than this layout holds is handed to the one-env-per-wave kernel
     // untouched (nothing of it has been written yet); once its outputs are out, it can only truncate like that kernel does
@@ -2455,7 +2576,7 @@ __device__ __forceinline__ bool control_step(const HModel& m, const HParams& p, 
   // ---- store the record
   SYNC();
   if (lane < m.nq) rec[R_QPOS + lane] = S.qpos[lane];
-  if (lane < NV) { rec[R_QVEL + lane] = S.qvel[lane]; rec[R_WARM + lane] = warm; }
+  if (lane < NV) { rec[R_QVEL + lane] = S.qvel[lane]; rec[R_WARM + lane] = S.qacc[lane]; }
   if (lane < m.nu) { rec[R_SQ + lane] = S.sq[lane]; rec[R_SV + lane] = S.sv[lane]; rec[R_FRC + lane] = S.frc[lane]; }
   if (lane < 3) rec[R_MODEREF + lane] = S.cmode_ref[lane];
   if (lane == 3) rec[R_EPRET] = S.cep_ret;
@@ -2709,6 +2830,32 @@ int humanoid_create(HumanoidEnv** out, const std::vector<int32_t>& mi, const std
     ai[AI_DOF] = jdof[j]; ai[AI_JNT] = j; ai[AI_CTRLLIMITED] = IF(LHW_IF_ACTUATOR_CTRLLIMITED)[u]; ai[AI_FORCELIMITED] = IF(LHW_IF_ACTUATOR_FORCELIMITED)[u];
   }
   m.nlevel = nlevel; m.nmpair = (int)mp.size() / 2;
+  // chain structure (see chain_solve): dofs 0..5 one free joint, then two serial chains of equal length hanging off the root
+  const int nch = (nv - 6) / 2;
+  bool chain2 = nv >= 8 && nv == 6 + 2 * nch && nch <= 10 && jtype[djnt[0]] == JT_FREE;
+  for (int d = 0; chain2 && d < 6; d++) chain2 = djnt[d] == djnt[0] && dparent[d] == d - 1;
+  for (int c = 0; chain2 && c < 2; c++)
+    for (int k = 0; chain2 && k < nch; k++) chain2 = dparent[6 + c * nch + k] == (k == 0 ? 5 : 6 + c * nch + k - 1);
+  if (!chain2) { humanoid_destroy(h); return lhw_fail(LHW_ERR_UNSUPPORTED, "the humanoid stepper needs a free root joint carrying two serial chains of (nv - 6) / 2 dofs each (the legs), dofs in that order"); }
+  m.chain2 = 1;
+  const int ntri = nv * (nv + 1) / 2;
+  std::vector<int> chain_idx(32 * (6 + std::max(nch, 0) + 1), ntri);
+  if (chain2) {
+    const int nr = 6 + nch;
+    auto tri = [](int i, int j) { return i >= j ? i * (i + 1) / 2 + j : j * (j + 1) / 2 + i; };
+    for (int lane = 0; lane < 32; lane++) {
+      const int cp = lane & 15, hh = lane >> 4;
+      if (cp >= nr) continue;
+      const int d = cp < 6 ? cp : 6 + hh * nch + (cp - 6);
+      int* ix = &chain_idx[(size_t)lane * (nr + 1)];
+      const bool rootb = cp < 6 && hh == 1;
+      for (int e = 0; e < nr; e++) {
+        const int c = e < 6 ? e : 6 + hh * nch + (e - 6);
+        ix[e] = (rootb && e < 6) ? ntri : tri(d, c);
+      }
+      ix[nr] = rootb ? ntri : tri(d, d);
+    }
+  }
   m.has_primbox = primbox_pairs > 0;
   auto BID = [&](int f) { const int b = cfg->task_iparams[f]; return (b >= 0 && b < nbm) ? bmap[b] : -1; };
   m.track_body[0] = BID(LHW_TI_ROOT_BODY); m.track_body[1] = BID(LHW_TI_RFOOT_BODY); m.track_body[2] = BID(LHW_TI_LFOOT_BODY);
@@ -2717,7 +2864,8 @@ int humanoid_create(HumanoidEnv** out, const std::vector<int32_t>& mi, const std
        (m.act_d = to_dev<double>(h, act_d.data(), act_d.size())) && (m.body_i = to_dev<int>(h, body_i.data(), body_i.size())) &&
        (m.jnt_i = to_dev<int>(h, jnt_i.data(), jnt_i.size())) && (m.dof_i = to_dev<int>(h, dof_i.data(), dof_i.size())) &&
        (m.geom_i = to_dev<int>(h, geom_i.data(), geom_i.size())) && (m.act_i = to_dev<int>(h, act_i.data(), act_i.size())) &&
-       (m.pair_i = to_dev<int>(h, pair_i.data(), pair_i.size())) && (m.mpair = to_dev<int>(h, mp.data(), mp.size()));
+       (m.pair_i = to_dev<int>(h, pair_i.data(), pair_i.size())) && (m.mpair = to_dev<int>(h, mp.data(), mp.size())) &&
+       (m.chain_idx = to_dev<int>(h, chain_idx.data(), chain_idx.size()));
   HParams& p = h->p;
   memset(&p, 0, sizeof p);
   p.n_envs = cfg->n_envs; p.frame_skip = cfg->frame_skip; p.max_traj_len = cfg->max_traj_len; p.period = cfg->period;

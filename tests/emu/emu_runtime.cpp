@@ -62,6 +62,7 @@ static int dpp_source(int ctrl, int i) {
   if (ctrl == 0x141) return row + (k < 8 ? 7 - k : 23 - k);                                        // row_half_mirror
   if (ctrl == 0x142) return row >= 16 ? row - 1 : -1;                                              // row_bcast:15
   if (ctrl == 0x143) return i >= 32 ? 31 : -1;                                                     // row_bcast:31
+  if (ctrl >= 0x150 && ctrl <= 0x15f) return row + (ctrl & 15);                                    // row_newbcast (gfx90a+)
   fprintf(stderr, "emu: unsupported DPP control 0x%x\n", ctrl);
   abort();
 }
@@ -106,15 +107,34 @@ static void resolve(Block& b) {
           l.res = at(b, w0 + s, OP_SWIZZLE) ? b.lanes[w0 + s].val : 0u;
           break;
         }
+        case OP_PERMLANE16_SWAP: {
+          // v_permlane16_swap vdst, src: odd rows of vdst <-> even rows of src (partner lane i ^ 16); an inactive partner
+          // leaves the lane's registers untouched
+          const int s = i ^ 16;
+          const bool ok = at(b, w0 + s, OP_PERMLANE16_SWAP);
+          l.res = l.val; l.res2 = l.val2;
+          if (ok) { if (i & 16) l.res = b.lanes[w0 + s].val2; else l.res2 = b.lanes[w0 + s].val; }
+          break;
+        }
         case OP_BALLOT: l.res64 = ballot; break;
         default: break;
       }
     }
   }
+  // group rendezvous: a lane waits until every live lane of its W-lane group has arrived
+  std::vector<char> hold(n, 0);
+  for (int i = 0; i < n; i++) {
+    const Lane& l = b.lanes[i];
+    if (l.state != BLOCKED || l.op != OP_GROUP_SYNC) continue;
+    const int W = l.sel, g0 = i - (i % W);
+    for (int j = g0; j < g0 + W && j < n; j++)
+      if (b.lanes[j].state != DONE && !(b.lanes[j].state == BLOCKED && b.lanes[j].op == OP_GROUP_SYNC)) hold[i] = 1;
+  }
   for (int i = 0; i < n; i++) {
     Lane& l = b.lanes[i];
     if (l.state != BLOCKED) continue;
     if (l.op == OP_BLOCK_BARRIER && !all_block_barrier) continue;
+    if (hold[i]) continue;
     l.state = RUNNABLE;
     l.op = OP_NONE;
   }

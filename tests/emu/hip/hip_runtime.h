@@ -66,7 +66,7 @@ static inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) { *p = 
 
 namespace emu {
 enum { RUNNABLE = 0, BLOCKED = 1, DONE = 2 };
-enum { OP_NONE = 0, OP_WAVE_BARRIER, OP_BLOCK_BARRIER, OP_DPP, OP_READLANE, OP_SWIZZLE, OP_BALLOT, OP_PERMLANE32_SWAP, OP_BPERMUTE };
+enum { OP_NONE = 0, OP_WAVE_BARRIER, OP_BLOCK_BARRIER, OP_DPP, OP_READLANE, OP_SWIZZLE, OP_BALLOT, OP_PERMLANE32_SWAP, OP_BPERMUTE, OP_PERMLANE16_SWAP, OP_GROUP_SYNC };
 struct Lane {
   void* sp = nullptr;
   char* stack = nullptr;
@@ -116,6 +116,19 @@ static inline int emu_update_dpp(int old, int src, int ctrl, int row_mask, int b
   emu::block_here();
   return (int)l.res;
 }
+// 64-bit DPP move (v_mov_b64_dpp: row_newbcast only on the hardware): the two halves travel as two 32-bit exchanges
+static inline long long emu_update_dpp(long long old, long long src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl) {
+  const uint32_t lo = (uint32_t)emu_update_dpp((int)(uint32_t)old, (int)(uint32_t)src, ctrl, row_mask, bank_mask, bound_ctrl);
+  const uint32_t hi = (uint32_t)emu_update_dpp((int)(uint32_t)((uint64_t)old >> 32), (int)(uint32_t)((uint64_t)src >> 32), ctrl, row_mask, bank_mask, bound_ctrl);
+  return (long long)(((uint64_t)hi << 32) | lo);
+}
+struct emu_uint2 { unsigned v[2]; unsigned operator[](int i) const { return v[i]; } };
+static inline emu_uint2 emu_permlane16_swap(unsigned a, unsigned b, bool, bool) {
+  emu::Lane& l = emu::cur();
+  l.op = emu::OP_PERMLANE16_SWAP; l.val = a; l.val2 = b;
+  emu::block_here();
+  return emu_uint2{{l.res, l.res2}};
+}
 static inline int emu_readlane(int v, int lane) {
   emu::Lane& l = emu::cur();
   l.op = emu::OP_READLANE; l.val = (uint32_t)v; l.sel = lane;
@@ -144,12 +157,20 @@ static inline void emu_wave_barrier() {
   emu::cur().op = emu::OP_WAVE_BARRIER;
   emu::block_here();
 }
+// rendezvous of the W-lane group the caller belongs to (GROUP_SYNC of the kernels: a no-op on the hardware, which reconverges
+// divergent lanes by itself)
+static inline void emu_group_sync(int W) {
+  emu::Lane& l = emu::cur();
+  l.op = emu::OP_GROUP_SYNC; l.sel = W;
+  emu::block_here();
+}
 static inline void __syncthreads() {
   emu::cur().op = emu::OP_BLOCK_BARRIER;
   emu::block_here();
 }
 #define __builtin_amdgcn_update_dpp emu_update_dpp
 #define __builtin_amdgcn_readlane emu_readlane
+#define __builtin_amdgcn_permlane16_swap emu_permlane16_swap
 #define __builtin_amdgcn_ds_swizzle emu_ds_swizzle
 #define __builtin_amdgcn_ds_bpermute emu_ds_bpermute
 #define __builtin_amdgcn_wave_barrier emu_wave_barrier
