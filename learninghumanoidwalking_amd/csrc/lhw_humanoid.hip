@@ -175,13 +175,13 @@ enum { LHW_STREAM_OBS = 4 };
 #define AI_FORCELIMITED 3
 
 struct HModel {
-  int nq, nv, nu, nbody, njnt, ngeom, npair, nlevel, nmpair, iterations, disableflags;
+  int nq, nv, nu, nbody, njnt, ngeom, npair, nlevel, iterations, disableflags;
   double timestep, gravity[3], tolerance, meaninertia, totalmass;
   const double *body_d, *jnt_d, *dof_d, *geom_d, *act_d;
-  const int *body_i, *jnt_i, *dof_i, *geom_i, *act_i, *pair_i, *mpair;
+  const int *body_i, *jnt_i, *dof_i, *geom_i, *act_i, *pair_i;
   int has_primbox;     // some collision pair is sphere-box or capsule-box (collide_primbox)
-  int chain2;          // free root + two serial chains of (nv - 6) / 2 dofs each: the chain solver applies
-  const int* chain_idx;  // [32][NR + 1]: for each lane of the chain layout, offsets into the packed M of its row (+ diagonal); TRI = zero
+  int max_owned;         // bodies per lane in chain_dynamics' per-body loop
+  const int* own_tab;    // [32][max_owned]: bodies whose force / inertia the lane of the chain layout contributes (-1: none)
   int track_body[3];  // bodies whose spatial velocity must survive the sub-step (the task reads them afterwards)
   double track_off[9];  // local offset of the tracked point on each of them (foot force sites for the stepping task)
 };
@@ -216,8 +216,14 @@ struct HState {
   long long* wave_cyc;  // optional [N] shader-clock cycles the env's group spent in the last control-step launch (NULL = off)
 };
 #define PROF_BEGIN() long long prof_t = (st_prof && lane == 0) ? (long long)clock64() : 0   // lane = lane within the group
+#ifdef LHW_ASM_MARKS   // (analysis builds: phase boundaries as comments in the ISA listing)
+#define ASM_MARK(slot) asm volatile("; LHW_PHASE " #slot)
+#else
+#define ASM_MARK(slot)
+#endif
 #define PROF_MARK(slot)                                                  \
   do {                                                                   \
+    ASM_MARK(slot);                                                      \
     if (st_prof && lane == 0) {                                          \
       long long now_ = (long long)clock64();                             \
       st_prof[slot] += now_ - prof_t;                                    \
@@ -709,9 +715,9 @@ __device__ void fwd_kinematics(const HModel& m, L& S, int lane) {
   }
 }
 
-// subtree com of the (single) dynamic tree rooted at body 1, cinert, cdof  (mj_comPos)
+// subtree com of the (single) dynamic tree rooted at body 1, cinert  (mj_comPos; cdof: chain_dynamics)
 template <class L>
-__device__ double fwd_com(const HModel& m, const HParams& p, L& S, int lane, int dq /* dof whose applied force this lane returns (-1: none) */) {
+__device__ void fwd_com(const HModel& m, const HParams& p, L& S, int lane) {
   double ms = 0, mx = 0, my = 0, mz = 0;
   if (lane >= 1 && lane < m.nbody && m.body_i[BIS * (lane) + BI_ROOT] == 1) {
     ms = prm_mass(m, S, lane);
@@ -736,139 +742,159 @@ __device__ double fwd_com(const HModel& m, const HParams& p, L& S, int lane, int
     ci[5] -= mass * dif[1] * dif[2];
     ci[6] = mass * dif[0]; ci[7] = mass * dif[1]; ci[8] = mass * dif[2]; ci[9] = mass;
   }
-  if (lane < NV) {
-    const int d = lane, j = m.dof_i[DIS * (d) + DI_JNT], b = m.dof_i[DIS * (d) + DI_BODY], kind = m.dof_i[DIS * (d) + DI_KIND];
-    const int t = kind <= 1 ? JT_FREE : (kind == 2 ? JT_SLIDE : JT_HINGE), k = d - m.jnt_i[JIS * (j) + JI_DADR];
-    double off[3], ax[3], c[6];
-    for (int a = 0; a < 3; a++) off[a] = com[a] - S.U[U_XANCHOR + 3 * j + a];
-    if (t == JT_FREE && k < 3) {
-      for (int a = 0; a < 6; a++) c[a] = 0;
-      c[3 + k] = 1;
-    } else if (t == JT_SLIDE) {
-      c[0] = c[1] = c[2] = 0;
-      for (int a = 0; a < 3; a++) c[3 + a] = S.U[U_XAXIS + 3 * j + a];
-    } else {
-      if (t == JT_FREE) { ax[0] = S.U[U_XMAT + 9 * b + (k - 3)]; ax[1] = S.U[U_XMAT + 9 * b + 3 + (k - 3)]; ax[2] = S.U[U_XMAT + 9 * b + 6 + (k - 3)]; }
-      else for (int a = 0; a < 3; a++) ax[a] = S.U[U_XAXIS + 3 * j + a];
-      c[0] = ax[0]; c[1] = ax[1]; c[2] = ax[2];
-      cross3(c + 3, ax, off);
-    }
-    for (int a = 0; a < 6; a++) S.U[U_CDOF + 6 * d + a] = c[a];
-  }
   SYNC();
-  // mj_xfrcAccumulate: Cartesian force / torque applied at the com of the perturbed bodies -> joint space
-  double qapp = 0;
-  if (L::PRM_ && p.env_params && dq >= 0) {
+}
+
+// ------------------------------------------------------------------------------------------------ tree dynamics, chain layout
+// mj_comPos (cdof), mj_comVel, mj_rne (bias force), mj_crb (joint-space inertia) in the half-env-per-DPP-row layout of the
+// chain solver: row position 0..5 = the root's dofs, 6.. = the dofs of the row's chain, parents first.  Everything that the
+// reference computes by walking the tree is a scan along the row here:
+//   cvel(body of dof p)  = inclusive prefix sum of cdof_e qvel_e             (row_shr scan)
+//   cacc                 = -g + inclusive prefix sum of cdof_dot_e qvel_e    (row_shr scan)
+//   subtree force / composite inertia = suffix sum of the per-body force / cinert     (row_shl scan)
+// A lane also does the per-body work of "its" bodies: a chain lane the body its dof moves; the root's 12 lanes (6 per row)
+// share the bodies that move with the root (pelvis, welded upper body), so the suffix sum at position 0, added over the two
+// rows, is the total of the whole tree = the root's subtree.  M[p][e] = cdof_e . (crb_p cdof_p) for e an ancestor dof of p comes
+// from row broadcasts of cdof; the mirror half of the (symmetric) row is fetched through a 12 x 12 transposition buffer in LDS.
+template <int CTRL>
+__device__ __forceinline__ double dpp_row(double v) { return dpp_d<CTRL, 0xf>(v, 0.0); }
+template <int N>
+__device__ __forceinline__ void row_prefix(double (&v)[N]) {   // inclusive prefix sums along the 16-lane row
+#pragma unroll
+  for (int a = 0; a < N; a++) { v[a] += dpp_row<0x111>(v[a]); v[a] += dpp_row<0x112>(v[a]); v[a] += dpp_row<0x114>(v[a]); v[a] += dpp_row<0x118>(v[a]); }
+}
+template <int N>
+__device__ __forceinline__ void row_suffix(double (&v)[N]) {   // inclusive suffix sums along the 16-lane row
+#pragma unroll
+  for (int a = 0; a < N; a++) { v[a] += dpp_row<0x101>(v[a]); v[a] += dpp_row<0x102>(v[a]); v[a] += dpp_row<0x104>(v[a]); v[a] += dpp_row<0x108>(v[a]); }
+}
+template <class L, int E>
+__device__ __forceinline__ void chain_mlow(const double (&buf)[6], const double (&cd)[6], double (&t)[NR]) {
+  if constexpr (E < NR) {
+    t[E] = buf[0] * rbc<E>(cd[0]) + buf[1] * rbc<E>(cd[1]) + buf[2] * rbc<E>(cd[2]) + buf[3] * rbc<E>(cd[3]) + buf[4] * rbc<E>(cd[4]) + buf[5] * rbc<E>(cd[5]);
+    chain_mlow<L, E + 1>(buf, cd, t);
+  }
+}
+#define U_TB (L::X_)   // transposition buffer [2][NR][NR] (stage B region; dead before and after)
+template <class L>
+__device__ __forceinline__ void chain_dynamics(const HModel& m, const HParams& p, L& S, const int lane, const int dof, const bool prim,
+                                               double (&Mrow)[NR], double& mdiag, double& marm, double& bias, double& qapp) {
+  const int cp = lane & 15, hh = (lane >> 4) & 1, dd = dof >= 0 ? dof : 0;
+  const bool isdof = dof >= 0, rootb = isdof && !prim;
+  // ---- cdof of this lane's dof (mj_comPos)
+  double cd[6] = {0, 0, 0, 0, 0, 0}, qv = 0;
+  if (isdof) {
+    const int j = m.dof_i[DIS * dd + DI_JNT], b = m.dof_i[DIS * dd + DI_BODY], kind = m.dof_i[DIS * dd + DI_KIND];
+    const int k = dd - m.jnt_i[JIS * j + JI_DADR];
+    double off[3], ax[3];
+    for (int a = 0; a < 3; a++) off[a] = S.com[a] - S.U[U_XANCHOR + 3 * j + a];
+    if (kind == 0) cd[3 + k] = 1;                              // free joint, translation k
+    else if (kind == 2) for (int a = 0; a < 3; a++) cd[3 + a] = S.U[U_XAXIS + 3 * j + a];   // slide
+    else {
+      if (kind == 1) { ax[0] = S.U[U_XMAT + 9 * b + (k - 3)]; ax[1] = S.U[U_XMAT + 9 * b + 3 + (k - 3)]; ax[2] = S.U[U_XMAT + 9 * b + 6 + (k - 3)]; }
+      else for (int a = 0; a < 3; a++) ax[a] = S.U[U_XAXIS + 3 * j + a];
+      cd[0] = ax[0]; cd[1] = ax[1]; cd[2] = ax[2];
+      cross3(cd + 3, ax, off);
+    }
+    qv = S.qvel[dd];
+  }
+  // ---- mj_xfrcAccumulate: Cartesian force / torque applied at the com of the perturbed bodies -> joint space
+  qapp = 0;
+  if (L::PRM_ && p.env_params && isdof) {
     for (int k = 0; k < p.n_pbody; k++) {
       const int pb = p.pbody[k];
-      if (!(((unsigned)m.body_i[BIS * pb + BI_DOFMASK] >> dq) & 1u)) continue;
+      if (!(((unsigned)m.body_i[BIS * pb + BI_DOFMASK] >> dd) & 1u)) continue;
       double off[3], t[3];
-      for (int a = 0; a < 3; a++) off[a] = S.U[U_XIPOS + 3 * pb + a] - com[a];
-      cross3(t, &S.U[U_CDOF + 6 * dq], off);
-      for (int a = 0; a < 3; a++)
-        qapp += (S.U[U_CDOF + 6 * dq + 3 + a] + t[a]) * S.xfrc[6 * k + a] + S.U[U_CDOF + 6 * dq + a] * S.xfrc[6 * k + 3 + a];
+      for (int a = 0; a < 3; a++) off[a] = S.U[U_XIPOS + 3 * pb + a] - S.com[a];
+      cross3(t, cd, off);
+      for (int a = 0; a < 3; a++) qapp += (cd[3 + a] + t[a]) * S.xfrc[6 * k + a] + cd[a] * S.xfrc[6 * k + 3 + a];
     }
   }
-  return qapp;
+  // ---- velocities (mj_comVel): cvel of the body behind each dof, cdof_dot
+  double cv[6];
+#pragma unroll
+  for (int a = 0; a < 6; a++) cv[a] = cd[a] * qv;
+  double vp[6];   // velocity seen by the dof when its cdof_dot is formed
+#pragma unroll
+  for (int a = 0; a < 6; a++) vp[a] = -cv[a];
+  row_prefix(cv);
+#pragma unroll
+  for (int a = 0; a < 6; a++) {
+    const double t2 = rbc<2>(cv[a]);          // free joint, rotations: the translations of the same joint only
+    vp[a] = cp >= 6 ? vp[a] + cv[a] : t2;   // chain dofs: everything above them
+  }
+  double ca[6];
+  {
+    double a3[3], b3[3], c3[3];
+    cross3(a3, vp, cd); cross3(b3, vp, cd + 3); cross3(c3, vp + 3, cd);
+    const bool zero = cp < 3 || !isdof;       // translations of the free joint: cdof_dot = 0
+    for (int a = 0; a < 3; a++) { ca[a] = zero ? 0.0 : a3[a] * qv; ca[3 + a] = zero ? 0.0 : (b3[a] + c3[a]) * qv; }
+  }
+  row_prefix(ca);
+#pragma unroll
+  for (int a = 0; a < 3; a++) ca[3 + a] -= m.gravity[a];
+  // ---- per-body bias force f = I a + v x* (I v) and inertia of the bodies this lane owns (mj_rne, no acceleration)
+  double bv[6], ba[6];   // velocity / bias acceleration of those bodies: own (chain) or the root's (root lanes)
+#pragma unroll
+  for (int a = 0; a < 6; a++) {
+    const double rv = rbc<5>(cv[a]), ra = rbc<5>(ca[a]);
+    bv[a] = cp >= 6 ? cv[a] : rv;
+    ba[a] = cp >= 6 ? ca[a] : ra;
+  }
+  double fs[6] = {0, 0, 0, 0, 0, 0}, ci[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  for (int q = 0; q < m.max_owned; q++) {
+    const int b = lane < 32 ? m.own_tab[(lane)*m.max_owned + q] : -1;
+    if (b >= 0) {
+      double I[10], t[6], t2[6], a3[3], b3[3], c3[3];
+#pragma unroll
+      for (int a = 0; a < 10; a++) { I[a] = S.U[U_CINERT + 10 * b + a]; ci[a] += I[a]; }
+      inert_vec(t, I, ba);
+      inert_vec(t2, I, bv);
+      cross3(a3, bv, t2); cross3(b3, bv + 3, t2 + 3); cross3(c3, bv, t2 + 3);
+      for (int a = 0; a < 3; a++) { fs[a] += a3[a] + b3[a] + t[a]; fs[3 + a] += c3[a] + t[3 + a]; }
+      // the task reads the velocity of three bodies after the step (root, feet)
+      for (int k = 0; k < 3; k++)
+        if (b == m.track_body[k]) for (int a = 0; a < 6; a++) S.svel[6 * k + a] = bv[a];
+    }
+  }
+  // ---- subtree sums along the row; the root's subtree is the whole tree
+  row_suffix(fs);
+  row_suffix(ci);
+#pragma unroll
+  for (int a = 0; a < 6; a++) { const double tot = xhalf_sum(rbc<0>(fs[a])); fs[a] = cp >= 6 ? fs[a] : tot; }
+#pragma unroll
+  for (int a = 0; a < 10; a++) { const double tot = xhalf_sum(rbc<0>(ci[a])); ci[a] = cp >= 6 ? ci[a] : tot; }
+  bias = 0;
+#pragma unroll
+  for (int a = 0; a < 6; a++) bias += cd[a] * fs[a];
+  // ---- joint-space inertia (mj_crb): row of this lane's dof over [root | own chain]
+  double buf[6], tl[NR];
+  inert_vec(buf, ci, cd);
+  chain_mlow<L, 0>(buf, cd, tl);
+  mdiag = 0;
+#pragma unroll
+  for (int a = 0; a < 6; a++) mdiag += buf[a] * cd[a];
+  marm = (prim ? m.dof_d[DDS * dd + DD_ARMATURE] : 0.0);
+  mdiag += marm;
+  SYNC();
+  if (isdof) {
+    if (prim) for (int a = 0; a < 6; a++) S.U[U_CDOF + 6 * dd + a] = cd[a];
+    double* tb = &S.U[U_TB + (hh * NR + cp) * NR];
+#pragma unroll
+    for (int e = 0; e < NR; e++) tb[e] = tl[e];
+  }
+  SYNC();
+#pragma unroll
+  for (int e = 0; e < NR; e++) {
+    const double tr = S.U[U_TB + (hh * NR + e) * NR + (cp < NR ? cp : 0)];   // M[e][p], computed by the lane of dof e
+    double v = e <= cp ? tl[e] : tr;
+    if (e < 6) v = rootb ? 0.0 : v;   // the root-root block lives in copy A of the root rows
+    Mrow[e] = v;
+  }
+  if (rootb) mdiag = 0.0;
+  SYNC();
 }
 
-// composite inertias + joint-space inertia M (mj_crb); lower triangle + mirrored upper
-template <class L>
-__device__ void fwd_crb(const HModel& m, L& S, int lane) {
-  for (int it = lane; it < m.nbody * 10; it += L::W_) {
-    const int b = it / 10, k = it - 10 * b;
-    double s = 0;
-    if (b >= 1) for (int d = b; d < m.body_i[BIS * (b) + BI_SUBEND]; d++) s += S.U[U_CINERT + 10 * d + k];
-    S.U[U_CRB + it] = s;
-  }
-  for (int it = lane; it <= L::TRI_; it += L::W_) S.U[U_M + it] = 0.0;   // packed lower triangle, then the zero the chain solver's row gather points at
-  SYNC();
-  // buf_i = crb[body(i)] * cdof_i (6 per dof)
-  if (lane < NV) {
-    double buf[6];
-    inert_vec(buf, &S.U[U_CRB + 10 * m.dof_i[DIS * (lane) + DI_BODY]], &S.U[U_CDOF + 6 * lane]);
-    for (int a = 0; a < 6; a++) S.U[U_BUF + 6 * lane + a] = buf[a];
-  }
-  SYNC();
-  for (int it = lane; it < m.nmpair; it += L::W_) {
-    const int i = m.mpair[2 * (it) + 0], j = m.mpair[2 * (it) + 1];
-    double s = 0;
-    for (int a = 0; a < 6; a++) s += S.U[U_CDOF + 6 * j + a] * S.U[U_BUF + 6 * i + a];
-    if (i == j) s += m.dof_d[DDS * (i) + DD_ARMATURE];
-    S.U[U_M + TRI(i, j)] = s;   // j is an ancestor dof of i or i itself: j <= i
-  }
-  SYNC();
-}
-
-// mj_fwdVelocity: cvel, cdof_dot, bias force (RNE, no acceleration), passive damping, constraint reference
-template <class L>
-__device__ double fwd_velocity(const HModel& m, L& S, int lane, int dq /* dof whose bias force this lane returns (-1: none) */) {
-  // velocity seen by dof j when its cdof_dot is formed: sum over dof_prevmask[j]
-  if (lane < NV) {
-    const int j = lane;
-    unsigned mask = (unsigned)m.dof_i[DIS * (j) + DI_PREVMASK];
-    double v[6] = {0, 0, 0, 0, 0, 0};
-    const bool zero = mask == 0xFFFFFFFFu;  // translational dofs of a free joint: cdof_dot = 0
-    if (!zero)
-      while (mask) {
-        const int k = __ffs(mask) - 1;
-        mask &= mask - 1;
-        const double qv = S.qvel[k];
-        for (int a = 0; a < 6; a++) v[a] += S.U[U_CDOF + 6 * k + a] * qv;
-      }
-    double a3[3], b3[3], c3[3];
-    const double* cd = &S.U[U_CDOF + 6 * j];
-    cross3(a3, v, cd); cross3(b3, v, cd + 3); cross3(c3, v + 3, cd);
-    for (int a = 0; a < 3; a++) {
-      S.U[U_CDOFDOT + 6 * j + a] = zero ? 0.0 : a3[a];
-      S.U[U_CDOFDOT + 6 * j + 3 + a] = zero ? 0.0 : b3[a] + c3[a];
-    }
-  }
-  SYNC();
-  for (int it = lane; it < m.nbody * 6; it += L::W_) {
-    const int b = it / 6, a = it - 6 * b;
-    unsigned mask = (unsigned)m.body_i[BIS * (b) + BI_DOFMASK];
-    double cv = 0, ca = (a >= 3) ? -m.gravity[a - 3] : 0.0;
-    while (mask) {
-      const int k = __ffs(mask) - 1;
-      mask &= mask - 1;
-      const double qv = S.qvel[k];
-      cv += S.U[U_CDOF + 6 * k + a] * qv;
-      ca += S.U[U_CDOFDOT + 6 * k + a] * qv;
-    }
-    S.U[U_CVEL + it] = cv;
-    S.U[U_CACC + it] = ca;
-  }
-  SYNC();
-  if (lane >= 1 && lane < m.nbody) {
-    const int b = lane;
-    double t[6], t2[6], f[6];
-    inert_vec(t, &S.U[U_CINERT + 10 * b], &S.U[U_CACC + 6 * b]);
-    inert_vec(t2, &S.U[U_CINERT + 10 * b], &S.U[U_CVEL + 6 * b]);
-    const double* v = &S.U[U_CVEL + 6 * b];
-    double a3[3], b3[3], c3[3];
-    cross3(a3, v, t2); cross3(b3, v + 3, t2 + 3); cross3(c3, v, t2 + 3);
-    for (int a = 0; a < 3; a++) { f[a] = a3[a] + b3[a] + t[a]; f[3 + a] = c3[a] + t[3 + a]; }
-    for (int a = 0; a < 6; a++) S.U[U_CFRC + 6 * b + a] = f[a];
-  }
-  if (lane == 0) for (int a = 0; a < 6; a++) S.U[U_CFRC + a] = 0;
-  if (lane < 18) S.svel[lane] = S.U[U_CVEL + 6 * m.track_body[lane / 6] + lane % 6];
-  SYNC();
-  for (int it = lane; it < m.nbody * 6; it += L::W_) {   // subtree sums (they overwrite cvel, which is dead now)
-    const int b = it / 6, a = it - 6 * b;
-    double s = 0;
-    if (b >= 1) for (int d = b; d < m.body_i[BIS * (b) + BI_SUBEND]; d++) s += S.U[U_CFRC + 6 * d + a];
-    S.U[U_CSUB + it] = s;
-  }
-  SYNC();
-  double bias = 0;
-  if (dq >= 0) {
-    const int b = m.dof_i[DIS * (dq) + DI_BODY];
-    for (int a = 0; a < 6; a++) bias += S.U[U_CDOF + 6 * dq + a] * S.U[U_CSUB + 6 * b + a];
-  }
-  SYNC();
-  return bias;
-}
 // ---- collision (engine_collision_primitive.c restated).  Two passes over the same narrow phase: pass 0 counts the
 // contacts of each candidate pair (lane = pair), a wave scan gives every pair its slot range in pair order, pass 1
 // recomputes and writes straight into the LDS contact arrays (no per-lane contact records in scratch).
@@ -1519,26 +1545,17 @@ __device__ __forceinline__ double dense_lds_solve(L& S, const double (&Hrow)[NR]
 // counts in sums over dofs and writes the dof's results.  `cross`: some contact couples the two chains (group-uniform).
 template <class L>
 __device__ __forceinline__ void solve_tail(const HModel& m, const HParams& p, L& S, const int lane, const int flags, long long* st_prof,
-                                           const int dof, const bool prim, const bool cross, const double qapp, const double bias) {
+                                           const int dof, const bool prim, const bool cross, const double (&Mrow)[NR], const double mdiag,
+                                           const double marm, const double qapp, const double bias) {
   constexpr int W = L::W_;
   PROF_BEGIN();
   const int dd = dof >= 0 ? dof : 0;   // (lanes without a dof shadow dof 0; nothing of theirs is used)
   const int cp = lane & 15;            // chain layout: position in the 16-lane row
   const bool rootb = dof >= 0 && !prim;
   const int coff = 6 + ((lane >> 4) & 1) * NCH;   // first dof of this row's chain
-  // row of M of this lane's dof stays in registers for every product of the solve; its LDS slot dies here
-  double Mrow[NR];
-  double mdiag;
-  {
-    const int* ix = m.chain_idx + (lane & 31) * (NR + 1);   // offsets into the packed M (TRI_: the zero behind it, for entries outside the lane's block row)
-#pragma unroll
-    for (int e = 0; e < NR; e++) Mrow[e] = S.U[U_M + ix[e]];
-    mdiag = S.U[U_M + ix[NR]];
-  }
-  SYNC();
   // M x for the dof vector x held one element per dof lane
   auto mprod = [&](double x) {
-    double acc = 0;
+    double acc = marm * x;   // (the row's own entry of Mrow carries the diagonal without the armature)
     chain_mrow<L, 0>(Mrow, x, acc);
     if (cp < 6) acc = xhalf_sum(acc);   // root rows: the two copies hold the coupling to one chain each
     GROUP_SYNC(W);
@@ -1888,13 +1905,12 @@ __device__ __forceinline__ void substep(const HModel& m, const HParams& p, L& S,
   const int cp = lane & 15, hh = (lane >> 4) & 1;
   const int dof = (lane < 32 && cp < NR) ? (cp < 6 ? cp : 6 + hh * NCH + (cp - 6)) : -1;
   const bool prim = dof >= 0 && (cp >= 6 || hh == 0);
-  const double qapp = fwd_com(m, p, S, lane, dof);
+  fwd_com(m, p, S, lane);
   PROF_MARK(1);
-  const double bias = fwd_velocity(m, S, lane, dof);
+  double Mrow[NR], mdiag, marm, bias, qapp;
+  chain_dynamics(m, p, S, lane, dof, prim, Mrow, mdiag, marm, bias, qapp);
   PROF_MARK(5);
-  fwd_crb(m, S, lane);
-  PROF_MARK(2);
-  solve_tail(m, p, S, lane, flags, st_prof, dof, prim, cross, qapp, bias);
+  solve_tail(m, p, S, lane, flags, st_prof, dof, prim, cross, Mrow, mdiag, marm, qapp, bias);
 }
 // ------------------------------------------------------------------------------------------------ task layer
 __device__ __forceinline__ void sample_ref(const HParams& p, unsigned genv, unsigned stream, unsigned counter, unsigned slot0,
@@ -2715,7 +2731,7 @@ int humanoid_create(HumanoidEnv** out, const std::vector<int32_t>& mi, const std
   m.tolerance = md[LHW_DH_TOLERANCE]; m.meaninertia = md[LHW_DH_MEANINERTIA]; m.totalmass = md[LHW_DH_TOTALMASS];
   bool ok = true;
   // ---- derived structure
-  std::vector<int> level(nb, 0), subend(nb, 0), mp;
+  std::vector<int> level(nb, 0), subend(nb, 0);
   std::vector<unsigned> bmask(nb, 0), pmask(nv, 0);
   int nlevel = 1;
   for (int b = 1; b < nb; b++) { level[b] = level[parent[b]] + 1; nlevel = std::max(nlevel, level[b] + 1); }
@@ -2736,7 +2752,6 @@ int humanoid_create(HumanoidEnv** out, const std::vector<int32_t>& mi, const std
     } else {
       for (int a = dparent[d]; a >= 0; a = dparent[a]) pmask[d] |= 1u << a;
     }
-    for (int a = d; a >= 0; a = dparent[a]) { mp.push_back(d); mp.push_back(a); }
   }
   // ---- packed per-role tables
   std::vector<double> body_d((size_t)nb * BDS, 0.0), jnt_d((size_t)nj * JDS, 0.0), dof_d((size_t)nv * DDS, 0.0),
@@ -2829,7 +2844,7 @@ int humanoid_create(HumanoidEnv** out, const std::vector<int32_t>& mi, const std
     const int j = IF(LHW_IF_ACTUATOR_TRNID)[u];
     ai[AI_DOF] = jdof[j]; ai[AI_JNT] = j; ai[AI_CTRLLIMITED] = IF(LHW_IF_ACTUATOR_CTRLLIMITED)[u]; ai[AI_FORCELIMITED] = IF(LHW_IF_ACTUATOR_FORCELIMITED)[u];
   }
-  m.nlevel = nlevel; m.nmpair = (int)mp.size() / 2;
+  m.nlevel = nlevel;
   // chain structure (see chain_solve): dofs 0..5 one free joint, then two serial chains of equal length hanging off the root
   const int nch = (nv - 6) / 2;
   bool chain2 = nv >= 8 && nv == 6 + 2 * nch && nch <= 10 && jtype[djnt[0]] == JT_FREE;
@@ -2837,26 +2852,24 @@ int humanoid_create(HumanoidEnv** out, const std::vector<int32_t>& mi, const std
   for (int c = 0; chain2 && c < 2; c++)
     for (int k = 0; chain2 && k < nch; k++) chain2 = dparent[6 + c * nch + k] == (k == 0 ? 5 : 6 + c * nch + k - 1);
   if (!chain2) { humanoid_destroy(h); return lhw_fail(LHW_ERR_UNSUPPORTED, "the humanoid stepper needs a free root joint carrying two serial chains of (nv - 6) / 2 dofs each (the legs), dofs in that order"); }
-  m.chain2 = 1;
-  const int ntri = nv * (nv + 1) / 2;
-  std::vector<int> chain_idx(32 * (6 + std::max(nch, 0) + 1), ntri);
-  if (chain2) {
-    const int nr = 6 + nch;
-    auto tri = [](int i, int j) { return i >= j ? i * (i + 1) / 2 + j : j * (j + 1) / 2 + i; };
-    for (int lane = 0; lane < 32; lane++) {
-      const int cp = lane & 15, hh = lane >> 4;
-      if (cp >= nr) continue;
-      const int d = cp < 6 ? cp : 6 + hh * nch + (cp - 6);
-      int* ix = &chain_idx[(size_t)lane * (nr + 1)];
-      const bool rootb = cp < 6 && hh == 1;
-      for (int e = 0; e < nr; e++) {
-        const int c = e < 6 ? e : 6 + hh * nch + (e - 6);
-        ix[e] = (rootb && e < 6) ? ntri : tri(d, c);
-      }
-      ix[nr] = rootb ? ntri : tri(d, d);
+  // bodies by owner dof (the last dof on their path from the root): a chain lane owns what moves with its dof, the root's
+  // twelve lanes share what moves with the root
+  std::vector<std::vector<int>> owned(32);
+  {
+    int nroot = 0;
+    for (int b = 1; b < nb; b++) {
+      if (!bmask[b]) continue;
+      int od = 31;
+      while (!((bmask[b] >> od) & 1u)) od--;
+      if (od < 6) { owned[(nroot % 6) + 16 * ((nroot / 6) % 2)].push_back(b); nroot++; }
+      else { const int c = (od - 6) / nch, k = (od - 6) % nch; owned[16 * c + 6 + k].push_back(b); }
     }
   }
-  m.has_primbox = primbox_pairs > 0;
+  size_t max_owned = 1;
+  for (auto& o : owned) max_owned = std::max(max_owned, o.size());
+  std::vector<int> own_tab(32 * max_owned, -1);
+  for (int l = 0; l < 32; l++) for (size_t q = 0; q < owned[l].size(); q++) own_tab[l * max_owned + q] = owned[l][q];
+  m.max_owned = (int)max_owned;
   auto BID = [&](int f) { const int b = cfg->task_iparams[f]; return (b >= 0 && b < nbm) ? bmap[b] : -1; };
   m.track_body[0] = BID(LHW_TI_ROOT_BODY); m.track_body[1] = BID(LHW_TI_RFOOT_BODY); m.track_body[2] = BID(LHW_TI_LFOOT_BODY);
   ok = ok && (m.body_d = to_dev<double>(h, body_d.data(), body_d.size())) && (m.jnt_d = to_dev<double>(h, jnt_d.data(), jnt_d.size())) &&
@@ -2864,8 +2877,7 @@ int humanoid_create(HumanoidEnv** out, const std::vector<int32_t>& mi, const std
        (m.act_d = to_dev<double>(h, act_d.data(), act_d.size())) && (m.body_i = to_dev<int>(h, body_i.data(), body_i.size())) &&
        (m.jnt_i = to_dev<int>(h, jnt_i.data(), jnt_i.size())) && (m.dof_i = to_dev<int>(h, dof_i.data(), dof_i.size())) &&
        (m.geom_i = to_dev<int>(h, geom_i.data(), geom_i.size())) && (m.act_i = to_dev<int>(h, act_i.data(), act_i.size())) &&
-       (m.pair_i = to_dev<int>(h, pair_i.data(), pair_i.size())) && (m.mpair = to_dev<int>(h, mp.data(), mp.size())) &&
-       (m.chain_idx = to_dev<int>(h, chain_idx.data(), chain_idx.size()));
+       (m.pair_i = to_dev<int>(h, pair_i.data(), pair_i.size())) && (m.own_tab = to_dev<int>(h, own_tab.data(), own_tab.size()));
   HParams& p = h->p;
   memset(&p, 0, sizeof p);
   p.n_envs = cfg->n_envs; p.frame_skip = cfg->frame_skip; p.max_traj_len = cfg->max_traj_len; p.period = cfg->period;

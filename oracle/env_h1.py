@@ -84,8 +84,9 @@ class OracleH1Env:
         s, e, sp = self.seed, self.env_id, self.spec
         for k, b in enumerate(self.pbodies):
             base = 71 + 7 * k
-            for ax in range(3):
+            for ax in range(3):     # (the reference draws the three forces, then the three torques)
                 self.sim.xfrc_applied[b, ax] = rng.uniform(s, e, rng.STREAM_STEP, counter, base + ax, -sp.force_magnitude, sp.force_magnitude)
+            for ax in range(3):
                 self.sim.xfrc_applied[b, 3 + ax] = rng.uniform(s, e, rng.STREAM_STEP, counter, base + 3 + ax, -sp.torque_magnitude, sp.torque_magnitude)
             if rng.randint(s, e, rng.STREAM_STEP, counter, base + 6, 2) == 0:
                 self.sim.xfrc_applied[:] = 0
