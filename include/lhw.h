@@ -150,6 +150,47 @@ int lhw_env_step_range(LhwEnv* env, int32_t first, int32_t count, const float* a
 /* Parity hooks; HOST pointers, synchronous.  qpos [N][nq], qvel [N][nv] float64. */
 int lhw_env_get_state(LhwEnv* env, double* qpos_host, double* qvel_host);
 int lhw_env_set_state(LhwEnv* env, const double* qpos_host, const double* qvel_host);
+/* The batched sim facade: everything the reference's tasks read through RobotInterface for one control step
+ * (envs/common/robot_interface.py:75-82 qpos / qvel / qacc, :163-185 actuator position / velocity / torque, :242-250 foot body
+ * positions, :269-325 foot-floor contacts and ground reaction forces, :357-380 body velocities, :382-394 object positions,
+ * :472-484 self collisions) plus the arguments RobotBase.step passes to calc_reward (robots/robot_base.py:88-96), as the fused
+ * kernel saw them when it evaluated the reward of the LAST control step.  Slow-path hook for task code that is not compiled
+ * into the kernel (a user's BaseTask, tasks/base_task.py:12-83, or the reference's own tasks/rewards.py run as a cross-check):
+ * enable once, step, then read the [N][LHW_TASK_INPUT_DIM] float64 records on the host or, for on-device consumers, through the
+ * device pointer.  Derived fields follow MuJoCo's staleness (SURVEY note S): positions / velocities of bodies, contacts, qacc
+ * and actuator fields describe the last forward pass, qpos / qvel the state after it. */
+enum LhwTaskInput {
+  LHW_TIN_GRF_R = 0,          /* get_rfoot_grf(): sum over the right foot's floor contacts of |contact wrench| */
+  LHW_TIN_GRF_L = 1,
+  LHW_TIN_CONTACT_Z = 2,      /* min z of the foot-floor contact points (0 when there is none) */
+  LHW_TIN_FOOT_CONTACT = 3,   /* check_rfoot_floor_collision() or check_lfoot_floor_collision() */
+  LHW_TIN_SELF_COLLISION = 4, /* check_self_collisions() */
+  LHW_TIN_PHASE = 5,          /* task._phase, mode (WalkModes / stepping mode index) and mode_ref AFTER task.step() */
+  LHW_TIN_MODE = 6,
+  LHW_TIN_MODE_REF = 7,       /* 3 */
+  LHW_TIN_RFOOT_VEL = 10,     /* 3: linear velocity of the body frame origin (mj_objectVelocity), world axes; the tasks use its norm */
+  LHW_TIN_LFOOT_VEL = 13,     /* 3 */
+  LHW_TIN_ROOT_VEL_LOCAL = 16,/* 3: get_body_vel(root, frame=1)[0] */
+  LHW_TIN_ROOT_XPOS = 19,     /* 3 */
+  LHW_TIN_HEAD_XPOS = 22,     /* 3 */
+  LHW_TIN_RFOOT_XPOS = 25,    /* 3 */
+  LHW_TIN_LFOOT_XPOS = 28,    /* 3 */
+  LHW_TIN_QPOS = 32,          /* nq <= 19 */
+  LHW_TIN_QVEL = 51,          /* nv <= 18 */
+  LHW_TIN_QACC = 69,          /* nv */
+  LHW_TIN_ACT_POS = 87,       /* nu <= 12: get_act_joint_positions() */
+  LHW_TIN_ACT_VEL = 99,
+  LHW_TIN_ACT_TAU = 111,      /* get_act_joint_torques() */
+  LHW_TIN_PREV_TORQUE = 123,  /* calc_reward(prev_torque, prev_action, action) */
+  LHW_TIN_PREV_ACTION = 135,
+  LHW_TIN_ACTION = 147,
+  LHW_TASK_INPUT_DIM = 160
+};
+int lhw_env_enable_task_inputs(LhwEnv* env, int enable);
+/* HOST pointer [N][LHW_TASK_INPUT_DIM] float64, synchronous; humanoid tasks only, after lhw_env_enable_task_inputs(env, 1). */
+int lhw_env_get_task_inputs(LhwEnv* env, double* out_host);
+/* The same records on the device (valid until the env is destroyed or the export disabled); NULL while disabled. */
+int lhw_env_task_inputs_device(LhwEnv* env, double** out_dev);
 /* Actuated-joint fields of the LAST forward pass, as the reference's RobotInterface getters return them after env.step
  * (envs/common/robot_interface.py:163-185: get_act_joint_positions / _velocities / _torques = actuator_length / gear,
  * actuator_velocity / gear, actuator_force * gear).  HOST pointers [N][nu] float64, synchronous; humanoid tasks only. */

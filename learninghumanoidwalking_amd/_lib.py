@@ -31,6 +31,24 @@ class LhwEnvConfig(ctypes.Structure):
     ]
 
 
+# include/lhw.h: enum LhwTaskInput (offsets into one env's record, length)
+TASK_INPUT_DIM = 160
+TASK_INPUT_FIELDS = dict(grf_r=(0, 1), grf_l=(1, 1), contact_z=(2, 1), foot_contact=(3, 1), self_collision=(4, 1), phase=(5, 1), mode=(6, 1),
+                         mode_ref=(7, 3), rfoot_vel=(10, 3), lfoot_vel=(13, 3), root_vel_local=(16, 3), root_xpos=(19, 3), head_xpos=(22, 3),
+                         rfoot_xpos=(25, 3), lfoot_xpos=(28, 3), qpos=(32, 19), qvel=(51, 18), qacc=(69, 18), act_pos=(87, 12), act_vel=(99, 12),
+                         act_tau=(111, 12), prev_torque=(123, 12), prev_action=(135, 12), action=(147, 12))
+
+
+def split_task_inputs(rec, nq, nv, nu):
+    """[N][TASK_INPUT_DIM] records -> dict of named arrays (vectors cut to the model's nq / nv / nu)."""
+    cut = dict(qpos=nq, qvel=nv, qacc=nv, act_pos=nu, act_vel=nu, act_tau=nu, prev_torque=nu, prev_action=nu, action=nu)
+    out = {}
+    for k, (o, n) in TASK_INPUT_FIELDS.items():
+        n = cut.get(k, n)
+        out[k] = rec[:, o] if n == 1 else rec[:, o:o + n]
+    return out
+
+
 def sources():
     return sorted(glob.glob(os.path.join(_HERE, "csrc", "*.hip")))
 
@@ -78,6 +96,9 @@ def declare(L):
     sig("lhw_env_pop_fault_stats", [vp, ctypes.POINTER(i64), ctypes.POINTER(i64)])
     sig("lhw_env_pop_rerun_count", [vp, ctypes.POINTER(i64)])
     sig("lhw_env_get_actuator_state", [vp, vp, vp, vp])
+    sig("lhw_env_enable_task_inputs", [vp, i32])
+    sig("lhw_env_get_task_inputs", [vp, vp])
+    sig("lhw_env_task_inputs_device", [vp, ctypes.POINTER(vp)])
     sig("lhw_env_debug_wave_cycles", [vp, vp])
     sig("lhw_debug_gemm", [i32, i32, i32, i32, i32, i32, vp, i32, vp, i32, vp, i32, vp, i32, vp, i32, i32, vp, vp, vp, vp])
     sig("lhw_env_phase_cycles", [vp, ctypes.c_int, vp])

@@ -157,6 +157,17 @@ class BatchedEnv:
         _lib.check(self._L.lhw_env_get_actuator_state(self._h, out[0].ctypes.data, out[1].ctypes.data, out[2].ctypes.data))
         return tuple(out)
 
+    def enable_task_inputs(self, enable: bool = True):
+        """Arm / disarm the batched sim facade (include/lhw.h: LhwTaskInput): from the next control step on the kernel exports,
+        per env, what the reference's tasks read through RobotInterface and what RobotBase.step passes to calc_reward."""
+        _lib.check(self._L.lhw_env_enable_task_inputs(self._h, int(bool(enable))))
+
+    def get_task_inputs(self) -> dict:
+        """Named float64 arrays of the last control step's task inputs (host copy, synchronous)."""
+        rec = np.zeros((self.n_envs, _lib.TASK_INPUT_DIM))
+        _lib.check(self._L.lhw_env_get_task_inputs(self._h, rec.ctypes.data))
+        return _lib.split_task_inputs(rec, self.nq, self.nv, self.act_dim)
+
     def wave_cycles(self):
         """Per-env shader-clock cycles of the last control-step launch (diagnostic; the first call only arms the recording)."""
         out = np.zeros(self.n_envs, dtype=np.int64)

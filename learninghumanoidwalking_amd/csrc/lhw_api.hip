@@ -276,6 +276,7 @@ extern "C" int lhw_env_debug_wave_cycles(LhwEnv* e, int64_t* out) {
   return LHW_OK;
 }
 
+
 extern "C" int lhw_env_pop_fault_stats(LhwEnv* e, int64_t* contact_overflow, int64_t* diverged) {
   if (!e) return lhw_fail(LHW_ERR_ARG, "null env");
   if (contact_overflow) *contact_overflow = 0;
@@ -291,6 +292,24 @@ extern "C" int lhw_env_pop_fault_stats(LhwEnv* e, int64_t* contact_overflow, int
   return LHW_OK;
 }
 
+extern "C" int lhw_env_enable_task_inputs(LhwEnv* e, int enable) {
+  if (!e || !e->hum) return lhw_fail(LHW_ERR_UNSUPPORTED, "task inputs exist for the humanoid tasks only");
+  HIPCHK(hipSetDevice(e->device));
+  if (humanoid_task_inputs(e->hum, enable ? 1 : 0, nullptr, nullptr)) return lhw_fail(LHW_ERR_HIP, "task input buffer");
+  return LHW_OK;
+}
+extern "C" int lhw_env_get_task_inputs(LhwEnv* e, double* out_host) {
+  if (!e || !e->hum || !out_host) return lhw_fail(LHW_ERR_ARG, "null argument / not a humanoid task");
+  HIPCHK(hipSetDevice(e->device));
+  const int rc = humanoid_task_inputs(e->hum, -1, out_host, nullptr);
+  if (rc == -2) return lhw_fail(LHW_ERR_ARG, "lhw_env_get_task_inputs: call lhw_env_enable_task_inputs(env, 1) first");
+  if (rc) return lhw_fail(LHW_ERR_HIP, "task input copy");
+  return LHW_OK;
+}
+extern "C" int lhw_env_task_inputs_device(LhwEnv* e, double** out_dev) {
+  if (!e || !e->hum || !out_dev) return lhw_fail(LHW_ERR_ARG, "null argument / not a humanoid task");
+  return humanoid_task_inputs(e->hum, -1, nullptr, out_dev) ? lhw_fail(LHW_ERR_HIP, "task input buffer") : LHW_OK;
+}
 extern "C" int lhw_env_get_actuator_state(LhwEnv* e, double* pos_host, double* vel_host, double* torque_host) {
   if (!e) return lhw_fail(LHW_ERR_ARG, "null env");
   if (!e->hum) return lhw_fail(LHW_ERR_UNSUPPORTED, "actuator state is kept by the humanoid steppers only");

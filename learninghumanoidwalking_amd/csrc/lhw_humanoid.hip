@@ -213,6 +213,7 @@ struct HState {
   unsigned char* slow;  // [N] set by the two-envs-per-wave kernel for an env that exceeded its contact capacity: nothing of that env
                         // was written, and the one-env-per-wave kernel repeats its control step
   long long* prof; // optional [16] per-phase cycle counters accumulated by env 0 (NULL = off)
+  double* tin;     // optional [N][LHW_TASK_INPUT_DIM]: the task layer's inputs of the last control step (lhw_env_enable_task_inputs)
   long long* wave_cyc;  // optional [N] shader-clock cycles the env's group spent in the last control-step launch (NULL = off)
 };
 #define PROF_BEGIN() long long prof_t = (st_prof && lane == 0) ? (long long)clock64() : 0   // lane = lane within the group
@@ -413,24 +414,53 @@ __device__ __forceinline__ int gbcast_i(int v, int src) {
     return group_id<W>() ? b : a;
   }
 }
-template <int W>
-__device__ __forceinline__ double gbcast(double v, int src) {
-  return __hiloint2double(gbcast_i<W>(__double2hiint(v), src), gbcast_i<W>(__double2loint(v), src));
+// value held by lane SRC of the caller's 16-lane row: one v_mov_b64_dpp (row_newbcast, gfx90a+)
+template <int SRC>
+__device__ __forceinline__ double rbc(double v) {
+  const long long lv = __double_as_longlong(v);
+  return __longlong_as_double(__builtin_amdgcn_update_dpp(lv, lv, 0x150 + SRC, 0xf, 0xf, false));
 }
+// The values of this lane and of lane ^ 16 (v_permlane16_swap, gfx950), as (value of the even row, value of the odd row) of the
+// row pair -- the same ordered pair in both lanes, so a reduction over it is bit-identical in the two rows.
+__device__ __forceinline__ void xhalf_pair(double v, double& even, double& odd) {
+  const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+  const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+  const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+  even = __hiloint2double((int)b[0], (int)a[0]);
+  odd = __hiloint2double((int)b[1], (int)a[1]);
+}
+__device__ __forceinline__ double xhalf_sum(double v) {   // v(this lane) + v(lane ^ 16)
+  double e, o;
+  xhalf_pair(v, e, o);
+  return e + o;
+}
+// likewise for lane ^ 32 (v_permlane32_swap)
+__device__ __forceinline__ void x32_pair(double v, double& lower, double& upper) {
+  const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+  const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+  const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+  lower = __hiloint2double((int)b[0], (int)a[0]);
+  upper = __hiloint2double((int)b[1], (int)a[1]);
+}
+// Group reductions: row_shr scan inside each 16-lane row (DPP), the row total from lane 15 (row_newbcast), then the rows of the
+// group are combined with lane-swap instructions -- no v_readlane / SGPR round trip, ~18 VALU instructions for W = 32.
 template <int W>
 __device__ __forceinline__ double gsum(double v) {
   v += dpp_d<0x111, 0xf>(v, 0.0); v += dpp_d<0x112, 0xf>(v, 0.0); v += dpp_d<0x114, 0xf>(v, 0.0); v += dpp_d<0x118, 0xf>(v, 0.0);
-  v += dpp_d<0x142, 0xa>(v, 0.0);
-  if constexpr (W == 64) v += dpp_d<0x143, 0xc>(v, 0.0);
-  return gbcast<W>(v, W - 1);
+  v = xhalf_sum(rbc<15>(v));
+  if constexpr (W == 64) { double l, u; x32_pair(v, l, u); v = l + u; }
+  return v;
 }
 template <int W>
 __device__ __forceinline__ double gmin(double v) {
   const double inf = __longlong_as_double(0x7ff0000000000000ll);
   v = fmin(v, dpp_d<0x111, 0xf>(v, inf)); v = fmin(v, dpp_d<0x112, 0xf>(v, inf)); v = fmin(v, dpp_d<0x114, 0xf>(v, inf));
-  v = fmin(v, dpp_d<0x118, 0xf>(v, inf)); v = fmin(v, dpp_d<0x142, 0xa>(v, inf));
-  if constexpr (W == 64) v = fmin(v, dpp_d<0x143, 0xc>(v, inf));
-  return gbcast<W>(v, W - 1);
+  v = fmin(v, dpp_d<0x118, 0xf>(v, inf));
+  double e, o;
+  xhalf_pair(rbc<15>(v), e, o);
+  v = fmin(e, o);
+  if constexpr (W == 64) { double l, u; x32_pair(v, l, u); v = fmin(l, u); }
+  return v;
 }
 // inclusive prefix sum across the group; *total receives the group total
 template <int W>
@@ -537,18 +567,6 @@ __device__ __forceinline__ double row_dot(const double (&row)[NV], const double*
 // never read), its diagonal entry in dg, and element p of the right-hand side.
 #define NCH ((L::NV_ - 6) / 2)
 #define NR (6 + NCH)
-template <int SRC>
-__device__ __forceinline__ double rbc(double v) {   // value held by lane SRC of the caller's 16-lane row
-  const long long lv = __double_as_longlong(v);
-  return __longlong_as_double(__builtin_amdgcn_update_dpp(lv, lv, 0x150 + SRC, 0xf, 0xf, false));
-}
-// v(this lane) + v(lane ^ 16): the same sum (row 0 + row 1 of the pair, in this order) in both rows
-__device__ __forceinline__ double xhalf_sum(double v) {
-  const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
-  const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
-  const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
-  return __hiloint2double((int)b[0], (int)a[0]) + __hiloint2double((int)b[1], (int)a[1]);
-}
 __device__ __forceinline__ double rcp_f64(double d) {
   double x = __builtin_amdgcn_rcp(d);
   x = fma(fma(-d, x, 1.0), x, x);
@@ -715,7 +733,7 @@ __device__ void fwd_kinematics(const HModel& m, L& S, int lane) {
   }
 }
 
-// subtree com of the (single) dynamic tree rooted at body 1, cinert  (mj_comPos; cdof: chain_dynamics)
+// subtree com of the (single) dynamic tree rooted at body 1, cinert, cdof  (mj_comPos)
 template <class L>
 __device__ void fwd_com(const HModel& m, const HParams& p, L& S, int lane) {
   double ms = 0, mx = 0, my = 0, mz = 0;
@@ -741,6 +759,25 @@ __device__ void fwd_com(const HModel& m, const HParams& p, L& S, int lane) {
     ci[4] -= mass * dif[0] * dif[2];
     ci[5] -= mass * dif[1] * dif[2];
     ci[6] = mass * dif[0]; ci[7] = mass * dif[1]; ci[8] = mass * dif[2]; ci[9] = mass;
+  }
+  if (lane < NV) {
+    const int d = lane, j = m.dof_i[DIS * (d) + DI_JNT], b = m.dof_i[DIS * (d) + DI_BODY], kind = m.dof_i[DIS * (d) + DI_KIND];
+    const int t = kind <= 1 ? JT_FREE : (kind == 2 ? JT_SLIDE : JT_HINGE), k = d - m.jnt_i[JIS * (j) + JI_DADR];
+    double off[3], ax[3], c[6];
+    for (int a = 0; a < 3; a++) off[a] = com[a] - S.U[U_XANCHOR + 3 * j + a];
+    if (t == JT_FREE && k < 3) {
+      for (int a = 0; a < 6; a++) c[a] = 0;
+      c[3 + k] = 1;
+    } else if (t == JT_SLIDE) {
+      c[0] = c[1] = c[2] = 0;
+      for (int a = 0; a < 3; a++) c[3 + a] = S.U[U_XAXIS + 3 * j + a];
+    } else {
+      if (t == JT_FREE) { ax[0] = S.U[U_XMAT + 9 * b + (k - 3)]; ax[1] = S.U[U_XMAT + 9 * b + 3 + (k - 3)]; ax[2] = S.U[U_XMAT + 9 * b + 6 + (k - 3)]; }
+      else for (int a = 0; a < 3; a++) ax[a] = S.U[U_XAXIS + 3 * j + a];
+      c[0] = ax[0]; c[1] = ax[1]; c[2] = ax[2];
+      cross3(c + 3, ax, off);
+    }
+    for (int a = 0; a < 6; a++) S.U[U_CDOF + 6 * d + a] = c[a];
   }
   SYNC();
 }
@@ -781,21 +818,11 @@ __device__ __forceinline__ void chain_dynamics(const HModel& m, const HParams& p
                                                double (&Mrow)[NR], double& mdiag, double& marm, double& bias, double& qapp) {
   const int cp = lane & 15, hh = (lane >> 4) & 1, dd = dof >= 0 ? dof : 0;
   const bool isdof = dof >= 0, rootb = isdof && !prim;
-  // ---- cdof of this lane's dof (mj_comPos)
+  // ---- cdof of this lane's dof (written by fwd_com, lane = dof)
   double cd[6] = {0, 0, 0, 0, 0, 0}, qv = 0;
   if (isdof) {
-    const int j = m.dof_i[DIS * dd + DI_JNT], b = m.dof_i[DIS * dd + DI_BODY], kind = m.dof_i[DIS * dd + DI_KIND];
-    const int k = dd - m.jnt_i[JIS * j + JI_DADR];
-    double off[3], ax[3];
-    for (int a = 0; a < 3; a++) off[a] = S.com[a] - S.U[U_XANCHOR + 3 * j + a];
-    if (kind == 0) cd[3 + k] = 1;                              // free joint, translation k
-    else if (kind == 2) for (int a = 0; a < 3; a++) cd[3 + a] = S.U[U_XAXIS + 3 * j + a];   // slide
-    else {
-      if (kind == 1) { ax[0] = S.U[U_XMAT + 9 * b + (k - 3)]; ax[1] = S.U[U_XMAT + 9 * b + 3 + (k - 3)]; ax[2] = S.U[U_XMAT + 9 * b + 6 + (k - 3)]; }
-      else for (int a = 0; a < 3; a++) ax[a] = S.U[U_XAXIS + 3 * j + a];
-      cd[0] = ax[0]; cd[1] = ax[1]; cd[2] = ax[2];
-      cross3(cd + 3, ax, off);
-    }
+#pragma unroll
+    for (int a = 0; a < 6; a++) cd[a] = S.U[U_CDOF + 6 * dd + a];
     qv = S.qvel[dd];
   }
   // ---- mj_xfrcAccumulate: Cartesian force / torque applied at the com of the perturbed bodies -> joint space
@@ -878,7 +905,6 @@ __device__ __forceinline__ void chain_dynamics(const HModel& m, const HParams& p
   mdiag += marm;
   SYNC();
   if (isdof) {
-    if (prim) for (int a = 0; a < 6; a++) S.U[U_CDOF + 6 * dd + a] = cd[a];
     double* tb = &S.U[U_TB + (hh * NR + cp) * NR];
 #pragma unroll
     for (int e = 0; e < NR; e++) tb[e] = tl[e];
@@ -2344,6 +2370,34 @@ __device__ __forceinline__ bool control_step(const HModel& m, const HParams& p, 
           const double z = S.qpos[2];
           terminated = z < 0.9 || z > 1.4 || self_collision;  // standing_task.py:111-131
         }
+        if (st.tin) {   // the batched sim facade (include/lhw.h: LhwTaskInput)
+          double* ti = st.tin + (size_t)env * LHW_TASK_INPUT_DIM;
+          double rv3[3], lv3[3], rl3[3], vl3[3];
+          body_linvel(S, 1, p.rfoot_body, rv3); body_linvel(S, 2, p.lfoot_body, lv3); body_linvel(S, 0, p.root_body, rl3);
+          matT_vec(vl3, S.rootmat, rl3);
+          if (lane == 0) {
+            ti[LHW_TIN_GRF_R] = grf_r; ti[LHW_TIN_GRF_L] = grf_l; ti[LHW_TIN_CONTACT_Z] = cz < 1e299 ? cz : 0.0;
+            int anyc = 0;
+            for (int c = 0; c < S.ncon; c++) {
+              const int b1 = m.geom_i[GIS * (S.con_g1[c]) + GI_BODY], b2 = m.geom_i[GIS * (S.con_g2[c]) + GI_BODY];
+              if (m.body_i[BIS * (b1) + BI_ROOT] != p.root_body && (b2 == p.rfoot_body || b2 == p.lfoot_body)) anyc = 1;
+            }
+            ti[LHW_TIN_FOOT_CONTACT] = anyc; ti[LHW_TIN_SELF_COLLISION] = self_collision ? 1.0 : 0.0;
+            ti[LHW_TIN_PHASE] = phase; ti[LHW_TIN_MODE] = mode;
+            for (int a = 0; a < 3; a++) {
+              ti[LHW_TIN_MODE_REF + a] = mode_ref[a];
+              ti[LHW_TIN_RFOOT_VEL + a] = rv3[a]; ti[LHW_TIN_LFOOT_VEL + a] = lv3[a]; ti[LHW_TIN_ROOT_VEL_LOCAL + a] = vl3[a];
+              ti[LHW_TIN_ROOT_XPOS + a] = S.xpos[3 * p.root_body + a]; ti[LHW_TIN_HEAD_XPOS + a] = S.xpos[3 * p.head_body + a];
+              ti[LHW_TIN_RFOOT_XPOS + a] = S.xpos[3 * p.rfoot_body + a]; ti[LHW_TIN_LFOOT_XPOS + a] = S.xpos[3 * p.lfoot_body + a];
+            }
+          }
+          if (lane < m.nq) ti[LHW_TIN_QPOS + lane] = S.qpos[lane];
+          if (lane < NV) { ti[LHW_TIN_QVEL + lane] = S.qvel[lane]; ti[LHW_TIN_QACC + lane] = S.qacc[lane]; }
+          if (lane < m.nu) {
+            ti[LHW_TIN_ACT_POS + lane] = S.sq[lane]; ti[LHW_TIN_ACT_VEL + lane] = S.sv[lane]; ti[LHW_TIN_ACT_TAU + lane] = cur_tq;
+            ti[LHW_TIN_PREV_TORQUE + lane] = prevtq; ti[LHW_TIN_PREV_ACTION + lane] = prevact; ti[LHW_TIN_ACTION + lane] = target;
+          }
+        }
         // failure detection: a non-finite state ends the episode (counted in ep_stats[4]); outputs are sanitised so one
         // diverged env cannot poison the batch (the reference has no equivalent: a NaN there propagates into the buffers)
         {
@@ -2870,6 +2924,7 @@ int humanoid_create(HumanoidEnv** out, const std::vector<int32_t>& mi, const std
   std::vector<int> own_tab(32 * max_owned, -1);
   for (int l = 0; l < 32; l++) for (size_t q = 0; q < owned[l].size(); q++) own_tab[l * max_owned + q] = owned[l][q];
   m.max_owned = (int)max_owned;
+  m.has_primbox = primbox_pairs > 0;
   auto BID = [&](int f) { const int b = cfg->task_iparams[f]; return (b >= 0 && b < nbm) ? bmap[b] : -1; };
   m.track_body[0] = BID(LHW_TI_ROOT_BODY); m.track_body[1] = BID(LHW_TI_RFOOT_BODY); m.track_body[2] = BID(LHW_TI_LFOOT_BODY);
   ok = ok && (m.body_d = to_dev<double>(h, body_d.data(), body_d.size())) && (m.jnt_d = to_dev<double>(h, jnt_d.data(), jnt_d.size())) &&
@@ -2958,7 +3013,7 @@ int humanoid_create(HumanoidEnv** out, const std::vector<int32_t>& mi, const std
   if (rec) h->dev_allocs.push_back(rec);
   if (irec) h->dev_allocs.push_back(irec);
   if (eps) h->dev_allocs.push_back(eps);
-  h->st.rec = (double*)rec; h->st.irec = (int*)irec; h->st.ep_stats = (double*)eps; h->st.prof = nullptr; h->st.wave_cyc = nullptr;
+  h->st.rec = (double*)rec; h->st.irec = (int*)irec; h->st.ep_stats = (double*)eps; h->st.prof = nullptr; h->st.wave_cyc = nullptr; h->st.tin = nullptr;
   if (!ok) { humanoid_destroy(h); return lhw_fail(LHW_ERR_HIP, "humanoid_create: device allocation failed or bad body ids"); }
   *obs_dim = stepping ? 39 : (walk ? 37 : (h1walk ? 43 : 35)); *act_dim = nu; *n_terms = ((walk && !stepping) || h1walk) ? 10 : 6;
   p.reset_template = -1;
@@ -3056,6 +3111,26 @@ int humanoid_wave_cycles(HumanoidEnv* h, long long* out) {
   if (!out) return 0;
   if (hipDeviceSynchronize() != hipSuccess) return -1;
   return hipMemcpy(out, h->st.wave_cyc, N * sizeof(long long), hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
+}
+// batched sim facade: per-env record of the task layer's inputs (LhwTaskInput); enable allocates, disable stops the export
+int humanoid_task_inputs(HumanoidEnv* h, int enable, double* out_host, double** out_dev) {
+  const size_t n = (size_t)h->p.n_envs * LHW_TASK_INPUT_DIM;
+  if (enable == 1 && !h->st.tin) {
+    void* d = nullptr;
+    if (hipMalloc(&d, n * sizeof(double)) != hipSuccess) return -1;
+    (void)hipMemset(d, 0, n * sizeof(double));
+    h->dev_allocs.push_back(d);
+    h->st.tin = (double*)d;
+  } else if (enable == 0) {
+    h->st.tin = nullptr;   // (the buffer is released with the env)
+  }
+  if (out_dev) *out_dev = h->st.tin;
+  if (out_host) {
+    if (!h->st.tin) return -2;
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (hipMemcpy(out_host, h->st.tin, n * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  }
+  return 0;
 }
 int humanoid_profile(HumanoidEnv* h, int enable, long long* out16) {
   if (enable && !h->st.prof) {

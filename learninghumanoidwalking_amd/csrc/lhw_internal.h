@@ -25,5 +25,6 @@ void humanoid_set_iteration(HumanoidEnv* h, int64_t it);
 int humanoid_occupancy();
 int humanoid_wave_cycles(HumanoidEnv* h, long long* out);
 int humanoid_profile(HumanoidEnv* h, int enable, long long* out16);
+int humanoid_task_inputs(HumanoidEnv* h, int enable /* -1: leave */, double* out_host, double** out_dev);
 int humanoid_actuator_state(HumanoidEnv* h, double* pos, double* vel, double* tq);
 int humanoid_step_record(HumanoidEnv* h, double* seq, double* floor_z, int32_t* istate);

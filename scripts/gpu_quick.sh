@@ -2,9 +2,9 @@
 # quick GPU check of a stepper change: jvrc GPU tests, short bench, phase profile, SQ counters.  $1 = output tag
 TAG=${1:-q}; OUT=/root/repo/gpurun_out/$TAG; mkdir -p $OUT
 cd /root/repo
-timeout 900 python -m pytest tests -m gpu -x -q ${PYTEST_K:+-k "$PYTEST_K"} > $OUT/pytest.txt 2>&1; tail -3 $OUT/pytest.txt
-python bench.py --steps 5 --warmup 2 --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/bench.json
-python scripts/jvrc_phase_profile.py 4096 > $OUT/phase.txt 2>/dev/null
+timeout 400 python -m pytest tests -m gpu -x -q ${PYTEST_K:+-k "$PYTEST_K"} > $OUT/pytest.txt 2>&1; tail -3 $OUT/pytest.txt
+timeout 300 python bench.py --steps 5 --warmup 2 --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/bench.json
+timeout 120 python scripts/jvrc_phase_profile.py 4096 > $OUT/phase.txt 2>/dev/null
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/pm
 timeout 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_ANY --output-format csv -d /tmp/pm -- python /root/repo/scripts/step_only.py 4096 4 > /tmp/pm.log 2>&1

@@ -116,6 +116,13 @@ static void resolve(Block& b) {
           if (ok) { if (i & 16) l.res = b.lanes[w0 + s].val2; else l.res2 = b.lanes[w0 + s].val; }
           break;
         }
+        case OP_PERMLANE32_SWAP: {   // upper half of vdst <-> lower half of src (partner lane i ^ 32)
+          const int s = i ^ 32;
+          const bool ok = at(b, w0 + s, OP_PERMLANE32_SWAP);
+          l.res = l.val; l.res2 = l.val2;
+          if (ok) { if (i & 32) l.res = b.lanes[w0 + s].val2; else l.res2 = b.lanes[w0 + s].val; }
+          break;
+        }
         case OP_BALLOT: l.res64 = ballot; break;
         default: break;
       }

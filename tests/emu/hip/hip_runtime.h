@@ -129,6 +129,12 @@ static inline emu_uint2 emu_permlane16_swap(unsigned a, unsigned b, bool, bool) 
   emu::block_here();
   return emu_uint2{{l.res, l.res2}};
 }
+static inline emu_uint2 emu_permlane32_swap(unsigned a, unsigned b, bool, bool) {
+  emu::Lane& l = emu::cur();
+  l.op = emu::OP_PERMLANE32_SWAP; l.val = a; l.val2 = b;
+  emu::block_here();
+  return emu_uint2{{l.res, l.res2}};
+}
 static inline int emu_readlane(int v, int lane) {
   emu::Lane& l = emu::cur();
   l.op = emu::OP_READLANE; l.val = (uint32_t)v; l.sel = lane;
@@ -171,6 +177,7 @@ static inline void __syncthreads() {
 #define __builtin_amdgcn_update_dpp emu_update_dpp
 #define __builtin_amdgcn_readlane emu_readlane
 #define __builtin_amdgcn_permlane16_swap emu_permlane16_swap
+#define __builtin_amdgcn_permlane32_swap emu_permlane32_swap
 #define __builtin_amdgcn_ds_swizzle emu_ds_swizzle
 #define __builtin_amdgcn_ds_bpermute emu_ds_bpermute
 #define __builtin_amdgcn_wave_barrier emu_wave_barrier

@@ -139,6 +139,67 @@ def run_env(tag, make_env, seed, T, act_dim, act_std, out, extra=None):
           f"mean reward {np.mean(log['rew']):.4f}")
 
 
+def gen_rollout_worker(out_path):
+    """EXECUTES the reference's RolloutWorker.sample (rl/workers/rollout_worker.py:97-199) + PPOBuffer on a scripted env with
+    the reference's own Gaussian_FF_Actor / FF_V: three consecutive sample() calls whose episodes end by termination, by
+    truncation at max_traj_len, in the middle of a buffer (carry-over) and exactly at a buffer end."""
+    import torch
+    ray = types.ModuleType("ray")
+    ray.remote = lambda *a, **k: (a[0] if a and callable(a[0]) else (lambda c: c))
+    sys.modules["ray"] = ray
+    tb = types.ModuleType("torch.utils.tensorboard")
+    tb.SummaryWriter = type("SummaryWriter", (), {"__init__": lambda self, *a, **k: None})
+    sys.modules["torch.utils.tensorboard"] = tb
+    from rl.policies.actor import Gaussian_FF_Actor
+    from rl.policies.critic import FF_V
+    from rl.workers.rollout_worker import RolloutWorker
+    torch.manual_seed(5)
+    D, A, MAXLEN, STEPS = 6, 3, 7, 20
+    rs = np.random.default_rng(9)
+    table = rs.normal(size=(400, D))
+    rewards = rs.uniform(0, 1, size=400)
+    term_at = {4, 30, 33, 39}            # env steps (global count) that terminate; 39 is the last step of the 2nd buffer
+
+    class Env:
+        def __init__(self):
+            self.k = 0                     # global step counter
+            self.resets = 0
+            self.robot = types.SimpleNamespace(iteration_count=0)
+            self.log = []
+
+        def reset(self):
+            self.resets += 1
+            self.log.append(("reset", self.k))
+            return table[(self.k * 7 + 3 * self.resets) % 400].copy()
+
+        def step(self, a):
+            k = self.k
+            self.k += 1
+            return table[(k * 7 + 1) % 400] + 0.01 * float(np.sum(a)), rewards[k], k in term_at, {}
+
+    policy = Gaussian_FF_Actor(D, A, layers=(16, 16), init_std=0.2, learn_std=False, bounded=False)
+    critic = FF_V(D, layers=(16, 16))
+    policy.obs_mean = critic.obs_mean = torch.zeros(D)
+    policy.obs_std = critic.obs_std = torch.ones(D)
+    w = RolloutWorker(Env, policy, critic, seed=None, worker_id=0)
+    out = {}
+    for call in range(3):
+        b = w.sample(0.99, 0.95, STEPS, MAXLEN, deterministic=True)
+        pre = f"c{call}_"
+        for f in ("states", "actions", "rewards", "values", "returns", "dones", "traj_idx", "ep_lens", "ep_rewards"):
+            out[pre + f] = getattr(b, f).numpy().copy()
+        out[pre + "carried"] = np.array([w.current_state is not None])
+        out[pre + "resets"] = np.array([w.env.resets])
+        out[pre + "final_state"] = (w.current_state.numpy().copy() if w.current_state is not None else np.zeros(D, np.float32))
+    with torch.no_grad():
+        for k, v in list(policy.state_dict().items()) + [("c_" + k, v) for k, v in critic.state_dict().items()]:
+            out["w_" + k] = v.numpy().copy()
+    out["table"], out["rew_table"], out["term_at"] = table, rewards, np.array(sorted(term_at))
+    out["cfg"] = np.array([D, A, MAXLEN, STEPS])
+    np.savez_compressed(out_path, **out)
+    print("wrote", out_path, "resets:", w.env.resets, "env log:", w.env.log)
+
+
 def main():
     _install()
     from learninghumanoidwalking_amd.envs.h1 import H1_STANDIN_XML
@@ -165,7 +226,12 @@ def main():
     run_env("h1_walk_a", H1WalkEnv, seed=7, T=220, act_dim=10, act_std=0.15, out=out)
     np.savez_compressed(os.path.join(OUT, "refenv.npz"), **out)
     print("wrote", os.path.join(OUT, "refenv.npz"))
+    gen_rollout_worker(os.path.join(OUT, "rollout_worker.npz"))
 
 
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "rollout":
+        _install()
+        gen_rollout_worker(os.path.join(OUT, "rollout_worker.npz"))
+    else:
+        main()
