@@ -76,6 +76,9 @@ def check_env(env, spec, steps, rs):
     worst = 0.0
     for t in range(steps):
         act = (rs.normal(size=(env.n_envs, 12)) * 0.3).astype(np.float32)
+        if hasattr(env.rew_terms, "cpu"):      # the product env takes device tensors
+            import torch
+            act = torch.from_numpy(act).cuda()
         env.step(act)
         ti = env.get_task_inputs()
         terms = np.array(env.rew_terms.cpu() if hasattr(env.rew_terms, "cpu") else env.rew_terms, dtype=np.float64)
