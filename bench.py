@@ -116,12 +116,16 @@ def main():
     if share:
         local_rank = 0
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # LHW_FORCE_DIST=1 (tests only): initialise the process group even for one rank, so that the RCCL branch below -- otherwise
+    # reached only on a multi-GPU node -- executes on a 1-GPU box
+    use_dist = world > 1 or os.environ.get("LHW_FORCE_DIST") == "1"
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         if share:
             dist.init_process_group("gloo")
         else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     from learninghumanoidwalking_amd import envs as lenvs
@@ -143,7 +147,7 @@ def main():
         algo.kernels.set_obs_norm(algo.obs_rms.mean, algo.obs_rms.std)
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -216,7 +220,7 @@ def main():
         torch.cuda.synchronize()
         isolated_ms = float(np.median([a.elapsed_time(b) for a, b in evs]))
     tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-    if world > 1:
+    if use_dist:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     elapsed = float(tmax[0])
 
@@ -283,7 +287,7 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = run_cpu_baseline(env_name)
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -1385,24 +1385,6 @@ __device__ void fwd_collision(const HModel& m, const HParams& p, L& S, int lane,
     if (BOXBOX && ter && ter[T_FLOOR] == 0.0 && ((g1 >= p.box_geom0 && g1 < p.box_geom0 + p.nbox) || (g2 >= p.box_geom0 && g2 < p.box_geom0 + p.nbox)))
       have = false;
   }
-  // bounding-sphere test (mj_collideGeoms does the same with geom_rbound): a pair whose bounding spheres are further apart than
-  // the margin cannot produce a contact, and the narrow-phase code of a pair type that no lane needs is never executed
-  if (have) {
-    const int t1 = m.geom_i[GIS * g1 + GI_TYPE], t2 = m.geom_i[GIS * g2 + GI_TYPE];
-    auto rbound = [&](int g, int t) {
-      const double a = m.geom_d[GDS * g + GD_SIZE], b = m.geom_d[GDS * g + GD_SIZE + 1], c = m.geom_d[GDS * g + GD_SIZE + 2];
-      return t == G_SPHERE ? a : (t == G_CAPSULE ? a + b : sqrt(a * a + b * b + c * c));
-    };
-    const double d[3] = {S.U[U_GPOS + 3 * g2] - S.U[U_GPOS + 3 * g1], S.U[U_GPOS + 3 * g2 + 1] - S.U[U_GPOS + 3 * g1 + 1],
-                         S.U[U_GPOS + 3 * g2 + 2] - S.U[U_GPOS + 3 * g1 + 2]};
-    if (t1 == G_PLANE) {
-      const double nn[3] = {S.U[U_GMAT + 9 * g1 + 2], S.U[U_GMAT + 9 * g1 + 5], S.U[U_GMAT + 9 * g1 + 8]};
-      have = dot3(d, nn) - rbound(g2, t2) <= margin;
-    } else {
-      const double rr = rbound(g1, t1) + rbound(g2, t2) + margin;
-      have = dot3(d, d) <= rr * rr || rr < 0;
-    }
-  }
   ConSink<L> k{&S, 0, 0, 0, g1, g2};
   // box-box pairs (stepping-task kernels only) run the SAT + clipping once, in the counting pass, and replay the recorded
   // contacts in the writing pass; every other pair type is cheap enough to be evaluated twice

@@ -340,7 +340,7 @@ __global__ void __launch_bounds__(256) colsum_final_kernel(const float* __restri
 // minibatch): one launch adds every segment's slices, in slice order, to its destination.
 #define MAX_SEGS 16
 struct Seg { const float* part; float* dst; int nslices, count, N, ldc; };   // partial z at part + z*count; element i -> dst[(i/N)*ldc + i%N]
-struct SegList { Seg s[MAX_SEGS]; int first[MAX_SEGS + 1]; int n; };
+struct SegList { Seg s[MAX_SEGS]; int first[MAX_SEGS + 1]; int n; float scale; };   // scale: applied to every total (undoes the loss scaling)
 __global__ void __launch_bounds__(256) reduce_segments_kernel(SegList L) {
   // block = 64 consecutive elements of one segment x 4 slice ranges; the four partial sums are combined in a fixed order
   __shared__ float red[4][64];
@@ -361,7 +361,7 @@ __global__ void __launch_bounds__(256) reduce_segments_kernel(SegList L) {
     const int t = threadIdx.x;
     const float tot = (red[0][t] + red[1][t]) + (red[2][t] + red[3][t]);
     const int row = e / sg.N, col = e - row * sg.N;
-    sg.dst[(size_t)row * sg.ldc + col] += tot;
+    sg.dst[(size_t)row * sg.ldc + col] += tot * L.scale;
   }
 }
 static void seg_add(SegList& L, const float* part, float* dst, int nslices, int M, int N, int ldc) {
@@ -629,7 +629,8 @@ __global__ void __launch_bounds__(256) ppo_loss_kernel(int B, int Rcap, int A, i
                                                        float* __restrict__ dstd /* [B][Op] or NULL */, float* __restrict__ stats_part,
                                                        const float* __restrict__ imit_target /* [B][A] or NULL */,
                                                        const unsigned char* __restrict__ imit_mask /* [B][A] */, float imit_coeff,
-                                                       float imit_inv_count, int seqB) {
+                                                       float imit_inv_count, int seqB,
+                                                       float gscale /* power of two applied to dya / dyc (fp16 update: loss scaling) */) {
   int m = blockIdx.x * blockDim.x + threadIdx.x;
   // row of sample m in the actor output buffer, and of its mirrored twin: FF minibatch: m and Rcap + m; recurrent minibatch
   // (time-major, seqB columns per step, mirrored columns appended per step): t * 2 seqB + b and + seqB
@@ -657,7 +658,7 @@ __global__ void __launch_bounds__(256) ppo_loss_kernel(int B, int Rcap, int A, i
     float v = yc[(size_t)m * 4];
     float e = ret[m] - v;
     s_critic = e * e;
-    dyc[(size_t)m * 4] = -2.f * e * invB;
+    dyc[(size_t)m * 4] = -2.f * e * invB * gscale;
     dyc[(size_t)m * 4 + 1] = 0.f; dyc[(size_t)m * 4 + 2] = 0.f; dyc[(size_t)m * 4 + 3] = 0.f;
     if (use_mirror) for (int a = 0; a < Op; a++) dya[rm * Op + a] = 0.f;
     for (int a = 0; a < Op; a++) {
@@ -673,7 +674,7 @@ __global__ void __launch_bounds__(256) ppo_loss_kernel(int B, int Rcap, int A, i
           s_mirror += diff * diff;
           g += mirror_coeff * 2.f * diff * invBA;
           // gradient wrt the mirrored-pass output it came from (act_src is a permutation: each slot written once)
-          dya[rm * Op + act_src[a]] = -mirror_coeff * 2.f * diff * invBA * act_sign[a];
+          dya[rm * Op + act_src[a]] = -mirror_coeff * 2.f * diff * invBA * act_sign[a] * gscale;
         }
         if (imit_target && imit_mask[(size_t)m * A + a]) {
           float diff = mu - imit_target[(size_t)m * A + a];
@@ -681,7 +682,7 @@ __global__ void __launch_bounds__(256) ppo_loss_kernel(int B, int Rcap, int A, i
           g += imit_coeff * 2.f * diff * imit_inv_count;
         }
       }
-      dya[rn * Op + a] = g;
+      dya[rn * Op + a] = g * gscale;
       if (dstd) dstd[(size_t)m * Op + a] = gs;
     }
   }
@@ -827,7 +828,7 @@ extern "C" int lhw_debug_gemm(int32_t a_kc, int32_t b_kc, int32_t wt, int32_t M,
   if (part) {   // the deferred path of the update: partials (and column sums) reduced by one launch, accumulating into C / colsum_out
     const int kc = ((std::max(1, k_chunk > 0 ? k_chunk : K) + BK - 1) / BK) * BK;
     SegList S;
-    S.n = 0;
+    S.n = 0; S.scale = 1.f;
     seg_add(S, part, C, (K + kc - 1) / kc, M, N, ldc);
     if (colsum) seg_add(S, colsum, colsum_out, (K + kc - 1) / kc, M, 1, 1);
     launch_reduce_segments(S, s);
@@ -1089,10 +1090,14 @@ extern "C" int lhw_ppo_grad(LhwPpo* p, const float* theta, float* grad, const fl
   }
   join();
   const int nblk = (B + 255) / 256;
+  // fp16 update: the back-propagated gradients are rounded to fp16 per GEMM, and d loss / d output carries 1 / B -- at B = 32768
+  // most of it would fall into the fp16 subnormal range.  Loss scaling by a power of two (exact in float32): the read-out
+  // gradients are multiplied by 2^ceil(log2 B) here and the weight-gradient totals divided by it in the final ordered reduction.
+  const float lscale = p->update_half ? exp2f(ceilf(log2f((float)B))) : 1.f;
   hipLaunchKernelGGL(ppo_loss_kernel, dim3(nblk), dim3(256), 0, s, B, R, p->A, Op, p->ya, p->yc, p->mb_act, p->mb_logp,
                      p->mb_adv, p->mb_ret, theta + p->off_std, p->clip, p->mirror_coeff, mir, p->d_act_src, p->d_act_sign, p->dya,
                      p->dyc, p->learn_std ? p->dstd : (float*)nullptr, p->stats_part, p->imit_target, p->imit_mask, p->imit_coeff,
-                     p->imit_inv_count, 0);
+                     p->imit_inv_count, 0, lscale);
   p->imit_target = nullptr; p->imit_mask = nullptr;   // armed for one call only
   hipLaunchKernelGGL(reduce_rows_kernel, dim3(1), dim3(64), 0, s, p->stats_part, nblk, NSTAT, stats_dev);
   if (p->learn_std) {
@@ -1115,7 +1120,7 @@ extern "C" int lhw_ppo_grad(LhwPpo* p, const float* theta, float* grad, const fl
   }
   join();
   SegList S;
-  S.n = 0;
+  S.n = 0; S.scale = 1.f / lscale;
   mlp_backward_segments(S, p->la, grad + p->off_actor, Pa, za);
   mlp_backward_segments(S, p->lc, grad + p->off_critic, Pc, zc);
   launch_reduce_segments(S, s);
@@ -1540,7 +1545,7 @@ extern "C" int lhw_rnn_grad(LhwRnn* p, const float* theta, float* grad, int32_t 
   hipLaunchKernelGGL(ppo_loss_kernel, dim3(nblk), dim3(256), 0, s, R, 0, p->A, Op, p->wa.y, p->wc.y, p->mb_act, p->mb_logp, p->mb_adv,
                      p->mb_ret, theta + p->off_std, p->clip, p->mirror_coeff, mir, p->d_act_src, p->d_act_sign, p->wa.dy, p->wc.dy,
                      p->learn_std ? p->dstd : (float*)nullptr, p->stats_part, (const float*)nullptr, (const unsigned char*)nullptr, 0.f, 0.f,
-                     mir ? B : 0);
+                     mir ? B : 0, 1.f);
   hipLaunchKernelGGL(reduce_rows_kernel, dim3(1), dim3(64), 0, s, p->stats_part, nblk, NSTAT, stats_dev);
   if (p->learn_std) {
     colsum_det(p->dstd, R, Op, p->A, grad + p->off_std, p->part, s);

@@ -4,8 +4,16 @@ these scalars and the flat gradient cross ranks."""
 from __future__ import annotations
 
 import math
+import os
 
 import torch
+
+# LHW_FORCE_DIST=1 (tests): issue the collectives even with a single rank, so that the RCCL calls execute on a 1-GPU box
+_FORCE = os.environ.get("LHW_FORCE_DIST") == "1"
+
+
+def _active(d) -> bool:
+    return bool(d) and (d.get_world_size() > 1 or _FORCE)
 
 
 def dist():
@@ -19,7 +27,7 @@ def global_mean_std(sum_x: torch.Tensor, sum_x2: torch.Tensor, n: float):
     pack = torch.stack([sum_x.double().reshape(()), sum_x2.double().reshape(()),
                         torch.tensor(float(n), dtype=torch.float64, device=sum_x.device)])
     d = dist()
-    if d and d.get_world_size() > 1:
+    if _active(d):
         d.all_reduce(pack)
     s, s2, cnt = (float(v) for v in pack)
     mean = s / cnt
@@ -34,7 +42,7 @@ def global_batch_moments(x: torch.Tensor):
     n = torch.tensor([float(x.shape[0])], dtype=torch.float64, device=x.device)
     pack = torch.cat([x.sum(0), (x * x).sum(0), n])
     d = dist()
-    if d and d.get_world_size() > 1:
+    if _active(d):
         d.all_reduce(pack)
     D = x.shape[1]
     cnt = pack[-1]
@@ -47,7 +55,7 @@ def allreduce_grad_(flat_grad: torch.Tensor) -> float:
     """Sum-all-reduce the flat gradient in place; returns the scale (1/world) that turns the sum of per-rank
     mean-gradients into the mean over the global minibatch."""
     d = dist()
-    if d and d.get_world_size() > 1:
+    if _active(d):
         d.all_reduce(flat_grad)
         return 1.0 / d.get_world_size()
     return 1.0
@@ -56,3 +64,16 @@ def allreduce_grad_(flat_grad: torch.Tensor) -> float:
 def shard_env_ids(n_envs_per_rank: int, rank: int) -> int:
     """Global index of this rank's first environment (RNG keys use global env ids)."""
     return rank * n_envs_per_rank
+
+
+def global_episode_stats(ret_sum: float, len_sum: float, count: float, device=None):
+    """Finished-episode statistics summed over all ranks: the reference averages the episodes of ALL workers for the
+    `Mean Eprew / Mean Eplen` table and for the evaluation reward that drives save-if-best (rl/algos/ppo.py:408-426,
+    :540-548), so every rank logs / checkpoints on the same numbers."""
+    d = dist()
+    if not _active(d):
+        return ret_sum, len_sum, count
+    pack = torch.tensor([float(ret_sum), float(len_sum), float(count)], dtype=torch.float64, device=device)
+    d.all_reduce(pack)
+    r, l, c = (float(v) for v in pack)
+    return r, l, c

@@ -74,6 +74,13 @@ class JvrcWalkSpec:
         self.sim_dt, self.control_dt = float(c["sim_dt"]), float(c["control_dt"])
         if int(c.get("obs_history_len", 1)) != 1:
             raise NotImplementedError("obs_history_len != 1")
+        # BaseHumanoidEnv.reset_model / step apply these for ANY env that configures them (base_humanoid_env.py:76-92,247-305); the
+        # JVRC kernels implement none of them (and copy a precomputed post-reset state into every auto-reset): refuse, do not ignore
+        for key in ("init_noise", "dynamics_randomization", "perturbation", "observation_noise"):
+            v = c.get(key)
+            on = (v.get("enable", v.get("enabled", False)) if isinstance(v, dict) else bool(v))
+            if on:
+                raise NotImplementedError(f"{key} is configured in {self.yaml_path}: the JVRC tasks do not implement it (the H1 tasks do)")
         self.action_smoothing = float(c["action_smoothing"])
         self.kp, self.kd = np.array(c["kp"], dtype=float), np.array(c["kd"], dtype=float)
         self.half_sitting_pose = np.deg2rad(np.array(c["half_sitting_pose"], dtype=float))

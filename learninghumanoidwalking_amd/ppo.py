@@ -35,6 +35,18 @@ class BatchData:
     traj_idx: torch.Tensor
     ep_lens: torch.Tensor
     ep_rewards: torch.Tensor
+    n_envs: int = 0          # > 0: the sample tensors are TIME-major ([T][N] flattened) and traj_idx indexes env_major()
+
+    def env_major(self) -> "BatchData":
+        """The same batch with the samples in ENV-major order (sample (env n, step t) at n * T + t): one env's steps are contiguous,
+        so `states[traj_idx[i]:traj_idx[i + 1]]` is trajectory i, as with the reference's concatenated worker buffers."""
+        if not self.n_envs:
+            return self
+        N = self.n_envs
+        tr = lambda x: x.reshape(-1, N, *x.shape[1:]).transpose(0, 1).reshape(x.shape)
+        return BatchData(states=tr(self.states), actions=tr(self.actions), rewards=tr(self.rewards), values=tr(self.values),
+                         returns=tr(self.returns), dones=tr(self.dones), traj_idx=self.traj_idx, ep_lens=self.ep_lens,
+                         ep_rewards=self.ep_rewards, n_envs=0)
 
 
 class _AdamView:
@@ -48,8 +60,10 @@ class _AdamView:
 
     def state_dict(self):
         k = self._k
-        state = {n: dict(step=int(k.adam_step), exp_avg=k._view(k.adam_m, n).detach().cpu().clone(),
-                         exp_avg_sq=k._view(k.adam_v, n).detach().cpu().clone()) for n in self._names if hasattr(k, "_view")}
+        key = getattr(k, "_adam_view_specs", None)      # (recurrent kernels: _view takes the tensor's spec)
+        view = (lambda flat, n: k._view(flat, key[n])) if key else k._view
+        state = {n: dict(step=int(k.adam_step), exp_avg=view(k.adam_m, n).detach().cpu().clone(),
+                         exp_avg_sq=view(k.adam_v, n).detach().cpu().clone()) for n in self._names}
         return dict(state=state, param_groups=[dict(self.defaults, params=list(self._names))])
 
     def zero_grad(self):      # gradients are zeroed by the apply kernel after every optimiser step
@@ -322,6 +336,10 @@ class PPO:
         # they are stored by the rollout (and recomputed in float32 for the fp16-inference mode), so old_policy is the policy.
         self.old_policy = self.kernels
         names = list(getattr(self.kernels, "TENSORS", []))
+        if self.recurrent:       # RnnKernels addresses its tensors by (name, offset, shape) specs
+            specs = self.kernels.tensor_specs()
+            names = list(specs)
+            self.kernels._adam_view_specs = specs
         self.actor_optimizer = _AdamView(self.kernels, [n for n in names if n.startswith("a_") or n == "stds"], self.lr, self.eps)
         self.critic_optimizer = _AdamView(self.kernels, [n for n in names if n.startswith("c_")], self.lr, self.eps)
         self.last_losses = {}
@@ -335,11 +353,11 @@ class PPO:
         self._adv, self._ret = adv, ret
         T, N = ro.T, ro.N
         rs, ls, cnt = self.env.pop_episode_stats()
-        self._ep_stats = (rs, ls, cnt)
+        self._ep_stats = dist_utils.global_episode_stats(rs, ls, cnt, device=self.device if _dist() and _dist().get_backend() == 'nccl' else None)
         return BatchData(states=ro.obs[:T].reshape(T * N, -1), actions=ro.act.reshape(T * N, -1),
                          rewards=ro.rew.reshape(T * N, 1), values=ro.val.reshape(T * N, 1), returns=ret.reshape(T * N, 1),
                          dones=ro.done.reshape(T * N, 1), traj_idx=self._traj_idx(ro.done),
-                         ep_lens=torch.tensor([ls / cnt] if cnt else []), ep_rewards=torch.tensor([rs / cnt] if cnt else []))
+                         ep_lens=torch.tensor([ls / cnt] if cnt else []), ep_rewards=torch.tensor([rs / cnt] if cnt else []), n_envs=N)
 
     @staticmethod
     def _traj_idx(done):

@@ -24,7 +24,8 @@ def _worker(rank, world, port, q):
     m, v, n = dist_utils.global_batch_moments(obs)
     g = torch.full((7,), float(rank + 1))
     scale = dist_utils.allreduce_grad_(g)
-    q.put((rank, mean, std, cnt, m.numpy(), v.numpy(), n, (g * scale).numpy(), dist_utils.shard_env_ids(4096, rank)))
+    eps = dist_utils.global_episode_stats(10.0 * (rank + 1), 100.0 + rank, 3 + rank)     # every rank reports all ranks' episodes
+    q.put((rank, mean, std, cnt, m.numpy(), v.numpy(), n, (g * scale).numpy(), dist_utils.shard_env_ids(4096, rank), eps))
     dist.destroy_process_group()
 
 
@@ -46,7 +47,8 @@ def test_two_rank_reductions_match_concatenated_batch():
         rs.normal(size=1000 + 37 * r)
         obs.append(torch.tensor(rs.normal(size=(50 + 10 * r, 5)) + r))
     allx, allo = torch.cat(xs), torch.cat(obs)
-    for rank, mean, std, cnt, m, v, n, g, base in res:
+    for rank, mean, std, cnt, m, v, n, g, base, eps in res:
+        assert eps == (30.0, 201.0, 7.0)               # rl/algos/ppo.py:408-426: mean over ALL workers' episodes
         assert abs(mean - float(allx.mean())) < 1e-12
         assert abs(std - float(allx.std())) < 1e-12          # unbiased, like ppo.py:485
         assert cnt == allx.numel()

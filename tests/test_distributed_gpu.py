@@ -26,3 +26,16 @@ def test_two_ranks_reproduce_the_single_process_union(tmp_path):
     assert a.shape == b.shape and np.isfinite(a).all()
     moved = np.abs(a - a.mean()).max()
     assert np.abs(a - b).max() <= 1e-6, f"max |theta_ranks - theta_union| = {np.abs(a - b).max():.3e} (weights span {moved:.2f})"
+
+
+def test_rccl_branch_of_bench_runs_with_one_rank():
+    """bench.py's RCCL path (init_process_group("nccl"), barrier, MAX all-reduce of the timing, gradient all-reduce inside
+    PPO) is otherwise reached only on a multi-GPU node: run it with world size 1 on this box."""
+    import json
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", LHW_FORCE_DIST="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                        "--master-port", "29573", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "1", "--num-envs", "128",
+                        "--traj-len", "8", "--minibatch-size", "512", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["scaling"] == "weak" and line["value"] > 0

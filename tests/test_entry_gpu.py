@@ -78,6 +78,11 @@ def test_ppo_evaluate_is_deterministic_and_tracks_the_best_checkpoint(tmp_path):
     assert torch.equal(mu, batch.actions[:64])
     ti = batch.traj_idx.cpu().numpy()
     assert ti[0] == 0 and ti[-1] == 64 * 40 and (np.diff(ti) > 0).all() and (np.diff(ti) <= 40).all()
+    em = batch.env_major()            # traj_idx slices the env-major view into whole trajectories (one env, consecutive steps)
+    dn = em.dones.reshape(-1).cpu().numpy()
+    for a, b in zip(ti[:-1], ti[1:]):
+        assert (dn[a:b - 1] == 0).all() and a // 40 == (b - 1) // 40
+    assert torch.equal(em.states.view(64, 40, -1)[5, 7], batch.states.view(40, 64, -1)[7, 5])
     r0, l0 = algo.evaluate(0)
     files = set(os.listdir(tmp_path))
     assert {"actor_0.pt", "critic_0.pt", "actor.pt", "critic.pt"} <= files and algo.best_metric == r0 and 0 < l0 <= 40

@@ -370,3 +370,30 @@ def test_fp16_update_matches_half_rounded_reference():
     assert worst16 < 6e-5, worst16
     assert worst32 > 1e-7, "the float32 update should differ from the half-rounded reference"
     print(f"fp16 update vs half-rounded torch reference: worst |dw| {worst16:.2e} (float32 update vs the same reference {worst32:.2e})")
+
+
+def test_fp16_update_gradients_survive_large_minibatches():
+    """d loss / d output carries 1 / B, so at B = 32768 the back-propagated gradients of the first layers sit in the
+    fp16 subnormal range once the fp16 update rounds them per GEMM.  With the power-of-two loss scaling of lhw_ppo_grad the
+    fp16 update's gradient stays within fp16 rounding of the float32 one at the benchmark's minibatch size."""
+    from learninghumanoidwalking_amd.ppo_kernels import PpoKernels, reference_init
+    D, A, H, B = 37, 12, 256, 32768
+    gen = torch.Generator().manual_seed(3)
+    obs = torch.randn(B, D, generator=gen).cuda()
+    adv = torch.randn(B, generator=gen).cuda()
+    ret = torch.randn(B, generator=gen).cuda()
+    idx = torch.arange(B, dtype=torch.int32, device="cuda")
+    grads = {}
+    for half in (False, True):
+        k = PpoKernels(D, A, hidden=H, max_rows=B)
+        k.set_tensors(reference_init(D, A, H, 0.223, generator_seed=0))     # actor read-out x 0.01: the early-training regime
+        k.set_update_fp16(half)
+        mu, act, logp, val = k.forward(obs, seed=1)
+        xn, _ = k.normalize(obs, want_mirror=False)
+        k.grad_minibatch(xn, None, act.clone(), logp.clone(), adv, ret, idx)
+        torch.cuda.synchronize()
+        grads[half] = {n: k._view(k.grad, n).clone().cpu() for n in ("a_w1", "a_w2", "a_w3", "c_w1", "c_w2", "c_w3")}
+    for n, g32 in grads[False].items():
+        g16 = grads[True][n]
+        rel = float((g16 - g32).norm() / g32.norm())
+        assert rel < 2e-2, f"{n}: fp16-update gradient off by {rel:.3f} (relative) at B = {B}"
