@@ -180,6 +180,10 @@ struct HModel {
   const double *body_d, *jnt_d, *dof_d, *geom_d, *act_d;
   const int *body_i, *jnt_i, *dof_i, *geom_i, *act_i, *pair_i;
   int has_primbox;     // some collision pair is sphere-box or capsule-box (collide_primbox)
+  const int* kin_i;      // [32][KIS], kin_d [32][KDS]: per lane of the chain layout, its jointed body and that body's frame relative to the
+  const double* kin_d;   //   previous jointed body (fwd_kinematics)
+  const int* fix_i;      // [nbody]: jointed body a welded body moves with (-1 for jointed bodies), fix_d [nbody][12]: its frame in that body's
+  const double* fix_d;
   int max_owned;         // bodies per lane in chain_dynamics' per-body loop
   const int* own_tab;    // [32][max_owned]: bodies whose force / inertia the lane of the chain layout contributes (-1: none)
   int track_body[3];  // bodies whose spatial velocity must survive the sub-step (the task reads them afterwards)
@@ -540,6 +544,8 @@ __device__ __forceinline__ void inert_vec(double* r, const double* i, const doub
   r[5] = i[7] * v[0] - i[6] * v[1] + i[9] * v[5];
 }
 
+#define NCH ((L::NV_ - 6) / 2)   // dofs per chain; NR: dof lanes per 16-lane row of the chain layout (see chain_solve)
+#define NR (6 + NCH)
 // ------------------------------------------------------------------------------------------------ row products
 // y_lane = sum_k row[k] * v[k] with the row in registers and v broadcast from LDS
 template <class L>
@@ -565,8 +571,6 @@ __device__ __forceinline__ double row_dot(const double (&row)[NV], const double*
 // two copies (their Schur complements add up: one v_permlane16_swap exchange per value after the chain columns).
 // Lane p holds row p of its half's matrix [[Krr_h, C_h^T], [C_h, T_h]] as R[0 .. NR) (full symmetric row; R[p] itself is
 // never read), its diagonal entry in dg, and element p of the right-hand side.
-#define NCH ((L::NV_ - 6) / 2)
-#define NR (6 + NCH)
 __device__ __forceinline__ double rcp_f64(double d) {
   double x = __builtin_amdgcn_rcp(d);
   x = fma(fma(-d, x, 1.0), x, x);
@@ -629,90 +633,126 @@ __device__ __forceinline__ double chain_solve(double (&R)[NR], double dg, double
 }
 
 // ------------------------------------------------------------------------------------------------ forward dynamics phases
-// mj_kinematics with rotation matrices: each lane precombines its body's local transform R_loc = R_body * R_joint(q)
-// (off the serial chain), so a tree level costs one 3x3 product and four matrix-vector products.
+// mj_kinematics.  The bodies that carry a joint (the root and the 2 NCH chain bodies) sit in the chain layout (row position 5 =
+// root, 6.. = chain bodies, parents first): each lane forms the affine map of its body relative to the previous one -- the fixed
+// offset composed, on the host, through any welded bodies in between, times the joint's rotation / translation -- and a
+// Hillis-Steele scan of map compositions along the row (row_shr 1, 2, 4 [, 8]; identity where a lane has no source) gives every
+// world frame in log2 depth: three rounds of 24 DPP moves + a 3x3 product instead of seven dependent tree levels with an LDS
+// hand-off each.  Bodies without a joint (welded upper body ...) are then one product with the frame of the body they move with.
+#define KIS 4    // kin_i: body jnt_type qposadr joint
+#define KDS 20   // kin_d: R0[9] p0[3] jnt_axis[3] jnt_pos[3] qpos0 pad   (R0, p0: frame relative to the previous jointed body)
+template <int CTRL>
+__device__ __forceinline__ double dpp_row_id(double v, double ident) { return dpp_d<CTRL, 0xf>(v, ident); }
+template <int CTRL>
+__device__ __forceinline__ void affine_scan_round(double (&R)[9], double (&pw)[3]) {
+  double Ra[9], pa[3];
+#pragma unroll
+  for (int k = 0; k < 9; k++) Ra[k] = dpp_row_id<CTRL>(R[k], (k % 4 == 0) ? 1.0 : 0.0);
+#pragma unroll
+  for (int k = 0; k < 3; k++) pa[k] = dpp_row_id<CTRL>(pw[k], 0.0);
+  double Rn[9], t[3];
+  mat_mul(Rn, Ra, R);
+  mat_vec(t, Ra, pw);
+#pragma unroll
+  for (int k = 0; k < 9; k++) R[k] = Rn[k];
+#pragma unroll
+  for (int k = 0; k < 3; k++) pw[k] = pa[k] + t[k];
+}
 template <bool STEPT, class L>
 __device__ void fwd_kinematics(const HModel& m, L& S, int lane) {
+  double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, pw[3] = {0, 0, 0}, jax[3] = {0, 0, 0}, jps[3] = {0, 0, 0};
+  int kb = -1, jt = -1, jid = 0;
+  if (lane < 32) {
+    const int* ki = m.kin_i + KIS * lane;
+    kb = ki[0]; jt = ki[1]; jid = ki[3];
+    if (kb >= 0) {
+      const int qa = ki[2];
+      double kd[KDS];
+#pragma unroll
+      for (int k = 0; k < KDS; k++) kd[k] = m.kin_d[KDS * lane + k];
+      for (int k = 0; k < 3; k++) { jax[k] = kd[12 + k]; jps[k] = kd[15 + k]; }
+      if (jt == JT_FREE) {
+        double q[4] = {S.qpos[qa + 3], S.qpos[qa + 4], S.qpos[qa + 5], S.qpos[qa + 6]};
+        normalize4(q);
+        if (lane < 16) for (int k = 0; k < 4; k++) { S.qpos[qa + 3 + k] = q[k]; if constexpr (STEPT) S.rootquat[k] = q[k]; }
+        quat2mat(R, q);
+        for (int k = 0; k < 3; k++) pw[k] = S.qpos[qa + k];
+      } else {
+        const double qj = S.qpos[qa] - kd[18];
+#pragma unroll
+        for (int k = 0; k < 9; k++) R[k] = kd[k];
+        if (jt == JT_HINGE) {
+          double sn, cs;
+          sincos(qj, &sn, &cs);
+          const double ax = jax[0], ay = jax[1], az = jax[2], t = 1.0 - cs;
+          const double Rj[9] = {cs + t * ax * ax, t * ax * ay - sn * az, t * ax * az + sn * ay,
+                                t * ax * ay + sn * az, cs + t * ay * ay, t * ay * az - sn * ax,
+                                t * ax * az - sn * ay, t * ay * az + sn * ax, cs + t * az * az};
+          double v0[3], v1[3];
+          mat_vec(v0, kd, jps);            // the anchor is fixed in both frames: p = p0 + R0 jpos - R jpos
+          mat_mul(R, kd, Rj);
+          mat_vec(v1, R, jps);
+          for (int k = 0; k < 3; k++) pw[k] = kd[9 + k] + v0[k] - v1[k];
+        } else {                            // slide: translation along the axis
+          double v0[3];
+          mat_vec(v0, kd, jax);
+          for (int k = 0; k < 3; k++) pw[k] = kd[9 + k] + v0[k] * qj;
+        }
+      }
+    }
+  }
+  affine_scan_round<0x111>(R, pw);
+  affine_scan_round<0x112>(R, pw);
+  affine_scan_round<0x114>(R, pw);
+  if constexpr (NR > 13) affine_scan_round<0x118>(R, pw);
   if (lane == 0) {
     S.xpos[0] = S.xpos[1] = S.xpos[2] = 0;
     for (int k = 0; k < 9; k++) S.U[U_XMAT + k] = (k % 4 == 0) ? 1.0 : 0.0;
     S.U[U_XIPOS + 0] = S.U[U_XIPOS + 1] = S.U[U_XIPOS + 2] = 0;
   }
+  if (kb >= 0 && (lane < 16 || (lane & 15) >= 6)) {     // (the root's frame: one of its two copies writes)
+    double anchor[3], waxis[3];
+    mat_vec(anchor, R, jps);
+    mat_vec(waxis, R, jax);
+    for (int k = 0; k < 3; k++) {
+      S.xpos[3 * kb + k] = pw[k];
+      S.U[U_XANCHOR + 3 * jid + k] = jt == JT_FREE ? pw[k] : pw[k] + anchor[k];
+      S.U[U_XAXIS + 3 * jid + k] = jt == JT_FREE ? jax[k] : waxis[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 9; k++) S.U[U_XMAT + 9 * kb + k] = R[k];
+  }
+  SYNC();
   const int b = lane;
   const bool valid = b >= 1 && b < m.nbody;
-  double kd[BD_NKIN];
-  int par = 0, mylvl = -1, jt = -1, qa = 0, ja = 0;
   if (valid) {
+    const int ow = m.fix_i[b];             // the jointed body this one is welded to (-1: it has a joint itself)
+    if (ow >= 0) {
+      double Ro[9], Rf[9], Rb[9], t[3];
 #pragma unroll
-    for (int k = 0; k < BD_NKIN; k++) kd[k] = m.body_d[BDS * b + k];
-    par = m.body_i[BIS * b]; mylvl = m.body_i[BIS * b + 1]; jt = m.body_i[BIS * b + 2]; qa = m.body_i[BIS * b + 3];
-    ja = m.body_i[BIS * b + BI_JNTADR];
-  }
-  double Rloc[9], qj = 0;
+      for (int k = 0; k < 9; k++) { Ro[k] = S.U[U_XMAT + 9 * ow + k]; Rf[k] = m.fix_d[12 * b + k]; }
+      const double pf[3] = {m.fix_d[12 * b + 9], m.fix_d[12 * b + 10], m.fix_d[12 * b + 11]};
+      mat_mul(Rb, Ro, Rf);
+      mat_vec(t, Ro, pf);
+      for (int k = 0; k < 3; k++) S.xpos[3 * b + k] = S.xpos[3 * ow + k] + t[k];
 #pragma unroll
-  for (int k = 0; k < 9; k++) Rloc[k] = valid ? kd[BD_RBODY + k] : 0.0;
-  if (valid && (jt == JT_HINGE || jt == JT_SLIDE)) {
-    qj = S.qpos[qa] - kd[BD_Q0];
-    if (jt == JT_HINGE) {
-      double sn, cs;
-      sincos(qj, &sn, &cs);
-      const double ax = kd[BD_JAXIS], ay = kd[BD_JAXIS + 1], az = kd[BD_JAXIS + 2], t = 1.0 - cs;
-      const double Rj[9] = {cs + t * ax * ax, t * ax * ay - sn * az, t * ax * az + sn * ay,
-                            t * ax * ay + sn * az, cs + t * ay * ay, t * ay * az - sn * ax,
-                            t * ax * az - sn * ay, t * ay * az + sn * ax, cs + t * az * az};
-      double Rb[9];
-#pragma unroll
-      for (int k = 0; k < 9; k++) Rb[k] = Rloc[k];
-      mat_mul(Rloc, Rb, Rj);
+      for (int k = 0; k < 9; k++) S.U[U_XMAT + 9 * b + k] = Rb[k];
     }
   }
   SYNC();
-  for (int lvl = 1; lvl < m.nlevel; lvl++) {
-    if (mylvl == lvl) {
-      double xp[3], R[9];
-      if (jt == JT_FREE) {
-        double q[4] = {S.qpos[qa + 3], S.qpos[qa + 4], S.qpos[qa + 5], S.qpos[qa + 6]};
-        normalize4(q);
-        for (int k = 0; k < 4; k++) { S.qpos[qa + 3 + k] = q[k]; if constexpr (STEPT) S.rootquat[k] = q[k]; }
-        quat2mat(R, q);
-        for (int k = 0; k < 3; k++) { xp[k] = S.qpos[qa + k]; S.U[U_XANCHOR + 3 * ja + k] = xp[k]; S.U[U_XAXIS + 3 * ja + k] = kd[BD_JAXIS + k]; }
-      } else {
-        double Rp[9], t[3];
-#pragma unroll
-        for (int k = 0; k < 9; k++) Rp[k] = S.U[U_XMAT + 9 * par + k];
-        mat_vec(t, Rp, kd + BD_POS);
-        for (int k = 0; k < 3; k++) xp[k] = S.xpos[3 * par + k] + t[k];
-        mat_mul(R, Rp, Rloc);
-        if (jt >= 0) {
-          double waxis[3], anchor[3];
-          mat_vec(waxis, Rp, kd + BD_V2);
-          mat_vec(anchor, Rp, kd + BD_V1);
-          for (int k = 0; k < 3; k++) { anchor[k] += xp[k]; S.U[U_XANCHOR + 3 * ja + k] = anchor[k]; S.U[U_XAXIS + 3 * ja + k] = waxis[k]; }
-          if (jt == JT_SLIDE) {
-            for (int k = 0; k < 3; k++) xp[k] += waxis[k] * qj;
-          } else {
-            double v[3];
-            mat_vec(v, R, kd + BD_JPOS);
-            for (int k = 0; k < 3; k++) xp[k] = anchor[k] - v[k];
-          }
-        }
-      }
-      double t[3];
-      const double bip[3] = {prm_ipos(m, S, b, 0), prm_ipos(m, S, b, 1), prm_ipos(m, S, b, 2)};
-      mat_vec(t, R, bip);
-      for (int k = 0; k < 3; k++) { S.xpos[3 * b + k] = xp[k]; S.U[U_XIPOS + 3 * b + k] = xp[k] + t[k]; }
-#pragma unroll
-      for (int k = 0; k < 9; k++) S.U[U_XMAT + 9 * b + k] = R[k];
-    }
-    SYNC();
-  }
-  // rotated inertia T = Ri diag(I) Ri^T of each body (completed with the com offset in fwd_com): all bodies at once
+  // com of each body and its rotated inertia T = Ri diag(I) Ri^T (completed with the com offset in fwd_com): all bodies at once
   if (valid) {
-    double R[9], Ri[9];
+    double Rb[9], Ri[9], t[3];
 #pragma unroll
-    for (int k = 0; k < 9; k++) R[k] = S.U[U_XMAT + 9 * b + k];
-    mat_mul(Ri, R, kd + BD_RINERT);
-    const double I0 = kd[BD_INERTIA], I1 = kd[BD_INERTIA + 1], I2 = kd[BD_INERTIA + 2];
+    for (int k = 0; k < 9; k++) Rb[k] = S.U[U_XMAT + 9 * b + k];
+    const double bip[3] = {prm_ipos(m, S, b, 0), prm_ipos(m, S, b, 1), prm_ipos(m, S, b, 2)};
+    mat_vec(t, Rb, bip);
+    for (int k = 0; k < 3; k++) S.U[U_XIPOS + 3 * b + k] = S.xpos[3 * b + k] + t[k];
+    double ri[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) ri[k] = m.body_d[BDS * b + BD_RINERT + k];
+    mat_mul(Ri, Rb, ri);
+    const double I0 = m.body_d[BDS * b + BD_INERTIA], I1 = m.body_d[BDS * b + BD_INERTIA + 1], I2 = m.body_d[BDS * b + BD_INERTIA + 2];
     double* ci = &S.U[U_CINERT + 10 * b];
     ci[0] = Ri[0] * I0 * Ri[0] + Ri[1] * I1 * Ri[1] + Ri[2] * I2 * Ri[2];
     ci[1] = Ri[3] * I0 * Ri[3] + Ri[4] * I1 * Ri[4] + Ri[5] * I2 * Ri[5];
@@ -2919,6 +2959,54 @@ int humanoid_create(HumanoidEnv** out, const std::vector<int32_t>& mi, const std
       else { const int c = (od - 6) / nch, k = (od - 6) % nch; owned[16 * c + 6 + k].push_back(b); }
     }
   }
+  // kinematic tables of the chain layout (fwd_kinematics): frame of every jointed body relative to the previous jointed body
+  // (welded bodies in between folded in), frame of every welded body in the jointed body it moves with
+  std::vector<int> kin_i(32 * KIS, -1), fix_i(nb, -1);
+  std::vector<double> kin_d(32 * KDS, 0.0), fix_d((size_t)nb * 12, 0.0);
+  {
+    auto rel = [&](int b, int anc, double* Rout, double* pout) {   // frame of body b in (jointed) ancestor anc, through joint-less bodies only
+      double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, pp[3] = {0, 0, 0};
+      for (int x = b; x != anc; x = parent[x]) {                   // T <- T(x in its parent) o T
+        const double* k = &body_d[(size_t)BDS * x];
+        double Rn[9], pn[3];
+        for (int r = 0; r < 3; r++) {
+          for (int c = 0; c < 3; c++) Rn[3 * r + c] = k[BD_RBODY + 3 * r] * R[c] + k[BD_RBODY + 3 * r + 1] * R[3 + c] + k[BD_RBODY + 3 * r + 2] * R[6 + c];
+          pn[r] = k[BD_POS + r] + k[BD_RBODY + 3 * r] * pp[0] + k[BD_RBODY + 3 * r + 1] * pp[1] + k[BD_RBODY + 3 * r + 2] * pp[2];
+        }
+        std::copy(Rn, Rn + 9, R); std::copy(pn, pn + 3, pp);
+        if (x != b && body_i[(size_t)BIS * x + 2] >= 0) return false;   // a jointed body in between: not a chain
+        if (x == 0) return false;
+      }
+      std::copy(R, R + 9, Rout); std::copy(pp, pp + 3, pout);
+      return true;
+    };
+    bool okk = true;
+    auto fill = [&](int lane, int b, int prevb) {
+      int* ki = &kin_i[(size_t)lane * KIS];
+      double* kd = &kin_d[(size_t)lane * KDS];
+      const double* k = &body_d[(size_t)BDS * b];
+      ki[0] = b; ki[1] = body_i[(size_t)BIS * b + 2]; ki[2] = body_i[(size_t)BIS * b + 3]; ki[3] = body_i[(size_t)BIS * b + BI_JNTADR];
+      if (prevb >= 0) okk = okk && rel(b, prevb, kd, kd + 9);
+      for (int a = 0; a < 3; a++) { kd[12 + a] = k[BD_JAXIS + a]; kd[15 + a] = k[BD_JPOS + a]; }
+      kd[18] = k[BD_Q0];
+    };
+    fill(5, 1, -1); fill(21, 1, -1);                       // the root body (free joint: frame from qpos), in both rows
+    for (int c = 0; c < 2; c++)
+      for (int k = 0; k < nch; k++) {
+        const int b = dof_i[(size_t)DIS * (6 + c * nch + k) + DI_BODY];
+        const int pb = k == 0 ? 1 : dof_i[(size_t)DIS * (6 + c * nch + k - 1) + DI_BODY];
+        fill(16 * c + 6 + k, b, pb);
+      }
+    for (int b = 2; b < nb; b++) {
+      if (body_i[(size_t)BIS * b + 2] >= 0) continue;      // has a joint
+      int ow = parent[b];
+      while (ow > 0 && body_i[(size_t)BIS * ow + 2] < 0) ow = parent[ow];
+      if (ow <= 0) { okk = false; break; }
+      fix_i[b] = ow;
+      okk = okk && rel(b, ow, &fix_d[(size_t)12 * b], &fix_d[(size_t)12 * b + 9]);
+    }
+    if (!okk || body_i[(size_t)BIS * 1 + 2] != JT_FREE) { humanoid_destroy(h); return lhw_fail(LHW_ERR_UNSUPPORTED, "kinematic tables: the jointed bodies must form root -> chain A / chain B with only joint-less bodies in between"); }
+  }
   size_t max_owned = 1;
   for (auto& o : owned) max_owned = std::max(max_owned, o.size());
   std::vector<int> own_tab(32 * max_owned, -1);
@@ -2932,7 +3020,9 @@ int humanoid_create(HumanoidEnv** out, const std::vector<int32_t>& mi, const std
        (m.act_d = to_dev<double>(h, act_d.data(), act_d.size())) && (m.body_i = to_dev<int>(h, body_i.data(), body_i.size())) &&
        (m.jnt_i = to_dev<int>(h, jnt_i.data(), jnt_i.size())) && (m.dof_i = to_dev<int>(h, dof_i.data(), dof_i.size())) &&
        (m.geom_i = to_dev<int>(h, geom_i.data(), geom_i.size())) && (m.act_i = to_dev<int>(h, act_i.data(), act_i.size())) &&
-       (m.pair_i = to_dev<int>(h, pair_i.data(), pair_i.size())) && (m.own_tab = to_dev<int>(h, own_tab.data(), own_tab.size()));
+       (m.pair_i = to_dev<int>(h, pair_i.data(), pair_i.size())) && (m.own_tab = to_dev<int>(h, own_tab.data(), own_tab.size())) &&
+       (m.kin_i = to_dev<int>(h, kin_i.data(), kin_i.size())) && (m.kin_d = to_dev<double>(h, kin_d.data(), kin_d.size())) &&
+       (m.fix_i = to_dev<int>(h, fix_i.data(), fix_i.size())) && (m.fix_d = to_dev<double>(h, fix_d.data(), fix_d.size()));
   HParams& p = h->p;
   memset(&p, 0, sizeof p);
   p.n_envs = cfg->n_envs; p.frame_skip = cfg->frame_skip; p.max_traj_len = cfg->max_traj_len; p.period = cfg->period;

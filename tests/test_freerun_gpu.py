@@ -5,7 +5,11 @@ repository's oracle, not MuJoCo (parity with MuJoCo itself is unpinned, DESIGN.m
 Both sides run in auto-reset mode and no state is ever copied between them: a robot that falls starts a new episode from the
 (deterministic) reset state on both sides, so the comparison covers whole episodes including the falls.  Two regimes:
 PD-hold (zero action; the stand-in robot slowly tips over, ~100-step episodes) and a trained policy's mean action (weights in tests/golden/jvrc_walk_actor_trained.npz, produced on
-the GPU by scripts/make_policy_fixture.py), evaluated in float64 numpy on each side's own float64 state."""
+the GPU by scripts/make_policy_fixture.py), evaluated in float64 numpy on each side's own float64 state.  Those two legs are
+CLOSED-LOOP (each side's policy sees its own state, which contracts differences); the third leg is OPEN-LOOP in the literal
+sense of BASELINE.json ("identical inputs"): one action tape for both sides, 1000 steps, no resets, no re-synchronisation -- in a
+regime that is not an inverted pendulum: the robot falls within ~100 steps and then lies on the floor under the tape (contact-rich
+but dissipative; rounding-level differences stay at 1e-11 there, as measured on the emulator)."""
 import os
 
 import numpy as np
@@ -77,14 +81,14 @@ def _free_run(env, orc, policy, T):
     return ended, longest, worst_q, worst_v
 
 
-def test_pd_hold_1000_free_running_steps():
+def test_closed_loop_pd_hold_1000_free_running_steps():
     spec, env, orc = _pair(3, seed=4)
     ended, longest, wq, wv = _free_run(env, orc, lambda o: np.zeros(12), 1000)
     print(f"PD-hold: 1000 free-running control steps x 3 envs, {ended} episodes ended (the stand-in robot tips over under "
           f"zero action), longest episode {longest}, worst |dqpos| {wq:.3e}, worst |dqvel| {wv:.3e}")
 
 
-def test_trained_policy_1000_free_running_steps():
+def test_closed_loop_trained_policy_1000_free_running_steps():
     path = os.path.join(HERE, "golden", "jvrc_walk_actor_trained.npz")
     if not os.path.exists(path):
         pytest.skip("tests/golden/jvrc_walk_actor_trained.npz missing (scripts/make_policy_fixture.py writes it on the GPU box)")
@@ -102,3 +106,33 @@ def test_trained_policy_1000_free_running_steps():
     print(f"trained policy: 1000 free-running control steps x 3 envs, {ended} episodes ended, longest episode {longest}, "
           f"worst |dqpos| {wq:.3e}, worst |dqvel| {wv:.3e}")
     assert longest >= 300, "the fixture policy should keep the robot up for hundreds of steps"
+
+
+def test_open_loop_identical_action_tape_1000_steps():
+    import torch
+    from learninghumanoidwalking_amd.envs.jvrc_walk import JvrcWalkSpec
+    from oracle.env_jvrc_walk import OracleJvrcWalkEnv
+    spec = JvrcWalkSpec()
+    N, T = 3, 1000
+    env = spec.make_batched(N, seed=4, device=0, max_traj_len=0)          # no auto-reset: the episode simply continues after the fall
+    orc = [OracleJvrcWalkEnv(spec, seed=4, env_id=i, max_traj_len=0) for i in range(N)]
+    env.reset()
+    for o in orc:
+        o.reset()
+    tape = (np.random.default_rng(5).normal(size=(T, N, 12)) * 0.1).astype(np.float32)
+    worst_q = worst_v = 0.0
+    fell = np.zeros(N, bool)
+    for t in range(T):
+        env.step(torch.from_numpy(tape[t]).cuda())
+        for i, o in enumerate(orc):
+            o.step(tape[t, i])
+        q, v = env.get_state()
+        oq = np.array([o.sim.qpos.copy() for o in orc]); ov = np.array([o.sim.qvel.copy() for o in orc])
+        eq, ev = np.abs(q - oq).max(), np.abs(v - ov).max()
+        worst_q, worst_v = max(worst_q, eq), max(worst_v, ev)
+        assert eq <= 1e-5 and ev <= 1e-5, f"step {t}: |dqpos| {eq:.3e} |dqvel| {ev:.3e}"
+        fell |= oq[:, 2] < 0.3
+    assert fell.all(), "the regime this leg is about: the robot is on the floor for most of the run"
+    assert env.pop_fault_stats() == (0, 0)
+    print(f"open loop: one action tape, 1000 control steps x {N} envs without reset or re-synchronisation, worst |dqpos| {worst_q:.3e}, "
+          f"worst |dqvel| {worst_v:.3e}")
