@@ -264,7 +264,8 @@ int lhw_ppo_forward_at(LhwPpo* ppo, const float* theta, const float* obs, int64_
                        const float* obs_std, uint64_t seed, uint32_t env_id_base, uint32_t counter, int deterministic,
                        int64_t ws_row, float* mu, float* act, float* logp, float* value, void* stream);
 /* fp16 != 0: lhw_ppo_forward (rollout inference) rounds weights and activations to fp16 and multiplies on the fp16 MFMA with
- * float32 accumulation (BASELINE config "fp16 actor/critic"); the update (lhw_ppo_grad) always uses float32 operands */
+ * float32 accumulation (BASELINE config "fp16 actor/critic"); the update (lhw_ppo_grad) uses float32 operands unless
+ * lhw_ppo_set_update_dtype selects fp16 as well */
 int lhw_ppo_set_inference_dtype(LhwPpo* ppo, int fp16);
 /* fp16 != 0: every GEMM of lhw_ppo_grad (forward, activation gradients, weight gradients) rounds both operands to fp16 and
  * runs on the fp16 MFMA with float32 accumulation -- BASELINE config 5 "fp16 actor/critic": fp16 weights and activations per

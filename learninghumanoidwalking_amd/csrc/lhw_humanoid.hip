@@ -168,7 +168,11 @@ enum { LHW_STREAM_OBS = 4 };
 #define AD_GEAR 0
 #define AD_CTRLRANGE 1
 #define AD_FORCERANGE 3
-#define AIS 4   // act_i: dof joint ctrllimited forcelimited
+#define PIS 6   // pair_i: geom1 geom2 condim xmask(dofs moving exactly one body) mask2(dofs moving body 2) pad
+#define PDS 12  // pair_d: margin includemargin friction solref2 solimp5 invweight(sum of the two bodies' translational) pad
+#define AIS 6   // act_i: dof joint ctrllimited forcelimited qposadr dofadr(of the joint)
+#define AI_QADR 4
+#define AI_DADR 5
 #define AI_DOF 0
 #define AI_JNT 1
 #define AI_CTRLLIMITED 2
@@ -178,7 +182,8 @@ struct HModel {
   int nq, nv, nu, nbody, njnt, ngeom, npair, nlevel, iterations, disableflags;
   double timestep, gravity[3], tolerance, meaninertia, totalmass;
   const double *body_d, *jnt_d, *dof_d, *geom_d, *act_d;
-  const int *body_i, *jnt_i, *dof_i, *geom_i, *act_i, *pair_i;
+  const int *body_i, *jnt_i, *dof_i, *geom_i, *act_i, *pair_i;   // pair_i / pair_d: one record per candidate pair (mj_contactParam is a function of the pair)
+  const double* pair_d;
   int has_primbox;     // some collision pair is sphere-box or capsule-box (collide_primbox)
   const int* kin_i;      // [32][KIS], kin_d [32][KDS]: per lane of the chain layout, its jointed body and that body's frame relative to the
   const double* kin_d;   //   previous jointed body (fwd_kinematics)
@@ -278,6 +283,7 @@ struct HumanoidEnv {
 #define U_CSOLREF (L::U_CSOLREF_)
 #define U_CSOLIMP (L::U_CSOLIMP_)
 #define U_CFRAME (L::U_CFRAME_)
+#define U_CTRAN (L::U_CTRAN_)    // body_invweight0 (translational) of the contact's two bodies, summed
 #define U_J (L::U_J_)
 #define U_L (L::U_L_)
 #define U_VEC (L::U_VEC_)
@@ -306,7 +312,7 @@ struct LdsT {
   // dead once the rows are built (the solver's vectors and the Cholesky rows then reuse the space)
   static constexpr int U_J_ = U_CINERT_, U_L_ = U_J_ + W_T * NV_T;
   static constexpr int U_CDIST_ = even(cmax(cmax(cmax(END_A_, END_B1_), END_B2_), U_L_)), U_CMARGIN_ = U_CDIST_ + NC_, U_CSOLREF_ = U_CMARGIN_ + NC_,
-                       U_CSOLIMP_ = U_CSOLREF_ + 2 * NC_, U_CFRAME_ = U_CSOLIMP_ + 5 * NC_, END_CON_ = U_CFRAME_ + 9 * NC_;   // (beyond J: they feed its rows)
+                       U_CSOLIMP_ = U_CSOLREF_ + 2 * NC_, U_CFRAME_ = U_CSOLIMP_ + 5 * NC_, U_CTRAN_ = U_CFRAME_ + 9 * NC_, END_CON_ = U_CTRAN_ + NC_;   // (beyond J: they feed its rows)
   static constexpr int U_VEC_ = even(U_L_ + TRI_), U_VEC2_ = U_VEC_ + NV_T, U_DG_ = U_VEC2_ + NV_T,
                        U_EVEC_ = U_DG_ + NV_T, U_DACT_ = U_EVEC_ + W_T, END_C_ = U_DACT_ + W_T;   // J rows are NV long (16-byte aligned)
   static constexpr int USIZE_ = even(cmax(END_CON_, END_C_));
@@ -318,6 +324,7 @@ struct LdsT {
   double efc_force[W_T];
   double con_pos[NC_ * 3], con_mu[NC_];
   int con_g1[NC_], con_g2[NC_], con_dim[NC_];
+  int con_xm[NC_], con_m2[NC_], con_pair[NC_];   // dofs that move exactly one of the contact's two bodies; dofs that move body 2 (sign of the Jacobian)
   double sq[NU], sv[NU], frc[NU];
   // per-env parameters, loaded once per launch (one-element stubs when the task reads the shared model tables instead)
   double damp[PRM_T ? NV_T : 1], floss[PRM_T ? NV_T : 1], bmass[PRM_T ? NB_T : 1], bipos[PRM_T ? NB_T * 3 : 1], xfrc[PRM_T ? 12 : 1];
@@ -454,6 +461,22 @@ __device__ __forceinline__ double gsum(double v) {
   v = xhalf_sum(rbc<15>(v));
   if constexpr (W == 64) { double l, u; x32_pair(v, l, u); v = l + u; }
   return v;
+}
+// two group sums for the price of one scan: the rows of each pair are folded first (even row <- a, odd row <- b), one row scan
+// reduces both, and a second lane swap hands every lane both totals
+template <int W>
+__device__ __forceinline__ void gsum2(double a, double b, double& sa, double& sb) {
+  const auto lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+  const auto hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+  // first result: [a(even row), b(even row)] per row pair, second: [a(odd row), b(odd row)]
+  double v = __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
+  v += dpp_d<0x111, 0xf>(v, 0.0); v += dpp_d<0x112, 0xf>(v, 0.0); v += dpp_d<0x114, 0xf>(v, 0.0); v += dpp_d<0x118, 0xf>(v, 0.0);
+  xhalf_pair(rbc<15>(v), sa, sb);
+  if constexpr (W == 64) {
+    double l, u;
+    x32_pair(sa, l, u); sa = l + u;
+    x32_pair(sb, l, u); sb = l + u;
+  }
 }
 template <int W>
 __device__ __forceinline__ double gmin(double v) {
@@ -967,7 +990,7 @@ __device__ __forceinline__ void chain_dynamics(const HModel& m, const HParams& p
 template <class L>
 struct ConSink {
   L* S;
-  int base, n, write, g1, g2;
+  int base, n, write, g1, g2, pair;
   __device__ __forceinline__ void emit(double dist, const double* pos, const double* nrm, const double* tan) {
     if (write) {
       const int c = base + n;
@@ -987,7 +1010,7 @@ struct ConSink {
         normalize3(f + 3);
         cross3(f + 6, f, f + 3);
         for (int a = 0; a < 9; a++) Z.U[U_CFRAME + 9 * c + a] = f[a];
-        Z.con_g1[c] = g1; Z.con_g2[c] = g2;
+        Z.con_g1[c] = g1; Z.con_g2[c] = g2; Z.con_pair[c] = pair;
       }
     }
     n++;
@@ -1418,14 +1441,14 @@ __device__ void fwd_collision(const HModel& m, const HParams& p, L& S, int lane,
   double margin = 0;
   bool have = lane < m.npair;
   if (have) {
-    g1 = m.pair_i[2 * (lane) + 0]; g2 = m.pair_i[2 * (lane) + 1];
-    margin = fmax(m.geom_d[GDS * (g1) + GD_MARGIN], m.geom_d[GDS * (g2) + GD_MARGIN]);
+    g1 = m.pair_i[PIS * lane]; g2 = m.pair_i[PIS * lane + 1];
+    margin = m.pair_d[PDS * lane];
     // boxes only collide while the floor is lowered (KNOWN DEVIATION, DESIGN.md sections 2 and 7: coplanar floor + box contacts
     // of the reference would need more constraint rows than a wave has lanes)
     if (BOXBOX && ter && ter[T_FLOOR] == 0.0 && ((g1 >= p.box_geom0 && g1 < p.box_geom0 + p.nbox) || (g2 >= p.box_geom0 && g2 < p.box_geom0 + p.nbox)))
       have = false;
   }
-  ConSink<L> k{&S, 0, 0, 0, g1, g2};
+  ConSink<L> k{&S, 0, 0, 0, g1, g2, lane};
   // box-box pairs (stepping-task kernels only) run the SAT + clipping once, in the counting pass, and replay the recorded
   // contacts in the writing pass; every other pair type is cheap enough to be evaluated twice
   BoxRec br;
@@ -1458,38 +1481,18 @@ __device__ void fwd_collision(const HModel& m, const HParams& p, L& S, int lane,
   }
   if (lane == 0) { S.ncon = min(total, NC); if (total > NC) S.overflow = 1; }   // sticky for the whole control step
   SYNC();
-  // mj_contactParam (lane = contact): priority, else solmix-weighted mix; friction = max; condim = max
+  // mj_contactParam (lane = contact): a function of the geom pair, evaluated at create (humanoid_create: pair_d / pair_i)
   if (lane < S.ncon) {
-    const int c = lane;
-    g1 = S.con_g1[c]; g2 = S.con_g2[c];
-    const double incm = fmax(m.geom_d[GDS * (g1) + GD_MARGIN], m.geom_d[GDS * (g2) + GD_MARGIN]) - fmax(m.geom_d[GDS * (g1) + GD_GAP], m.geom_d[GDS * (g2) + GD_GAP]);
-    int dim;
-    double mu, sr[2], si[5];
-    const int pr1 = m.geom_i[GIS * (g1) + GI_PRIORITY], pr2 = m.geom_i[GIS * (g2) + GI_PRIORITY];
-    if (pr1 != pr2) {
-      const int g = pr1 > pr2 ? g1 : g2;
-      dim = m.geom_i[GIS * (g) + GI_CONDIM]; mu = m.geom_d[GDS * (g) + GD_FRICTION];
-      sr[0] = m.geom_d[GDS * (g) + GD_SOLREF]; sr[1] = m.geom_d[GDS * (g) + GD_SOLREF + 1];
-      for (int a = 0; a < 5; a++) si[a] = m.geom_d[GDS * (g) + GD_SOLIMP + a];
-    } else {
-      dim = max(m.geom_i[GIS * (g1) + GI_CONDIM], m.geom_i[GIS * (g2) + GI_CONDIM]);
-      const double m1 = m.geom_d[GDS * (g1) + GD_SOLMIX], m2 = m.geom_d[GDS * (g2) + GD_SOLMIX];
-      double mix;
-      if (m1 >= HMINVAL && m2 >= HMINVAL) mix = m1 / (m1 + m2);
-      else if (m1 < HMINVAL && m2 < HMINVAL) mix = 0.5;
-      else mix = m1 < HMINVAL ? 0.0 : 1.0;
-      if (m.geom_d[GDS * (g1) + GD_SOLREF] > 0 && m.geom_d[GDS * (g2) + GD_SOLREF] > 0)
-        for (int a = 0; a < 2; a++) sr[a] = mix * m.geom_d[GDS * (g1) + GD_SOLREF + a] + (1 - mix) * m.geom_d[GDS * (g2) + GD_SOLREF + a];
-      else
-        for (int a = 0; a < 2; a++) sr[a] = fmin(m.geom_d[GDS * (g1) + GD_SOLREF + a], m.geom_d[GDS * (g2) + GD_SOLREF + a]);
-      for (int a = 0; a < 5; a++) si[a] = mix * m.geom_d[GDS * (g1) + GD_SOLIMP + a] + (1 - mix) * m.geom_d[GDS * (g2) + GD_SOLIMP + a];
-      mu = fmax(m.geom_d[GDS * (g1) + GD_FRICTION], m.geom_d[GDS * (g2) + GD_FRICTION]);
-    }
+    const int c = lane, q = S.con_pair[c];
+    const double* pd = m.pair_d + PDS * q;
+    const double incm = pd[1];
+    S.con_xm[c] = m.pair_i[PIS * q + 3]; S.con_m2[c] = m.pair_i[PIS * q + 4];
+    S.U[U_CTRAN + c] = pd[10];
     S.U[U_CMARGIN + c] = incm;
-    S.con_dim[c] = (S.U[U_CDIST + c] >= incm) ? 0 : dim;  // 0: excluded from the constraint set (gap)
-    S.con_mu[c] = mu;
-    S.U[U_CSOLREF + 2 * c] = sr[0]; S.U[U_CSOLREF + 2 * c + 1] = sr[1];
-    for (int a = 0; a < 5; a++) S.U[U_CSOLIMP + 5 * c + a] = si[a];
+    S.con_dim[c] = (S.U[U_CDIST + c] >= incm) ? 0 : m.pair_i[PIS * q + 2];  // 0: excluded from the constraint set (gap)
+    S.con_mu[c] = pd[2];
+    S.U[U_CSOLREF + 2 * c] = pd[3]; S.U[U_CSOLREF + 2 * c + 1] = pd[4];
+    for (int a = 0; a < 5; a++) S.U[U_CSOLIMP + 5 * c + a] = pd[5 + a];
   }
   SYNC();
 }
@@ -1633,11 +1636,10 @@ __device__ __forceinline__ void solve_tail(const HModel& m, const HParams& p, L&
   const int ncon = S.ncon, nrow = 4 * ncon;
   for (int it = lane; it < ncon * NV; it += W) {
     const int c = it / NV, k = it - c * NV;
-    const int b1 = m.geom_i[GIS * (S.con_g1[c]) + GI_BODY], b2 = m.geom_i[GIS * (S.con_g2[c]) + GI_BODY];
     const unsigned bit = 1u << k;
-    const bool in1 = ((unsigned)m.body_i[BIS * (b1) + BI_DOFMASK] & bit) != 0, in2 = ((unsigned)m.body_i[BIS * (b2) + BI_DOFMASK] & bit) != 0;
+    const bool in2 = ((unsigned)S.con_m2[c] & bit) != 0;
     double d[3] = {0, 0, 0};
-    if (in1 != in2) {
+    if ((unsigned)S.con_xm[c] & bit) {
       double off[3], t[3];
       for (int a = 0; a < 3; a++) off[a] = S.con_pos[3 * c + a] - S.com[a];
       cross3(t, &S.U[U_CDOF + 6 * k], off);
@@ -1676,8 +1678,7 @@ __device__ __forceinline__ void solve_tail(const HModel& m, const HParams& p, L&
     isrow = have && (dim == 3 || (dim == 1 && e == 0));
     const double jv0 = jrow_dot(S.qvel);
     if (isrow) {
-      const int b1 = m.geom_i[GIS * (S.con_g1[c]) + GI_BODY], b2 = m.geom_i[GIS * (S.con_g2[c]) + GI_BODY];
-      const double tran = m.body_d[BDS * (b1) + BD_INVW] + m.body_d[BDS * (b2) + BD_INVW];
+      const double tran = S.U[U_CTRAN + c];
       const double mu = S.con_mu[c];
       double K, B, imp, R;
       const double diag = dim == 1 ? tran : tran + mu * mu * tran;
@@ -1725,10 +1726,9 @@ __device__ __forceinline__ void solve_tail(const HModel& m, const HParams& p, L&
   PROF_MARK(4);
   // transmission + actuation (lane = actuator)
   if (lane < m.nu) {
-    const int j = m.act_i[AIS * (lane) + AI_JNT];
     const double gear = m.act_d[ADS * (lane) + AD_GEAR];
-    S.sq[lane] = (gear * S.qpos[m.jnt_i[JIS * (j) + JI_QADR]]) / gear;  // actuator_length / gear, as the reference computes it
-    S.sv[lane] = (gear * S.qvel[m.jnt_i[JIS * (j) + JI_DADR]]) / gear;
+    S.sq[lane] = (gear * S.qpos[m.act_i[AIS * lane + AI_QADR]]) / gear;  // actuator_length / gear, as the reference computes it
+    S.sv[lane] = (gear * S.qvel[m.act_i[AIS * lane + AI_DADR]]) / gear;
     double f = 0;
     if (flags & 1) {
       double c = S.ctrl[lane];
@@ -1786,8 +1786,8 @@ __device__ __forceinline__ void solve_tail(const HModel& m, const HParams& p, L&
       eval_rows(jw, w, &cw, &tf, &td, &tu, &tv);
       eval_rows(js, as, &cs0, &tf, &td, &tu, &tv);
       if (prim) cw += 0.5 * (Ma - fs) * (w - as);
-      cw = gsum<W>(cw);
-      const double cs = gsum<W>(cs0);
+      double cs;
+      gsum2<W>(cw, cs0, cw, cs);
       qacc = (cw > cs) ? as : w;
     }
     double cost = 0, oldcost = 0;
@@ -1801,13 +1801,13 @@ __device__ __forceinline__ void solve_tail(const HModel& m, const HParams& p, L&
       eval_rows(ja, qacc, &c, &force, &dactive, &ufrc, &udact);
       if (prim) c += 0.5 * (Ma - fs) * (qacc - as);
       oldcost = cost;
-      cost = gsum<W>(c);
       S.U[U_EVEC + lane] = force; S.efc_force[lane] = force; S.U[U_DACT + lane] = dactive;   // lane = contact row (NE == W)
       SYNC();
       double grad = 0;
       fcon = 0;
       {
         double f0 = 0, f1 = 0, f2 = 0, f3 = 0;
+#pragma unroll 2
         for (int r = 0; r < nrow; r += 4) {   // whole contacts: nrow is a multiple of 4
           f0 += S.U[U_J + r * NV + dd] * S.U[U_EVEC + r];
           f1 += S.U[U_J + (r + 1) * NV + dd] * S.U[U_EVEC + r + 1];
@@ -1819,17 +1819,21 @@ __device__ __forceinline__ void solve_tail(const HModel& m, const HParams& p, L&
           grad = Ma - fs - fcon;
         }
       }
-      const double gn = sqrt(gsum<W>(prim ? grad * grad : 0.0));
+      double gn;
+      gsum2<W>(c, prim ? grad * grad : 0.0, cost, gn);   // the cost of this iterate and the squared gradient norm in one reduction
+      gn = sqrt(gn);
       if (iter > 0) { if (scale * (oldcost - cost) < m.tolerance || scale * gn < m.tolerance) break; }
       else if (scale * gn < m.tolerance) break;
       if (iter == m.iterations) break;
       // H = M + J^T D_active J, row of this lane's dof accumulated in the registers the factorisation works on; the diagonal
       // entry travels separately (hd)
+      PROF_MARK(7);    // (Newton: cost / gradient passes in slot 7, Hessian + factor + solve in slot 2, line search in slot 15)
       double Hrow[NR], hd = mdiag + udact;
 #pragma unroll
       for (int k = 0; k < NR; k++) Hrow[k] = Mrow[k];
       {
-        for (int r = 0; r < nrow; r++) {
+#pragma unroll 4
+        for (int r = 0; r < nrow; r++) {      // (nrow is a multiple of 4; unrolled so that the LDS reads of four rows are in flight together)
           const double jl = S.U[U_J + r * NV + dd], cj = S.U[U_DACT + r] * jl;
           hd += cj * jl;
 #pragma unroll
@@ -1856,11 +1860,12 @@ __device__ __forceinline__ void solve_tail(const HModel& m, const HParams& p, L&
         }
       }
       const double search = cross ? -dense_lds_solve<L>(S, Hrow, hd, grad, dof, prim, coff, nrow) : -spd_solve(Hrow, hd, grad);
+      PROF_MARK(2);
       if (prim) S.U[U_VEC2 + dd] = search;
       SYNC();
       const double jv = jrow_dot(S.U + U_VEC2), Mv = mprod(search);
-      const double qg1 = gsum<W>(prim ? search * (Ma - fs) : 0.0);
-      const double qg2 = gsum<W>(prim ? 0.5 * search * Mv : 0.0);
+      double qg1, qg2;
+      gsum2<W>(prim ? search * (Ma - fs) : 0.0, prim ? 0.5 * search * Mv : 0.0, qg1, qg2);
       // exact line search on the convex piecewise-quadratic: safeguarded Newton on its derivative
       const double x0 = ja - aref, xu0 = qacc - uaref[0], xu1 = qacc - uaref[1], xu2 = -qacc - uaref[2];
       auto deriv_rows = [&](double a, double* d1, double* d2) {
@@ -1877,8 +1882,9 @@ __device__ __forceinline__ void solve_tail(const HModel& m, const HParams& p, L&
       {
         double r1, r2;
         deriv_rows(0.0, &r1, &r2);
-        double d1 = gsum<W>(r1) + qg1;
-        double d2 = gsum<W>(r2) + 2 * qg2;
+        double d1, d2;
+        gsum2<W>(r1, r2, d1, d2);
+        d1 += qg1; d2 += 2 * qg2;
         if (!(d1 >= 0 || d2 <= 0)) {
           const double d0 = fabs(d1);
           double lo = 0, hi = -1;
@@ -1887,8 +1893,9 @@ __device__ __forceinline__ void solve_tail(const HModel& m, const HParams& p, L&
             double a = alpha - d1 / d2;
             if (hi >= 0 && (a <= lo || a >= hi)) a = 0.5 * (lo + hi);
             deriv_rows(a, &r1, &r2);
-            d1 = gsum<W>(r1) + 2 * a * qg2 + qg1;
-            d2 = gsum<W>(r2) + 2 * qg2;
+            gsum2<W>(r1, r2, d1, d2);
+            d1 += 2 * a * qg2 + qg1;
+            d2 += 2 * qg2;
             if (d1 < 0) lo = a; else hi = a;
             alpha = a;
             if (fabs(d1) <= 1e-14 * d0) break;
@@ -1896,6 +1903,7 @@ __device__ __forceinline__ void solve_tail(const HModel& m, const HParams& p, L&
           }
         }
       }
+      PROF_MARK(15);
       if (alpha == 0) break;
       qacc += alpha * search;
     }
@@ -1962,8 +1970,7 @@ __device__ __forceinline__ void substep(const HModel& m, const HParams& p, L& S,
   // episode): those Hessians are factorised by the looped dense Cholesky in LDS instead (dense_lds_solve).
   bool cross = false;
   if (lane < S.ncon && S.con_dim[lane] != 0) {
-    const unsigned m1 = (unsigned)m.body_i[BIS * m.geom_i[GIS * S.con_g1[lane] + GI_BODY] + BI_DOFMASK];
-    const unsigned m2 = (unsigned)m.body_i[BIS * m.geom_i[GIS * S.con_g2[lane] + GI_BODY] + BI_DOFMASK];
+    const unsigned m2 = (unsigned)S.con_m2[lane], m1 = (unsigned)S.con_xm[lane] ^ m2;
     const unsigned ca = ((1u << NCH) - 1u) << 6, cb = ca << NCH;
     cross = ((m1 & ca) && (m2 & cb)) || ((m1 & cb) && (m2 & ca));
   }
@@ -2851,7 +2858,7 @@ int humanoid_create(HumanoidEnv** out, const std::vector<int32_t>& mi, const std
   std::vector<double> body_d((size_t)nb * BDS, 0.0), jnt_d((size_t)nj * JDS, 0.0), dof_d((size_t)nv * DDS, 0.0),
       geom_d((size_t)ng * GDS, 0.0), act_d((size_t)nu * ADS, 0.0);
   std::vector<int> body_i((size_t)nb * BIS, 0), jnt_i((size_t)nj * JIS, 0), dof_i((size_t)nv * DIS, 0), geom_i((size_t)ng * GIS, 0),
-      act_i((size_t)nu * AIS, 0), pair_i((size_t)np * 2, 0);
+      act_i((size_t)nu * AIS, 0), pair_i((size_t)np * PIS, 0);
   for (int b = 0; b < nb; b++) {
     double* k = &body_d[(size_t)BDS * b];
     const int mb = bsrc[b];
@@ -2928,7 +2935,37 @@ int humanoid_create(HumanoidEnv** out, const std::vector<int32_t>& mi, const std
     gi[GI_TYPE] = IF(LHW_IF_GEOM_TYPE)[g]; gi[GI_BODY] = bmap[gmb]; gi[GI_CONDIM] = IF(LHW_IF_GEOM_CONDIM)[g];
     gi[GI_PRIORITY] = IF(LHW_IF_GEOM_PRIORITY)[g];
   }
-  for (int q = 0; q < np; q++) { pair_i[2 * q] = IF(LHW_IF_PAIR_GEOM1)[q]; pair_i[2 * q + 1] = IF(LHW_IF_PAIR_GEOM2)[q]; }
+  std::vector<double> pair_d((size_t)np * PDS, 0.0);
+  for (int q = 0; q < np; q++) {   // mj_contactParam: priority, else solmix-weighted mix; friction = max; condim = max
+    const int g1 = IF(LHW_IF_PAIR_GEOM1)[q], g2 = IF(LHW_IF_PAIR_GEOM2)[q];
+    const double *G1 = &geom_d[(size_t)GDS * g1], *G2 = &geom_d[(size_t)GDS * g2];
+    const int *I1 = &geom_i[(size_t)GIS * g1], *I2 = &geom_i[(size_t)GIS * g2];
+    double* pd = &pair_d[(size_t)PDS * q];
+    int* pi = &pair_i[(size_t)PIS * q];
+    pi[0] = g1; pi[1] = g2;
+    pd[0] = std::max(G1[GD_MARGIN], G2[GD_MARGIN]);
+    pd[1] = pd[0] - std::max(G1[GD_GAP], G2[GD_GAP]);
+    if (I1[GI_PRIORITY] != I2[GI_PRIORITY]) {
+      const double* G = I1[GI_PRIORITY] > I2[GI_PRIORITY] ? G1 : G2;
+      pi[2] = (I1[GI_PRIORITY] > I2[GI_PRIORITY] ? I1 : I2)[GI_CONDIM];
+      pd[2] = G[GD_FRICTION]; pd[3] = G[GD_SOLREF]; pd[4] = G[GD_SOLREF + 1];
+      for (int a = 0; a < 5; a++) pd[5 + a] = G[GD_SOLIMP + a];
+    } else {
+      pi[2] = std::max(I1[GI_CONDIM], I2[GI_CONDIM]);
+      const double m1 = G1[GD_SOLMIX], m2 = G2[GD_SOLMIX];
+      double mix;
+      if (m1 >= HMINVAL && m2 >= HMINVAL) mix = m1 / (m1 + m2);
+      else if (m1 < HMINVAL && m2 < HMINVAL) mix = 0.5;
+      else mix = m1 < HMINVAL ? 0.0 : 1.0;
+      for (int a = 0; a < 2; a++)
+        pd[3 + a] = (G1[GD_SOLREF] > 0 && G2[GD_SOLREF] > 0) ? mix * G1[GD_SOLREF + a] + (1 - mix) * G2[GD_SOLREF + a] : std::min(G1[GD_SOLREF + a], G2[GD_SOLREF + a]);
+      for (int a = 0; a < 5; a++) pd[5 + a] = mix * G1[GD_SOLIMP + a] + (1 - mix) * G2[GD_SOLIMP + a];
+      pd[2] = std::max(G1[GD_FRICTION], G2[GD_FRICTION]);
+    }
+    const int b1 = I1[GI_BODY], b2 = I2[GI_BODY];
+    pi[3] = (int)(bmask[b1] ^ bmask[b2]); pi[4] = (int)bmask[b2];
+    pd[10] = body_d[(size_t)BDS * b1 + BD_INVW] + body_d[(size_t)BDS * b2 + BD_INVW];
+  }
   for (int u = 0; u < nu; u++) {
     double* k = &act_d[(size_t)ADS * u];
     k[AD_GEAR] = DF(LHW_DF_ACTUATOR_GEAR)[u];
@@ -2937,6 +2974,7 @@ int humanoid_create(HumanoidEnv** out, const std::vector<int32_t>& mi, const std
     int* ai = &act_i[(size_t)AIS * u];
     const int j = IF(LHW_IF_ACTUATOR_TRNID)[u];
     ai[AI_DOF] = jdof[j]; ai[AI_JNT] = j; ai[AI_CTRLLIMITED] = IF(LHW_IF_ACTUATOR_CTRLLIMITED)[u]; ai[AI_FORCELIMITED] = IF(LHW_IF_ACTUATOR_FORCELIMITED)[u];
+    ai[AI_QADR] = IF(LHW_IF_JNT_QPOSADR)[j]; ai[AI_DADR] = jdof[j];
   }
   m.nlevel = nlevel;
   // chain structure (see chain_solve): dofs 0..5 one free joint, then two serial chains of equal length hanging off the root
@@ -3020,7 +3058,7 @@ int humanoid_create(HumanoidEnv** out, const std::vector<int32_t>& mi, const std
        (m.act_d = to_dev<double>(h, act_d.data(), act_d.size())) && (m.body_i = to_dev<int>(h, body_i.data(), body_i.size())) &&
        (m.jnt_i = to_dev<int>(h, jnt_i.data(), jnt_i.size())) && (m.dof_i = to_dev<int>(h, dof_i.data(), dof_i.size())) &&
        (m.geom_i = to_dev<int>(h, geom_i.data(), geom_i.size())) && (m.act_i = to_dev<int>(h, act_i.data(), act_i.size())) &&
-       (m.pair_i = to_dev<int>(h, pair_i.data(), pair_i.size())) && (m.own_tab = to_dev<int>(h, own_tab.data(), own_tab.size())) &&
+       (m.pair_i = to_dev<int>(h, pair_i.data(), pair_i.size())) && (m.pair_d = to_dev<double>(h, pair_d.data(), pair_d.size())) && (m.own_tab = to_dev<int>(h, own_tab.data(), own_tab.size())) &&
        (m.kin_i = to_dev<int>(h, kin_i.data(), kin_i.size())) && (m.kin_d = to_dev<double>(h, kin_d.data(), kin_d.size())) &&
        (m.fix_i = to_dev<int>(h, fix_i.data(), fix_i.size())) && (m.fix_d = to_dev<double>(h, fix_d.data(), fix_d.size()));
   HParams& p = h->p;

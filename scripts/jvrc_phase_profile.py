@@ -30,9 +30,11 @@ e1.record(); torch.cuda.synchronize()
 c = env.phase_cycles(True)
 from learninghumanoidwalking_amd import _lib
 print("occupancy blocks/CU (runtime query):", _lib.lib().lhw_debug_stepper_occupancy())
-names = ["kinematics", "com/cdof", "crba", "collision", "constraints", "velocity/rne", "smooth solve", "newton", "euler", "prologue", "task/reward"]
-tot = c[:11].sum()
-print(f"N={N} ms/step {e0.elapsed_time(e1)/steps:.3f}  env0 cycles/control-step {tot/steps:.0f}  per sub-step {tot/steps/25:.0f}")
-for n, v in zip(names, c[:11]): print(f"  {n:14s} {v/steps/25:9.0f} cyc/substep  {100*v/tot:5.1f}%")
-print("  detail slots 11..15:", (c[11:16]/steps/25).astype(int))
+names = {0: "kinematics", 3: "collision", 1: "com / cinert / cdof", 5: "tree dynamics (rne, crb)", 4: "constraint rows", 11: "actuation + qfrc_smooth",
+         12: "M solve", 7: "newton: cost / gradient passes", 2: "newton: Hessian + factor + solve", 15: "newton: line search", 13: "Euler solve",
+         8: "integrate"}
+sub = sum(c[k] for k in names) / steps / 25
+print(f"N={N} ms/step {e0.elapsed_time(e1)/steps:.3f}  env0 cycles per sub-step {sub:.0f} (sum of the phases below; clock64 ticks)"
+      f"  control-step prologue + epilogue per sub-step {(c[9] + c[10]) / steps / 25 - sub:.0f}")
+for k, n in names.items(): print(f"  {n:34s} {c[k]/steps/25:9.0f} cyc/substep  {100*c[k]/steps/25/sub:5.1f}%")
 print(f"  newton passes per sub-step (env 0): {c[6]/steps/25:.2f}   line-search passes per sub-step: {c[14]/steps/25:.2f}")
