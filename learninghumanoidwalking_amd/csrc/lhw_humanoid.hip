@@ -197,20 +197,25 @@ struct HModel {
 
 struct HParams {
   int n_envs, frame_skip, max_traj_len, period, task;
-  int env_first, env_count;             // sub-range of envs this launch advances (lhw_env_step_range); blockIdx.x is relative to it
-  int only_flagged;                     // 1: advance only the envs whose st.slow flag is set (re-run of fast-path overflows), clearing it
   int reset_template;                   // >= 0: record index of the template env whose freshly reset state every auto-reset copies (-1: resets are computed)
   int root_body, head_body, rfoot_body, lfoot_body;
   int env_params;                       // 1: damping / frictionloss / mass / ipos / xfrc come from the per-env record
   int dynrand_interval, perturb_interval, n_pbody, pbody[2];
   int rand_dof[10], rand_body[11], n_rand_dof, n_rand_body;
-  int box_geom0, nbox, floor_geom, delay_frames, nplans, iteration;  // stepping task
+  int box_geom0, nbox, floor_geom, delay_frames, nplans;  // stepping task
   double target_radius;
   const double* plans;                  // [nplans][1 + MAX_SEQ * 3]: length, then (x y theta) rows
   unsigned env_id_base;
   unsigned long long seed;
   double action_smoothing, goal_height, init_noise, force_mag, torque_mag;
   const double *kp, *kd, *nominal_qpos, *action_offset, *clock_lut, *neutral_pose, *obs_noise;
+};
+
+// what changes from launch to launch (everything else of the task configuration sits in device memory: HumanoidEnv::p_dev)
+struct HLaunch {
+  int env_first, env_count;             // sub-range of envs this launch advances (lhw_env_step_range); blockIdx.x is relative to it
+  int only_flagged;                     // 1: advance only the envs whose st.slow flag is set (re-run of fast-path overflows), clearing it
+  int iteration;                        // training iteration (stepping-task curriculum)
 };
 
 struct HState {
@@ -244,6 +249,8 @@ struct HState {
 struct HumanoidEnv {
   HModel m;
   HParams p;
+  HParams* p_dev;   // device copy the kernels read (passed by pointer: its fields need not live in SGPRs across the sub-steps)
+  int iteration;
   HState st;
   std::vector<void*> dev_allocs;
   int device;
@@ -1807,7 +1814,6 @@ __device__ __forceinline__ void solve_tail(const HModel& m, const HParams& p, L&
       fcon = 0;
       {
         double f0 = 0, f1 = 0, f2 = 0, f3 = 0;
-#pragma unroll 2
         for (int r = 0; r < nrow; r += 4) {   // whole contacts: nrow is a multiple of 4
           f0 += S.U[U_J + r * NV + dd] * S.U[U_EVEC + r];
           f1 += S.U[U_J + (r + 1) * NV + dd] * S.U[U_EVEC + r + 1];
@@ -1832,8 +1838,7 @@ __device__ __forceinline__ void solve_tail(const HModel& m, const HParams& p, L&
 #pragma unroll
       for (int k = 0; k < NR; k++) Hrow[k] = Mrow[k];
       {
-#pragma unroll 4
-        for (int r = 0; r < nrow; r++) {      // (nrow is a multiple of 4; unrolled so that the LDS reads of four rows are in flight together)
+        for (int r = 0; r < nrow; r++) {      // (measured: unrolling this loop, or the J^T f loop above, is slower -- DESIGN.md section 4)
           const double jl = S.U[U_J + r * NV + dd], cj = S.U[U_DACT + r] * jl;
           hd += cj * jl;
 #pragma unroll
@@ -2127,7 +2132,7 @@ struct LayoutOf {
 // (`lane` = lane within the group, S = the group's LDS working set).  Returns true iff the env exceeded the contact capacity
 // of the two-envs-per-wave layout before anything of this control step was written: the caller repeats the step with W = 64.
 template <int MODE, int TASK, int W>
-__device__ __forceinline__ bool control_step(const HModel& m, const HParams& p, const HState& st, typename LayoutOf<TASK, W>::type& S, const int env,
+__device__ __forceinline__ bool control_step(const HModel& m, const HParams& p, const HLaunch& lz, const HState& st, typename LayoutOf<TASK, W>::type& S, const int env,
                                              const int lane, const float* __restrict__ act, float* __restrict__ obs, float* __restrict__ term_obs,
                                              float* __restrict__ rew, unsigned char* __restrict__ done_out, float* __restrict__ rew_terms,
                                              double* __restrict__ xq, double* __restrict__ xv) {
@@ -2561,7 +2566,7 @@ __device__ __forceinline__ bool control_step(const HModel& m, const HParams& p, 
             const double size = mode == WALK_BACKWARD ? -0.1 : 0.3, gap = 0.15;
             double height = 0;
             if (mode == WALK_FORWARD) {
-              const double hh = fmin(1.0, fmax(0.0, ((double)p.iteration - 3000.0) / 8000.0)) * 0.1;
+              const double hh = fmin(1.0, fmax(0.0, ((double)lz.iteration - 3000.0) / 8000.0)) * 0.1;
               height = lhw_rng_randint(p.seed, genv, LHW_STREAM_RESET, reset_count, 2, 2) == 0 ? -hh : hh;
             }
             const double uf = lhw_rng_uniform(p.seed, genv, LHW_STREAM_RESET, reset_count, 3, 0.095, 0.105);
@@ -2703,13 +2708,13 @@ __device__ __forceinline__ bool control_step(const HModel& m, const HParams& p, 
                   : lane == CI_T2 ? RI_T2 : lane == CI_REACHED ? RI_REACHED : lane == CI_FRAMES ? RI_FRAMES : RI_NSEQ;
     irec[dst] = S.ci[lane];
   }
-  if (lane == 0 && MODE == 0 && p.only_flagged) { st.slow[env] = 0; atomicAdd(&st.ep_stats[5], 1.0); }
+  if (lane == 0 && MODE == 0 && lz.only_flagged) { st.slow[env] = 0; atomicAdd(&st.ep_stats[5], 1.0); }
   if (MODE == 0 && st.wave_cyc && lane == 0) st.wave_cyc[env] = (long long)clock64() - t_launch;
   return false;
 }
 
 template <int MODE, int TASK, int W>  // MODE: 0 step, 1 reset(mask), 2 set_state, 3 get_state; TASK: TASK_WALK / TASK_STAND / TASK_STEP / TASK_H1WALK; W: lanes per env
-__global__ void __launch_bounds__(64, 2) humanoid_kernel(HModel m, HParams p, HState st, const float* __restrict__ act,
+__global__ void __launch_bounds__(64, 2) humanoid_kernel(HModel m, const HParams* __restrict__ pp, HLaunch lz, HState st, const float* __restrict__ act,
                                                       float* __restrict__ obs, float* __restrict__ term_obs,
                                                       float* __restrict__ rew, unsigned char* __restrict__ done_out,
                                                       float* __restrict__ rew_terms, const unsigned char* __restrict__ mask,
@@ -2719,11 +2724,12 @@ __global__ void __launch_bounds__(64, 2) humanoid_kernel(HModel m, HParams p, HS
   __shared__ L SG[G];
   const int lane = threadIdx.x & (W - 1);   // lane within the env's group
   const int eidx = blockIdx.x * G + group_id<W>();
-  if (eidx >= p.env_count) return;
-  const int env = eidx + p.env_first;
+  if (eidx >= lz.env_count) return;
+  const int env = eidx + lz.env_first;
+  const HParams& p = *pp;
   if (MODE == 1 && mask && !mask[env]) return;
-  if (MODE == 0 && p.only_flagged && !st.slow[env]) return;
-  control_step<MODE, TASK, W>(m, p, st, SG[group_id<W>()], env, lane, act, obs, term_obs, rew, done_out, rew_terms, xq, xv);
+  if (MODE == 0 && lz.only_flagged && !st.slow[env]) return;
+  control_step<MODE, TASK, W>(m, p, lz, st, SG[group_id<W>()], env, lane, act, obs, term_obs, rew, done_out, rew_terms, xq, xv);
 }
 
 // ------------------------------------------------------------------------------------------------ host side
@@ -2742,6 +2748,16 @@ static const T* to_dev(HumanoidEnv* h, const T* src, size_t n) {
   if (n && hipMemcpy(d, src, n * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
   h->dev_allocs.push_back(d);
   return (const T*)d;
+}
+
+static bool humanoid_upload_params(HumanoidEnv* h) {
+  if (!h->p_dev) {
+    void* d = nullptr;
+    if (hipMalloc(&d, sizeof(HParams)) != hipSuccess) return false;
+    h->dev_allocs.push_back(d);
+    h->p_dev = (HParams*)d;
+  }
+  return hipMemcpy(h->p_dev, &h->p, sizeof(HParams), hipMemcpyHostToDevice) == hipSuccess;
 }
 
 int humanoid_create(HumanoidEnv** out, const std::vector<int32_t>& mi, const std::vector<double>& md, const LhwEnvConfig* cfg,
@@ -2822,6 +2838,7 @@ int humanoid_create(HumanoidEnv** out, const std::vector<int32_t>& mi, const std
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return lhw_fail(LHW_ERR_NO_DEVICE, "no HIP device");
   HumanoidEnv* h = new HumanoidEnv();
   h->device = cfg->device;
+  h->p_dev = nullptr; h->iteration = 0;
   // two envs per wave (W = 32) where the model fits half a wavefront; the stepping task needs the 16-contact layout throughout
   h->fast = !stepping && np <= 32 && ng <= 16 && nj <= 32 && nb <= (stand ? 15 : 18) && !getenv("LHW_ONE_ENV_PER_WAVE");
   HModel& m = h->m;
@@ -3147,14 +3164,15 @@ int humanoid_create(HumanoidEnv** out, const std::vector<int32_t>& mi, const std
   p.reset_template = -1;
   if (p.task == TASK_WALK && !getenv("LHW_NO_RESET_TEMPLATE")) {
     // reset the template record (index N) once with the ordinary reset kernel; auto-resets copy its state from then on
-    HParams pp = p;
-    pp.env_first = (int)N; pp.env_count = 1; pp.only_flagged = 0;
-    hipLaunchKernelGGL((humanoid_kernel<1, TASK_WALK, 64>), dim3(1), dim3(64), 0, 0, h->m, pp, h->st, (const float*)nullptr, (float*)nullptr,
+    if (!humanoid_upload_params(h)) { humanoid_destroy(h); return lhw_fail(LHW_ERR_HIP, "humanoid_create: parameter upload failed"); }
+    const HLaunch lz{(int)N, 1, 0, 0};
+    hipLaunchKernelGGL((humanoid_kernel<1, TASK_WALK, 64>), dim3(1), dim3(64), 0, 0, h->m, (const HParams*)h->p_dev, lz, h->st, (const float*)nullptr, (float*)nullptr,
                        (float*)nullptr, (float*)nullptr, (unsigned char*)nullptr, (float*)nullptr, (const unsigned char*)nullptr, (double*)nullptr,
                        (double*)nullptr);
     if (hipDeviceSynchronize() != hipSuccess) { humanoid_destroy(h); return lhw_fail(LHW_ERR_HIP, "humanoid_create: reset template launch failed"); }
     p.reset_template = (int)N;
   }
+  if (!humanoid_upload_params(h)) { humanoid_destroy(h); return lhw_fail(LHW_ERR_HIP, "humanoid_create: parameter upload failed"); }
   *out = h;
   return LHW_OK;
 }
@@ -3170,16 +3188,16 @@ void humanoid_destroy(HumanoidEnv* h) {
 #define LAUNCH_OTHER_TASKS(MODE, WIDTH, ...)
 #else
 #define LAUNCH_OTHER_TASKS(MODE, WIDTH, ...)                                                                        \
-    else if (pp_.task == TASK_STEP) hipLaunchKernelGGL((humanoid_kernel<MODE, TASK_STEP, 64>), grid_, dim3(64), 0, s, h->m, pp_, h->st, __VA_ARGS__); \
-    else if (pp_.task == TASK_H1WALK) hipLaunchKernelGGL((humanoid_kernel<MODE, TASK_H1WALK, WIDTH>), grid_, dim3(64), 0, s, h->m, pp_, h->st, __VA_ARGS__); \
-    else hipLaunchKernelGGL((humanoid_kernel<MODE, TASK_STAND, WIDTH>), grid_, dim3(64), 0, s, h->m, pp_, h->st, __VA_ARGS__);
+    else if (pp_.task == TASK_STEP) hipLaunchKernelGGL((humanoid_kernel<MODE, TASK_STEP, 64>), grid_, dim3(64), 0, s, h->m, (const HParams*)h->p_dev, lz_, h->st, __VA_ARGS__); \
+    else if (pp_.task == TASK_H1WALK) hipLaunchKernelGGL((humanoid_kernel<MODE, TASK_H1WALK, WIDTH>), grid_, dim3(64), 0, s, h->m, (const HParams*)h->p_dev, lz_, h->st, __VA_ARGS__); \
+    else hipLaunchKernelGGL((humanoid_kernel<MODE, TASK_STAND, WIDTH>), grid_, dim3(64), 0, s, h->m, (const HParams*)h->p_dev, lz_, h->st, __VA_ARGS__);
 #endif
 #define LAUNCH_RANGE(MODE, WIDTH, FLAGGED, FIRST, COUNT, ...)                                                       \
   do {                                                                                                             \
-    HParams pp_ = h->p;                                                                                            \
-    pp_.env_first = (FIRST); pp_.env_count = (COUNT); pp_.only_flagged = (FLAGGED);                                \
-    const dim3 grid_((pp_.env_count + (64 / WIDTH) - 1) / (64 / WIDTH));                                           \
-    if (pp_.task == TASK_WALK) hipLaunchKernelGGL((humanoid_kernel<MODE, TASK_WALK, WIDTH>), grid_, dim3(64), 0, s, h->m, pp_, h->st, __VA_ARGS__); \
+    const HParams& pp_ = h->p;                                                                                     \
+    const HLaunch lz_{(FIRST), (COUNT), (FLAGGED), h->iteration};                                                  \
+    const dim3 grid_((lz_.env_count + (64 / WIDTH) - 1) / (64 / WIDTH));                                           \
+    if (pp_.task == TASK_WALK) hipLaunchKernelGGL((humanoid_kernel<MODE, TASK_WALK, WIDTH>), grid_, dim3(64), 0, s, h->m, (const HParams*)h->p_dev, lz_, h->st, __VA_ARGS__); \
     LAUNCH_OTHER_TASKS(MODE, WIDTH, __VA_ARGS__)                                                                   \
   } while (0)
 #define LAUNCH(MODE, ...) LAUNCH_RANGE(MODE, 64, 0, 0, h->p.n_envs, __VA_ARGS__)
@@ -3276,7 +3294,7 @@ int humanoid_profile(HumanoidEnv* h, int enable, long long* out16) {
   return 0;
 }
 // curriculum input of the stepping task (stair height, stepping_task.py:305); the other tasks ignore it
-void humanoid_set_iteration(HumanoidEnv* h, int64_t it) { h->p.iteration = (int)std::min<int64_t>(it, 1 << 30); }
+void humanoid_set_iteration(HumanoidEnv* h, int64_t it) { h->iteration = (int)std::min<int64_t>(it, 1 << 30); }
 // sq / sv / frc of the persistent records (fields of the last forward pass) -> host, torque = force * gear
 int humanoid_actuator_state(HumanoidEnv* h, double* pos, double* vel, double* tq) {
   const size_t N = h->p.n_envs;
