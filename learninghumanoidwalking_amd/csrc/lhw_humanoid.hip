@@ -249,6 +249,7 @@ struct HState {
 struct HumanoidEnv {
   HModel m;
   HParams p;
+  HModel* m_dev;    // device copy of m (same reason)
   HParams* p_dev;   // device copy the kernels read (passed by pointer: its fields need not live in SGPRs across the sub-steps)
   int iteration;
   HState st;
@@ -1838,7 +1839,12 @@ __device__ __forceinline__ void solve_tail(const HModel& m, const HParams& p, L&
 #pragma unroll
       for (int k = 0; k < NR; k++) Hrow[k] = Mrow[k];
       {
-        for (int r = 0; r < nrow; r++) {      // (measured: unrolling this loop, or the J^T f loop above, is slower -- DESIGN.md section 4)
+        // only rows that are active (in either env of the wave: the row index must be wave-uniform) contribute
+        unsigned long long mm = __ballot(dactive != 0.0);
+        if constexpr (W == 32) mm = (mm | (mm >> 32)) & 0xffffffffull;
+        while (mm) {      // (measured: unrolling this loop, or the J^T f loop above, is slower -- DESIGN.md section 4)
+          const int r = __ffsll(mm) - 1;
+          mm &= mm - 1;
           const double jl = S.U[U_J + r * NV + dd], cj = S.U[U_DACT + r] * jl;
           hd += cj * jl;
 #pragma unroll
@@ -2714,7 +2720,7 @@ __device__ __forceinline__ bool control_step(const HModel& m, const HParams& p, 
 }
 
 template <int MODE, int TASK, int W>  // MODE: 0 step, 1 reset(mask), 2 set_state, 3 get_state; TASK: TASK_WALK / TASK_STAND / TASK_STEP / TASK_H1WALK; W: lanes per env
-__global__ void __launch_bounds__(64, 2) humanoid_kernel(HModel m, const HParams* __restrict__ pp, HLaunch lz, HState st, const float* __restrict__ act,
+__global__ void __launch_bounds__(64, 2) humanoid_kernel(const HModel* __restrict__ mp, const HParams* __restrict__ pp, HLaunch lz, HState st, const float* __restrict__ act,
                                                       float* __restrict__ obs, float* __restrict__ term_obs,
                                                       float* __restrict__ rew, unsigned char* __restrict__ done_out,
                                                       float* __restrict__ rew_terms, const unsigned char* __restrict__ mask,
@@ -2727,6 +2733,7 @@ __global__ void __launch_bounds__(64, 2) humanoid_kernel(HModel m, const HParams
   if (eidx >= lz.env_count) return;
   const int env = eidx + lz.env_first;
   const HParams& p = *pp;
+  const HModel& m = *mp;
   if (MODE == 1 && mask && !mask[env]) return;
   if (MODE == 0 && lz.only_flagged && !st.slow[env]) return;
   control_step<MODE, TASK, W>(m, p, lz, st, SG[group_id<W>()], env, lane, act, obs, term_obs, rew, done_out, rew_terms, xq, xv);
@@ -2757,7 +2764,14 @@ static bool humanoid_upload_params(HumanoidEnv* h) {
     h->dev_allocs.push_back(d);
     h->p_dev = (HParams*)d;
   }
-  return hipMemcpy(h->p_dev, &h->p, sizeof(HParams), hipMemcpyHostToDevice) == hipSuccess;
+  if (!h->m_dev) {
+    void* d = nullptr;
+    if (hipMalloc(&d, sizeof(HModel)) != hipSuccess) return false;
+    h->dev_allocs.push_back(d);
+    h->m_dev = (HModel*)d;
+  }
+  return hipMemcpy(h->p_dev, &h->p, sizeof(HParams), hipMemcpyHostToDevice) == hipSuccess &&
+         hipMemcpy(h->m_dev, &h->m, sizeof(HModel), hipMemcpyHostToDevice) == hipSuccess;
 }
 
 int humanoid_create(HumanoidEnv** out, const std::vector<int32_t>& mi, const std::vector<double>& md, const LhwEnvConfig* cfg,
@@ -2838,7 +2852,7 @@ int humanoid_create(HumanoidEnv** out, const std::vector<int32_t>& mi, const std
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return lhw_fail(LHW_ERR_NO_DEVICE, "no HIP device");
   HumanoidEnv* h = new HumanoidEnv();
   h->device = cfg->device;
-  h->p_dev = nullptr; h->iteration = 0;
+  h->p_dev = nullptr; h->m_dev = nullptr; h->iteration = 0;
   // two envs per wave (W = 32) where the model fits half a wavefront; the stepping task needs the 16-contact layout throughout
   h->fast = !stepping && np <= 32 && ng <= 16 && nj <= 32 && nb <= (stand ? 15 : 18) && !getenv("LHW_ONE_ENV_PER_WAVE");
   HModel& m = h->m;
@@ -3166,7 +3180,7 @@ int humanoid_create(HumanoidEnv** out, const std::vector<int32_t>& mi, const std
     // reset the template record (index N) once with the ordinary reset kernel; auto-resets copy its state from then on
     if (!humanoid_upload_params(h)) { humanoid_destroy(h); return lhw_fail(LHW_ERR_HIP, "humanoid_create: parameter upload failed"); }
     const HLaunch lz{(int)N, 1, 0, 0};
-    hipLaunchKernelGGL((humanoid_kernel<1, TASK_WALK, 64>), dim3(1), dim3(64), 0, 0, h->m, (const HParams*)h->p_dev, lz, h->st, (const float*)nullptr, (float*)nullptr,
+    hipLaunchKernelGGL((humanoid_kernel<1, TASK_WALK, 64>), dim3(1), dim3(64), 0, 0, (const HModel*)h->m_dev, (const HParams*)h->p_dev, lz, h->st, (const float*)nullptr, (float*)nullptr,
                        (float*)nullptr, (float*)nullptr, (unsigned char*)nullptr, (float*)nullptr, (const unsigned char*)nullptr, (double*)nullptr,
                        (double*)nullptr);
     if (hipDeviceSynchronize() != hipSuccess) { humanoid_destroy(h); return lhw_fail(LHW_ERR_HIP, "humanoid_create: reset template launch failed"); }
@@ -3188,16 +3202,16 @@ void humanoid_destroy(HumanoidEnv* h) {
 #define LAUNCH_OTHER_TASKS(MODE, WIDTH, ...)
 #else
 #define LAUNCH_OTHER_TASKS(MODE, WIDTH, ...)                                                                        \
-    else if (pp_.task == TASK_STEP) hipLaunchKernelGGL((humanoid_kernel<MODE, TASK_STEP, 64>), grid_, dim3(64), 0, s, h->m, (const HParams*)h->p_dev, lz_, h->st, __VA_ARGS__); \
-    else if (pp_.task == TASK_H1WALK) hipLaunchKernelGGL((humanoid_kernel<MODE, TASK_H1WALK, WIDTH>), grid_, dim3(64), 0, s, h->m, (const HParams*)h->p_dev, lz_, h->st, __VA_ARGS__); \
-    else hipLaunchKernelGGL((humanoid_kernel<MODE, TASK_STAND, WIDTH>), grid_, dim3(64), 0, s, h->m, (const HParams*)h->p_dev, lz_, h->st, __VA_ARGS__);
+    else if (pp_.task == TASK_STEP) hipLaunchKernelGGL((humanoid_kernel<MODE, TASK_STEP, 64>), grid_, dim3(64), 0, s, (const HModel*)h->m_dev, (const HParams*)h->p_dev, lz_, h->st, __VA_ARGS__); \
+    else if (pp_.task == TASK_H1WALK) hipLaunchKernelGGL((humanoid_kernel<MODE, TASK_H1WALK, WIDTH>), grid_, dim3(64), 0, s, (const HModel*)h->m_dev, (const HParams*)h->p_dev, lz_, h->st, __VA_ARGS__); \
+    else hipLaunchKernelGGL((humanoid_kernel<MODE, TASK_STAND, WIDTH>), grid_, dim3(64), 0, s, (const HModel*)h->m_dev, (const HParams*)h->p_dev, lz_, h->st, __VA_ARGS__);
 #endif
 #define LAUNCH_RANGE(MODE, WIDTH, FLAGGED, FIRST, COUNT, ...)                                                       \
   do {                                                                                                             \
     const HParams& pp_ = h->p;                                                                                     \
     const HLaunch lz_{(FIRST), (COUNT), (FLAGGED), h->iteration};                                                  \
     const dim3 grid_((lz_.env_count + (64 / WIDTH) - 1) / (64 / WIDTH));                                           \
-    if (pp_.task == TASK_WALK) hipLaunchKernelGGL((humanoid_kernel<MODE, TASK_WALK, WIDTH>), grid_, dim3(64), 0, s, h->m, (const HParams*)h->p_dev, lz_, h->st, __VA_ARGS__); \
+    if (pp_.task == TASK_WALK) hipLaunchKernelGGL((humanoid_kernel<MODE, TASK_WALK, WIDTH>), grid_, dim3(64), 0, s, (const HModel*)h->m_dev, (const HParams*)h->p_dev, lz_, h->st, __VA_ARGS__); \
     LAUNCH_OTHER_TASKS(MODE, WIDTH, __VA_ARGS__)                                                                   \
   } while (0)
 #define LAUNCH(MODE, ...) LAUNCH_RANGE(MODE, 64, 0, 0, h->p.n_envs, __VA_ARGS__)
