@@ -2719,8 +2719,11 @@ __device__ __forceinline__ bool control_step(const HModel& m, const HParams& p, 
   return false;
 }
 
+#ifndef LHW_WAVES_PER_SIMD
+#define LHW_WAVES_PER_SIMD 2      // 256 VGPRs per lane; 8 one-wave blocks per CU (the LDS working set allows no more)
+#endif
 template <int MODE, int TASK, int W>  // MODE: 0 step, 1 reset(mask), 2 set_state, 3 get_state; TASK: TASK_WALK / TASK_STAND / TASK_STEP / TASK_H1WALK; W: lanes per env
-__global__ void __launch_bounds__(64, 2) humanoid_kernel(const HModel* __restrict__ mp, const HParams* __restrict__ pp, HLaunch lz, HState st, const float* __restrict__ act,
+__global__ void __launch_bounds__(64, LHW_WAVES_PER_SIMD) humanoid_kernel(const HModel* __restrict__ mp, const HParams* __restrict__ pp, HLaunch lz, HState st, const float* __restrict__ act,
                                                       float* __restrict__ obs, float* __restrict__ term_obs,
                                                       float* __restrict__ rew, unsigned char* __restrict__ done_out,
                                                       float* __restrict__ rew_terms, const unsigned char* __restrict__ mask,
