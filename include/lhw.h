@@ -216,6 +216,17 @@ int lhw_env_pop_rerun_count(LhwEnv* env, int64_t* reruns);
 int lhw_debug_gemm(int32_t a_kc, int32_t b_kc, int32_t wt, int32_t M, int32_t N, int32_t K, const float* A, int32_t lda, const float* B,
                    int32_t ldb, float* C, int32_t ldc, const float* bias, int32_t relu, const float* mask, int32_t ldmask,
                    int32_t k_chunk, float* part, float* colsum, float* colsum_out, void* stream);
+/* Test hooks for the LDS-resident strip kernels of the update's MLPs (csrc/lhw_mlp_strip.hip; reference:
+ * /root/reference/rl/algos/ppo.py:299-406, the actor / critic forward and the activation gradients of loss.backward()):
+ * forward  h1 = relu(x W1^T + b1), h2 = relu(h1 W2^T + b2), y = h2 W3^T + b3 for R rows in one launch;
+ * backward dh2 = (dy W3) * (h2 > 0), dh1 = (dh2 W2) * (h1 > 0).  Weights in torch Linear layout ([out][in]; W1 row stride Dp,
+ * a multiple of 4; W3 [Op][H]); device buffers; H must be 256, Dp <= 64, O <= 32 (LHW_ERR_UNSUPPORTED otherwise).  wt_scratch:
+ * (Dp + 256 + Op) * 256 floats for the transposed weight copies the forward kernel reads. */
+int lhw_debug_mlp_strip_forward(int32_t H, int32_t Dp, int32_t O, int32_t Op, const float* w1, const float* b1, const float* w2,
+                                const float* b2, const float* w3, const float* b3, const float* x, int32_t ldx, int32_t R,
+                                float* h1, float* h2, float* y, float* wt_scratch, void* stream);
+int lhw_debug_mlp_strip_backward(int32_t H, int32_t O, int32_t Op, const float* w2, const float* w3, const float* dy, int32_t R,
+                                 const float* h1, const float* h2, float* dh2, float* dh1, void* stream);
 /* Diagnostic (load balance): the first call arms the recording; later calls return, per env, the shader-clock cycles its
  * wavefront group spent in the most recent control-step launch.  HOST pointer [N] int64, synchronous; humanoid tasks only. */
 int lhw_env_debug_wave_cycles(LhwEnv* env, int64_t* cycles_host);

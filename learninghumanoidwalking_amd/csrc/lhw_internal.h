@@ -28,3 +28,22 @@ int humanoid_profile(HumanoidEnv* h, int enable, long long* out16);
 int humanoid_task_inputs(HumanoidEnv* h, int enable /* -1: leave */, double* out_host, double** out_dev);
 int humanoid_actuator_state(HumanoidEnv* h, double* pos, double* vel, double* tq);
 int humanoid_step_record(HumanoidEnv* h, double* seq, double* floor_z, int32_t* istate);
+
+// LDS-resident strip kernels of the 3-layer MLPs (lhw_mlp_strip.hip); hidden width 256 only, callers fall back to the per-layer
+// GEMMs otherwise
+struct MlpStripFwd {
+  const float *w1t, *b1, *w2t, *b2, *w3t, *b3;   // TRANSPOSED weights ([in][out]: W1^T [Dp][256], W2^T [256][256], W3^T [256][Op]) from mlp_strip_prepare
+  const float* x; int ldx;                   // [R][ldx] inputs (Dp used columns)
+  int Dp, O, Op, R;
+  float *h1, *h2, *y;                        // [R][256], [R][256], [R][Op]
+};
+struct MlpStripBwd {
+  const float *w2, *w3, *dy, *h1, *h2;       // torch Linear layout [out][in]: W2 [256][256], W3 [Op][256]; dy [R][Op]
+  int O, Op, R;
+  float *dh2, *dh1;                          // [R][256] each
+};
+bool mlp_strip_supported(int H, int Dp, int O, int Op);
+size_t mlp_strip_wt_floats(int Dp, int Op);
+void mlp_strip_prepare(const float* w1, const float* w2, const float* w3, int Dp, int O, int Op, float* wt, hipStream_t s);
+void mlp_strip_forward(const MlpStripFwd& a, hipStream_t s);
+void mlp_strip_backward(const MlpStripBwd& a, hipStream_t s);

@@ -1,0 +1,300 @@
+// LDS-resident strip kernels for the 3-layer MLPs of the PPO update (actor / critic: in -> 256 -> 256 -> out).
+//
+// Takes over, for one network, the layer-by-layer passes of /root/reference/rl/algos/ppo.py:299-406 (`update_actor_critic`:
+// actor / critic forward, loss.backward()) that lhw_ppo.hip otherwise runs as one GEMM launch per layer with the activations
+// round-tripping HBM between the launches.  A workgroup owns a SLAB of 64 rows and keeps it in LDS through all layers:
+//
+//   forward   x slab -> h1 = relu(x W1^T + b1) -> h2 = relu(h1 W2^T + b2) -> y = h2 W3^T + b3
+//             (h1 / h2 are written to HBM once, for the backward pass, and never read back by the forward pass)
+//   backward  dy slab -> dh2 = (dy W3) * (h2 > 0) -> dh1 = (dh2 W2) * (h1 > 0)
+//             (dh2 / dh1 are written once, for the weight-gradient GEMMs, which contract over the minibatch rows and stay
+//             split-K GEMMs in lhw_ppo.hip)
+//
+// The slab sits k-major in LDS (S[k][row]): that is the A-operand layout of v_mfma_f32_32x32x2_f32 (lane l: A[row = l % 32]
+// [k = l / 32]), so a layer's output tile, written back column by column, IS the next layer's A operand.  The weights are the
+// B operand and come straight from global memory (L2-resident, 0.3 MB per network) in [in][out] order -- for the forward pass
+// from transposed copies made once per optimiser step (mlp_strip_prepare) -- so a wave's load of one k row of its 64 output
+// columns is two 128-byte segments and the K loop needs no LDS staging and no barrier: 256 threads = 4 waves, wave w owns all
+// 64 rows x the 64 columns 64 w .. 64 w + 63 (2 x 2 MFMA tiles: one A read and one B load feed two MFMAs each), the operands
+// of K step s + 1 are in flight while step s is multiplied, and the only barriers are the two per layer around the slab
+// hand-off.  70 KB of LDS per block: two blocks per CU, so one block's epilogue (the single HBM write of h / dh) overlaps the
+// other's products.  The read-out layer (N <= 32) is split over K between the four waves and summed in a fixed order.
+// Float32 operands and accumulation (the f32-input MFMA is an fmaf chain over ascending k), so the hidden layers are
+// bit-identical to the per-layer GEMM path and the networks keep the reference's float32 semantics; only the read-out's
+// summation order differs.
+#include <hip/hip_runtime.h>
+
+#include "../../include/lhw.h"
+#include "lhw_internal.h"
+
+#ifndef __HIP_EMU__
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+#endif
+
+#define SH 256          // hidden width the strip kernels are compiled for
+#define SROWS 64        // rows per slab
+#define SLD (SROWS + 4) // slab row stride (floats)
+#define SBK 16          // K step (one register buffer of weight operands)
+#define STHR 256
+#define SXK 64          // capacity of the input slab (padded input width of the first layer / output width of the last)
+
+struct StripLds {
+  float S[SH][SLD];         // activation slab, k-major (69 632 B: two workgroups per CU).  The input slab (x / dy, at most SXK
+};                          // columns) occupies its last SXK rows until the first layer's products are done
+
+__device__ __forceinline__ void zero_acc(f32x16 (&acc)[2][2]) {
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+}
+
+// One K step (SBK rows of k) of operands, as the MFMA wants them: lane l holds, for kk = 0 .. SBK/2, the element of row
+// k0 + 2 kk + l / 32.
+struct WOp { float v[SBK / 2][2]; };   // weights: columns n0 + l % 32 and n0 + 32 + l % 32
+
+// weights of step k0 straight from global memory: stored [K][ldb] with the output unit contiguous, so one load instruction of
+// the wave fetches two 128-byte segments; no LDS staging.  Rows k >= K are clamped copies of row K - 1 (the slab holds zeros
+// there), so the prefetches can run past the end unconditionally.
+__device__ __forceinline__ void wload(WOp& w, const float* __restrict__ Bg, const int ldb, const int K, const int k0) {
+  const int lane = threadIdx.x & 63, l31 = lane & 31, kh = lane >> 5, n0 = (threadIdx.x >> 6) * 64 + l31;
+#pragma unroll
+  for (int kk = 0; kk < SBK / 2; kk++) {
+    const int k = min(k0 + kk * 2 + kh, K - 1);
+#pragma unroll
+    for (int j = 0; j < 2; j++) w.v[kk][j] = Bg[(size_t)k * ldb + n0 + 32 * j];
+  }
+}
+
+// acc[i][j] += (A[rows 32 i .. +32][0 .. K) * B[0 .. K)[columns 64 wave + 32 j .. +32])^T.  A is the LDS slab (k-major; rows
+// k >= K up to the next multiple of SBK must hold ZEROS), B the weights (wload).  No barrier in the K loop: the four waves of the
+// block own disjoint output columns and share only the read-only slab.  The weights of step s + 1 are in flight while step s is
+// multiplied; `w0` arrives holding the weights of step 0 (the caller
+// issues that load early, e.g. before the previous layer's epilogue).
+// The weights are the MFMA's A operand and the slab its B operand, so the accumulators hold the TRANSPOSED output tile: lane =
+// slab row, four consecutive output units per register quad (16-byte row-major stores in the epilogue).
+__device__ __forceinline__ void slab_mma(const float (*A)[SLD], const int K, const float* __restrict__ Bg, const int ldb, WOp& w0,
+                                         f32x16 (&acc)[2][2]) {
+  const int lane = threadIdx.x & 63, l31 = lane & 31, kh = lane >> 5;
+  WOp w1;
+  auto mul = [&](const WOp& w, int k0) {
+#pragma unroll
+    for (int kk = 0; kk < SBK / 2; kk++) {
+      const int k = k0 + kk * 2 + kh;
+      const float a0 = A[k][l31], a1 = A[k][32 + l31];
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w.v[kk][0], a0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w.v[kk][1], a0, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w.v[kk][0], a1, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w.v[kk][1], a1, acc[1][1], 0, 0, 0);
+    }
+  };
+  // (the prefetches are unconditional, so the loop body is one straight path and a multiply waits only for its own, older,
+  // loads; the scheduling barriers keep the machine scheduler from sinking a prefetch down to its first use.  Prefetching the
+  // slab rows a step ahead as well measured slower: 155 vs 147 us per 65536-row forward pass)
+  for (int k0 = 0; k0 < K; k0 += 2 * SBK) {
+    wload(w1, Bg, ldb, K, k0 + SBK);
+    __builtin_amdgcn_sched_barrier(0);
+    mul(w0, k0);
+    __builtin_amdgcn_sched_barrier(0);
+    wload(w0, Bg, ldb, K, k0 + 2 * SBK);
+    __builtin_amdgcn_sched_barrier(0);
+    if (k0 + SBK < K) mul(w1, k0 + SBK);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// Epilogue of a 256-wide layer: v = acc (+ bias[n]) (ReLU) (masked by mask[row][n] > 0); to HBM (row-major, ld SH) and, with
+// TO_SLAB, into the slab as the next layer's operand.  The accumulators hold the transposed tile (see slab_mma): lane l of tile
+// (i, j) owns slab row 32 i + l % 32 and, in registers 4 g .. 4 g + 3, the output units 64 wave + 32 j + 8 g + 4 (l / 32) + 0..3 --
+// one 16-byte store (and one 16-byte mask / bias load) per register quad.  Rows beyond R are computed (finite values from zero
+// inputs) but never stored to HBM.
+template <bool TO_SLAB, bool FULL>
+__device__ __forceinline__ void store_act_t(StripLds& L, const f32x16 (&acc)[2][2], const float* __restrict__ bias, const bool relu,
+                                            const float* __restrict__ mask, float* __restrict__ out, const int row0, const int R) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, kh = lane >> 5;
+#pragma unroll
+  for (int j = 0; j < 2; j++) {
+    const int nb = wave * 64 + 32 * j + 4 * kh;
+    // the mask values of this column tile first, as one batch of independent loads (interleaved with the stores below they
+    // would be serialised: the compiler cannot prove that `out` does not alias `mask`)
+    float4 mk[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+      for (int g = 0; g < 4; g++) {
+        const int row = 32 * i + l31;
+        mk[i][g] = make_float4(1.f, 1.f, 1.f, 1.f);
+        if (mask && (FULL || row0 + row < R)) mk[i][g] = *reinterpret_cast<const float4*>(mask + (size_t)(row0 + row) * SH + nb + 8 * g);
+      }
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+      const int n = nb + 8 * g;
+      float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (bias) bv = *reinterpret_cast<const float4*>(bias + n);
+#pragma unroll
+      for (int i = 0; i < 2; i++) {
+        const int row = 32 * i + l31;
+        const bool live = FULL || row0 + row < R;
+        float4 v = make_float4(acc[i][j][4 * g] + bv.x, acc[i][j][4 * g + 1] + bv.y, acc[i][j][4 * g + 2] + bv.z, acc[i][j][4 * g + 3] + bv.w);
+        if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        if (mask) {
+          v.x = (live && mk[i][g].x > 0.f) ? v.x : 0.f; v.y = (live && mk[i][g].y > 0.f) ? v.y : 0.f;
+          v.z = (live && mk[i][g].z > 0.f) ? v.z : 0.f; v.w = (live && mk[i][g].w > 0.f) ? v.w : 0.f;
+        }
+        if (TO_SLAB) { L.S[n][row] = v.x; L.S[n + 1][row] = v.y; L.S[n + 2][row] = v.z; L.S[n + 3][row] = v.w; }
+        if (live) *reinterpret_cast<float4*>(out + (size_t)(row0 + row) * SH + n) = v;
+      }
+    }
+  }
+}
+template <bool TO_SLAB>
+__device__ __forceinline__ void store_act(StripLds& L, const f32x16 (&acc)[2][2], const float* __restrict__ bias, const bool relu,
+                                          const float* __restrict__ mask, float* __restrict__ out, const int row0, const int R) {
+  if (row0 + SROWS <= R) store_act_t<TO_SLAB, true>(L, acc, bias, relu, mask, out, row0, R);   // (all but the last slab: no per-row tests)
+  else store_act_t<TO_SLAB, false>(L, acc, bias, relu, mask, out, row0, R);
+}
+
+// stage a [rows][K] row-major slab (row stride ld) k-major into X, zero-padded to a multiple of SBK in k and beyond R in rows
+__device__ __forceinline__ void stage_input(float (*X)[SLD], const float* __restrict__ x, const int ld, const int K, const int row0, const int R) {
+  const int Kp = (K + SBK - 1) & ~(SBK - 1);
+  for (int i = threadIdx.x; i < SROWS * Kp; i += STHR) {
+    const int r = i / Kp, k = i - r * Kp;
+    float v = 0.f;
+    if (k < K && row0 + r < R) v = x[(size_t)(row0 + r) * ld + k];
+    X[k][r] = v;
+  }
+}
+
+__global__ void __launch_bounds__(STHR, 2) mlp_fwd_strip_kernel(MlpStripFwd a) {
+  __shared__ StripLds L;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, kh = lane >> 5;
+  const int row0 = (int)blockIdx.x * SROWS;
+  float (*X)[SLD] = &L.S[SH - SXK];
+  WOp w;
+  wload(w, a.w1t, SH, a.Dp, 0);   // (the first weights of a layer are in flight while the slab is staged / the previous epilogue runs)
+  stage_input(X, a.x, a.ldx, a.Dp, row0, a.R);
+  __syncthreads();
+  f32x16 acc[2][2];
+  zero_acc(acc);
+  slab_mma(X, a.Dp, a.w1t, SH, w, acc);
+  wload(w, a.w2t, SH, SH, 0);
+  __syncthreads();   // every wave is done with the input slab
+  store_act<true>(L, acc, a.b1, true, nullptr, a.h1, row0, a.R);
+  __syncthreads();
+  zero_acc(acc);
+  slab_mma(L.S, SH, a.w2t, SH, w, acc);
+  __syncthreads();
+  store_act<true>(L, acc, a.b2, true, nullptr, a.h2, row0, a.R);
+  __syncthreads();
+  // read-out: y = h2 W3^T + b3, N = O <= 32: one column tile; wave w takes k in [64 w, 64 w + 64) for both row tiles, the four
+  // partial products are summed in wave order
+  f32x16 p[2];
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) p[i][r] = 0.f;
+#pragma unroll 8
+  for (int kk = 0; kk < 32; kk++) {
+    const int k = wave * 64 + kk * 2 + kh;
+    const float bv = a.w3t[(size_t)k * a.Op + min(l31, a.O - 1)], b = l31 < a.O ? bv : 0.f;
+    p[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(L.S[k][l31], b, p[0], 0, 0, 0);
+    p[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(L.S[k][32 + l31], b, p[1], 0, 0, 0);
+  }
+  __syncthreads();   // all waves are done with the slab: it now holds the four partial products
+  float (*P)[SROWS][32] = reinterpret_cast<float (*)[SROWS][32]>(&L.S[0][0]);
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) P[wave][32 * i + (r & 3) + 8 * (r >> 2) + 4 * kh][l31] = p[i][r];
+  __syncthreads();
+  for (int i = tid; i < SROWS * 32; i += STHR) {
+    const int row = i >> 5, col = i & 31;
+    if (col < a.O && row0 + row < a.R)
+      a.y[(size_t)(row0 + row) * a.Op + col] = (((P[0][row][col] + P[1][row][col]) + P[2][row][col]) + P[3][row][col]) + a.b3[col];
+  }
+}
+
+__global__ void __launch_bounds__(STHR, 2) mlp_bwd_strip_kernel(MlpStripBwd a) {
+  __shared__ StripLds L;
+  const int row0 = (int)blockIdx.x * SROWS;
+  float (*X)[SLD] = &L.S[SH - SXK];
+  WOp w;
+  wload(w, a.w3, SH, a.O, 0);
+  stage_input(X, a.dy, a.Op, a.O, row0, a.R);
+  __syncthreads();
+  f32x16 acc[2][2];
+  zero_acc(acc);
+  slab_mma(X, a.O, a.w3, SH, w, acc);                                       // dy W3: B[k = o][n] = W3[o][n]
+  wload(w, a.w2, SH, SH, 0);
+  __syncthreads();
+  store_act<true>(L, acc, nullptr, false, a.h2, a.dh2, row0, a.R);
+  __syncthreads();
+  zero_acc(acc);
+  slab_mma(L.S, SH, a.w2, SH, w, acc);                                      // dh2 W2: B[k = o][n = i] = W2[o][i]
+  store_act<false>(L, acc, nullptr, false, a.h1, a.dh1, row0, a.R);
+}
+
+// WT [cols][rows] <- W [rows][ld] for three matrices in one launch (the forward pass multiplies by W^T: its weight operand must
+// have the output unit contiguous); 32 x 32 tiles through LDS, block b of matrix m handles tile b - first[m]
+struct TransposeJob { const float* W; float* WT; int rows, cols, ld, ldt, first; };
+struct TransposeJobs { TransposeJob j[3]; };
+__global__ void __launch_bounds__(256) transpose3_kernel(TransposeJobs J) {
+  __shared__ float T[32][33];
+  const int b = (int)blockIdx.x, m = b >= J.j[2].first ? 2 : (b >= J.j[1].first ? 1 : 0);
+  const TransposeJob q = J.j[m];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+  const int tc = (q.cols + 31) / 32, t = b - q.first, r0 = (t / tc) * 32, c0 = (t % tc) * 32;
+  for (int y = ty; y < 32; y += 8) T[y][tx] = (r0 + y < q.rows && c0 + tx < q.cols) ? q.W[(size_t)(r0 + y) * q.ld + c0 + tx] : 0.f;
+  __syncthreads();
+  for (int y = ty; y < 32; y += 8)
+    if (c0 + y < q.cols && r0 + tx < q.rows) q.WT[(size_t)(c0 + y) * q.ldt + r0 + tx] = T[tx][y];
+}
+
+size_t mlp_strip_wt_floats(int Dp, int Op) { return (size_t)Dp * SH + (size_t)SH * SH + (size_t)SH * Op; }
+
+// transposed copies of the three weight matrices ([in][out]) for the forward strip kernel, into wt (mlp_strip_wt_floats floats)
+void mlp_strip_prepare(const float* w1, const float* w2, const float* w3, int Dp, int O, int Op, float* wt, hipStream_t s) {
+  float *w1t = wt, *w2t = wt + (size_t)Dp * SH, *w3t = w2t + (size_t)SH * SH;
+  auto tiles = [](int rows, int cols) { return ((rows + 31) / 32) * ((cols + 31) / 32); };
+  TransposeJobs J;
+  J.j[0] = TransposeJob{w1, w1t, SH, Dp, Dp, SH, 0};
+  J.j[1] = TransposeJob{w2, w2t, SH, SH, SH, SH, tiles(SH, Dp)};
+  J.j[2] = TransposeJob{w3, w3t, O, SH, SH, Op, tiles(SH, Dp) + tiles(SH, SH)};
+  hipLaunchKernelGGL(transpose3_kernel, dim3(J.j[2].first + tiles(O, SH)), dim3(256), 0, s, J);
+}
+
+bool mlp_strip_supported(int H, int Dp, int O, int Op) { return H == SH && Dp > 0 && Dp <= SXK && (Dp & 3) == 0 && O > 0 && O <= 32 && Op >= O; }
+
+void mlp_strip_forward(const MlpStripFwd& a, hipStream_t s) {
+  if (a.R <= 0) return;
+  hipLaunchKernelGGL(mlp_fwd_strip_kernel, dim3((a.R + SROWS - 1) / SROWS), dim3(STHR), 0, s, a);
+}
+
+void mlp_strip_backward(const MlpStripBwd& a, hipStream_t s) {
+  if (a.R <= 0) return;
+  hipLaunchKernelGGL(mlp_bwd_strip_kernel, dim3((a.R + SROWS - 1) / SROWS), dim3(STHR), 0, s, a);
+}
+
+extern "C" int lhw_debug_mlp_strip_forward(int32_t H, int32_t Dp, int32_t O, int32_t Op, const float* w1, const float* b1, const float* w2,
+                                           const float* b2, const float* w3, const float* b3, const float* x, int32_t ldx, int32_t R,
+                                           float* h1, float* h2, float* y, float* wt_scratch, void* stream) {
+  if (!wt_scratch || !w1 || !b1 || !w2 || !b2 || !w3 || !b3 || !x || !h1 || !h2 || !y) return lhw_fail(LHW_ERR_ARG, "null argument");
+  if (!mlp_strip_supported(H, Dp, O, Op) || ldx < Dp) return lhw_fail(LHW_ERR_UNSUPPORTED, "strip kernels: hidden width 256, padded input width <= 64, outputs <= 32");
+  mlp_strip_prepare(w1, w2, w3, Dp, O, Op, wt_scratch, (hipStream_t)stream);
+  MlpStripFwd a{wt_scratch, b1, wt_scratch + (size_t)Dp * SH, b2, wt_scratch + (size_t)Dp * SH + (size_t)SH * SH, b3, x, ldx, Dp, O, Op, R, h1, h2, y};
+  mlp_strip_forward(a, (hipStream_t)stream);
+  return hipGetLastError() == hipSuccess ? LHW_OK : lhw_fail(LHW_ERR_HIP, "mlp_fwd_strip_kernel launch failed");
+}
+
+extern "C" int lhw_debug_mlp_strip_backward(int32_t H, int32_t O, int32_t Op, const float* w2, const float* w3, const float* dy, int32_t R,
+                                            const float* h1, const float* h2, float* dh2, float* dh1, void* stream) {
+  if (!w2 || !w3 || !dy || !h1 || !h2 || !dh2 || !dh1) return lhw_fail(LHW_ERR_ARG, "null argument");
+  if (!mlp_strip_supported(H, 4, O, Op)) return lhw_fail(LHW_ERR_UNSUPPORTED, "strip kernels: hidden width 256, outputs <= 32");
+  MlpStripBwd a{w2, w3, dy, h1, h2, O, Op, R, dh2, dh1};
+  mlp_strip_backward(a, (hipStream_t)stream);
+  return hipGetLastError() == hipSuccess ? LHW_OK : lhw_fail(LHW_ERR_HIP, "mlp_bwd_strip_kernel launch failed");
+}

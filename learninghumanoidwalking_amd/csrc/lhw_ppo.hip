@@ -445,6 +445,7 @@ struct LhwPpo {
   float *stats = nullptr;  // [16] loss scalars; [8],[9] grad norm^2 actor/critic
   float *part = nullptr;       // split-K partial tiles [max slices][H*H]
   float *dstd = nullptr;       // per-row d loss / d std [R][Op]
+  float *wt_a = nullptr, *wt_c = nullptr;   // [in][out] weight copies for the strip kernels (hidden width 256 only)
   float *stats_part = nullptr; // per-block loss partials [blocks][NSTAT]
   const float* imit_target = nullptr;          // imitation term of the NEXT lhw_ppo_grad call (lhw_ppo_set_imitation)
   const unsigned char* imit_mask = nullptr;
@@ -466,8 +467,22 @@ struct LhwPpo {
   } while (0)
 
 // y = mlp(x) for R rows; keeps h1/h2 for the backward pass.  half != 0: fp16 operands (rollout inference only)
+// LHW_MLP_STRIP (tuning aid): 0 = per-layer GEMMs everywhere, 1 = LDS-resident strip kernels for the update's forward and
+// activation-gradient passes, 2 = for the rollout inference as well (default: the rollout and the update then evaluate the
+// networks with the same kernel, bit for bit)
+static int strip_mode() {
+  static const int m = getenv("LHW_MLP_STRIP") ? atoi(getenv("LHW_MLP_STRIP")) : 2;
+  return m;
+}
 static void mlp_forward(const MlpLayout& L, const float* theta, const float* x, int ldx, int R, float* h1, float* h2,
-                        float* y, hipStream_t s, int half = 0) {
+                        float* y, hipStream_t s, int half = 0, float* strip_wt = nullptr) {
+  if (strip_wt && !half && mlp_strip_supported(L.H, L.Dp, L.O, L.Op)) {   // one launch, h1 / h2 stay in LDS between the layers
+    mlp_strip_prepare(theta + L.w1, theta + L.w2, theta + L.w3, L.Dp, L.O, L.Op, strip_wt, s);   // [in][out] copies of the weights
+    MlpStripFwd a{strip_wt, theta + L.b1, strip_wt + (size_t)L.Dp * L.H, theta + L.b2, strip_wt + (size_t)L.Dp * L.H + (size_t)L.H * L.H,
+                  theta + L.b3, x, ldx, L.Dp, L.O, L.Op, R, h1, h2, y};
+    mlp_strip_forward(a, s);
+    return;
+  }
   GemmArgs g{};
   g.A = x; g.lda = ldx; g.B = theta + L.w1; g.ldb = L.Dp; g.C = h1; g.ldc = L.H; g.M = R; g.N = L.H; g.K = L.Dp;
   g.bias = theta + L.b1; g.relu = 1;
@@ -517,25 +532,34 @@ static BwdParts bwd_parts_carve(const MlpLayout& L, size_t rows, int passes, flo
 static void mlp_backward(const MlpLayout& L, const float* theta, const float* x, int ldx, int R, const float* h1, const float* h2,
                          const float* dy, float* dh2, float* dh1, const BwdParts& P, BwdSlices& z, hipStream_t s, int half = 0) {
   GemmArgs g{};
+  const bool strip = strip_mode() >= 1 && !half && mlp_strip_supported(L.H, L.Dp, L.O, L.Op);
+  if (strip) {   // dh2 = (dy W3) * (h2 > 0) and dh1 = (dh2 W2) * (h1 > 0) in one launch, the dh2 slab staying in LDS
+    MlpStripBwd a{theta + L.w2, theta + L.w3, dy, h1, h2, L.O, L.Op, R, dh2, dh1};
+    mlp_strip_backward(a, s);
+  }
   // dW3 [O][H] = dy^T h2 ; db3 = colsum(dy)
   g.A = dy; g.lda = L.Op; g.B = h2; g.ldb = L.H; g.M = L.O; g.N = L.H; g.K = R;
   g.part = P.w3 + (size_t)z.w3 * L.O * L.H; g.colsum = P.b3 + (size_t)z.w3 * L.O; g.k_chunk = KC_SKINNY;
   launch_gemm<false, false>(g, s, 1, 0, half);
   // dh2 = (dy W3) * (h2 > 0)
-  g = GemmArgs{};
-  g.A = dy; g.lda = L.Op; g.B = theta + L.w3; g.ldb = L.H; g.C = dh2; g.ldc = L.H; g.M = R; g.N = L.H; g.K = L.O;
-  g.mask = h2; g.ldmask = L.H;
-  launch_gemm<true, false>(g, s, 0, 0, half);
+  if (!strip) {
+    g = GemmArgs{};
+    g.A = dy; g.lda = L.Op; g.B = theta + L.w3; g.ldb = L.H; g.C = dh2; g.ldc = L.H; g.M = R; g.N = L.H; g.K = L.O;
+    g.mask = h2; g.ldmask = L.H;
+    launch_gemm<true, false>(g, s, 0, 0, half);
+  }
   // dW2 = dh2^T h1 ; db2 = colsum(dh2)
   g = GemmArgs{};
   g.A = dh2; g.lda = L.H; g.B = h1; g.ldb = L.H; g.M = L.H; g.N = L.H; g.K = R;
   g.part = P.w2 + (size_t)z.w2 * L.H * L.H; g.colsum = P.b2 + (size_t)z.w2 * L.H; g.k_chunk = KC_WIDE;
   launch_gemm<false, false>(g, s, 1, 0, half);
   // dh1 = (dh2 W2) * (h1 > 0)
-  g = GemmArgs{};
-  g.A = dh2; g.lda = L.H; g.B = theta + L.w2; g.ldb = L.H; g.C = dh1; g.ldc = L.H; g.M = R; g.N = L.H; g.K = L.H;
-  g.mask = h1; g.ldmask = L.H;
-  launch_gemm<true, false>(g, s, 0, 0, half);
+  if (!strip) {
+    g = GemmArgs{};
+    g.A = dh2; g.lda = L.H; g.B = theta + L.w2; g.ldb = L.H; g.C = dh1; g.ldc = L.H; g.M = R; g.N = L.H; g.K = L.H;
+    g.mask = h1; g.ldmask = L.H;
+    launch_gemm<true, false>(g, s, 0, 0, half);
+  }
   // dW1 [H][Dp] = dh1^T x ; db1 = colsum(dh1)
   g = GemmArgs{};
   g.A = dh1; g.lda = L.H; g.B = x; g.ldb = ldx; g.M = L.H; g.N = L.Dp; g.K = R;
@@ -868,6 +892,8 @@ extern "C" int lhw_ppo_create(const LhwPpoConfig* c, LhwPpo** out) {
   p->max_slices = (int)((R + 511) / 512);
   ok = ok && alloc(&p->part, std::max<size_t>((size_t)p->max_slices * H * std::max<size_t>(H, Dp), (size_t)COLSUM_CHUNKS * H));
   ok = ok && alloc(&p->bwd_part, bwd_parts_floats(p->la, R, 2) + bwd_parts_floats(p->lc, R, 1));
+  if (mlp_strip_supported(p->la.H, p->la.Dp, p->la.O, p->la.Op)) ok = ok && alloc(&p->wt_a, mlp_strip_wt_floats(p->la.Dp, p->la.Op));
+  if (mlp_strip_supported(p->lc.H, p->lc.Dp, p->lc.O, p->lc.Op)) ok = ok && alloc(&p->wt_c, mlp_strip_wt_floats(p->lc.Dp, p->lc.Op));
   if (ok && p->use_mirror) {
     std::vector<int> osrc(Dp, 0), asrc(p->A, 0);
     std::vector<float> osgn(Dp, 0.f), asgn(p->A, 0.f);
@@ -901,7 +927,7 @@ extern "C" int lhw_ppo_destroy(LhwPpo* p) {
   (void)hipSetDevice(p->device);
   float* bufs[] = {p->xb, p->h1a, p->h2a, p->ya, p->h1c, p->h2c, p->yc, p->dya, p->dh2a, p->dh1a, p->dyc, p->dh2c, p->dh1c,
                    p->mb_act, p->mb_logp, p->mb_adv, p->mb_ret, p->stats, p->d_obs_sign, p->d_act_sign, p->part, p->dstd, p->stats_part,
-                   p->norm_part, p->bwd_part};
+                   p->norm_part, p->bwd_part, p->wt_a, p->wt_c};
   for (float* b : bufs) if (b) (void)hipFree(b);
   if (p->d_obs_src) (void)hipFree(p->d_obs_src);
   if (p->d_act_src) (void)hipFree(p->d_act_src);
@@ -969,7 +995,7 @@ static int ppo_forward_impl(LhwPpo* p, const float* theta, const float* obs, int
   hipLaunchKernelGGL(normalize_kernel, dim3((n + 255) / 256), dim3(256), 0, s, obs, p->D, p->la.Dp, (size_t)N, obs_mean, obs_std,
                      xb, (float*)nullptr, (const int*)nullptr, (const float*)nullptr);
   if (act || mu) {
-    mlp_forward(p->la, theta + p->off_actor, xb, p->la.Dp, (int)N, h1a, h2a, ya, s, p->infer_half);
+    mlp_forward(p->la, theta + p->off_actor, xb, p->la.Dp, (int)N, h1a, h2a, ya, s, p->infer_half, strip_mode() >= 2 ? p->wt_a : nullptr);
     if (mu) HIPCHK(hipMemcpy2DAsync(mu, sizeof(float) * p->A, ya, sizeof(float) * p->la.Op, sizeof(float) * p->A, N, hipMemcpyDeviceToDevice, s));
     if (act) {
       if (!logp) return lhw_fail(LHW_ERR_ARG, "logp required with act");
@@ -978,7 +1004,7 @@ static int ppo_forward_impl(LhwPpo* p, const float* theta, const float* obs, int
     }
   }
   if (value) {
-    mlp_forward(p->lc, theta + p->off_critic, xb, p->la.Dp, (int)N, h1c, h2c, yc, s, p->infer_half);
+    mlp_forward(p->lc, theta + p->off_critic, xb, p->la.Dp, (int)N, h1c, h2c, yc, s, p->infer_half, strip_mode() >= 2 ? p->wt_c : nullptr);
     HIPCHK(hipMemcpy2DAsync(value, sizeof(float), yc, sizeof(float) * 4, sizeof(float), N, hipMemcpyDeviceToDevice, s));
   }
   HIPCHK(hipGetLastError());
@@ -1080,13 +1106,13 @@ extern "C" int lhw_ppo_grad(LhwPpo* p, const float* theta, float* grad, const fl
   auto join = [&]() { if (sc != s) { (void)hipEventRecord(p->ev_join, sc); (void)hipStreamWaitEvent(s, p->ev_join, 0); } };
   // forward: rows [0,B) and, if mirroring, rows [R, R+B)
   fork();
-  mlp_forward(p->lc, th_c, p->xb, Dp, B, p->h1c, p->h2c, p->yc, sc, p->update_half);
+  mlp_forward(p->lc, th_c, p->xb, Dp, B, p->h1c, p->h2c, p->yc, sc, p->update_half, strip_mode() >= 1 ? p->wt_c : nullptr);
   if (mir && B == R) {
-    mlp_forward(p->la, th_a, p->xb, Dp, 2 * B, p->h1a, p->h2a, p->ya, s, p->update_half);   // mirrored rows follow without a gap
+    mlp_forward(p->la, th_a, p->xb, Dp, 2 * B, p->h1a, p->h2a, p->ya, s, p->update_half, strip_mode() >= 1 ? p->wt_a : nullptr);   // mirrored rows follow without a gap
   } else {
-    mlp_forward(p->la, th_a, p->xb, Dp, B, p->h1a, p->h2a, p->ya, s, p->update_half);
+    mlp_forward(p->la, th_a, p->xb, Dp, B, p->h1a, p->h2a, p->ya, s, p->update_half, strip_mode() >= 1 ? p->wt_a : nullptr);
     if (mir)
-      mlp_forward(p->la, th_a, p->xb + (size_t)R * Dp, Dp, B, p->h1a + (size_t)R * p->H, p->h2a + (size_t)R * p->H, p->ya + (size_t)R * Op, s, p->update_half);
+      mlp_forward(p->la, th_a, p->xb + (size_t)R * Dp, Dp, B, p->h1a + (size_t)R * p->H, p->h2a + (size_t)R * p->H, p->ya + (size_t)R * Op, s, p->update_half, strip_mode() >= 1 ? p->wt_a : nullptr);
   }
   join();
   const int nblk = (B + 255) / 256;

@@ -4,8 +4,8 @@
 against the emulator header in this directory into tests/emu/_build/liblhw_emu.so; `EmuBatchedEnv` drives that
 library through the same C ABI (include/lhw.h) with numpy buffers.  It exists so that the `-m "not gpu"` suite can
 check the *kernel source* against the CPU oracle (lane mappings, cross-lane reductions, LDS hand-offs, sub-wave
-groups) before a GPU is involved.  Nothing under learninghumanoidwalking_amd/ imports this package, and the PPO
-kernels (MFMA) are not emulated.
+groups) before a GPU is involved.  Nothing under learninghumanoidwalking_amd/ imports this package.  Of the PPO
+kernels only the LDS-resident MLP strip kernels (lhw_mlp_strip.hip, f32 MFMA emulated as its fmaf chain) are built here.
 """
 from __future__ import annotations
 
@@ -21,7 +21,7 @@ _ROOT = os.path.dirname(os.path.dirname(_HERE))
 _CSRC = os.path.join(_ROOT, "learninghumanoidwalking_amd", "csrc")
 _BUILD = os.path.join(_HERE, "_build")
 LIB_PATH = os.path.join(_BUILD, "liblhw_emu.so")
-SOURCES = ["lhw_humanoid.hip", "lhw_cartpole.hip", "lhw_api.hip"]
+SOURCES = ["lhw_humanoid.hip", "lhw_cartpole.hip", "lhw_api.hip", "lhw_mlp_strip.hip"]
 _LIB = None
 
 

@@ -78,6 +78,20 @@ static void resolve(Block& b) {
     uint64_t ballot = 0;
     for (int i = 0; i < wn; i++)
       if (at(b, w0 + i, OP_BALLOT) && b.lanes[w0 + i].val) ballot |= 1ull << i;
+    {   // MFMA: snapshot the operands of the wave's lanes (inactive lanes contribute zeros)
+      bool any = false;
+      for (int i = 0; i < wn; i++) any = any || at(b, w0 + i, OP_MFMA);
+      if (any) {
+        if (b.mfma.size() < (size_t)(n + 63) / 64 * 128) b.mfma.resize((size_t)(n + 63) / 64 * 128);
+        float* snap = b.mfma.data() + (size_t)(w0 / 64) * 128;
+        for (int i = 0; i < 64; i++) {
+          float a = 0.f, bb = 0.f;
+          if (i < wn && at(b, w0 + i, OP_MFMA)) { memcpy(&a, &b.lanes[w0 + i].val, 4); memcpy(&bb, &b.lanes[w0 + i].val2, 4); }
+          snap[i] = a; snap[64 + i] = bb;
+        }
+        for (int i = 0; i < wn; i++) if (at(b, w0 + i, OP_MFMA)) b.lanes[w0 + i].mfma = snap;
+      }
+    }
     for (int i = 0; i < wn; i++) {
       Lane& l = b.lanes[w0 + i];
       if (l.state != BLOCKED) continue;

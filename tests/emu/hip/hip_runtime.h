@@ -66,7 +66,7 @@ static inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) { *p = 
 
 namespace emu {
 enum { RUNNABLE = 0, BLOCKED = 1, DONE = 2 };
-enum { OP_NONE = 0, OP_WAVE_BARRIER, OP_BLOCK_BARRIER, OP_DPP, OP_READLANE, OP_SWIZZLE, OP_BALLOT, OP_PERMLANE32_SWAP, OP_BPERMUTE, OP_PERMLANE16_SWAP, OP_GROUP_SYNC };
+enum { OP_NONE = 0, OP_WAVE_BARRIER, OP_BLOCK_BARRIER, OP_DPP, OP_READLANE, OP_SWIZZLE, OP_BALLOT, OP_PERMLANE32_SWAP, OP_BPERMUTE, OP_PERMLANE16_SWAP, OP_GROUP_SYNC, OP_MFMA };
 struct Lane {
   void* sp = nullptr;
   char* stack = nullptr;
@@ -74,6 +74,7 @@ struct Lane {
   int ctrl = 0, row_mask = 0, bank_mask = 0, bound = 0, sel = 0;
   uint32_t val = 0, val2 = 0, old = 0, res = 0, res2 = 0;
   uint64_t res64 = 0;
+  const float* mfma = nullptr;   // OP_MFMA: the wave's operand snapshot [2][64] (a of every lane, then b; 0 for inactive lanes)
   dim3 tid;
 };
 struct Block {
@@ -82,6 +83,7 @@ struct Block {
   int cur = -1;
   dim3 bid, bdim, gdim;
   std::function<void()> body;
+  std::vector<float> mfma;       // per wave [2][64]
 };
 extern Block* g_blk;
 extern "C" void emu_switch(void** from_sp, void* to_sp);
@@ -153,6 +155,29 @@ static inline int emu_ds_bpermute(int addr, int v) {
   emu::block_here();
   return (int)l.res;
 }
+// v_mfma_f32_32x32x2_f32: D = A (32 x 2) B (2 x 32) + C over the wave.  Lane l holds A[l % 32][l / 32] and B[l / 32][l % 32];
+// register r of lane l holds C[(r & 3) + 8 (r >> 2) + 4 (l / 32)][l % 32].  The k = 0 product is accumulated first, then k = 1,
+// each as a fused multiply-add (the hardware's accumulation order for this instruction).
+struct f32x16 {
+  float v[16];
+  float& operator[](int i) { return v[i]; }
+  const float& operator[](int i) const { return v[i]; }
+};
+static inline f32x16 emu_mfma_f32_32x32x2f32(float a, float b, f32x16 c, int, int, int) {
+  emu::Lane& l = emu::cur();
+  l.op = emu::OP_MFMA;
+  memcpy(&l.val, &a, 4); memcpy(&l.val2, &b, 4);
+  emu::block_here();
+  const float *A = l.mfma, *B = l.mfma + 64;
+  const int lane = emu::g_blk->cur & 63, col = lane & 31, hi = lane >> 5;
+  for (int r = 0; r < 16; r++) {
+    const int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
+    c.v[r] = fmaf(A[row], B[col], c.v[r]);
+    c.v[r] = fmaf(A[32 + row], B[32 + col], c.v[r]);
+  }
+  return c;
+}
+#define __builtin_amdgcn_mfma_f32_32x32x2f32 emu_mfma_f32_32x32x2f32
 static inline unsigned long long emu_ballot(int pred) {
   emu::Lane& l = emu::cur();
   l.op = emu::OP_BALLOT; l.val = pred ? 1u : 0u;
@@ -216,3 +241,4 @@ using std::min;
 struct alignas(16) double2 { double x, y; };
 struct alignas(8) float2 { float x, y; };
 struct alignas(16) float4 { float x, y, z, w; };
+static inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }

@@ -1,0 +1,69 @@
+"""GPU twin of tests/test_emu_mlp_strip.py: the LDS-resident MLP strip kernels through the C ABI hooks against float64 numpy,
+at sizes that cover many slabs, a ragged last slab, the actor (12 outputs) and critic (1 output) shapes; and against the
+per-layer GEMM path of the same library (lhw_debug_gemm), which they replace in the update."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev(c):
+    import torch
+    return {k: (torch.from_numpy(v).cuda() if isinstance(v, np.ndarray) else v) for k, v in c.items()}
+
+
+@pytest.mark.parametrize("R,Dp,O,Op", [(64 * 37 + 5, 40, 12, 12), (4096, 36, 1, 4), (17, 44, 12, 12)])
+def test_strip_kernels_match_float64_reference(R, Dp, O, Op):
+    import torch
+    from learninghumanoidwalking_amd import _lib
+    from tests.test_emu_mlp_strip import make_case, reference, reference_backward
+    L = _lib.lib()
+    c = make_case(R=R, Dp=Dp, O=O, Op=Op, seed=R)
+    d = _dev(c)
+    h1 = torch.full((R + 3, 256), 7.0, device="cuda"); h2 = torch.full((R + 3, 256), 7.0, device="cuda"); y = torch.full((R + 3, Op), 7.0, device="cuda")
+    p = lambda t: t.data_ptr()
+    wt = torch.zeros((Dp + 256 + Op) * 256, device="cuda")
+    _lib.check(L.lhw_debug_mlp_strip_forward(256, Dp, O, Op, p(d["w1"]), p(d["b1"]), p(d["w2"]), p(d["b2"]), p(d["w3"]), p(d["b3"]), p(d["x"]), Dp, R,
+                                             p(h1), p(h2), p(y), p(wt), None))
+    torch.cuda.synchronize()
+    r1, r2, ry = reference(c)
+    assert (h1[R:] == 7.0).all() and (h2[R:] == 7.0).all() and (y[R:] == 7.0).all()
+    np.testing.assert_allclose(h1[:R].cpu().numpy(), r1, rtol=0, atol=2e-5)
+    np.testing.assert_allclose(h2[:R].cpu().numpy(), r2, rtol=0, atol=5e-5)
+    np.testing.assert_allclose(y[:R, :O].cpu().numpy(), ry[:, :O], rtol=0, atol=5e-5)
+    dh2 = torch.full((R + 3, 256), 7.0, device="cuda"); dh1 = torch.full((R + 3, 256), 7.0, device="cuda")
+    _lib.check(L.lhw_debug_mlp_strip_backward(256, O, Op, p(d["w2"]), p(d["w3"]), p(d["dy"]), R, p(h1), p(h2), p(dh2), p(dh1), None))
+    torch.cuda.synchronize()
+    g2, g1 = reference_backward(c, h1[:R].cpu().numpy().astype(np.float64), h2[:R].cpu().numpy().astype(np.float64))
+    assert (dh2[R:] == 7.0).all() and (dh1[R:] == 7.0).all()
+    np.testing.assert_allclose(dh2[:R].cpu().numpy(), g2, rtol=0, atol=5e-5)
+    np.testing.assert_allclose(dh1[:R].cpu().numpy(), g1, rtol=0, atol=1e-4)
+
+
+def test_strip_hidden_layers_are_bit_identical_to_the_gemm_path():
+    """h1 / h2 / dh2 / dh1 are the same fmaf chains over ascending k in both paths (only the K-split read-out sums in another order)."""
+    import torch
+    from learninghumanoidwalking_amd import _lib
+    from tests.test_emu_mlp_strip import make_case
+    L = _lib.lib()
+    R, Dp, O, Op = 1000, 40, 12, 12
+    c = make_case(R=R, Dp=Dp, O=O, Op=Op, seed=3)
+    d = _dev(c)
+    p = lambda t: t.data_ptr()
+    h1 = torch.zeros(R, 256, device="cuda"); h2 = torch.zeros(R, 256, device="cuda"); y = torch.zeros(R, Op, device="cuda")
+    wt = torch.zeros((Dp + 256 + Op) * 256, device="cuda")
+    _lib.check(L.lhw_debug_mlp_strip_forward(256, Dp, O, Op, p(d["w1"]), p(d["b1"]), p(d["w2"]), p(d["b2"]), p(d["w3"]), p(d["b3"]), p(d["x"]), Dp, R,
+                                             p(h1), p(h2), p(y), p(wt), None))
+    g1 = torch.zeros(R, 256, device="cuda"); g2 = torch.zeros(R, 256, device="cuda")
+    z = None
+    _lib.check(L.lhw_debug_gemm(1, 1, 1, R, 256, Dp, p(d["x"]), Dp, p(d["w1"]), Dp, p(g1), 256, p(d["b1"]), 1, z, 0, 0, z, z, z, None))
+    _lib.check(L.lhw_debug_gemm(1, 1, 1, R, 256, 256, p(g1), 256, p(d["w2"]), 256, p(g2), 256, p(d["b2"]), 1, z, 0, 0, z, z, z, None))
+    torch.cuda.synchronize()
+    assert torch.equal(h1, g1) and torch.equal(h2, g2)
+    dh2 = torch.zeros(R, 256, device="cuda"); dh1 = torch.zeros(R, 256, device="cuda")
+    _lib.check(L.lhw_debug_mlp_strip_backward(256, O, Op, p(d["w2"]), p(d["w3"]), p(d["dy"]), R, p(h1), p(h2), p(dh2), p(dh1), None))
+    e2 = torch.zeros(R, 256, device="cuda"); e1 = torch.zeros(R, 256, device="cuda")
+    _lib.check(L.lhw_debug_gemm(1, 0, 1, R, 256, O, p(d["dy"]), Op, p(d["w3"]), 256, p(e2), 256, z, 0, p(h2), 256, 0, z, z, z, None))
+    _lib.check(L.lhw_debug_gemm(1, 0, 1, R, 256, 256, p(e2), 256, p(d["w2"]), 256, p(e1), 256, z, 0, p(h1), 256, 0, z, z, z, None))
+    torch.cuda.synchronize()
+    assert torch.equal(dh2, e2) and torch.equal(dh1, e1)
