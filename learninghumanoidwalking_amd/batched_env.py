@@ -26,6 +26,17 @@ def _stream_ptr(device):
     return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
+def history_update(prev_full: torch.Tensor, base_obs: torch.Tensor, term_base: torch.Tensor, done: torch.Tensor, base: int):
+    """Observation history of the reference (envs/common/base_humanoid_env.py:177-197, 274): the observation is a deque of the
+    last `history_len` base observations, newest first, flattened; a reset empties it and zero-fills before the first push.
+    prev_full [n, H*base]: the full observation before this control step; base_obs: what the kernel returns (for an env whose
+    episode ended: the first observation after the auto-reset); term_base: the base observation of the state the step reached;
+    done [n] uint8.  Returns (full observation, full terminal observation), both [n, H*base]."""
+    tail = prev_full[:, :-base]
+    keep = (done == 0).to(prev_full.dtype).unsqueeze(1)
+    return torch.cat([base_obs, tail * keep], dim=1), torch.cat([term_base, tail], dim=1)
+
+
 class BatchedEnv:
     """N copies of one task, state resident in HBM.
 
@@ -38,7 +49,7 @@ class BatchedEnv:
     def __init__(self, model: Model, task: int, n_envs: int, *, frame_skip: int, kp, kd, seed: int = 0,
                  device: int | torch.device = 0, max_traj_len: int = 0, env_id_base: int = 0,
                  action_smoothing: float = 1.0, nominal_qpos=None, action_offset=None, task_params=None,
-                 task_iparams=None, clock_lut=None):
+                 task_iparams=None, clock_lut=None, history_len: int = 1):
         if not torch.cuda.is_available():
             raise _lib.LhwError(-5, "no GPU visible: BatchedEnv has no CPU fallback")
         self.device = torch.device("cuda", device) if isinstance(device, int) else device
@@ -73,7 +84,13 @@ class BatchedEnv:
         _lib.check(L.lhw_env_create(self._ib.ctypes.data, self._ib.size, self._db.ctypes.data, self._db.size,
                                     ctypes.byref(cfg), ctypes.byref(self._h)))
         self._L = L
-        self.obs_dim = L.lhw_env_obs_dim(self._h)
+        # obs_history_len > 1 (base_humanoid_env.py:177-197) is kept above the kernels: they emit the base observation, the
+        # history rows are shifted on the device by a few torch ops per step (history_update); obs_dim is the full length
+        self.base_obs_dim = L.lhw_env_obs_dim(self._h)
+        self.history_len = int(history_len)
+        if self.history_len < 1:
+            raise ValueError("history_len must be >= 1")
+        self.obs_dim = self.base_obs_dim * self.history_len
         self.act_dim = L.lhw_env_act_dim(self._h)
         self.n_terms = L.lhw_env_num_reward_terms(self._h)
         self.nq, self.nv = L.lhw_env_nq(self._h), L.lhw_env_nv(self._h)
@@ -83,6 +100,10 @@ class BatchedEnv:
         self.rew = torch.zeros(N, dtype=torch.float32, device=dev)
         self.done = torch.zeros(N, dtype=torch.uint8, device=dev)
         self.rew_terms = torch.zeros(N, self.n_terms, dtype=torch.float32, device=dev)
+        if self.history_len > 1:
+            self._base = torch.zeros(N, self.base_obs_dim, dtype=torch.float32, device=dev)    # kernel outputs
+            self._tbase = torch.zeros(N, self.base_obs_dim, dtype=torch.float32, device=dev)
+            self._full = torch.zeros(N, self.obs_dim, dtype=torch.float32, device=dev)         # current full observation
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:
@@ -98,8 +119,22 @@ class BatchedEnv:
     def reset(self, mask: torch.Tensor | None = None) -> torch.Tensor:
         if mask is not None:
             assert mask.dtype == torch.uint8 and mask.is_cuda and mask.numel() == self.n_envs
+        if self.history_len > 1:
+            _lib.check(self._L.lhw_env_reset(self._h, _ptr(mask), _ptr(self._base), _stream_ptr(self.device)))
+            sel = slice(None) if mask is None else mask.bool()
+            self._full[sel] = 0
+            self._full[sel, :self.base_obs_dim] = self._base[sel]
+            self.obs.copy_(self._full)
+            return self.obs
         _lib.check(self._L.lhw_env_reset(self._h, _ptr(mask), _ptr(self.obs), _stream_ptr(self.device)))
         return self.obs
+
+    def _history(self, a, b, obs, tob, done):
+        """full observation / terminal observation of envs [a, b) from the kernel's base outputs"""
+        full, term = history_update(self._full[a:b], self._base[a:b], self._tbase[a:b], done[a:b], self.base_obs_dim)
+        self._full[a:b] = full
+        obs[a:b] = full
+        tob[a:b] = term
 
     def step(self, act: torch.Tensor, obs_out: torch.Tensor | None = None, term_obs_out: torch.Tensor | None = None,
              rew_out: torch.Tensor | None = None, done_out: torch.Tensor | None = None):
@@ -109,6 +144,11 @@ class BatchedEnv:
         tob = self.term_obs if term_obs_out is None else term_obs_out
         rew = self.rew if rew_out is None else rew_out
         done = self.done if done_out is None else done_out
+        if self.history_len > 1:
+            _lib.check(self._L.lhw_env_step(self._h, _ptr(act), _ptr(self._base), _ptr(self._tbase), _ptr(rew), _ptr(done),
+                                            _ptr(self.rew_terms), _stream_ptr(self.device)))
+            self._history(0, self.n_envs, obs, tob, done)
+            return obs, rew, done, tob
         _lib.check(self._L.lhw_env_step(self._h, _ptr(act), _ptr(obs), _ptr(tob), _ptr(rew), _ptr(done),
                                         _ptr(self.rew_terms), _stream_ptr(self.device)))
         return obs, rew, done, tob
@@ -118,6 +158,11 @@ class BatchedEnv:
         """Advance envs [first, first + count) only, on the current stream.  All tensors are the FULL-batch buffers ([N, ...]);
         independent groups issued on different streams overlap on the GPU (no batch-wide barrier per control step)."""
         assert act.is_cuda and act.dtype == torch.float32 and act.is_contiguous() and act.numel() == self.n_envs * self.act_dim
+        if self.history_len > 1:
+            _lib.check(self._L.lhw_env_step_range(self._h, int(first), int(count), _ptr(act), _ptr(self._base), _ptr(self._tbase), _ptr(rew),
+                                                  _ptr(done), _ptr(self.rew_terms), _stream_ptr(self.device)))
+            self._history(int(first), int(first) + int(count), obs, term_obs, done)
+            return
         _lib.check(self._L.lhw_env_step_range(self._h, int(first), int(count), _ptr(act), _ptr(obs), _ptr(term_obs), _ptr(rew),
                                               _ptr(done), _ptr(self.rew_terms), _stream_ptr(self.device)))
 

@@ -59,7 +59,7 @@ class _SingleEnv:
         self._env = spec.make_batched(1, seed=seed, device=device, max_traj_len=0)
         self.observation_space = np.zeros(spec.obs_dim)
         self.action_space = np.zeros(spec.act_dim)
-        self.base_obs_len, self.history_len = spec.obs_dim, 1
+        self.base_obs_len, self.history_len = getattr(spec, "base_obs_dim", spec.obs_dim), getattr(spec, "history_len", 1)
         if spec.obs_mean is not None:
             self.obs_mean, self.obs_std = np.asarray(spec.obs_mean), np.asarray(spec.obs_std)
         self.robot = SimpleNamespace(iteration_count=np.inf)

@@ -49,8 +49,9 @@ class H1Spec:
         self.cfg = load_config(self.yaml_path)
         c = self.cfg
         self.sim_dt, self.control_dt = float(c["sim_dt"]), float(c["control_dt"])
-        if int(c.get("obs_history_len", 1)) != 1:
-            raise NotImplementedError("obs_history_len != 1")
+        self.history_len = int(c.get("obs_history_len", 1))     # base_humanoid_env.py:53,177-197 (kept above the kernels: BatchedEnv)
+        if self.history_len < 1:
+            raise ValueError("obs_history_len must be >= 1")
         self.action_smoothing = float(c["action_smoothing"])
         g = c["pdgains"]
         self.kp = np.array([g[j][0] for j in LEG_JOINTS], dtype=float)   # h1_base.py:48-51
@@ -80,6 +81,11 @@ class H1Spec:
         self.obs_mean = np.concatenate([np.zeros(5), self.half_sitting_pose, np.zeros(10), np.zeros(10)])
         self.obs_std = np.concatenate([[0.2, 0.2, 1, 1, 1], 0.5 * np.ones(10), 4 * np.ones(10), 100 * np.ones(10)])
         self._model = None
+        self._apply_history()
+
+    def _apply_history(self):
+        from .jvrc_walk import JvrcWalkSpec
+        JvrcWalkSpec._apply_history(self)    # (h1_env.py:54-55: the same np.tile over the history)
 
     @property
     def frame_skip(self) -> int:
@@ -132,7 +138,8 @@ class H1Spec:
         return BatchedEnv(self.model(), TASK_H1_STAND, n_envs, frame_skip=self.frame_skip, kp=self.kp, kd=self.kd, seed=seed,
                           device=device, max_traj_len=max_traj_len, env_id_base=env_id_base,
                           action_smoothing=self.action_smoothing, nominal_qpos=self.nominal_pose,
-                          action_offset=self.action_offset(), task_params=self.task_params(), task_iparams=self.task_iparams())
+                          action_offset=self.action_offset(), task_params=self.task_params(), task_iparams=self.task_iparams(),
+                          history_len=self.history_len)
 
     def algorithmic_bytes_per_env_step(self) -> int:
         """State record (168 f64) + per-env randomised model parameters (128 f64) read + written, action in, obs x2, reward, flags, 6 terms."""

@@ -40,12 +40,13 @@ class H1WalkSpec(H1Spec):
         self.obs_mean = np.concatenate([np.zeros(5), self.half_sitting_pose, np.zeros(10), np.zeros(10), [0, 0], [0.5, 0.5, 0.5, 0, 0, 0]])
         self.obs_std = np.concatenate([[0.2, 0.2, 1, 1, 1], 0.5 * np.ones(10), 4 * np.ones(10), 100 * np.ones(10), [1, 1],
                                        [1, 1, 1, 0.5, 0.5, 0.5]])
+        self._apply_history()
 
     def clock_lut(self):
         return phase_clock_lut(self.swing_duration, self.stance_duration, 0.1, 1 / self.control_dt, self.period)
 
     def mirror_inds(self):
-        ext = [len(BASE_MIRROR_OBS) + i for i in range(self.obs_dim - 35)]
+        ext = [len(BASE_MIRROR_OBS) + i for i in range(self.base_obs_dim - 35)]
         return BASE_MIRROR_OBS + ext, MIRROR_ACTS, ext[0:2]
 
     def mirror_tables(self):
@@ -62,7 +63,7 @@ class H1WalkSpec(H1Spec):
                           device=device, max_traj_len=max_traj_len, env_id_base=env_id_base,
                           action_smoothing=self.action_smoothing, nominal_qpos=self.nominal_pose,
                           action_offset=self.action_offset(), task_params=self.task_params(), task_iparams=self.task_iparams(),
-                          clock_lut=self.clock_lut())
+                          clock_lut=self.clock_lut(), history_len=self.history_len)
 
     def algorithmic_bytes_per_env_step(self) -> int:
         return 2 * (168 + 128) * 8 + 10 * 4 + 2 * 43 * 4 + 4 + 1 + 10 * 4

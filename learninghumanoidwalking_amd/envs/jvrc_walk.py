@@ -72,8 +72,9 @@ class JvrcWalkSpec:
             self.cfg = yaml.safe_load(f)
         c = self.cfg
         self.sim_dt, self.control_dt = float(c["sim_dt"]), float(c["control_dt"])
-        if int(c.get("obs_history_len", 1)) != 1:
-            raise NotImplementedError("obs_history_len != 1")
+        self.history_len = int(c.get("obs_history_len", 1))     # base_humanoid_env.py:53,177-197 (kept above the kernels: BatchedEnv)
+        if self.history_len < 1:
+            raise ValueError("obs_history_len must be >= 1")
         # BaseHumanoidEnv.reset_model / step apply these for ANY env that configures them (base_humanoid_env.py:76-92,247-305); the
         # JVRC kernels implement none of them (and copy a precomputed post-reset state into every auto-reset): refuse, do not ignore
         for key in ("init_noise", "dynamics_randomization", "perturbation", "observation_noise"):
@@ -95,6 +96,15 @@ class JvrcWalkSpec:
         self.obs_mean = np.concatenate([np.zeros(5), self.half_sitting_pose, np.zeros(12), [0, 0, 0.5, 0.5, 0.5, 0, 0, 0]])
         self.obs_std = np.concatenate([[0.2, 0.2, 1, 1, 1], 0.5 * np.ones(12), 4 * np.ones(12), [1, 1, 1, 1, 1, 0.5, 0.5, 0.5]])
         self._model = None
+        self._apply_history()
+
+    def _apply_history(self):
+        """obs_dim / obs_mean / obs_std for obs_history_len > 1 (jvrc_walk.py:62-63: np.tile over the history); called at the end
+        of every __post_init__ of the Spec hierarchy (a parent's call leaves a child's longer base observation alone)."""
+        base = type(self).__dataclass_fields__["obs_dim"].default
+        self.base_obs_dim, self.obs_dim = base, base * self.history_len
+        if self.history_len > 1 and self.obs_mean is not None and len(self.obs_mean) == base:
+            self.obs_mean, self.obs_std = np.tile(self.obs_mean, self.history_len), np.tile(self.obs_std, self.history_len)
 
     @property
     def frame_skip(self) -> int:
@@ -115,12 +125,16 @@ class JvrcWalkSpec:
         return phase_clock_lut(self.swing_duration, self.stance_duration, 0.1, 1 / self.control_dt, self.period)
 
     def mirror_inds(self):
-        n_ext = self.obs_dim - 29
+        n_ext = self.base_obs_dim - 29
         ext = [len(BASE_MIRROR_OBS) + i for i in range(n_ext)]
         return BASE_MIRROR_OBS + ext, MIRROR_ACTS, ext[0:2]
 
     def mirror_tables(self):
         """((obs_src, obs_sign), (act_src, act_sign)): signed permutations of rl/envs/wrappers.py:78-85 as gathers."""
+        if self.history_len > 1:
+            # the reference's mirrored_obs lists base_obs_len indices only (jvrc_walk.py, h1_walk.py): its SymmetricEnv cannot
+            # mirror a history observation either
+            raise NotImplementedError("mirror loss with obs_history_len > 1: the reference defines mirror indices for the base observation only; train with --no-mirror")
         mo, ma, clock = self.mirror_inds()
 
         def tab(mirrored, clock_inds=()):
@@ -148,7 +162,7 @@ class JvrcWalkSpec:
                           device=device, max_traj_len=max_traj_len, env_id_base=env_id_base,
                           action_smoothing=self.action_smoothing, nominal_qpos=self.nominal_pose,
                           action_offset=self.action_offset(), task_params=[self.goal_height],
-                          task_iparams=self.body_ids(), clock_lut=self.clock_lut())
+                          task_iparams=self.body_ids(), clock_lut=self.clock_lut(), history_len=self.history_len)
 
     def algorithmic_bytes_per_env_step(self) -> int:
         """Persistent state record read + written once per control step (168 f64 words) plus

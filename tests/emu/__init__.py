@@ -62,8 +62,10 @@ class EmuBatchedEnv:
 
     def __init__(self, model, task, n_envs, *, frame_skip, kp, kd, seed=0, max_traj_len=0, env_id_base=0,
                  action_smoothing=1.0, nominal_qpos=None, action_offset=None, task_params=None, task_iparams=None,
-                 clock_lut=None, device=0):
+                 clock_lut=None, device=0, history_len=1):
         from learninghumanoidwalking_amd import _lib as product
+        if int(history_len) != 1:
+            raise NotImplementedError("the emulated env returns base observations (the history is kept by BatchedEnv, above the kernels)")
         self.n_envs, self.task, self.model = int(n_envs), task, model
         self._ib, self._db = model.pack()
         self._keep = []

@@ -229,8 +229,32 @@ def main():
     gen_rollout_worker(os.path.join(OUT, "rollout_worker.npz"))
 
 
+def gen_history(out_path):
+    """obs_history_len = 3 (base_humanoid_env.py:177-197: deque of base observations, newest first, zero-filled after a reset):
+    the reference's JvrcWalkEnv on a copy of its own YAML with only that key changed."""
+    _install()
+    from learninghumanoidwalking_amd.envs.jvrc_walk import JVRC_STANDIN_XML
+    _export("jvrc_walk", "jvrc.xml", JVRC_STANDIN_XML)
+    from envs.jvrc.jvrc_walk import JvrcWalkEnv
+    src = open(os.path.join(REF, "envs", "jvrc", "configs", "base.yaml")).read()
+    assert "obs_history_len: 1" in src
+    yml = "/tmp/jvrc_hist3.yaml"
+    open(yml, "w").write(src.replace("obs_history_len: 1", "obs_history_len: 3"))
+    out = {}
+
+    def extra(env, out, pre):
+        out[pre + "obs_mean"], out[pre + "obs_std"] = env.obs_mean, env.obs_std
+        out[pre + "base_obs_len"], out[pre + "history_len"] = env.base_obs_len, env.history_len
+    run_env("jvrc_walk_h3", lambda: JvrcWalkEnv(path_to_yaml=yml), seed=3, T=160, act_dim=12, act_std=0.223, out=out, extra=extra)
+    keep = {k: v for k, v in out.items() if k.split("jvrc_walk_h3_")[1] in ("obs", "done", "reset_obs", "reset_at", "obs_mean", "obs_std", "base_obs_len", "history_len", "acts")}
+    np.savez_compressed(out_path, **keep)
+    print("wrote", out_path)
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "rollout":
+    if len(sys.argv) > 1 and sys.argv[1] == "history":
+        gen_history(os.path.join(OUT, "refenv_history.npz"))
+    elif len(sys.argv) > 1 and sys.argv[1] == "rollout":
         _install()
         gen_rollout_worker(os.path.join(OUT, "rollout_worker.npz"))
     else:
