@@ -445,7 +445,9 @@ struct LhwPpo {
   float *stats = nullptr;  // [16] loss scalars; [8],[9] grad norm^2 actor/critic
   float *part = nullptr;       // split-K partial tiles [max slices][H*H]
   float *dstd = nullptr;       // per-row d loss / d std [R][Op]
-  float *wt_a = nullptr, *wt_c = nullptr;   // [in][out] weight copies for the strip kernels (hidden width 256 only)
+  float *wt_a = nullptr, *wt_c = nullptr;   // [in][out] weight copies for the strip kernels (hidden width 256 only): the update's
+  float *wt_inf = nullptr;                  // ... and WT_SLOTS pairs (actor, critic) for rollout inference, one per eighth of the
+                                            // forward workspace, so that concurrent calls (disjoint row ranges, different streams) do not share one
   float *stats_part = nullptr; // per-block loss partials [blocks][NSTAT]
   const float* imit_target = nullptr;          // imitation term of the NEXT lhw_ppo_grad call (lhw_ppo_set_imitation)
   const unsigned char* imit_mask = nullptr;
@@ -470,6 +472,7 @@ struct LhwPpo {
 // LHW_MLP_STRIP (tuning aid): 0 = per-layer GEMMs everywhere, 1 = LDS-resident strip kernels for the update's forward and
 // activation-gradient passes, 2 = for the rollout inference as well (default: the rollout and the update then evaluate the
 // networks with the same kernel, bit for bit)
+#define WT_SLOTS 8
 static int strip_mode() {
   static const int m = getenv("LHW_MLP_STRIP") ? atoi(getenv("LHW_MLP_STRIP")) : 2;
   return m;
@@ -894,6 +897,7 @@ extern "C" int lhw_ppo_create(const LhwPpoConfig* c, LhwPpo** out) {
   ok = ok && alloc(&p->bwd_part, bwd_parts_floats(p->la, R, 2) + bwd_parts_floats(p->lc, R, 1));
   if (mlp_strip_supported(p->la.H, p->la.Dp, p->la.O, p->la.Op)) ok = ok && alloc(&p->wt_a, mlp_strip_wt_floats(p->la.Dp, p->la.Op));
   if (mlp_strip_supported(p->lc.H, p->lc.Dp, p->lc.O, p->lc.Op)) ok = ok && alloc(&p->wt_c, mlp_strip_wt_floats(p->lc.Dp, p->lc.Op));
+  if (p->wt_a && p->wt_c) ok = ok && alloc(&p->wt_inf, WT_SLOTS * (mlp_strip_wt_floats(p->la.Dp, p->la.Op) + mlp_strip_wt_floats(p->lc.Dp, p->lc.Op)));
   if (ok && p->use_mirror) {
     std::vector<int> osrc(Dp, 0), asrc(p->A, 0);
     std::vector<float> osgn(Dp, 0.f), asgn(p->A, 0.f);
@@ -927,7 +931,7 @@ extern "C" int lhw_ppo_destroy(LhwPpo* p) {
   (void)hipSetDevice(p->device);
   float* bufs[] = {p->xb, p->h1a, p->h2a, p->ya, p->h1c, p->h2c, p->yc, p->dya, p->dh2a, p->dh1a, p->dyc, p->dh2c, p->dh1c,
                    p->mb_act, p->mb_logp, p->mb_adv, p->mb_ret, p->stats, p->d_obs_sign, p->d_act_sign, p->part, p->dstd, p->stats_part,
-                   p->norm_part, p->bwd_part, p->wt_a, p->wt_c};
+                   p->norm_part, p->bwd_part, p->wt_a, p->wt_c, p->wt_inf};
   for (float* b : bufs) if (b) (void)hipFree(b);
   if (p->d_obs_src) (void)hipFree(p->d_obs_src);
   if (p->d_act_src) (void)hipFree(p->d_act_src);
@@ -992,10 +996,16 @@ static int ppo_forward_impl(LhwPpo* p, const float* theta, const float* obs, int
   float *xb = p->xb + r0 * Dp, *h1a = p->h1a + r0 * H, *h2a = p->h2a + r0 * H, *ya = p->ya + r0 * Op;
   float *h1c = p->h1c + r0 * H, *h2c = p->h2c + r0 * H, *yc = p->yc + r0 * 4;
   size_t n = (size_t)N * Dp;
+  float *wta = nullptr, *wtc = nullptr;   // this call's weight copies for the strip kernel
+  if (strip_mode() >= 2 && p->wt_inf) {
+    const size_t fa = mlp_strip_wt_floats(p->la.Dp, p->la.Op), fc = mlp_strip_wt_floats(p->lc.Dp, p->lc.Op);
+    wta = p->wt_inf + (size_t)(ws_row * WT_SLOTS / p->max_rows) * (fa + fc);
+    wtc = wta + fa;
+  }
   hipLaunchKernelGGL(normalize_kernel, dim3((n + 255) / 256), dim3(256), 0, s, obs, p->D, p->la.Dp, (size_t)N, obs_mean, obs_std,
                      xb, (float*)nullptr, (const int*)nullptr, (const float*)nullptr);
   if (act || mu) {
-    mlp_forward(p->la, theta + p->off_actor, xb, p->la.Dp, (int)N, h1a, h2a, ya, s, p->infer_half, strip_mode() >= 2 ? p->wt_a : nullptr);
+    mlp_forward(p->la, theta + p->off_actor, xb, p->la.Dp, (int)N, h1a, h2a, ya, s, p->infer_half, wta);
     if (mu) HIPCHK(hipMemcpy2DAsync(mu, sizeof(float) * p->A, ya, sizeof(float) * p->la.Op, sizeof(float) * p->A, N, hipMemcpyDeviceToDevice, s));
     if (act) {
       if (!logp) return lhw_fail(LHW_ERR_ARG, "logp required with act");
@@ -1004,7 +1014,7 @@ static int ppo_forward_impl(LhwPpo* p, const float* theta, const float* obs, int
     }
   }
   if (value) {
-    mlp_forward(p->lc, theta + p->off_critic, xb, p->la.Dp, (int)N, h1c, h2c, yc, s, p->infer_half, strip_mode() >= 2 ? p->wt_c : nullptr);
+    mlp_forward(p->lc, theta + p->off_critic, xb, p->la.Dp, (int)N, h1c, h2c, yc, s, p->infer_half, wtc);
     HIPCHK(hipMemcpy2DAsync(value, sizeof(float), yc, sizeof(float) * 4, sizeof(float), N, hipMemcpyDeviceToDevice, s));
   }
   HIPCHK(hipGetLastError());
