@@ -2732,14 +2732,33 @@ __global__ void __launch_bounds__(64, LHW_WAVES_PER_SIMD) humanoid_kernel(const 
   constexpr int G = 64 / W;   // envs per wavefront
   __shared__ L SG[G];
   const int lane = threadIdx.x & (W - 1);   // lane within the env's group
-  const int eidx = blockIdx.x * G + group_id<W>();
-  if (eidx >= lz.env_count) return;
-  const int env = eidx + lz.env_first;
   const HParams& p = *pp;
   const HModel& m = *mp;
-  if (MODE == 1 && mask && !mask[env]) return;
-  if (MODE == 0 && lz.only_flagged && !st.slow[env]) return;
-  control_step<MODE, TASK, W>(m, p, lz, st, SG[group_id<W>()], env, lane, act, obs, term_obs, rew, done_out, rew_terms, xq, xv);
+  if constexpr (MODE == 0 && W == 64) {
+    // One call site for both uses of the one-env-per-wave step kernel.  As the re-run behind the two-envs-per-wave kernel
+    // (only_flagged) it is launched with FEW workgroups, each scanning the flags of `chunk` <= 64 consecutive envs and stepping
+    // the flagged ones in turn: on most control steps nothing is flagged, and a grid of one workgroup per env would have to
+    // wait for wave slots (and 16 KB of LDS each) behind the other rollout group's kernel just to find that out.
+    int e0 = (int)blockIdx.x;
+    unsigned long long todo = e0 < lz.env_count ? 1ull : 0ull;
+    if (lz.only_flagged) {
+      const int chunk = (lz.env_count + (int)gridDim.x - 1) / (int)gridDim.x;
+      e0 = (int)blockIdx.x * chunk;
+      const int t = (int)threadIdx.x;
+      todo = __ballot(t < chunk && e0 + t < lz.env_count && st.slow[lz.env_first + e0 + t] != 0);
+    }
+    while (todo) {
+      const int i = __ffsll(todo) - 1;
+      todo &= todo - 1;
+      control_step<MODE, TASK, W>(m, p, lz, st, SG[0], lz.env_first + e0 + i, lane, act, obs, term_obs, rew, done_out, rew_terms, xq, xv);
+    }
+  } else {
+    const int eidx = blockIdx.x * G + group_id<W>();
+    if (eidx >= lz.env_count) return;
+    const int env = eidx + lz.env_first;
+    if (MODE == 1 && mask && !mask[env]) return;
+    control_step<MODE, TASK, W>(m, p, lz, st, SG[group_id<W>()], env, lane, act, obs, term_obs, rew, done_out, rew_terms, xq, xv);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ host side
@@ -3213,14 +3232,16 @@ void humanoid_destroy(HumanoidEnv* h) {
   do {                                                                                                             \
     const HParams& pp_ = h->p;                                                                                     \
     const HLaunch lz_{(FIRST), (COUNT), (FLAGGED), h->iteration};                                                  \
-    const dim3 grid_((lz_.env_count + (64 / WIDTH) - 1) / (64 / WIDTH));                                           \
+    /* the re-run launch scans the flags with few workgroups (at most 64 envs each): see humanoid_kernel */           \
+    const int full_ = (lz_.env_count + (64 / WIDTH) - 1) / (64 / WIDTH);                                            \
+    const dim3 grid_((FLAGGED) ? std::min(full_, std::max(256, (lz_.env_count + 63) / 64)) : full_);                \
     if (pp_.task == TASK_WALK) hipLaunchKernelGGL((humanoid_kernel<MODE, TASK_WALK, WIDTH>), grid_, dim3(64), 0, s, (const HModel*)h->m_dev, (const HParams*)h->p_dev, lz_, h->st, __VA_ARGS__); \
     LAUNCH_OTHER_TASKS(MODE, WIDTH, __VA_ARGS__)                                                                   \
   } while (0)
 #define LAUNCH(MODE, ...) LAUNCH_RANGE(MODE, 64, 0, 0, h->p.n_envs, __VA_ARGS__)
 // One control step of envs [first, first + count): two envs per wave where the model allows it, followed by the one-env-per-wave
 // kernel over the same range for the envs that flagged themselves (more than 8 contacts); that launch finds nothing to do on
-// most steps and its waves exit on their first load.
+// most steps: a few workgroups scan the flags and exit.
 #define LAUNCH_STEP(FIRST, COUNT, ...)                                                       \
   do {                                                                                       \
     if (h->fast) {                                                                           \

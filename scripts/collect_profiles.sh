@@ -28,6 +28,12 @@ for C in FETCH_SIZE WRITE_SIZE; do
 done
 timeout 120 python /root/repo/scripts/jvrc_phase_profile.py 4096 > $OUT/jvrc_walk_phase_cycles.txt 2>/dev/null
 timeout 200 python /root/repo/scripts/gemm_bench.py 32768 > $OUT/ppo_gemm_shapes.txt 2>/dev/null
+# MLP strip kernels vs the per-layer GEMM sequence, isolated (one actor minibatch with its mirrored rows; one critic minibatch)
+( timeout 100 python /root/repo/scripts/strip_bench.py 65536; timeout 100 python /root/repo/scripts/strip_bench.py 32768 ) 2>/dev/null | grep rows > $OUT/ppo_strip_bench.txt
+for C in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_LDS" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_VALU SQ_INSTS_SALU"; do
+  rm -rf /tmp/pm; timeout 200 rocprofv3 --pmc $C --output-format csv -d /tmp/pm -- python /root/repo/scripts/strip_bench.py 65536 > /tmp/pm.log 2>&1
+  python /root/repo/scripts/pmc_summary.py /tmp/pm | grep -E "kernel,|strip" >> $OUT/ppo_strip_pmc.csv
+done
 if [ "${QUICK:-0}" != 1 ]; then
 for C in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_SALU SQ_IFETCH SQ_INSTS_SMEM" "SQC_ICACHE_REQ SQC_ICACHE_MISSES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_FLAT" "SQ_INSTS_VALU SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_INT32 SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU"; do
   rm -rf /tmp/pm; timeout 300 rocprofv3 --pmc $C --output-format csv -d /tmp/pm -- python /root/repo/scripts/step_only.py 4096 4 > /tmp/pm.log 2>&1
