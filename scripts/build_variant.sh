@@ -5,5 +5,5 @@ set -e
 cd "$(dirname "$0")/.."
 NAME=$1; shift
 mkdir -p learninghumanoidwalking_amd/variants
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared "$@" -o learninghumanoidwalking_amd/variants/liblhw_$NAME.so learninghumanoidwalking_amd/csrc/*.hip
+/opt/rocm/bin/hipcc --offload-arch=gfx950 ${OPT:--O3} -std=c++17 -fPIC -shared "$@" -o learninghumanoidwalking_amd/variants/liblhw_$NAME.so learninghumanoidwalking_amd/csrc/*.hip
 echo built learninghumanoidwalking_amd/variants/liblhw_$NAME.so
