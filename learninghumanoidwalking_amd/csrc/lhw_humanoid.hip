@@ -1565,53 +1565,77 @@ __device__ __forceinline__ void row_deriv(bool valid, double fl, double D, doubl
   *d1 = a; *d2 = b;
 }
 
-// K^-1 x for a Hessian whose contacts couple the two chains (no block structure left): a plain left-looking Cholesky on the
-// packed lower triangle in LDS (the U_L region, which the chain solver leaves idle), one dof per lane, rolled loops.  Slow
-// (~2 k instructions) and small: it runs in the few sub-steps with leg-leg contacts and must not cost the hot path registers.
-// Hrow / hd: the chain-layout row of M + J^T D J (root + own-chain columns) as assembled for chain_solve.
+// K^-1 x for a Hessian whose contacts couple the two chains (no block structure left): dense Cholesky with one dof per lane.
+// It runs only in sub-steps with leg-leg contacts -- but in a batch of thousands of envs SOME wave has one in nearly every
+// launch, and a launch lasts as long as its slowest wave: the first version (rolled loops, every operand through LDS, the
+// chain A x chain B block summed entry by entry over all rows) took ~50 k cycles per solve and made those waves twice as long
+// as the average one (scripts/tail_waves.py).  This version keeps the lane's row of the factor in registers (statically
+// indexed: the column loops are fully unrolled), reads the pivot row as LDS broadcasts that do not sit on the dependency
+// chain, carries the right-hand side through the factorisation (no separate forward substitution) and assembles the A x B
+// block from the active rows only.  Packed lower triangle of the factor in LDS (the U_L region, which the chain solver leaves
+// idle).  Hrow / hd: the chain-layout row of M + J^T D J (root + own-chain columns) as assembled for chain_solve;
+// active_rows: ballot of the rows with a non-zero D (either env of the wave).
 template <class L>
-__device__ __forceinline__ double dense_lds_solve(L& S, const double (&Hrow)[NR], double hd, double x, int dof, bool prim, int coff, int nrow) {
+__device__ __forceinline__ double dense_lds_solve(L& S, const double (&Hrow)[NR], double hd, double x, int dof, bool prim, int coff,
+                                                  unsigned long long active_rows) {
   double* A = S.U + U_L;
   double* xs = S.U + U_DG;
   const int d = dof >= 0 ? dof : 0;
-  SYNC();
-  if (prim) {
+  const bool chainB = prim && d >= 6 + NCH;
+  // row d of H by dof index (lower triangle: only columns c <= d are used); the diagonal travels separately
+  double row[NV];
 #pragma unroll
-    for (int e = 0; e < NR; e++) {
-      const int c = e < 6 ? e : coff + e - 6;
-      if (c < d) A[TRI(d, c)] = Hrow[e];
+  for (int c = 0; c < 6; c++) row[c] = Hrow[c];
+  {
+    // chain B rows: the chain A columns carry the coupling J^T D J only -- summed over the active rows
+    double xb[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; c++) xb[c] = 0.0;
+    while (active_rows) {
+      const int r = __ffsll(active_rows) - 1;
+      active_rows &= active_rows - 1;
+      const double cj = S.U[U_DACT + r] * S.U[U_J + r * NV + d];
+#pragma unroll
+      for (int c = 0; c < NCH; c++) xb[c] += cj * S.U[U_J + r * NV + 6 + c];
     }
-    A[TRI(d, d)] = hd;
-    if (d >= 6 + NCH)   // chain B rows: the chain A columns carry the coupling J^T D J only
-      for (int c = 6; c < 6 + NCH; c++) {
-        double s = 0;
-        for (int r = 0; r < nrow; r++) s += S.U[U_DACT + r] * S.U[U_J + r * NV + d] * S.U[U_J + r * NV + c];
-        A[TRI(d, c)] = s;
-      }
+#pragma unroll
+    for (int c = 0; c < NCH; c++) {
+      row[6 + c] = chainB ? xb[c] : Hrow[6 + c];
+      row[6 + NCH + c] = chainB ? Hrow[6 + c] : 0.0;
+    }
   }
   SYNC();
+  double y = x;   // right-hand side element, then y = L^-1 b
+#pragma unroll
   for (int j = 0; j < NV; j++) {
-    double s = 0;
-    const bool act = prim && d >= j;
-    if (act) {
-      s = A[TRI(d, j)];
-      for (int k = 0; k < j; k++) s -= A[TRI(d, k)] * A[TRI(j, k)];
+    // s = H[d][j] - sum_{k<j} L[d][k] L[j][k] for the lanes d >= j (row[k] holds this lane's finished L[d][k]); lane j also
+    // finishes y_j = (b_j - sum_{k<j} L[j][k] y_k) / L[j][j]
+    double s = d == j ? hd : row[j], t = y;
+#pragma unroll
+    for (int k = 0; k < j; k++) {
+      s -= row[k] * A[TRI(j, k)];
+      t -= row[k] * xs[k];
+    }
+    if (prim && d == j) {
+      const double piv = sqrt(fmax(s, HMINVAL));
+      A[TRI(j, j)] = piv;
+      y = t / piv;
+      xs[j] = y;
     }
     SYNC();
-    if (act && d == j) A[TRI(j, j)] = sqrt(fmax(s, HMINVAL));
-    SYNC();
-    if (act && d > j) A[TRI(d, j)] = s / A[TRI(j, j)];
+    if (prim && d > j) {
+      row[j] = s / A[TRI(j, j)];
+      A[TRI(d, j)] = row[j];
+    }
     SYNC();
   }
-  for (int j = 0; j < NV; j++) {
-    if (prim && d == j) { x = x / A[TRI(j, j)]; xs[j] = x; }
-    SYNC();
-    if (prim && d > j) x -= A[TRI(d, j)] * xs[j];
-  }
+  // back substitution, column by column: x_j = y_j / L[j][j], then every lane d < j takes L[j][d] x_j off its own y
+  double xd = 0.0;
+#pragma unroll
   for (int j = NV - 1; j >= 0; j--) {
-    if (prim && d == j) { x = x / A[TRI(j, j)]; xs[j] = x; }
+    if (prim && d == j) { xd = y / A[TRI(j, j)]; xs[j] = xd; }
     SYNC();
-    if (prim && d < j) x -= A[TRI(j, d)] * xs[j];
+    if (prim && d < j) y -= A[TRI(j, d)] * xs[j];
   }
   SYNC();
   return dof >= 0 ? xs[d] : 0.0;
@@ -1838,10 +1862,11 @@ __device__ __forceinline__ void solve_tail(const HModel& m, const HParams& p, L&
       double Hrow[NR], hd = mdiag + udact;
 #pragma unroll
       for (int k = 0; k < NR; k++) Hrow[k] = Mrow[k];
+      // only rows that are active (in either env of the wave: the row index must be wave-uniform) contribute
+      unsigned long long mm_all = __ballot(dactive != 0.0);
+      if constexpr (W == 32) mm_all = (mm_all | (mm_all >> 32)) & 0xffffffffull;
       {
-        // only rows that are active (in either env of the wave: the row index must be wave-uniform) contribute
-        unsigned long long mm = __ballot(dactive != 0.0);
-        if constexpr (W == 32) mm = (mm | (mm >> 32)) & 0xffffffffull;
+        unsigned long long mm = mm_all;
         while (mm) {      // (measured: unrolling this loop, or the J^T f loop above, is slower -- DESIGN.md section 4)
           const int r = __ffsll(mm) - 1;
           mm &= mm - 1;
@@ -1870,7 +1895,7 @@ __device__ __forceinline__ void solve_tail(const HModel& m, const HParams& p, L&
           for (int k = 0; k < 6; k++) Hrow[k] = 0.0;
         }
       }
-      const double search = cross ? -dense_lds_solve<L>(S, Hrow, hd, grad, dof, prim, coff, nrow) : -spd_solve(Hrow, hd, grad);
+      const double search = cross ? -dense_lds_solve<L>(S, Hrow, hd, grad, dof, prim, coff, mm_all) : -spd_solve(Hrow, hd, grad);
       PROF_MARK(2);
       if (prim) S.U[U_VEC2 + dd] = search;
       SYNC();
