@@ -26,10 +26,20 @@ sc = ti["self_collision"].reshape(-1, 2)
 fc = ti["foot_contact"].reshape(-1, 2) if "foot_contact" in ti else None
 print(f"waves {len(w)}  mean {w.mean():.3e}  p50 {np.percentile(w,50):.3e}  p90 {np.percentile(w,90):.3e}  p99 {np.percentile(w,99):.3e}  max {w.max():.3e}  max/mean {w.max()/w.mean():.2f}")
 order = np.argsort(-w)
-print("slowest waves: cycles/mean, done flags of the two envs, root z (pre-reset terminal z), self-collision flags")
+qv = np.abs(ti["qvel"]).max(1).reshape(-1, 2)
+grf = (ti["grf_r"] + ti["grf_l"]).reshape(-1, 2)
+fcn = ti["foot_contact"].reshape(-1, 2) if "foot_contact" in ti else np.zeros_like(grf)
+print("slowest waves: cycles/mean, done flags of the two envs, root z (pre-reset terminal z), self-collision flags, max |qvel|, GRF, foot-contact flag")
 for i in order[:16]:
-    print(f"  wave {i:5d}  {w[i]/w.mean():.2f}  done {d[i]}  z {np.round(z[i],2)}  selfcol {sc[i]}")
+    print(f"  wave {i:5d}  {w[i]/w.mean():.2f}  done {d[i]}  z {np.round(z[i],2)}  selfcol {sc[i]}  qvel {np.round(qv[i],1)}  grf {np.round(grf[i])}  fc {fcn[i]}")
 dd = d.max(1) > 0
 print(f"waves with an episode end: {dd.sum()} of {len(w)}: mean {w[dd].mean()/w.mean():.2f} x mean;  without: {w[~dd].mean()/w.mean():.2f} x, max without {w[~dd].max()/w.mean():.2f} x")
 ss = sc.max(1) > 0
 print(f"waves with a self-collision: {ss.sum()}: mean {w[ss].mean()/w.mean() if ss.any() else 0:.2f} x; low root (z<0.5): {(z.min(1)<0.5).sum()} waves, mean {w[z.min(1)<0.5].mean()/w.mean() if (z.min(1)<0.5).any() else 0:.2f} x")
+
+lo = order[-8:]
+print("fastest waves:")
+for i in lo:
+    print(f"  wave {i:5d}  {w[i]/w.mean():.2f}  done {d[i]}  z {np.round(z[i],2)}  qvel {np.round(qv[i],1)}  grf {np.round(grf[i])}  fc {fcn[i]}")
+both_air = (grf.max(1) == 0)
+print(f"waves with both envs airborne (no GRF): {both_air.sum()}, mean {w[both_air].mean()/w.mean() if both_air.any() else 0:.2f} x;  both on the ground: {(grf.min(1)>0).sum()}, mean {w[grf.min(1)>0].mean()/w.mean():.2f} x")
