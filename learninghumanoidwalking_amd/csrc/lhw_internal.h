@@ -45,5 +45,5 @@ struct MlpStripBwd {
 bool mlp_strip_supported(int H, int Dp, int O, int Op);
 size_t mlp_strip_wt_floats(int Dp, int Op);
 void mlp_strip_prepare(const float* w1, const float* w2, const float* w3, int Dp, int O, int Op, float* wt, hipStream_t s);
-void mlp_strip_forward(const MlpStripFwd& a, hipStream_t s);
+void mlp_strip_forward(const MlpStripFwd& a, hipStream_t s, int shape = 0);   // shape: 0 by row count, 1 small (32-row slabs), 2 big (64-row)
 void mlp_strip_backward(const MlpStripBwd& a, hipStream_t s);

@@ -24,6 +24,8 @@
 // summation order differs.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "../../include/lhw.h"
 #include "lhw_internal.h"
 
@@ -32,73 +34,92 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #endif
 
 #define SH 256          // hidden width the strip kernels are compiled for
-#define SROWS 64        // rows per slab
-#define SLD (SROWS + 4) // slab row stride (floats)
 #define SBK 16          // K step (one register buffer of weight operands)
-#define STHR 256
 #define SXK 64          // capacity of the input slab (padded input width of the first layer / output width of the last)
+#define SKQ 32          // the read-out is summed as SH / SKQ partial products of SKQ k each, in ascending order, whatever the shape
 
+// Shape of a workgroup: RT row tiles of 32 slab rows, NW waves, each owning CT column tiles of 32 output units (NW * CT * 32 =
+// SH).  Big: 64-row slabs, 4 waves x 64 columns -- 2 x 2 MFMA tiles per wave, one slab / weight operand feeds two MFMAs each;
+// 70 KB of LDS (two workgroups per CU): the update's shape.  Small: 32-row slabs, 8 waves x 32 columns -- a quarter of the
+// MFMA chain per wave: the shape of rollout inference, where a few thousand rows put fewer slabs on the chip than it has CUs
+// and the latency of one slab is the latency of the policy step (41 -> ~15 us).  Results are identical between the shapes (the
+// hidden layers are the same fmaf chains, the read-out has the same partial sums).
+template <int RT_, int CT_, int NW_>
+struct StripShape {
+  static constexpr int RT = RT_, CT = CT_, NW = NW_, ROWS = 32 * RT_, LD = ROWS + 4, THR = 64 * NW_;
+  static_assert(NW_ * CT_ * 32 == SH, "the waves' column tiles must cover the hidden width");
+};
+typedef StripShape<2, 2, 4> StripBig;
+typedef StripShape<1, 1, 8> StripSmall;
+
+template <class C>
 struct StripLds {
-  float S[SH][SLD];         // activation slab, k-major (69 632 B: two workgroups per CU).  The input slab (x / dy, at most SXK
-};                          // columns) occupies its last SXK rows until the first layer's products are done
+  float S[SH][C::LD];       // activation slab, k-major (Big: 69 632 B).  The input slab (x / dy, at most SXK columns) occupies
+};                          // its last SXK rows until the first layer's products are done
 
-__device__ __forceinline__ void zero_acc(f32x16 (&acc)[2][2]) {
+template <class C>
+__device__ __forceinline__ void zero_acc(f32x16 (&acc)[C::RT][C::CT]) {
 #pragma unroll
-  for (int i = 0; i < 2; i++)
+  for (int i = 0; i < C::RT; i++)
 #pragma unroll
-    for (int j = 0; j < 2; j++)
+    for (int j = 0; j < C::CT; j++)
 #pragma unroll
       for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
 }
 
-// One K step (SBK rows of k) of operands, as the MFMA wants them: lane l holds, for kk = 0 .. SBK/2, the element of row
-// k0 + 2 kk + l / 32.
-struct WOp { float v[SBK / 2][2]; };   // weights: columns n0 + l % 32 and n0 + 32 + l % 32
+// One K step (SBK rows of k) of weights, as the MFMA wants them: lane l holds, for kk = 0 .. SBK/2, the element of row
+// k0 + 2 kk + l / 32 in the wave's CT column tiles.
+template <class C>
+struct WOp { float v[SBK / 2][C::CT]; };
 
 // weights of step k0 straight from global memory: stored [K][ldb] with the output unit contiguous, so one load instruction of
 // the wave fetches two 128-byte segments; no LDS staging.  Rows k >= K are clamped copies of row K - 1 (the slab holds zeros
 // there), so the prefetches can run past the end unconditionally.
-__device__ __forceinline__ void wload(WOp& w, const float* __restrict__ Bg, const int ldb, const int K, const int k0) {
-  const int lane = threadIdx.x & 63, l31 = lane & 31, kh = lane >> 5, n0 = (threadIdx.x >> 6) * 64 + l31;
+template <class C>
+__device__ __forceinline__ void wload(WOp<C>& w, const float* __restrict__ Bg, const int ldb, const int K, const int k0) {
+  const int lane = threadIdx.x & 63, l31 = lane & 31, kh = lane >> 5, n0 = (threadIdx.x >> 6) * 32 * C::CT + l31;
 #pragma unroll
   for (int kk = 0; kk < SBK / 2; kk++) {
     const int k = min(k0 + kk * 2 + kh, K - 1);
 #pragma unroll
-    for (int j = 0; j < 2; j++) w.v[kk][j] = Bg[(size_t)k * ldb + n0 + 32 * j];
+    for (int j = 0; j < C::CT; j++) w.v[kk][j] = Bg[(size_t)k * ldb + n0 + 32 * j];
   }
 }
 
-// acc[i][j] += (A[rows 32 i .. +32][0 .. K) * B[0 .. K)[columns 64 wave + 32 j .. +32])^T.  A is the LDS slab (k-major; rows
-// k >= K up to the next multiple of SBK must hold ZEROS), B the weights (wload).  No barrier in the K loop: the four waves of the
-// block own disjoint output columns and share only the read-only slab.  The weights of step s + 1 are in flight while step s is
-// multiplied; `w0` arrives holding the weights of step 0 (the caller
-// issues that load early, e.g. before the previous layer's epilogue).
+// acc[i][j] += (A[rows 32 i .. +32][0 .. K) * B[0 .. K)[the wave's column tile j])^T.  A is the LDS slab (k-major; rows k >= K up
+// to the next multiple of SBK must hold ZEROS), B the weights (wload).  No barrier in the K loop: the waves of the block own
+// disjoint output columns and share only the read-only slab.  The weights of step s + 1 are in flight while step s is
+// multiplied; `w0` arrives holding the weights of step 0 (the caller issues that load early, e.g. before the previous layer's
+// epilogue).
 // The weights are the MFMA's A operand and the slab its B operand, so the accumulators hold the TRANSPOSED output tile: lane =
 // slab row, four consecutive output units per register quad (16-byte row-major stores in the epilogue).
-__device__ __forceinline__ void slab_mma(const float (*A)[SLD], const int K, const float* __restrict__ Bg, const int ldb, WOp& w0,
-                                         f32x16 (&acc)[2][2]) {
+template <class C>
+__device__ __forceinline__ void slab_mma(const float (*A)[C::LD], const int K, const float* __restrict__ Bg, const int ldb, WOp<C>& w0,
+                                         f32x16 (&acc)[C::RT][C::CT]) {
   const int lane = threadIdx.x & 63, l31 = lane & 31, kh = lane >> 5;
-  WOp w1;
-  auto mul = [&](const WOp& w, int k0) {
+  WOp<C> w1;
+  auto mul = [&](const WOp<C>& w, int k0) {
 #pragma unroll
     for (int kk = 0; kk < SBK / 2; kk++) {
       const int k = k0 + kk * 2 + kh;
-      const float a0 = A[k][l31], a1 = A[k][32 + l31];
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w.v[kk][0], a0, acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w.v[kk][1], a0, acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w.v[kk][0], a1, acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w.v[kk][1], a1, acc[1][1], 0, 0, 0);
+      float a[C::RT];
+#pragma unroll
+      for (int i = 0; i < C::RT; i++) a[i] = A[k][32 * i + l31];
+#pragma unroll
+      for (int i = 0; i < C::RT; i++)
+#pragma unroll
+        for (int j = 0; j < C::CT; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(w.v[kk][j], a[i], acc[i][j], 0, 0, 0);
     }
   };
   // (the prefetches are unconditional, so the loop body is one straight path and a multiply waits only for its own, older,
   // loads; the scheduling barriers keep the machine scheduler from sinking a prefetch down to its first use.  Prefetching the
   // slab rows a step ahead as well measured slower: 155 vs 147 us per 65536-row forward pass)
   for (int k0 = 0; k0 < K; k0 += 2 * SBK) {
-    wload(w1, Bg, ldb, K, k0 + SBK);
+    wload<C>(w1, Bg, ldb, K, k0 + SBK);
     __builtin_amdgcn_sched_barrier(0);
     mul(w0, k0);
     __builtin_amdgcn_sched_barrier(0);
-    wload(w0, Bg, ldb, K, k0 + 2 * SBK);
+    wload<C>(w0, Bg, ldb, K, k0 + 2 * SBK);
     __builtin_amdgcn_sched_barrier(0);
     if (k0 + SBK < K) mul(w1, k0 + SBK);
     __builtin_amdgcn_sched_barrier(0);
@@ -107,22 +128,22 @@ __device__ __forceinline__ void slab_mma(const float (*A)[SLD], const int K, con
 
 // Epilogue of a 256-wide layer: v = acc (+ bias[n]) (ReLU) (masked by mask[row][n] > 0); to HBM (row-major, ld SH) and, with
 // TO_SLAB, into the slab as the next layer's operand.  The accumulators hold the transposed tile (see slab_mma): lane l of tile
-// (i, j) owns slab row 32 i + l % 32 and, in registers 4 g .. 4 g + 3, the output units 64 wave + 32 j + 8 g + 4 (l / 32) + 0..3 --
-// one 16-byte store (and one 16-byte mask / bias load) per register quad.  Rows beyond R are computed (finite values from zero
-// inputs) but never stored to HBM.
-template <bool TO_SLAB, bool FULL>
-__device__ __forceinline__ void store_act_t(StripLds& L, const f32x16 (&acc)[2][2], const float* __restrict__ bias, const bool relu,
+// (i, j) owns slab row 32 i + l % 32 and, in registers 4 g .. 4 g + 3, the output units (wave's first) + 32 j + 8 g + 4 (l / 32) +
+// 0..3 -- one 16-byte store (and one 16-byte mask / bias load) per register quad.  Rows beyond R are computed (finite values
+// from zero inputs) but never stored to HBM.
+template <class C, bool TO_SLAB, bool FULL>
+__device__ __forceinline__ void store_act_t(StripLds<C>& L, const f32x16 (&acc)[C::RT][C::CT], const float* __restrict__ bias, const bool relu,
                                             const float* __restrict__ mask, float* __restrict__ out, const int row0, const int R) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, kh = lane >> 5;
 #pragma unroll
-  for (int j = 0; j < 2; j++) {
-    const int nb = wave * 64 + 32 * j + 4 * kh;
+  for (int j = 0; j < C::CT; j++) {
+    const int nb = wave * 32 * C::CT + 32 * j + 4 * kh;
     // the mask values of this column tile first, as one batch of independent loads (interleaved with the stores below they
     // would be serialised: the compiler cannot prove that `out` does not alias `mask`)
-    float4 mk[2][4];
+    float4 mk[C::RT][4];
 #pragma unroll
-    for (int i = 0; i < 2; i++)
+    for (int i = 0; i < C::RT; i++)
 #pragma unroll
       for (int g = 0; g < 4; g++) {
         const int row = 32 * i + l31;
@@ -135,7 +156,7 @@ __device__ __forceinline__ void store_act_t(StripLds& L, const f32x16 (&acc)[2][
       float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
       if (bias) bv = *reinterpret_cast<const float4*>(bias + n);
 #pragma unroll
-      for (int i = 0; i < 2; i++) {
+      for (int i = 0; i < C::RT; i++) {
         const int row = 32 * i + l31;
         const bool live = FULL || row0 + row < R;
         float4 v = make_float4(acc[i][j][4 * g] + bv.x, acc[i][j][4 * g + 1] + bv.y, acc[i][j][4 * g + 2] + bv.z, acc[i][j][4 * g + 3] + bv.w);
@@ -150,17 +171,18 @@ __device__ __forceinline__ void store_act_t(StripLds& L, const f32x16 (&acc)[2][
     }
   }
 }
-template <bool TO_SLAB>
-__device__ __forceinline__ void store_act(StripLds& L, const f32x16 (&acc)[2][2], const float* __restrict__ bias, const bool relu,
+template <class C, bool TO_SLAB>
+__device__ __forceinline__ void store_act(StripLds<C>& L, const f32x16 (&acc)[C::RT][C::CT], const float* __restrict__ bias, const bool relu,
                                           const float* __restrict__ mask, float* __restrict__ out, const int row0, const int R) {
-  if (row0 + SROWS <= R) store_act_t<TO_SLAB, true>(L, acc, bias, relu, mask, out, row0, R);   // (all but the last slab: no per-row tests)
-  else store_act_t<TO_SLAB, false>(L, acc, bias, relu, mask, out, row0, R);
+  if (row0 + C::ROWS <= R) store_act_t<C, TO_SLAB, true>(L, acc, bias, relu, mask, out, row0, R);   // (all but the last slab: no per-row tests)
+  else store_act_t<C, TO_SLAB, false>(L, acc, bias, relu, mask, out, row0, R);
 }
 
 // stage a [rows][K] row-major slab (row stride ld) k-major into X, zero-padded to a multiple of SBK in k and beyond R in rows
-__device__ __forceinline__ void stage_input(float (*X)[SLD], const float* __restrict__ x, const int ld, const int K, const int row0, const int R) {
+template <class C>
+__device__ __forceinline__ void stage_input(float (*X)[C::LD], const float* __restrict__ x, const int ld, const int K, const int row0, const int R) {
   const int Kp = (K + SBK - 1) & ~(SBK - 1);
-  for (int i = threadIdx.x; i < SROWS * Kp; i += STHR) {
+  for (int i = threadIdx.x; i < C::ROWS * Kp; i += C::THR) {
     const int r = i / Kp, k = i - r * Kp;
     float v = 0.f;
     if (k < K && row0 + r < R) v = x[(size_t)(row0 + r) * ld + k];
@@ -168,74 +190,89 @@ __device__ __forceinline__ void stage_input(float (*X)[SLD], const float* __rest
   }
 }
 
-__global__ void __launch_bounds__(STHR, 2) mlp_fwd_strip_kernel(MlpStripFwd a) {
-  __shared__ StripLds L;
+template <class C>
+__global__ void __launch_bounds__(C::THR, 2) mlp_fwd_strip_kernel(MlpStripFwd a) {
+  __shared__ StripLds<C> L;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, kh = lane >> 5;
-  const int row0 = (int)blockIdx.x * SROWS;
-  float (*X)[SLD] = &L.S[SH - SXK];
-  WOp w;
-  wload(w, a.w1t, SH, a.Dp, 0);   // (the first weights of a layer are in flight while the slab is staged / the previous epilogue runs)
-  stage_input(X, a.x, a.ldx, a.Dp, row0, a.R);
+  const int row0 = (int)blockIdx.x * C::ROWS;
+  float (*X)[C::LD] = &L.S[SH - SXK];
+  WOp<C> w;
+  wload<C>(w, a.w1t, SH, a.Dp, 0);   // (the first weights of a layer are in flight while the slab is staged / the previous epilogue runs)
+  stage_input<C>(X, a.x, a.ldx, a.Dp, row0, a.R);
   __syncthreads();
-  f32x16 acc[2][2];
-  zero_acc(acc);
-  slab_mma(X, a.Dp, a.w1t, SH, w, acc);
-  wload(w, a.w2t, SH, SH, 0);
+  f32x16 acc[C::RT][C::CT];
+  zero_acc<C>(acc);
+  slab_mma<C>(X, a.Dp, a.w1t, SH, w, acc);
+  wload<C>(w, a.w2t, SH, SH, 0);
   __syncthreads();   // every wave is done with the input slab
-  store_act<true>(L, acc, a.b1, true, nullptr, a.h1, row0, a.R);
+  store_act<C, true>(L, acc, a.b1, true, nullptr, a.h1, row0, a.R);
   __syncthreads();
-  zero_acc(acc);
-  slab_mma(L.S, SH, a.w2t, SH, w, acc);
+  zero_acc<C>(acc);
+  slab_mma<C>(L.S, SH, a.w2t, SH, w, acc);
   __syncthreads();
-  store_act<true>(L, acc, a.b2, true, nullptr, a.h2, row0, a.R);
+  store_act<C, true>(L, acc, a.b2, true, nullptr, a.h2, row0, a.R);
   __syncthreads();
-  // read-out: y = h2 W3^T + b3, N = O <= 32: one column tile; wave w takes k in [64 w, 64 w + 64) for both row tiles, the four
-  // partial products are summed in wave order
-  f32x16 p[2];
+  // read-out: y = h2 W3^T + b3, N = O <= 32: one column tile.  The K range is cut into SH / SKQ partial products of SKQ k each
+  // (the same cut for every workgroup shape, so every shape returns the same bits); a wave takes QW consecutive ones for all
+  // row tiles, and the partials are summed in ascending k order afterwards.
+  constexpr int NQ = SH / SKQ, QW = NQ / C::NW;
+  f32x16 p[QW][C::RT];
 #pragma unroll
-  for (int i = 0; i < 2; i++)
+  for (int q = 0; q < QW; q++)
 #pragma unroll
-    for (int r = 0; r < 16; r++) p[i][r] = 0.f;
+    for (int i = 0; i < C::RT; i++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) p[q][i][r] = 0.f;
+#pragma unroll
+  for (int q = 0; q < QW; q++) {
 #pragma unroll 8
-  for (int kk = 0; kk < 32; kk++) {
-    const int k = wave * 64 + kk * 2 + kh;
-    const float bv = a.w3t[(size_t)k * a.Op + min(l31, a.O - 1)], b = l31 < a.O ? bv : 0.f;
-    p[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(L.S[k][l31], b, p[0], 0, 0, 0);
-    p[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(L.S[k][32 + l31], b, p[1], 0, 0, 0);
+    for (int kk = 0; kk < SKQ / 2; kk++) {
+      const int k = (wave * QW + q) * SKQ + kk * 2 + kh;
+      const float bv = a.w3t[(size_t)k * a.Op + min(l31, a.O - 1)], b = l31 < a.O ? bv : 0.f;
+#pragma unroll
+      for (int i = 0; i < C::RT; i++) p[q][i] = __builtin_amdgcn_mfma_f32_32x32x2f32(L.S[k][32 * i + l31], b, p[q][i], 0, 0, 0);
+    }
   }
-  __syncthreads();   // all waves are done with the slab: it now holds the four partial products
-  float (*P)[SROWS][32] = reinterpret_cast<float (*)[SROWS][32]>(&L.S[0][0]);
+  __syncthreads();   // all waves are done with the slab: it now holds the partial products
+  float (*P)[C::ROWS][32] = reinterpret_cast<float (*)[C::ROWS][32]>(&L.S[0][0]);     // [NQ][ROWS][32]: NQ * ROWS * 128 B <= the slab
 #pragma unroll
-  for (int i = 0; i < 2; i++)
+  for (int q = 0; q < QW; q++)
 #pragma unroll
-    for (int r = 0; r < 16; r++) P[wave][32 * i + (r & 3) + 8 * (r >> 2) + 4 * kh][l31] = p[i][r];
+    for (int i = 0; i < C::RT; i++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) P[wave * QW + q][32 * i + (r & 3) + 8 * (r >> 2) + 4 * kh][l31] = p[q][i][r];
   __syncthreads();
-  for (int i = tid; i < SROWS * 32; i += STHR) {
+  for (int i = tid; i < C::ROWS * 32; i += C::THR) {
     const int row = i >> 5, col = i & 31;
-    if (col < a.O && row0 + row < a.R)
-      a.y[(size_t)(row0 + row) * a.Op + col] = (((P[0][row][col] + P[1][row][col]) + P[2][row][col]) + P[3][row][col]) + a.b3[col];
+    if (col < a.O && row0 + row < a.R) {
+      float s = P[0][row][col];
+#pragma unroll
+      for (int q = 1; q < NQ; q++) s += P[q][row][col];
+      a.y[(size_t)(row0 + row) * a.Op + col] = s + a.b3[col];
+    }
   }
 }
 
-__global__ void __launch_bounds__(STHR, 2) mlp_bwd_strip_kernel(MlpStripBwd a) {
-  __shared__ StripLds L;
-  const int row0 = (int)blockIdx.x * SROWS;
-  float (*X)[SLD] = &L.S[SH - SXK];
-  WOp w;
-  wload(w, a.w3, SH, a.O, 0);
-  stage_input(X, a.dy, a.Op, a.O, row0, a.R);
+template <class C>
+__global__ void __launch_bounds__(C::THR, 2) mlp_bwd_strip_kernel(MlpStripBwd a) {
+  __shared__ StripLds<C> L;
+  const int row0 = (int)blockIdx.x * C::ROWS;
+  float (*X)[C::LD] = &L.S[SH - SXK];
+  WOp<C> w;
+  wload<C>(w, a.w3, SH, a.O, 0);
+  stage_input<C>(X, a.dy, a.Op, a.O, row0, a.R);
   __syncthreads();
-  f32x16 acc[2][2];
-  zero_acc(acc);
-  slab_mma(X, a.O, a.w3, SH, w, acc);                                       // dy W3: B[k = o][n] = W3[o][n]
-  wload(w, a.w2, SH, SH, 0);
+  f32x16 acc[C::RT][C::CT];
+  zero_acc<C>(acc);
+  slab_mma<C>(X, a.O, a.w3, SH, w, acc);                                    // dy W3: B[k = o][n] = W3[o][n]
+  wload<C>(w, a.w2, SH, SH, 0);
   __syncthreads();
-  store_act<true>(L, acc, nullptr, false, a.h2, a.dh2, row0, a.R);
+  store_act<C, true>(L, acc, nullptr, false, a.h2, a.dh2, row0, a.R);
   __syncthreads();
-  zero_acc(acc);
-  slab_mma(L.S, SH, a.w2, SH, w, acc);                                      // dh2 W2: B[k = o][n = i] = W2[o][i]
-  store_act<false>(L, acc, nullptr, false, a.h1, a.dh1, row0, a.R);
+  zero_acc<C>(acc);
+  slab_mma<C>(L.S, SH, a.w2, SH, w, acc);                                   // dh2 W2: B[k = o][n = i] = W2[o][i]
+  store_act<C, false>(L, acc, nullptr, false, a.h1, a.dh1, row0, a.R);
 }
 
 // WT [cols][rows] <- W [rows][ld] for three matrices in one launch (the forward pass multiplies by W^T: its weight operand must
@@ -269,14 +306,20 @@ void mlp_strip_prepare(const float* w1, const float* w2, const float* w3, int Dp
 
 bool mlp_strip_supported(int H, int Dp, int O, int Op) { return H == SH && Dp > 0 && Dp <= SXK && (Dp & 3) == 0 && O > 0 && O <= 32 && Op >= O; }
 
-void mlp_strip_forward(const MlpStripFwd& a, hipStream_t s) {
+// Rows up to which the small shape is used: below it the slabs of the big shape would not even fill the CUs once, and the call
+// is latency-bound (rollout inference); above it the big shape's operand reuse wins (the update's minibatches).
+#define STRIP_SMALL_ROWS 16384
+void mlp_strip_forward(const MlpStripFwd& a, hipStream_t s, int shape /* 0: by row count, 1: small, 2: big */) {
   if (a.R <= 0) return;
-  hipLaunchKernelGGL(mlp_fwd_strip_kernel, dim3((a.R + SROWS - 1) / SROWS), dim3(STHR), 0, s, a);
+  if (shape == 1 || (shape == 0 && a.R <= STRIP_SMALL_ROWS))
+    hipLaunchKernelGGL((mlp_fwd_strip_kernel<StripSmall>), dim3((a.R + StripSmall::ROWS - 1) / StripSmall::ROWS), dim3(StripSmall::THR), 0, s, a);
+  else
+    hipLaunchKernelGGL((mlp_fwd_strip_kernel<StripBig>), dim3((a.R + StripBig::ROWS - 1) / StripBig::ROWS), dim3(StripBig::THR), 0, s, a);
 }
 
 void mlp_strip_backward(const MlpStripBwd& a, hipStream_t s) {
   if (a.R <= 0) return;
-  hipLaunchKernelGGL(mlp_bwd_strip_kernel, dim3((a.R + SROWS - 1) / SROWS), dim3(STHR), 0, s, a);
+  hipLaunchKernelGGL((mlp_bwd_strip_kernel<StripBig>), dim3((a.R + StripBig::ROWS - 1) / StripBig::ROWS), dim3(StripBig::THR), 0, s, a);
 }
 
 extern "C" int lhw_debug_mlp_strip_forward(int32_t H, int32_t Dp, int32_t O, int32_t Op, const float* w1, const float* b1, const float* w2,
@@ -286,7 +329,8 @@ extern "C" int lhw_debug_mlp_strip_forward(int32_t H, int32_t Dp, int32_t O, int
   if (!mlp_strip_supported(H, Dp, O, Op) || ldx < Dp) return lhw_fail(LHW_ERR_UNSUPPORTED, "strip kernels: hidden width 256, padded input width <= 64, outputs <= 32");
   mlp_strip_prepare(w1, w2, w3, Dp, O, Op, wt_scratch, (hipStream_t)stream);
   MlpStripFwd a{wt_scratch, b1, wt_scratch + (size_t)Dp * SH, b2, wt_scratch + (size_t)Dp * SH + (size_t)SH * SH, b3, x, ldx, Dp, O, Op, R, h1, h2, y};
-  mlp_strip_forward(a, (hipStream_t)stream);
+  const char* sh = getenv("LHW_DEBUG_STRIP_SHAPE");     // (tests: "small" / "big" force the workgroup shape; default by row count)
+  mlp_strip_forward(a, (hipStream_t)stream, sh ? (sh[0] == 's' ? 1 : 2) : 0);
   return hipGetLastError() == hipSuccess ? LHW_OK : lhw_fail(LHW_ERR_HIP, "mlp_fwd_strip_kernel launch failed");
 }
 

@@ -51,3 +51,17 @@ def step_timed(busy):
         ts.append(e0.elapsed_time(e1) * 1e3)
     return np.median(ts)
 print(f"control step of 2048 envs alone: {step_timed(0):.0f} us;  beside the other group's: {step_timed(1):.0f} us")
+
+# breakdown of the whole-batch chain on an idle GPU: repeated launches of each piece alone (back to back, so launch gaps included)
+import ctypes
+from learninghumanoidwalking_amd import _lib
+def rep(f, n=200):
+    for _ in range(10): f()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n): f()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / n
+for rows in (2048, 4096):
+    print(f"rows {rows}: whole chain {rep(lambda: chain(0, rows)):.1f} us per call (back-to-back calls)")

@@ -70,6 +70,21 @@ def test_strip_forward_and_backward_on_the_emulator():
     np.testing.assert_allclose(dh1[:R], g1, rtol=0, atol=1e-4)
 
 
+def test_both_workgroup_shapes_return_the_same_bits(monkeypatch):
+    """32-row / 8-wave slabs (rollout inference) and 64-row / 4-wave slabs (the update): same fmaf chains, same partial sums."""
+    from tests import emu
+    L = emu.lib()
+    c = make_case(R=70, Dp=40, O=12, Op=12, seed=4)
+    outs = {}
+    for shape in ("small", "big"):
+        monkeypatch.setenv("LHW_DEBUG_STRIP_SHAPE", shape)
+        outs[shape] = run_forward(L, c)
+    for a, b in zip(outs["small"], outs["big"]):
+        np.testing.assert_array_equal(a, b)
+    r1, r2, ry = reference(c)
+    np.testing.assert_allclose(outs["big"][2][:70, :12], ry[:, :12], rtol=0, atol=5e-5)
+
+
 def test_strip_critic_shape_single_output_on_the_emulator():
     from tests import emu
     L = emu.lib()

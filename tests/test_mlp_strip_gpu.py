@@ -67,3 +67,25 @@ def test_strip_hidden_layers_are_bit_identical_to_the_gemm_path():
     _lib.check(L.lhw_debug_gemm(1, 0, 1, R, 256, 256, p(e2), 256, p(d["w2"]), 256, p(e1), 256, z, 0, p(h1), 256, 0, z, z, z, None))
     torch.cuda.synchronize()
     assert torch.equal(dh2, e2) and torch.equal(dh1, e1)
+
+
+def test_both_workgroup_shapes_return_the_same_bits_gpu(monkeypatch):
+    import torch
+    from learninghumanoidwalking_amd import _lib
+    from tests.test_emu_mlp_strip import make_case
+    L = _lib.lib()
+    R, Dp, O, Op = 5000, 40, 12, 12
+    c = make_case(R=R, Dp=Dp, O=O, Op=Op, seed=6)
+    d = _dev(c)
+    p = lambda t: t.data_ptr()
+    outs = {}
+    for shape in ("small", "big"):
+        monkeypatch.setenv("LHW_DEBUG_STRIP_SHAPE", shape)
+        h1 = torch.zeros(R, 256, device="cuda"); h2 = torch.zeros(R, 256, device="cuda"); y = torch.zeros(R, Op, device="cuda")
+        wt = torch.zeros((Dp + 256 + Op) * 256, device="cuda")
+        _lib.check(L.lhw_debug_mlp_strip_forward(256, Dp, O, Op, p(d["w1"]), p(d["b1"]), p(d["w2"]), p(d["b2"]), p(d["w3"]), p(d["b3"]), p(d["x"]), Dp, R,
+                                                 p(h1), p(h2), p(y), p(wt), None))
+        torch.cuda.synchronize()
+        outs[shape] = (h1, h2, y)
+    for a, b in zip(outs["small"], outs["big"]):
+        assert torch.equal(a, b)
