@@ -36,6 +36,12 @@ struct MlpStripFwd {
   const float* x; int ldx;                   // [R][ldx] inputs (Dp used columns)
   int Dp, O, Op, R;
   float *h1, *h2, *y;                        // [R][256], [R][256], [R][Op]
+  // optional fusions for rollout inference (all NULL / 0 otherwise):
+  const float *in_mean = nullptr, *in_std = nullptr; int in_dim = 0;   // x holds RAW observations [R][ldx = in_dim]: the slab is staged
+                                                                      // as (x - mean) / std for columns < in_dim, zero up to Dp
+  const float* stdv = nullptr;               // Gaussian head on the read-out (lhw_policy.h): act [R][O] = sample(y, stdv), logp [R]
+  float *act = nullptr, *logp = nullptr;
+  unsigned long long seed = 0; unsigned env_base = 0, counter = 0; int deterministic = 0;
 };
 struct MlpStripBwd {
   const float *w2, *w3, *dy, *h1, *h2;       // torch Linear layout [out][in]: W2 [256][256], W3 [Op][256]; dy [R][Op]

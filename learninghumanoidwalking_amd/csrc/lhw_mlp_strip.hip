@@ -28,6 +28,7 @@
 
 #include "../../include/lhw.h"
 #include "lhw_internal.h"
+#include "lhw_policy.h"
 
 #ifndef __HIP_EMU__
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -179,13 +180,18 @@ __device__ __forceinline__ void store_act(StripLds<C>& L, const f32x16 (&acc)[C:
 }
 
 // stage a [rows][K] row-major slab (row stride ld) k-major into X, zero-padded to a multiple of SBK in k and beyond R in rows
+// (mean / stdv: the input is a raw observation row of in_dim entries, normalised on the way in -- the same expression as
+// normalize_kernel, so the update, which normalises its minibatches there, sees the same bits)
 template <class C>
-__device__ __forceinline__ void stage_input(float (*X)[C::LD], const float* __restrict__ x, const int ld, const int K, const int row0, const int R) {
+__device__ __forceinline__ void stage_input(float (*X)[C::LD], const float* __restrict__ x, const int ld, const int K, const int row0, const int R,
+                                            const float* __restrict__ mean = nullptr, const float* __restrict__ stdv = nullptr, const int in_dim = 0) {
   const int Kp = (K + SBK - 1) & ~(SBK - 1);
   for (int i = threadIdx.x; i < C::ROWS * Kp; i += C::THR) {
     const int r = i / Kp, k = i - r * Kp;
     float v = 0.f;
-    if (k < K && row0 + r < R) v = x[(size_t)(row0 + r) * ld + k];
+    if (mean) {
+      if (k < in_dim && row0 + r < R) v = (x[(size_t)(row0 + r) * ld + k] - mean[k]) / stdv[k];
+    } else if (k < K && row0 + r < R) v = x[(size_t)(row0 + r) * ld + k];
     X[k][r] = v;
   }
 }
@@ -199,7 +205,7 @@ __global__ void __launch_bounds__(C::THR, 2) mlp_fwd_strip_kernel(MlpStripFwd a)
   float (*X)[C::LD] = &L.S[SH - SXK];
   WOp<C> w;
   wload<C>(w, a.w1t, SH, a.Dp, 0);   // (the first weights of a layer are in flight while the slab is staged / the previous epilogue runs)
-  stage_input<C>(X, a.x, a.ldx, a.Dp, row0, a.R);
+  stage_input<C>(X, a.x, a.ldx, a.Dp, row0, a.R, a.in_mean, a.in_std, a.in_dim);
   __syncthreads();
   f32x16 acc[C::RT][C::CT];
   zero_acc<C>(acc);
@@ -249,8 +255,23 @@ __global__ void __launch_bounds__(C::THR, 2) mlp_fwd_strip_kernel(MlpStripFwd a)
       float s = P[0][row][col];
 #pragma unroll
       for (int q = 1; q < NQ; q++) s += P[q][row][col];
-      a.y[(size_t)(row0 + row) * a.Op + col] = s + a.b3[col];
+      s += a.b3[col];
+      a.y[(size_t)(row0 + row) * a.Op + col] = s;
+      if (a.act) {   // Gaussian head (rollout inference): the action component here, its log-density term through P[0] (this
+        float term;  // thread's own, now spent, entry) to the row's first thread below
+        a.act[(size_t)(row0 + row) * a.O + col] = lhw_policy_sample(s, a.stdv[col], a.seed, a.env_base + (unsigned)(row0 + row), a.counter, col, a.deterministic, &term);
+        P[0][row][col] = term;
+      }
     }
+  }
+  if (a.act) {
+    __syncthreads();
+    for (int row = tid; row < C::ROWS; row += C::THR)
+      if (row0 + row < a.R) {
+        float lp = 0.f;
+        for (int k = 0; k < a.O; k++) lp += P[0][row][k];     // (the order of sample_kernel's sum)
+        a.logp[row0 + row] = lp;
+      }
   }
 }
 

@@ -1002,6 +1002,22 @@ static int ppo_forward_impl(LhwPpo* p, const float* theta, const float* obs, int
     wta = p->wt_inf + (size_t)(ws_row * WT_SLOTS / p->max_rows) * (fa + fc);
     wtc = wta + fa;
   }
+  // the rollout's policy step (actions + log-densities only) as ONE strip launch: observation normalisation on the way into the
+  // slab, the three layers, the Gaussian head on the read-out -- instead of normalise / forward / sample launches
+  const bool fused = act && logp && !mu && !value && wta && !p->infer_half && mlp_strip_supported(p->la.H, p->la.Dp, p->la.O, p->la.Op);
+  if (fused) {
+    const MlpLayout& La = p->la;
+    const float* th = theta + p->off_actor;
+    mlp_strip_prepare(th + La.w1, th + La.w2, th + La.w3, La.Dp, La.O, La.Op, wta, s);
+    MlpStripFwd a{wta, th + La.b1, wta + (size_t)La.Dp * La.H, th + La.b2, wta + (size_t)La.Dp * La.H + (size_t)La.H * La.H, th + La.b3,
+                  obs, p->D, La.Dp, La.O, La.Op, (int)N, h1a, h2a, ya};
+    a.in_mean = obs_mean; a.in_std = obs_std; a.in_dim = p->D;
+    a.stdv = theta + p->off_std; a.act = act; a.logp = logp;
+    a.seed = seed; a.env_base = env_id_base; a.counter = counter; a.deterministic = deterministic;
+    mlp_strip_forward(a, s);
+    HIPCHK(hipGetLastError());
+    return LHW_OK;
+  }
   hipLaunchKernelGGL(normalize_kernel, dim3((n + 255) / 256), dim3(256), 0, s, obs, p->D, p->la.Dp, (size_t)N, obs_mean, obs_std,
                      xb, (float*)nullptr, (const int*)nullptr, (const float*)nullptr);
   if (act || mu) {

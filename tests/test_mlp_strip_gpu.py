@@ -89,3 +89,21 @@ def test_both_workgroup_shapes_return_the_same_bits_gpu(monkeypatch):
         outs[shape] = (h1, h2, y)
     for a, b in zip(outs["small"], outs["big"]):
         assert torch.equal(a, b)
+
+
+def test_fused_policy_step_equals_the_three_launch_path():
+    """Rollout inference without mu / value runs normalisation, the three layers and the Gaussian head as one strip launch; with
+    want_mu it runs normalize_kernel + forward strip + sample_kernel.  Same actions and log-densities, bit for bit."""
+    import torch
+    from learninghumanoidwalking_amd.ppo_kernels import PpoKernels, reference_init
+    k = PpoKernels(37, 12, hidden=256, max_rows=8192, device=0)
+    k.set_tensors(reference_init(37, 12, 256, 0.223, generator_seed=3))
+    rs = np.random.default_rng(0)
+    k.set_obs_norm(rs.normal(size=37) * 0.3, 0.5 + rs.random(37))
+    for N, ws in ((1000, 0), (2048, 2048), (77, 4096)):
+        obs = torch.from_numpy(rs.normal(size=(N, 37)).astype(np.float32)).cuda()
+        for det in (False, True):
+            _, a1, l1, _ = k.forward(obs, seed=5, env_id_base=17, counter=9, deterministic=det, want_value=False, want_mu=True, ws_row=ws)
+            _, a2, l2, _ = k.forward(obs, seed=5, env_id_base=17, counter=9, deterministic=det, want_value=False, want_mu=False, ws_row=ws)
+            torch.cuda.synchronize()
+            assert torch.equal(a1, a2) and torch.equal(l1, l2), (N, det)
