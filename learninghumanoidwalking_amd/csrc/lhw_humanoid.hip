@@ -24,14 +24,15 @@
 // MuJoCo's impedance / reference acceleration / regulariser model, the primal Newton solver with exact line search and
 // warm start, Euler integration with implicit joint damping.
 //
-// Mapping onto CDNA4: the env's working set (body frames, spatial inertias, contact Jacobian, Cholesky factor ...) lives
-// in LDS for the whole launch; nv-vectors are held one element per lane (lane i <-> dof i); the pyramid rows of contact c
-// sit in lanes 4c..4c+3 with their Jacobian row in registers, and frictionloss / joint-limit rows -- unit vectors -- are
-// scalars of their dof's lane (no Jacobian storage, no row lanes).  Mat-vec products are conflict-free LDS row / column
-// sweeps, reductions are DPP scans; H = M + J^T D J is accumulated one row per dof lane straight into the registers the
-// left-looking Cholesky works on, whose finished rows are published through LDS (one broadcast read per column step
-// instead of one v_readlane per element).  The persistent state is one contiguous 1.3 KB record per env, read and written
-// once per control step with lane-strided (coalesced) accesses.
+// Mapping onto CDNA4: the env's working set (body frames, spatial inertias, contact Jacobian ...) lives in LDS for the whole
+// launch.  The dof-indexed work uses the CHAIN LAYOUT: half an env -- the free root's six dofs plus one leg's serial chain --
+// per 16-lane DPP row (the root held by both rows), so that broadcasts are v_mov_b64_dpp row_newbcast, the tree recursions of
+// kinematics / RNE / CRB are row_shr / row_shl scans, and M, M + h D and the Newton Hessian are factorised as two chains in
+// lockstep (reverse L^T D L in registers, no fill-in) with one v_permlane16_swap merge at the root; sub-steps whose contacts
+// couple the two legs fall back to a dense Cholesky (one dof per lane, factor row in registers).  The pyramid rows of contact c
+// sit in lanes 4c..4c+3 with their Jacobian row in LDS, and frictionloss / joint-limit rows -- unit vectors -- are scalars of
+// their dof's lane (no Jacobian storage, no row lanes).  Reductions are DPP scans.  The persistent state is one contiguous
+// 1.3 KB record per env, read and written once per control step with lane-strided (coalesced) accesses.  
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -266,7 +267,7 @@ struct HumanoidEnv {
 //   stage A  kinematics + collision   : xmat xipos xanchor xaxis gpos gmat            (over X)
 //   stage B1 velocity / RNE           : cdofdot cvel cacc=cfrc, subtree sums over cvel (over X)
 //   stage B2 CRBA                     : crb buf M                                     (over X; M goes to registers at once)
-//   stage C  constraints + solve      : J (over cinert and X), the published Cholesky rows L
+//   stage C  constraints + solve      : J (over cinert and X), the packed factor of the dense fallback solve (U_L)
 #define NE (L::NE_)      // contact rows = lanes of the group: rows 4c .. 4c+3 belong to contact c
 #define NC (L::NC_)      // contacts kept per sub-step
 #define NV (L::NV_)      // dof width the kernel is compiled for (18 JVRC, 16 H1): sizes the Cholesky, the row products, the LDS matrices

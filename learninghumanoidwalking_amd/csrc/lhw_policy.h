@@ -1,8 +1,8 @@
-// Gaussian policy head shared by the stand-alone sampling kernel (lhw_ppo.hip) and the in-kernel policy of the persistent
-// rollout (lhw_humanoid.hip): act = mu + std * N(0,1) with a counter-based normal (Box-Muller on two uniforms keyed by
-// (seed, global env id, policy stream, step counter, action index)) and the action's log-density term.  One definition, so
-// the two rollout paths produce bit-identical actions and log-probabilities (the reference samples torch.distributions.Normal,
-// rl/policies/actor.py:160-188).
+// Gaussian policy head shared by the stand-alone sampling kernel (lhw_ppo.hip) and the fused read-out of the forward strip
+// kernel (lhw_mlp_strip.hip: the rollout's one-launch policy step): act = mu + std * N(0,1) with a counter-based normal
+// (Box-Muller on two uniforms keyed by (seed, global env id, policy stream, step counter, action index)) and the action's
+// log-density term.  One definition, so both paths produce bit-identical actions and log-probabilities (the reference samples
+// torch.distributions.Normal, rl/policies/actor.py:160-188).
 #pragma once
 #include "lhw_rng.h"
 

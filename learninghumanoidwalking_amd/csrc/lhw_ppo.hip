@@ -619,7 +619,7 @@ __global__ void gather_kernel(const int* __restrict__ idx, int B, int Rcap, int 
 // One (row, action component) per lane, 32 lanes per row (act_dim <= 32): the Box-Muller draw is ~400 instructions of float64
 // transcendentals per component, so a thread per row (12 draws in sequence, 8 blocks for a 2048-row group) left this kernel
 // latency-bound at 15 us on the rollout's critical path.  The log-density terms are summed by the row's first lane in
-// component order, as the in-kernel policy of the rollout kernel does (bit-identical log-probabilities).
+// component order, as the fused read-out of the forward strip kernel does (bit-identical log-probabilities).
 __global__ void __launch_bounds__(256) sample_kernel(const float* __restrict__ mu, int ldmu, int A, int N, const float* __restrict__ stdv,
                                                      uint64_t seed, uint32_t env_base, uint32_t counter, int deterministic,
                                                      float* __restrict__ act, float* __restrict__ logp) {
