@@ -122,6 +122,20 @@ def lib():
     return L
 
 
+_POISON = os.environ.get("LHW_POISON") == "1"
+
+
+def empty(*shape, dtype, device):
+    """torch.empty for the buffers the kernels fill -- NaN-filled under LHW_POISON=1 (debug: together with the library's 0xFF-filled
+    allocations and a -DLHW_POISON build, a kernel that reads what nobody wrote shows up as a NaN instead of as a result that
+    depends on what the allocator handed out)."""
+    import torch
+    t = torch.empty(*shape, dtype=dtype, device=device)
+    if _POISON:
+        t.fill_(float("nan"))
+    return t
+
+
 def check(rc: int):
     if rc != 0:
         raise LhwError(rc, lib().lhw_last_error().decode(errors="replace"))

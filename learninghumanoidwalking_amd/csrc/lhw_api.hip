@@ -4,6 +4,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -22,6 +23,13 @@ int lhw_fail(int code, const char* fmt, ...) {
   va_end(ap);
   g_err = buf;
   return code;
+}
+
+hipError_t lhw_malloc(void** p, size_t n) {
+  static const bool poison = getenv("LHW_POISON") && atoi(getenv("LHW_POISON")) != 0;
+  hipError_t e = hipMalloc(p, n);
+  if (e == hipSuccess && poison && n) e = hipMemset(*p, 0xFF, n);
+  return e;
 }
 
 #define HIPCHK(x)                                                                                   \
@@ -125,13 +133,13 @@ static int create_cartpole(LhwEnv* e, const LhwEnvConfig* cfg) {
   p.kp = cfg->kp ? cfg->kp[0] : 0; p.kd = cfg->kd ? cfg->kd[0] : 0;
   e->obs_dim = 5; e->act_dim = 1; e->n_terms = 4;
   const size_t N = e->n_envs;
-  HIPCHK(hipMalloc(&e->cps.d, sizeof(double) * CARTPOLE_NFIELDS * N));
+  HIPCHK(lhw_malloc(&e->cps.d, sizeof(double) * CARTPOLE_NFIELDS * N));
   HIPCHK(hipMemset(e->cps.d, 0, sizeof(double) * CARTPOLE_NFIELDS * N));
-  HIPCHK(hipMalloc(&e->cps.traj_len, sizeof(int32_t) * N));
+  HIPCHK(lhw_malloc(&e->cps.traj_len, sizeof(int32_t) * N));
   HIPCHK(hipMemset(e->cps.traj_len, 0, sizeof(int32_t) * N));
-  HIPCHK(hipMalloc(&e->cps.reset_count, sizeof(uint32_t) * N));
+  HIPCHK(lhw_malloc(&e->cps.reset_count, sizeof(uint32_t) * N));
   HIPCHK(hipMemset(e->cps.reset_count, 0, sizeof(uint32_t) * N));
-  HIPCHK(hipMalloc(&e->cps.ep_stats, sizeof(double) * 3));
+  HIPCHK(lhw_malloc(&e->cps.ep_stats, sizeof(double) * 3));
   HIPCHK(hipMemset(e->cps.ep_stats, 0, sizeof(double) * 3));
   return LHW_OK;
 }
@@ -157,9 +165,9 @@ extern "C" int lhw_env_create(const int32_t* model_i, int64_t n_model_i, const d
   else if (cfg->task == LHW_TASK_JVRC_WALK || cfg->task == LHW_TASK_H1_STAND || cfg->task == LHW_TASK_JVRC_STEP || cfg->task == LHW_TASK_H1_WALK) rc = humanoid_create(&e->hum, e->mi, e->md, cfg, &e->obs_dim, &e->act_dim, &e->n_terms);
   else rc = lhw_fail(LHW_ERR_ARG, "unknown task %d", cfg->task);
   if (rc == LHW_OK) {
-    if (hipMalloc(&e->stage_q, sizeof(double) * (size_t)e->n_envs * e->nq) != hipSuccess ||
-        hipMalloc(&e->stage_v, sizeof(double) * (size_t)e->n_envs * e->nv) != hipSuccess)
-      rc = lhw_fail(LHW_ERR_HIP, "hipMalloc(staging) failed");
+    if (lhw_malloc(&e->stage_q, sizeof(double) * (size_t)e->n_envs * e->nq) != hipSuccess ||
+        lhw_malloc(&e->stage_v, sizeof(double) * (size_t)e->n_envs * e->nv) != hipSuccess)
+      rc = lhw_fail(LHW_ERR_HIP, "lhw_malloc(staging) failed");
   }
   if (rc != LHW_OK) { lhw_env_destroy(e); return rc; }
   *out = e;

@@ -425,6 +425,16 @@ __device__ __forceinline__ double dpp_d(double v, double ident) {
 }
 // index of this lane's group inside the wavefront (0 for W = 64)
 template <int W> __device__ __forceinline__ int group_id() { return W == 64 ? 0 : (int)(threadIdx.x >> 5); }
+// Mask of the contact rows (= lanes) of ONE env's group: a 32-bit per-lane value in the two-envs-per-wave layouts (the two envs of a
+// wave iterate over their own rows side by side), the wave's 64-bit ballot with one env per wave.
+template <int W> struct RowMask { typedef unsigned long long type; };
+template <> struct RowMask<32> { typedef unsigned type; };
+template <int W> __device__ __forceinline__ typename RowMask<W>::type group_rows(unsigned long long ballot) {
+  if constexpr (W == 32) return (unsigned)(ballot >> (32 * group_id<W>()));
+  else return ballot;
+}
+__device__ __forceinline__ int first_row(unsigned m) { return __ffs(m) - 1; }
+__device__ __forceinline__ int first_row(unsigned long long m) { return __ffsll(m) - 1; }
 // value held by lane `src` (0 <= src < W, uniform) of the caller's group
 template <int W>
 __device__ __forceinline__ int gbcast_i(int v, int src) {
@@ -1575,10 +1585,10 @@ __device__ __forceinline__ void row_deriv(bool valid, double fl, double D, doubl
 // chain, carries the right-hand side through the factorisation (no separate forward substitution) and assembles the A x B
 // block from the active rows only.  Packed lower triangle of the factor in LDS (the U_L region, which the chain solver leaves
 // idle).  Hrow / hd: the chain-layout row of M + J^T D J (root + own-chain columns) as assembled for chain_solve;
-// active_rows: ballot of the rows with a non-zero D (either env of the wave).
+// active_rows: the env's rows with a non-zero D (group_rows).
 template <class L>
 __device__ __forceinline__ double dense_lds_solve(L& S, const double (&Hrow)[NR], double hd, double x, int dof, bool prim, int coff,
-                                                  unsigned long long active_rows) {
+                                                  typename RowMask<L::W_>::type active_rows) {
   double* A = S.U + U_L;
   double* xs = S.U + U_DG;
   const int d = dof >= 0 ? dof : 0;
@@ -1593,7 +1603,7 @@ __device__ __forceinline__ double dense_lds_solve(L& S, const double (&Hrow)[NR]
 #pragma unroll
     for (int c = 0; c < NCH; c++) xb[c] = 0.0;
     while (active_rows) {
-      const int r = __ffsll(active_rows) - 1;
+      const int r = first_row(active_rows);
       active_rows &= active_rows - 1;
       const double cj = S.U[U_DACT + r] * S.U[U_J + r * NV + d];
 #pragma unroll
@@ -1863,13 +1873,15 @@ __device__ __forceinline__ void solve_tail(const HModel& m, const HParams& p, L&
       double Hrow[NR], hd = mdiag + udact;
 #pragma unroll
       for (int k = 0; k < NR; k++) Hrow[k] = Mrow[k];
-      // only rows that are active (in either env of the wave: the row index must be wave-uniform) contribute
-      unsigned long long mm_all = __ballot(dactive != 0.0);
-      if constexpr (W == 32) mm_all = (mm_all | (mm_all >> 32)) & 0xffffffffull;
+      // Only the env's own active rows contribute.  The two envs of a wave walk their own row lists side by side (the row index
+      // is a per-lane value): max(|A|, |B|) trips instead of |A or B|, and no env ever touches a Jacobian row beyond its own
+      // 4 ncon -- those are never written in a sub-step and hold whatever the LDS held before (round 4: the union loop of
+      // round 3 multiplied them by D = 0, which a NaN bit pattern left by another kernel survives).
+      const typename RowMask<W>::type mm_all = group_rows<W>(__ballot(dactive != 0.0));
       {
-        unsigned long long mm = mm_all;
+        typename RowMask<W>::type mm = mm_all;
         while (mm) {      // (measured: unrolling this loop, or the J^T f loop above, is slower -- DESIGN.md section 4)
-          const int r = __ffsll(mm) - 1;
+          const int r = first_row(mm);
           mm &= mm - 1;
           const double jl = S.U[U_J + r * NV + dd], cj = S.U[U_DACT + r] * jl;
           hd += cj * jl;
@@ -2757,6 +2769,7 @@ __global__ void __launch_bounds__(64, LHW_WAVES_PER_SIMD) humanoid_kernel(const 
   using L = typename LayoutOf<TASK, W>::type;
   constexpr int G = 64 / W;   // envs per wavefront
   __shared__ L SG[G];
+  LHW_LDS_POISON(SG);
   const int lane = threadIdx.x & (W - 1);   // lane within the env's group
   const HParams& p = *pp;
   const HModel& m = *mp;
@@ -2799,7 +2812,7 @@ static void h_quat2mat(double* R, const double* q) {
 template <typename T>
 static const T* to_dev(HumanoidEnv* h, const T* src, size_t n) {
   void* d = nullptr;
-  if (hipMalloc(&d, std::max<size_t>(1, n) * sizeof(T)) != hipSuccess) return nullptr;
+  if (lhw_malloc(&d, std::max<size_t>(1, n) * sizeof(T)) != hipSuccess) return nullptr;
   if (n && hipMemcpy(d, src, n * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
   h->dev_allocs.push_back(d);
   return (const T*)d;
@@ -2808,13 +2821,13 @@ static const T* to_dev(HumanoidEnv* h, const T* src, size_t n) {
 static bool humanoid_upload_params(HumanoidEnv* h) {
   if (!h->p_dev) {
     void* d = nullptr;
-    if (hipMalloc(&d, sizeof(HParams)) != hipSuccess) return false;
+    if (lhw_malloc(&d, sizeof(HParams)) != hipSuccess) return false;
     h->dev_allocs.push_back(d);
     h->p_dev = (HParams*)d;
   }
   if (!h->m_dev) {
     void* d = nullptr;
-    if (hipMalloc(&d, sizeof(HModel)) != hipSuccess) return false;
+    if (lhw_malloc(&d, sizeof(HModel)) != hipSuccess) return false;
     h->dev_allocs.push_back(d);
     h->m_dev = (HModel*)d;
   }
@@ -3210,13 +3223,13 @@ int humanoid_create(HumanoidEnv** out, const std::vector<int32_t>& mi, const std
     ok = ok && h->st.ter != nullptr;
   }
   void *rec = nullptr, *irec = nullptr, *eps = nullptr, *slow = nullptr;
-  ok = ok && hipMalloc(&slow, N + 1) == hipSuccess && hipMemset(slow, 0, N + 1) == hipSuccess;
+  ok = ok && lhw_malloc(&slow, N + 1) == hipSuccess && hipMemset(slow, 0, N + 1) == hipSuccess;
   if (slow) h->dev_allocs.push_back(slow);
   h->st.slow = (unsigned char*)slow;
   // (one record more than envs: the reset template of the jvrc_walk kernels)
-  ok = ok && hipMalloc(&rec, sizeof(double) * REC_D * (N + 1)) == hipSuccess && hipMemset(rec, 0, sizeof(double) * REC_D * (N + 1)) == hipSuccess &&
-       hipMalloc(&irec, sizeof(int) * REC_I * (N + 1)) == hipSuccess && hipMemset(irec, 0, sizeof(int) * REC_I * (N + 1)) == hipSuccess &&
-       hipMalloc(&eps, sizeof(double) * 8) == hipSuccess && hipMemset(eps, 0, sizeof(double) * 8) == hipSuccess;
+  ok = ok && lhw_malloc(&rec, sizeof(double) * REC_D * (N + 1)) == hipSuccess && hipMemset(rec, 0, sizeof(double) * REC_D * (N + 1)) == hipSuccess &&
+       lhw_malloc(&irec, sizeof(int) * REC_I * (N + 1)) == hipSuccess && hipMemset(irec, 0, sizeof(int) * REC_I * (N + 1)) == hipSuccess &&
+       lhw_malloc(&eps, sizeof(double) * 8) == hipSuccess && hipMemset(eps, 0, sizeof(double) * 8) == hipSuccess;
   if (rec) h->dev_allocs.push_back(rec);
   if (irec) h->dev_allocs.push_back(irec);
   if (eps) h->dev_allocs.push_back(eps);
@@ -3312,7 +3325,7 @@ int humanoid_wave_cycles(HumanoidEnv* h, long long* out) {
   const size_t N = h->p.n_envs;
   if (!h->st.wave_cyc) {
     void* d = nullptr;
-    if (hipMalloc(&d, (N + 1) * sizeof(long long)) != hipSuccess) return -1;
+    if (lhw_malloc(&d, (N + 1) * sizeof(long long)) != hipSuccess) return -1;
     (void)hipMemset(d, 0, (N + 1) * sizeof(long long));
     h->dev_allocs.push_back(d);
     h->st.wave_cyc = (long long*)d;
@@ -3327,7 +3340,7 @@ int humanoid_task_inputs(HumanoidEnv* h, int enable, double* out_host, double** 
   const size_t n = (size_t)h->p.n_envs * LHW_TASK_INPUT_DIM;
   if (enable == 1 && !h->st.tin) {
     void* d = nullptr;
-    if (hipMalloc(&d, n * sizeof(double)) != hipSuccess) return -1;
+    if (lhw_malloc(&d, n * sizeof(double)) != hipSuccess) return -1;
     (void)hipMemset(d, 0, n * sizeof(double));
     h->dev_allocs.push_back(d);
     h->st.tin = (double*)d;
@@ -3345,7 +3358,7 @@ int humanoid_task_inputs(HumanoidEnv* h, int enable, double* out_host, double** 
 int humanoid_profile(HumanoidEnv* h, int enable, long long* out16) {
   if (enable && !h->st.prof) {
     void* d = nullptr;
-    if (hipMalloc(&d, 16 * sizeof(long long)) != hipSuccess) return -1;
+    if (lhw_malloc(&d, 16 * sizeof(long long)) != hipSuccess) return -1;
     (void)hipMemset(d, 0, 16 * sizeof(long long));
     h->dev_allocs.push_back(d);
     h->st.prof = (long long*)d;

@@ -9,6 +9,27 @@
 
 int lhw_fail(int code, const char* fmt, ...);
 
+// POISON MODE (debug): nothing on the GPU zero-fills LDS, and what a workgroup finds there is whatever the previous occupant
+// of the CU left -- another kernel, another process.  LHW_LDS_POISON(obj), placed right behind a __shared__ declaration,
+// fills the object with 0xFF bytes (NaN as float / double, -1 as int) in the SIMT emulator of tests/emu (always) and in a
+// -DLHW_POISON build of the GPU library (scripts/build_variant.sh), so that a read of a never-written word shows up as a NaN
+// instead of depending on the CU's history.  A no-op in the product build.
+#if defined(__HIP_EMU__)
+#define LHW_LDS_POISON(obj) emu::poison_shared((void*)&(obj), sizeof(obj))
+#elif defined(LHW_POISON)
+#define LHW_LDS_POISON(obj)                                                                                            \
+  do {                                                                                                                 \
+    unsigned* w_ = reinterpret_cast<unsigned*>(&(obj));                                                                \
+    for (unsigned i_ = threadIdx.x; i_ < sizeof(obj) / 4; i_ += blockDim.x) w_[i_] = 0xFFFFFFFFu;                      \
+    __syncthreads();                                                                                                   \
+  } while (0)
+#else
+#define LHW_LDS_POISON(obj) ((void)0)
+#endif
+// device allocations of the library: 0xFF-filled when LHW_POISON=1 is set in the environment (hipMalloc does not zero either)
+hipError_t lhw_malloc(void** p, size_t n);
+template <class T> static inline hipError_t lhw_malloc(T** p, size_t n) { return lhw_malloc((void**)p, n); }
+
 struct HumanoidEnv;
 int humanoid_create(HumanoidEnv** out, const std::vector<int32_t>& mi, const std::vector<double>& md, const LhwEnvConfig* cfg,
                     int* obs_dim, int* act_dim, int* n_terms);

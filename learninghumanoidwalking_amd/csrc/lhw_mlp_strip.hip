@@ -199,6 +199,7 @@ __device__ __forceinline__ void stage_input(float (*X)[C::LD], const float* __re
 template <class C>
 __global__ void __launch_bounds__(C::THR, 2) mlp_fwd_strip_kernel(MlpStripFwd a) {
   __shared__ StripLds<C> L;
+  LHW_LDS_POISON(L);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, kh = lane >> 5;
   const int row0 = (int)blockIdx.x * C::ROWS;
@@ -278,6 +279,7 @@ __global__ void __launch_bounds__(C::THR, 2) mlp_fwd_strip_kernel(MlpStripFwd a)
 template <class C>
 __global__ void __launch_bounds__(C::THR, 2) mlp_bwd_strip_kernel(MlpStripBwd a) {
   __shared__ StripLds<C> L;
+  LHW_LDS_POISON(L);
   const int row0 = (int)blockIdx.x * C::ROWS;
   float (*X)[C::LD] = &L.S[SH - SXK];
   WOp<C> w;
@@ -302,6 +304,7 @@ struct TransposeJob { const float* W; float* WT; int rows, cols, ld, ldt, first;
 struct TransposeJobs { TransposeJob j[3]; };
 __global__ void __launch_bounds__(256) transpose3_kernel(TransposeJobs J) {
   __shared__ float T[32][33];
+  LHW_LDS_POISON(T);
   const int b = (int)blockIdx.x, m = b >= J.j[2].first ? 2 : (b >= J.j[1].first ? 1 : 0);
   const TransposeJob q = J.j[m];
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8

@@ -59,7 +59,9 @@ template <bool A_KC, bool B_KC, int WT>
 __global__ void __launch_bounds__(256) gemm_f32_kernel(GemmArgs g) {
   constexpr int TM = 64 * WT, LD = TM + 4;
   __shared__ float As[2][BK][LD];
+  LHW_LDS_POISON(As);
   __shared__ float Bs[2][BK][LD];
+  LHW_LDS_POISON(Bs);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave & 1, wn = wave >> 1;
   // XCD-aware block order.  Workgroups are dealt round-robin to the 8 XCDs, each with its own L2, so XCD x takes the contiguous
@@ -206,8 +208,11 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 template <bool A_KC, bool B_KC>
 __global__ void __launch_bounds__(256) gemm_f16_kernel(GemmArgs g) {
   __shared__ _Float16 Ah[2][BM][HLD];
+  LHW_LDS_POISON(Ah);
   __shared__ _Float16 Bh[2][BN][HLD];
+  LHW_LDS_POISON(Bh);
   __shared__ float red[256];
+  LHW_LDS_POISON(red);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave & 1, wn = wave >> 1;
   const int per = (int)gridDim.x >> 3, v = ((int)blockIdx.x & 7) * per + ((int)blockIdx.x >> 3);   // XCD-aware order (gemm_f32_kernel)
@@ -319,6 +324,7 @@ __global__ void __launch_bounds__(256) reduce_slices_kernel(const float* __restr
 #define COLSUM_CHUNKS 128
 __global__ void __launch_bounds__(256) colsum_det_kernel(const float* __restrict__ X, int rows, int ld, int ncols, float* __restrict__ part) {
   __shared__ float red[4][64];
+  LHW_LDS_POISON(red);
   const int c = blockIdx.x * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6;
   const int per = (rows + COLSUM_CHUNKS - 1) / COLSUM_CHUNKS, r0 = blockIdx.y * per, r1 = min(rows, r0 + per);
   float s = 0.f;
@@ -344,6 +350,7 @@ struct SegList { Seg s[MAX_SEGS]; int first[MAX_SEGS + 1]; int n; float scale; }
 __global__ void __launch_bounds__(256) reduce_segments_kernel(SegList L) {
   // block = 64 consecutive elements of one segment x 4 slice ranges; the four partial sums are combined in a fixed order
   __shared__ float red[4][64];
+  LHW_LDS_POISON(red);
   const int e0 = blockIdx.x * 64;
   int k = 0;
   while (e0 >= L.first[k + 1]) k++;
@@ -624,6 +631,7 @@ __global__ void __launch_bounds__(256) sample_kernel(const float* __restrict__ m
                                                      uint64_t seed, uint32_t env_base, uint32_t counter, int deterministic,
                                                      float* __restrict__ act, float* __restrict__ logp) {
   __shared__ float terms[8][32];
+  LHW_LDS_POISON(terms);
   const int r = threadIdx.x >> 5, a = threadIdx.x & 31, n = blockIdx.x * 8 + r;
   if (n < N && a < A) {
     float term;
@@ -666,6 +674,7 @@ __global__ void __launch_bounds__(256) ppo_loss_kernel(int B, int Rcap, int A, i
   float s_actor = 0, s_critic = 0, s_mirror = 0, s_kl = 0, s_cf = 0, s_imit = 0;
   const float invB = 1.f / (float)B, invBA = 1.f / ((float)B * (float)A);
   __shared__ float red[NSTAT][4];
+  LHW_LDS_POISON(red);
   if (m < B) {
     float lp = 0.f;
     for (int a = 0; a < A; a++) {
@@ -749,6 +758,7 @@ __global__ void __launch_bounds__(256) sumsq_kernel(const float* __restrict__ g,
   }
   for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
   __shared__ float red[4];
+  LHW_LDS_POISON(red);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
   if (threadIdx.x == 0) part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
@@ -816,6 +826,7 @@ __global__ void __launch_bounds__(256) moments_kernel(const float* __restrict__ 
   }
   for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o); s2 += __shfl_xor(s2, o); }
   __shared__ double red[2][4];
+  LHW_LDS_POISON(red);
   if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s; red[1][threadIdx.x >> 6] = s2; }
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -885,7 +896,7 @@ extern "C" int lhw_ppo_create(const LhwPpoConfig* c, LhwPpo** out) {
   p->off_critic = p->off_std + pad4(p->A);
   p->n_params = p->off_critic + p->lc.total;
   const size_t R = p->max_rows, Dp = p->la.Dp, H = p->H, Op = p->la.Op;
-  auto alloc = [&](float** ptr, size_t n) { return hipMalloc(ptr, sizeof(float) * n) == hipSuccess && hipMemset(*ptr, 0, sizeof(float) * n) == hipSuccess; };
+  auto alloc = [&](float** ptr, size_t n) { return lhw_malloc(ptr, sizeof(float) * n) == hipSuccess && hipMemset(*ptr, 0, sizeof(float) * n) == hipSuccess; };
   bool ok = alloc(&p->xb, 2 * R * Dp) && alloc(&p->h1a, 2 * R * H) && alloc(&p->h2a, 2 * R * H) && alloc(&p->ya, 2 * R * Op) &&
             alloc(&p->h1c, R * H) && alloc(&p->h2c, R * H) && alloc(&p->yc, R * 4) && alloc(&p->dya, 2 * R * Op) &&
             alloc(&p->dh2a, 2 * R * H) && alloc(&p->dh1a, 2 * R * H) && alloc(&p->dyc, R * 4) && alloc(&p->dh2c, R * H) &&
@@ -905,8 +916,8 @@ extern "C" int lhw_ppo_create(const LhwPpoConfig* c, LhwPpo** out) {
     for (int j = 0; j < p->A; j++) { asrc[j] = c->mirror_act_src[j]; asgn[j] = c->mirror_act_sign[j]; }
     for (int j = 0; j < p->D; j++) if (osrc[j] < 0 || osrc[j] >= p->D) { ok = false; }
     for (int j = 0; j < p->A; j++) if (asrc[j] < 0 || asrc[j] >= p->A) { ok = false; }
-    ok = ok && hipMalloc(&p->d_obs_src, sizeof(int) * Dp) == hipSuccess && hipMalloc(&p->d_act_src, sizeof(int) * p->A) == hipSuccess &&
-         hipMalloc(&p->d_obs_sign, sizeof(float) * Dp) == hipSuccess && hipMalloc(&p->d_act_sign, sizeof(float) * p->A) == hipSuccess;
+    ok = ok && lhw_malloc(&p->d_obs_src, sizeof(int) * Dp) == hipSuccess && lhw_malloc(&p->d_act_src, sizeof(int) * p->A) == hipSuccess &&
+         lhw_malloc(&p->d_obs_sign, sizeof(float) * Dp) == hipSuccess && lhw_malloc(&p->d_act_sign, sizeof(float) * p->A) == hipSuccess;
     if (ok) {
       (void)hipMemcpy(p->d_obs_src, osrc.data(), sizeof(int) * Dp, hipMemcpyHostToDevice);
       (void)hipMemcpy(p->d_act_src, asrc.data(), sizeof(int) * p->A, hipMemcpyHostToDevice);
@@ -1084,7 +1095,7 @@ extern "C" int lhw_moments(const float* x, int64_t n, double* out2_dev, void* st
   double* scratch;
   {
     std::lock_guard<std::mutex> lock(mu);
-    if (!scratch_of[dev]) HIPCHK(hipMalloc(&scratch_of[dev], sizeof(double) * 2 * MOM_BLOCKS));
+    if (!scratch_of[dev]) HIPCHK(lhw_malloc(&scratch_of[dev], sizeof(double) * 2 * MOM_BLOCKS));
     scratch = scratch_of[dev];
   }
   hipLaunchKernelGGL(moments_kernel, dim3(MOM_BLOCKS), dim3(256), 0, (hipStream_t)stream, x, (size_t)n, scratch);
@@ -1463,7 +1474,7 @@ extern "C" int lhw_rnn_create(const LhwPpoConfig* c, int32_t seq_len, int32_t se
   bool ok = true;
   auto alloc = [&](auto** ptr, size_t n) {
     void* d = nullptr;
-    if (!ok || hipMalloc(&d, sizeof(**ptr) * std::max<size_t>(n, 1)) != hipSuccess || hipMemset(d, 0, sizeof(**ptr) * std::max<size_t>(n, 1)) != hipSuccess) { ok = false; return; }
+    if (!ok || lhw_malloc(&d, sizeof(**ptr) * std::max<size_t>(n, 1)) != hipSuccess || hipMemset(d, 0, sizeof(**ptr) * std::max<size_t>(n, 1)) != hipSuccess) { ok = false; return; }
     p->allocs.push_back(d);
     *ptr = (decltype(*ptr))d;
   };

@@ -19,7 +19,7 @@ from pathlib import Path
 import numpy as np
 import torch
 
-from . import dist_utils
+from . import _lib, dist_utils
 from .ppo_kernels import PpoKernels, reference_init
 
 
@@ -512,7 +512,7 @@ class PPO:
     def _float32_log_probs(self, obs_flat, act_flat):
         k = self.kernels
         sd = k.get_tensors()["stds"].to(self.device)
-        out = torch.empty(obs_flat.shape[0], dtype=torch.float32, device=self.device)
+        out = _lib.empty(obs_flat.shape[0], dtype=torch.float32, device=self.device)
         k.set_inference_fp16(False)
         try:
             chunk = int(k.max_rows)

@@ -141,11 +141,11 @@ class RnnKernels:
                 want_value=True, mu=None, act=None, logp=None, value=None):
         N, dev = obs.shape[0], self.device
         if want_actor:
-            mu = torch.empty(N, self.act_dim, dtype=torch.float32, device=dev) if mu is None else mu
-            act = torch.empty(N, self.act_dim, dtype=torch.float32, device=dev) if act is None else act
-            logp = torch.empty(N, dtype=torch.float32, device=dev) if logp is None else logp
+            mu = _lib.empty(N, self.act_dim, dtype=torch.float32, device=dev) if mu is None else mu
+            act = _lib.empty(N, self.act_dim, dtype=torch.float32, device=dev) if act is None else act
+            logp = _lib.empty(N, dtype=torch.float32, device=dev) if logp is None else logp
         if want_value:
-            value = torch.empty(N, dtype=torch.float32, device=dev) if value is None else value
+            value = _lib.empty(N, dtype=torch.float32, device=dev) if value is None else value
         _lib.check(self._L.lhw_rnn_forward(self._h, _p(self.theta), _p(obs), N, _p(self.obs_mean), _p(self.obs_std), _p(reset),
                                            int(seed) & (2**64 - 1), int(env_id_base), int(counter), int(deterministic), int(commit),
                                            _p(mu) if want_actor else None, _p(act) if want_actor else None,
@@ -155,15 +155,15 @@ class RnnKernels:
     def normalize(self, obs, want_mirror=None):
         R = obs.shape[0]
         want_mirror = self.use_mirror if want_mirror is None else want_mirror
-        xn = torch.empty(R, self.Dp, dtype=torch.float32, device=self.device)
-        xm = torch.empty(R, self.Dp, dtype=torch.float32, device=self.device) if want_mirror else None
+        xn = _lib.empty(R, self.Dp, dtype=torch.float32, device=self.device)
+        xm = _lib.empty(R, self.Dp, dtype=torch.float32, device=self.device) if want_mirror else None
         _lib.check(self._L.lhw_rnn_normalize(self._h, _p(obs), R, _p(self.obs_mean), _p(self.obs_std), _p(xn), _p(xm), self._stream()))
         return xn, xm
 
     def gae(self, rew, val, done, vterm, vfinal, gamma, lam):
         T, N = rew.shape
-        ret = torch.empty(T, N, dtype=torch.float32, device=self.device)
-        adv = torch.empty(T, N, dtype=torch.float32, device=self.device)
+        ret = _lib.empty(T, N, dtype=torch.float32, device=self.device)
+        adv = _lib.empty(T, N, dtype=torch.float32, device=self.device)
         _lib.check(self._L.lhw_gae(T, N, _p(rew), _p(val), _p(done), _p(vterm), _p(vfinal), float(gamma), float(lam), _p(ret), _p(adv),
                                    self._stream()))
         return ret, adv

@@ -14,6 +14,27 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+# Collection order of the suite (the driver runs it with -x): kernel-vs-oracle parity first, in-process integration next, and the
+# tests that spawn processes (entry point, RCCL branch, the two-rank data-parallel run) last -- one integration flake must not hide
+# the parity results of every kernel behind it (round 3: test_distributed_gpu.py, second file in alphabetical order, failed and
+# 112 parity tests never ran).
+_ORDER = ["test_cartpole_gpu", "test_jvrc_gpu", "test_h1_gpu", "test_h1_walk_gpu", "test_jvrc_step_gpu", "test_model_variants_gpu",
+          "test_task_inputs_gpu", "test_obs_history_gpu", "test_gemm_gpu", "test_mlp_strip_gpu", "test_ppo_gpu", "test_rnn_gpu",
+          "test_errors_gpu", "test_fullsize_gpu", "test_freerun_gpu", "test_iteration_gpu"]
+_LAST = ["test_reference_configs", "test_entry_gpu", "test_distributed_gpu"]
+
+
+def pytest_collection_modifyitems(session, config, items):
+    def key(item):
+        mod = os.path.splitext(os.path.basename(str(item.fspath)))[0]
+        if mod in _ORDER:
+            return (0, _ORDER.index(mod))
+        if mod in _LAST:
+            return (2, _LAST.index(mod))
+        return (1, 0)
+    items.sort(key=key)      # (stable: the order inside a file, and of files not listed, is kept)
+
+
 @pytest.fixture(scope="session")
 def have_reference():
     return os.path.isdir(os.path.join(REFERENCE, "rl"))

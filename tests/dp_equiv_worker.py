@@ -1,8 +1,13 @@
-"""Worker of tests/test_distributed_gpu.py: two PPO iterations of jvrc_walk, either as one rank of a data-parallel job
+"""Worker of tests/test_distributed_gpu.py: PPO iterations of jvrc_walk, either as one rank of a data-parallel job
 (`--mode ranks`, N envs per rank, launched with torch.distributed.run) or as ONE process holding the union of the ranks' envs
 (`--mode union`, world x N envs) with the ranks' minibatches merged -- the single-process semantics the data-parallel run has
 to reproduce (reference rl/algos/ppo.py:393-394 gradient clipping on the whole minibatch, :484-485 advantage statistics of the
-whole batch).  Writes the final flat parameter vector (rank 0)."""
+whole batch).
+
+Every process writes `<out>.rank<r>.npz` (the union: rank 0) with, per iteration i: the rollout (`obs_i act_i logp_i rew_i done_i`,
+time-major), `ret_i` and the normalised `adv_i`, the first minibatch's gradient before and after the all-reduce (`g0_i`, `g1_i`,
+already multiplied by 1 / world) and the weights after the iteration (`theta_i`) -- so that a mismatch can be localised to the
+stage where it first appears instead of being read off the final weights."""
 import argparse
 import os
 import sys
@@ -21,6 +26,7 @@ ap.add_argument("--envs", type=int, default=64)
 ap.add_argument("--traj", type=int, default=32)
 ap.add_argument("--mb", type=int, default=512)
 ap.add_argument("--iters", type=int, default=2)
+ap.add_argument("--backend", default="gloo")
 ap.add_argument("--out", required=True)
 a = ap.parse_args()
 
@@ -29,7 +35,8 @@ world = int(os.environ.get("WORLD_SIZE", 1))
 if a.mode == "ranks":
     assert world == a.world
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    dist.init_process_group("gloo")      # both ranks share GPU 0 on the 1-GPU test box (LHW_SHARE_GPU semantics)
+    dist.init_process_group(a.backend)      # both ranks share GPU 0 on the 1-GPU test box (LHW_SHARE_GPU semantics)
+from learninghumanoidwalking_amd import dist_utils
 from learninghumanoidwalking_amd.envs import ENVIRONMENTS
 from learninghumanoidwalking_amd.ppo import PPO
 
@@ -54,9 +61,47 @@ if union:
         return torch.cat(parts, dim=1).reshape(-1).to(torch.int32)
 
     PPO._minibatch_perm = union_perm
+
+rank = dist.get_rank() if dist.is_initialized() else 0
+dump = {}
+state = {"itr": 0, "first": True}
+orig_allreduce = dist_utils.allreduce_grad_
+
+
+def traced_allreduce(flat_grad):
+    if state["first"]:
+        dump[f"g0_{state['itr']}"] = flat_grad.detach().cpu().numpy().copy()
+    scale = orig_allreduce(flat_grad)
+    if state["first"]:
+        dump[f"g1_{state['itr']}"] = flat_grad.detach().cpu().numpy() * np.float32(scale)
+        state["first"] = False
+    return scale
+
+
+dist_utils.allreduce_grad_ = traced_allreduce
+orig_optimize = algo.optimize
+
+
+def traced_optimize(itr):
+    ro = algo.rollout
+    T = ro.T
+    torch.cuda.synchronize()
+    for name, t in (("obs", ro.obs[:T]), ("act", ro.act), ("logp", ro.logp), ("rew", ro.rew), ("done", ro.done), ("ret", algo._ret)):
+        dump[f"{name}_{itr}"] = t.detach().cpu().numpy().copy()
+    state["itr"], state["first"] = itr, True
+    out = orig_optimize(itr)
+    torch.cuda.synchronize()
+    dump[f"adv_{itr}"] = algo._adv.detach().cpu().numpy().copy()      # normalised in place by optimize()
+    dump[f"theta_{itr}"] = algo.kernels.theta.detach().cpu().numpy().copy()
+    return out
+
+
+algo.optimize = traced_optimize
 for i in range(a.iters):
     algo.iterate(i)
-if (dist.get_rank() if dist.is_initialized() else 0) == 0:
-    np.save(a.out, algo.kernels.theta.detach().cpu().numpy())
+faults = algo.env.pop_fault_stats() if hasattr(algo.env, "pop_fault_stats") else (0, 0)
+dump["faults"] = np.asarray(faults, np.int64)          # (contact overflows, diverged envs): both must be 0
+np.savez(f"{a.out}.rank{rank}.npz", **dump)
 if dist.is_initialized():
+    dist.barrier()
     dist.destroy_process_group()

@@ -28,6 +28,7 @@ emu_switch:
 )");
 
 static const size_t STACK = 1024 * 1024;
+static const size_t POISON_STACK = 96 * 1024;
 
 static void trampoline() {
   Block* b = g_blk;
@@ -166,9 +167,11 @@ void run_block(Block& b) {
   static const bool reverse = getenv("LHW_EMU_REVERSE") && atoi(getenv("LHW_EMU_REVERSE"));
   Block* outer = g_blk;
   g_blk = &b;
+  b.poisoned.clear();
   for (int i = 0; i < n; i++) {
     Lane& l = b.lanes[i];
     if (!l.stack) l.stack = (char*)malloc(STACK);
+    if (poison_on()) memset(l.stack + STACK - POISON_STACK, 0xFF, POISON_STACK);   // the part of the stack a kernel's locals live in
     l.tid = dim3(i);
     l.state = RUNNABLE;
     l.op = OP_NONE;

@@ -46,7 +46,18 @@ typedef int hipError_t;
 enum { hipSuccess = 0, hipErrorUnknown = 999 };
 enum hipMemcpyKind { hipMemcpyHostToHost, hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice, hipMemcpyDefault };
 
-static inline hipError_t hipMalloc(void** p, size_t n) { *p = calloc(1, n ? n : 1); return *p ? hipSuccess : hipErrorUnknown; }
+// POISON MODE (default on; LHW_EMU_POISON=0 turns it off): device allocations, every __shared__ object a kernel declares
+// (through LHW_LDS_POISON in the kernel source) and the lanes' stacks (the "scratch" of uninitialised local arrays) are filled
+// with 0xFF bytes -- a NaN as float and as double, -1 as an integer -- before use, as nothing on the GPU zero-fills them.  A
+// kernel that reads a word it never wrote then produces NaNs / wild indices here instead of silently reading a zero.
+namespace emu {
+static inline bool poison_on() { static const bool on = !(getenv("LHW_EMU_POISON") && atoi(getenv("LHW_EMU_POISON")) == 0); return on; }
+}
+static inline hipError_t hipMalloc(void** p, size_t n) {
+  *p = malloc(n ? n : 1);
+  if (*p) memset(*p, emu::poison_on() ? 0xFF : 0, n ? n : 1);
+  return *p ? hipSuccess : hipErrorUnknown;
+}
 template <class T> static inline hipError_t hipMalloc(T** p, size_t n) { return hipMalloc((void**)p, n); }
 static inline hipError_t hipFree(void* p) { free(p); return hipSuccess; }
 static inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { memcpy(d, s, n); return hipSuccess; }
@@ -84,12 +95,20 @@ struct Block {
   dim3 bid, bdim, gdim;
   std::function<void()> body;
   std::vector<float> mfma;       // per wave [2][64]
+  std::vector<void*> poisoned;   // __shared__ objects already poisoned for the running workgroup
 };
 extern Block* g_blk;
 extern "C" void emu_switch(void** from_sp, void* to_sp);
 void run_block(Block& b);
 void block_here();   // current lane yields to the scheduler (state/op already set)
 inline Lane& cur() { return g_blk->lanes[g_blk->cur]; }
+// first lane of the workgroup to reach the declaration fills the object (the other fibers have not started yet or find it listed)
+inline void poison_shared(void* p, size_t n) {
+  if (!poison_on()) return;
+  for (void* q : g_blk->poisoned) if (q == p) return;
+  g_blk->poisoned.push_back(p);
+  memset(p, 0xFF, n);
+}
 
 template <class K, class... A>
 void launch(K kernel, dim3 grid, dim3 block, A... args) {
