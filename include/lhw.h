@@ -269,6 +269,14 @@ int lhw_ppo_normalize(LhwPpo* ppo, const float* obs, int64_t R, const float* obs
 int lhw_ppo_forward(LhwPpo* ppo, const float* theta, const float* obs, int64_t N, const float* obs_mean,
                     const float* obs_std, uint64_t seed, uint32_t env_id_base, uint32_t counter, int deterministic,
                     float* mu, float* act, float* logp, float* value, void* stream);
+/* Rollout bracket.  theta does not change while a rollout is collected (the reference's workers hold a frozen copy of the policy,
+ * rl/workers/rollout_worker.py:62-77 sync_policy), so the [in][out] weight copies the forward strip kernel multiplies by are made
+ * ONCE here (on `stream`; streams that issue forwards afterwards must be ordered behind it) instead of in every policy step.
+ * Until lhw_ppo_end_rollout -- or lhw_ppo_apply, which changes theta -- every lhw_ppo_forward / _forward_at call with this theta
+ * pointer reads those copies (read-only: any number of concurrent calls on any streams).  Outside a bracket each call makes
+ * its own copies, as before. */
+int lhw_ppo_begin_rollout(LhwPpo* ppo, const float* theta, void* stream);
+int lhw_ppo_end_rollout(LhwPpo* ppo);
 /* lhw_ppo_forward on workspace rows [ws_row, ws_row + N): calls issued on different streams for disjoint env groups may run
  * concurrently (env_id_base must be the global id of the group's first env) */
 int lhw_ppo_forward_at(LhwPpo* ppo, const float* theta, const float* obs, int64_t N, const float* obs_mean,
@@ -288,6 +296,10 @@ int lhw_gae(int32_t T, int32_t N, const float* rew, const float* val, const uint
             const float* vfinal, double gamma, double lam, float* ret, float* adv, void* stream);
 int lhw_moments(const float* x, int64_t n, double* out2_dev, void* stream);
 int lhw_scale_shift(float* x, int64_t n, float mean, float inv_scale, void* stream);
+/* x <- (x - mean) / (std + eps), mean and UNBIASED std taken on the device from stats3_dev = {sum, sum of squares, count} (float64;
+ * e.g. lhw_moments' output with the count appended, summed over ranks by an all-reduce): the advantage normalisation of
+ * rl/algos/ppo.py:484-485 over the global batch without a device -> host round trip */
+int lhw_standardize(float* x, int64_t n, const double* stats3_dev, double eps, void* stream);
 /* Imitation term of the NEXT lhw_ppo_grad call (reference rl/algos/ppo.py:360-368, rl/algos/imitation.py): the host
  * evaluates env.imitation_projector() and the frozen expert policy, and passes the expert means scattered into a dense
  * [B][act_dim] target with a [B][act_dim] 0/1 mask (minibatch row order), the coefficient and the number of selected

@@ -455,6 +455,8 @@ struct LhwPpo {
   float *wt_a = nullptr, *wt_c = nullptr;   // [in][out] weight copies for the strip kernels (hidden width 256 only): the update's
   float *wt_inf = nullptr;                  // ... and WT_SLOTS pairs (actor, critic) for rollout inference, one per eighth of the
                                             // forward workspace, so that concurrent calls (disjoint row ranges, different streams) do not share one
+  float *wt_roll = nullptr;                 // ... and the pair made once per rollout by lhw_ppo_begin_rollout (read-only until end_rollout / apply)
+  const float* roll_theta = nullptr;        // theta the wt_roll copies were made from (NULL: no rollout bracket open)
   float *stats_part = nullptr; // per-block loss partials [blocks][NSTAT]
   const float* imit_target = nullptr;          // imitation term of the NEXT lhw_ppo_grad call (lhw_ppo_set_imitation)
   const unsigned char* imit_mask = nullptr;
@@ -485,9 +487,9 @@ static int strip_mode() {
   return m;
 }
 static void mlp_forward(const MlpLayout& L, const float* theta, const float* x, int ldx, int R, float* h1, float* h2,
-                        float* y, hipStream_t s, int half = 0, float* strip_wt = nullptr) {
+                        float* y, hipStream_t s, int half = 0, float* strip_wt = nullptr, bool wt_ready = false) {
   if (strip_wt && !half && mlp_strip_supported(L.H, L.Dp, L.O, L.Op)) {   // one launch, h1 / h2 stay in LDS between the layers
-    mlp_strip_prepare(theta + L.w1, theta + L.w2, theta + L.w3, L.Dp, L.O, L.Op, strip_wt, s);   // [in][out] copies of the weights
+    if (!wt_ready) mlp_strip_prepare(theta + L.w1, theta + L.w2, theta + L.w3, L.Dp, L.O, L.Op, strip_wt, s);   // [in][out] copies of the weights
     MlpStripFwd a{strip_wt, theta + L.b1, strip_wt + (size_t)L.Dp * L.H, theta + L.b2, strip_wt + (size_t)L.Dp * L.H + (size_t)L.H * L.H,
                   theta + L.b3, x, ldx, L.Dp, L.O, L.Op, R, h1, h2, y};
     mlp_strip_forward(a, s);
@@ -846,6 +848,16 @@ __global__ void scale_shift_kernel(float* __restrict__ x, size_t n, float mean, 
   if (i < n) x[i] = (x[i] - mean) * inv;
 }
 
+// x <- (x - mean) / (std + eps) with mean / UNBIASED std formed on the device from (sum, sum of squares, count) -- the same double
+// arithmetic, rounded to float32 at the same point, as the host path of lhw_scale_shift's callers (global_mean_std)
+__global__ void standardize_kernel(float* __restrict__ x, size_t n, const double* __restrict__ st, double eps) {
+  const double cnt = st[2], mean = st[0] / cnt;
+  const double var = fmax(0.0, (st[1] - cnt * mean * mean) / fmax(1.0, cnt - 1.0));
+  const float mean_f = (float)mean, inv_f = (float)(1.0 / (sqrt(var) + eps));
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) x[i] = (x[i] - mean_f) * inv_f;
+}
+
 // ------------------------------------------------------------------------------------------- C ABI
 // Test / tuning hook: one GEMM of the update path on caller-provided device buffers (see include/lhw.h).
 extern "C" int lhw_debug_gemm(int32_t a_kc, int32_t b_kc, int32_t wt, int32_t M, int32_t N, int32_t K, const float* A, int32_t lda,
@@ -908,7 +920,8 @@ extern "C" int lhw_ppo_create(const LhwPpoConfig* c, LhwPpo** out) {
   ok = ok && alloc(&p->bwd_part, bwd_parts_floats(p->la, R, 2) + bwd_parts_floats(p->lc, R, 1));
   if (mlp_strip_supported(p->la.H, p->la.Dp, p->la.O, p->la.Op)) ok = ok && alloc(&p->wt_a, mlp_strip_wt_floats(p->la.Dp, p->la.Op));
   if (mlp_strip_supported(p->lc.H, p->lc.Dp, p->lc.O, p->lc.Op)) ok = ok && alloc(&p->wt_c, mlp_strip_wt_floats(p->lc.Dp, p->lc.Op));
-  if (p->wt_a && p->wt_c) ok = ok && alloc(&p->wt_inf, WT_SLOTS * (mlp_strip_wt_floats(p->la.Dp, p->la.Op) + mlp_strip_wt_floats(p->lc.Dp, p->lc.Op)));
+  if (p->wt_a && p->wt_c) ok = ok && alloc(&p->wt_inf, WT_SLOTS * (mlp_strip_wt_floats(p->la.Dp, p->la.Op) + mlp_strip_wt_floats(p->lc.Dp, p->lc.Op))) &&
+                               alloc(&p->wt_roll, mlp_strip_wt_floats(p->la.Dp, p->la.Op) + mlp_strip_wt_floats(p->lc.Dp, p->lc.Op));
   if (ok && p->use_mirror) {
     std::vector<int> osrc(Dp, 0), asrc(p->A, 0);
     std::vector<float> osgn(Dp, 0.f), asgn(p->A, 0.f);
@@ -942,7 +955,7 @@ extern "C" int lhw_ppo_destroy(LhwPpo* p) {
   (void)hipSetDevice(p->device);
   float* bufs[] = {p->xb, p->h1a, p->h2a, p->ya, p->h1c, p->h2c, p->yc, p->dya, p->dh2a, p->dh1a, p->dyc, p->dh2c, p->dh1c,
                    p->mb_act, p->mb_logp, p->mb_adv, p->mb_ret, p->stats, p->d_obs_sign, p->d_act_sign, p->part, p->dstd, p->stats_part,
-                   p->norm_part, p->bwd_part, p->wt_a, p->wt_c, p->wt_inf};
+                   p->norm_part, p->bwd_part, p->wt_a, p->wt_c, p->wt_inf, p->wt_roll};
   for (float* b : bufs) if (b) (void)hipFree(b);
   if (p->d_obs_src) (void)hipFree(p->d_obs_src);
   if (p->d_act_src) (void)hipFree(p->d_act_src);
@@ -1008,18 +1021,21 @@ static int ppo_forward_impl(LhwPpo* p, const float* theta, const float* obs, int
   float *h1c = p->h1c + r0 * H, *h2c = p->h2c + r0 * H, *yc = p->yc + r0 * 4;
   size_t n = (size_t)N * Dp;
   float *wta = nullptr, *wtc = nullptr;   // this call's weight copies for the strip kernel
+  const bool wt_ready = p->roll_theta != nullptr && p->roll_theta == theta;   // inside a rollout bracket: made once by lhw_ppo_begin_rollout
   if (strip_mode() >= 2 && p->wt_inf) {
     const size_t fa = mlp_strip_wt_floats(p->la.Dp, p->la.Op), fc = mlp_strip_wt_floats(p->lc.Dp, p->lc.Op);
-    wta = p->wt_inf + (size_t)(ws_row * WT_SLOTS / p->max_rows) * (fa + fc);
+    wta = wt_ready ? p->wt_roll : p->wt_inf + (size_t)(ws_row * WT_SLOTS / p->max_rows) * (fa + fc);
     wtc = wta + fa;
   }
   // the rollout's policy step (actions + log-densities only) as ONE strip launch: observation normalisation on the way into the
   // slab, the three layers, the Gaussian head on the read-out -- instead of normalise / forward / sample launches
-  const bool fused = act && logp && !mu && !value && wta && !p->infer_half && mlp_strip_supported(p->la.H, p->la.Dp, p->la.O, p->la.Op);
+  // (the fused staging reads RAW observation rows of width obs_dim: without the normalisation vectors it would have to copy rows
+  // of width Dp, which the caller's buffer does not have -- those calls take the three-launch path)
+  const bool fused = act && logp && !mu && !value && wta && obs_mean && obs_std && !p->infer_half && mlp_strip_supported(p->la.H, p->la.Dp, p->la.O, p->la.Op);
   if (fused) {
     const MlpLayout& La = p->la;
     const float* th = theta + p->off_actor;
-    mlp_strip_prepare(th + La.w1, th + La.w2, th + La.w3, La.Dp, La.O, La.Op, wta, s);
+    if (!wt_ready) mlp_strip_prepare(th + La.w1, th + La.w2, th + La.w3, La.Dp, La.O, La.Op, wta, s);
     MlpStripFwd a{wta, th + La.b1, wta + (size_t)La.Dp * La.H, th + La.b2, wta + (size_t)La.Dp * La.H + (size_t)La.H * La.H, th + La.b3,
                   obs, p->D, La.Dp, La.O, La.Op, (int)N, h1a, h2a, ya};
     a.in_mean = obs_mean; a.in_std = obs_std; a.in_dim = p->D;
@@ -1032,7 +1048,7 @@ static int ppo_forward_impl(LhwPpo* p, const float* theta, const float* obs, int
   hipLaunchKernelGGL(normalize_kernel, dim3((n + 255) / 256), dim3(256), 0, s, obs, p->D, p->la.Dp, (size_t)N, obs_mean, obs_std,
                      xb, (float*)nullptr, (const int*)nullptr, (const float*)nullptr);
   if (act || mu) {
-    mlp_forward(p->la, theta + p->off_actor, xb, p->la.Dp, (int)N, h1a, h2a, ya, s, p->infer_half, wta);
+    mlp_forward(p->la, theta + p->off_actor, xb, p->la.Dp, (int)N, h1a, h2a, ya, s, p->infer_half, wta, wt_ready);
     if (mu) HIPCHK(hipMemcpy2DAsync(mu, sizeof(float) * p->A, ya, sizeof(float) * p->la.Op, sizeof(float) * p->A, N, hipMemcpyDeviceToDevice, s));
     if (act) {
       if (!logp) return lhw_fail(LHW_ERR_ARG, "logp required with act");
@@ -1041,10 +1057,30 @@ static int ppo_forward_impl(LhwPpo* p, const float* theta, const float* obs, int
     }
   }
   if (value) {
-    mlp_forward(p->lc, theta + p->off_critic, xb, p->la.Dp, (int)N, h1c, h2c, yc, s, p->infer_half, wtc);
+    mlp_forward(p->lc, theta + p->off_critic, xb, p->la.Dp, (int)N, h1c, h2c, yc, s, p->infer_half, wtc, wt_ready);
     HIPCHK(hipMemcpy2DAsync(value, sizeof(float), yc, sizeof(float) * 4, sizeof(float), N, hipMemcpyDeviceToDevice, s));
   }
   HIPCHK(hipGetLastError());
+  return LHW_OK;
+}
+
+extern "C" int lhw_ppo_begin_rollout(LhwPpo* p, const float* theta, void* stream) {
+  if (!p || !theta) return lhw_fail(LHW_ERR_ARG, "null argument");
+  p->roll_theta = nullptr;
+  if (strip_mode() < 2 || !p->wt_roll) return LHW_OK;   // per-layer GEMM inference reads theta itself: nothing to prepare
+  HIPCHK(hipSetDevice(p->device));
+  hipStream_t s = (hipStream_t)stream;
+  const MlpLayout &La = p->la, &Lc = p->lc;
+  const float *tha = theta + p->off_actor, *thc = theta + p->off_critic;
+  mlp_strip_prepare(tha + La.w1, tha + La.w2, tha + La.w3, La.Dp, La.O, La.Op, p->wt_roll, s);
+  mlp_strip_prepare(thc + Lc.w1, thc + Lc.w2, thc + Lc.w3, Lc.Dp, Lc.O, Lc.Op, p->wt_roll + mlp_strip_wt_floats(La.Dp, La.Op), s);
+  HIPCHK(hipGetLastError());
+  p->roll_theta = theta;
+  return LHW_OK;
+}
+extern "C" int lhw_ppo_end_rollout(LhwPpo* p) {
+  if (!p) return lhw_fail(LHW_ERR_ARG, "null ppo");
+  p->roll_theta = nullptr;
   return LHW_OK;
 }
 
@@ -1108,6 +1144,15 @@ extern "C" int lhw_scale_shift(float* x, int64_t n, float mean, float inv_scale,
   int dev = 0;
   if (device_of(x, &dev)) return LHW_ERR_HIP;
   hipLaunchKernelGGL(scale_shift_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, (size_t)n, mean, inv_scale);
+  HIPCHK(hipGetLastError());
+  return LHW_OK;
+}
+
+extern "C" int lhw_standardize(float* x, int64_t n, const double* stats3_dev, double eps, void* stream) {
+  if (!x || !stats3_dev || n <= 0) return lhw_fail(LHW_ERR_ARG, "bad argument");
+  int dev = 0;
+  if (device_of(x, &dev)) return LHW_ERR_HIP;
+  hipLaunchKernelGGL(standardize_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, (size_t)n, stats3_dev, eps);
   HIPCHK(hipGetLastError());
   return LHW_OK;
 }
@@ -1213,6 +1258,7 @@ extern "C" int lhw_ppo_apply(LhwPpo* p, float* theta, float* grad, float* adam_m
                              void* stream) {
   if (!p || !theta || !grad || !adam_m || !adam_v || step <= 0) return lhw_fail(LHW_ERR_ARG, "bad argument");
   HIPCHK(hipSetDevice(p->device));
+  p->roll_theta = nullptr;   // theta changes: the weight copies of an open rollout bracket are stale
   hipStream_t s = (hipStream_t)stream;
   const size_t na = p->learn_std ? p->off_std + p->A : p->off_std;  // actor group (+ stds if they are parameters)
   clip_and_adam(theta, grad, adam_m, adam_v, na, p->off_critic, p->lc.total, step, grad_scale, p->norm_part, p->stats, p->grad_clip,

@@ -35,6 +35,18 @@ def global_mean_std(sum_x: torch.Tensor, sum_x2: torch.Tensor, n: float):
     return mean, math.sqrt(var), cnt
 
 
+def global_moments_pack(mom2: torch.Tensor, n: float) -> torch.Tensor:
+    """Device-resident {sum, sum of squares, count} of the union of all ranks' samples: this rank's two moments (float64, on the
+    device) with the count appended, sum-all-reduced -- the input of lhw_standardize.  No value visits the host."""
+    pack = torch.empty(3, dtype=torch.float64, device=mom2.device)
+    pack[:2] = mom2.reshape(2)
+    pack[2] = float(n)
+    d = dist()
+    if _active(d):
+        d.all_reduce(pack)
+    return pack
+
+
 def global_batch_moments(x: torch.Tensor):
     """Per-feature mean / biased variance / count of the union of all ranks' rows (RunningMeanStd.update
     on the concatenated batch, reference rl/envs/normalize.py:16-33)."""

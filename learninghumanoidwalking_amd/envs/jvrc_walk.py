@@ -102,8 +102,13 @@ class JvrcWalkSpec:
         """obs_dim / obs_mean / obs_std for obs_history_len > 1 (jvrc_walk.py:62-63: np.tile over the history); called at the end
         of every __post_init__ of the Spec hierarchy (a parent's call leaves a child's longer base observation alone)."""
         base = type(self).__dataclass_fields__["obs_dim"].default
+        if not hasattr(self, "base_obs_dim") and self.obs_dim != base:
+            # the base observation is produced by the task's kernel: its width is not a free parameter of the Spec
+            raise ValueError(f"{type(self).__name__}: obs_dim is fixed by the task ({base}); got obs_dim={self.obs_dim}")
         self.base_obs_dim, self.obs_dim = base, base * self.history_len
-        if self.history_len > 1 and self.obs_mean is not None and len(self.obs_mean) == base:
+        # (a parent's __post_init__ runs this while obs_mean is still the parent's: only a vector of the base length is tiled here,
+        # and PPO checks the final length against obs_dim before it hands the vectors to the kernels)
+        if self.obs_mean is not None and len(self.obs_mean) == base and self.history_len > 1:
             self.obs_mean, self.obs_std = np.tile(self.obs_mean, self.history_len), np.tile(self.obs_std, self.history_len)
 
     @property

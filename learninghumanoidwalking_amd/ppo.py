@@ -155,6 +155,14 @@ class Rollout:
         # of two extra 3-GEMM passes per control step (same values, ~2000 fewer kernel launches per iteration).
         if self.tob_all is None:
             self.tob_all = torch.zeros(T, self.N, self.obs.shape[2], dtype=torch.float32, device=self.obs.device)
+        k.begin_rollout()      # theta is frozen for the whole rollout (policy steps and the batched critic passes behind them)
+        try:
+            self._collect_steps(deterministic)
+        finally:
+            k.end_rollout()
+
+    def _collect_steps(self, deterministic):
+        env, k, T = self.env, self.k, self.T
         G = self.groups
         if G <= 1:
             for t in range(T):
@@ -316,6 +324,9 @@ class PPO:
         if continued:
             pass
         elif spec.obs_mean is not None:
+            if len(spec.obs_mean) != obs_dim or len(spec.obs_std) != obs_dim:
+                raise ValueError(f"{type(spec).__name__}: obs_mean / obs_std have {len(spec.obs_mean)} / {len(spec.obs_std)} entries "
+                                 f"for an observation of {obs_dim} (base {getattr(spec, 'base_obs_dim', obs_dim)} x history)")
             self.obs_rms = None
             self.kernels.set_obs_norm(spec.obs_mean, spec.obs_std)
             self._log("Using fixed observation normalization from environment.")
@@ -384,9 +395,8 @@ class PPO:
     # ------------------------------------------------------------------ update
     def _normalize_advantages(self, adv_flat):
         """(adv - mean) / (unbiased std + eps) over the GLOBAL batch (ppo.py:484-485)."""
-        mom = self.kernels.moments(adv_flat).clone()
-        mean, std, _ = dist_utils.global_mean_std(mom[0], mom[1], adv_flat.numel())
-        self.kernels.scale_shift(adv_flat, mean, 1.0 / (std + self.eps))
+        pack = dist_utils.global_moments_pack(self.kernels.moments(adv_flat), adv_flat.numel())   # stays on the device
+        self.kernels.standardize(adv_flat, pack, self.eps)
 
     def update_actor_critic(self, obs_batch, action_batch, return_batch, advantage_batch, mask=1, mirror_observation=None,
                             mirror_action=None, old_log_probs=None):

@@ -41,11 +41,14 @@ def _setup(L):
     L.lhw_gae.argtypes = [i32, i32, vp, vp, vp, vp, vp, ctypes.c_double, ctypes.c_double, vp, vp, vp]
     L.lhw_moments.argtypes = [vp, i64, vp, vp]
     L.lhw_scale_shift.argtypes = [vp, i64, f32, f32, vp]
+    L.lhw_standardize.argtypes = [vp, i64, vp, ctypes.c_double, vp]
     L.lhw_ppo_grad.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp]
     L.lhw_ppo_apply.argtypes = [vp, vp, vp, vp, vp, i64, f32, vp]
     L.lhw_ppo_set_inference_dtype.argtypes = [vp, ctypes.c_int]
     L.lhw_ppo_set_update_dtype.argtypes = [vp, ctypes.c_int]
     L.lhw_ppo_forward_at.argtypes = [vp, vp, vp, i64, vp, vp, u64, u32, u32, ctypes.c_int, i64, vp, vp, vp, vp, vp]
+    L.lhw_ppo_begin_rollout.argtypes = [vp, vp, vp]
+    L.lhw_ppo_end_rollout.argtypes = [vp]
     _SETUP = True
 
 
@@ -174,6 +177,14 @@ class PpoKernels:
                                               self._stream()))
         return mu, act, logp, value
 
+    def begin_rollout(self):
+        """theta is frozen until end_rollout(): the strip kernel's weight copies are made once (on the current stream) instead of
+        in every policy step (lhw_ppo_begin_rollout)."""
+        _lib.check(self._L.lhw_ppo_begin_rollout(self._h, _p(self.theta), self._stream()))
+
+    def end_rollout(self):
+        _lib.check(self._L.lhw_ppo_end_rollout(self._h))
+
     def normalize(self, obs, want_mirror=None):
         R = obs.shape[0]
         want_mirror = self.use_mirror if want_mirror is None else want_mirror
@@ -194,6 +205,11 @@ class PpoKernels:
     def moments(self, x):
         _lib.check(self._L.lhw_moments(_p(x), x.numel(), _p(self._mom), self._stream()))
         return self._mom
+
+    def standardize(self, x, stats3, eps):
+        """x <- (x - mean) / (std + eps) from the device-resident {sum, sum of squares, count} (no host round trip)."""
+        assert stats3.dtype == torch.float64 and stats3.numel() == 3 and stats3.is_cuda
+        _lib.check(self._L.lhw_standardize(_p(x), x.numel(), _p(stats3), float(eps), self._stream()))
 
     def scale_shift(self, x, mean, inv):
         _lib.check(self._L.lhw_scale_shift(_p(x), x.numel(), float(mean), float(inv), self._stream()))

@@ -8,7 +8,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .ppo_kernels import LhwPpoConfig, _p, _setup
+from .ppo_kernels import LhwPpoConfig, PpoKernels, _p, _setup
 
 _SETUP_RNN = False
 
@@ -173,6 +173,8 @@ class RnnKernels:
             self._mom = torch.zeros(2, dtype=torch.float64, device=self.device)
         _lib.check(self._L.lhw_moments(_p(x), x.numel(), _p(self._mom), self._stream()))
         return self._mom
+
+    standardize = PpoKernels.standardize
 
     def scale_shift(self, x, mean, inv):
         _lib.check(self._L.lhw_scale_shift(_p(x), x.numel(), float(mean), float(inv), self._stream()))

@@ -20,12 +20,13 @@ def _worker(rank, world, port, q):
     rs = np.random.default_rng(100 + rank)
     x = torch.tensor(rs.normal(size=1000 + 37 * rank) * (1 + rank) + rank)
     mean, std, cnt = dist_utils.global_mean_std(x.sum(), (x * x).sum(), x.numel())
+    pack = dist_utils.global_moments_pack(torch.stack([x.sum(), (x * x).sum()]), x.numel()).numpy()   # device-resident form (lhw_standardize)
     obs = torch.tensor(rs.normal(size=(50 + 10 * rank, 5)) + rank)
     m, v, n = dist_utils.global_batch_moments(obs)
     g = torch.full((7,), float(rank + 1))
     scale = dist_utils.allreduce_grad_(g)
     eps = dist_utils.global_episode_stats(10.0 * (rank + 1), 100.0 + rank, 3 + rank)     # every rank reports all ranks' episodes
-    q.put((rank, mean, std, cnt, m.numpy(), v.numpy(), n, (g * scale).numpy(), dist_utils.shard_env_ids(4096, rank), eps))
+    q.put((rank, mean, std, cnt, m.numpy(), v.numpy(), n, (g * scale).numpy(), dist_utils.shard_env_ids(4096, rank), eps, pack))
     dist.destroy_process_group()
 
 
@@ -47,7 +48,11 @@ def test_two_rank_reductions_match_concatenated_batch():
         rs.normal(size=1000 + 37 * r)
         obs.append(torch.tensor(rs.normal(size=(50 + 10 * r, 5)) + r))
     allx, allo = torch.cat(xs), torch.cat(obs)
-    for rank, mean, std, cnt, m, v, n, g, base, eps in res:
+    for rank, mean, std, cnt, m, v, n, g, base, eps, pack in res:
+        # the kernel's formula (standardize_kernel) on the all-reduced pack
+        pm = pack[0] / pack[2]
+        ps = np.sqrt(max(0.0, (pack[1] - pack[2] * pm * pm) / max(1.0, pack[2] - 1.0)))
+        assert pack[2] == allx.numel() and abs(pm - float(allx.mean())) < 1e-12 and abs(ps - float(allx.std())) < 1e-12
         assert eps == (30.0, 201.0, 7.0)               # rl/algos/ppo.py:408-426: mean over ALL workers' episodes
         assert abs(mean - float(allx.mean())) < 1e-12
         assert abs(std - float(allx.std())) < 1e-12          # unbiased, like ppo.py:485
