@@ -425,6 +425,26 @@ __device__ __forceinline__ double dpp_d(double v, double ident) {
 }
 // index of this lane's group inside the wavefront (0 for W = 64)
 template <int W> __device__ __forceinline__ int group_id() { return W == 64 ? 0 : (int)(threadIdx.x >> 5); }
+// The lane's index within its wavefront, produced where the optimiser cannot see through it -- and cannot keep it: every phase of
+// the sub-step derives its lane index, its group's LDS base and the addresses built from them from a FRESH copy (two VALU
+// instructions), so that none of them is live across the other phases.  Left to itself the compiler computes lane, 4 lane,
+// S + 4 lane, S + 8 lane, 6 lane ... once at kernel entry, runs out of registers in the solver and parks exactly these in
+// scratch: ~60 of the ~200 scratch reloads per sub-step were reloads of values that cost one or two instructions to recompute
+// (round 4, from the ISA: slots holding lane, lane << 2, &S + (lane << 2)).
+__device__ __forceinline__ int fresh_wave_lane() {
+#if defined(__HIP_DEVICE_COMPILE__)
+  int l;
+  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+  return l;
+#else
+  return (int)threadIdx.x;   // (host pass / SIMT emulator; workgroup = one wavefront)
+#endif
+}
+#define FRESH_GROUP(W, SG0)                      \
+  const int wl_ = fresh_wave_lane();             \
+  const int lane = wl_ & ((W) - 1);              \
+  L& S = (SG0)[(W) == 32 ? (wl_ >> 5) : 0]
+
 // Mask of the contact rows (= lanes) of ONE env's group: a 32-bit per-lane value in the two-envs-per-wave layouts (the two envs of a
 // wave iterate over their own rows side by side), the wave's 64-bit ballot with one env per wave.
 template <int W> struct RowMask { typedef unsigned long long type; };
@@ -2007,13 +2027,12 @@ __device__ __forceinline__ void solve_tail(const HModel& m, const HParams& p, L&
 // J x is the lane's own element, J^T f lands on the lane's own dof, J^T D J on its own diagonal entry.  Only the summation
 // order differs from the row order of the reference; every row is there.
 template <bool BOXBOX, class L>
-__device__ __forceinline__ void substep(const HModel& m, const HParams& p, L& S, int lane, int flags, long long* st_prof, const double* ter) {
+__device__ __forceinline__ void substep(const HModel& m, const HParams& p, L* SG0, int flags, long long* st_prof, const double* ter) {
   constexpr int W = L::W_;
-  PROF_BEGIN();
-  fwd_kinematics<BOXBOX>(m, S, lane);
-  PROF_MARK(0);
-  fwd_collision<BOXBOX>(m, p, S, lane, ter);   // stage A temporaries (geom frames) die with fwd_com
-  PROF_MARK(3);
+  long long prof_t;
+  { FRESH_GROUP(W, SG0); prof_t = (st_prof && lane == 0) ? (long long)clock64() : 0; fwd_kinematics<BOXBOX>(m, S, lane); PROF_MARK(0); }
+  { FRESH_GROUP(W, SG0); fwd_collision<BOXBOX>(m, p, S, lane, ter); PROF_MARK(3); }   // stage A temporaries (geom frames) die with fwd_com
+  FRESH_GROUP(W, SG0);
   // The chain solver needs the [root | chain A | chain B] block structure of M (checked at create).  A contact between bodies
   // of the two chains couples them in the Newton Hessian (rare: it is a self-collision, i.e. the last control step of an
   // episode): those Hessians are factorised by the looped dense Cholesky in LDS instead (dense_lds_solve).
@@ -2172,11 +2191,16 @@ struct LayoutOf {
                ((TASK == TASK_STEP || W == 64) ? NG : 16), (W == 64 ? NB : ((TASK == TASK_STAND || TASK == TASK_H1WALK) ? 15 : 18)), TASK == TASK_STEP> type;
 };
 
+template <int MODE, int TASK, int W>
+__device__ __forceinline__ bool store_record(const HModel& m, const HLaunch& lz, const HState& st, typename LayoutOf<TASK, W>::type* SG0, const int env,
+                                             const long long t_launch);
+
 // One control step (MODE 0), reset (1), set_state (2) or get_state (3) of env `env` by the group of W lanes that calls it
 // (`lane` = lane within the group, S = the group's LDS working set).  Returns true iff the env exceeded the contact capacity
 // of the two-envs-per-wave layout before anything of this control step was written: the caller repeats the step with W = 64.
 template <int MODE, int TASK, int W>
-__device__ __forceinline__ bool control_step(const HModel& m, const HParams& p, const HLaunch& lz, const HState& st, typename LayoutOf<TASK, W>::type& S, const int env,
+__device__ __forceinline__ bool control_step(const HModel& m, const HParams& p, const HLaunch& lz, const HState& st, typename LayoutOf<TASK, W>::type* SG0,
+                                             typename LayoutOf<TASK, W>::type& S, const int env,
                                              const int lane, const float* __restrict__ act, float* __restrict__ obs, float* __restrict__ term_obs,
                                              float* __restrict__ rew, unsigned char* __restrict__ done_out, float* __restrict__ rew_terms,
                                              double* __restrict__ xq, double* __restrict__ xv) {
@@ -2252,6 +2276,7 @@ __device__ __forceinline__ bool control_step(const HModel& m, const HParams& p, 
     target = p.action_smoothing * a_in + (1 - p.action_smoothing) * rec[R_PREVPRED + lane] + p.action_offset[lane];
   }
   for (;;) {
+    FRESH_GROUP(W, SG0);   // (shadows the parameters inside the stage loop: nothing lane-derived is carried across a sub-step)
     int flags = 3;
     if (stage == ST_CONTROL) {
       if (kstep < p.frame_skip) {
@@ -2719,17 +2744,10 @@ __device__ __forceinline__ bool control_step(const HModel& m, const HParams& p, 
       stage = ST_LAST;
     }
     if (stage == ST_END) break;
-#ifndef LHW_NO_OPAQUE_LANE
-    // The lane index goes through a value the compiler cannot see through (opaque_zero()).  Everything a lane
-    // reads from the model tables in a sub-step is indexed by it and invariant across the 25 sub-steps; left alone, the
-    // compiler hoists those ~100 loads out of the loop and -- with the registers full -- parks them in scratch, from where
-    // every sub-step reloads them: ~300 scratch loads per sub-step against an 11 MB-per-XCD footprint that misses L2
-    // (FETCH_SIZE 708 MB per launch), instead of loads from tables that all waves share and that stay in L1 / L2.
-    const int lane_s = lane + opaque_zero();
-#else
-    const int lane_s = lane;
-#endif
-    substep<TASK == TASK_STEP>(m, p, S, lane_s, flags, sprof, ter);
+    // (Every phase of the sub-step takes its lane index from fresh_wave_lane(): besides keeping the addresses built from it out of
+    // scratch, the opaque value keeps the ~100 model-table loads of a sub-step -- indexed by the lane, invariant across the 25
+    // sub-steps -- inside the loop.  Hoisted, they would be parked in scratch and reloaded from there, FETCH_SIZE 708 MB per launch.)
+    substep<TASK == TASK_STEP>(m, p, SG0, flags, sprof, ter);
     if (stage == ST_LAST) break;
     // two envs per wave: an env that needs more contacts than this layout holds is handed to the one-env-per-wave kernel
     // untouched (nothing of it has been written yet); once its outputs are out, it can only truncate like that kernel does
@@ -2741,6 +2759,17 @@ __device__ __forceinline__ bool control_step(const HModel& m, const HParams& p, 
   PROF_MARK(10);
   // ---- store the record
   SYNC();
+  return store_record<MODE, TASK, W>(m, lz, st, SG0, env, t_launch);
+}
+
+// The persistent record goes back to HBM (lane-strided); everything it needs is re-derived from the env index and a fresh lane.
+template <int MODE, int TASK, int W>
+__device__ __forceinline__ bool store_record(const HModel& m, const HLaunch& lz, const HState& st, typename LayoutOf<TASK, W>::type* SG0, const int env,
+                                             const long long t_launch) {
+  using L = typename LayoutOf<TASK, W>::type;
+  FRESH_GROUP(W, SG0);
+  double* rec = st.rec + (size_t)env * REC_D;
+  int* irec = st.irec + (size_t)env * REC_I;
   if (lane < m.nq) rec[R_QPOS + lane] = S.qpos[lane];
   if (lane < NV) { rec[R_QVEL + lane] = S.qvel[lane]; rec[R_WARM + lane] = S.qacc[lane]; }
   if (lane < m.nu) { rec[R_SQ + lane] = S.sq[lane]; rec[R_SV + lane] = S.sv[lane]; rec[R_FRC + lane] = S.frc[lane]; }
@@ -2789,14 +2818,14 @@ __global__ void __launch_bounds__(64, LHW_WAVES_PER_SIMD) humanoid_kernel(const 
     while (todo) {
       const int i = __ffsll(todo) - 1;
       todo &= todo - 1;
-      control_step<MODE, TASK, W>(m, p, lz, st, SG[0], lz.env_first + e0 + i, lane, act, obs, term_obs, rew, done_out, rew_terms, xq, xv);
+      control_step<MODE, TASK, W>(m, p, lz, st, SG, SG[0], lz.env_first + e0 + i, lane, act, obs, term_obs, rew, done_out, rew_terms, xq, xv);
     }
   } else {
     const int eidx = blockIdx.x * G + group_id<W>();
     if (eidx >= lz.env_count) return;
     const int env = eidx + lz.env_first;
     if (MODE == 1 && mask && !mask[env]) return;
-    control_step<MODE, TASK, W>(m, p, lz, st, SG[group_id<W>()], env, lane, act, obs, term_obs, rew, done_out, rew_terms, xq, xv);
+    control_step<MODE, TASK, W>(m, p, lz, st, SG, SG[group_id<W>()], env, lane, act, obs, term_obs, rew, done_out, rew_terms, xq, xv);
   }
 }
 
