@@ -2880,8 +2880,9 @@ int humanoid_create(HumanoidEnv** out, const std::vector<int32_t>& mi, const std
   }
   const int nb = (int)bsrc.size();
   if (nq > NQ || nv > NVMAX || nu > NU || nb > NB || nj > NJ || ng > NG || np > NP || nb > 64 || np > 64)
-    return lhw_fail(LHW_ERR_MODEL, "model exceeds compiled limits (nq %d/%d nv %d/%d nu %d/%d nbody %d/%d njnt %d/%d ngeom %d/%d npair %d/%d)",
-                    nq, NQ, nv, NVMAX, nu, NU, nb, NB, nj, NJ, ng, NG, np, NP);
+    return lhw_fail(LHW_ERR_MODEL, "model exceeds compiled limits (nq %d/%d nv %d/%d nu %d/%d nbody %d/%d njnt %d/%d ngeom %d/%d npair %d/%d)%s",
+                    nq, NQ, nv, NVMAX, nu, NU, nb, NB, nj, NJ, ng, NG, np, NP,
+                    nb > NB ? ": fold the welded (joint-less) links into their parents first -- Model.fuse_static / fit_stepper_limits, or MuJoCo's fusestatic" : "");
   const bool stepping = cfg->task == LHW_TASK_JVRC_STEP, h1walk = cfg->task == LHW_TASK_H1_WALK;
   const bool walk = cfg->task == LHW_TASK_JVRC_WALK || stepping;             // JVRC robot + gait clock
   const bool stand = cfg->task == LHW_TASK_H1_STAND || h1walk;               // H1 robot: observation noise, domain randomisation
@@ -3085,7 +3086,7 @@ int humanoid_create(HumanoidEnv** out, const std::vector<int32_t>& mi, const std
     }
     const int b1 = I1[GI_BODY], b2 = I2[GI_BODY];
     pi[3] = (int)(bmask[b1] ^ bmask[b2]); pi[4] = (int)bmask[b2];
-    pd[10] = body_d[(size_t)BDS * b1 + BD_INVW] + body_d[(size_t)BDS * b2 + BD_INVW];
+    pd[10] = DF(LHW_DF_GEOM_INVWEIGHT0)[2 * g1] + DF(LHW_DF_GEOM_INVWEIGHT0)[2 * g2];   // (the geoms' own copies: Model.fuse_static keeps them)
   }
   for (int u = 0; u < nu; u++) {
     double* k = &act_d[(size_t)ADS * u];

@@ -13,6 +13,7 @@ import yaml
 
 from .. import mjcf
 from ..batched_env import TASK_H1_STAND, BatchedEnv
+from ..model import fit_stepper_limits
 
 _ASSETS = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "assets")
 H1_STANDIN_XML = os.path.join(_ASSETS, "h1_standin.xml")
@@ -100,7 +101,10 @@ class H1Spec:
             m.arrays["body_mass"][m.body_id("pelvis")] = 8.89
             m.arrays["body_mass"][m.body_id("torso_link")] = 21.289
             m.totalmass = float(m.arrays["body_mass"].sum())
-            self._model = m
+            # (a full menagerie H1 keeps its arm links welded to the torso: folded if there are too many.  The pelvis and the leg
+            # bodies are randomised relative to their default mass / inertial offset, so nothing is folded into them; the torso and
+            # the perturbed bodies stay bodies)
+            self._model = fit_stepper_limits(m, 15, keep=("torso_link",) + tuple(getattr(self, "perturb_bodies", ())), protect=("pelvis",))
         return self._model
 
     def mirror_tables(self):

@@ -14,6 +14,7 @@ import numpy as np
 import yaml
 
 from .. import mjcf
+from ..model import fit_stepper_limits
 from ..batched_env import TASK_JVRC_WALK, BatchedEnv
 
 _ASSETS = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "assets")
@@ -123,7 +124,9 @@ class JvrcWalkSpec:
             names = [m.jnt_names[j] for j in m.actuator_trnid]
             if names != LEG_JOINTS or m.nq != 19 or m.nv != 18:
                 raise ValueError("model does not have the JVRC leg actuator layout (free root + 12 leg hinges)")
-            self._model = m
+            # a real JVRC export keeps ~30 arm / head / finger links welded to the torso after gen_xml.py:84-87 deleted their
+            # joints: they are folded into the bodies they move with (exact; the head stays a body, the task reads its position)
+            self._model = fit_stepper_limits(m, 18, keep=("NECK_P_S",))
         return self._model
 
     def clock_lut(self):

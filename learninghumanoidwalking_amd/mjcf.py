@@ -717,6 +717,7 @@ def set_const(m: Model) -> None:
     nv = m.nv
     a["dof_invweight0"] = np.zeros(nv)
     a["body_invweight0"] = np.zeros((m.nbody, 2))
+    a["geom_invweight0"] = np.zeros((m.ngeom, 2))
     if nv == 0:
         m.meaninertia = 1.0
         return
@@ -737,6 +738,7 @@ def set_const(m: Model) -> None:
         Jt, Jr = _jac_point(m, xpos, xquat, b, xipos[b])
         a["body_invweight0"][b, 0] = np.trace(Jt @ Minv @ Jt.T) / 3.0
         a["body_invweight0"][b, 1] = np.trace(Jr @ Minv @ Jr.T) / 3.0
+    a["geom_invweight0"] = a["body_invweight0"][a["geom_bodyid"]].copy() if m.ngeom else np.zeros((0, 2))
 
 
 # ----------------------------------------------------------------------------- public API

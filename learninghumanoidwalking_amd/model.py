@@ -20,7 +20,7 @@ from dataclasses import dataclass, field
 import numpy as np
 
 MAGIC = 0x4C48574D  # "LHWM"
-VERSION = 1
+VERSION = 2   # v2: geom_invweight0 (the contact regulariser's inverse weights travel with the geom, see Model.fuse_static)
 
 # joint types / geom types use MuJoCo's enum values (mjtJoint, mjtGeom)
 JNT_FREE, JNT_BALL, JNT_SLIDE, JNT_HINGE = 0, 1, 2, 3
@@ -93,6 +93,9 @@ FIELDS = [
     ("geom_solimp", "d", 5, "ngeom"),
     ("geom_margin", "d", 1, "ngeom"),
     ("geom_gap", "d", 1, "ngeom"),
+    # body_invweight0 of the body the geom was attached to when the constants were computed (mj_setConst at qpos0): the contact
+    # rows' diagApprox reads it per geom, so that folding welded links into their parents (fuse_static) does not change it
+    ("geom_invweight0", "d", 2, "ngeom"),
     # statically filtered collision candidates, in MuJoCo's body-pair order
     ("pair_geom1", "i", 1, "npair"),
     ("pair_geom2", "i", 1, "npair"),
@@ -149,6 +152,7 @@ class Model:
     geom_names: list = field(default_factory=list)
     actuator_names: list = field(default_factory=list)
     site_names: list = field(default_factory=list)
+    fused_into: dict = field(default_factory=dict)   # fuse_static: absorbed body name -> absorbing body name
 
     def __getattr__(self, name):
         arrays = self.__dict__.get("arrays", {})
@@ -178,6 +182,105 @@ class Model:
         for k in ("body_names", "jnt_names", "geom_names", "actuator_names", "site_names"):
             setattr(m, k, list(getattr(self, k)))
         return m
+
+    # -- fusestatic -----------------------------------------------------------------
+    def fuse_static(self, keep=(), protect=()) -> "Model":
+        """Fold the joint-less (welded) bodies of the dynamic tree into the body they move with -- MuJoCo's compiler option
+        ``fusestatic``, done on the compiled model.  The reference's robots reach the stepper with their upper-body joints
+        deleted (reference envs/jvrc/gen_xml.py:84-87, envs/h1/gen_xml.py:64-77): ~30 links of a real JVRC export are then
+        rigidly attached to the pelvis, and the stepper's per-env LDS working set is sized for the bodies that MOVE
+        independently, not for them.
+
+        Exact: the absorbing body gets the combined mass, centre of mass and inertia tensor (parallel-axis sums, principal axes
+        by ``numpy.linalg.eigh``), geoms and sites are re-attached with the composed pose, children are re-parented with the
+        composed frame -- the joint-space dynamics are unchanged -- and every geom keeps the ``body_invweight0`` of the body it
+        came from (``geom_invweight0``), so contact rows get the same regulariser as in the unfused model (MuJoCo's own
+        ``fusestatic`` recomputes it for the fused body).  ``keep``: names of welded bodies that stay bodies (the task reads
+        their position: the head).  ``protect``: bodies that must not absorb others (their mass / inertial offset are
+        randomised per episode relative to the default model).  Collision candidates (``pair_geom*``) were filtered on the
+        unfused tree and are kept as they are."""
+        from .mjcf import mat2quat, quat2mat, quat_mul
+        a = self.arrays
+        nb = self.nbody
+        par, jn, weld = a["body_parentid"], a["body_jntnum"], a["body_weldid"]
+        keep, protect = set(keep), set(protect)
+        fused = np.zeros(nb, bool)
+        for b in range(1, nb):
+            if jn[b] == 0 and weld[b] != 0 and self.body_names[b] not in keep:
+                # absorbed by the nearest ancestor that stays: allowed unless that ancestor is protected
+                t = par[b]
+                while fused[t]:
+                    t = par[t]
+                fused[b] = self.body_names[t] not in protect
+        if not fused.any():
+            return self
+        # frame of every body in its target (itself if it stays)
+        target = np.arange(nb)
+        Rt = [np.eye(3) for _ in range(nb)]
+        pt = [np.zeros(3) for _ in range(nb)]
+        qt = [np.array([1.0, 0, 0, 0]) for _ in range(nb)]
+        for b in range(1, nb):          # parents first (depth-first numbering)
+            if fused[b]:
+                p = par[b]
+                Rb = quat2mat(a["body_quat"][b])
+                target[b] = target[p] if fused[p] else p
+                Rp, pp, qp = (Rt[p], pt[p], qt[p]) if fused[p] else (np.eye(3), np.zeros(3), np.array([1.0, 0, 0, 0]))
+                Rt[b], pt[b], qt[b] = Rp @ Rb, pp + Rp @ a["body_pos"][b], quat_mul(qp, a["body_quat"][b])
+        out = self.copy()
+        o = out.arrays
+        # inertia of the absorbing bodies
+        for t in sorted(set(int(x) for x in target[fused])):
+            parts = [(t, np.eye(3), np.zeros(3))] + [(int(b), Rt[b], pt[b]) for b in np.nonzero(fused & (target == t))[0]]
+            M = sum(a["body_mass"][b] for b, _, _ in parts)
+            if M <= 0:
+                continue
+            coms = [p0 + R @ a["body_ipos"][b] for b, R, p0 in parts]
+            com = sum(a["body_mass"][b] * c for (b, _, _), c in zip(parts, coms)) / M
+            I = np.zeros((3, 3))
+            for (b, R, _), c in zip(parts, coms):
+                Ri = R @ quat2mat(a["body_iquat"][b])
+                d = c - com
+                I += Ri @ np.diag(a["body_inertia"][b]) @ Ri.T + a["body_mass"][b] * (np.dot(d, d) * np.eye(3) - np.outer(d, d))
+            w, V = np.linalg.eigh(0.5 * (I + I.T))
+            w, V = w[::-1], V[:, ::-1]                      # principal moments in descending order, as MuJoCo stores them
+            if np.linalg.det(V) < 0:
+                V[:, 2] = -V[:, 2]
+            o["body_mass"][t], o["body_ipos"][t], o["body_inertia"][t], o["body_iquat"][t] = M, com, w, mat2quat(V)
+        # geoms / sites of absorbed bodies move to the target with the composed pose
+        for pre, n in (("geom", self.ngeom), ("site", self.nsite)):
+            for g in range(n):
+                b = int(a[pre + "_bodyid"][g])
+                if fused[b]:
+                    o[pre + "_pos"][g] = pt[b] + Rt[b] @ a[pre + "_pos"][g]
+                    o[pre + "_quat"][g] = quat_mul(qt[b], a[pre + "_quat"][g])
+                    o[pre + "_bodyid"][g] = target[b]
+        # children of absorbed bodies hang off the target with the composed frame
+        for b in range(1, nb):
+            p = par[b]
+            if not fused[b] and fused[p]:
+                o["body_pos"][b] = pt[p] + Rt[p] @ a["body_pos"][b]
+                o["body_quat"][b] = quat_mul(qt[p], a["body_quat"][b])
+                o["body_parentid"][b] = target[p]
+        # drop the absorbed bodies and renumber
+        stay = np.nonzero(~fused)[0]
+        newid = -np.ones(nb, np.int64)
+        newid[stay] = np.arange(len(stay))
+        for name, _, width, sym in FIELDS:
+            if sym == "nbody":
+                o[name] = np.ascontiguousarray(o[name].reshape(nb, -1)[stay].reshape((len(stay),) if width == 1 else (len(stay), width)))
+        o["body_parentid"] = newid[o["body_parentid"]].astype(np.int32)
+        for name in ("jnt_bodyid", "dof_bodyid", "geom_bodyid", "site_bodyid"):
+            o[name] = newid[o[name]].astype(np.int32)
+        out.nbody = len(stay)
+        out.body_names = [self.body_names[b] for b in stay]
+        out.fused_into = {self.body_names[b]: self.body_names[target[b]] for b in np.nonzero(fused)[0]}
+        rootid, weldid = np.zeros(out.nbody, np.int32), np.zeros(out.nbody, np.int32)
+        for i in range(1, out.nbody):
+            p = o["body_parentid"][i]
+            rootid[i] = i if p == 0 else rootid[p]
+            weldid[i] = i if o["body_jntnum"][i] else weldid[p]
+        o["body_rootid"], o["body_weldid"] = rootid, weldid
+        return out
 
     # -- packing ------------------------------------------------------------------
     def pack(self) -> tuple[np.ndarray, np.ndarray]:
@@ -249,6 +352,24 @@ def generate_header() -> str:
     return "\n".join(out)
 
 
+def tree_bodies(m: Model) -> int:
+    """Bodies the stepper holds per env: the world plus the dynamic tree (static children of the world are folded into the world
+    by lhw_env_create)."""
+    return 1 + int(np.count_nonzero(np.asarray(m.body_weldid)[1:] != 0))
+
+
+def fit_stepper_limits(m: Model, max_bodies: int, keep=(), protect=()) -> Model:
+    """The model as the stepper can hold it: unchanged if its dynamic tree has at most ``max_bodies`` bodies, otherwise with the
+    welded links folded into the bodies they move with (``Model.fuse_static``; exact).  Raises if it still does not fit."""
+    if tree_bodies(m) <= max_bodies:
+        return m
+    f = m.fuse_static(keep=keep, protect=protect)
+    if tree_bodies(f) > max_bodies:
+        raise ValueError(f"model has {tree_bodies(m)} bodies in its dynamic tree, {tree_bodies(f)} after folding the welded links "
+                         f"(kept: {sorted(keep)}, protected: {sorted(protect)}); the stepper holds {max_bodies}")
+    return f
+
+
 def model_from_mjmodel(m) -> Model:
     """Build a `Model` from a real ``mujoco.MjModel`` (reference-side binding; scripts/pin_vs_mujoco.py runs the CPU oracle on
     it next to ``mj_step``).  Not exercised in this container (mujoco is not installed); see INTEGRATION.md.
@@ -269,7 +390,9 @@ def model_from_mjmodel(m) -> Model:
     for name, kind, width, sym in FIELDS:
         if name.startswith("pair_"):
             continue
-        if name == "actuator_trnid":
+        if name == "geom_invweight0":      # (ours: the geom's copy of its body's inverse weights, see FIELDS)
+            v = np.asarray(m.body_invweight0)[np.asarray(m.geom_bodyid)]
+        elif name == "actuator_trnid":
             v = np.asarray(m.actuator_trnid)[:, 0]
         elif name == "actuator_gear":
             v = np.asarray(m.actuator_gear)[:, 0]

@@ -929,7 +929,10 @@ static void makeConstraint(OData* d) {
   }
   d->nl = d->nefc - d->nf;
   const int32_t* gbody = IF(m, LHW_IF_GEOM_BODYID);
-  const double* binvw = DF(m, LHW_DF_BODY_INVWEIGHT0);
+  /* engine_core_constraint.c mj_makeImpedance / diagApprox: body_invweight0 of the two geoms' bodies -- carried per geom in the
+   * packed model (geom_invweight0), so that a model whose welded links were folded into their parents (Model.fuse_static)
+   * keeps the regulariser of the unfused one */
+  const double* ginvw = DF(m, LHW_DF_GEOM_INVWEIGHT0);
   double* jp1 = dalloc(3 * nv);
   double* jp2 = dalloc(3 * nv);
   for (int ci = 0; ci < d->ncon; ci++) {
@@ -939,7 +942,7 @@ static void makeConstraint(OData* d) {
     jacPoint(d, jp1, c->pos, b1);
     jacPoint(d, jp2, c->pos, b2);
     /* relative-velocity Jacobian in the contact frame: Jc = frame * (J2 - J1) */
-    double tran = binvw[2 * b1] + binvw[2 * b2];
+    double tran = ginvw[2 * c->geom1] + ginvw[2 * c->geom2];
     if (c->dim == 1) {
       int r = addRow(d, EFC_CONTACT, ci, c->dist, c->includemargin, tran, c->solref, c->solimp, 0);
       if (r < 0) break;

@@ -18,7 +18,7 @@ def pytest_configure(config):
 # tests that spawn processes (entry point, RCCL branch, the two-rank data-parallel run) last -- one integration flake must not hide
 # the parity results of every kernel behind it (round 3: test_distributed_gpu.py, second file in alphabetical order, failed and
 # 112 parity tests never ran).
-_ORDER = ["test_cartpole_gpu", "test_jvrc_gpu", "test_h1_gpu", "test_h1_walk_gpu", "test_jvrc_step_gpu", "test_model_variants_gpu",
+_ORDER = ["test_cartpole_gpu", "test_jvrc_gpu", "test_h1_gpu", "test_h1_walk_gpu", "test_jvrc_step_gpu", "test_model_variants_gpu", "test_fuse_static_gpu",
           "test_task_inputs_gpu", "test_obs_history_gpu", "test_gemm_gpu", "test_mlp_strip_gpu", "test_ppo_gpu", "test_rnn_gpu",
           "test_errors_gpu", "test_fullsize_gpu", "test_freerun_gpu", "test_iteration_gpu"]
 _LAST = ["test_reference_configs", "test_entry_gpu", "test_distributed_gpu"]

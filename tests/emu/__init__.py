@@ -184,7 +184,9 @@ def make_emulated(spec, n_envs, **kw):
         def __init__(self, model, task, n, **k):
             captured.update(model=model, task=task, n=n, k=k)
 
-    mod = __import__(type(spec).__module__, fromlist=["x"])
+    import sys
+    mod = sys.modules[type(spec).make_batched.__module__]      # the module whose BatchedEnv name make_batched resolves (a subclass
+                                                               # defined elsewhere, e.g. in a test, inherits the method)
     orig = mod.BatchedEnv
     mod.BatchedEnv = _Capture
     try:
