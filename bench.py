@@ -29,7 +29,7 @@ def static_pmc_traffic(kernel_substr, stem="step"):
     correction of MI355X_MICROARCH.md (FETCH_SIZE under-reports coalesced reads by 2x; WRITE_SIZE uncalibrated).  Static: it
     is NOT measured by this run (the counters need their own rocprofv3 passes, scripts/collect_profiles.sh)."""
     import csv
-    for rnd in ("r03", "r02"):          # newest committed round first
+    for rnd in ("r04", "r03", "r02"):          # newest committed round first
         vals = {}
         for name in ("fetch_size", "write_size"):
             path = os.path.join(ROOT, "profiles", f"{rnd}_jvrc_walk_{stem}_pmc_{name}.csv")
@@ -42,6 +42,42 @@ def static_pmc_traffic(kernel_substr, stem="step"):
             return dict(bytes_per_launch=2.0 * vals["fetch_size"] + vals["write_size"], envs_per_launch=4096, control_steps_per_launch=1,
                         source=f"profiles/{rnd}_jvrc_walk_{stem}_pmc_{{fetch,write}}_size.csv: 2*FETCH_SIZE + WRITE_SIZE, whole-batch launches")
     return None
+
+
+def static_pmc_executed_fp64(kernel_substr):
+    """fp64 FLOPs one launch of the dominant kernel EXECUTES, from the committed SQ counter pass (profiles/): (2 FMA + MUL + ADD)
+    wave-instructions x the average number of active lanes per VALU instruction (SQ_THREAD_CYCLES_VALU / SQ_INSTS_VALU / 4: the
+    counter advances 4 per lane and instruction).  Static, like the traffic figure; it is what the hardware did, where
+    `algorithmic_flops_per_env_step` is SURVEY.md 8(d)'s estimate for a dense 18 x 18 solver with four Newton iterations."""
+    import csv
+    for rnd in ("r04", "r03"):
+        path = os.path.join(ROOT, "profiles", f"{rnd}_jvrc_walk_step_pmc_sq.csv")
+        if not os.path.exists(path):
+            continue
+        v = {}
+        for row in csv.reader(open(path)):
+            if len(row) >= 4 and kernel_substr in row[0]:
+                try:
+                    v[row[1]] = float(row[3])
+                except ValueError:
+                    pass
+        need = ("SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_ADD_F64", "SQ_THREAD_CYCLES_VALU", "SQ_INSTS_VALU")
+        if all(k in v for k in need):
+            lanes = v["SQ_THREAD_CYCLES_VALU"] / v["SQ_INSTS_VALU"] / 4.0
+            return dict(flops_per_launch=(2 * v["SQ_INSTS_VALU_FMA_F64"] + v["SQ_INSTS_VALU_MUL_F64"] + v["SQ_INSTS_VALU_ADD_F64"]) * lanes,
+                        active_lanes_per_valu_instruction=lanes, valu_instructions_per_launch=v["SQ_INSTS_VALU"], envs_per_launch=4096,
+                        source=f"profiles/{rnd}_jvrc_walk_step_pmc_sq.csv")
+    return None
+
+
+def update_flops_per_sample_epoch(D, H, A, mirror):
+    """Multiply-add FLOPs the update performs per sample and epoch: actor forward + backward on the row (and on its mirrored twin),
+    critic forward + backward.  forward = 2 (D H + H H + H O); backward = the weight gradients (the same count) + the activation
+    gradients of the two upper layers.  No old-policy forward: the behaviour log-probabilities are stored by the rollout."""
+    def net(O):
+        fwd = 2 * (D * H + H * H + H * O)
+        return fwd + fwd + 2 * (H * H + H * O)
+    return (2 if mirror else 1) * net(A) + net(1)
 
 
 def cpu_baseline_worker(a):
@@ -244,12 +280,16 @@ def main():
         # `achieved` / `frac` are those of an ISOLATED whole-batch launch (what an isolated rocprofv3 dispatch shows); the
         # rollout itself runs `concurrent_launches` half-batch launches side by side, whose per-launch spans are in `overlapped`.
         iso_tf = None if isolated_ms is None else flops_per_env_step * N / (isolated_ms * 1e-3) / 1e12
+        executed = static_pmc_executed_fp64(spec.step_kernel_name) if env_name == "jvrc_walk" else None
+        if executed is not None and isolated_ms is not None and N == executed["envs_per_launch"]:
+            executed["tflops"] = executed["flops_per_launch"] / (isolated_ms * 1e-3) / 1e12
+            executed["frac_of_fp64_peak"] = executed["tflops"] / FP64_VALU_PEAK_TFLOPS
         roofline = dict(
             bound="valu_fp64", kernel=spec.step_kernel_name, achieved=iso_tf if iso_tf is not None else overlapped_tf,
             peak=FP64_VALU_PEAK_TFLOPS, unit="TFLOP/s",
             frac=(iso_tf if iso_tf is not None else overlapped_tf) / FP64_VALU_PEAK_TFLOPS, traffic=None,
             traffic_note="HBM bytes are not measured by this run (PMC counters need separate rocprofv3 passes); see traffic_static",
-            traffic_static=static,
+            traffic_static=static, executed_static=executed,
             algorithmic_flops_per_launch=flops_per_env_step * N, algorithmic_bytes_per_launch=bytes_per_env_step * N,
             algorithmic_flops_per_env_step=flops_per_env_step, algorithmic_bytes_per_env_step=bytes_per_env_step,
             avg_launch_ms=isolated_ms if isolated_ms is not None else avg_step_ms, envs_per_launch=N if isolated_ms is not None else NL,
@@ -267,7 +307,17 @@ def main():
             hbm=dict(bound="hbm", achieved=achieved_gbs, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved_gbs / HBM_PEAK_GBS,
                      note="secondary: algorithmic bytes / launch span; ~3e-4 of peak by construction"))
         L = algo.last_losses
-        upd_flops = algo.kernels_update_flops_per_sample_epoch() * N * T * args.epochs if hasattr(algo, "kernels_update_flops_per_sample_epoch") else None
+        kk = algo.kernels
+        use_mirror = bool(getattr(kk, "use_mirror", False))
+        n_upd = int(L.get("n_updates") or 0)
+        upd_flops = update_flops_per_sample_epoch(kk.obs_dim, kk.hidden, kk.act_dim, use_mirror) * float(n_upd * min(args.minibatch_size, N * T)) if not getattr(kk, "recurrent", False) else None
+        if upd_flops:
+            upd_tf = upd_flops / (opt_t / K) / 1e12
+            roofline["update"] = dict(bound="mfma", achieved=upd_tf, peak=MFMA_F32_PEAK_TFLOPS, unit="TFLOP/s", frac=upd_tf / MFMA_F32_PEAK_TFLOPS,
+                                      flops_per_iteration=upd_flops, flops_per_sample_epoch=update_flops_per_sample_epoch(kk.obs_dim, kk.hidden, kk.act_dim, use_mirror),
+                                      seconds_per_iteration=opt_t / K,
+                                      note="whole update phase (gather, forward, loss, backward, ordered reductions, clip + Adam of every optimiser step) "
+                                           "over its wall time; f32-input MFMA peak" + ("; fp16-operand GEMMs: priced against the f32 peak all the same" if args.fp16 else ""))
         out = dict(
             metric="env-steps/s (whole job): on-device rollout + GAE + PPO update", value=value, unit="env-steps/s",
             n_gpus=world, steps=K, warmup=args.warmup, ms_per_step=elapsed / K * 1e3, higher_is_better=True, scaling="weak",

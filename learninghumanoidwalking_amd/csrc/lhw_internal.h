@@ -56,7 +56,7 @@ struct MlpStripFwd {
   const float *w1t, *b1, *w2t, *b2, *w3t, *b3;   // TRANSPOSED weights ([in][out]: W1^T [Dp][256], W2^T [256][256], W3^T [256][Op]) from mlp_strip_prepare
   const float* x; int ldx;                   // [R][ldx] inputs (Dp used columns)
   int Dp, O, Op, R;
-  float *h1, *h2, *y;                        // [R][256], [R][256], [R][Op]
+  float *h1, *h2, *y;                        // [R][256], [R][256], [R][Op]; h1 / h2 may be NULL (inference: not written to HBM)
   // optional fusions for rollout inference (all NULL / 0 otherwise):
   const float *in_mean = nullptr, *in_std = nullptr; int in_dim = 0;   // x holds RAW observations [R][ldx = in_dim]: the slab is staged
                                                                       // as (x - mean) / std for columns < in_dim, zero up to Dp

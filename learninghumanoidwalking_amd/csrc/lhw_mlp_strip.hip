@@ -167,7 +167,7 @@ __device__ __forceinline__ void store_act_t(StripLds<C>& L, const f32x16 (&acc)[
           v.z = (live && mk[i][g].z > 0.f) ? v.z : 0.f; v.w = (live && mk[i][g].w > 0.f) ? v.w : 0.f;
         }
         if (TO_SLAB) { L.S[n][row] = v.x; L.S[n + 1][row] = v.y; L.S[n + 2][row] = v.z; L.S[n + 3][row] = v.w; }
-        if (live) *reinterpret_cast<float4*>(out + (size_t)(row0 + row) * SH + n) = v;
+        if (live && out) *reinterpret_cast<float4*>(out + (size_t)(row0 + row) * SH + n) = v;   // (out == NULL: inference, the hidden layers stay in LDS)
       }
     }
   }

@@ -487,11 +487,11 @@ static int strip_mode() {
   return m;
 }
 static void mlp_forward(const MlpLayout& L, const float* theta, const float* x, int ldx, int R, float* h1, float* h2,
-                        float* y, hipStream_t s, int half = 0, float* strip_wt = nullptr, bool wt_ready = false) {
+                        float* y, hipStream_t s, int half = 0, float* strip_wt = nullptr, bool wt_ready = false, bool keep_hidden = true) {
   if (strip_wt && !half && mlp_strip_supported(L.H, L.Dp, L.O, L.Op)) {   // one launch, h1 / h2 stay in LDS between the layers
     if (!wt_ready) mlp_strip_prepare(theta + L.w1, theta + L.w2, theta + L.w3, L.Dp, L.O, L.Op, strip_wt, s);   // [in][out] copies of the weights
     MlpStripFwd a{strip_wt, theta + L.b1, strip_wt + (size_t)L.Dp * L.H, theta + L.b2, strip_wt + (size_t)L.Dp * L.H + (size_t)L.H * L.H,
-                  theta + L.b3, x, ldx, L.Dp, L.O, L.Op, R, h1, h2, y};
+                  theta + L.b3, x, ldx, L.Dp, L.O, L.Op, R, keep_hidden ? h1 : nullptr, keep_hidden ? h2 : nullptr, y};   // (inference: h1 / h2 never leave LDS)
     mlp_strip_forward(a, s);
     return;
   }
@@ -752,9 +752,17 @@ __global__ void entropy_grad_kernel(const float* __restrict__ stdv, int A, float
 
 // sum of squares of a flat range (grad norm), with pre-scale: per-block partials (fixed grid), summed in block order
 #define SUMSQ_BLOCKS 128
-__global__ void __launch_bounds__(256) sumsq_kernel(const float* __restrict__ g, size_t n, float scale, float* __restrict__ part) {
+// clip_grad_norm_ (coef = max_norm/(norm+1e-6), applied only if < 1) + torch.optim.Adam step; zeroes the gradient
+// The two parameter groups (actor [+ stds], critic) in two launches instead of six: the per-block sums of squares of both groups
+// from one grid, and one Adam grid over both groups whose blocks each add their group's SUMSQ_BLOCKS partials in the order
+// sumsq_final_kernel used (same bits), instead of waiting for a one-thread launch per group to do it.
+__global__ void __launch_bounds__(256) sumsq2_kernel(const float* __restrict__ g0, size_t n0, const float* __restrict__ g1, size_t n1, float scale,
+                                                     float* __restrict__ part /* [2][SUMSQ_BLOCKS] */) {
+  const int grp = blockIdx.x / SUMSQ_BLOCKS, b = blockIdx.x - grp * SUMSQ_BLOCKS;
+  const float* __restrict__ g = grp ? g1 : g0;
+  const size_t n = grp ? n1 : n0;
   float s = 0.f;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+  for (size_t i = (size_t)b * blockDim.x + threadIdx.x; i < n; i += (size_t)SUMSQ_BLOCKS * blockDim.x) {
     float v = g[i] * scale;
     s += v * v;
   }
@@ -765,31 +773,33 @@ __global__ void __launch_bounds__(256) sumsq_kernel(const float* __restrict__ g,
   __syncthreads();
   if (threadIdx.x == 0) part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
-__global__ void sumsq_final_kernel(const float* __restrict__ part, int n, float* __restrict__ out) {
+__global__ void __launch_bounds__(256) adam2_kernel(float* __restrict__ theta, float* __restrict__ grad, float* __restrict__ m, float* __restrict__ v,
+                                                    size_t n0, size_t off1, size_t n1, int blocks0, float gscale, const float* __restrict__ part,
+                                                    float* __restrict__ normsq_out /* [2] */, float max_norm, float lr, float beta1, float beta2,
+                                                    float eps, float bc1, float bc2sqrt) {
+  const int grp = (int)blockIdx.x >= blocks0 ? 1 : 0;
+  __shared__ float nsq;
+  LHW_LDS_POISON(nsq);
   if (threadIdx.x == 0) {
     float s = 0.f;
-    for (int b = 0; b < n; b++) s += part[b];
-    *out = s;
+    for (int b = 0; b < SUMSQ_BLOCKS; b++) s += part[grp * SUMSQ_BLOCKS + b];
+    nsq = s;
+    if ((int)blockIdx.x == (grp ? blocks0 : 0)) normsq_out[grp] = s;
   }
-}
-
-// clip_grad_norm_ (coef = max_norm/(norm+1e-6), applied only if < 1) + torch.optim.Adam step; zeroes the gradient
-__global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ theta, float* __restrict__ grad, float* __restrict__ m,
-                                                   float* __restrict__ v, size_t n, float gscale, const float* __restrict__ normsq,
-                                                   float max_norm, float lr, float beta1, float beta2, float eps, float bc1,
-                                                   float bc2sqrt) {
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  float norm = sqrtf(*normsq);
+  __syncthreads();
+  const size_t i = (size_t)((int)blockIdx.x - (grp ? blocks0 : 0)) * blockDim.x + threadIdx.x;
+  if (i >= (grp ? n1 : n0)) return;
+  const size_t e = (grp ? off1 : 0) + i;
+  float norm = sqrtf(nsq);
   float coef = max_norm / (norm + 1e-6f);
   coef = coef < 1.f ? coef : 1.f;
-  float g = grad[i] * gscale * coef;
-  float mi = beta1 * m[i] + (1.f - beta1) * g;
-  float vi = beta2 * v[i] + (1.f - beta2) * g * g;
-  m[i] = mi; v[i] = vi;
+  float g = grad[e] * gscale * coef;
+  float mi = beta1 * m[e] + (1.f - beta1) * g;
+  float vi = beta2 * v[e] + (1.f - beta2) * g * g;
+  m[e] = mi; v[e] = vi;
   float denom = sqrtf(vi) / bc2sqrt + eps;
-  theta[i] -= (lr / bc1) * (mi / denom);
-  grad[i] = 0.f;
+  theta[e] -= (lr / bc1) * (mi / denom);
+  grad[e] = 0.f;
 }
 
 // GAE(lambda) over a time-major rollout, one lane per env, float64 accumulation
@@ -1037,7 +1047,7 @@ static int ppo_forward_impl(LhwPpo* p, const float* theta, const float* obs, int
     const float* th = theta + p->off_actor;
     if (!wt_ready) mlp_strip_prepare(th + La.w1, th + La.w2, th + La.w3, La.Dp, La.O, La.Op, wta, s);
     MlpStripFwd a{wta, th + La.b1, wta + (size_t)La.Dp * La.H, th + La.b2, wta + (size_t)La.Dp * La.H + (size_t)La.H * La.H, th + La.b3,
-                  obs, p->D, La.Dp, La.O, La.Op, (int)N, h1a, h2a, ya};
+                  obs, p->D, La.Dp, La.O, La.Op, (int)N, nullptr, nullptr, ya};
     a.in_mean = obs_mean; a.in_std = obs_std; a.in_dim = p->D;
     a.stdv = theta + p->off_std; a.act = act; a.logp = logp;
     a.seed = seed; a.env_base = env_id_base; a.counter = counter; a.deterministic = deterministic;
@@ -1048,7 +1058,7 @@ static int ppo_forward_impl(LhwPpo* p, const float* theta, const float* obs, int
   hipLaunchKernelGGL(normalize_kernel, dim3((n + 255) / 256), dim3(256), 0, s, obs, p->D, p->la.Dp, (size_t)N, obs_mean, obs_std,
                      xb, (float*)nullptr, (const int*)nullptr, (const float*)nullptr);
   if (act || mu) {
-    mlp_forward(p->la, theta + p->off_actor, xb, p->la.Dp, (int)N, h1a, h2a, ya, s, p->infer_half, wta, wt_ready);
+    mlp_forward(p->la, theta + p->off_actor, xb, p->la.Dp, (int)N, h1a, h2a, ya, s, p->infer_half, wta, wt_ready, false);
     if (mu) HIPCHK(hipMemcpy2DAsync(mu, sizeof(float) * p->A, ya, sizeof(float) * p->la.Op, sizeof(float) * p->A, N, hipMemcpyDeviceToDevice, s));
     if (act) {
       if (!logp) return lhw_fail(LHW_ERR_ARG, "logp required with act");
@@ -1057,7 +1067,7 @@ static int ppo_forward_impl(LhwPpo* p, const float* theta, const float* obs, int
     }
   }
   if (value) {
-    mlp_forward(p->lc, theta + p->off_critic, xb, p->la.Dp, (int)N, h1c, h2c, yc, s, p->infer_half, wtc, wt_ready);
+    mlp_forward(p->lc, theta + p->off_critic, xb, p->la.Dp, (int)N, h1c, h2c, yc, s, p->infer_half, wtc, wt_ready, false);
     HIPCHK(hipMemcpy2DAsync(value, sizeof(float), yc, sizeof(float) * 4, sizeof(float), N, hipMemcpyDeviceToDevice, s));
   }
   HIPCHK(hipGetLastError());
@@ -1240,16 +1250,11 @@ extern "C" int lhw_ppo_grad(LhwPpo* p, const float* theta, float* grad, const fl
 static void clip_and_adam(float* theta, float* grad, float* adam_m, float* adam_v, size_t na, size_t off_critic, size_t nc,
                           int64_t step, float grad_scale, float* norm_part, float* stats, float grad_clip, float lr, float beta1,
                           float beta2, float adam_eps, hipStream_t s) {
-  hipLaunchKernelGGL(sumsq_kernel, dim3(SUMSQ_BLOCKS), dim3(256), 0, s, grad, na, grad_scale, norm_part);
-  hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(64), 0, s, norm_part, SUMSQ_BLOCKS, stats + 8);
-  hipLaunchKernelGGL(sumsq_kernel, dim3(SUMSQ_BLOCKS), dim3(256), 0, s, grad + off_critic, nc, grad_scale, norm_part + SUMSQ_BLOCKS);
-  hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(64), 0, s, norm_part + SUMSQ_BLOCKS, SUMSQ_BLOCKS, stats + 9);
   const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
-  hipLaunchKernelGGL(adam_kernel, dim3((na + 255) / 256), dim3(256), 0, s, theta, grad, adam_m, adam_v, na, grad_scale, stats + 8,
-                     grad_clip, lr, beta1, beta2, adam_eps, bc1, sqrtf(bc2));
-  hipLaunchKernelGGL(adam_kernel, dim3((nc + 255) / 256), dim3(256), 0, s, theta + off_critic, grad + off_critic,
-                     adam_m + off_critic, adam_v + off_critic, nc, grad_scale, stats + 9, grad_clip, lr, beta1, beta2, adam_eps, bc1,
-                     sqrtf(bc2));
+  const int blocks0 = (int)((na + 255) / 256), blocks1 = (int)((nc + 255) / 256);
+  hipLaunchKernelGGL(sumsq2_kernel, dim3(2 * SUMSQ_BLOCKS), dim3(256), 0, s, grad, na, grad + off_critic, nc, grad_scale, norm_part);
+  hipLaunchKernelGGL(adam2_kernel, dim3(blocks0 + blocks1), dim3(256), 0, s, theta, grad, adam_m, adam_v, na, off_critic, nc, blocks0, grad_scale,
+                     norm_part, stats + 8, grad_clip, lr, beta1, beta2, adam_eps, bc1, sqrtf(bc2));
 }
 
 // clip_grad_norm_ on the actor and critic parameter groups separately, then one Adam step each; zeroes grad.

@@ -66,6 +66,8 @@ def test_full_iteration_matches_oracle_chain(env_name):
         o_vfinal = orc.value(T_(cur)).numpy().reshape(N)
         o_logp = orc.log_prob(T_(o_obs.reshape(T * N, -1)), T_(g_act.reshape(T * N, -1))).numpy().reshape(T, N)
     np.testing.assert_allclose(g_val, o_val, rtol=1e-3, atol=2e-4)
+    used = ((g_done & 2) != 0) & ((g_done & 1) == 0)       # V(terminal obs) is evaluated where GAE bootstraps from it (truncations) ...
+    o_vterm = np.where(used, o_vterm, 0.0)                  # ... and is 0 (unread) everywhere else
     np.testing.assert_allclose(g_vterm, o_vterm, rtol=1e-3, atol=2e-4)
     np.testing.assert_allclose(g_vfinal, o_vfinal, rtol=1e-3, atol=2e-4)
     np.testing.assert_allclose(g_logp, o_logp, rtol=1e-3, atol=2e-3)
