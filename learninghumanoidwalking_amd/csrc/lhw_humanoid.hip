@@ -230,6 +230,8 @@ struct HState {
   long long* prof; // optional [16] per-phase cycle counters accumulated by env 0 (NULL = off)
   double* tin;     // optional [N][LHW_TASK_INPUT_DIM]: the task layer's inputs of the last control step (lhw_env_enable_task_inputs)
   long long* wave_cyc;  // optional [N] shader-clock cycles the env's group spent in the last control-step launch (NULL = off)
+  double* bigd;    // stepping task: [N][BW_DOUBLES] / [N][BW_INTS] workspace of the many-contact path (NULL for the other tasks)
+  int* bigi;
 };
 #define PROF_BEGIN() long long prof_t = (st_prof && lane == 0) ? (long long)clock64() : 0   // lane = lane within the group
 #ifdef LHW_ASM_MARKS   // (analysis builds: phase boundaries as comments in the ISA listing)
@@ -246,6 +248,55 @@ struct HState {
       prof_t = now_;                                                     \
     }                                                                    \
   } while (0)
+
+// Many contacts in the stepping task (one env per wave).  Every walk mode but FORWARD leaves the 20 terrain boxes coplanar with the
+// floor (tasks/stepping_task.py:320-334), so a foot rests on the floor AND on every box under it: 16 (STANDING) to ~110 (LATERAL)
+// contacts per env, against 16 whose pyramid rows fit one lane each.  Two steps deal with them:
+//  1. MERGING.  Most of those contacts are copies of one another -- a foot corner that lies inside twelve overlapping boxes yields
+//     twelve contacts with bitwise the same distance, position and frame (106 contacts, 20 distinct ones in LATERAL mode).  k
+//     identical rows of the soft-constraint problem are ONE row with k times the D (cost k (1/2) D r^2, total force k f): the
+//     collision stage writes all contacts of such a sub-step to an HBM workspace ("raw" region), merges exact duplicates of the
+//     same pair class, and hands the distinct ones on with their multiplicity.  If at most 16 remain -- nearly always -- they go
+//     back into the LDS arrays and the ordinary one-row-per-lane solver runs, with D scaled by the multiplicity.
+//  2. MANY DISTINCT CONTACTS (more than 16 after merging): they stay in the workspace ("unique" region) with the per-row solver
+//     state, and newton_big walks the rows in chunks of 64.
+#define NCR 192                            // raw contacts per sub-step (beyond: dropped and counted as a contact overflow)
+#define AR_DIST 0
+#define AR_POS (AR_DIST + NCR)
+#define AR_FRAME (AR_POS + 3 * NCR)
+#define AR_DOUBLES (AR_FRAME + 9 * NCR)
+#define ARI_G1 0
+#define ARI_G2 (ARI_G1 + NCR)
+#define ARI_PAIR (ARI_G2 + NCR)
+#define ARI_FIRST (ARI_PAIR + NCR)         // index of the first contact this one is a copy of (itself: distinct)
+#define ARI_RANK (ARI_FIRST + NCR)         // distinct contacts: position among the distinct ones
+#define ARI_COUNT (ARI_RANK + NCR)         // by rank: multiplicity
+#define AR_INTS (ARI_COUNT + NCR)
+#define NCB 64                             // distinct contacts the many-contact solver holds (4 NCB rows)
+#define NRB (4 * NCB)
+#define BW_DIST AR_DOUBLES
+#define BW_POS (BW_DIST + NCB)
+#define BW_FRAME (BW_POS + 3 * NCB)
+#define BW_MU (BW_FRAME + 9 * NCB)
+#define BW_MARGIN (BW_MU + NCB)
+#define BW_TRAN (BW_MARGIN + NCB)
+#define BW_SOLREF (BW_TRAN + NCB)
+#define BW_SOLIMP (BW_SOLREF + 2 * NCB)
+#define BW_MULT (BW_SOLIMP + 5 * NCB)      // multiplicity of the contact
+#define BW_D (BW_MULT + NCB)               // per row (4 c .. 4 c + 3: the pyramid edges of contact c): multiplicity / R; 0: not a row
+#define BW_AREF (BW_D + NRB)
+#define BW_JAR (BW_AREF + NRB)            // J a - aref at the current iterate
+#define BW_JV (BW_JAR + NRB)              // J search
+#define BW_FRC (BW_JV + NRB)              // efc_force (of the merged row: the sum over its copies)
+#define BW_DACT (BW_FRC + NRB)            // D of the active rows, 0 for the others
+#define BW_DOUBLES (BW_DACT + NRB)
+#define BWI_G1 AR_INTS
+#define BWI_G2 (BWI_G1 + NCB)
+#define BWI_PAIR (BWI_G2 + NCB)
+#define BWI_DIM (BWI_PAIR + NCB)
+#define BWI_XM (BWI_DIM + NCB)
+#define BWI_M2 (BWI_XM + NCB)
+#define BW_INTS (BWI_M2 + NCB)
 
 struct HumanoidEnv {
   HModel m;
@@ -307,11 +358,28 @@ constexpr int even(int a) { return (a + 1) & ~1; }
 // The layout is a template of the group width (contact / row capacity), the dof width, the geom and body capacities and the
 // task features that need extra state, so that the two-envs-per-wave kernels of the walking / standing tasks stay within
 // 10 KB per env: eight wavefronts = all 4096 envs of the headline batch are resident at once on the 256 CUs.
+// LDS state that only the stepping-task layouts carry (an empty base otherwise: the walking / standing layouts are sized to the
+// byte for eight workgroups per CU)
+template <bool ON, int NC_T>
+struct StepLds {
+  static constexpr int NCK_ = 32;
+  double con_mult[NC_T];   // number of identical contacts this one stands for (scales the D of its rows; fwd_collision's merge)
+  // many-contact path: number of distinct contacts of the last forward pass kept in the HBM workspace (0: they are in the LDS
+  // arrays) and what the task layer reads off them (robot_interface.py:262-325, 472-484)
+  int nbig, big_selfcol, big_anyfoot;
+  double big_grf_r, big_grf_l, big_cz;
+  // newton_big: position / frame / friction and dof masks / condim of up to NCK contacts, cached for the rebuilds of their rows
+  double bk_rec[NCK_ * 13];
+  int bk_i[NCK_ * 3];
+};
+template <int NC_T> struct StepLds<false, NC_T> { static constexpr int NCK_ = 1; };
+
 template <int W_T, bool PRM_T, int NV_T, int NG_T, int NB_T, bool STEP_T>
-struct LdsT {
+struct LdsT : StepLds<STEP_T, W_T / 4> {
   typedef LdsT L;
   static constexpr int W_ = W_T, NC_ = W_T / 4, NE_ = W_T, NV_ = NV_T, NG_ = NG_T, NB_ = NB_T, TRI_ = NV_T * (NV_T + 1) / 2;
   static constexpr bool PRM_ = PRM_T;   // per-env model parameters are staged in LDS (else read from the model tables)
+  static constexpr bool STEP_ = STEP_T;
   static constexpr int U_CDOF_ = 0, U_CINERT_ = U_CDOF_ + NV_T * 6, X_ = U_CINERT_ + NB_T * 10;
   static constexpr int U_XMAT_ = X_, U_XIPOS_ = U_XMAT_ + NB_T * 9, U_XANCHOR_ = U_XIPOS_ + NB_T * 3, U_XAXIS_ = U_XANCHOR_ + NJ * 3,
                        U_GPOS_ = U_XAXIS_ + NJ * 3, U_GMAT_ = U_GPOS_ + NG_T * 3, END_A_ = U_GMAT_ + NG_T * 9;
@@ -1030,14 +1098,17 @@ template <class L>
 struct ConSink {
   L* S;
   int base, n, write, g1, g2, pair;
+  double* gd = nullptr;   // non-NULL: the contacts go to the raw region of the HBM workspace (AR_* / ARI_* layout), capacity NCR
+  int* gi = nullptr;
   __device__ __forceinline__ void emit(double dist, const double* pos, const double* nrm, const double* tan) {
     if (write) {
       const int c = base + n;
-      if (c < NC) {
+      if (c < (gd ? NCR : NC)) {
         L& Z = *S;
-        Z.U[U_CDIST + c] = dist;
         double f[9];
-        for (int a = 0; a < 3; a++) { Z.con_pos[3 * c + a] = pos[a]; f[a] = nrm[a]; f[3 + a] = tan[a]; }
+        for (int a = 0; a < 3; a++) { f[a] = nrm[a]; f[3 + a] = tan[a]; }
+        if (gd) { gd[AR_DIST + c] = dist; for (int a = 0; a < 3; a++) gd[AR_POS + 3 * c + a] = pos[a]; }
+        else { Z.U[U_CDIST + c] = dist; for (int a = 0; a < 3; a++) Z.con_pos[3 * c + a] = pos[a]; }
         // mju_makeFrame
         normalize3(f);
         if (sqrt(dot3(f + 3, f + 3)) < 0.5) {
@@ -1048,8 +1119,13 @@ struct ConSink {
         for (int a = 0; a < 3; a++) f[3 + a] -= tt * f[a];
         normalize3(f + 3);
         cross3(f + 6, f, f + 3);
-        for (int a = 0; a < 9; a++) Z.U[U_CFRAME + 9 * c + a] = f[a];
-        Z.con_g1[c] = g1; Z.con_g2[c] = g2; Z.con_pair[c] = pair;
+        if (gd) {
+          for (int a = 0; a < 9; a++) gd[AR_FRAME + 9 * c + a] = f[a];
+          gi[ARI_G1 + c] = g1; gi[ARI_G2 + c] = g2; gi[ARI_PAIR + c] = pair;
+        } else {
+          for (int a = 0; a < 9; a++) Z.U[U_CFRAME + 9 * c + a] = f[a];
+          Z.con_g1[c] = g1; Z.con_g2[c] = g2; Z.con_pair[c] = pair;
+        }
       }
     }
     n++;
@@ -1453,7 +1529,7 @@ __device__ void collide_pair(ConSink<L>& k, const HModel& m, const L& S, int g1,
 }
 
 template <bool BOXBOX, class L>
-__device__ void fwd_collision(const HModel& m, const HParams& p, L& S, int lane, const double* ter) {
+__device__ void fwd_collision(const HModel& m, const HParams& p, L& S, int lane, const double* ter, double* bd, int* bi) {
   if (lane < m.ngeom) {
     const int g = lane, b = m.geom_i[GIS * (g) + GI_BODY];
     double gp[3] = {m.geom_d[GDS * (g) + GD_POS], m.geom_d[GDS * (g) + GD_POS + 1], m.geom_d[GDS * (g) + GD_POS + 2]}, t[3];
@@ -1482,10 +1558,8 @@ __device__ void fwd_collision(const HModel& m, const HParams& p, L& S, int lane,
   if (have) {
     g1 = m.pair_i[PIS * lane]; g2 = m.pair_i[PIS * lane + 1];
     margin = m.pair_d[PDS * lane];
-    // boxes only collide while the floor is lowered (KNOWN DEVIATION, DESIGN.md sections 2 and 7: coplanar floor + box contacts
-    // of the reference would need more constraint rows than a wave has lanes)
-    if (BOXBOX && ter && ter[T_FLOOR] == 0.0 && ((g1 >= p.box_geom0 && g1 < p.box_geom0 + p.nbox) || (g2 >= p.box_geom0 && g2 < p.box_geom0 + p.nbox)))
-      have = false;
+    // (the terrain boxes collide in every walk mode, as the reference leaves them -- coplanar with the floor outside FORWARD mode,
+    // tasks/stepping_task.py:320-334: an env with more than NC contacts takes the many-contact path below)
   }
   ConSink<L> k{&S, 0, 0, 0, g1, g2, lane};
   // box-box pairs (stepping-task kernels only) run the SAT + clipping once, in the counting pass, and replay the recorded
@@ -1510,15 +1584,109 @@ __device__ void fwd_collision(const HModel& m, const HParams& p, L& S, int lane,
   const int mine = k.n;   // (pairs without a contact skip the writing pass: most of them, most of the time)
   const int base = gscan<L::W_>(k.n, &total) - k.n;
   k.base = base; k.n = 0; k.write = 1;
-  if (have && !boxpair && !primbox && mine > 0 && base < NC) collide_pair(k, m, S, g1, g2, margin);
-  if (m.has_primbox) { if (primbox && mine > 0 && base < NC) collide_primbox(k, m, S, g1, g2, margin); }
+  // more contacts than the group has row lanes for (stepping task, one env per wave): all of them go to the raw region of the HBM
+  // workspace, exact copies are merged there, and the distinct ones come back with their multiplicity (see the workspace layout)
+  bool big = false;
+  if constexpr (BOXBOX && L::W_ == 64) big = bd != nullptr && total > NC;
+  const int cap = big ? NCR : NC;
+  if (big) { k.gd = bd; k.gi = bi; }
+  if (have && !boxpair && !primbox && mine > 0 && base < cap) collide_pair(k, m, S, g1, g2, margin);
+  if (m.has_primbox) { if (primbox && mine > 0 && base < cap) collide_primbox(k, m, S, g1, g2, margin); }
   if constexpr (BOXBOX) {
-    if (boxpair && base < NC) {
+    if (boxpair && base < cap) {
       const double zero[3] = {0, 0, 0};
       for (int q = 0; q < br.cnt; q++) k.emit(br.dist[q], &br.pos[3 * q], br.n, zero);
     }
   }
-  if (lane == 0) { S.ncon = min(total, NC); if (total > NC) S.overflow = 1; }   // sticky for the whole control step
+  int ndist = min(total, NC);   // contacts the LDS arrays will hold
+  bool merged = false;
+  if constexpr (BOXBOX && L::W_ == 64) {
+    if (big) {
+      constexpr int W = L::W_;
+      __syncthreads();   // (one wave per workgroup: orders the workspace writes above before the reads below)
+      const int nr = min(total, NCR);
+      // first[c]: the earliest contact c is a bitwise copy of -- same pair class (contact parameters, dof masks and the roles of
+      // the two bodies in the task's contact queries: humanoid_create), same distance, position and frame
+      for (int c = lane; c < nr; c += W) { bi[ARI_RANK + c] = m.pair_i[PIS * bi[ARI_PAIR + c] + 5]; bi[ARI_COUNT + c] = 0; }   // (class, parked in the rank slot)
+      __syncthreads();
+      for (int c = lane; c < nr; c += W) {
+        const int cls = bi[ARI_RANK + c];
+        const double dc = bd[AR_DIST + c];
+        int f = c;
+        // candidates in batches of eight: the class and distance loads of a batch are independent of one another (one memory
+        // round trip per batch instead of one per candidate); nearly every candidate fails on the distance
+        for (int e0 = 0; e0 < c && f == c; e0 += 8) {
+          int cl[8];
+          double de[8];
+#pragma unroll
+          for (int j = 0; j < 8; j++) { const int e = min(e0 + j, c); cl[j] = bi[ARI_RANK + e]; de[j] = bd[AR_DIST + e]; }
+#pragma unroll
+          for (int j = 0; j < 8; j++) {
+            const int e = e0 + j;
+            if (f != c || e >= c || cl[j] != cls || de[j] != dc) continue;
+            bool same = true;
+            for (int a = 0; a < 3; a++) same = same && bd[AR_POS + 3 * e + a] == bd[AR_POS + 3 * c + a];
+            for (int a = 0; a < 9; a++) same = same && bd[AR_FRAME + 9 * e + a] == bd[AR_FRAME + 9 * c + a];
+            if (same) f = e;
+          }
+        }
+        bi[ARI_FIRST + c] = f;
+      }
+      __syncthreads();
+      // rank of the distinct contacts (in contact order), multiplicities by rank
+      int nu = 0;
+      for (int c0 = 0; c0 < nr; c0 += W) {
+        const int c = c0 + lane;
+        const bool uq = c < nr && bi[ARI_FIRST + c] == c;
+        const unsigned long long bal = __ballot(uq);
+        if (uq) bi[ARI_RANK + c] = nu + __popcll(bal & ((1ull << lane) - 1ull));
+        nu += __popcll(bal);
+      }
+      __syncthreads();
+      for (int c = lane; c < nr; c += W) atomicAdd(&bi[ARI_COUNT + bi[ARI_RANK + bi[ARI_FIRST + c]]], 1);   // (integer: order-free)
+      __syncthreads();
+      merged = true;
+      ndist = nu;
+      const bool tolds = nu <= NC;
+      // the distinct contacts, in contact order: back into the LDS arrays if they fit the row lanes, else into the unique region
+      for (int c = lane; c < nr; c += W) {
+        if (bi[ARI_FIRST + c] != c) continue;
+        const int u = bi[ARI_RANK + c];
+        const double mult = (double)bi[ARI_COUNT + u];
+        if (tolds) {
+          S.U[U_CDIST + u] = bd[AR_DIST + c];
+          for (int a = 0; a < 3; a++) S.con_pos[3 * u + a] = bd[AR_POS + 3 * c + a];
+          for (int a = 0; a < 9; a++) S.U[U_CFRAME + 9 * u + a] = bd[AR_FRAME + 9 * c + a];
+          S.con_g1[u] = bi[ARI_G1 + c]; S.con_g2[u] = bi[ARI_G2 + c]; S.con_pair[u] = bi[ARI_PAIR + c];
+          if constexpr (L::STEP_) S.con_mult[u] = mult;
+        } else if (u < NCB) {
+          const int q = bi[ARI_PAIR + c];
+          const double* pd = m.pair_d + PDS * q;
+          const double incm = pd[1], dist = bd[AR_DIST + c];
+          bd[BW_DIST + u] = dist;
+          for (int a = 0; a < 3; a++) bd[BW_POS + 3 * u + a] = bd[AR_POS + 3 * c + a];
+          for (int a = 0; a < 9; a++) bd[BW_FRAME + 9 * u + a] = bd[AR_FRAME + 9 * c + a];
+          bi[BWI_G1 + u] = bi[ARI_G1 + c]; bi[BWI_G2 + u] = bi[ARI_G2 + c]; bi[BWI_PAIR + u] = q;
+          bd[BW_MULT + u] = mult;
+          // mj_contactParam, from the pair tables
+          bi[BWI_XM + u] = m.pair_i[PIS * q + 3]; bi[BWI_M2 + u] = m.pair_i[PIS * q + 4];
+          bd[BW_TRAN + u] = pd[10];
+          bd[BW_MARGIN + u] = incm;
+          bi[BWI_DIM + u] = (dist >= incm) ? 0 : m.pair_i[PIS * q + 2];
+          bd[BW_MU + u] = pd[2];
+          bd[BW_SOLREF + 2 * u] = pd[3]; bd[BW_SOLREF + 2 * u + 1] = pd[4];
+          for (int a = 0; a < 5; a++) bd[BW_SOLIMP + 5 * u + a] = pd[5 + a];
+        }
+      }
+      __syncthreads();
+    }
+  }
+  if (lane == 0) {
+    const bool inlds = ndist <= NC;
+    S.ncon = inlds ? ndist : 0;
+    if constexpr (L::STEP_) S.nbig = inlds ? 0 : min(ndist, NCB);
+    if (total > cap || (!inlds && ndist > NCB)) S.overflow = 1;   // sticky for the whole control step
+  }
   SYNC();
   // mj_contactParam (lane = contact): a function of the geom pair, evaluated at create (humanoid_create: pair_d / pair_i)
   if (lane < S.ncon) {
@@ -1532,6 +1700,7 @@ __device__ void fwd_collision(const HModel& m, const HParams& p, L& S, int lane,
     S.con_mu[c] = pd[2];
     S.U[U_CSOLREF + 2 * c] = pd[3]; S.U[U_CSOLREF + 2 * c + 1] = pd[4];
     for (int a = 0; a < 5; a++) S.U[U_CSOLIMP + 5 * c + a] = pd[5 + a];
+    if constexpr (L::STEP_) { if (!merged) S.con_mult[c] = 1.0; }
   }
   SYNC();
 }
@@ -1596,45 +1765,15 @@ __device__ __forceinline__ void row_deriv(bool valid, double fl, double D, doubl
   *d1 = a; *d2 = b;
 }
 
-// K^-1 x for a Hessian whose contacts couple the two chains (no block structure left): dense Cholesky with one dof per lane.
-// It runs only in sub-steps with leg-leg contacts -- but in a batch of thousands of envs SOME wave has one in nearly every
-// launch, and a launch lasts as long as its slowest wave: the first version (rolled loops, every operand through LDS, the
-// chain A x chain B block summed entry by entry over all rows) took ~50 k cycles per solve and made those waves twice as long
-// as the average one (scripts/tail_waves.py).  This version keeps the lane's row of the factor in registers (statically
-// indexed: the column loops are fully unrolled), reads the pivot row as LDS broadcasts that do not sit on the dependency
-// chain, carries the right-hand side through the factorisation (no separate forward substitution) and assembles the A x B
-// block from the active rows only.  Packed lower triangle of the factor in LDS (the U_L region, which the chain solver leaves
-// idle).  Hrow / hd: the chain-layout row of M + J^T D J (root + own-chain columns) as assembled for chain_solve;
-// active_rows: the env's rows with a non-zero D (group_rows).
+// Dense Cholesky + solve with one dof per lane: `row` = this lane's row of the symmetric matrix by dof index (lower triangle: only the
+// columns c < d are read), `hd` its diagonal entry, `x` its right-hand side element; returns its element of the solution.  The factor
+// row stays in registers (statically indexed: the column loops are fully unrolled), the pivot row is read as LDS broadcasts off the
+// dependency chain, the right-hand side is carried through the factorisation.  Packed lower triangle of the factor in the U_L region.
 template <class L>
-__device__ __forceinline__ double dense_lds_solve(L& S, const double (&Hrow)[NR], double hd, double x, int dof, bool prim, int coff,
-                                                  typename RowMask<L::W_>::type active_rows) {
+__device__ __forceinline__ double dense_factor_solve(L& S, double (&row)[NV], const double hd, const double x, const int dof, const bool prim) {
   double* A = S.U + U_L;
   double* xs = S.U + U_DG;
   const int d = dof >= 0 ? dof : 0;
-  const bool chainB = prim && d >= 6 + NCH;
-  // row d of H by dof index (lower triangle: only columns c <= d are used); the diagonal travels separately
-  double row[NV];
-#pragma unroll
-  for (int c = 0; c < 6; c++) row[c] = Hrow[c];
-  {
-    // chain B rows: the chain A columns carry the coupling J^T D J only -- summed over the active rows
-    double xb[NCH];
-#pragma unroll
-    for (int c = 0; c < NCH; c++) xb[c] = 0.0;
-    while (active_rows) {
-      const int r = first_row(active_rows);
-      active_rows &= active_rows - 1;
-      const double cj = S.U[U_DACT + r] * S.U[U_J + r * NV + d];
-#pragma unroll
-      for (int c = 0; c < NCH; c++) xb[c] += cj * S.U[U_J + r * NV + 6 + c];
-    }
-#pragma unroll
-    for (int c = 0; c < NCH; c++) {
-      row[6 + c] = chainB ? xb[c] : Hrow[6 + c];
-      row[6 + NCH + c] = chainB ? Hrow[6 + c] : 0.0;
-    }
-  }
   SYNC();
   double y = x;   // right-hand side element, then y = L^-1 b
 #pragma unroll
@@ -1672,13 +1811,350 @@ __device__ __forceinline__ double dense_lds_solve(L& S, const double (&Hrow)[NR]
   return dof >= 0 ? xs[d] : 0.0;
 }
 
+// K^-1 x for a Hessian whose contacts couple the two chains (no block structure left): dense Cholesky with one dof per lane.
+// It runs only in sub-steps with leg-leg contacts -- but in a batch of thousands of envs SOME wave has one in nearly every
+// launch, and a launch lasts as long as its slowest wave: the first version (rolled loops, every operand through LDS, the
+// chain A x chain B block summed entry by entry over all rows) took ~50 k cycles per solve and made those waves twice as long
+// as the average one (scripts/tail_waves.py).  This version keeps the lane's row of the factor in registers (statically
+// indexed: the column loops are fully unrolled), reads the pivot row as LDS broadcasts that do not sit on the dependency
+// chain, carries the right-hand side through the factorisation (no separate forward substitution) and assembles the A x B
+// block from the active rows only.  Packed lower triangle of the factor in LDS (the U_L region, which the chain solver leaves
+// idle).  Hrow / hd: the chain-layout row of M + J^T D J (root + own-chain columns) as assembled for chain_solve;
+// active_rows: the env's rows with a non-zero D (group_rows).
+template <class L>
+__device__ __forceinline__ double dense_lds_solve(L& S, const double (&Hrow)[NR], double hd, double x, int dof, bool prim, int coff,
+                                                  typename RowMask<L::W_>::type active_rows) {
+  const int d = dof >= 0 ? dof : 0;
+  const bool chainB = prim && d >= 6 + NCH;
+  // row d of H by dof index (lower triangle: only columns c <= d are used); the diagonal travels separately
+  double row[NV];
+#pragma unroll
+  for (int c = 0; c < 6; c++) row[c] = Hrow[c];
+  {
+    // chain B rows: the chain A columns carry the coupling J^T D J only -- summed over the active rows
+    double xb[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; c++) xb[c] = 0.0;
+    while (active_rows) {
+      const int r = first_row(active_rows);
+      active_rows &= active_rows - 1;
+      const double cj = S.U[U_DACT + r] * S.U[U_J + r * NV + d];
+#pragma unroll
+      for (int c = 0; c < NCH; c++) xb[c] += cj * S.U[U_J + r * NV + 6 + c];
+    }
+#pragma unroll
+    for (int c = 0; c < NCH; c++) {
+      row[6 + c] = chainB ? xb[c] : Hrow[6 + c];
+      row[6 + NCH + c] = chainB ? Hrow[6 + c] : 0.0;
+    }
+  }
+  return dense_factor_solve<L>(S, row, hd, x, dof, prim);
+}
+
+// ------------------------------------------------------------------------------------------------ many-contact Newton
+// The constraint solve of a sub-step whose contacts live in the HBM workspace (fwd_collision: more than NC contacts; stepping task,
+// one env per wave).  Same problem, same algorithm and the same stopping rules as the in-LDS solver of solve_tail -- primal Newton
+// with exact line search and warm start (engine_solver.c) -- with the rows walked in strides of the 64 lanes instead of one row per
+// lane: Jacobian rows, 1 / R, aref, the residual J a - aref, J search, force and active-D of every row in the workspace; the
+// Hessian M + J^T D J assembled densely (lane = dof, all columns) and factorised by dense_factor_solve.  Also leaves what the task
+// layer reads off the contacts of this forward pass (ground reaction forces, lowest foot contact, self-collision) in S.big_*.
+// Slow by construction (~100 contacts = ~400 rows = seven chunks per sweep, five to six sweeps per sub-step): it exists so that the
+// terrain of the reference is the terrain of the kernel, not to be fast.
+template <class L>
+__device__ __noinline__ void newton_big(const HModel& m, const HParams& p, L& S, const int lane, double* __restrict__ bd, int* __restrict__ bi,
+                                        const int dof, const bool prim, const double (&Mrow)[NR], const double mdiag, const double marm,
+                                        const double fs, const double as, const bool (&uon)[3], const double (&uD)[3],
+                                        const double (&uaref)[3], const double ufl, const bool anyunit, double& qacc_out, double& fcon_out) {
+  constexpr int W = L::W_;
+  const int dd = dof >= 0 ? dof : 0, cp = lane & 15;
+  const int nc = S.nbig, nrow = 4 * nc, nchunk = (nrow + W - 1) / W;
+  auto mprod = [&](double x) {
+    double acc = marm * x;
+    chain_mrow<L, 0>(Mrow, x, acc);
+    if (cp < 6) acc = xhalf_sum(acc);
+    GROUP_SYNC(W);
+    return acc;
+  };
+  // The rows are processed in CHUNKS of W = 64 (16 contacts).  A chunk's Jacobian rows are staged in the LDS region the in-LDS solver
+  // keeps its 64 rows in (U_J, idle on this path) and everything that walks rows one after the other -- J^T f, the Hessian's
+  // J^T D J -- reads them from there, as the in-LDS solver does.  They are REBUILT from the contact records at every staging
+  // (position, frame, friction, dof masks: 13 doubles per contact against 72 for its four rows): the first version walked the rows
+  // in HBM -- a chain of ~400 dependent L2 round trips per product, jvrc_step fell from 1.5 M to 0.08 M env-steps/s -- the second
+  // staged stored rows -- 61 KB per env and sweep, ~30 GB of HBM traffic per control step of 4096 envs: 0.16 M.
+  // rows 4c .. 4c+3 = Jn +- mu Jt1, Jn +- mu Jt2 (condim 1: row 4c = Jn)
+  // (up to NCK contacts -- the usual case: ~20 distinct contacts in LATERAL mode -- keep the 13 doubles and 3 ints a row rebuild
+  // reads in LDS; beyond that the rebuilds read the workspace)
+  constexpr int NCK = L::NCK_;
+  const bool cached = nc <= NCK;
+  if (cached) {
+    for (int i = lane; i < nc * 13; i += W) {
+      const int c = i / 13, a = i - 13 * c;
+      S.bk_rec[i] = a < 3 ? bd[BW_POS + 3 * c + a] : (a < 12 ? bd[BW_FRAME + 9 * c + (a - 3)] : bd[BW_MU + c]);
+    }
+    for (int c = lane; c < nc; c += W) { S.bk_i[3 * c] = bi[BWI_XM + c]; S.bk_i[3 * c + 1] = bi[BWI_M2 + c]; S.bk_i[3 * c + 2] = bi[BWI_DIM + c]; }
+    SYNC();
+  }
+  auto stage = [&](int ch) {
+    const int c0 = ch * (W / 4), ncc = min(W / 4, nc - c0);
+    for (int it = lane; it < (W / 4) * NV; it += W) {
+      const int cl = it / NV, k = it - cl * NV, c = c0 + cl;
+      double j0 = 0, j1 = 0, j2 = 0, j3 = 0;
+      if (cl < ncc) {
+        const unsigned bit = 1u << k;
+        double pos[3], f[9], mu;
+        int xm, m2, dim;
+        if (cached) {
+          const double* rc = &S.bk_rec[13 * c];
+          for (int a = 0; a < 3; a++) pos[a] = rc[a];
+          for (int a = 0; a < 9; a++) f[a] = rc[3 + a];
+          mu = rc[12];
+          xm = S.bk_i[3 * c]; m2 = S.bk_i[3 * c + 1]; dim = S.bk_i[3 * c + 2];
+        } else {
+          for (int a = 0; a < 3; a++) pos[a] = bd[BW_POS + 3 * c + a];
+          for (int a = 0; a < 9; a++) f[a] = bd[BW_FRAME + 9 * c + a];
+          mu = bd[BW_MU + c];
+          xm = bi[BWI_XM + c]; m2 = bi[BWI_M2 + c]; dim = bi[BWI_DIM + c];
+        }
+        const bool in2 = ((unsigned)m2 & bit) != 0;
+        double d[3] = {0, 0, 0};
+        if ((unsigned)xm & bit) {
+          double off[3], t[3];
+          for (int a = 0; a < 3; a++) off[a] = pos[a] - S.com[a];
+          cross3(t, &S.U[U_CDOF + 6 * k], off);
+          const double sg = in2 ? 1.0 : -1.0;
+          for (int a = 0; a < 3; a++) d[a] = sg * (S.U[U_CDOF + 6 * k + 3 + a] + t[a]);
+        }
+        const double jn = dot3(f, d);
+        const bool pyr = dim != 1;
+        const double t1 = mu * dot3(f + 3, d), t2 = mu * dot3(f + 6, d);
+        j0 = pyr ? jn + t1 : jn; j1 = pyr ? jn - t1 : 0.0; j2 = pyr ? jn + t2 : 0.0; j3 = pyr ? jn - t2 : 0.0;
+      }
+      double* Jc = &S.U[U_J + 4 * cl * NV + k];
+      Jc[0] = j0; Jc[NV] = j1; Jc[2 * NV] = j2; Jc[3 * NV] = j3;
+    }
+    SYNC();
+  };
+  auto jrow = [&](const double* v) {   // (this lane's staged row) . v
+    double Jrow[NV];
+#pragma unroll
+    for (int k = 0; k < NV; k += 2) {
+      const double2 ab = *reinterpret_cast<const double2*>(&S.U[U_J + lane * NV + k]);
+      Jrow[k] = ab.x; Jrow[k + 1] = ab.y;
+    }
+    return row_dot<L>(Jrow, v);
+  };
+  // ---- row parameters (lane = row of the chunk): impedance / regulariser / reference acceleration
+  for (int ch = 0; ch < nchunk; ch++) {
+    stage(ch);
+    const int r = ch * W + lane, c = r >> 2, e = r & 3;
+    double D = 0, aref = 0;
+    if (r < nrow) {
+      const int dim = bi[BWI_DIM + c];
+      if (dim == 3 || (dim == 1 && e == 0)) {
+        const double jv0 = jrow(S.qvel);
+        const double tran = bd[BW_TRAN + c], mu = bd[BW_MU + c];
+        double K, B, imp, R;
+        const double diag = dim == 1 ? tran : tran + mu * mu * tran;
+        row_params(m, &bd[BW_SOLREF + 2 * c], &bd[BW_SOLIMP + 5 * c], bd[BW_DIST + c], bd[BW_MARGIN + c], diag, &K, &B, &imp, &R);
+        if (dim == 3) R = fmax(HMINVAL, 2 * mu * mu * R);
+        D = (1 / R) * bd[BW_MULT + c];   // (k identical contacts merged by the collision stage: one row with k times the D)
+        aref = -B * jv0 - K * imp * (bd[BW_DIST + c] - bd[BW_MARGIN + c]);
+      }
+      bd[BW_D + r] = D; bd[BW_AREF + r] = aref;   // D == 0: not a row (its cost, force and derivatives are zero)
+    }
+    SYNC();
+  }
+  __syncthreads();   // (one wave per workgroup: the workspace writes above are visible to the loads below)
+  // unit rows of this lane's dof at acceleration a
+  auto eval_units = [&](double a, double* cost, double* ufrc, double* udact) {
+    double cu = 0, uf = 0, ud = 0;
+    if (anyunit) {
+      double c, f, da;
+      row_eval(uon[0], ufl, uD[0], a - uaref[0], &c, &f, &da); cu += c; uf += f; ud += da;
+      row_eval(uon[1], 0.0, uD[1], a - uaref[1], &c, &f, &da); cu += c; uf += f; ud += da;
+      row_eval(uon[2], 0.0, uD[2], -a - uaref[2], &c, &f, &da); cu += c; uf -= f; ud += da;
+    }
+    *cost = prim ? cu : 0.0; *ufrc = uf; *udact = ud;
+  };
+  const double scale = 1.0 / (m.meaninertia * (NV > 1 ? NV : 1));
+  double qacc = as, fcon = 0;
+  if (!(m.disableflags & (1 << 7))) {   // warm start: cheaper of qacc_warmstart and qacc_smooth
+    const double w = dof >= 0 ? S.qacc[dd] : 0.0;
+    SYNC();
+    if (prim) { S.U[U_VEC + dd] = w; S.U[U_VEC2 + dd] = as; }
+    SYNC();
+    double cw = 0, cs0 = 0;
+    for (int ch = 0; ch < nchunk; ch++) {
+      stage(ch);
+      const int r = ch * W + lane;
+      const double D = r < nrow ? bd[BW_D + r] : 0.0, aref = r < nrow ? bd[BW_AREF + r] : 0.0;
+      const double jw = jrow(S.U + U_VEC), js = jrow(S.U + U_VEC2);
+      double c, f, da;
+      row_eval(D > 0, 0.0, D, jw - aref, &c, &f, &da); cw += c;
+      row_eval(D > 0, 0.0, D, js - aref, &c, &f, &da); cs0 += c;
+      SYNC();
+    }
+    double cu, tu, tv;
+    eval_units(w, &cu, &tu, &tv); cw += cu;
+    eval_units(as, &cu, &tu, &tv); cs0 += cu;
+    const double Ma = mprod(w);
+    if (prim) cw += 0.5 * (Ma - fs) * (w - as);
+    double cs;
+    gsum2<W>(cw, cs0, cw, cs);
+    qacc = (cw > cs) ? as : w;
+  }
+  double cost = 0, oldcost = 0;
+  for (int iter = 0; iter <= m.iterations; iter++) {
+    SYNC();
+    if (prim) S.U[U_VEC + dd] = qacc;
+    SYNC();
+    // one sweep over the rows: residual / force / active-D of every row, J^T f, and the Hessian's J^T D J (dense row of this lane's dof)
+    double row[NV], c = 0, f0 = 0, f1 = 0, f2 = 0, f3 = 0, hd = 0;
+    {
+      const bool chainB = prim && dd >= 6 + NCH;
+#pragma unroll
+      for (int k = 0; k < 6; k++) row[k] = Mrow[k];
+#pragma unroll
+      for (int k = 0; k < NCH; k++) { row[6 + k] = chainB ? 0.0 : Mrow[6 + k]; row[6 + NCH + k] = chainB ? Mrow[6 + k] : 0.0; }
+    }
+    for (int ch = 0; ch < nchunk; ch++) {
+      stage(ch);
+      const int r = ch * W + lane;
+      const double D = r < nrow ? bd[BW_D + r] : 0.0, aref = r < nrow ? bd[BW_AREF + r] : 0.0;
+      const double x = jrow(S.U + U_VEC) - aref;
+      double cr, force, dactive;
+      row_eval(D > 0, 0.0, D, x, &cr, &force, &dactive);
+      c += cr;
+      if (r < nrow) { bd[BW_JAR + r] = x; bd[BW_FRC + r] = force; bd[BW_DACT + r] = dactive; }
+      S.U[U_EVEC + lane] = force; S.U[U_DACT + lane] = dactive;
+      SYNC();
+      for (int q = 0; q < W; q += 4) {
+        f0 += S.U[U_J + q * NV + dd] * S.U[U_EVEC + q];
+        f1 += S.U[U_J + (q + 1) * NV + dd] * S.U[U_EVEC + q + 1];
+        f2 += S.U[U_J + (q + 2) * NV + dd] * S.U[U_EVEC + q + 2];
+        f3 += S.U[U_J + (q + 3) * NV + dd] * S.U[U_EVEC + q + 3];
+      }
+      unsigned long long mm = __ballot(dactive != 0.0);
+      while (mm) {
+        const int q = __ffsll(mm) - 1;
+        mm &= mm - 1;
+        const double jl = S.U[U_J + q * NV + dd], cj = S.U[U_DACT + q] * jl;
+        hd += cj * jl;
+#pragma unroll
+        for (int k = 0; k < NV; k += 2) {
+          const double2 ab = *reinterpret_cast<const double2*>(&S.U[U_J + q * NV + k]);
+          row[k] += cj * ab.x;
+          row[k + 1] += cj * ab.y;
+        }
+      }
+      SYNC();
+    }
+    double cu, ufrc, udact;
+    eval_units(qacc, &cu, &ufrc, &udact);
+    c += cu;
+    hd += mdiag + udact;
+    const double Ma = mprod(qacc);
+    if (prim) c += 0.5 * (Ma - fs) * (qacc - as);
+    oldcost = cost;
+    double grad = 0;
+    fcon = 0;
+    if (dof >= 0) { fcon = ((f0 + f1) + (f2 + f3)) + ufrc; grad = Ma - fs - fcon; }
+    double gn;
+    gsum2<W>(c, prim ? grad * grad : 0.0, cost, gn);
+    gn = sqrt(gn);
+    if (iter > 0) { if (scale * (oldcost - cost) < m.tolerance || scale * gn < m.tolerance) break; }
+    else if (scale * gn < m.tolerance) break;
+    if (iter == m.iterations) break;
+    const double search = -dense_factor_solve<L>(S, row, hd, grad, dof, prim);
+    if (prim) S.U[U_VEC2 + dd] = search;
+    SYNC();
+    for (int ch = 0; ch < nchunk; ch++) {   // J search of every row
+      stage(ch);
+      const int r = ch * W + lane;
+      const double jv = jrow(S.U + U_VEC2);
+      if (r < nrow) bd[BW_JV + r] = bd[BW_D + r] > 0 ? jv : 0.0;
+      SYNC();
+    }
+    const double Mv = mprod(search);
+    __syncthreads();
+    double qg1, qg2;
+    gsum2<W>(prim ? search * (Ma - fs) : 0.0, prim ? 0.5 * search * Mv : 0.0, qg1, qg2);
+    const double xu0 = qacc - uaref[0], xu1 = qacc - uaref[1], xu2 = -qacc - uaref[2];
+    // exact line search on the convex piecewise-quadratic: safeguarded Newton on its derivative (rows strided over the lanes)
+    auto deriv_all = [&](double a, double* d1, double* d2) {
+      double r1 = 0, r2 = 0, s1, s2;
+      for (int r = lane; r < nrow; r += W) {
+        const double D = bd[BW_D + r], jv = bd[BW_JV + r];
+        row_deriv(D > 0, 0.0, D, bd[BW_JAR + r] + a * jv, jv, &s1, &s2); r1 += s1; r2 += s2;
+      }
+      if (anyunit && prim) {
+        row_deriv(uon[0], ufl, uD[0], xu0 + a * search, search, &s1, &s2); r1 += s1; r2 += s2;
+        row_deriv(uon[1], 0.0, uD[1], xu1 + a * search, search, &s1, &s2); r1 += s1; r2 += s2;
+        row_deriv(uon[2], 0.0, uD[2], xu2 - a * search, -search, &s1, &s2); r1 += s1; r2 += s2;
+      }
+      gsum2<W>(r1, r2, *d1, *d2);
+    };
+    double alpha = 0;
+    {
+      double d1, d2;
+      deriv_all(0.0, &d1, &d2);
+      d1 += qg1; d2 += 2 * qg2;
+      if (!(d1 >= 0 || d2 <= 0)) {
+        const double d0 = fabs(d1);
+        double lo = 0, hi = -1;
+        for (int it = 0; it < 40; it++) {
+          double a = alpha - d1 / d2;
+          if (hi >= 0 && (a <= lo || a >= hi)) a = 0.5 * (lo + hi);
+          deriv_all(a, &d1, &d2);
+          d1 += 2 * a * qg2 + qg1;
+          d2 += 2 * qg2;
+          if (d1 < 0) lo = a; else hi = a;
+          alpha = a;
+          if (fabs(d1) <= 1e-14 * d0) break;
+          if (hi >= 0 && hi - lo <= 4e-16 * hi) break;
+        }
+      }
+    }
+    if (alpha == 0) break;
+    qacc += alpha * search;
+  }
+  __syncthreads();
+  // ---- what the task layer reads off the contacts of this forward pass: GRF per foot (sum over its foot-floor contacts of the
+  // norm of the decoded pyramid force), lowest foot-floor contact point, any foot contact, self-collision
+  // (robot_interface.py:262-325, 472-484: "floor" = geom1 on a body outside the robot's tree, geom2 on the foot body)
+  {
+    double grf_r = 0, grf_l = 0, cz = 1e300;
+    int anyfoot = 0, selfcol = 0;
+    for (int c = lane; c < nc; c += W) {
+      const int b1 = m.geom_i[GIS * (bi[BWI_G1 + c]) + GI_BODY], b2 = m.geom_i[GIS * (bi[BWI_G2 + c]) + GI_BODY];
+      const bool floor1 = m.body_i[BIS * (b1) + BI_ROOT] != p.root_body;
+      if (m.body_i[BIS * (b1) + BI_ROOT] == p.root_body && m.body_i[BIS * (b2) + BI_ROOT] == p.root_body) selfcol = 1;
+      double fn = 0;
+      const int r0 = 4 * c, dim = bi[BWI_DIM + c];
+      if (dim == 3) {
+        const double g0 = bd[BW_FRC + r0], g1 = bd[BW_FRC + r0 + 1], g2 = bd[BW_FRC + r0 + 2], g3 = bd[BW_FRC + r0 + 3], mu = bd[BW_MU + c];
+        const double n = g0 + g1 + g2 + g3, t1f = mu * (g0 - g1), t2f = mu * (g2 - g3);
+        fn = sqrt(n * n + t1f * t1f + t2f * t2f);
+      } else if (dim == 1) fn = fabs(bd[BW_FRC + r0]);
+      if (floor1 && b2 == p.rfoot_body) { grf_r += fn; cz = fmin(cz, bd[BW_POS + 3 * c + 2]); anyfoot = 1; }
+      if (floor1 && b2 == p.lfoot_body) { grf_l += fn; cz = fmin(cz, bd[BW_POS + 3 * c + 2]); anyfoot = 1; }
+    }
+    grf_r = gsum<W>(grf_r); grf_l = gsum<W>(grf_l); cz = gmin<W>(cz);
+    const bool af = gany<W>(anyfoot), sc = gany<W>(selfcol);
+    SYNC();
+    if (lane == 0) { S.big_grf_r = grf_r; S.big_grf_l = grf_l; S.big_cz = af ? cz : 0.0; S.big_anyfoot = af ? 1 : 0; S.big_selfcol = sc ? 1 : 0; }
+    SYNC();
+  }
+  qacc_out = qacc; fcon_out = fcon;
+}
+
 // Everything of the sub-step behind the joint-space inertia: constraint rows, smooth acceleration, Newton, Euler.
 // Dofs sit in the half-env-per-DPP-row layout of the chain solver: a root dof is held by two lanes, `prim` marks the one that
 // counts in sums over dofs and writes the dof's results.  `cross`: some contact couples the two chains (group-uniform).
 template <class L>
 __device__ __forceinline__ void solve_tail(const HModel& m, const HParams& p, L& S, const int lane, const int flags, long long* st_prof,
                                            const int dof, const bool prim, const bool cross, const double (&Mrow)[NR], const double mdiag,
-                                           const double marm, const double qapp, const double bias) {
+                                           const double marm, const double qapp, const double bias, double* bd, int* bi) {
   constexpr int W = L::W_;
   PROF_BEGIN();
   const int dd = dof >= 0 ? dof : 0;   // (lanes without a dof shadow dof 0; nothing of theirs is used)
@@ -1748,6 +2224,7 @@ __device__ __forceinline__ void solve_tail(const HModel& m, const HParams& p, L&
       row_params(m, &S.U[U_CSOLREF + 2 * c], &S.U[U_CSOLIMP + 5 * c], S.U[U_CDIST + c], S.U[U_CMARGIN + c], diag, &K, &B, &imp, &R);
       if (dim == 3) R = fmax(HMINVAL, 2 * mu * mu * R);  // every pyramid edge shares 2 mu^2 R(first edge)
       D = 1 / R;
+      if constexpr (L::STEP_) D *= S.con_mult[c];   // k identical contacts merged by the collision stage: one row with k times the D
       aref = -B * jv0 - K * imp * (S.U[U_CDIST + c] - S.U[U_CMARGIN + c]);
     }
   }
@@ -1821,7 +2298,13 @@ __device__ __forceinline__ void solve_tail(const HModel& m, const HParams& p, L&
   }
   PROF_MARK(12);
   double qacc = as, fcon = 0;  // element of this lane's dof
-  if (anyrow) {
+  bool bigpath = false;
+  if constexpr (L::STEP_ && W == 64) bigpath = bd != nullptr && S.nbig > 0;
+  if (bigpath) {
+    // more contacts than row lanes (fwd_collision left them in the HBM workspace; S.ncon is 0, the in-LDS row code above idled)
+    if constexpr (L::STEP_ && W == 64) newton_big<L>(m, p, S, lane, bd, bi, dof, prim, Mrow, mdiag, marm, fs, as, uon, uD, uaref, ufl, anyunit, qacc, fcon);
+    S.efc_force[lane] = 0;
+  } else if (anyrow) {
     // ------------------------------------------------------------ primal Newton (engine_solver.c)
     // cost / force / active-D of this lane's rows at acceleration a (ja = J a of the contact row, a = own dof element)
     auto eval_rows = [&](double ja, double a, double* cost, double* force, double* dactive, double* ufrc, double* udact) {
@@ -2027,11 +2510,11 @@ __device__ __forceinline__ void solve_tail(const HModel& m, const HParams& p, L&
 // J x is the lane's own element, J^T f lands on the lane's own dof, J^T D J on its own diagonal entry.  Only the summation
 // order differs from the row order of the reference; every row is there.
 template <bool BOXBOX, class L>
-__device__ __forceinline__ void substep(const HModel& m, const HParams& p, L* SG0, int flags, long long* st_prof, const double* ter) {
+__device__ __forceinline__ void substep(const HModel& m, const HParams& p, L* SG0, int flags, long long* st_prof, const double* ter, double* bd, int* bi) {
   constexpr int W = L::W_;
   long long prof_t;
   { FRESH_GROUP(W, SG0); prof_t = (st_prof && lane == 0) ? (long long)clock64() : 0; fwd_kinematics<BOXBOX>(m, S, lane); PROF_MARK(0); }
-  { FRESH_GROUP(W, SG0); fwd_collision<BOXBOX>(m, p, S, lane, ter); PROF_MARK(3); }   // stage A temporaries (geom frames) die with fwd_com
+  { FRESH_GROUP(W, SG0); fwd_collision<BOXBOX>(m, p, S, lane, ter, bd, bi); PROF_MARK(3); }   // stage A temporaries (geom frames) die with fwd_com
   FRESH_GROUP(W, SG0);
   // The chain solver needs the [root | chain A | chain B] block structure of M (checked at create).  A contact between bodies
   // of the two chains couples them in the Newton Hessian (rare: it is a self-collision, i.e. the last control step of an
@@ -2051,7 +2534,7 @@ __device__ __forceinline__ void substep(const HModel& m, const HParams& p, L* SG
   double Mrow[NR], mdiag, marm, bias, qapp;
   chain_dynamics(m, p, S, lane, dof, prim, Mrow, mdiag, marm, bias, qapp);
   PROF_MARK(5);
-  solve_tail(m, p, S, lane, flags, st_prof, dof, prim, cross, Mrow, mdiag, marm, qapp, bias);
+  solve_tail(m, p, S, lane, flags, st_prof, dof, prim, cross, Mrow, mdiag, marm, qapp, bias, bd, bi);
 }
 // ------------------------------------------------------------------------------------------------ task layer
 __device__ __forceinline__ void sample_ref(const HParams& p, unsigned genv, unsigned stream, unsigned counter, unsigned slot0,
@@ -2255,7 +2738,7 @@ __device__ __forceinline__ bool control_step(const HModel& m, const HParams& p, 
     if (lane < 12) S.xfrc[lane] = prm ? prm[P_XFRC + lane] : 0.0;
   }
   SYNC();
-  if (lane == 0) S.overflow = 0;
+  if (lane == 0) { S.overflow = 0; if constexpr (L::STEP_) S.nbig = 0; }
   SYNC();
 
   // One loop, one sub-step call site.  Each env walks through its stages -- the frame_skip control sub-steps, then (if
@@ -2333,6 +2816,12 @@ __device__ __forceinline__ bool control_step(const HModel& m, const HParams& p, 
           }
           grf_r = gsum<W>(grf_r); grf_l = gsum<W>(grf_l); cz = gmin<W>(cz);
           if (!gany<W>(anyfoot)) cz = 0;
+        }
+        if constexpr (TASK == TASK_STEP && W == 64) {
+          if (S.nbig) {   // the last forward pass took the many-contact path: its contacts are in HBM, newton_big left these
+            self_collision = S.big_selfcol != 0;
+            grf_r = S.big_grf_r; grf_l = S.big_grf_l; cz = S.big_cz;
+          }
         }
         if (WALKT) {
         // ---- WalkingTask.step (walking_task.py:149-170)
@@ -2503,6 +2992,7 @@ __device__ __forceinline__ bool control_step(const HModel& m, const HParams& p, 
               const int b1 = m.geom_i[GIS * (S.con_g1[c]) + GI_BODY], b2 = m.geom_i[GIS * (S.con_g2[c]) + GI_BODY];
               if (m.body_i[BIS * (b1) + BI_ROOT] != p.root_body && (b2 == p.rfoot_body || b2 == p.lfoot_body)) anyc = 1;
             }
+            if constexpr (TASK == TASK_STEP && W == 64) { if (S.nbig) anyc = S.big_anyfoot; }
             ti[LHW_TIN_FOOT_CONTACT] = anyc; ti[LHW_TIN_SELF_COLLISION] = self_collision ? 1.0 : 0.0;
             ti[LHW_TIN_PHASE] = phase; ti[LHW_TIN_MODE] = mode;
             for (int a = 0; a < 3; a++) {
@@ -2747,7 +3237,8 @@ __device__ __forceinline__ bool control_step(const HModel& m, const HParams& p, 
     // (Every phase of the sub-step takes its lane index from fresh_wave_lane(): besides keeping the addresses built from it out of
     // scratch, the opaque value keeps the ~100 model-table loads of a sub-step -- indexed by the lane, invariant across the 25
     // sub-steps -- inside the loop.  Hoisted, they would be parked in scratch and reloaded from there, FETCH_SIZE 708 MB per launch.)
-    substep<TASK == TASK_STEP>(m, p, SG0, flags, sprof, ter);
+    substep<TASK == TASK_STEP>(m, p, SG0, flags, sprof, ter, (TASK == TASK_STEP && W == 64 && st.bigd) ? st.bigd + (size_t)env * BW_DOUBLES : nullptr,
+                               (TASK == TASK_STEP && W == 64 && st.bigd) ? st.bigi + (size_t)env * BW_INTS : nullptr);
     if (stage == ST_LAST) break;
     // two envs per wave: an env that needs more contacts than this layout holds is handed to the one-env-per-wave kernel
     // untouched (nothing of it has been written yet); once its outputs are out, it can only truncate like that kernel does
@@ -3086,6 +3577,18 @@ int humanoid_create(HumanoidEnv** out, const std::vector<int32_t>& mi, const std
     }
     const int b1 = I1[GI_BODY], b2 = I2[GI_BODY];
     pi[3] = (int)(bmask[b1] ^ bmask[b2]); pi[4] = (int)bmask[b2];
+    // pair class (fwd_collision merges bitwise identical contacts of the same class): pairs whose contact parameters and dof
+    // masks are equal AND whose bodies play the same roles in the task's contact queries (geom1 on / off the robot, body of geom2)
+    pi[5] = q;
+    for (int e = 0; e < q; e++) {
+      const double* ed = &pair_d[(size_t)PDS * e];
+      const int* ei = &pair_i[(size_t)PIS * e];
+      const int eb1 = geom_i[(size_t)GIS * ei[0] + GI_BODY], eb2 = geom_i[(size_t)GIS * ei[1] + GI_BODY];
+      bool same = ei[2] == pi[2] && ei[3] == pi[3] && ei[4] == pi[4] && eb2 == b2 && (eb1 == 0) == (b1 == 0);
+      for (int a = 0; a < 10 && same; a++) same = ed[a] == pd[a];
+      same = same && ed[10] == DF(LHW_DF_GEOM_INVWEIGHT0)[2 * g1] + DF(LHW_DF_GEOM_INVWEIGHT0)[2 * g2];
+      if (same) { pi[5] = ei[5]; break; }
+    }
     pd[10] = DF(LHW_DF_GEOM_INVWEIGHT0)[2 * g1] + DF(LHW_DF_GEOM_INVWEIGHT0)[2 * g2];   // (the geoms' own copies: Model.fuse_static keeps them)
   }
   for (int u = 0; u < nu; u++) {
@@ -3251,6 +3754,14 @@ int humanoid_create(HumanoidEnv** out, const std::vector<int32_t>& mi, const std
     for (size_t n = 0; n < N; n++) std::copy(one.begin(), one.end(), all.begin() + n * TER_D);
     h->st.ter = const_cast<double*>(to_dev<double>(h, all.data(), all.size()));
     ok = ok && h->st.ter != nullptr;
+  }
+  h->st.bigd = nullptr; h->st.bigi = nullptr;
+  if (ok && stepping && !getenv("LHW_STEP_NO_BIG")) {   // many-contact workspace (newton_big): 51 KB per env
+    void *bdp = nullptr, *bip = nullptr;
+    ok = ok && lhw_malloc(&bdp, sizeof(double) * (size_t)BW_DOUBLES * N) == hipSuccess && lhw_malloc(&bip, sizeof(int) * (size_t)BW_INTS * N) == hipSuccess;
+    if (bdp) h->dev_allocs.push_back(bdp);
+    if (bip) h->dev_allocs.push_back(bip);
+    h->st.bigd = (double*)bdp; h->st.bigi = (int*)bip;
   }
   void *rec = nullptr, *irec = nullptr, *eps = nullptr, *slow = nullptr;
   ok = ok && lhw_malloc(&slow, N + 1) == hipSuccess && hipMemset(slow, 0, N + 1) == hipSuccess;

@@ -8,10 +8,9 @@ terrain, then task.reset), tasks/rewards.py:177-194 (orientation reward).
 Random draws (oracle/rng.py, STREAM_RESET, counter = reset count): slot 0 initial phase, 1 walk mode, 2 the mode's own
 choice (plan index / lateral side / stair direction), 3 first-step offset, 4 number of flat steps.
 
-KNOWN DEVIATION shared with the HIP kernel: outside FORWARD mode the reference leaves the 20 boxes
-coplanar with the floor, so every foot touches floor AND boxes (up to 40 redundant contacts).  The wave-per-env solver
-holds 64 constraint rows, so boxes only collide while the floor is lowered (FORWARD mode); otherwise they are sunk to
-z = -1.1 like the unused ones.  The supporting surface is identical, the contact multiplicity (ground stiffness) is not.
+Terrain as the reference leaves it (stepping_task.py:316-334): every box of the sequence under its target step in EVERY walk
+mode -- outside FORWARD mode their top faces are coplanar with the floor, so a foot rests on the floor and on each box under it
+(16 ... ~110 contacts per env; the oracle holds 256) -- the unused boxes sunk to z = -1.1, the floor lowered in FORWARD mode.
 """
 import numpy as np
 
@@ -121,11 +120,10 @@ class OracleJvrcStepEnv(OracleJvrcWalkEnv):
         self.sequence = np.tile(np.array([0.0, 0.0, -1.0, 0.0]), (NBOX, 1))
         self.sequence[: len(out)] = np.array(out)
         self._update_target_steps()
-        # terrain (stepping_task.py:316-334); see KNOWN DEVIATION in the module docstring
+        # terrain (stepping_task.py:316-334)
         m = self.m
-        collide = self.mode == FORWARD
         for k in range(NBOX):
-            st = self.sequence[k] if collide else np.array([0.0, 0.0, -1.0, 0.0])
+            st = self.sequence[k]
             m.body_pos[self.box_body[k]] = st[0:3] - np.array([0, 0, 0.1])
             m.body_quat[self.box_body[k]] = [np.cos(st[3] / 2), 0, 0, np.sin(st[3] / 2)]      # euler2quat(0, 0, theta)
         m.body_pos[self.floor_body] = [0, 0, -2.0 if self.mode == FORWARD else 0.0]

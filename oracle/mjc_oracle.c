@@ -26,7 +26,7 @@
 
 #include "../include/lhw_model_fields.h"
 
-#define MAXCON 64
+#define MAXCON 256
 #define MAXEFC (4 * MAXCON + 128)
 #define MINVAL 1e-15
 #define MINIMP 0.0001

@@ -167,6 +167,26 @@ def test_emulated_jvrc_step_forward_mode_on_boxes():
     _run_tape(env, orc, tape)
 
 
+def test_emulated_jvrc_step_every_walk_mode_on_the_reference_terrain():
+    """Outside FORWARD mode the reference leaves the terrain boxes coplanar with the floor (tasks/stepping_task.py:320-334): a foot
+    rests on the floor and on every box under it -- 16 (STANDING) to ~110 (LATERAL) contacts per env, far beyond the 16 whose
+    rows fit one lane each.  Those sub-steps take the many-contact path (contacts / Jacobian rows / row state in the HBM
+    workspace, rows walked in strides of the wave: newton_big) and must match the oracle, which collides every box, like any other."""
+    from learninghumanoidwalking_amd.envs.jvrc_step import JvrcStepSpec
+    from oracle.env_jvrc_step import OracleJvrcStepEnv
+    N = 7
+    spec, env, orc = _mk(JvrcStepSpec, OracleJvrcStepEnv, N, seed=7)
+    obs = env.reset().copy()
+    ref = np.array([o.reset() for o in orc])
+    np.testing.assert_allclose(obs, ref, rtol=1e-6, atol=1e-6)
+    assert {o.mode for o in orc} == {0, 1, 2, 3, 4}, [o.mode for o in orc]     # CURVED, STANDING, BACKWARD, LATERAL, FORWARD
+    tape = (np.random.default_rng(3).normal(size=(3, N, 12)) * 0.1).astype(np.float32)
+    env.step(tape[0]); [o.step(tape[0, i]) for i, o in enumerate(orc)]
+    ncon = {o.mode: o.sim.ncon for o in orc}
+    assert ncon[4] == 8 and ncon[3] > 64 and ncon[2] > 16 and ncon[0] > 16, ncon
+    _run_tape(env, orc, tape)
+
+
 def test_emulated_cartpole():
     from learninghumanoidwalking_amd.envs import CartpoleSpec
     from oracle.env_cartpole import OracleCartpoleEnv

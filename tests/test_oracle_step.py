@@ -56,11 +56,12 @@ def test_task_logic_matches_reference_stepping_task(env):
             assert [e.phase, e.period, e.t1, e.t2, e.spec.delay_frames, e.spec.target_radius] == list(st)
             np.testing.assert_array_equal(m.body_pos[e.floor_body], g[pre + "floor"])
             ref_pos, ref_quat = g[pre + "boxpos"], g[pre + "boxquat"]
-            if mode_idx == 4:      # FORWARD: the boxes carry the robot -> identical terrain
-                np.testing.assert_allclose(m.body_pos[e.box_body], ref_pos, rtol=0, atol=1e-13)
-                np.testing.assert_allclose(m.body_quat[e.box_body], ref_quat, rtol=0, atol=1e-13)
-            else:                  # KNOWN DEVIATION: the reference leaves boxes coplanar with the floor, we sink them
-                assert np.allclose(ref_pos[: e.nseq, 2], -0.1) and np.allclose(m.body_pos[e.box_body][:, 2], -1.1)
+            # identical terrain in EVERY walk mode: the sequence's boxes under their steps (coplanar with the floor outside
+            # FORWARD mode, stepping_task.py:320-334), the unused ones sunk
+            np.testing.assert_allclose(m.body_pos[e.box_body], ref_pos, rtol=0, atol=1e-13)
+            np.testing.assert_allclose(m.body_quat[e.box_body], ref_quat, rtol=0, atol=1e-13)
+            if mode_idx != 4:
+                assert np.allclose(ref_pos[: e.nseq, 2], -0.1)
             seen_modes.add(mode_idx)
             # ---- scripted control steps
             kin, goal, rew, done, tst = g[pre + "kin"], g[pre + "goal"], g[pre + "rew"], g[pre + "done"], g[pre + "tstate"]
