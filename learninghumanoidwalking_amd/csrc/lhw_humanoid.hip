@@ -2321,6 +2321,8 @@ __device__ __forceinline__ void solve_tail(const HModel& m, const HParams& p, L&
       *cost = cs; *ufrc = uf; *udact = ud;
     };
     const double scale = 1.0 / (m.meaninertia * (NV > 1 ? NV : 1));
+    double warm_jw = 0, warm_js = 0, warm_Ma = 0;
+    bool warm_pick_s = false, warm_have = false;
     // warm start: cheaper of qacc_warmstart and qacc_smooth
     if (!(m.disableflags & (1 << 7))) {
       const double w = dof >= 0 ? S.qacc[dd] : 0.0;   // qacc of the previous forward pass = qacc_warmstart
@@ -2335,14 +2337,26 @@ __device__ __forceinline__ void solve_tail(const HModel& m, const HParams& p, L&
       double cs;
       gsum2<W>(cw, cs0, cw, cs);
       qacc = (cw > cs) ? as : w;
+      warm_jw = jw; warm_js = js; warm_Ma = Ma; warm_pick_s = cw > cs; warm_have = true;
     }
     double cost = 0, oldcost = 0;
+    double ja_run = 0, Ma_run = 0;
+    bool have_prod = false;
+    // (the products of the start point were formed for the warm-start comparison: round 4, same box -0.5 %)
+    if (warm_have) { ja_run = warm_pick_s ? warm_js : warm_jw; Ma_run = warm_pick_s ? mprod(as) : warm_Ma; have_prod = true; }
     for (int iter = 0; iter <= m.iterations; iter++) {
       if (st_prof && lane == 0) st_prof[6] += 1;    // diagnostic: Newton passes (cost evaluations) of env 0
-      SYNC();
-      if (prim) S.U[U_VEC + dd] = qacc;
-      SYNC();
-      const double ja = jrow_dot(S.U + U_VEC), Ma = mprod(qacc);
+      // J qacc and M qacc: computed for the first iterate, then advanced with the step (J search and M search exist for the line
+      // search anyway) -- mj_solNewton's own bookkeeping (engine_solver.c: Jaref += alpha jv, Ma += alpha Mv).  Round 4, same box:
+      // control step -1.5 % (round 3 measured +1 %: two more values live across the line search then cost spills)
+      if (!have_prod) {
+        SYNC();
+        if (prim) S.U[U_VEC + dd] = qacc;
+        SYNC();
+        ja_run = jrow_dot(S.U + U_VEC); Ma_run = mprod(qacc);
+        have_prod = true;
+      }
+      const double ja = ja_run, Ma = Ma_run;
       double c, force, dactive, ufrc, udact;
       eval_rows(ja, qacc, &c, &force, &dactive, &ufrc, &udact);
       if (prim) c += 0.5 * (Ma - fs) * (qacc - as);
@@ -2353,7 +2367,14 @@ __device__ __forceinline__ void solve_tail(const HModel& m, const HParams& p, L&
       fcon = 0;
       {
         double f0 = 0, f1 = 0, f2 = 0, f3 = 0;
-        for (int r = 0; r < nrow; r += 4) {   // whole contacts: nrow is a multiple of 4
+        int r = 0;
+        for (; r + 8 <= nrow; r += 8) {   // two contacts per trip: eight independent LDS reads in flight (round 4, same box: -1.1 %)
+          const double a0 = S.U[U_J + r * NV + dd], a1 = S.U[U_J + (r + 1) * NV + dd], a2 = S.U[U_J + (r + 2) * NV + dd], a3 = S.U[U_J + (r + 3) * NV + dd];
+          const double a4 = S.U[U_J + (r + 4) * NV + dd], a5 = S.U[U_J + (r + 5) * NV + dd], a6 = S.U[U_J + (r + 6) * NV + dd], a7 = S.U[U_J + (r + 7) * NV + dd];
+          f0 += a0 * S.U[U_EVEC + r]; f1 += a1 * S.U[U_EVEC + r + 1]; f2 += a2 * S.U[U_EVEC + r + 2]; f3 += a3 * S.U[U_EVEC + r + 3];
+          f0 += a4 * S.U[U_EVEC + r + 4]; f1 += a5 * S.U[U_EVEC + r + 5]; f2 += a6 * S.U[U_EVEC + r + 6]; f3 += a7 * S.U[U_EVEC + r + 7];
+        }
+        if (r < nrow) {
           f0 += S.U[U_J + r * NV + dd] * S.U[U_EVEC + r];
           f1 += S.U[U_J + (r + 1) * NV + dd] * S.U[U_EVEC + r + 1];
           f2 += S.U[U_J + (r + 2) * NV + dd] * S.U[U_EVEC + r + 2];
@@ -2383,27 +2404,35 @@ __device__ __forceinline__ void solve_tail(const HModel& m, const HParams& p, L&
       const typename RowMask<W>::type mm_all = group_rows<W>(__ballot(dactive != 0.0));
       {
         typename RowMask<W>::type mm = mm_all;
-        while (mm) {      // (measured: unrolling this loop, or the J^T f loop above, is slower -- DESIGN.md section 4)
+        while (mm) {      // two active rows per trip: their LDS reads are in flight together, the sums keep the row order
+                          // (round 4, same box: -1.9 %; four rows per trip: +1 %; round 3's `#pragma unroll` of the one-row loop had lost)
           const int r = first_row(mm);
           mm &= mm - 1;
-          const double jl = S.U[U_J + r * NV + dd], cj = S.U[U_DACT + r] * jl;
+          const bool two = mm != 0;
+          const int r2 = two ? first_row(mm) : r;
+          if (two) mm &= mm - 1;
+          const double jl = S.U[U_J + r * NV + dd], jl2 = S.U[U_J + r2 * NV + dd];
+          const double cj = S.U[U_DACT + r] * jl, cj2 = two ? S.U[U_DACT + r2] * jl2 : 0.0;
           hd += cj * jl;
+          hd += cj2 * jl2;
 #pragma unroll
           for (int k = 0; k < 6; k += 2) {
             const double2 ab = *reinterpret_cast<const double2*>(&S.U[U_J + r * NV + k]);
-            Hrow[k] += cj * ab.x;
-            Hrow[k + 1] += cj * ab.y;
+            const double2 cd = *reinterpret_cast<const double2*>(&S.U[U_J + r2 * NV + k]);
+            Hrow[k] += cj * ab.x; Hrow[k + 1] += cj * ab.y;
+            Hrow[k] += cj2 * cd.x; Hrow[k + 1] += cj2 * cd.y;
           }
           if constexpr (NCH % 2 == 0) {
 #pragma unroll
             for (int k = 0; k < NCH; k += 2) {
               const double2 ab = *reinterpret_cast<const double2*>(&S.U[U_J + r * NV + coff + k]);
-              Hrow[6 + k] += cj * ab.x;
-              Hrow[6 + k + 1] += cj * ab.y;
+              const double2 cd = *reinterpret_cast<const double2*>(&S.U[U_J + r2 * NV + coff + k]);
+              Hrow[6 + k] += cj * ab.x; Hrow[6 + k + 1] += cj * ab.y;
+              Hrow[6 + k] += cj2 * cd.x; Hrow[6 + k + 1] += cj2 * cd.y;
             }
           } else {
 #pragma unroll
-            for (int k = 0; k < NCH; k++) Hrow[6 + k] += cj * S.U[U_J + r * NV + coff + k];
+            for (int k = 0; k < NCH; k++) { Hrow[6 + k] += cj * S.U[U_J + r * NV + coff + k]; Hrow[6 + k] += cj2 * S.U[U_J + r2 * NV + coff + k]; }
           }
         }
         if (rootb) {   // the root-root block lives in copy A
@@ -2458,6 +2487,7 @@ __device__ __forceinline__ void solve_tail(const HModel& m, const HParams& p, L&
       PROF_MARK(15);
       if (alpha == 0) break;
       qacc += alpha * search;
+      ja_run += alpha * jv; Ma_run += alpha * Mv;
     }
   } else {
     S.efc_force[lane] = 0;
