@@ -2080,13 +2080,21 @@ __device__ __noinline__ void newton_big(const HModel& m, const HParams& p, L& S,
     double qg1, qg2;
     gsum2<W>(prim ? search * (Ma - fs) : 0.0, prim ? 0.5 * search * Mv : 0.0, qg1, qg2);
     const double xu0 = qacc - uaref[0], xu1 = qacc - uaref[1], xu2 = -qacc - uaref[2];
-    // exact line search on the convex piecewise-quadratic: safeguarded Newton on its derivative (rows strided over the lanes)
+    // exact line search on the convex piecewise-quadratic: safeguarded Newton on its derivative.  The rows are strided over the lanes
+    // (row 64 q + lane, q < NRB / 64); a lane's rows -- 1 / R, residual, J search -- are fetched ONCE into registers instead of being
+    // re-read from the workspace in each of the (up to 40, typically 3-4 per Newton iteration) derivative evaluations: jvrc_step +5 %
+    constexpr int RPL = NRB / W;
+    double Dl[RPL], xl[RPL], vl[RPL];
+#pragma unroll
+    for (int q = 0; q < RPL; q++) {
+      const int r = q * W + lane;
+      const bool ok = r < nrow;
+      Dl[q] = ok ? bd[BW_D + r] : 0.0; xl[q] = ok ? bd[BW_JAR + r] : 0.0; vl[q] = ok ? bd[BW_JV + r] : 0.0;
+    }
     auto deriv_all = [&](double a, double* d1, double* d2) {
       double r1 = 0, r2 = 0, s1, s2;
-      for (int r = lane; r < nrow; r += W) {
-        const double D = bd[BW_D + r], jv = bd[BW_JV + r];
-        row_deriv(D > 0, 0.0, D, bd[BW_JAR + r] + a * jv, jv, &s1, &s2); r1 += s1; r2 += s2;
-      }
+#pragma unroll
+      for (int q = 0; q < RPL; q++) { row_deriv(Dl[q] > 0, 0.0, Dl[q], xl[q] + a * vl[q], vl[q], &s1, &s2); r1 += s1; r2 += s2; }
       if (anyunit && prim) {
         row_deriv(uon[0], ufl, uD[0], xu0 + a * search, search, &s1, &s2); r1 += s1; r2 += s2;
         row_deriv(uon[1], 0.0, uD[1], xu1 + a * search, search, &s1, &s2); r1 += s1; r2 += s2;
