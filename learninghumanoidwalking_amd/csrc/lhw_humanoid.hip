@@ -169,7 +169,7 @@ enum { LHW_STREAM_OBS = 4 };
 #define AD_GEAR 0
 #define AD_CTRLRANGE 1
 #define AD_FORCERANGE 3
-#define PIS 6   // pair_i: geom1 geom2 condim xmask(dofs moving exactly one body) mask2(dofs moving body 2) pad
+#define PIS 8   // pair_i: geom1 geom2 condim xmask(dofs moving exactly one body) mask2(dofs moving body 2) class | merge class, robot-is-geom1
 #define PDS 12  // pair_d: margin includemargin friction solref2 solimp5 invweight(sum of the two bodies' translational) pad
 #define AIS 6   // act_i: dof joint ctrllimited forcelimited qposadr dofadr(of the joint)
 #define AI_QADR 4
@@ -253,11 +253,13 @@ struct HState {
 // floor (tasks/stepping_task.py:320-334), so a foot rests on the floor AND on every box under it: 16 (STANDING) to ~110 (LATERAL)
 // contacts per env, against 16 whose pyramid rows fit one lane each.  Two steps deal with them:
 //  1. MERGING.  Most of those contacts are copies of one another -- a foot corner that lies inside twelve overlapping boxes yields
-//     twelve contacts with bitwise the same distance, position and frame (106 contacts, 20 distinct ones in LATERAL mode).  k
-//     identical rows of the soft-constraint problem are ONE row with k times the D (cost k (1/2) D r^2, total force k f): the
-//     collision stage writes all contacts of such a sub-step to an HBM workspace ("raw" region), merges exact duplicates of the
-//     same pair class, and hands the distinct ones on with their multiplicity.  If at most 16 remain -- nearly always -- they go
-//     back into the LDS arrays and the ordinary one-row-per-lane solver runs, with D scaled by the multiplicity.
+//     twelve box contacts with bitwise the same distance, position and frame, and the floor contact of that corner is the same
+//     constraint once more with the roles of the two geoms swapped (frame mirrored, values within 1-2 ulp): 106 contacts, 12-14
+//     distinct ones in LATERAL mode.  k identical rows of the soft-constraint problem are ONE row with k times the D (cost
+//     k (1/2) D r^2, total force k f): the collision stage writes all contacts of such a sub-step to an HBM workspace ("raw" region),
+//     merges the copies and hands the distinct contacts on with their multiplicity (and, for the ground-reaction query, the share
+//     of the copies that are floor contacts of a foot).  If at most 16 remain -- nearly always -- they go back into the LDS arrays
+//     and the ordinary one-row-per-lane solver runs, with D scaled by the multiplicity.
 //  2. MANY DISTINCT CONTACTS (more than 16 after merging): they stay in the workspace ("unique" region) with the per-row solver
 //     state, and newton_big walks the rows in chunks of 64.
 #define NCR 192                            // raw contacts per sub-step (beyond: dropped and counted as a contact overflow)
@@ -271,7 +273,9 @@ struct HState {
 #define ARI_FIRST (ARI_PAIR + NCR)         // index of the first contact this one is a copy of (itself: distinct)
 #define ARI_RANK (ARI_FIRST + NCR)         // distinct contacts: position among the distinct ones
 #define ARI_COUNT (ARI_RANK + NCR)         // by rank: multiplicity
-#define AR_INTS (ARI_COUNT + NCR)
+#define ARI_CNTR (ARI_COUNT + NCR)         // by rank: copies that are floor contacts of the right / left foot (robot_interface.py:269-301)
+#define ARI_CNTL (ARI_CNTR + NCR)
+#define AR_INTS (ARI_CNTL + NCR)
 #define NCB 64                             // distinct contacts the many-contact solver holds (4 NCB rows)
 #define NRB (4 * NCB)
 #define BW_DIST AR_DOUBLES
@@ -283,7 +287,9 @@ struct HState {
 #define BW_SOLREF (BW_TRAN + NCB)
 #define BW_SOLIMP (BW_SOLREF + 2 * NCB)
 #define BW_MULT (BW_SOLIMP + 5 * NCB)      // multiplicity of the contact
-#define BW_D (BW_MULT + NCB)               // per row (4 c .. 4 c + 3: the pyramid edges of contact c): multiplicity / R; 0: not a row
+#define BW_WR (BW_MULT + NCB)              // share of the copies that are floor contacts of the right / left foot
+#define BW_WL (BW_WR + NCB)
+#define BW_D (BW_WL + NCB)               // per row (4 c .. 4 c + 3: the pyramid edges of contact c): multiplicity / R; 0: not a row
 #define BW_AREF (BW_D + NRB)
 #define BW_JAR (BW_AREF + NRB)            // J a - aref at the current iterate
 #define BW_JV (BW_JAR + NRB)              // J search
@@ -364,6 +370,7 @@ template <bool ON, int NC_T>
 struct StepLds {
   static constexpr int NCK_ = 32;
   double con_mult[NC_T];   // number of identical contacts this one stands for (scales the D of its rows; fwd_collision's merge)
+  double con_wr[NC_T], con_wl[NC_T];   // share of those copies that are floor contacts of the right / left foot (the GRF query)
   // many-contact path: number of distinct contacts of the last forward pass kept in the HBM workspace (0: they are in the LDS
   // arrays) and what the task layer reads off them (robot_interface.py:262-325, 472-484)
   int nbig, big_selfcol, big_anyfoot;
@@ -1605,13 +1612,24 @@ __device__ void fwd_collision(const HModel& m, const HParams& p, L& S, int lane,
       constexpr int W = L::W_;
       __syncthreads();   // (one wave per workgroup: orders the workspace writes above before the reads below)
       const int nr = min(total, NCR);
-      // first[c]: the earliest contact c is a bitwise copy of -- same pair class (contact parameters, dof masks and the roles of
-      // the two bodies in the task's contact queries: humanoid_create), same distance, position and frame
-      for (int c = lane; c < nr; c += W) { bi[ARI_RANK + c] = m.pair_i[PIS * bi[ARI_PAIR + c] + 5]; bi[ARI_COUNT + c] = 0; }   // (class, parked in the rank slot)
+      // first[c]: the earliest contact c is a copy of.  Copies come in two kinds.  (a) The same pair class (contact parameters, dof
+      // masks, roles of the two bodies: humanoid_create) with bitwise the same distance, position and frame: a foot corner inside
+      // several overlapping boxes.  (b) The same MERGE class -- a robot body against a static geom, whichever of the two is geom1 --
+      // with the frame mirrored (normal and second tangent negated: makeFrame of -n; with the roles of the bodies swapped the
+      // four pyramid rows are the same four rows, the first two in the other order) and distance / position equal to within a few
+      // ulp: the floor contact of that foot corner (plane-box: geom1 = floor) beside its box contacts (box-box: geom1 = foot), which
+      // two narrow phases compute to within 1-2 ulp of each other (measured: |d dist| <= 1e-18, |d pos| <= 3e-17).  The group's
+      // representative is its earliest member; the copies only raise its multiplicity.
+      for (int c = lane; c < nr; c += W) {
+        const int q = bi[ARI_PAIR + c];
+        bi[ARI_RANK + c] = m.pair_i[PIS * q + 6] * 2 + m.pair_i[PIS * q + 7];   // (merge class and orientation, parked in the rank slot)
+        bi[ARI_COUNT + c] = 0; bi[ARI_CNTR + c] = 0; bi[ARI_CNTL + c] = 0;
+      }
       __syncthreads();
       for (int c = lane; c < nr; c += W) {
-        const int cls = bi[ARI_RANK + c];
+        const int key = bi[ARI_RANK + c];
         const double dc = bd[AR_DIST + c];
+        const double dtol = 1e-17 + 4e-16 * fabs(dc);
         int f = c;
         // candidates in batches of eight: the class and distance loads of a batch are independent of one another (one memory
         // round trip per batch instead of one per candidate); nearly every candidate fails on the distance
@@ -1623,15 +1641,36 @@ __device__ void fwd_collision(const HModel& m, const HParams& p, L& S, int lane,
 #pragma unroll
           for (int j = 0; j < 8; j++) {
             const int e = e0 + j;
-            if (f != c || e >= c || cl[j] != cls || de[j] != dc) continue;
-            bool same = true;
-            for (int a = 0; a < 3; a++) same = same && bd[AR_POS + 3 * e + a] == bd[AR_POS + 3 * c + a];
-            for (int a = 0; a < 9; a++) same = same && bd[AR_FRAME + 9 * e + a] == bd[AR_FRAME + 9 * c + a];
+            if (f != c || e >= c || (cl[j] >> 1) != (key >> 1) || fabs(de[j] - dc) > dtol) continue;
+            const bool mirror = ((cl[j] ^ key) & 1) != 0;
+            bool same = mirror || de[j] == dc;
+            for (int a = 0; a < 3; a++) {
+              const double pe = bd[AR_POS + 3 * e + a], pc = bd[AR_POS + 3 * c + a];
+              same = same && (mirror ? fabs(pe - pc) <= 1e-15 : pe == pc);
+            }
+            for (int a = 0; a < 9; a++) {
+              const double fe = bd[AR_FRAME + 9 * e + a], fc = bd[AR_FRAME + 9 * c + a];
+              same = same && (mirror ? fabs(((a < 3 || a >= 6) ? -fe : fe) - fc) <= 1e-15 : fe == fc);
+            }
             if (same) f = e;
           }
         }
         bi[ARI_FIRST + c] = f;
       }
+      __syncthreads();
+      // (equality up to a tolerance is not transitive: a contact may have matched a copy whose own match it failed on -- follow the
+      // chain to the group's representative)
+      int rep[(NCR + W - 1) / W];
+#pragma unroll
+      for (int q = 0; q < (NCR + W - 1) / W; q++) {
+        const int c = q * W + lane;
+        int f = c < nr ? bi[ARI_FIRST + c] : 0;
+        if (c < nr) while (bi[ARI_FIRST + f] != f) f = bi[ARI_FIRST + f];
+        rep[q] = f;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < (NCR + W - 1) / W; q++) { const int c = q * W + lane; if (c < nr) bi[ARI_FIRST + c] = rep[q]; }
       __syncthreads();
       // rank of the distinct contacts (in contact order), multiplicities by rank
       int nu = 0;
@@ -1643,7 +1682,16 @@ __device__ void fwd_collision(const HModel& m, const HParams& p, L& S, int lane,
         nu += __popcll(bal);
       }
       __syncthreads();
-      for (int c = lane; c < nr; c += W) atomicAdd(&bi[ARI_COUNT + bi[ARI_RANK + bi[ARI_FIRST + c]]], 1);   // (integer: order-free)
+      for (int c = lane; c < nr; c += W) {   // (integer atomics: order-free)
+        const int u = bi[ARI_RANK + bi[ARI_FIRST + c]];
+        atomicAdd(&bi[ARI_COUNT + u], 1);
+        // the copy's role in the ground-reaction query (robot_interface.py:269-301): geom1 off the robot, geom2 on a foot body
+        const int b1 = m.geom_i[GIS * bi[ARI_G1 + c] + GI_BODY], b2 = m.geom_i[GIS * bi[ARI_G2 + c] + GI_BODY];
+        if (m.body_i[BIS * b1 + BI_ROOT] != p.root_body) {
+          if (b2 == p.rfoot_body) atomicAdd(&bi[ARI_CNTR + u], 1);
+          if (b2 == p.lfoot_body) atomicAdd(&bi[ARI_CNTL + u], 1);
+        }
+      }
       __syncthreads();
       merged = true;
       ndist = nu;
@@ -1658,7 +1706,7 @@ __device__ void fwd_collision(const HModel& m, const HParams& p, L& S, int lane,
           for (int a = 0; a < 3; a++) S.con_pos[3 * u + a] = bd[AR_POS + 3 * c + a];
           for (int a = 0; a < 9; a++) S.U[U_CFRAME + 9 * u + a] = bd[AR_FRAME + 9 * c + a];
           S.con_g1[u] = bi[ARI_G1 + c]; S.con_g2[u] = bi[ARI_G2 + c]; S.con_pair[u] = bi[ARI_PAIR + c];
-          if constexpr (L::STEP_) S.con_mult[u] = mult;
+          if constexpr (L::STEP_) { S.con_mult[u] = mult; S.con_wr[u] = (double)bi[ARI_CNTR + u] / mult; S.con_wl[u] = (double)bi[ARI_CNTL + u] / mult; }
         } else if (u < NCB) {
           const int q = bi[ARI_PAIR + c];
           const double* pd = m.pair_d + PDS * q;
@@ -1667,7 +1715,7 @@ __device__ void fwd_collision(const HModel& m, const HParams& p, L& S, int lane,
           for (int a = 0; a < 3; a++) bd[BW_POS + 3 * u + a] = bd[AR_POS + 3 * c + a];
           for (int a = 0; a < 9; a++) bd[BW_FRAME + 9 * u + a] = bd[AR_FRAME + 9 * c + a];
           bi[BWI_G1 + u] = bi[ARI_G1 + c]; bi[BWI_G2 + u] = bi[ARI_G2 + c]; bi[BWI_PAIR + u] = q;
-          bd[BW_MULT + u] = mult;
+          bd[BW_MULT + u] = mult; bd[BW_WR + u] = (double)bi[ARI_CNTR + u] / mult; bd[BW_WL + u] = (double)bi[ARI_CNTL + u] / mult;
           // mj_contactParam, from the pair tables
           bi[BWI_XM + u] = m.pair_i[PIS * q + 3]; bi[BWI_M2 + u] = m.pair_i[PIS * q + 4];
           bd[BW_TRAN + u] = pd[10];
@@ -1700,7 +1748,13 @@ __device__ void fwd_collision(const HModel& m, const HParams& p, L& S, int lane,
     S.con_mu[c] = pd[2];
     S.U[U_CSOLREF + 2 * c] = pd[3]; S.U[U_CSOLREF + 2 * c + 1] = pd[4];
     for (int a = 0; a < 5; a++) S.U[U_CSOLIMP + 5 * c + a] = pd[5 + a];
-    if constexpr (L::STEP_) { if (!merged) S.con_mult[c] = 1.0; }
+    if constexpr (L::STEP_) {
+      if (!merged) {   // no merge in this sub-step: every contact stands for itself
+        const int b1 = m.geom_i[GIS * S.con_g1[c] + GI_BODY], b2 = m.geom_i[GIS * S.con_g2[c] + GI_BODY];
+        const bool floor1 = m.body_i[BIS * b1 + BI_ROOT] != p.root_body;
+        S.con_mult[c] = 1.0; S.con_wr[c] = (floor1 && b2 == p.rfoot_body) ? 1.0 : 0.0; S.con_wl[c] = (floor1 && b2 == p.lfoot_body) ? 1.0 : 0.0;
+      }
+    }
   }
   SYNC();
 }
@@ -2144,8 +2198,9 @@ __device__ __noinline__ void newton_big(const HModel& m, const HParams& p, L& S,
         const double n = g0 + g1 + g2 + g3, t1f = mu * (g0 - g1), t2f = mu * (g2 - g3);
         fn = sqrt(n * n + t1f * t1f + t2f * t2f);
       } else if (dim == 1) fn = fabs(bd[BW_FRC + r0]);
-      if (floor1 && b2 == p.rfoot_body) { grf_r += fn; cz = fmin(cz, bd[BW_POS + 3 * c + 2]); anyfoot = 1; }
-      if (floor1 && b2 == p.lfoot_body) { grf_l += fn; cz = fmin(cz, bd[BW_POS + 3 * c + 2]); anyfoot = 1; }
+      const double wr = bd[BW_WR + c], wl = bd[BW_WL + c];   // share of the merged copies that are floor contacts of the foot
+      if (wr > 0) { grf_r += wr * fn; cz = fmin(cz, bd[BW_POS + 3 * c + 2]); anyfoot = 1; }
+      if (wl > 0) { grf_l += wl * fn; cz = fmin(cz, bd[BW_POS + 3 * c + 2]); anyfoot = 1; }
     }
     grf_r = gsum<W>(grf_r); grf_l = gsum<W>(grf_l); cz = gmin<W>(cz);
     const bool af = gany<W>(anyfoot), sc = gany<W>(selfcol);
@@ -2849,8 +2904,15 @@ __device__ __forceinline__ bool control_step(const HModel& m, const HParams& p, 
                 fn = sqrt(n * n + t1f * t1f + t2f * t2f);
               } else fn = fabs(S.efc_force[r0]);
             }
-            if (floor1 && b2 == p.rfoot_body) { grf_r = fn; cz = S.con_pos[3 * c + 2]; anyfoot = 1; }
-            if (floor1 && b2 == p.lfoot_body) { grf_l = fn; cz = S.con_pos[3 * c + 2]; anyfoot = 1; }
+            if constexpr (TASK == TASK_STEP) {
+              // (a merged contact carries the sum of its copies' forces; the share of the copies that are floor contacts of the foot)
+              const double wr = S.con_wr[c], wl = S.con_wl[c];
+              if (wr > 0) { grf_r = wr * fn; cz = S.con_pos[3 * c + 2]; anyfoot = 1; }
+              if (wl > 0) { grf_l = wl * fn; cz = S.con_pos[3 * c + 2]; anyfoot = 1; }
+            } else {
+              if (floor1 && b2 == p.rfoot_body) { grf_r = fn; cz = S.con_pos[3 * c + 2]; anyfoot = 1; }
+              if (floor1 && b2 == p.lfoot_body) { grf_l = fn; cz = S.con_pos[3 * c + 2]; anyfoot = 1; }
+            }
           }
           grf_r = gsum<W>(grf_r); grf_l = gsum<W>(grf_l); cz = gmin<W>(cz);
           if (!gany<W>(anyfoot)) cz = 0;
@@ -3029,6 +3091,7 @@ __device__ __forceinline__ bool control_step(const HModel& m, const HParams& p, 
             for (int c = 0; c < S.ncon; c++) {
               const int b1 = m.geom_i[GIS * (S.con_g1[c]) + GI_BODY], b2 = m.geom_i[GIS * (S.con_g2[c]) + GI_BODY];
               if (m.body_i[BIS * (b1) + BI_ROOT] != p.root_body && (b2 == p.rfoot_body || b2 == p.lfoot_body)) anyc = 1;
+              if constexpr (TASK == TASK_STEP) { if (S.con_wr[c] > 0 || S.con_wl[c] > 0) anyc = 1; }
             }
             if constexpr (TASK == TASK_STEP && W == 64) { if (S.nbig) anyc = S.big_anyfoot; }
             ti[LHW_TIN_FOOT_CONTACT] = anyc; ti[LHW_TIN_SELF_COLLISION] = self_collision ? 1.0 : 0.0;
@@ -3626,6 +3689,22 @@ int humanoid_create(HumanoidEnv** out, const std::vector<int32_t>& mi, const std
       for (int a = 0; a < 10 && same; a++) same = ed[a] == pd[a];
       same = same && ed[10] == DF(LHW_DF_GEOM_INVWEIGHT0)[2 * g1] + DF(LHW_DF_GEOM_INVWEIGHT0)[2 * g2];
       if (same) { pi[5] = ei[5]; break; }
+    }
+    // merge class: a robot body against a static geom, whichever of the two is geom1 (same parameters, same robot body); pi[7] = 1
+    // if the robot's geom is geom1.  Other pairs (robot-robot, static-static) are a class of their own.
+    pi[6] = q; pi[7] = (b1 != 0 && b2 == 0) ? 1 : 0;
+    if ((b1 == 0) != (b2 == 0)) {
+      const int rb = b1 != 0 ? b1 : b2;
+      for (int e = 0; e < q; e++) {
+        const double* ed = &pair_d[(size_t)PDS * e];
+        const int* ei = &pair_i[(size_t)PIS * e];
+        const int eb1 = geom_i[(size_t)GIS * ei[0] + GI_BODY], eb2 = geom_i[(size_t)GIS * ei[1] + GI_BODY];
+        if ((eb1 == 0) == (eb2 == 0) || (eb1 != 0 ? eb1 : eb2) != rb || ei[2] != pi[2] || ei[3] != pi[3]) continue;
+        bool same = true;
+        for (int a = 0; a < 10 && same; a++) same = ed[a] == pd[a];
+        same = same && ed[10] == DF(LHW_DF_GEOM_INVWEIGHT0)[2 * g1] + DF(LHW_DF_GEOM_INVWEIGHT0)[2 * g2];
+        if (same) { pi[6] = ei[6]; break; }
+      }
     }
     pd[10] = DF(LHW_DF_GEOM_INVWEIGHT0)[2 * g1] + DF(LHW_DF_GEOM_INVWEIGHT0)[2 * g2];   // (the geoms' own copies: Model.fuse_static keeps them)
   }
