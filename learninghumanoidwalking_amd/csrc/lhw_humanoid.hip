@@ -1620,24 +1620,29 @@ __device__ void fwd_collision(const HModel& m, const HParams& p, L& S, int lane,
       // ulp: the floor contact of that foot corner (plane-box: geom1 = floor) beside its box contacts (box-box: geom1 = foot), which
       // two narrow phases compute to within 1-2 ulp of each other (measured: |d dist| <= 1e-18, |d pos| <= 3e-17).  The group's
       // representative is its earliest member; the copies only raise its multiplicity.
+      // (the scan's working arrays -- distance, class key, first -- live in LDS, in the contact-record cache of newton_big, idle here)
+      static_assert(L::NCK_ * 13 >= 2 * NCR, "merge scratch does not fit the record cache");
+      double* dds = S.bk_rec;                                   // [NCR] distance
+      int* kks = reinterpret_cast<int*>(S.bk_rec + NCR);        // [NCR] merge class * 2 + orientation
+      int* ffs = kks + NCR;                                     // [NCR] first
       for (int c = lane; c < nr; c += W) {
         const int q = bi[ARI_PAIR + c];
-        bi[ARI_RANK + c] = m.pair_i[PIS * q + 6] * 2 + m.pair_i[PIS * q + 7];   // (merge class and orientation, parked in the rank slot)
+        kks[c] = m.pair_i[PIS * q + 6] * 2 + m.pair_i[PIS * q + 7];
+        dds[c] = bd[AR_DIST + c];
         bi[ARI_COUNT + c] = 0; bi[ARI_CNTR + c] = 0; bi[ARI_CNTL + c] = 0;
       }
-      __syncthreads();
+      SYNC();
       for (int c = lane; c < nr; c += W) {
-        const int key = bi[ARI_RANK + c];
-        const double dc = bd[AR_DIST + c];
+        const int key = kks[c];
+        const double dc = dds[c];
         const double dtol = 1e-17 + 4e-16 * fabs(dc);
         int f = c;
-        // candidates in batches of eight: the class and distance loads of a batch are independent of one another (one memory
-        // round trip per batch instead of one per candidate); nearly every candidate fails on the distance
+        // candidates in batches of eight (eight independent LDS reads in flight); nearly every candidate fails on class or distance
         for (int e0 = 0; e0 < c && f == c; e0 += 8) {
           int cl[8];
           double de[8];
 #pragma unroll
-          for (int j = 0; j < 8; j++) { const int e = min(e0 + j, c); cl[j] = bi[ARI_RANK + e]; de[j] = bd[AR_DIST + e]; }
+          for (int j = 0; j < 8; j++) { const int e = min(e0 + j, c); cl[j] = kks[e]; de[j] = dds[e]; }
 #pragma unroll
           for (int j = 0; j < 8; j++) {
             const int e = e0 + j;
@@ -1655,28 +1660,28 @@ __device__ void fwd_collision(const HModel& m, const HParams& p, L& S, int lane,
             if (same) f = e;
           }
         }
-        bi[ARI_FIRST + c] = f;
+        ffs[c] = f;
       }
-      __syncthreads();
+      SYNC();
       // (equality up to a tolerance is not transitive: a contact may have matched a copy whose own match it failed on -- follow the
       // chain to the group's representative)
       int rep[(NCR + W - 1) / W];
 #pragma unroll
       for (int q = 0; q < (NCR + W - 1) / W; q++) {
         const int c = q * W + lane;
-        int f = c < nr ? bi[ARI_FIRST + c] : 0;
-        if (c < nr) while (bi[ARI_FIRST + f] != f) f = bi[ARI_FIRST + f];
+        int f = c < nr ? ffs[c] : 0;
+        if (c < nr) while (ffs[f] != f) f = ffs[f];
         rep[q] = f;
       }
-      __syncthreads();
+      SYNC();
 #pragma unroll
-      for (int q = 0; q < (NCR + W - 1) / W; q++) { const int c = q * W + lane; if (c < nr) bi[ARI_FIRST + c] = rep[q]; }
-      __syncthreads();
+      for (int q = 0; q < (NCR + W - 1) / W; q++) { const int c = q * W + lane; if (c < nr) { ffs[c] = rep[q]; bi[ARI_FIRST + c] = rep[q]; } }
+      SYNC();
       // rank of the distinct contacts (in contact order), multiplicities by rank
       int nu = 0;
       for (int c0 = 0; c0 < nr; c0 += W) {
         const int c = c0 + lane;
-        const bool uq = c < nr && bi[ARI_FIRST + c] == c;
+        const bool uq = c < nr && ffs[c] == c;
         const unsigned long long bal = __ballot(uq);
         if (uq) bi[ARI_RANK + c] = nu + __popcll(bal & ((1ull << lane) - 1ull));
         nu += __popcll(bal);
