@@ -199,7 +199,8 @@ int lhw_env_get_actuator_state(LhwEnv* env, double* pos_host, double* vel_host, 
  * sum of finished-episode lengths, number of finished episodes (host pointers, synchronous, resets them). */
 int lhw_env_pop_episode_stats(LhwEnv* env, double* ret_sum, double* len_sum, int64_t* count);
 /* Fault counters since the last call (host pointers, synchronous, resets them): control steps in which contacts were
- * dropped because more than the compiled-in cap were active, and control steps in which an env's state became
+ * dropped because more than the compiled-in cap were active (16 per env; the stepping task, whose feet rest on the floor AND on
+ * the terrain boxes under them, merges identical contacts and holds 192 found / 64 distinct ones per sub-step), and control steps in which an env's state became
  * non-finite (the env is flagged terminated, its outputs are zeroed, and it is reset like any finished episode). */
 int lhw_env_pop_fault_stats(LhwEnv* env, int64_t* contact_overflow, int64_t* diverged);
 /* Control steps since the last call that the two-envs-per-wave kernels handed to the one-env-per-wave kernel because an
