@@ -179,19 +179,40 @@ enum { LHW_STREAM_OBS = 4 };
 #define AI_CTRLLIMITED 2
 #define AI_FORCELIMITED 3
 
+// The model / task tables are read through pointers that are themselves loaded from HModel / HParams in device memory; the
+// compiler cannot tell where such a pointer points and would read the tables with FLAT loads -- 64-bit address arithmetic per
+// access, and a flat load counts on the LDS counter too, so every wait for an LDS read would also wait for the table loads in
+// flight.  Declared as global-address-space pointers (device pass only; the host pass and the SIMT emulator see plain pointers)
+// they become global loads off a scalar base, ordered independently of the LDS traffic.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define LHW_GLOBAL_AS __attribute__((address_space(1)))
+#else
+#define LHW_GLOBAL_AS
+#endif
+typedef const double LHW_GLOBAL_AS* gtab_d;
+typedef const int LHW_GLOBAL_AS* gtab_i;
+template <typename T>
+struct DevTab {   // what to_dev returns: converts to the table pointer type of either pass
+  const T* p;
+  operator const T*() const { return p; }
+#if defined(__HIP_DEVICE_COMPILE__)
+  operator const T LHW_GLOBAL_AS*() const { return (const T LHW_GLOBAL_AS*)p; }
+#endif
+};
+
 struct HModel {
   int nq, nv, nu, nbody, njnt, ngeom, npair, nlevel, iterations, disableflags;
   double timestep, gravity[3], tolerance, meaninertia, totalmass;
-  const double *body_d, *jnt_d, *dof_d, *geom_d, *act_d;
-  const int *body_i, *jnt_i, *dof_i, *geom_i, *act_i, *pair_i;   // pair_i / pair_d: one record per candidate pair (mj_contactParam is a function of the pair)
-  const double* pair_d;
+  gtab_d body_d, jnt_d, dof_d, geom_d, act_d;
+  gtab_i body_i, jnt_i, dof_i, geom_i, act_i, pair_i;   // pair_i / pair_d: one record per candidate pair (mj_contactParam is a function of the pair)
+  gtab_d pair_d;
   int has_primbox;     // some collision pair is sphere-box or capsule-box (collide_primbox)
-  const int* kin_i;      // [32][KIS], kin_d [32][KDS]: per lane of the chain layout, its jointed body and that body's frame relative to the
-  const double* kin_d;   //   previous jointed body (fwd_kinematics)
-  const int* fix_i;      // [nbody]: jointed body a welded body moves with (-1 for jointed bodies), fix_d [nbody][12]: its frame in that body's
-  const double* fix_d;
+  gtab_i kin_i;          // [32][KIS], kin_d [32][KDS]: per lane of the chain layout, its jointed body and that body's frame relative to the
+  gtab_d kin_d;          //   previous jointed body (fwd_kinematics)
+  gtab_i fix_i;          // [nbody]: jointed body a welded body moves with (-1 for jointed bodies), fix_d [nbody][12]: its frame in that body's
+  gtab_d fix_d;
   int max_owned;         // bodies per lane in chain_dynamics' per-body loop
-  const int* own_tab;    // [32][max_owned]: bodies whose force / inertia the lane of the chain layout contributes (-1: none)
+  gtab_i own_tab;        // [32][max_owned]: bodies whose force / inertia the lane of the chain layout contributes (-1: none)
   int track_body[3];  // bodies whose spatial velocity must survive the sub-step (the task reads them afterwards)
   double track_off[9];  // local offset of the tracked point on each of them (foot force sites for the stepping task)
 };
@@ -205,11 +226,11 @@ struct HParams {
   int rand_dof[10], rand_body[11], n_rand_dof, n_rand_body;
   int box_geom0, nbox, floor_geom, delay_frames, nplans;  // stepping task
   double target_radius;
-  const double* plans;                  // [nplans][1 + MAX_SEQ * 3]: length, then (x y theta) rows
+  gtab_d plans;                         // [nplans][1 + MAX_SEQ * 3]: length, then (x y theta) rows
   unsigned env_id_base;
   unsigned long long seed;
   double action_smoothing, goal_height, init_noise, force_mag, torque_mag;
-  const double *kp, *kd, *nominal_qpos, *action_offset, *clock_lut, *neutral_pose, *obs_noise;
+  gtab_d kp, kd, nominal_qpos, action_offset, clock_lut, neutral_pose, obs_noise;
 };
 
 // what changes from launch to launch (everything else of the task configuration sits in device memory: HumanoidEnv::p_dev)
@@ -233,6 +254,18 @@ struct HState {
   double* bigd;    // stepping task: [N][BW_DOUBLES] / [N][BW_INTS] workspace of the many-contact path (NULL for the other tasks)
   int* bigi;
 };
+// Analysis builds (-DLHW_FINEPROF=<phase slot>): the phase of that slot is split further, FINE_MARK(phase, i) accumulating the
+// clock of env 0 into g_fine[i] (read back through lhw_env_profile in place of the phase table).  Compiled out of the product.
+#ifdef LHW_FINEPROF
+__device__ long long g_fine[16];
+__device__ long long g_fine_t;
+#define FINE_ON(ph) (LHW_FINEPROF == (ph) && blockIdx.x == 0 && threadIdx.x == 0)
+#define FINE_BEGIN(ph) do { if (FINE_ON(ph)) g_fine_t = (long long)clock64(); } while (0)
+#define FINE_MARK(ph, i) do { if (FINE_ON(ph)) { const long long n_ = (long long)clock64(); g_fine[i] += n_ - g_fine_t; g_fine_t = n_; } } while (0)
+#else
+#define FINE_BEGIN(ph)
+#define FINE_MARK(ph, i)
+#endif
 #define PROF_BEGIN() long long prof_t = (st_prof && lane == 0) ? (long long)clock64() : 0   // lane = lane within the group
 #ifdef LHW_ASM_MARKS   // (analysis builds: phase boundaries as comments in the ISA listing)
 #define ASM_MARK(slot) asm volatile("; LHW_PHASE " #slot)
@@ -1537,6 +1570,7 @@ __device__ void collide_pair(ConSink<L>& k, const HModel& m, const L& S, int g1,
 
 template <bool BOXBOX, class L>
 __device__ void fwd_collision(const HModel& m, const HParams& p, L& S, int lane, const double* ter, double* bd, int* bi) {
+  FINE_BEGIN(3);
   if (lane < m.ngeom) {
     const int g = lane, b = m.geom_i[GIS * (g) + GI_BODY];
     double gp[3] = {m.geom_d[GDS * (g) + GD_POS], m.geom_d[GDS * (g) + GD_POS + 1], m.geom_d[GDS * (g) + GD_POS + 2]}, t[3];
@@ -1559,6 +1593,7 @@ __device__ void fwd_collision(const HModel& m, const HParams& p, L& S, int lane,
     for (int k = 0; k < 9; k++) S.U[U_GMAT + 9 * g + k] = R[k];
   }
   SYNC();
+  FINE_MARK(3, 0);
   int g1 = 0, g2 = 0;
   double margin = 0;
   bool have = lane < m.npair;
@@ -1588,8 +1623,10 @@ __device__ void fwd_collision(const HModel& m, const HParams& p, L& S, int lane,
     }
   }
   int total;
+  FINE_MARK(3, 1);
   const int mine = k.n;   // (pairs without a contact skip the writing pass: most of them, most of the time)
   const int base = gscan<L::W_>(k.n, &total) - k.n;
+  FINE_MARK(3, 2);
   k.base = base; k.n = 0; k.write = 1;
   // more contacts than the group has row lanes for (stepping task, one env per wave): all of them go to the raw region of the HBM
   // workspace, exact copies are merged there, and the distinct ones come back with their multiplicity (see the workspace layout)
@@ -1605,6 +1642,7 @@ __device__ void fwd_collision(const HModel& m, const HParams& p, L& S, int lane,
       for (int q = 0; q < br.cnt; q++) k.emit(br.dist[q], &br.pos[3 * q], br.n, zero);
     }
   }
+  FINE_MARK(3, 3);
   int ndist = min(total, NC);   // contacts the LDS arrays will hold
   bool merged = false;
   if constexpr (BOXBOX && L::W_ == 64) {
@@ -1734,6 +1772,7 @@ __device__ void fwd_collision(const HModel& m, const HParams& p, L& S, int lane,
       __syncthreads();
     }
   }
+  FINE_MARK(3, 4);
   if (lane == 0) {
     const bool inlds = ndist <= NC;
     S.ncon = inlds ? ndist : 0;
@@ -1762,6 +1801,7 @@ __device__ void fwd_collision(const HModel& m, const HParams& p, L& S, int lane,
     }
   }
   SYNC();
+  FINE_MARK(3, 5);
 }
 
 // getsolparam + getimpedance + KBIP + R for one row
@@ -2388,6 +2428,7 @@ __device__ __forceinline__ void solve_tail(const HModel& m, const HParams& p, L&
       }
       *cost = cs; *ufrc = uf; *udact = ud;
     };
+    FINE_BEGIN(7);
     const double scale = 1.0 / (m.meaninertia * (NV > 1 ? NV : 1));
     double warm_jw = 0, warm_js = 0, warm_Ma = 0;
     bool warm_pick_s = false, warm_have = false;
@@ -2407,6 +2448,7 @@ __device__ __forceinline__ void solve_tail(const HModel& m, const HParams& p, L&
       qacc = (cw > cs) ? as : w;
       warm_jw = jw; warm_js = js; warm_Ma = Ma; warm_pick_s = cw > cs; warm_have = true;
     }
+    FINE_MARK(7, 0);
     double cost = 0, oldcost = 0;
     double ja_run = 0, Ma_run = 0;
     bool have_prod = false;
@@ -2429,6 +2471,7 @@ __device__ __forceinline__ void solve_tail(const HModel& m, const HParams& p, L&
       eval_rows(ja, qacc, &c, &force, &dactive, &ufrc, &udact);
       if (prim) c += 0.5 * (Ma - fs) * (qacc - as);
       oldcost = cost;
+      FINE_MARK(7, 1);
       S.U[U_EVEC + lane] = force; S.efc_force[lane] = force; S.U[U_DACT + lane] = dactive;   // lane = contact row (NE == W)
       SYNC();
       double grad = 0;
@@ -2453,6 +2496,7 @@ __device__ __forceinline__ void solve_tail(const HModel& m, const HParams& p, L&
           grad = Ma - fs - fcon;
         }
       }
+      FINE_MARK(7, 2);
       double gn;
       gsum2<W>(c, prim ? grad * grad : 0.0, cost, gn);   // the cost of this iterate and the squared gradient norm in one reduction
       gn = sqrt(gn);
@@ -2461,6 +2505,8 @@ __device__ __forceinline__ void solve_tail(const HModel& m, const HParams& p, L&
       if (iter == m.iterations) break;
       // H = M + J^T D_active J, row of this lane's dof accumulated in the registers the factorisation works on; the diagonal
       // entry travels separately (hd)
+      FINE_MARK(7, 3);
+      FINE_BEGIN(2);
       PROF_MARK(7);    // (Newton: cost / gradient passes in slot 7, Hessian + factor + solve in slot 2, line search in slot 15)
       double Hrow[NR], hd = mdiag + udact;
 #pragma unroll
@@ -2508,7 +2554,9 @@ __device__ __forceinline__ void solve_tail(const HModel& m, const HParams& p, L&
           for (int k = 0; k < 6; k++) Hrow[k] = 0.0;
         }
       }
+      FINE_MARK(2, 0);
       const double search = cross ? -dense_lds_solve<L>(S, Hrow, hd, grad, dof, prim, coff, mm_all) : -spd_solve(Hrow, hd, grad);
+      FINE_MARK(2, 1);
       PROF_MARK(2);
       if (prim) S.U[U_VEC2 + dd] = search;
       SYNC();
@@ -2553,6 +2601,7 @@ __device__ __forceinline__ void solve_tail(const HModel& m, const HParams& p, L&
         }
       }
       PROF_MARK(15);
+      FINE_BEGIN(7);
       if (alpha == 0) break;
       qacc += alpha * search;
       ja_run += alpha * jv; Ma_run += alpha * Mv;
@@ -2563,6 +2612,7 @@ __device__ __forceinline__ void solve_tail(const HModel& m, const HParams& p, L&
   SYNC();
   if (prim) S.qacc[dd] = qacc;   // mj_fwdConstraint: also the next warm start
   SYNC();
+  FINE_MARK(7, 4);
   PROF_MARK(7);
   if (!(flags & 2)) return;
   // ------------------------------------------------------------ mj_Euler (implicit joint damping) + mj_advance
@@ -3436,12 +3486,12 @@ static void h_quat2mat(double* R, const double* q) {
 }
 
 template <typename T>
-static const T* to_dev(HumanoidEnv* h, const T* src, size_t n) {
+static DevTab<T> to_dev(HumanoidEnv* h, const T* src, size_t n) {
   void* d = nullptr;
-  if (lhw_malloc(&d, std::max<size_t>(1, n) * sizeof(T)) != hipSuccess) return nullptr;
-  if (n && hipMemcpy(d, src, n * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+  if (lhw_malloc(&d, std::max<size_t>(1, n) * sizeof(T)) != hipSuccess) return DevTab<T>{nullptr};
+  if (n && hipMemcpy(d, src, n * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) return DevTab<T>{nullptr};
   h->dev_allocs.push_back(d);
-  return (const T*)d;
+  return DevTab<T>{(const T*)d};
 }
 
 static bool humanoid_upload_params(HumanoidEnv* h) {
@@ -3860,7 +3910,7 @@ int humanoid_create(HumanoidEnv** out, const std::vector<int32_t>& mi, const std
       for (int a = 0; a < 3; a++) one[P_IPOS + 3 * b + a] = DF(LHW_DF_BODY_IPOS)[3 * bsrc[b] + a];
     }
     for (size_t n = 0; n < N; n++) std::copy(one.begin(), one.end(), all.begin() + n * PRM_D);
-    h->st.prm = const_cast<double*>(to_dev<double>(h, all.data(), all.size()));
+    h->st.prm = const_cast<double*>(to_dev<double>(h, all.data(), all.size()).p);
     ok = ok && h->st.prm != nullptr;
   }
   h->st.ter = nullptr;
@@ -3874,7 +3924,7 @@ int humanoid_create(HumanoidEnv** out, const std::vector<int32_t>& mi, const std
       one[T_SEQ + 6 * k + 3] = 0; one[T_SEQ + 6 * k + 4] = 1; one[T_SEQ + 6 * k + 5] = 0;
     }
     for (size_t n = 0; n < N; n++) std::copy(one.begin(), one.end(), all.begin() + n * TER_D);
-    h->st.ter = const_cast<double*>(to_dev<double>(h, all.data(), all.size()));
+    h->st.ter = const_cast<double*>(to_dev<double>(h, all.data(), all.size()).p);
     ok = ok && h->st.ter != nullptr;
   }
   h->st.bigd = nullptr; h->st.bigi = nullptr;
@@ -4030,6 +4080,11 @@ int humanoid_profile(HumanoidEnv* h, int enable, long long* out16) {
     (void)hipDeviceSynchronize();
     (void)hipMemcpy(out16, h->st.prof, 16 * sizeof(long long), hipMemcpyDeviceToHost);
     (void)hipMemset(h->st.prof, 0, 16 * sizeof(long long));
+#ifdef LHW_FINEPROF
+    static const long long zero16[16] = {0};
+    (void)hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_fine), 16 * sizeof(long long));
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_fine), zero16, 16 * sizeof(long long));
+#endif
   }
   return 0;
 }
