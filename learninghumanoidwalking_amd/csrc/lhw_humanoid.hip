@@ -191,6 +191,8 @@ enum { LHW_STREAM_OBS = 4 };
 #endif
 typedef const double LHW_GLOBAL_AS* gtab_d;
 typedef const int LHW_GLOBAL_AS* gtab_i;
+typedef double LHW_GLOBAL_AS* gws_d;   // (the many-contact workspace of the stepping task: read and written)
+typedef int LHW_GLOBAL_AS* gws_i;
 template <typename T>
 struct DevTab {   // what to_dev returns: converts to the table pointer type of either pass
   const T* p;
@@ -1138,8 +1140,8 @@ template <class L>
 struct ConSink {
   L* S;
   int base, n, write, g1, g2, pair;
-  double* gd = nullptr;   // non-NULL: the contacts go to the raw region of the HBM workspace (AR_* / ARI_* layout), capacity NCR
-  int* gi = nullptr;
+  gws_d gd = nullptr;     // non-NULL: the contacts go to the raw region of the HBM workspace (AR_* / ARI_* layout), capacity NCR
+  gws_i gi = nullptr;
   __device__ __forceinline__ void emit(double dist, const double* pos, const double* nrm, const double* tan) {
     if (write) {
       const int c = base + n;
@@ -1569,7 +1571,7 @@ __device__ void collide_pair(ConSink<L>& k, const HModel& m, const L& S, int g1,
 }
 
 template <bool BOXBOX, class L>
-__device__ void fwd_collision(const HModel& m, const HParams& p, L& S, int lane, const double* ter, double* bd, int* bi) {
+__device__ void fwd_collision(const HModel& m, const HParams& p, L& S, int lane, gtab_d ter, gws_d bd, gws_i bi) {
   FINE_BEGIN(3);
   if (lane < m.ngeom) {
     const int g = lane, b = m.geom_i[GIS * (g) + GI_BODY];
@@ -1960,7 +1962,7 @@ __device__ __forceinline__ double dense_lds_solve(L& S, const double (&Hrow)[NR]
 // Slow by construction (~100 contacts = ~400 rows = seven chunks per sweep, five to six sweeps per sub-step): it exists so that the
 // terrain of the reference is the terrain of the kernel, not to be fast.
 template <class L>
-__device__ __noinline__ void newton_big(const HModel& m, const HParams& p, L& S, const int lane, double* __restrict__ bd, int* __restrict__ bi,
+__device__ __noinline__ void newton_big(const HModel& m, const HParams& p, L& S, const int lane, gws_d __restrict__ bd, gws_i __restrict__ bi,
                                         const int dof, const bool prim, const double (&Mrow)[NR], const double mdiag, const double marm,
                                         const double fs, const double as, const bool (&uon)[3], const double (&uD)[3],
                                         const double (&uaref)[3], const double ufl, const bool anyunit, double& qacc_out, double& fcon_out) {
@@ -2262,7 +2264,7 @@ __device__ __noinline__ void newton_big(const HModel& m, const HParams& p, L& S,
 template <class L>
 __device__ __forceinline__ void solve_tail(const HModel& m, const HParams& p, L& S, const int lane, const int flags, long long* st_prof,
                                            const int dof, const bool prim, const bool cross, const double (&Mrow)[NR], const double mdiag,
-                                           const double marm, const double qapp, const double bias, double* bd, int* bi) {
+                                           const double marm, const double qapp, const double bias, gws_d bd, gws_i bi) {
   constexpr int W = L::W_;
   PROF_BEGIN();
   const int dd = dof >= 0 ? dof : 0;   // (lanes without a dof shadow dof 0; nothing of theirs is used)
@@ -2658,7 +2660,7 @@ __device__ __forceinline__ void solve_tail(const HModel& m, const HParams& p, L&
 // J x is the lane's own element, J^T f lands on the lane's own dof, J^T D J on its own diagonal entry.  Only the summation
 // order differs from the row order of the reference; every row is there.
 template <bool BOXBOX, class L>
-__device__ __forceinline__ void substep(const HModel& m, const HParams& p, L* SG0, int flags, long long* st_prof, const double* ter, double* bd, int* bi) {
+__device__ __forceinline__ void substep(const HModel& m, const HParams& p, L* SG0, int flags, long long* st_prof, gtab_d ter, gws_d bd, gws_i bi) {
   constexpr int W = L::W_;
   long long prof_t;
   { FRESH_GROUP(W, SG0); prof_t = (st_prof && lane == 0) ? (long long)clock64() : 0; fwd_kinematics<BOXBOX>(m, S, lane); PROF_MARK(0); }
@@ -3393,8 +3395,9 @@ __device__ __forceinline__ bool control_step(const HModel& m, const HParams& p, 
     // (Every phase of the sub-step takes its lane index from fresh_wave_lane(): besides keeping the addresses built from it out of
     // scratch, the opaque value keeps the ~100 model-table loads of a sub-step -- indexed by the lane, invariant across the 25
     // sub-steps -- inside the loop.  Hoisted, they would be parked in scratch and reloaded from there, FETCH_SIZE 708 MB per launch.)
-    substep<TASK == TASK_STEP>(m, p, SG0, flags, sprof, ter, (TASK == TASK_STEP && W == 64 && st.bigd) ? st.bigd + (size_t)env * BW_DOUBLES : nullptr,
-                               (TASK == TASK_STEP && W == 64 && st.bigd) ? st.bigi + (size_t)env * BW_INTS : nullptr);
+    substep<TASK == TASK_STEP>(m, p, SG0, flags, sprof, (gtab_d)ter,
+                               (TASK == TASK_STEP && W == 64 && st.bigd) ? (gws_d)(st.bigd + (size_t)env * BW_DOUBLES) : (gws_d) nullptr,
+                               (TASK == TASK_STEP && W == 64 && st.bigd) ? (gws_i)(st.bigi + (size_t)env * BW_INTS) : (gws_i) nullptr);
     if (stage == ST_LAST) break;
     // two envs per wave: an env that needs more contacts than this layout holds is handed to the one-env-per-wave kernel
     // untouched (nothing of it has been written yet); once its outputs are out, it can only truncate like that kernel does
