@@ -136,7 +136,7 @@ enum { LHW_STREAM_OBS = 4 };
 #define JI_LIMITED 1
 #define JI_QADR 2
 #define JI_DADR 3
-#define DDS 12  // dof_d: armature damping invweight0 frictionloss solref2 solimp5 gear(of the dof's actuator)
+#define DDS 16  // dof_d: armature damping invweight0 frictionloss solref2 solimp5 gear(of the dof's actuator) | range2 margin of its joint (copies) pad
 #define DD_ARMATURE 0
 #define DD_DAMPING 1
 #define DD_INVW 2
@@ -144,12 +144,18 @@ enum { LHW_STREAM_OBS = 4 };
 #define DD_SOLREF 4
 #define DD_SOLIMP 6
 #define DD_GEAR 11
-#define DIS 6   // dof_i: body joint kind(0 free-trans 1 free-rot 2 slide 3 hinge) prevmask actuator(-1 none) pad
+#define DD_RANGE 12
+#define DD_MARGIN 14
+#define DIS 8   // dof_i: body joint kind(0 free-trans 1 free-rot 2 slide 3 hinge) prevmask actuator(-1 none) | index within its joint,
+                //        joint limited, joint qposadr (copies of the joint record: one table round trip where the dof is the key)
 #define DI_BODY 0
 #define DI_JNT 1
 #define DI_KIND 2
 #define DI_PREVMASK 3
 #define DI_ACT 4
+#define DI_KIDX 5
+#define DI_LIMITED 6
+#define DI_QADR 7
 #define GDS 28  // geom_d: pos3 R_local9 size3 friction3 solmix solref2 solimp5 margin gap
 #define GD_POS 0
 #define GD_RLOC 3
@@ -169,8 +175,13 @@ enum { LHW_STREAM_OBS = 4 };
 #define AD_GEAR 0
 #define AD_CTRLRANGE 1
 #define AD_FORCERANGE 3
-#define PIS 8   // pair_i: geom1 geom2 condim xmask(dofs moving exactly one body) mask2(dofs moving body 2) class | merge class, robot-is-geom1
-#define PDS 12  // pair_d: margin includemargin friction solref2 solimp5 invweight(sum of the two bodies' translational) pad
+#define PIS 10  // pair_i: geom1 geom2 condim xmask(dofs moving exactly one body) mask2(dofs moving body 2) class | merge class, robot-is-geom1 |
+                //         type of geom1, of geom2 (copies: the narrow phase reads its pair record only, one table round trip)
+#define PDS 18  // pair_d: margin includemargin friction solref2 solimp5 invweight(sum of the two bodies' translational) | size3 of geom1, of geom2 | pad
+#define PD_SIZE1 11
+#define PD_SIZE2 14
+#define PI_TYPE1 8
+#define PI_TYPE2 9
 #define AIS 6   // act_i: dof joint ctrllimited forcelimited qposadr dofadr(of the joint)
 #define AI_QADR 4
 #define AI_DADR 5
@@ -837,11 +848,13 @@ __device__ void fwd_kinematics(const HModel& m, L& S, int lane) {
   if (lane < 32) {
     const int* ki = m.kin_i + KIS * lane;
     kb = ki[0]; jt = ki[1]; jid = ki[3];
+    // (the lane's frame record is fetched beside its index record, not behind it: one table round trip instead of two; lanes without
+    // a body hold a zero record)
+    double kd[KDS];
+#pragma unroll
+    for (int k = 0; k < KDS; k++) kd[k] = m.kin_d[KDS * lane + k];
     if (kb >= 0) {
       const int qa = ki[2];
-      double kd[KDS];
-#pragma unroll
-      for (int k = 0; k < KDS; k++) kd[k] = m.kin_d[KDS * lane + k];
       for (int k = 0; k < 3; k++) { jax[k] = kd[12 + k]; jps[k] = kd[15 + k]; }
       if (jt == JT_FREE) {
         double q[4] = {S.qpos[qa + 3], S.qpos[qa + 4], S.qpos[qa + 5], S.qpos[qa + 6]};
@@ -899,11 +912,14 @@ __device__ void fwd_kinematics(const HModel& m, L& S, int lane) {
   const bool valid = b >= 1 && b < m.nbody;
   if (valid) {
     const int ow = m.fix_i[b];             // the jointed body this one is welded to (-1: it has a joint itself)
-    if (ow >= 0) {
-      double Ro[9], Rf[9], Rb[9], t[3];
+    double Rf[9];
 #pragma unroll
-      for (int k = 0; k < 9; k++) { Ro[k] = S.U[U_XMAT + 9 * ow + k]; Rf[k] = m.fix_d[12 * b + k]; }
-      const double pf[3] = {m.fix_d[12 * b + 9], m.fix_d[12 * b + 10], m.fix_d[12 * b + 11]};
+    for (int k = 0; k < 9; k++) Rf[k] = m.fix_d[12 * b + k];   // (fetched beside the index, not behind it)
+    const double pf[3] = {m.fix_d[12 * b + 9], m.fix_d[12 * b + 10], m.fix_d[12 * b + 11]};
+    if (ow >= 0) {
+      double Ro[9], Rb[9], t[3];
+#pragma unroll
+      for (int k = 0; k < 9; k++) Ro[k] = S.U[U_XMAT + 9 * ow + k];
       mat_mul(Rb, Ro, Rf);
       mat_vec(t, Ro, pf);
       for (int k = 0; k < 3; k++) S.xpos[3 * b + k] = S.xpos[3 * ow + k] + t[k];
@@ -974,7 +990,7 @@ __device__ void fwd_com(const HModel& m, const HParams& p, L& S, int lane) {
   }
   if (lane < NV) {
     const int d = lane, j = m.dof_i[DIS * (d) + DI_JNT], b = m.dof_i[DIS * (d) + DI_BODY], kind = m.dof_i[DIS * (d) + DI_KIND];
-    const int t = kind <= 1 ? JT_FREE : (kind == 2 ? JT_SLIDE : JT_HINGE), k = d - m.jnt_i[JIS * (j) + JI_DADR];
+    const int t = kind <= 1 ? JT_FREE : (kind == 2 ? JT_SLIDE : JT_HINGE), k = m.dof_i[DIS * (d) + DI_KIDX];
     double off[3], ax[3], c[6];
     for (int a = 0; a < 3; a++) off[a] = com[a] - S.U[U_XANCHOR + 3 * j + a];
     if (t == JT_FREE && k < 3) {
@@ -1221,10 +1237,10 @@ __device__ __forceinline__ double sel3(int i, double a0, double a1, double a2) {
 // whole narrow phase lives in registers: the first version kept the clipped polygon in scratch memory and cost ~58 k
 // cycles per sub-step for a wave with feet on boxes.
 template <class L>
-__device__ __noinline__ void col_box_box(BoxRec& k, const HModel& m, const L& S, int g1, int g2, double margin) {
+__device__ __noinline__ void col_box_box(BoxRec& k, const HModel& m, const L& S, int q, int g1, int g2, double margin) {
   double p1[3], p2[3], R1[9], R2[9], s1[3], s2[3];
 #pragma unroll
-  for (int a = 0; a < 3; a++) { p1[a] = S.U[U_GPOS + 3 * g1 + a]; p2[a] = S.U[U_GPOS + 3 * g2 + a]; s1[a] = m.geom_d[GDS * (g1) + GD_SIZE + a]; s2[a] = m.geom_d[GDS * (g2) + GD_SIZE + a]; }
+  for (int a = 0; a < 3; a++) { p1[a] = S.U[U_GPOS + 3 * g1 + a]; p2[a] = S.U[U_GPOS + 3 * g2 + a]; s1[a] = m.pair_d[PDS * q + PD_SIZE1 + a]; s2[a] = m.pair_d[PDS * q + PD_SIZE2 + a]; }
 #pragma unroll
   for (int a = 0; a < 9; a++) { R1[a] = S.U[U_GMAT + 9 * g1 + a]; R2[a] = S.U[U_GMAT + 9 * g2 + a]; }
   double A[3][3], B[3][3];
@@ -1444,11 +1460,11 @@ __device__ __forceinline__ double seg_box_slope(const double* c0, const double* 
 // scalar branch): models without such pairs -- the stand-ins -- must not pay for this code (inside collide_pair's dispatch
 // chain the compiler speculated parts of it for every pair: +8 % VALU instructions per sub-step).
 template <class L>
-__device__ void collide_primbox(ConSink<L>& k, const HModel& m, const L& S, int g1, int g2, double margin) {
+__device__ void collide_primbox(ConSink<L>& k, const HModel& m, const L& S, int q, int g1, int g2, double margin) {
   const double zero[3] = {0, 0, 0};
-  const int t1 = m.geom_i[GIS * (g1) + GI_TYPE];
+  const int t1 = m.pair_i[PIS * q + PI_TYPE1];
   double p1[3], p2[3], R1[9], R2[9], s1[3], s2[3];
-  for (int a = 0; a < 3; a++) { p1[a] = S.U[U_GPOS + 3 * g1 + a]; p2[a] = S.U[U_GPOS + 3 * g2 + a]; s1[a] = m.geom_d[GDS * (g1) + GD_SIZE + a]; s2[a] = m.geom_d[GDS * (g2) + GD_SIZE + a]; }
+  for (int a = 0; a < 3; a++) { p1[a] = S.U[U_GPOS + 3 * g1 + a]; p2[a] = S.U[U_GPOS + 3 * g2 + a]; s1[a] = m.pair_d[PDS * q + PD_SIZE1 + a]; s2[a] = m.pair_d[PDS * q + PD_SIZE2 + a]; }
   for (int a = 0; a < 9; a++) { R1[a] = S.U[U_GMAT + 9 * g1 + a]; R2[a] = S.U[U_GMAT + 9 * g2 + a]; }
   if (t1 == G_SPHERE) {
     double dist, pos[3], nrm[3];
@@ -1501,11 +1517,11 @@ __device__ void collide_primbox(ConSink<L>& k, const HModel& m, const L& S, int 
 }
 
 template <class L>
-__device__ void collide_pair(ConSink<L>& k, const HModel& m, const L& S, int g1, int g2, double margin) {
+__device__ void collide_pair(ConSink<L>& k, const HModel& m, const L& S, int q, int g1, int g2, double margin) {
   const double zero[3] = {0, 0, 0};
-  const int t1 = m.geom_i[GIS * (g1) + GI_TYPE], t2 = m.geom_i[GIS * (g2) + GI_TYPE];
+  const int t1 = m.pair_i[PIS * q + PI_TYPE1], t2 = m.pair_i[PIS * q + PI_TYPE2];
   double p1[3], p2[3], R1[9], R2[9], s1[3], s2[3];
-  for (int a = 0; a < 3; a++) { p1[a] = S.U[U_GPOS + 3 * g1 + a]; p2[a] = S.U[U_GPOS + 3 * g2 + a]; s1[a] = m.geom_d[GDS * (g1) + GD_SIZE + a]; s2[a] = m.geom_d[GDS * (g2) + GD_SIZE + a]; }
+  for (int a = 0; a < 3; a++) { p1[a] = S.U[U_GPOS + 3 * g1 + a]; p2[a] = S.U[U_GPOS + 3 * g2 + a]; s1[a] = m.pair_d[PDS * q + PD_SIZE1 + a]; s2[a] = m.pair_d[PDS * q + PD_SIZE2 + a]; }
   for (int a = 0; a < 9; a++) { R1[a] = S.U[U_GMAT + 9 * g1 + a]; R2[a] = S.U[U_GMAT + 9 * g2 + a]; }
   if (t1 == G_PLANE && t2 == G_SPHERE) col_plane_sphere(k, p1, R1, p2, s2[0], margin, zero);
   else if (t1 == G_PLANE && t2 == G_CAPSULE) {
@@ -1596,11 +1612,11 @@ __device__ void fwd_collision(const HModel& m, const HParams& p, L& S, int lane,
   }
   SYNC();
   FINE_MARK(3, 0);
-  int g1 = 0, g2 = 0;
+  int g1 = 0, g2 = 0, ty1 = -1, ty2 = -1;
   double margin = 0;
   bool have = lane < m.npair;
   if (have) {
-    g1 = m.pair_i[PIS * lane]; g2 = m.pair_i[PIS * lane + 1];
+    g1 = m.pair_i[PIS * lane]; g2 = m.pair_i[PIS * lane + 1]; ty1 = m.pair_i[PIS * lane + PI_TYPE1]; ty2 = m.pair_i[PIS * lane + PI_TYPE2];
     margin = m.pair_d[PDS * lane];
     // (the terrain boxes collide in every walk mode, as the reference leaves them -- coplanar with the floor outside FORWARD mode,
     // tasks/stepping_task.py:320-334: an env with more than NC contacts takes the many-contact path below)
@@ -1611,17 +1627,17 @@ __device__ void fwd_collision(const HModel& m, const HParams& p, L& S, int lane,
   BoxRec br;
   br.cnt = 0;
   bool boxpair = false;
-  if constexpr (BOXBOX) boxpair = have && m.geom_i[GIS * g1 + GI_TYPE] == G_BOX && m.geom_i[GIS * g2 + GI_TYPE] == G_BOX;
+  if constexpr (BOXBOX) boxpair = have && ty1 == G_BOX && ty2 == G_BOX;
   bool primbox = false;
   if (m.has_primbox && have) {
-    const int ta = m.geom_i[GIS * g1 + GI_TYPE], tb = m.geom_i[GIS * g2 + GI_TYPE];
+    const int ta = ty1, tb = ty2;
     primbox = tb == G_BOX && (ta == G_SPHERE || ta == G_CAPSULE);
   }
-  if (have && !boxpair && !primbox) collide_pair(k, m, S, g1, g2, margin);
-  if (m.has_primbox) { if (primbox) collide_primbox(k, m, S, g1, g2, margin); }
+  if (have && !boxpair && !primbox) collide_pair(k, m, S, lane, g1, g2, margin);
+  if (m.has_primbox) { if (primbox) collide_primbox(k, m, S, lane, g1, g2, margin); }
   if constexpr (BOXBOX) {
     if (gany<L::W_>(boxpair)) {
-      if (boxpair) { col_box_box(br, m, S, g1, g2, margin); k.n = br.cnt; }
+      if (boxpair) { col_box_box(br, m, S, lane, g1, g2, margin); k.n = br.cnt; }
     }
   }
   int total;
@@ -1636,8 +1652,8 @@ __device__ void fwd_collision(const HModel& m, const HParams& p, L& S, int lane,
   if constexpr (BOXBOX && L::W_ == 64) big = bd != nullptr && total > NC;
   const int cap = big ? NCR : NC;
   if (big) { k.gd = bd; k.gi = bi; }
-  if (have && !boxpair && !primbox && mine > 0 && base < cap) collide_pair(k, m, S, g1, g2, margin);
-  if (m.has_primbox) { if (primbox && mine > 0 && base < cap) collide_primbox(k, m, S, g1, g2, margin); }
+  if (have && !boxpair && !primbox && mine > 0 && base < cap) collide_pair(k, m, S, lane, g1, g2, margin);
+  if (m.has_primbox) { if (primbox && mine > 0 && base < cap) collide_primbox(k, m, S, lane, g1, g2, margin); }
   if constexpr (BOXBOX) {
     if (boxpair && base < cap) {
       const double zero[3] = {0, 0, 0};
@@ -2352,9 +2368,9 @@ __device__ __forceinline__ void solve_tail(const HModel& m, const HParams& p, L&
       uon[0] = true; uD[0] = 1 / R; uaref[0] = -B * qv; ufl = fl;
     }
     const int j = m.dof_i[DIS * d + DI_JNT];
-    if (m.dof_i[DIS * d + DI_KIND] >= 2 && m.jnt_i[JIS * j + JI_LIMITED]) {
-      const double q = S.qpos[m.jnt_i[JIS * j + JI_QADR]], mg = m.jnt_d[JDS * j + JD_MARGIN];
-      const double dlo = q - m.jnt_d[JDS * j + JD_RANGE], dhi = m.jnt_d[JDS * j + JD_RANGE + 1] - q;
+    if (m.dof_i[DIS * d + DI_KIND] >= 2 && m.dof_i[DIS * d + DI_LIMITED]) {
+      const double q = S.qpos[m.dof_i[DIS * d + DI_QADR]], mg = m.dof_d[DDS * d + DD_MARGIN];
+      const double dlo = q - m.dof_d[DDS * d + DD_RANGE], dhi = m.dof_d[DDS * d + DD_RANGE + 1] - q;
       if (dlo < mg || dhi < mg) {
         double sr[2] = {m.jnt_d[JDS * j + JD_SOLREF], m.jnt_d[JDS * j + JD_SOLREF + 1]}, si[5], K, B, imp, R;
         for (int a = 0; a < 5; a++) si[a] = m.jnt_d[JDS * j + JD_SOLIMP + a];
@@ -3451,7 +3467,7 @@ __global__ void __launch_bounds__(64, LHW_WAVES_PER_SIMD) humanoid_kernel(const 
   LHW_LDS_POISON(SG);
   const int lane = threadIdx.x & (W - 1);   // lane within the env's group
   const HParams& p = *pp;
-  const HModel& m = *mp;
+  const HModel& m = *mp;   // (a register copy of the whole record was measured: +3.5 %, its ~100 scalars crowd the SGPR file)
   if constexpr (MODE == 0 && W == 64) {
     // One call site for both uses of the one-env-per-wave step kernel.  As the re-run behind the two-envs-per-wave kernel
     // (only_flagged) it is launched with FEW workgroups, each scanning the flags of `chunk` <= 64 consecutive envs and stepping
@@ -3674,6 +3690,8 @@ int humanoid_create(HumanoidEnv** out, const std::vector<int32_t>& mi, const std
     di[DI_BODY] = bmap[IF(LHW_IF_DOF_BODYID)[d]]; di[DI_JNT] = j;
     di[DI_KIND] = jtype[j] == JT_FREE ? (kk < 3 ? 0 : 1) : (jtype[j] == JT_SLIDE ? 2 : 3);
     di[DI_PREVMASK] = (int)pmask[d];
+    di[DI_KIDX] = kk; di[DI_LIMITED] = IF(LHW_IF_JNT_LIMITED)[j]; di[DI_QADR] = IF(LHW_IF_JNT_QPOSADR)[j];
+    k[DD_RANGE] = DF(LHW_DF_JNT_RANGE)[2 * j]; k[DD_RANGE + 1] = DF(LHW_DF_JNT_RANGE)[2 * j + 1]; k[DD_MARGIN] = DF(LHW_DF_JNT_MARGIN)[j];
     di[DI_ACT] = -1;
     for (int u = 0; u < nu; u++)
       if (jdof[IF(LHW_IF_ACTUATOR_TRNID)[u]] == d) {
@@ -3714,7 +3732,8 @@ int humanoid_create(HumanoidEnv** out, const std::vector<int32_t>& mi, const std
     const int *I1 = &geom_i[(size_t)GIS * g1], *I2 = &geom_i[(size_t)GIS * g2];
     double* pd = &pair_d[(size_t)PDS * q];
     int* pi = &pair_i[(size_t)PIS * q];
-    pi[0] = g1; pi[1] = g2;
+    pi[0] = g1; pi[1] = g2; pi[PI_TYPE1] = I1[GI_TYPE]; pi[PI_TYPE2] = I2[GI_TYPE];
+    for (int a = 0; a < 3; a++) { pd[PD_SIZE1 + a] = G1[GD_SIZE + a]; pd[PD_SIZE2 + a] = G2[GD_SIZE + a]; }
     pd[0] = std::max(G1[GD_MARGIN], G2[GD_MARGIN]);
     pd[1] = pd[0] - std::max(G1[GD_GAP], G2[GD_GAP]);
     if (I1[GI_PRIORITY] != I2[GI_PRIORITY]) {
