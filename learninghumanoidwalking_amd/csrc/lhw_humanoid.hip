@@ -175,13 +175,16 @@ enum { LHW_STREAM_OBS = 4 };
 #define AD_GEAR 0
 #define AD_CTRLRANGE 1
 #define AD_FORCERANGE 3
-#define PIS 10  // pair_i: geom1 geom2 condim xmask(dofs moving exactly one body) mask2(dofs moving body 2) class | merge class, robot-is-geom1 |
-                //         type of geom1, of geom2 (copies: the narrow phase reads its pair record only, one table round trip)
+#define PIS 12  // pair_i: geom1 geom2 condim xmask(dofs moving exactly one body) mask2(dofs moving body 2) class | merge class, robot-is-geom1 |
+                //         type of geom1, of geom2 (copies: the narrow phase reads its pair record only, one table round trip) |
+                //         body of geom2, root body of geom1's body (the ground-reaction query of the stepping task)
 #define PDS 18  // pair_d: margin includemargin friction solref2 solimp5 invweight(sum of the two bodies' translational) | size3 of geom1, of geom2 | pad
 #define PD_SIZE1 11
 #define PD_SIZE2 14
 #define PI_TYPE1 8
 #define PI_TYPE2 9
+#define PI_BODY2 10
+#define PI_ROOT1 11
 #define AIS 6   // act_i: dof joint ctrllimited forcelimited qposadr dofadr(of the joint)
 #define AI_QADR 4
 #define AI_DADR 5
@@ -422,7 +425,7 @@ struct StepLds {
   int nbig, big_selfcol, big_anyfoot;
   double big_grf_r, big_grf_l, big_cz;
   // newton_big: position / frame / friction and dof masks / condim of up to NCK contacts, cached for the rebuilds of their rows
-  double bk_rec[NCK_ * 13];
+  alignas(16) double bk_rec[NCK_ * 13];
   int bk_i[NCK_ * 3];
 };
 template <int NC_T> struct StepLds<false, NC_T> { static constexpr int NCK_ = 1; };
@@ -1152,10 +1155,31 @@ __device__ __forceinline__ void chain_dynamics(const HModel& m, const HParams& p
 // ---- collision (engine_collision_primitive.c restated).  Two passes over the same narrow phase: pass 0 counts the
 // contacts of each candidate pair (lane = pair), a wave scan gives every pair its slot range in pair order, pass 1
 // recomputes and writes straight into the LDS contact arrays (no per-lane contact records in scratch).
+// LDS working set of the merge of duplicate contacts (fwd_collision, many-contact path), laid over the contact-record cache of
+// newton_big, which is idle during the collision stage.  Per raw contact: a float32 FILTER WORD v = x + 1.7 y + 64 * merge class (x, y:
+// position; copies agree in it to a float32 ulp, the other corners of a foot are centimetres away -- also the ones that share x or
+// y with it -- and other classes tens of units; a chance coincidence only costs the exact check), walked sixteen candidates per trip; y and the distance in float32 for the few candidates that pass (which are then compared
+// exactly, in float64, from the workspace); the merge key and the pair index.  Once the groups are known, the three float arrays are
+// reused for rank / multiplicity / ground-reaction counts.
+template <class L>
+struct MergeLds {
+  float *d32, *v32, *y32;
+  unsigned short *k16, *f16, *p16;
+  int *rank, *cnt, *crl;
+  __device__ __forceinline__ explicit MergeLds(L& S) {
+    static_assert(L::NCK_ * 13 * 8 >= 3 * NCR * 4 + 2 * NCR * 2 && L::NCK_ * 3 * 4 >= NCR * 2, "merge scratch does not fit the record cache");
+    v32 = reinterpret_cast<float*>(S.bk_rec); d32 = v32 + NCR; y32 = d32 + NCR;   // (v32 first: read as float4, bk_rec is 16-byte aligned)
+    k16 = reinterpret_cast<unsigned short*>(y32 + NCR); f16 = k16 + NCR;
+    p16 = reinterpret_cast<unsigned short*>(S.bk_i);
+    rank = reinterpret_cast<int*>(v32); cnt = reinterpret_cast<int*>(d32); crl = reinterpret_cast<int*>(y32);
+  }
+};
+
 template <class L>
 struct ConSink {
   L* S;
   int base, n, write, g1, g2, pair;
+  int key = 0;            // merge class * 2 + orientation of this lane's pair (many-contact path: the merge scan's key)
   gws_d gd = nullptr;     // non-NULL: the contacts go to the raw region of the HBM workspace (AR_* / ARI_* layout), capacity NCR
   gws_i gi = nullptr;
   __device__ __forceinline__ void emit(double dist, const double* pos, const double* nrm, const double* tan) {
@@ -1180,6 +1204,11 @@ struct ConSink {
         if (gd) {
           for (int a = 0; a < 9; a++) gd[AR_FRAME + 9 * c + a] = f[a];
           gi[ARI_G1 + c] = g1; gi[ARI_G2 + c] = g2; gi[ARI_PAIR + c] = pair;
+          if constexpr (L::STEP_) {   // what the merge scan filters on, in LDS (see MergeLds): nothing of it is read back from the workspace
+            MergeLds<L> ml(Z);
+            ml.d32[c] = (float)dist; ml.v32[c] = (float)(pos[0] + 1.7 * pos[1] + 64.0 * (double)(key >> 1)); ml.y32[c] = (float)pos[1];
+            ml.k16[c] = (unsigned short)key; ml.p16[c] = (unsigned short)pair;
+          }
         } else {
           for (int a = 0; a < 9; a++) Z.U[U_CFRAME + 9 * c + a] = f[a];
           Z.con_g1[c] = g1; Z.con_g2[c] = g2; Z.con_pair[c] = pair;
@@ -1612,11 +1641,12 @@ __device__ void fwd_collision(const HModel& m, const HParams& p, L& S, int lane,
   }
   SYNC();
   FINE_MARK(3, 0);
-  int g1 = 0, g2 = 0, ty1 = -1, ty2 = -1;
+  int g1 = 0, g2 = 0, ty1 = -1, ty2 = -1, pkey = 0;
   double margin = 0;
   bool have = lane < m.npair;
   if (have) {
     g1 = m.pair_i[PIS * lane]; g2 = m.pair_i[PIS * lane + 1]; ty1 = m.pair_i[PIS * lane + PI_TYPE1]; ty2 = m.pair_i[PIS * lane + PI_TYPE2];
+    if constexpr (BOXBOX && L::W_ == 64) pkey = m.pair_i[PIS * lane + 6] * 2 + m.pair_i[PIS * lane + 7];
     margin = m.pair_d[PDS * lane];
     // (the terrain boxes collide in every walk mode, as the reference leaves them -- coplanar with the floor outside FORWARD mode,
     // tasks/stepping_task.py:320-334: an env with more than NC contacts takes the many-contact path below)
@@ -1651,7 +1681,7 @@ __device__ void fwd_collision(const HModel& m, const HParams& p, L& S, int lane,
   bool big = false;
   if constexpr (BOXBOX && L::W_ == 64) big = bd != nullptr && total > NC;
   const int cap = big ? NCR : NC;
-  if (big) { k.gd = bd; k.gi = bi; }
+  if (big) { k.gd = bd; k.gi = bi; k.key = pkey; }
   if (have && !boxpair && !primbox && mine > 0 && base < cap) collide_pair(k, m, S, lane, g1, g2, margin);
   if (m.has_primbox) { if (primbox && mine > 0 && base < cap) collide_primbox(k, m, S, lane, g1, g2, margin); }
   if constexpr (BOXBOX) {
@@ -1677,106 +1707,116 @@ __device__ void fwd_collision(const HModel& m, const HParams& p, L& S, int lane,
       // two narrow phases compute to within 1-2 ulp of each other (measured: |d dist| <= 1e-18, |d pos| <= 3e-17).  The group's
       // representative is its earliest member; the copies only raise its multiplicity.
       // (the scan's working arrays -- distance, class key, first -- live in LDS, in the contact-record cache of newton_big, idle here)
-      static_assert(L::NCK_ * 13 >= 2 * NCR, "merge scratch does not fit the record cache");
-      double* dds = S.bk_rec;                                   // [NCR] distance
-      int* kks = reinterpret_cast<int*>(S.bk_rec + NCR);        // [NCR] merge class * 2 + orientation
-      int* ffs = kks + NCR;                                     // [NCR] first
+      MergeLds<L> ml(S);
       for (int c = lane; c < nr; c += W) {
-        const int q = bi[ARI_PAIR + c];
-        kks[c] = m.pair_i[PIS * q + 6] * 2 + m.pair_i[PIS * q + 7];
-        dds[c] = bd[AR_DIST + c];
-        bi[ARI_COUNT + c] = 0; bi[ARI_CNTR + c] = 0; bi[ARI_CNTL + c] = 0;
-      }
-      SYNC();
-      for (int c = lane; c < nr; c += W) {
-        const int key = kks[c];
-        const double dc = dds[c];
+        const float dc32 = ml.d32[c], vc32 = ml.v32[c], yc32 = ml.y32[c];
+        const int key = ml.k16[c];
+        // this contact's exact record (the loads are in flight while the filter walks LDS)
+        const double dc = bd[AR_DIST + c];
+        double pc[3], fc[9];
+        for (int a = 0; a < 3; a++) pc[a] = bd[AR_POS + 3 * c + a];
+        for (int a = 0; a < 9; a++) fc[a] = bd[AR_FRAME + 9 * c + a];
         const double dtol = 1e-17 + 4e-16 * fabs(dc);
+        const float tolv = 4e-3f, tol32 = 1e-5f, rel32 = 2e-6f;   // (float32 ulp at |v| < 8192: 4.9e-4; of a coordinate below 30: 1.9e-6)
         int f = c;
-        // candidates in batches of eight (eight independent LDS reads in flight); nearly every candidate fails on class or distance
-        for (int e0 = 0; e0 < c && f == c; e0 += 8) {
-          int cl[8];
-          double de[8];
+        for (int e0 = 0; e0 < c && f == c; e0 += 16) {   // sixteen candidates per trip: four 16-byte LDS reads
+          float v[16];
 #pragma unroll
-          for (int j = 0; j < 8; j++) { const int e = min(e0 + j, c); cl[j] = kks[e]; de[j] = dds[e]; }
+          for (int j = 0; j < 16; j += 4) {
+            const float4 q4 = *reinterpret_cast<const float4*>(&ml.v32[e0 + j]);
+            v[j] = q4.x; v[j + 1] = q4.y; v[j + 2] = q4.z; v[j + 3] = q4.w;
+          }
+          unsigned hits = 0;
 #pragma unroll
-          for (int j = 0; j < 8; j++) {
-            const int e = e0 + j;
-            if (f != c || e >= c || (cl[j] >> 1) != (key >> 1) || fabs(de[j] - dc) > dtol) continue;
-            const bool mirror = ((cl[j] ^ key) & 1) != 0;
-            bool same = mirror || de[j] == dc;
+          for (int j = 0; j < 16; j++) hits |= (fabsf(v[j] - vc32) <= tolv) ? (1u << j) : 0u;
+          if (c - e0 < 16) hits &= (1u << (c - e0)) - 1u;   // candidates are the EARLIER contacts
+          while (hits && f == c) {
+            const int e = e0 + __ffs(hits) - 1;
+            hits &= hits - 1;
+            const int cle = ml.k16[e];
+            if ((cle >> 1) != (key >> 1)) continue;
+            if (fabsf(ml.d32[e] - dc32) > tol32 + rel32 * fabsf(dc32) || fabsf(ml.y32[e] - yc32) > tol32 + rel32 * fabsf(yc32)) continue;
+            const double dex = bd[AR_DIST + e];
+            if (fabs(dex - dc) > dtol) continue;
+            const bool mirror = ((cle ^ key) & 1) != 0;
+            bool same = mirror || dex == dc;
             for (int a = 0; a < 3; a++) {
-              const double pe = bd[AR_POS + 3 * e + a], pc = bd[AR_POS + 3 * c + a];
-              same = same && (mirror ? fabs(pe - pc) <= 1e-15 : pe == pc);
+              const double pe = bd[AR_POS + 3 * e + a];
+              same = same && (mirror ? fabs(pe - pc[a]) <= 1e-15 : pe == pc[a]);
             }
             for (int a = 0; a < 9; a++) {
-              const double fe = bd[AR_FRAME + 9 * e + a], fc = bd[AR_FRAME + 9 * c + a];
-              same = same && (mirror ? fabs(((a < 3 || a >= 6) ? -fe : fe) - fc) <= 1e-15 : fe == fc);
+              const double fe = bd[AR_FRAME + 9 * e + a];
+              same = same && (mirror ? fabs(((a < 3 || a >= 6) ? -fe : fe) - fc[a]) <= 1e-15 : fe == fc[a]);
             }
             if (same) f = e;
           }
         }
-        ffs[c] = f;
+        ml.f16[c] = (unsigned short)f;
       }
       SYNC();
+      FINE_MARK(3, 6);
       // (equality up to a tolerance is not transitive: a contact may have matched a copy whose own match it failed on -- follow the
       // chain to the group's representative)
       int rep[(NCR + W - 1) / W];
 #pragma unroll
       for (int q = 0; q < (NCR + W - 1) / W; q++) {
         const int c = q * W + lane;
-        int f = c < nr ? ffs[c] : 0;
-        if (c < nr) while (ffs[f] != f) f = ffs[f];
+        int f = c < nr ? ml.f16[c] : 0;
+        if (c < nr) while (ml.f16[f] != f) f = ml.f16[f];
         rep[q] = f;
       }
       SYNC();
 #pragma unroll
-      for (int q = 0; q < (NCR + W - 1) / W; q++) { const int c = q * W + lane; if (c < nr) { ffs[c] = rep[q]; bi[ARI_FIRST + c] = rep[q]; } }
+      for (int q = 0; q < (NCR + W - 1) / W; q++) { const int c = q * W + lane; if (c < nr) ml.f16[c] = (unsigned short)rep[q]; }
+      // (the filter arrays are dead: rank / multiplicity / ground-reaction counts take their place)
+      for (int c = lane; c < nr; c += W) { ml.cnt[c] = 0; ml.crl[c] = 0; }
       SYNC();
       // rank of the distinct contacts (in contact order), multiplicities by rank
       int nu = 0;
       for (int c0 = 0; c0 < nr; c0 += W) {
         const int c = c0 + lane;
-        const bool uq = c < nr && ffs[c] == c;
+        const bool uq = c < nr && ml.f16[c] == c;
         const unsigned long long bal = __ballot(uq);
-        if (uq) bi[ARI_RANK + c] = nu + __popcll(bal & ((1ull << lane) - 1ull));
+        if (uq) ml.rank[c] = nu + __popcll(bal & ((1ull << lane) - 1ull));
         nu += __popcll(bal);
       }
-      __syncthreads();
-      for (int c = lane; c < nr; c += W) {   // (integer atomics: order-free)
-        const int u = bi[ARI_RANK + bi[ARI_FIRST + c]];
-        atomicAdd(&bi[ARI_COUNT + u], 1);
-        // the copy's role in the ground-reaction query (robot_interface.py:269-301): geom1 off the robot, geom2 on a foot body
-        const int b1 = m.geom_i[GIS * bi[ARI_G1 + c] + GI_BODY], b2 = m.geom_i[GIS * bi[ARI_G2 + c] + GI_BODY];
-        if (m.body_i[BIS * b1 + BI_ROOT] != p.root_body) {
-          if (b2 == p.rfoot_body) atomicAdd(&bi[ARI_CNTR + u], 1);
-          if (b2 == p.lfoot_body) atomicAdd(&bi[ARI_CNTL + u], 1);
+      SYNC();
+      for (int c = lane; c < nr; c += W) {   // (integer atomics in LDS: order-free)
+        const int u = ml.rank[ml.f16[c]], q = ml.p16[c];
+        atomicAdd(&ml.cnt[u], 1);
+        // the copy's role in the ground-reaction query (robot_interface.py:269-301): geom1 off the robot, geom2 on a foot body;
+        // right-foot copies count in the low half of the word, left-foot copies in the high half
+        const int b2 = m.pair_i[PIS * q + PI_BODY2];
+        if (m.pair_i[PIS * q + PI_ROOT1] != p.root_body) {
+          if (b2 == p.rfoot_body) atomicAdd(&ml.crl[u], 1);
+          if (b2 == p.lfoot_body) atomicAdd(&ml.crl[u], 1 << 16);
         }
       }
-      __syncthreads();
+      SYNC();
+      FINE_MARK(3, 7);
       merged = true;
       ndist = nu;
       const bool tolds = nu <= NC;
       // the distinct contacts, in contact order: back into the LDS arrays if they fit the row lanes, else into the unique region
       for (int c = lane; c < nr; c += W) {
-        if (bi[ARI_FIRST + c] != c) continue;
-        const int u = bi[ARI_RANK + c];
-        const double mult = (double)bi[ARI_COUNT + u];
+        if (ml.f16[c] != c) continue;
+        const int u = ml.rank[c];
+        const double mult = (double)ml.cnt[u], nright = (double)(ml.crl[u] & 0xffff), nleft = (double)(ml.crl[u] >> 16);
         if (tolds) {
           S.U[U_CDIST + u] = bd[AR_DIST + c];
           for (int a = 0; a < 3; a++) S.con_pos[3 * u + a] = bd[AR_POS + 3 * c + a];
           for (int a = 0; a < 9; a++) S.U[U_CFRAME + 9 * u + a] = bd[AR_FRAME + 9 * c + a];
-          S.con_g1[u] = bi[ARI_G1 + c]; S.con_g2[u] = bi[ARI_G2 + c]; S.con_pair[u] = bi[ARI_PAIR + c];
-          if constexpr (L::STEP_) { S.con_mult[u] = mult; S.con_wr[u] = (double)bi[ARI_CNTR + u] / mult; S.con_wl[u] = (double)bi[ARI_CNTL + u] / mult; }
+          S.con_g1[u] = bi[ARI_G1 + c]; S.con_g2[u] = bi[ARI_G2 + c]; S.con_pair[u] = ml.p16[c];
+          if constexpr (L::STEP_) { S.con_mult[u] = mult; S.con_wr[u] = nright / mult; S.con_wl[u] = nleft / mult; }
         } else if (u < NCB) {
-          const int q = bi[ARI_PAIR + c];
+          const int q = ml.p16[c];
           const double* pd = m.pair_d + PDS * q;
           const double incm = pd[1], dist = bd[AR_DIST + c];
           bd[BW_DIST + u] = dist;
           for (int a = 0; a < 3; a++) bd[BW_POS + 3 * u + a] = bd[AR_POS + 3 * c + a];
           for (int a = 0; a < 9; a++) bd[BW_FRAME + 9 * u + a] = bd[AR_FRAME + 9 * c + a];
           bi[BWI_G1 + u] = bi[ARI_G1 + c]; bi[BWI_G2 + u] = bi[ARI_G2 + c]; bi[BWI_PAIR + u] = q;
-          bd[BW_MULT + u] = mult; bd[BW_WR + u] = (double)bi[ARI_CNTR + u] / mult; bd[BW_WL + u] = (double)bi[ARI_CNTL + u] / mult;
+          bd[BW_MULT + u] = mult; bd[BW_WR + u] = nright / mult; bd[BW_WL + u] = nleft / mult;
           // mj_contactParam, from the pair tables
           bi[BWI_XM + u] = m.pair_i[PIS * q + 3]; bi[BWI_M2 + u] = m.pair_i[PIS * q + 4];
           bd[BW_TRAN + u] = pd[10];
@@ -1812,8 +1852,8 @@ __device__ void fwd_collision(const HModel& m, const HParams& p, L& S, int lane,
     for (int a = 0; a < 5; a++) S.U[U_CSOLIMP + 5 * c + a] = pd[5 + a];
     if constexpr (L::STEP_) {
       if (!merged) {   // no merge in this sub-step: every contact stands for itself
-        const int b1 = m.geom_i[GIS * S.con_g1[c] + GI_BODY], b2 = m.geom_i[GIS * S.con_g2[c] + GI_BODY];
-        const bool floor1 = m.body_i[BIS * b1 + BI_ROOT] != p.root_body;
+        const int b2 = m.pair_i[PIS * q + PI_BODY2];
+        const bool floor1 = m.pair_i[PIS * q + PI_ROOT1] != p.root_body;
         S.con_mult[c] = 1.0; S.con_wr[c] = (floor1 && b2 == p.rfoot_body) ? 1.0 : 0.0; S.con_wl[c] = (floor1 && b2 == p.lfoot_body) ? 1.0 : 0.0;
       }
     }
@@ -3733,6 +3773,7 @@ int humanoid_create(HumanoidEnv** out, const std::vector<int32_t>& mi, const std
     double* pd = &pair_d[(size_t)PDS * q];
     int* pi = &pair_i[(size_t)PIS * q];
     pi[0] = g1; pi[1] = g2; pi[PI_TYPE1] = I1[GI_TYPE]; pi[PI_TYPE2] = I2[GI_TYPE];
+    pi[PI_BODY2] = I2[GI_BODY]; pi[PI_ROOT1] = body_i[(size_t)BIS * I1[GI_BODY] + BI_ROOT];
     for (int a = 0; a < 3; a++) { pd[PD_SIZE1 + a] = G1[GD_SIZE + a]; pd[PD_SIZE2 + a] = G2[GD_SIZE + a]; }
     pd[0] = std::max(G1[GD_MARGIN], G2[GD_MARGIN]);
     pd[1] = pd[0] - std::max(G1[GD_GAP], G2[GD_GAP]);

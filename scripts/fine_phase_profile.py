@@ -6,7 +6,8 @@ import torch
 from learninghumanoidwalking_amd.envs import ENVIRONMENTS
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 name = sys.argv[2] if len(sys.argv) > 2 else "jvrc_walk"
-env = ENVIRONMENTS[name]().make_batched(N, seed=1, device=0, max_traj_len=400)
+seed = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+env = ENVIRONMENTS[name]().make_batched(N, seed=seed, device=0, max_traj_len=400)
 env.reset()
 gen = torch.Generator(device="cuda"); gen.manual_seed(0)
 def draw(): return torch.randn(N, env.act_dim, device="cuda", generator=gen) * 0.223
@@ -15,4 +16,4 @@ env.phase_cycles(True)
 steps = 20
 for _ in range(steps): env.step(draw())
 c = env.phase_cycles(True)
-print(os.path.basename(os.environ.get("LHW_LIB", "default")), name, " ".join(f"[{i}] {c[i] / steps / 25:.0f}" for i in range(8)), "ticks / sub-step")
+print(os.path.basename(os.environ.get("LHW_LIB", "default")), name, "seed", seed, " ".join(f"[{i}] {c[i] / steps / 25:.0f}" for i in range(8)), "ticks / sub-step")
