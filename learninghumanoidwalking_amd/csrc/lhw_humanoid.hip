@@ -319,12 +319,7 @@ __device__ long long g_fine_t;
 #define ARI_G1 0
 #define ARI_G2 (ARI_G1 + NCR)
 #define ARI_PAIR (ARI_G2 + NCR)
-#define ARI_FIRST (ARI_PAIR + NCR)         // index of the first contact this one is a copy of (itself: distinct)
-#define ARI_RANK (ARI_FIRST + NCR)         // distinct contacts: position among the distinct ones
-#define ARI_COUNT (ARI_RANK + NCR)         // by rank: multiplicity
-#define ARI_CNTR (ARI_COUNT + NCR)         // by rank: copies that are floor contacts of the right / left foot (robot_interface.py:269-301)
-#define ARI_CNTL (ARI_CNTR + NCR)
-#define AR_INTS (ARI_CNTL + NCR)
+#define AR_INTS (ARI_PAIR + NCR)            // (the merge's own bookkeeping -- first copy, rank, multiplicity, foot counts -- lives in LDS: MergeLds)
 #define NCB 64                             // distinct contacts the many-contact solver holds (4 NCB rows)
 #define NRB (4 * NCB)
 #define BW_DIST AR_DOUBLES

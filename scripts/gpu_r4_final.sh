@@ -6,7 +6,7 @@ timeout 300 python __graft_entry__.py smoke > $O/smoke.txt 2>&1
 timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -8 > $O/pytest_full.txt
 LHW_LIB=$PWD/learninghumanoidwalking_amd/variants/liblhw_poison.so LHW_POISON=1 timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -8 > $O/pytest_poison.txt
 for i in $(seq 1 10); do timeout 300 python -m pytest tests/test_distributed_gpu.py -m gpu -q -k two_ranks 2>&1 | tail -1; done > $O/dp_repeat.txt
-timeout 600 python bench.py > $O/bench.json 2> $O/bench.err
+timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err   # (the driver's command line)
 tail -3 $O/smoke.txt; tail -2 $O/pytest_full.txt; tail -2 $O/pytest_poison.txt; sort $O/dp_repeat.txt | cut -c1-20 | uniq -c
 python - <<PY
 import json
