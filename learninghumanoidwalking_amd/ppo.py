@@ -124,16 +124,15 @@ class Rollout:
         self.tob = torch.zeros(N, D, dtype=torch.float32, device=dev)
         self.tob_all = None      # [T][N][D] terminal observations of the feed-forward path (allocated on first use)
         # Number of independent env groups pipelined on separate streams (wave-per-env steppers; LHW_ROLLOUT_GROUPS overrides).
-        # A control-step launch should fill the chip's wave slots once (8 one-wave blocks per CU, the LDS limit of the stepper):
-        # measured (scripts/gpu_groups.sh), one group wins while the whole batch is at most ~1.5 x that (jvrc_walk @ 4096 = 2048
-        # waves: 2.07 M env-steps/s vs 1.99 M with two groups), two groups win from two fills on (h1 @ 8192, jvrc_step @ 4096,
-        # jvrc_walk @ 8192: +15-20 %), where one group's policy launches hide behind the other group's step kernel.
+        # Two groups: one group's policy launch and the tail of its control-step kernel -- a launch ends with its slowest wave,
+        # the chip draining meanwhile -- hide behind the other group's kernel.  Measured on the round-4 kernels
+        # (scripts/gpu_r4_groups.sh, profiles/r04_rollout_groups.txt): jvrc_walk @ 4096 +11-12 % env-steps/s over one group
+        # (rollout 0.608 -> 0.538 s), h1 @ 4096 +11 %, jvrc_walk @ 2048 / 1024 +4 / +3 %; three or four groups lose badly
+        # (jvrc_walk @ 4096: 1.07 s).  (An earlier round had measured one group ahead at 4096 envs, 2.07 vs 1.99 M, on a
+        # slower control step and an unfused policy step.)  Small batches keep one group: their launches are latency-bound.
         auto = "1"
         if hasattr(env, "step_range") and env.task != 0:
-            from .batched_env import TASK_JVRC_STEP
-            slots = 8 * torch.cuda.get_device_properties(dev).multi_processor_count
-            waves = N // (1 if env.task == TASK_JVRC_STEP else 2)      # the stepping task runs one env per wave, the others two
-            auto = "2" if waves >= 1.5 * slots else "1"
+            auto = "2" if N >= 1024 else "1"
         want = int(os.environ.get("LHW_ROLLOUT_GROUPS", auto))
         self.groups = max(1, min(want, N)) if env.task != 0 else 1
         self.streams = None
