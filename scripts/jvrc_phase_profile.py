@@ -37,4 +37,5 @@ sub = sum(c[k] for k in names) / steps / 25
 print(f"N={N} ms/step {e0.elapsed_time(e1)/steps:.3f}  env0 cycles per sub-step {sub:.0f} (sum of the phases below; clock64 ticks)"
       f"  control-step prologue + epilogue per sub-step {(c[9] + c[10]) / steps / 25 - sub:.0f}")
 for k, n in names.items(): print(f"  {n:34s} {c[k]/steps/25:9.0f} cyc/substep  {100*c[k]/steps/25/sub:5.1f}%")
+print(f"  per control step (ticks): slot 9 (prologue + whatever the stage loop spends outside the marked phases) {c[9]/steps:.0f}, slot 10 (task step, reward, observation, reset, hand-over) {c[10]/steps:.0f}; all marked sub-step phases {sub*25:.0f}")
 print(f"  newton passes per sub-step (env 0): {c[6]/steps/25:.2f}   line-search passes per sub-step: {c[14]/steps/25:.2f}")
