@@ -223,6 +223,8 @@ struct HModel {
   gtab_i body_i, jnt_i, dof_i, geom_i, act_i, pair_i;   // pair_i / pair_d: one record per candidate pair (mj_contactParam is a function of the pair)
   gtab_d pair_d;
   int has_primbox;     // some collision pair is sphere-box or capsule-box (collide_primbox)
+  int npb, pb_pair[4]; // plane-box pairs (floor against a foot box), in pair order, if there are at most four of them (else npb = 0):
+                       // their eight corners are tested on eight lanes each instead of one after the other on the pair's lane
   gtab_i kin_i;          // [32][KIS], kin_d [32][KDS]: per lane of the chain layout, its jointed body and that body's frame relative to the
   gtab_d kin_d;          //   previous jointed body (fwd_kinematics)
   gtab_i fix_i;          // [nbody]: jointed body a welded body moves with (-1 for jointed bodies), fix_d [nbody][12]: its frame in that body's
@@ -1658,7 +1660,51 @@ __device__ void fwd_collision(const HModel& m, const HParams& p, L& S, int lane,
     const int ta = ty1, tb = ty2;
     primbox = tb == G_BOX && (ta == G_SPHERE || ta == G_CAPSULE);
   }
-  if (have && !boxpair && !primbox) collide_pair(k, m, S, lane, g1, g2, margin);
+  // Plane-box pairs (the floor against a foot box; kernels without box-box pairs): lane 8 j + i tests corner i of the j-th such
+  // pair -- the same expressions, corner by corner, as collide_pair's loop, which walks the eight corners one after the other on the
+  // pair's own lane, twice (counting, writing).  A ballot gives every corner its rank among the corners in contact (the first four
+  // count, mjc_PlaneBox) and the pair's lane its count; after the scan the corner lanes write their contacts themselves.
+  bool pbpair = false, cemit = false;
+  int cj = -1, crank = 0, cq = 0, cg1 = 0, cg2 = 0;
+  double cdist = 0, cpos[3] = {0, 0, 0}, cnn[3] = {0, 0, 0};
+  if constexpr (!BOXBOX) {
+    const int npb = m.npb;
+    if (npb > 0) {
+      const int j = lane >> 3, i = lane & 7;
+      bool pass = false;
+      if (j < npb) {
+        cj = j;
+        cq = j == 0 ? m.pb_pair[0] : (j == 1 ? m.pb_pair[1] : (j == 2 ? m.pb_pair[2] : m.pb_pair[3]));
+        cg1 = m.pair_i[PIS * cq]; cg2 = m.pair_i[PIS * cq + 1];
+        const double mg = m.pair_d[PDS * cq];
+        const double s2[3] = {m.pair_d[PDS * cq + PD_SIZE2], m.pair_d[PDS * cq + PD_SIZE2 + 1], m.pair_d[PDS * cq + PD_SIZE2 + 2]};
+        double p1[3], p2[3], R2[9];
+        for (int a = 0; a < 3; a++) { p1[a] = S.U[U_GPOS + 3 * cg1 + a]; p2[a] = S.U[U_GPOS + 3 * cg2 + a]; cnn[a] = S.U[U_GMAT + 9 * cg1 + 3 * a + 2]; }
+        for (int a = 0; a < 9; a++) R2[a] = S.U[U_GMAT + 9 * cg2 + a];
+        const double dif[3] = {p2[0] - p1[0], p2[1] - p1[1], p2[2] - p1[2]};
+        const double dist = dot3(dif, cnn);
+        const double v[3] = {(i & 1 ? s2[0] : -s2[0]), (i & 2 ? s2[1] : -s2[1]), (i & 4 ? s2[2] : -s2[2])};
+        double corner[3];
+        mat_vec(corner, R2, v);
+        const double ld = dot3(cnn, corner);
+        pass = !(dist + ld > mg || ld > 0);
+        cdist = dist + ld;
+        for (int a = 0; a < 3; a++) cpos[a] = corner[a] + p2[a] - cnn[a] * (dist + ld) * 0.5;
+      }
+      const typename RowMask<L::W_>::type bal = group_rows<L::W_>(__ballot(pass));
+      if (cj >= 0) {
+        const unsigned m8 = (unsigned)(bal >> (8 * cj)) & 0xffu;
+        crank = __popc(m8 & ((1u << i) - 1u));
+        cemit = pass && crank < 4;
+      }
+      if (have && ty1 == G_PLANE && ty2 == G_BOX) {
+#pragma unroll
+        for (int jj = 0; jj < 4; jj++)
+          if (jj < npb && m.pb_pair[jj] == lane) { pbpair = true; k.n = min(4, __popc((unsigned)(bal >> (8 * jj)) & 0xffu)); }
+      }
+    }
+  }
+  if (have && !boxpair && !primbox && !pbpair) collide_pair(k, m, S, lane, g1, g2, margin);
   if (m.has_primbox) { if (primbox) collide_primbox(k, m, S, lane, g1, g2, margin); }
   if constexpr (BOXBOX) {
     if (gany<L::W_>(boxpair)) {
@@ -1677,7 +1723,20 @@ __device__ void fwd_collision(const HModel& m, const HParams& p, L& S, int lane,
   if constexpr (BOXBOX && L::W_ == 64) big = bd != nullptr && total > NC;
   const int cap = big ? NCR : NC;
   if (big) { k.gd = bd; k.gi = bi; k.key = pkey; }
-  if (have && !boxpair && !primbox && mine > 0 && base < cap) collide_pair(k, m, S, lane, g1, g2, margin);
+  if constexpr (!BOXBOX) {
+    if (m.npb > 0) {   // the corner lanes write: slot = their pair's base (read off the pair's lane) + rank
+      int bq = 0;
+#pragma unroll
+      for (int jj = 0; jj < 4; jj++)
+        if (jj < m.npb) { const int bj = gbcast_i<L::W_>(base, m.pb_pair[jj]); if (cj == jj) bq = bj; }
+      if (cemit) {
+        const double zero[3] = {0, 0, 0};
+        ConSink<L> kc{&S, bq, crank, 1, cg1, cg2, cq};
+        kc.emit(cdist, cpos, cnn, zero);
+      }
+    }
+  }
+  if (have && !boxpair && !primbox && !pbpair && mine > 0 && base < cap) collide_pair(k, m, S, lane, g1, g2, margin);
   if (m.has_primbox) { if (primbox && mine > 0 && base < cap) collide_primbox(k, m, S, lane, g1, g2, margin); }
   if constexpr (BOXBOX) {
     if (boxpair && base < cap) {
@@ -3906,6 +3965,13 @@ int humanoid_create(HumanoidEnv** out, const std::vector<int32_t>& mi, const std
   for (int l = 0; l < 32; l++) for (size_t q = 0; q < owned[l].size(); q++) own_tab[l * max_owned + q] = owned[l][q];
   m.max_owned = (int)max_owned;
   m.has_primbox = primbox_pairs > 0;
+  {
+    int cnt = 0, idx[4] = {0, 0, 0, 0};
+    for (int q = 0; q < np; q++)
+      if (pair_i[(size_t)PIS * q + PI_TYPE1] == G_PLANE && pair_i[(size_t)PIS * q + PI_TYPE2] == G_BOX) { if (cnt < 4) idx[cnt] = q; cnt++; }
+    m.npb = cnt <= 4 ? cnt : 0;
+    for (int a = 0; a < 4; a++) m.pb_pair[a] = idx[a];
+  }
   auto BID = [&](int f) { const int b = cfg->task_iparams[f]; return (b >= 0 && b < nbm) ? bmap[b] : -1; };
   m.track_body[0] = BID(LHW_TI_ROOT_BODY); m.track_body[1] = BID(LHW_TI_RFOOT_BODY); m.track_body[2] = BID(LHW_TI_LFOOT_BODY);
   ok = ok && (m.body_d = to_dev<double>(h, body_d.data(), body_d.size())) && (m.jnt_d = to_dev<double>(h, jnt_d.data(), jnt_d.size())) &&
