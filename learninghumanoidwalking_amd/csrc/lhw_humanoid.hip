@@ -178,9 +178,12 @@ enum { LHW_STREAM_OBS = 4 };
 #define PIS 12  // pair_i: geom1 geom2 condim xmask(dofs moving exactly one body) mask2(dofs moving body 2) class | merge class, robot-is-geom1 |
                 //         type of geom1, of geom2 (copies: the narrow phase reads its pair record only, one table round trip) |
                 //         body of geom2, root body of geom1's body (the ground-reaction query of the stepping task)
-#define PDS 18  // pair_d: margin includemargin friction solref2 solimp5 invweight(sum of the two bodies' translational) | size3 of geom1, of geom2 | pad
+#define PDS 20  // pair_d: margin includemargin friction solref2 solimp5 invweight(sum of the two bodies' translational) | size3 of geom1, of geom2 |
+                //         bounding radius of geom1, of geom2 (the broad-phase test of fwd_collision) | pad
 #define PD_SIZE1 11
 #define PD_SIZE2 14
+#define PD_RBOUND1 17
+#define PD_RBOUND2 18
 #define PI_TYPE1 8
 #define PI_TYPE2 9
 #define PI_BODY2 10
@@ -1647,6 +1650,24 @@ __device__ void fwd_collision(const HModel& m, const HParams& p, L& S, int lane,
     margin = m.pair_d[PDS * lane];
     // (the terrain boxes collide in every walk mode, as the reference leaves them -- coplanar with the floor outside FORWARD mode,
     // tasks/stepping_task.py:320-334: an env with more than NC contacts takes the many-contact path below)
+  }
+  // Broad phase (the bounding-sphere filter of mj_collideGeoms): a pair whose bounding spheres -- or, against a plane, whose sphere and
+  // the plane -- are further apart than the margin cannot yield a contact and skips both passes.  Conservative (1e-9 of slack), so the
+  // contacts are the same; what it buys is that a TYPE of narrow phase none of whose pairs is in range is not executed at all -- on
+  // an upright robot that is every type but the feet's (the lanes of a group walk the types one after the other).
+  if (have) {
+    const double rb1 = m.pair_d[PDS * lane + PD_RBOUND1], rb2 = m.pair_d[PDS * lane + PD_RBOUND2];
+    double dif[3];
+    for (int a = 0; a < 3; a++) dif[a] = S.U[U_GPOS + 3 * g2 + a] - S.U[U_GPOS + 3 * g1 + a];
+    bool far;
+    if (ty1 == G_PLANE) {
+      const double nn[3] = {S.U[U_GMAT + 9 * g1 + 2], S.U[U_GMAT + 9 * g1 + 5], S.U[U_GMAT + 9 * g1 + 8]};
+      far = dot3(dif, nn) - rb2 > margin + 1e-9;
+    } else {
+      const double lim = rb1 + rb2 + margin + 1e-9;
+      far = lim > 0 && dot3(dif, dif) > lim * lim;
+    }
+    have = !far;
   }
   ConSink<L> k{&S, 0, 0, 0, g1, g2, lane};
   // box-box pairs (stepping-task kernels only) run the SAT + clipping once, in the counting pass, and replay the recorded
@@ -3829,6 +3850,15 @@ int humanoid_create(HumanoidEnv** out, const std::vector<int32_t>& mi, const std
     pi[0] = g1; pi[1] = g2; pi[PI_TYPE1] = I1[GI_TYPE]; pi[PI_TYPE2] = I2[GI_TYPE];
     pi[PI_BODY2] = I2[GI_BODY]; pi[PI_ROOT1] = body_i[(size_t)BIS * I1[GI_BODY] + BI_ROOT];
     for (int a = 0; a < 3; a++) { pd[PD_SIZE1 + a] = G1[GD_SIZE + a]; pd[PD_SIZE2 + a] = G2[GD_SIZE + a]; }
+    {  // radius of a sphere about the geom's centre that contains it (planes: unused)
+      auto rbound = [](int type, const double* sz) {
+        if (type == G_SPHERE) return sz[0];
+        if (type == G_CAPSULE) return sz[0] + sz[1];
+        if (type == G_BOX) return std::sqrt(sz[0] * sz[0] + sz[1] * sz[1] + sz[2] * sz[2]);
+        return 0.0;
+      };
+      pd[PD_RBOUND1] = rbound(I1[GI_TYPE], G1 + GD_SIZE); pd[PD_RBOUND2] = rbound(I2[GI_TYPE], G2 + GD_SIZE);
+    }
     pd[0] = std::max(G1[GD_MARGIN], G2[GD_MARGIN]);
     pd[1] = pd[0] - std::max(G1[GD_GAP], G2[GD_GAP]);
     if (I1[GI_PRIORITY] != I2[GI_PRIORITY]) {
