@@ -1154,7 +1154,10 @@ __device__ __forceinline__ void chain_dynamics(const HModel& m, const HParams& p
 
 // ---- collision (engine_collision_primitive.c restated).  Two passes over the same narrow phase: pass 0 counts the
 // contacts of each candidate pair (lane = pair), a wave scan gives every pair its slot range in pair order, pass 1
-// recomputes and writes straight into the LDS contact arrays (no per-lane contact records in scratch).
+// recomputes and writes straight into the LDS contact arrays (no per-lane contact records in scratch).  Exceptions: box-box pairs
+// keep their contacts between the passes (BoxRec), and plane-box pairs -- the feet on the floor, nearly all contacts of a walking
+// robot -- are evaluated once, one lane per box corner (fwd_collision).  A bounding-sphere broad phase runs in front of both passes.
+
 // LDS working set of the merge of duplicate contacts (fwd_collision, many-contact path), laid over the contact-record cache of
 // newton_big, which is idle during the collision stage.  Per raw contact: a float32 FILTER WORD v = x + 1.7 y + 64 * merge class (x, y:
 // position; copies agree in it to a float32 ulp, the other corners of a foot are centimetres away -- also the ones that share x or
