@@ -220,6 +220,22 @@ def main():
             return r
 
         env.step_range = timed_range
+    rollout_events = []
+    if hasattr(env, "rollout"):
+        orig_rollout = env.rollout
+
+        def timed_rollout(*a, **k):
+            if not timing["on"]:
+                return orig_rollout(*a, **k)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = orig_rollout(*a, **k)
+            e1.record()
+            if r:
+                rollout_events.append((e0, e1))
+            return r
+
+        env.rollout = timed_rollout
     for i in range(args.warmup):
         algo.iterate(i)
     barrier()
@@ -265,11 +281,15 @@ def main():
         total_env_steps = N * T * K * world
         value = total_env_steps / elapsed
         step_ms = [a.elapsed_time(b) for a, b in step_events]
-        avg_step_ms = float(np.mean(step_ms)) if step_ms else float("nan")
+        resident_ms = [a.elapsed_time(b) for a, b in rollout_events]
+        resident = bool(resident_ms)
+        # resident rollout: ONE launch advances all N envs by T control steps; its span / T is the per-control-step figure the
+        # launch-per-step pipeline reports per launch
+        avg_step_ms = float(np.mean(resident_ms)) / T if resident else (float(np.mean(step_ms)) if step_ms else float("nan"))
         spec = algo.spec
         bytes_per_env_step = spec.algorithmic_bytes_per_env_step()
         flops_per_env_step = spec.algorithmic_flops_per_env_step()
-        NL = launch_envs["n"]                      # envs per launch (N / rollout groups)
+        NL = N if resident else launch_envs["n"]   # envs per launch (N / rollout groups)
         groups = max(1, N // NL)
         achieved_gbs = bytes_per_env_step * NL / (avg_step_ms * 1e-3) / 1e9
         overlapped_tf = flops_per_env_step * NL / (avg_step_ms * 1e-3) / 1e12
@@ -295,6 +315,11 @@ def main():
             avg_launch_ms=isolated_ms if isolated_ms is not None else avg_step_ms, envs_per_launch=N if isolated_ms is not None else NL,
             launch_note="median of 20 whole-batch control-step launches issued one at a time after the timed region, HIP events on the "
                         "launch stream (no overlap): the duration rocprofv3 --kernel-trace reports for an isolated dispatch",
+            rollout_mode=getattr(algo.rollout, "last_mode", "steps"),
+            resident=(dict(kernel="humanoid_rollout_kernel", launches=len(resident_ms), avg_launch_ms=float(np.mean(resident_ms)), control_steps_per_launch=T,
+                           envs_per_launch=N, ms_per_control_step=avg_step_ms, fp64_tflops=overlapped_tf, fp64_frac=overlapped_tf / FP64_VALU_PEAK_TFLOPS,
+                           note="HIP events around lhw_env_rollout on its stream over the timed region: one launch = T control steps of all N envs, "
+                                "policy steps included; algorithmic FLOPs of N x T env-steps / that span") if resident else None),
             overlapped=dict(avg_launch_ms=avg_step_ms, launches=len(step_ms), envs_per_launch=NL, concurrent_launches=groups,
                             fp64_tflops=overlapped_tf, fp64_frac=overlapped_tf / FP64_VALU_PEAK_TFLOPS,
                             note="HIP events on the launch stream around lhw_env_step_range over the timed region: the two-envs-per-wave "

@@ -147,6 +147,33 @@ int lhw_env_debug_step_record(LhwEnv* env, double* seq, double* floor_z, int32_t
  * control step, the tail of one group's kernel overlaps the next group's (wave-per-env steppers only). */
 int lhw_env_step_range(LhwEnv* env, int32_t first, int32_t count, const float* act_dev, float* obs_dev, float* term_obs_dev,
                        float* rew_dev, uint8_t* done_dev, float* rew_terms_dev, void* stream);
+/* The frozen actor as the resident rollout evaluates it inside the stepper's wavefronts: the reference's worker holds a copy of
+ * the policy for the whole rollout (rl/workers/rollout_worker.py:62-77 sync_policy) and calls it once per control step
+ * (:142-150, Gaussian_FF_Actor.forward rl/policies/actor.py:160-188).  Device pointers, filled by lhw_ppo_rollout_policy. */
+typedef struct {
+  const float *w1t, *b1, *w2t, *b2, *w3t, *b3; /* TRANSPOSED weights ([in][out]: W1^T [obs_pad][hidden], W2^T [hidden][hidden],
+                                                  W3^T [hidden][act_pad]) and the biases */
+  const float *stdv;                           /* [act_dim] standard deviations of the Gaussian head */
+  const float *obs_mean, *obs_std;             /* [obs_dim] observation normalisation (actor.obs_mean / obs_std) */
+  int32_t obs_dim, obs_pad, act_dim, act_pad, hidden;
+  int32_t deterministic;                       /* != 0: act = mean (evaluation) */
+  uint64_t seed;                               /* policy-noise key, as lhw_ppo_forward's */
+  uint32_t counter;                            /* policy-stream counter of the FIRST control step; step t uses counter + t */
+} LhwRolloutPolicy;
+/* The resident rollout: T control steps of envs [first, first + count) in ONE launch -- the body of RolloutWorker.sample's loop
+ * (rl/workers/rollout_worker.py:142-181: action = policy(state); env.step(action); store; reset on episode end) executed wave
+ * by wave, no wavefront ever waiting for another env's control step.  Bitwise the values of T x { lhw_ppo_forward_at(act, logp
+ * only) ; lhw_env_step_range } on the same buffers.  All pointers are device buffers, TIME-major over the FULL batch (N = the
+ * env's n_envs; the range indexes into each time slice):
+ *   obs_dev      [T + 1][N][obs_dim] f32: slice 0 in (the observation to act on first: lhw_env_reset's output or slice T of the
+ *                previous rollout), slices 1 .. T out
+ *   act_dev      [T][N][act_dim], logp_dev [T][N]: sampled actions and their log-densities, out
+ *   term_obs_dev [T][N][obs_dim], rew_dev [T][N], done_dev [T][N] (LHW_DONE_*): as lhw_env_step, per control step, out
+ *   rew_terms_dev [N][num_reward_terms] of the LAST control step, nullable
+ * Humanoid tasks only, feed-forward float32 actor with hidden width 256 and act_dim <= 12 (LHW_ERR_UNSUPPORTED otherwise: the
+ * caller keeps the launch-per-step pipeline). */
+int lhw_env_rollout(LhwEnv* env, const LhwRolloutPolicy* policy, int32_t first, int32_t count, int32_t T, float* obs_dev, float* act_dev,
+                    float* logp_dev, float* term_obs_dev, float* rew_dev, uint8_t* done_dev, float* rew_terms_dev, void* stream);
 /* Parity hooks; HOST pointers, synchronous.  qpos [N][nq], qvel [N][nv] float64. */
 int lhw_env_get_state(LhwEnv* env, double* qpos_host, double* qvel_host);
 int lhw_env_set_state(LhwEnv* env, const double* qpos_host, const double* qvel_host);
@@ -228,6 +255,11 @@ int lhw_debug_mlp_strip_forward(int32_t H, int32_t Dp, int32_t O, int32_t Op, co
                                 float* h1, float* h2, float* y, float* wt_scratch, void* stream);
 int lhw_debug_mlp_strip_backward(int32_t H, int32_t O, int32_t Op, const float* w2, const float* w3, const float* dy, int32_t R,
                                  const float* h1, const float* h2, float* dh2, float* dh1, void* stream);
+/* Test hook: the rollout's per-control-step policy launch (observation normalisation -> actor -> Gaussian head, one strip launch;
+ * what lhw_ppo_forward_at runs when only act / logp are requested) on R raw observation rows [R][obs_dim], from an actor view.
+ * y [R][act_pad] receives the means.  The reference of lhw_env_rollout's in-wave policy step (bitwise). */
+int lhw_debug_policy_step(const LhwRolloutPolicy* policy, const float* obs, int32_t R, uint32_t env_id_base, uint32_t counter, float* y,
+                          float* act, float* logp, void* stream);
 /* Diagnostic (load balance): the first call arms the recording; later calls return, per env, the shader-clock cycles its
  * wavefront group spent in the most recent control-step launch.  HOST pointer [N] int64, synchronous; humanoid tasks only. */
 int lhw_env_debug_wave_cycles(LhwEnv* env, int64_t* cycles_host);
@@ -278,6 +310,11 @@ int lhw_ppo_forward(LhwPpo* ppo, const float* theta, const float* obs, int64_t N
  * its own copies, as before. */
 int lhw_ppo_begin_rollout(LhwPpo* ppo, const float* theta, void* stream);
 int lhw_ppo_end_rollout(LhwPpo* ppo);
+/* Inside a rollout bracket opened with this theta: the actor of theta as lhw_env_rollout reads it (the bracket's [in][out]
+ * weight copies, biases and stds inside theta, the caller's normalisation vectors).  Valid until lhw_ppo_end_rollout /
+ * lhw_ppo_apply.  LHW_ERR_UNSUPPORTED outside a bracket, with fp16 inference, or for shapes the strip kernels do not cover. */
+int lhw_ppo_rollout_policy(LhwPpo* ppo, const float* theta, const float* obs_mean, const float* obs_std, uint64_t seed,
+                           uint32_t counter, int deterministic, LhwRolloutPolicy* out);
 /* lhw_ppo_forward on workspace rows [ws_row, ws_row + N): calls issued on different streams for disjoint env groups may run
  * concurrently (env_id_base must be the global id of the group's first env) */
 int lhw_ppo_forward_at(LhwPpo* ppo, const float* theta, const float* obs, int64_t N, const float* obs_mean,

@@ -31,6 +31,12 @@ class LhwEnvConfig(ctypes.Structure):
     ]
 
 
+class LhwRolloutPolicy(ctypes.Structure):      # include/lhw.h: the frozen actor as lhw_env_rollout reads it
+    _fields_ = [(n, ctypes.c_void_p) for n in ("w1t", "b1", "w2t", "b2", "w3t", "b3", "stdv", "obs_mean", "obs_std")] + [
+        (n, ctypes.c_int32) for n in ("obs_dim", "obs_pad", "act_dim", "act_pad", "hidden", "deterministic")] + [
+        ("seed", ctypes.c_uint64), ("counter", ctypes.c_uint32)]
+
+
 # include/lhw.h: enum LhwTaskInput (offsets into one env's record, length)
 TASK_INPUT_DIM = 160
 TASK_INPUT_FIELDS = dict(grf_r=(0, 1), grf_l=(1, 1), contact_z=(2, 1), foot_contact=(3, 1), self_collision=(4, 1), phase=(5, 1), mode=(6, 1),
@@ -58,7 +64,7 @@ def sources():
 # allocator then parks them in scratch and every use becomes a scratch reload (one slot holding the constant 1.0 was reloaded
 # 42 times in the round-3 ISA).  Without it: scratch 480 -> 352 B per lane, SGPR spills 438 -> 206, VGPR spills 154 -> 100,
 # control step -5 %.  The GEMM / strip kernels keep the default pipeline.
-EXTRA_FLAGS = {"lhw_humanoid.hip": ["-mllvm", "-disable-machine-licm"]}
+EXTRA_FLAGS = {"lhw_humanoid.hip": ["-mllvm", "-disable-machine-licm"], "lhw_humanoid_rollout.hip": ["-mllvm", "-disable-machine-licm"]}
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
@@ -129,6 +135,9 @@ def declare(L):
     sig("lhw_env_step_range", [vp, i32, i32, vp, vp, vp, vp, vp, vp, vp])
     sig("lhw_ppo_set_imitation", [vp, vp, vp, ctypes.c_float, i64])
     sig("lhw_env_debug_step_record", [vp, vp, vp, vp])
+    sig("lhw_env_rollout", [vp, ctypes.POINTER(LhwRolloutPolicy), i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp])
+    sig("lhw_ppo_rollout_policy", [vp, vp, vp, vp, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_int, ctypes.POINTER(LhwRolloutPolicy)])
+    sig("lhw_debug_policy_step", [ctypes.POINTER(LhwRolloutPolicy), vp, i32, ctypes.c_uint32, ctypes.c_uint32, vp, vp, vp, vp])
     return L
 
 

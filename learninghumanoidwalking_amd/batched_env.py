@@ -69,6 +69,7 @@ class BatchedEnv:
         cfg = _lib.LhwEnvConfig()
         cfg.task, cfg.n_envs, cfg.device = task, self.n_envs, self.device.index or 0
         cfg.frame_skip, cfg.max_traj_len, cfg.env_id_base = int(frame_skip), int(max_traj_len), int(env_id_base)
+        self.env_id_base = int(env_id_base)      # global index of env 0: every RNG key of the kernels uses env_id_base + n
         cfg.seed, cfg.action_smoothing = int(seed) & (2**64 - 1), float(action_smoothing)
         cfg.kp, _ = arr(np.atleast_1d(kp), np.float64)
         cfg.kd, _ = arr(np.atleast_1d(kd), np.float64)
@@ -165,6 +166,27 @@ class BatchedEnv:
             return
         _lib.check(self._L.lhw_env_step_range(self._h, int(first), int(count), _ptr(act), _ptr(obs), _ptr(term_obs), _ptr(rew),
                                               _ptr(done), _ptr(self.rew_terms), _stream_ptr(self.device)))
+
+    def rollout(self, policy, T: int, obs: torch.Tensor, act: torch.Tensor, logp: torch.Tensor, term_obs: torch.Tensor, rew: torch.Tensor,
+                done: torch.Tensor, first: int = 0, count: int | None = None) -> bool:
+        """The resident rollout (lhw_env_rollout): T control steps of envs [first, first + count) in ONE launch on the current
+        stream, the actor (`policy`: PpoKernels.rollout_policy()) evaluated inside the stepper's wavefronts -- the body of
+        RolloutWorker.sample's loop (reference rl/workers/rollout_worker.py:142-181) with no wavefront waiting for another env.
+        Buffers are time-major over the full batch: obs [T + 1, N, D] (slice 0 in), act [T, N, A], logp / rew / done [T, N],
+        term_obs [T, N, D].  Returns False (nothing launched) where the library has no resident kernel for this env / policy."""
+        N = self.n_envs
+        if self.history_len > 1 or policy is None or not hasattr(self._L, "lhw_env_rollout"):
+            return False
+        assert obs.shape == (T + 1, N, self.obs_dim) and act.shape == (T, N, self.act_dim) and term_obs.shape == (T, N, self.obs_dim)
+        assert logp.shape == (T, N) and rew.shape == (T, N) and done.shape == (T, N) and done.dtype == torch.uint8
+        for x in (obs, act, logp, term_obs, rew, done):
+            assert x.is_cuda and x.is_contiguous()
+        rc = self._L.lhw_env_rollout(self._h, ctypes.byref(policy), int(first), int(N - first if count is None else count), int(T), _ptr(obs),
+                                     _ptr(act), _ptr(logp), _ptr(term_obs), _ptr(rew), _ptr(done), _ptr(self.rew_terms), _stream_ptr(self.device))
+        if rc == -4:      # LHW_ERR_UNSUPPORTED
+            return False
+        _lib.check(rc)
+        return True
 
     def get_state(self):
         qpos = np.zeros((self.n_envs, self.nq))

@@ -1,0 +1,232 @@
+// The resident rollout: policy step + control step for T control steps of a rollout in ONE launch, wave by wave.
+//
+// Takes over the body of the reference's worker loop (rl/workers/rollout_worker.py:142-181: `action = policy(state)`,
+// `env.step(action)`, store, reset on episode end) for every env of a range.  In the reference each worker advances its own
+// env without ever waiting for another one; the launch-per-control-step pipeline (lhw_env_step_range + lhw_ppo_forward_at)
+// instead ends every control step on the slowest of the batch's wavefronts before the policy launch -- a launch lasts as long
+// as its slowest wave (1.58x the mean wave of a 4096-env launch) and the chip drains meanwhile.  Here a wavefront keeps its
+// env(s) for the whole rollout and evaluates the actor itself:
+//
+//   for t in 0 .. T-1:   obs[t] rows of the wave's envs  ->  policy_step  ->  act[t], logp[t]
+//                        control_step<0, TASK, W>         ->  obs[t+1], term_obs[t], rew[t], done[t]   (auto-reset inside)
+//
+// The policy step is the fused strip launch of lhw_mlp_strip.hip restated for the 1-2 rows a wave owns: two rows x 256 hidden
+// units are nowhere near an MFMA tile (1/16 of a 32x32 tile), so the layers are plain v_fma_f32 over all 64 lanes -- lane l
+// owns hidden units 4l .. 4l+3 of both rows, the weights come straight from L2 in [in][out] order (one 16-byte load per lane
+// and k row = 1 KB per wave, fully coalesced; 0.3 MB per wave and control step, ~2 % of a control step), the activations sit
+// in the stepper's LDS stage region, which is dead between control steps.  Every value is produced by the SAME operations in
+// the SAME order as mlp_fwd_strip_kernel's (normalisation expression, fmaf chains over ascending k from 0, bias added after
+// the chain, the read-out cut into eight 32-k partial sums added in ascending order, lhw_policy_sample), so a rollout collected
+// here is bitwise the rollout of the launch-per-step pipeline (tests/test_rollout_resident*.py).
+//
+// Two envs per wave (W = 32): an env that exceeds the layout's 8 contacts in a control step returns untouched from
+// control_step<0, TASK, 32>; the launch-per-step path repeats its step with the one-env-per-wave kernel in a second launch.
+// Here the wave does that itself, at once: both envs have left the LDS working set by then (everything persistent is in the HBM
+// record between control steps), so the wave re-interprets its LDS allocation as the W = 64 layout and runs
+// control_step<0, TASK, 64> for the flagged env with all 64 lanes -- same code, same bits as the second launch.
+#include "lhw_humanoid_dev.h"
+#include "lhw_policy.h"
+
+#define PH 256      // hidden width of the actor (rl/policies/actor.py:127)
+#define PKQ 32      // the read-out is summed as PH / PKQ partial products of PKQ k each (SKQ of lhw_mlp_strip.hip)
+#define PXK 64      // capacity of the padded observation row
+#define PO_MAX 12   // action dims the read-out's lane mapping covers (JVRC 12, H1 10)
+
+struct HRollout {
+  int T;                 // control steps of this launch
+  int n_total;           // envs of the batch: row count of one time slice of the buffers below
+  float* obs;            // [T + 1][n_total][obs_dim]: slice 0 is read (the observation to act on first), 1 .. T are written
+  float* act;            // [T][n_total][act_dim]
+  float* logp;           // [T][n_total]
+  float* tob;            // [T][n_total][obs_dim] observation returned by env.step itself (bootstrap input where an episode ended)
+  float* rew;            // [T][n_total]
+  unsigned char* done;   // [T][n_total] LHW_DONE_* flags
+  float* rew_terms;      // [n_total][n_terms] of the last control step, nullable
+  LhwRolloutPolicy pol;
+};
+
+// One 256-wide ReLU layer for the wave's G rows: hout[r][n] = relu(chain_k fmaf(W^T[k][n], xin[r][k]) + bias[n]), n = 4 wl .. 4 wl + 3.
+template <int G>
+__device__ __forceinline__ void policy_hidden(const float* __restrict__ wt, const float* __restrict__ bias, const float* xin, const int ldx, const int K,
+                                              float* hout, const int wl) {
+  float acc[G][4];
+#pragma unroll
+  for (int r = 0; r < G; r++)
+#pragma unroll
+    for (int c = 0; c < 4; c++) acc[r][c] = 0.f;
+  const float4* w4 = reinterpret_cast<const float4*>(wt) + wl;
+#pragma unroll 8
+  for (int k = 0; k < K; k++) {
+    const float4 w = w4[(size_t)k * (PH / 4)];
+#pragma unroll
+    for (int r = 0; r < G; r++) {
+      const float x = xin[r * ldx + k];
+      acc[r][0] = fmaf(w.x, x, acc[r][0]); acc[r][1] = fmaf(w.y, x, acc[r][1]);
+      acc[r][2] = fmaf(w.z, x, acc[r][2]); acc[r][3] = fmaf(w.w, x, acc[r][3]);
+    }
+  }
+  const float4 b = reinterpret_cast<const float4*>(bias)[wl];
+#pragma unroll
+  for (int r = 0; r < G; r++) {
+    float4 v = make_float4(fmaxf(acc[r][0] + b.x, 0.f), fmaxf(acc[r][1] + b.y, 0.f), fmaxf(acc[r][2] + b.z, 0.f), fmaxf(acc[r][3] + b.w, 0.f));
+    *reinterpret_cast<float4*>(hout + r * PH + 4 * wl) = v;
+  }
+}
+
+// floats of LDS the policy step of a wave with G rows needs
+template <int G> struct PolicyLds { static constexpr int XS = 0, H1 = XS + G * PXK, H2 = H1 + G * PH, PP = H2 + G * PH, TM = PP + 8 * G * 16, FLOATS = TM + G * 16; };
+
+// Actor forward + Gaussian head for the wave's rows (envs env0 .. env0 + nlive - 1 of this time slice); all 64 lanes take part.
+template <int G>
+__device__ __forceinline__ void policy_step(const LhwRolloutPolicy& q, float* sc, const float* __restrict__ obs_t, float* __restrict__ act_t,
+                                            float* __restrict__ logp_t, const int env0, const int nlive, const unsigned genv0, const unsigned counter) {
+  typedef PolicyLds<G> PL;
+  const int wl = fresh_wave_lane();
+  const int D = q.obs_dim, O = q.act_dim, Op = q.act_pad;
+  float *xs = sc + PL::XS, *h1 = sc + PL::H1, *h2 = sc + PL::H2, *Pp = sc + PL::PP, *Tm = sc + PL::TM;
+  // the normalised observation rows (the expression of stage_input / normalize_kernel), zero beyond the observation width
+  for (int i = wl; i < G * PXK; i += 64) {
+    const int r = i / PXK, k = i - r * PXK;
+    float v = 0.f;
+    if (k < D && r < nlive) v = (obs_t[(size_t)(env0 + r) * D + k] - q.obs_mean[k]) / q.obs_std[k];
+    xs[i] = v;
+  }
+  SYNC();
+  policy_hidden<G>(q.w1t, q.b1, xs, PXK, q.obs_pad, h1, wl);
+  SYNC();
+#ifdef LHW_DBG_POL
+  if (wl == 0 && env0 == 0) printf("dbg counter %u xs %g %g %g %g h1 %g %g %g %g w1t %g %g b1 %g\n", counter, xs[0], xs[1], xs[36], xs[37], h1[0], h1[1], h1[2], h1[255], q.w1t[0], q.w1t[1], q.b1[0]);
+#endif
+  policy_hidden<G>(q.w2t, q.b2, h1, PH, PH, h2, wl);
+  SYNC();
+  // read-out: lane = (partial q8 of 8, row, column group); CPL columns per lane
+  constexpr int CG = 8 / G, CPL = (PO_MAX + CG - 1) / CG;
+  const int q8 = wl >> 3, r = G == 2 ? ((wl >> 2) & 1) : 0, cg = G == 2 ? (wl & 3) : (wl & 7);
+  float pacc[CPL];
+#pragma unroll
+  for (int c = 0; c < CPL; c++) pacc[c] = 0.f;
+#pragma unroll 8
+  for (int kk = 0; kk < PKQ; kk++) {
+    const int k = q8 * PKQ + kk;
+    const float h = h2[r * PH + k];
+#pragma unroll
+    for (int c = 0; c < CPL; c++) {
+      const int col = cg * CPL + c;
+      const float wv = q.w3t[(size_t)k * Op + min(col, O - 1)];
+      pacc[c] = fmaf(h, col < O ? wv : 0.f, pacc[c]);
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < CPL; c++) Pp[(q8 * G + r) * 16 + cg * CPL + c] = pacc[c];
+  SYNC();
+  if (wl < 16 * G) {
+    const int rr = wl >> 4, col = wl & 15;
+    if (col < O && rr < nlive) {
+      float s = Pp[rr * 16 + col];
+#pragma unroll
+      for (int j = 1; j < PH / PKQ; j++) s += Pp[(j * G + rr) * 16 + col];
+      s += q.b3[col];
+      float term;
+      const float a = lhw_policy_sample(s, q.stdv[col], q.seed, genv0 + (unsigned)rr, counter, col, q.deterministic, &term);
+      act_t[(size_t)(env0 + rr) * O + col] = a;
+      Tm[rr * 16 + col] = term;
+    }
+  }
+  SYNC();
+  if (wl < nlive) {
+    float lp = 0.f;
+    for (int k = 0; k < O; k++) lp += Tm[wl * 16 + k];     // (the order of sample_kernel's sum)
+    logp_t[env0 + wl] = lp;
+  }
+  SYNC();
+}
+
+template <int TASK, int W>
+__global__ void __launch_bounds__(64, LHW_WAVES_PER_SIMD) humanoid_rollout_kernel(const HModel* __restrict__ mp, const HParams* __restrict__ pp, HLaunch lz, HState st, HRollout ro) {
+  using L = typename LayoutOf<TASK, W>::type;
+  using L1 = typename LayoutOf<TASK, 64>::type;
+  constexpr int G = 64 / W;   // envs per wavefront
+  constexpr size_t LDS_BYTES = sizeof(L) * G > sizeof(L1) ? sizeof(L) * G : sizeof(L1);
+  static_assert(W == 64 || sizeof(L1) <= sizeof(L) * G, "the one-env-per-wave layout must fit the wave's two-env allocation (8 workgroups per CU)");
+  static_assert(L::USIZE_ * 2 - 48 >= PolicyLds<G>::FLOATS, "the policy step's activations must fit the stage region in front of the observation staging");
+  __shared__ __attribute__((aligned(16))) unsigned char SGraw[LDS_BYTES];
+  LHW_LDS_POISON(SGraw);
+  L* SG = reinterpret_cast<L*>(SGraw);
+  const HParams& p = *pp;
+  const HModel& m = *mp;
+  const int eidx0 = (int)blockIdx.x * G;
+  if (eidx0 >= lz.env_count) return;
+  const int nlive = min(G, lz.env_count - eidx0);
+  const int env0 = lz.env_first + eidx0;
+  const int OBS = TASK == TASK_WALK ? 37 : (TASK == TASK_STEP ? 39 : (TASK == TASK_H1WALK ? 43 : 35));
+  const size_t N = (size_t)ro.n_total;
+  for (int t = 0; t < ro.T; t++) {
+    GROUP_SYNC(64);
+    // what this wave wrote in the previous control step (the observation rows it now reads; after a W = 64 re-run, by other
+    // lanes than the ones that read them) is visible
+    __threadfence();
+    const float* obs_t = ro.obs + (size_t)t * N * OBS;
+    float* act_t = ro.act + (size_t)t * N * m.nu;
+    policy_step<G>(ro.pol, reinterpret_cast<float*>(SG[0].U), obs_t, act_t, ro.logp + (size_t)t * N, env0, nlive, p.env_id_base + (unsigned)env0,
+                   ro.pol.counter + (unsigned)t);
+    __threadfence();   // the action rows are read back by the lanes of their env's group
+    const int wl = fresh_wave_lane();
+    const int g = W == 32 ? (wl >> 5) : 0, lane = wl & (W - 1);
+    float* obs_n = ro.obs + (size_t)(t + 1) * N * OBS;
+    float* tob_t = ro.tob + (size_t)t * N * OBS;
+    float* rew_t = ro.rew + (size_t)t * N;
+    unsigned char* done_t = ro.done + (size_t)t * N;
+    bool ovf = false;
+    if (g < nlive)
+      ovf = control_step<0, TASK, W>(m, p, lz, st, SG, SG[g], env0 + g, lane, act_t, obs_n, tob_t, rew_t, done_t, ro.rew_terms, nullptr, nullptr);
+    if constexpr (W == 32) {
+      GROUP_SYNC(64);
+      const unsigned long long ob = __ballot(ovf);
+      if (ob) {
+        HLaunch lz1 = lz;
+        lz1.only_flagged = 1;   // (store_record clears the env's flag and counts the re-run)
+        L1* S1 = reinterpret_cast<L1*>(SGraw);
+        for (int gg = 0; gg < 2; gg++)
+          if ((ob >> (32 * gg)) & 1ull) {
+            SYNC();
+            control_step<0, TASK, 64>(m, p, lz1, st, S1, S1[0], env0 + gg, fresh_wave_lane(), act_t, obs_n, tob_t, rew_t, done_t, ro.rew_terms, nullptr, nullptr);
+          }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+#ifdef LHW_ONLY_WALK
+#define ROLLOUT_OTHER_TASKS(WIDTH)
+#else
+#define ROLLOUT_OTHER_TASKS(WIDTH)                                                                                                                              \
+  else if (h->p.task == TASK_H1WALK) hipLaunchKernelGGL((humanoid_rollout_kernel<TASK_H1WALK, WIDTH>), grid, dim3(64), 0, s, (const HModel*)h->m_dev, (const HParams*)h->p_dev, lz, h->st, ro); \
+  else hipLaunchKernelGGL((humanoid_rollout_kernel<TASK_STAND, WIDTH>), grid, dim3(64), 0, s, (const HModel*)h->m_dev, (const HParams*)h->p_dev, lz, h->st, ro);
+#endif
+
+int humanoid_rollout(HumanoidEnv* h, int first, int count, int T, const LhwRolloutPolicy* pol, float* obs, float* act, float* logp, float* term_obs,
+                     float* rew, uint8_t* done, float* rew_terms, hipStream_t s) {
+  if (first < 0 || count <= 0 || first + count > h->p.n_envs || T <= 0) return -1;
+  const int obs_dim = h->p.task == TASK_STEP ? 39 : (h->p.task == TASK_WALK ? 37 : (h->p.task == TASK_H1WALK ? 43 : 35));
+  if (pol->hidden != PH || pol->obs_dim != obs_dim || pol->act_dim != h->m.nu || pol->act_dim > PO_MAX || pol->act_pad < pol->act_dim ||
+      pol->obs_pad < obs_dim || pol->obs_pad > PXK || (pol->obs_pad & 3))
+    return -2;
+  HRollout ro;
+  ro.T = T; ro.n_total = h->p.n_envs;
+  ro.obs = obs; ro.act = act; ro.logp = logp; ro.tob = term_obs; ro.rew = rew; ro.done = done; ro.rew_terms = rew_terms;
+  ro.pol = *pol;
+  const HLaunch lz{first, count, 0, h->iteration};
+  if (h->fast) {
+    const dim3 grid((count + 1) / 2);
+    if (h->p.task == TASK_WALK) hipLaunchKernelGGL((humanoid_rollout_kernel<TASK_WALK, 32>), grid, dim3(64), 0, s, (const HModel*)h->m_dev, (const HParams*)h->p_dev, lz, h->st, ro);
+    ROLLOUT_OTHER_TASKS(32)
+  } else if (h->p.task == TASK_STEP) {
+#ifndef LHW_ONLY_WALK
+    hipLaunchKernelGGL((humanoid_rollout_kernel<TASK_STEP, 64>), dim3(count), dim3(64), 0, s, (const HModel*)h->m_dev, (const HParams*)h->p_dev, lz, h->st, ro);
+#endif
+  } else {
+    return -3;   // a walking / standing model that does not fit the two-envs-per-wave layout (or LHW_ONE_ENV_PER_WAVE): launch-per-step only
+  }
+  return 0;
+}

@@ -366,3 +366,18 @@ extern "C" int lhw_debug_mlp_strip_backward(int32_t H, int32_t O, int32_t Op, co
   mlp_strip_backward(a, (hipStream_t)stream);
   return hipGetLastError() == hipSuccess ? LHW_OK : lhw_fail(LHW_ERR_HIP, "mlp_bwd_strip_kernel launch failed");
 }
+
+// the rollout's fused policy step (normalisation -> three layers -> Gaussian head) on R observation rows, from the actor view the
+// resident rollout reads: the launch lhw_ppo_forward_at issues per control step, reachable without an LhwPpo (tests, SIMT emulator)
+extern "C" int lhw_debug_policy_step(const LhwRolloutPolicy* q, const float* obs, int32_t R, uint32_t env_id_base, uint32_t counter, float* y,
+                                     float* act, float* logp, void* stream) {
+  if (!q || !obs || !y || !act || !logp || R <= 0) return lhw_fail(LHW_ERR_ARG, "bad argument");
+  if (!mlp_strip_supported(q->hidden, q->obs_pad, q->act_dim, q->act_pad)) return lhw_fail(LHW_ERR_UNSUPPORTED, "strip kernels: hidden width 256, padded input width <= 64, outputs <= 32");
+  MlpStripFwd a{q->w1t, q->b1, q->w2t, q->b2, q->w3t, q->b3, obs, q->obs_dim, q->obs_pad, q->act_dim, q->act_pad, R, nullptr, nullptr, y};
+  a.in_mean = q->obs_mean; a.in_std = q->obs_std; a.in_dim = q->obs_dim;
+  a.stdv = q->stdv; a.act = act; a.logp = logp;
+  a.seed = q->seed; a.env_base = env_id_base; a.counter = counter; a.deterministic = q->deterministic;
+  const char* sh = getenv("LHW_DEBUG_STRIP_SHAPE");
+  mlp_strip_forward(a, (hipStream_t)stream, sh ? (sh[0] == 's' ? 1 : 2) : 0);
+  return hipGetLastError() == hipSuccess ? LHW_OK : lhw_fail(LHW_ERR_HIP, "mlp_fwd_strip_kernel launch failed");
+}

@@ -1094,6 +1094,25 @@ extern "C" int lhw_ppo_end_rollout(LhwPpo* p) {
   return LHW_OK;
 }
 
+extern "C" int lhw_ppo_rollout_policy(LhwPpo* p, const float* theta, const float* obs_mean, const float* obs_std, uint64_t seed,
+                                      uint32_t counter, int deterministic, LhwRolloutPolicy* out) {
+  if (!p || !theta || !obs_mean || !obs_std || !out) return lhw_fail(LHW_ERR_ARG, "null argument");
+  const MlpLayout& La = p->la;
+  if (p->roll_theta == nullptr || p->roll_theta != theta || !p->wt_roll)
+    return lhw_fail(LHW_ERR_UNSUPPORTED, "lhw_ppo_rollout_policy: no rollout bracket open for this theta (lhw_ppo_begin_rollout)");
+  if (p->infer_half || !mlp_strip_supported(La.H, La.Dp, La.O, La.Op))
+    return lhw_fail(LHW_ERR_UNSUPPORTED, "lhw_ppo_rollout_policy: float32 actor with hidden width 256 only");
+  const float* th = theta + p->off_actor;
+  const float* wt = p->wt_roll;
+  out->w1t = wt; out->b1 = th + La.b1;
+  out->w2t = wt + (size_t)La.Dp * La.H; out->b2 = th + La.b2;
+  out->w3t = wt + (size_t)La.Dp * La.H + (size_t)La.H * La.H; out->b3 = th + La.b3;
+  out->stdv = theta + p->off_std; out->obs_mean = obs_mean; out->obs_std = obs_std;
+  out->obs_dim = p->D; out->obs_pad = La.Dp; out->act_dim = La.O; out->act_pad = La.Op; out->hidden = La.H;
+  out->deterministic = deterministic; out->seed = seed; out->counter = counter;
+  return LHW_OK;
+}
+
 // Rollout inference for N rows (N <= max_rows): normalise, actor + critic forward, sample.
 //   act/logp/mu may be NULL to run the critic only; value may be NULL to run the actor only.
 extern "C" int lhw_ppo_forward(LhwPpo* p, const float* theta, const float* obs, int64_t N, const float* obs_mean,

@@ -160,10 +160,32 @@ class Rollout:
         finally:
             k.end_rollout()
 
+    def _collect_resident(self, deterministic) -> bool:
+        """All T control steps in one launch per rollout group, the actor evaluated inside the stepper's wavefronts
+        (BatchedEnv.rollout): bitwise the values of the launch-per-step loop below, without its per-control-step barrier across
+        the envs of a group.  LHW_ROLLOUT_MODE=steps keeps the launch-per-step pipeline."""
+        env, k, T = self.env, self.k, self.T
+        if os.environ.get("LHW_ROLLOUT_MODE", "resident") != "resident" or not hasattr(env, "rollout") or not hasattr(k, "rollout_policy"):
+            return False
+        pol = k.rollout_policy(seed=self.seed, counter=self.counter, deterministic=deterministic)
+        if pol is None:
+            return False
+        self._pol_keep = pol      # (passed by value at the launch; kept for the debugger's sake)
+        # (the in-wave policy step keys its noise by the env's own global ids; the per-step calls below pass self.env_base + row)
+        if getattr(env, "env_id_base", 0) != self.env_base:
+            return False
+        if not env.rollout(pol, T, self.obs, self.act, self.logp, self.tob_all, self.rew, self.done):
+            return False
+        self.counter += T
+        return True
+
     def _collect_steps(self, deterministic):
         env, k, T = self.env, self.k, self.T
         G = self.groups
-        if G <= 1:
+        self.last_mode = "steps"      # which path collected the last rollout (tests, bench line)
+        if self._collect_resident(deterministic):
+            self.last_mode = "resident"
+        elif G <= 1:
             for t in range(T):
                 k.forward(self.obs[t], seed=self.seed, env_id_base=self.env_base, counter=self.counter,
                           deterministic=deterministic, want_value=False, want_mu=False, act=self.act[t], logp=self.logp[t])

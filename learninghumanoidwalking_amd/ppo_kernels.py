@@ -185,6 +185,18 @@ class PpoKernels:
     def end_rollout(self):
         _lib.check(self._L.lhw_ppo_end_rollout(self._h))
 
+    def rollout_policy(self, *, seed=0, counter=0, deterministic=False):
+        """The frozen actor as the resident rollout (BatchedEnv.rollout -> lhw_env_rollout) evaluates it inside the stepper's
+        wavefronts; valid inside a begin_rollout() bracket.  Returns None where the in-wave policy step does not apply (fp16
+        inference, shapes outside the strip kernels): the caller keeps the launch-per-step pipeline."""
+        view = _lib.LhwRolloutPolicy()
+        rc = self._L.lhw_ppo_rollout_policy(self._h, _p(self.theta), _p(self.obs_mean), _p(self.obs_std), int(seed) & (2**64 - 1),
+                                            int(counter) & 0xFFFFFFFF, int(bool(deterministic)), ctypes.byref(view))
+        if rc == -4:      # LHW_ERR_UNSUPPORTED
+            return None
+        _lib.check(rc)
+        return view
+
     def normalize(self, obs, want_mirror=None):
         R = obs.shape[0]
         want_mirror = self.use_mirror if want_mirror is None else want_mirror

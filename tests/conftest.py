@@ -20,7 +20,7 @@ def pytest_configure(config):
 # 112 parity tests never ran).
 _ORDER = ["test_cartpole_gpu", "test_jvrc_gpu", "test_h1_gpu", "test_h1_walk_gpu", "test_jvrc_step_gpu", "test_model_variants_gpu", "test_fuse_static_gpu",
           "test_task_inputs_gpu", "test_obs_history_gpu", "test_gemm_gpu", "test_mlp_strip_gpu", "test_ppo_gpu", "test_rnn_gpu",
-          "test_errors_gpu", "test_fullsize_gpu", "test_freerun_gpu", "test_iteration_gpu"]
+          "test_errors_gpu", "test_fullsize_gpu", "test_freerun_gpu", "test_iteration_gpu", "test_rollout_resident_gpu"]
 _LAST = ["test_reference_configs", "test_entry_gpu", "test_distributed_gpu"]
 
 

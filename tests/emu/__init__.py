@@ -21,7 +21,7 @@ _ROOT = os.path.dirname(os.path.dirname(_HERE))
 _CSRC = os.path.join(_ROOT, "learninghumanoidwalking_amd", "csrc")
 _BUILD = os.path.join(_HERE, "_build")
 LIB_PATH = os.path.join(_BUILD, "liblhw_emu.so")
-SOURCES = ["lhw_humanoid.hip", "lhw_cartpole.hip", "lhw_api.hip", "lhw_mlp_strip.hip"]
+SOURCES = ["lhw_humanoid.hip", "lhw_humanoid_rollout.hip", "lhw_cartpole.hip", "lhw_api.hip", "lhw_mlp_strip.hip"]
 _LIB = None
 
 
@@ -126,6 +126,15 @@ class EmuBatchedEnv:
         self._check(self._L.lhw_env_step(self._h, act.ctypes.data, self.obs.ctypes.data, self.term_obs.ctypes.data,
                                          self.rew.ctypes.data, self.done.ctypes.data, self.rew_terms.ctypes.data, None))
         return self.obs, self.rew, self.done, self.term_obs
+
+    def rollout(self, policy, T, obs, act, logp, tob, rew, done, first=0, count=None):
+        """lhw_env_rollout on numpy buffers (time-major over the full batch; obs[0] is the input)."""
+        N = self.n_envs
+        assert obs.shape == (T + 1, N, self.obs_dim) and act.shape == (T, N, self.act_dim) and tob.shape == (T, N, self.obs_dim)
+        assert all(a.flags.c_contiguous for a in (obs, act, logp, tob, rew, done))
+        self._check(self._L.lhw_env_rollout(self._h, ctypes.byref(policy), int(first), int(N - first if count is None else count), int(T),
+                                            obs.ctypes.data, act.ctypes.data, logp.ctypes.data, tob.ctypes.data, rew.ctypes.data,
+                                            done.ctypes.data, self.rew_terms.ctypes.data, None))
 
     def get_state(self):
         q, v = np.zeros((self.n_envs, self.nq)), np.zeros((self.n_envs, self.nv))

@@ -150,7 +150,8 @@ static void resolve(Block& b) {
     if (l.state != BLOCKED || l.op != OP_GROUP_SYNC) continue;
     const int W = l.sel, g0 = i - (i % W);
     for (int j = g0; j < g0 + W && j < n; j++)
-      if (b.lanes[j].state != DONE && !(b.lanes[j].state == BLOCKED && b.lanes[j].op == OP_GROUP_SYNC)) hold[i] = 1;
+      if (b.lanes[j].state != DONE && !(b.lanes[j].state == BLOCKED && b.lanes[j].op == OP_GROUP_SYNC && b.lanes[j].sel == W)) hold[i] = 1;   // (a lane waiting at a
+                                                                         // rendezvous of ANOTHER width -- its own 32-lane group's, inside a control step -- has not arrived at this one)
   }
   for (int i = 0; i < n; i++) {
     Lane& l = b.lanes[i];

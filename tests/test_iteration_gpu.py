@@ -120,6 +120,7 @@ def test_grouped_rollout_is_bitwise_identical_to_single_stream(env_name, monkeyp
     from learninghumanoidwalking_amd.ppo import PPO
 
     def run(groups):
+        monkeypatch.setenv("LHW_ROLLOUT_MODE", "steps")      # (the resident rollout, tests/test_rollout_resident_gpu.py, has no groups)
         monkeypatch.setenv("LHW_ROLLOUT_GROUPS", str(groups))
         args = SimpleNamespace(gamma=0.99, lam=0.95, lr=3e-4, eps=1e-5, entropy_coeff=0.0, clip=0.2, minibatch_size=512, epochs=1,
                                max_traj_len=12, num_procs=96, num_envs=96, max_grad_norm=0.5, mirror_coeff=0.4, eval_freq=10**9,
@@ -130,6 +131,7 @@ def test_grouped_rollout_is_bitwise_identical_to_single_stream(env_name, monkeyp
         for _ in range(2):
             algo.sample_parallel_with_workers()
         ro = algo.rollout
+        assert ro.last_mode == "steps"
         return [x.clone() for x in (ro.obs, ro.act, ro.logp, ro.rew, ro.done, ro.val, ro.vterm, ro.vfinal)]
 
     a, b, c = run(1), run(2), run(3)

@@ -1,0 +1,99 @@
+"""The resident rollout on the GPU (lhw_env_rollout: all T control steps of a rollout in one launch, the actor evaluated inside the
+stepper's wavefronts; csrc/lhw_humanoid_rollout.hip) against the launch-per-step pipeline (T x { lhw_ppo_forward_at ;
+lhw_env_step_range }): every stored value BITWISE equal -- which also holds the in-wave v_fma_f32 policy step to the MFMA strip
+kernel's bits.  Reference: the body of RolloutWorker.sample's loop, /root/reference/rl/workers/rollout_worker.py:142-181.
+GPU twin of tests/test_rollout_resident.py (SIMT emulator)."""
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _args(N, T, std=0.4):
+    return SimpleNamespace(gamma=0.99, lam=0.95, lr=3e-4, eps=1e-5, entropy_coeff=0.0, clip=0.2, minibatch_size=512, epochs=1,
+                           max_traj_len=T, num_procs=N, num_envs=N, max_grad_norm=0.5, mirror_coeff=0.4, eval_freq=10**9,
+                           recurrent=False, imitate=None, learn_std=False, std_dev=std, no_mirror=True, continued=None,
+                           logdir="/tmp/lhw_test_resident", device_index=0)
+
+
+def _buffers(ro):
+    return [x.clone() for x in (ro.obs, ro.act, ro.logp, ro.tob_all, ro.rew, ro.done, ro.val, ro.vterm, ro.vfinal)]
+
+
+@pytest.mark.parametrize("env_name", ["jvrc_walk", "h1", "h1_walk", "jvrc_step"])
+def test_resident_rollout_is_bitwise_the_launch_per_step_rollout(env_name, monkeypatch):
+    from learninghumanoidwalking_amd.envs import ENVIRONMENTS
+    from learninghumanoidwalking_amd.ppo import PPO
+
+    def run(mode):
+        monkeypatch.setenv("LHW_ROLLOUT_MODE", mode)
+        algo = PPO(ENVIRONMENTS[env_name], _args(97, 12), seed=9)      # odd batch: the last wavefront holds one env
+        out = []
+        for _ in range(3):                                            # episodes end (falls, truncation at 12) and carry over
+            algo.sample_parallel_with_workers()
+            assert algo.rollout.last_mode == mode
+            out.append(_buffers(algo.rollout))
+        q, v = algo.env.get_state()
+        return out, q, v, algo.env.pop_fault_stats()
+
+    (a, qa, va, fa), (b, qb, vb, fb) = run("steps"), run("resident")
+    for ra, rb in zip(a, b):
+        for x, y in zip(ra, rb):
+            assert torch.equal(x, y)
+    np.testing.assert_array_equal(qa, qb)
+    np.testing.assert_array_equal(va, vb)
+    assert fa == fb == (0, 0)
+    assert (a[0][5] != 0).any(), "no episode ended inside the rollouts"
+
+
+def test_resident_rollout_repeats_overflowing_envs_inside_the_wave(monkeypatch):
+    """envs lying on the floor with 10 .. 13 contacts (beyond the two-envs-per-wave layout's 8): a second launch in the
+    launch-per-step pipeline, the same wavefront with its LDS re-interpreted in the resident rollout -- same bits, same count"""
+    from learninghumanoidwalking_amd.envs import ENVIRONMENTS
+    from learninghumanoidwalking_amd.ppo import PPO
+    poses = ([0.0, 0.0, 0.2571, -0.7309, -0.1371, 0.232, 0.627, -0.9859, -0.3243, -0.4729, 0.119, 0.609, 0.1118, -1.4146, 0.1458, 0.4932, 2.1903, 0.42, -0.5225],
+             [0.0, 0.0, 0.1223, -0.4502, 0.0287, 0.3794, 0.8078, -1.2999, -0.2333, 0.4393, 0.4916, 0.2839, -0.8672, -1.533, 0.0192, -0.4235, 2.2823, -0.1645, -1.051],
+             [0.0, 0.0, 0.142, -0.7055, -0.3568, 0.5444, 0.2804, 0.2372, -0.0299, -0.0106, 1.5965, -0.2912, -0.7387, -0.6059, -0.272, 0.0915, 0.445, -0.3003, 0.7158])
+
+    def run(mode):
+        monkeypatch.setenv("LHW_ROLLOUT_MODE", mode)
+        algo = PPO(ENVIRONMENTS["jvrc_walk"], _args(16, 6, std=0.1), seed=2)
+        env = algo.env
+        algo.rollout.obs[algo.rollout.T].copy_(env.reset())      # (collect() continues from the last observation of the previous rollout)
+        algo.rollout.started = True
+        q, v = env.get_state()
+        for i, pose in zip((0, 5, 15), poses):      # first / second env of a wavefront
+            q[i] = pose
+            q[i, 3:7] /= np.linalg.norm(q[i, 3:7])
+            v[i] = 0
+        env.set_state(q, v)
+        env.pop_rerun_count()
+        algo.rollout.collect()
+        assert algo.rollout.last_mode == mode
+        return _buffers(algo.rollout), env.get_state(), env.pop_rerun_count(), env.pop_fault_stats()
+
+    (a, sa, ra, fa), (b, sb, rb, fb) = run("steps"), run("resident")
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+    np.testing.assert_array_equal(sa[0], sb[0])
+    assert ra > 0 and ra == rb, (ra, rb)
+    assert fa == fb == (0, 0)
+
+
+def test_training_with_the_resident_rollout_ends_with_the_same_weights(monkeypatch):
+    from learninghumanoidwalking_amd.envs import ENVIRONMENTS
+    from learninghumanoidwalking_amd.ppo import PPO
+
+    def run(mode):
+        monkeypatch.setenv("LHW_ROLLOUT_MODE", mode)
+        a = _args(64, 16, std=0.223)
+        a.no_mirror = False
+        algo = PPO(ENVIRONMENTS["jvrc_walk"], a, seed=3)
+        for itr in range(2):
+            algo.iterate(itr)
+        return algo.kernels.theta.clone()
+
+    assert torch.equal(run("steps"), run("resident"))
