@@ -138,6 +138,11 @@ def main():
     ap.add_argument("--fp16", action="store_true", help="BASELINE config 5: fp16 actor / critic (inference and every GEMM of the update with fp16 operands, f32 accumulation / master weights / Adam)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` as a plain command: become N ranks (rank 0 prints the one JSON line)
+        from learninghumanoidwalking_amd.dist_utils import relaunch_under_torchrun
+        raise SystemExit(relaunch_under_torchrun(args.gpus, os.path.abspath(__file__), sys.argv[1:]))
+
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -244,6 +249,9 @@ def main():
     if hasattr(env, "pop_rerun_count"):
         env.pop_rerun_count()
     timing["on"] = rank == 0
+    from learninghumanoidwalking_amd import dist_utils
+    if use_dist and rank == 0:
+        dist_utils.allreduce_events = []
     t0 = time.time()
     sample_t = opt_t = 0.0
     iter_s = []
@@ -359,6 +367,14 @@ def main():
                                   env_steps=int(N * T * K),
                                   note="rank 0, timed iterations: control steps that dropped contacts beyond the 16-contact layout / whose state "
                                        "went non-finite / that the two-envs-per-wave kernel handed to the one-env-per-wave kernel (> 8 contacts)"))
+        if use_dist:
+            ar = [a.elapsed_time(b) for a, b in (dist_utils.allreduce_events or [])]
+            out["data_parallel"] = dict(n_gpus=world, envs_per_rank=[N] * world, backend="gloo (LHW_SHARE_GPU test mode)" if share else "nccl (RCCL)",
+                                        gradient_floats=int(kk.grad.numel()) if hasattr(kk, "grad") else None,
+                                        allreduce_calls_per_iter=len(ar) / K if K else 0, allreduce_ms_per_step=float(np.mean(ar)) if ar else None,
+                                        allreduce_ms_per_iter=float(np.sum(ar)) / K if ar else None,
+                                        note="rank 0, timed iterations: one sum-all-reduce of the flat gradient per optimiser step (events on the update's stream, "
+                                             "so a call's span includes waiting for the slowest rank's minibatch); envs are sharded by global env id, no other data-path collective")
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = run_cpu_baseline(env_name)
         print(json.dumps(out))

@@ -307,7 +307,9 @@ int lhw_ppo_forward(LhwPpo* ppo, const float* theta, const float* obs, int64_t N
  * ONCE here (on `stream`; streams that issue forwards afterwards must be ordered behind it) instead of in every policy step.
  * Until lhw_ppo_end_rollout -- or lhw_ppo_apply, which changes theta -- every lhw_ppo_forward / _forward_at call with this theta
  * pointer reads those copies (read-only: any number of concurrent calls on any streams).  Outside a bracket each call makes
- * its own copies, as before. */
+ * its own copies, as before.  theta must NOT be written between lhw_ppo_begin_rollout and lhw_ppo_end_rollout (a checkpoint load, a
+ * parameter broadcast): the bracket is keyed by the pointer, so the copies would silently go stale -- close it first (the Python
+ * layer's PpoKernels.set_tensors does). */
 int lhw_ppo_begin_rollout(LhwPpo* ppo, const float* theta, void* stream);
 int lhw_ppo_end_rollout(LhwPpo* ppo);
 /* Inside a rollout bracket opened with this theta: the actor of theta as lhw_env_rollout reads it (the bracket's [in][out]

@@ -67,31 +67,64 @@ def sources():
 EXTRA_FLAGS = {"lhw_humanoid.hip": ["-mllvm", "-disable-machine-licm"], "lhw_humanoid_rollout.hip": ["-mllvm", "-disable-machine-licm"]}
 
 
+def _stale(deps) -> bool:
+    return not os.path.exists(LIB_PATH) or any(os.path.getmtime(LIB_PATH) < os.path.getmtime(d) for d in deps)
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
-    """Compile liblhw.so for gfx950 in-tree (hipcc cross-compiles without a GPU): one object per source, in parallel, then link."""
+    """Compile liblhw.so for gfx950 in-tree (hipcc cross-compiles without a GPU): one object per source, in parallel, then link.
+    Safe under concurrent callers (the ranks of a torch.distributed.run job that all find the library stale): an exclusive file lock
+    serialises them and the staleness test is repeated once the lock is held; objects and the library are written under per-process
+    temporary names and renamed into place, so nobody can dlopen a half-written file."""
+    import fcntl
     srcs = sources()
     deps = srcs + glob.glob(os.path.join(_HERE, "csrc", "*.h")) + glob.glob(os.path.join(_ROOT, "include", "*.h")) + [os.path.abspath(__file__)]
-    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
+    if not force and not _stale(deps):
         return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     objdir = os.path.join(_HERE, "build")
     os.makedirs(objdir, exist_ok=True)
-    base = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
-    procs, objs = [], []
-    for s in srcs:
-        o = os.path.join(objdir, os.path.basename(s) + ".o")
-        objs.append(o)
-        cmd = base + EXTRA_FLAGS.get(os.path.basename(s), []) + ["-c", s, "-o", o]
-        if verbose:
-            print(" ".join(cmd))
-        procs.append((cmd, subprocess.Popen(cmd)))
-    for cmd, p in procs:
-        if p.wait() != 0:
-            raise subprocess.CalledProcessError(p.returncode, cmd)
-    cmd = base + ["-shared", "-o", LIB_PATH] + objs
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
+    with open(os.path.join(objdir, ".lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if not force and not _stale(deps):      # another process built it while this one waited
+            return LIB_PATH
+        base = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
+        tag = f".{os.getpid()}.tmp"
+        procs, objs, tmps = [], [], []
+        try:
+            for s in srcs:
+                o = os.path.join(objdir, os.path.basename(s) + ".o")
+                objs.append(o)
+                tmps.append(o + tag)
+                cmd = base + EXTRA_FLAGS.get(os.path.basename(s), []) + ["-c", s, "-o", o + tag]
+                if verbose:
+                    print(" ".join(cmd))
+                procs.append((cmd, subprocess.Popen(cmd)))
+            failed = None
+            for cmd, p in procs:
+                if p.wait() != 0 and failed is None:
+                    failed = (p.returncode, cmd)
+                    for _, q in procs:          # one source failed: stop the others instead of leaving them running
+                        if q.poll() is None:
+                            q.terminate()
+            if failed:
+                raise subprocess.CalledProcessError(*failed)
+            for o in objs:
+                os.replace(o + tag, o)
+            cmd = base + ["-shared", "-o", LIB_PATH + tag] + objs
+            tmps.append(LIB_PATH + tag)
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.check_call(cmd)
+            os.replace(LIB_PATH + tag, LIB_PATH)
+        finally:
+            for _, q in procs:
+                if q.poll() is None:
+                    q.kill()
+                q.wait()
+            for t in tmps:
+                if os.path.exists(t):
+                    os.remove(t)
     return LIB_PATH
 
 

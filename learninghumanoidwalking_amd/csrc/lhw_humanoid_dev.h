@@ -1753,11 +1753,16 @@ __device__ void fwd_collision(const HModel& m, const HParams& p, L& S, int lane,
   if (big) { k.gd = bd; k.gi = bi; k.key = pkey; }
   if constexpr (!BOXBOX) {
     if (m.npb > 0) {   // the corner lanes write: slot = their pair's base (read off the pair's lane) + rank
-      int bq = 0;
+      // (and only as many as the pair's lane reserved: 0 if the broad phase dropped the pair, so a corner lane can never write into
+      // the slots of the next pair even if its own test and the pair lane's ever disagreed)
+      int bq = 0, nq = 0;
 #pragma unroll
       for (int jj = 0; jj < 4; jj++)
-        if (jj < m.npb) { const int bj = gbcast_i<L::W_>(base, m.pb_pair[jj]); if (cj == jj) bq = bj; }
-      if (cemit) {
+        if (jj < m.npb) {
+          const int bj = gbcast_i<L::W_>(base, m.pb_pair[jj]), nj = gbcast_i<L::W_>(mine, m.pb_pair[jj]);
+          if (cj == jj) { bq = bj; nq = nj; }
+        }
+      if (cemit && crank < nq) {
         const double zero[3] = {0, 0, 0};
         ConSink<L> kc{&S, bq, crank, 1, cg1, cg2, cq};
         kc.emit(cdist, cpos, cnn, zero);
@@ -1824,7 +1829,10 @@ __device__ void fwd_collision(const HModel& m, const HParams& p, L& S, int lane,
             bool same = mirror || dex == dc;
             for (int a = 0; a < 3; a++) {
               const double pe = bd[AR_POS + 3 * e + a];
-              same = same && (mirror ? fabs(pe - pc[a]) <= 1e-15 : pe == pc[a]);
+              // (the two narrow phases agree to 1-2 ulp of the coordinate: an absolute floor for coordinates near zero, which are sums
+              // of terms of order 0.1, and a relative part so that the copies still merge metres away from the origin -- one ulp
+              // at |x| >= 4 m is 0.9e-15)
+              same = same && (mirror ? fabs(pe - pc[a]) <= 1e-15 + 4e-16 * fabs(pc[a]) : pe == pc[a]);
             }
             for (int a = 0; a < 9; a++) {
               const double fe = bd[AR_FRAME + 9 * e + a];

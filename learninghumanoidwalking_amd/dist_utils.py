@@ -63,14 +63,47 @@ def global_batch_moments(x: torch.Tensor):
     return mean, var, float(cnt)
 
 
+# bench.py: when a list, every gradient all-reduce is bracketed by two events on the current stream and appended here
+allreduce_events = None
+
+
 def allreduce_grad_(flat_grad: torch.Tensor) -> float:
     """Sum-all-reduce the flat gradient in place; returns the scale (1/world) that turns the sum of per-rank
     mean-gradients into the mean over the global minibatch."""
     d = dist()
     if _active(d):
-        d.all_reduce(flat_grad)
+        if allreduce_events is not None and flat_grad.is_cuda:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            d.all_reduce(flat_grad)
+            e1.record()
+            allreduce_events.append((e0, e1))
+        else:
+            d.all_reduce(flat_grad)
         return 1.0 / d.get_world_size()
     return 1.0
+
+
+def relaunch_under_torchrun(n_procs: int, script: str, argv: list) -> int:
+    """Fan-out is the entry point's job (the reference's PPO starts its own Ray workers, rl/algos/ppo.py:215-297): a plain
+    `python <script> --gpus N` with N > 1 and no launcher environment re-executes itself as N ranks on this node under
+    torch.distributed.run (one process per GPU, rendezvous on 127.0.0.1 at a free port) and returns the launcher's exit code."""
+    import socket
+    import subprocess
+    import sys
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={int(n_procs)}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), script] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
+def launched() -> bool:
+    """True inside a torch.distributed.run / torchrun worker (RANK and WORLD_SIZE are set by the launcher)."""
+    return "WORLD_SIZE" in os.environ and "RANK" in os.environ
 
 
 def shard_env_ids(n_envs_per_rank: int, rank: int) -> int:

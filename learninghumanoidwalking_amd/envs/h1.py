@@ -101,10 +101,13 @@ class H1Spec:
             m.arrays["body_mass"][m.body_id("pelvis")] = 8.89
             m.arrays["body_mass"][m.body_id("torso_link")] = 21.289
             m.totalmass = float(m.arrays["body_mass"].sum())
-            # (a full menagerie H1 keeps its arm links welded to the torso: folded if there are too many.  The pelvis and the leg
-            # bodies are randomised relative to their default mass / inertial offset, so nothing is folded into them; the torso and
-            # the perturbed bodies stay bodies)
-            self._model = fit_stepper_limits(m, 15, keep=("torso_link",) + tuple(getattr(self, "perturb_bodies", ())), protect=("pelvis",))
+            # (a full menagerie H1 keeps its arm links welded to the torso: folded if there are too many; the torso and the
+            # perturbed bodies stay bodies)
+            # randomize_dynamics (domain_randomization.py:44-49) rescales the mass and shifts the inertial offset of the pelvis AND of the
+            # body of every leg joint relative to the default model: none of them may absorb a welded link (a sole plate under an ankle
+            # link would silently change the randomisation base) -- such a link stays a body, and the fit raises if that is one too many
+            rand = ("pelvis",) + tuple(m.body_names[int(m.jnt_bodyid[m.jnt_id(j)])] for j in LEG_JOINTS)
+            self._model = fit_stepper_limits(m, 15, keep=("torso_link",) + tuple(getattr(self, "perturb_bodies", ())), protect=rand)
         return self._model
 
     def mirror_tables(self):

@@ -138,6 +138,8 @@ class PpoKernels:
         return {n: self._view(flat, n).detach().cpu().clone() for n in self.TENSORS}
 
     def set_tensors(self, tensors: dict):
+        # theta changes: a rollout bracket opened on the old weights (its [in][out] copies, the resident rollout's actor view) is void
+        self.end_rollout()
         for n, t in tensors.items():
             self._view(self.theta, n).copy_(torch.as_tensor(t, dtype=torch.float32).reshape(self._view(self.theta, n).shape))
 

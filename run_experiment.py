@@ -2,6 +2,7 @@
 on-device rollout + PPO of this repository.
 
     python run_experiment.py train --env jvrc_walk --logdir /tmp/logs --num-envs 4096 --n-itr 100 --seed 0
+    python run_experiment.py train --env jvrc_walk --gpus 8 ...        (re-executes itself as 8 ranks under torch.distributed.run)
     python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 run_experiment.py train --env jvrc_walk ...
 
 Differences from the reference, by design: no Ray (`--num-procs` is the number of on-device envs per GPU unless
@@ -51,6 +52,8 @@ def build_parser():
     p.add_argument("--yaml", type=str, default=None)
     p.add_argument("--device", type=str, default="auto", choices=["auto", "cpu", "cuda"])
     p.add_argument("--seed", type=int, default=None)
+    p.add_argument("--gpus", type=int, default=1, help="GPUs of this node to train on (data parallel: envs sharded, gradients all-reduced over RCCL); "
+                                                        "N > 1 outside a torch.distributed.run launcher re-executes this command as N ranks")
     return p
 
 
@@ -99,4 +102,8 @@ if __name__ == "__main__":
         raise SystemExit("`eval` (GL viewer / video on CPU MuJoCo) is outside the hot path of this repository; "
                          "use the reference's run_experiment.py eval")
     sys.argv.remove("train")
-    run_experiment(build_parser().parse_args())
+    args = build_parser().parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        from learninghumanoidwalking_amd.dist_utils import relaunch_under_torchrun
+        raise SystemExit(relaunch_under_torchrun(args.gpus, os.path.abspath(__file__), ["train"] + sys.argv[1:]))
+    run_experiment(args)
