@@ -117,9 +117,15 @@ class BatchedEnv:
         except Exception:
             pass
 
-    def reset(self, mask: torch.Tensor | None = None) -> torch.Tensor:
+    def reset(self, mask: torch.Tensor | None = None, obs_out: torch.Tensor | None = None) -> torch.Tensor:
+        """Reset the envs whose mask byte is non-zero (None: all).  The first observation of the reset envs goes to `obs_out`
+        ([N, obs_dim], rows of the other envs untouched) or, by default, to self.obs."""
         if mask is not None:
             assert mask.dtype == torch.uint8 and mask.is_cuda and mask.numel() == self.n_envs
+        if obs_out is not None and self.history_len == 1:
+            assert obs_out.is_cuda and obs_out.dtype == torch.float32 and obs_out.is_contiguous() and obs_out.shape == self.obs.shape
+            _lib.check(self._L.lhw_env_reset(self._h, _ptr(mask), _ptr(obs_out), _stream_ptr(self.device)))
+            return obs_out
         if self.history_len > 1:
             _lib.check(self._L.lhw_env_reset(self._h, _ptr(mask), _ptr(self._base), _stream_ptr(self.device)))
             sel = slice(None) if mask is None else mask.bool()

@@ -30,7 +30,7 @@
 #define PH 256      // hidden width of the actor (rl/policies/actor.py:127)
 #define PKQ 32      // the read-out is summed as PH / PKQ partial products of PKQ k each (SKQ of lhw_mlp_strip.hip)
 #define PXK 64      // capacity of the padded observation row
-#define PO_MAX 12   // action dims the read-out's lane mapping covers (JVRC 12, H1 10)
+#define PO_MAX 16   // action dims the read-out's lane mapping covers (JVRC 12, H1 10): four column groups of four
 
 struct HRollout {
   int T;                 // control steps of this launch
@@ -46,6 +46,12 @@ struct HRollout {
 };
 
 // One 256-wide ReLU layer for the wave's G rows: hout[r][n] = relu(chain_k fmaf(W^T[k][n], xin[r][k]) + bias[n]), n = 4 wl .. 4 wl + 3.
+// The weight rows of PU consecutive k are requested as one batch of independent 16-byte loads, a batch ahead of the one being
+// multiplied (left to itself the compiler waits for every load right behind its issue -- s_waitcnt vmcnt(0) 293 times per policy
+// step, each a full L2 round trip; the scheduling barriers keep the batches apart, as in slab_mma of lhw_mlp_strip.hip).  Rows
+// k >= K are clamped copies of row K - 1 multiplied by the zeros xin holds there (K is padded to a multiple of 2 PU by the caller's
+// buffer: the observation row is zero beyond its width up to PXK), so the prefetches run past the end unconditionally.
+#define PU 8
 template <int G>
 __device__ __forceinline__ void policy_hidden(const float* __restrict__ wt, const float* __restrict__ bias, const float* xin, const int ldx, const int K,
                                               float* hout, const int wl) {
@@ -55,15 +61,31 @@ __device__ __forceinline__ void policy_hidden(const float* __restrict__ wt, cons
 #pragma unroll
     for (int c = 0; c < 4; c++) acc[r][c] = 0.f;
   const float4* w4 = reinterpret_cast<const float4*>(wt) + wl;
-#pragma unroll 8
-  for (int k = 0; k < K; k++) {
-    const float4 w = w4[(size_t)k * (PH / 4)];
+  float4 wa[PU], wb[PU];
+  auto load = [&](float4 (&w)[PU], const int k0) {
 #pragma unroll
-    for (int r = 0; r < G; r++) {
-      const float x = xin[r * ldx + k];
-      acc[r][0] = fmaf(w.x, x, acc[r][0]); acc[r][1] = fmaf(w.y, x, acc[r][1]);
-      acc[r][2] = fmaf(w.z, x, acc[r][2]); acc[r][3] = fmaf(w.w, x, acc[r][3]);
-    }
+    for (int j = 0; j < PU; j++) w[j] = w4[(size_t)min(k0 + j, K - 1) * (PH / 4)];
+  };
+  auto mul = [&](const float4 (&w)[PU], const int k0) {
+#pragma unroll
+    for (int j = 0; j < PU; j++)
+#pragma unroll
+      for (int r = 0; r < G; r++) {
+        const float x = xin[r * ldx + k0 + j];
+        acc[r][0] = fmaf(w[j].x, x, acc[r][0]); acc[r][1] = fmaf(w[j].y, x, acc[r][1]);
+        acc[r][2] = fmaf(w[j].z, x, acc[r][2]); acc[r][3] = fmaf(w[j].w, x, acc[r][3]);
+      }
+  };
+  load(wa, 0);
+  for (int k0 = 0; k0 < K; k0 += 2 * PU) {
+    load(wb, k0 + PU);
+    __builtin_amdgcn_sched_barrier(0);
+    mul(wa, k0);
+    __builtin_amdgcn_sched_barrier(0);
+    load(wa, k0 + 2 * PU);
+    __builtin_amdgcn_sched_barrier(0);
+    if (k0 + PU < K) mul(wb, k0 + PU);
+    __builtin_amdgcn_sched_barrier(0);
   }
   const float4 b = reinterpret_cast<const float4*>(bias)[wl];
 #pragma unroll
@@ -99,25 +121,30 @@ __device__ __forceinline__ void policy_step(const LhwRolloutPolicy& q, float* sc
 #endif
   policy_hidden<G>(q.w2t, q.b2, h1, PH, PH, h2, wl);
   SYNC();
-  // read-out: lane = (partial q8 of 8, row, column group); CPL columns per lane
-  constexpr int CG = 8 / G, CPL = (PO_MAX + CG - 1) / CG;
-  const int q8 = wl >> 3, r = G == 2 ? ((wl >> 2) & 1) : 0, cg = G == 2 ? (wl & 3) : (wl & 7);
-  float pacc[CPL];
+  // read-out: lane = (partial q8 of 8, row r, column group cg of four output units); with one row per wave the r = 1 lanes repeat
+  // the r = 0 lanes' work and keep it to themselves.  One 16-byte weight load per lane and k (W3^T rows are act_pad floats), PU of
+  // them in flight
+  const int q8 = wl >> 3, r = (wl >> 2) & 1, rr_ = G == 2 ? r : 0, cg = wl & 3;
+  const bool colsin = 4 * cg < Op;      // (act_pad = 12: the fourth column group has no columns)
+  float pacc[4] = {0.f, 0.f, 0.f, 0.f};
+  const float* w3 = q.w3t + (size_t)(q8 * PKQ) * Op + 4 * (colsin ? cg : 0);
+  for (int kk0 = 0; kk0 < PKQ; kk0 += PU) {
+    float4 w[PU];
 #pragma unroll
-  for (int c = 0; c < CPL; c++) pacc[c] = 0.f;
-#pragma unroll 8
-  for (int kk = 0; kk < PKQ; kk++) {
-    const int k = q8 * PKQ + kk;
-    const float h = h2[r * PH + k];
+    for (int j = 0; j < PU; j++) w[j] = *reinterpret_cast<const float4*>(w3 + (size_t)(kk0 + j) * Op);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int c = 0; c < CPL; c++) {
-      const int col = cg * CPL + c;
-      const float wv = q.w3t[(size_t)k * Op + min(col, O - 1)];
-      pacc[c] = fmaf(h, col < O ? wv : 0.f, pacc[c]);
+    for (int j = 0; j < PU; j++) {
+      const float h = h2[rr_ * PH + q8 * PKQ + kk0 + j];
+      pacc[0] = fmaf(h, 4 * cg + 0 < O ? w[j].x : 0.f, pacc[0]); pacc[1] = fmaf(h, 4 * cg + 1 < O ? w[j].y : 0.f, pacc[1]);
+      pacc[2] = fmaf(h, 4 * cg + 2 < O ? w[j].z : 0.f, pacc[2]); pacc[3] = fmaf(h, 4 * cg + 3 < O ? w[j].w : 0.f, pacc[3]);
     }
+    __builtin_amdgcn_sched_barrier(0);
   }
+  if (colsin && (G == 2 || r == 0)) {
 #pragma unroll
-  for (int c = 0; c < CPL; c++) Pp[(q8 * G + r) * 16 + cg * CPL + c] = pacc[c];
+    for (int c = 0; c < 4; c++) Pp[(q8 * G + rr_) * 16 + 4 * cg + c] = pacc[c];
+  }
   SYNC();
   if (wl < 16 * G) {
     const int rr = wl >> 4, col = wl & 15;
@@ -209,7 +236,7 @@ int humanoid_rollout(HumanoidEnv* h, int first, int count, int T, const LhwRollo
                      float* rew, uint8_t* done, float* rew_terms, hipStream_t s) {
   if (first < 0 || count <= 0 || first + count > h->p.n_envs || T <= 0) return -1;
   const int obs_dim = h->p.task == TASK_STEP ? 39 : (h->p.task == TASK_WALK ? 37 : (h->p.task == TASK_H1WALK ? 43 : 35));
-  if (pol->hidden != PH || pol->obs_dim != obs_dim || pol->act_dim != h->m.nu || pol->act_dim > PO_MAX || pol->act_pad < pol->act_dim ||
+  if (pol->hidden != PH || pol->obs_dim != obs_dim || pol->act_dim != h->m.nu || pol->act_pad > PO_MAX || (pol->act_pad & 3) || pol->act_pad < pol->act_dim ||
       pol->obs_pad < obs_dim || pol->obs_pad > PXK || (pol->obs_pad & 3))
     return -2;
   HRollout ro;

@@ -108,8 +108,11 @@ class Rollout:
     bootstrap (not done) * V(s') at episode ends and V(s_T) where the buffer fills mid-episode.
     """
 
-    def __init__(self, env, kernels: PpoKernels, T: int, seed: int = 0):
+    def __init__(self, env, kernels: PpoKernels, T: int, seed: int = 0, task=None, max_traj_len: int | None = None):
         self.env, self.k, self.T, self.seed = env, kernels, int(T), int(seed)
+        # task: a task_hook.VectorTask evaluated OUTSIDE the kernels after every control step; its reward / termination replace
+        # the fused ones and the rollout, not the env, truncates at max_traj_len and resets (see _collect_hooked)
+        self.task, self.max_traj_len = task, int(max_traj_len if max_traj_len is not None else T)
         N, D, A, dev = env.n_envs, env.obs_dim, env.act_dim, env.device
         self.N = N
         self.obs = torch.zeros(T + 1, N, D, dtype=torch.float32, device=dev)
@@ -160,6 +163,55 @@ class Rollout:
         finally:
             k.end_rollout()
 
+    def _collect_hooked(self, deterministic):
+        """Launch-per-step rollout with the TASK outside the kernels (task_hook.py): after each control step the env's exported
+        task inputs go to `self.task.evaluate`, whose reward and termination are stored; truncation at max_traj_len, the episode
+        statistics and the resets (`lhw_env_reset(mask)`: the reset code and random draws of the in-kernel auto-reset) are done
+        here -- RobotBase.step + the episode handling of RolloutWorker.sample (robots/robot_base.py:88-96,
+        rl/workers/rollout_worker.py:150-181) with an exchangeable task."""
+        from .task_hook import device_task_inputs
+        env, k, T, dev = self.env, self.k, self.T, self.obs.device
+        ti = device_task_inputs(env)
+        if not hasattr(self, "_traj_len"):
+            self._traj_len = torch.zeros(self.N, dtype=torch.int32, device=dev)
+            self._ep_ret = torch.zeros(self.N, dtype=torch.float64, device=dev)
+            self._stats = torch.zeros(3, dtype=torch.float64, device=dev)      # sum of returns, sum of lengths, episodes
+            self._scratch_rew = torch.zeros(self.N, dtype=torch.float32, device=dev)
+            self._scratch_done = torch.zeros(self.N, dtype=torch.uint8, device=dev)
+        for t in range(T):
+            k.forward(self.obs[t], seed=self.seed, env_id_base=self.env_base, counter=self.counter, deterministic=deterministic,
+                      want_value=False, want_mu=False, act=self.act[t], logp=self.logp[t])
+            env.step(self.act[t], obs_out=self.obs[t + 1], term_obs_out=self.tob_all[t], rew_out=self._scratch_rew, done_out=self._scratch_done)
+            rew, term = self.task.evaluate(ti)
+            bad = ~torch.isfinite(rew)                 # a diverged env (the kernel has sanitised its state): the episode ends
+            rew = torch.where(bad, torch.zeros_like(rew), rew)
+            term = term.bool() | bad
+            self.rew[t].copy_(rew)
+            self._traj_len += 1
+            self._ep_ret += rew.double()
+            trunc = self._traj_len >= self.max_traj_len
+            self.done[t].copy_(term.to(torch.uint8) | (trunc.to(torch.uint8) << 1))
+            ended = term | trunc
+            if bool(ended.any()):
+                self._stats += torch.stack([(self._ep_ret * ended).sum(), (self._traj_len * ended).sum().double(), ended.sum().double()])
+                self.task.reset(ended)
+                env.reset(ended.to(torch.uint8), obs_out=self.obs[t + 1])      # rows of the other envs are left untouched
+                self._traj_len[ended] = 0
+                self._ep_ret[ended] = 0
+            self.counter += 1
+        self.last_mode = "hooked"
+
+    def pop_episode_stats(self):
+        """(sum of finished-episode returns, sum of their lengths, their number) since the last call -- the env's own counters, or,
+        with a task plugged in, the rollout's (returns in the plugged task's reward)."""
+        if self.task is None:
+            return self.env.pop_episode_stats()
+        if not hasattr(self, "_stats"):
+            return 0.0, 0.0, 0
+        s = self._stats.cpu().numpy()
+        self._stats.zero_()
+        return float(s[0]), float(s[1]), int(s[2])
+
     def _collect_resident(self, deterministic) -> bool:
         """All T control steps in one launch per rollout group, the actor evaluated inside the stepper's wavefronts
         (BatchedEnv.rollout): bitwise the values of the launch-per-step loop below, without its per-control-step barrier across
@@ -183,7 +235,9 @@ class Rollout:
         env, k, T = self.env, self.k, self.T
         G = self.groups
         self.last_mode = "steps"      # which path collected the last rollout (tests, bench line)
-        if self._collect_resident(deterministic):
+        if self.task is not None:
+            self._collect_hooked(deterministic)
+        elif self._collect_resident(deterministic):
             self.last_mode = "resident"
         elif G <= 1:
             for t in range(T):
@@ -261,7 +315,10 @@ class Rollout:
 
 
 class PPO:
-    def __init__(self, env_fn, args, seed=None):
+    def __init__(self, env_fn, args, seed=None, task=None):
+        """`task`: None -- the task fused into the env's kernels (the reference's own) -- or a callable `task(spec, device)`
+        returning a task_hook.VectorTask: reward and termination then come from that object, evaluated outside the kernels on the
+        exported task inputs after every control step (feed-forward policies, humanoid envs; see task_hook.py)."""
         self.seed = seed
         self.gamma, self.lam, self.lr, self.eps = args.gamma, args.lam, args.lr, args.eps
         self.ent_coeff, self.clip = args.entropy_coeff, args.clip
@@ -367,10 +424,14 @@ class PPO:
             self._log("Using running observation normalization (will update during training).")
         env_seed = (seed if seed is not None else int(time.time())) & 0x7FFFFFFF
         self.env_seed = env_seed
-        self.env = spec.make_batched(self.n_proc, seed=env_seed, device=self.device, max_traj_len=self.max_traj_len,
+        if task is not None and self.recurrent:
+            raise NotImplementedError("a plugged-in task needs the feed-forward policies")
+        # (with a task plugged in the env never ends an episode by itself: the rollout truncates and resets, Rollout._collect_hooked)
+        self.env = spec.make_batched(self.n_proc, seed=env_seed, device=self.device, max_traj_len=0 if task is not None else self.max_traj_len,
                                      env_id_base=dist_utils.shard_env_ids(self.n_proc, self.rank))
         self.env.env_id_base = dist_utils.shard_env_ids(self.n_proc, self.rank)
-        self.rollout = Rollout(self.env, self.kernels, self.max_traj_len, seed=env_seed ^ 0x5DEECE66D)
+        self.task = task(spec, self.device) if task is not None else None
+        self.rollout = Rollout(self.env, self.kernels, self.max_traj_len, seed=env_seed ^ 0x5DEECE66D, task=self.task, max_traj_len=self.max_traj_len)
         # --imitate: frozen expert + the env's projector (reference rl/algos/ppo.py:111-122)
         self.base_policy, self.imitation_projector = None, None
         if getattr(args, "imitate", None):
@@ -404,7 +465,7 @@ class PPO:
         ret, adv = self.kernels.gae(ro.rew, ro.val, ro.done, ro.vterm, ro.vfinal, self.gamma, self.lam)
         self._adv, self._ret = adv, ret
         T, N = ro.T, ro.N
-        rs, ls, cnt = self.env.pop_episode_stats()
+        rs, ls, cnt = ro.pop_episode_stats()
         self._ep_stats = dist_utils.global_episode_stats(rs, ls, cnt, device=self.device if _dist() and _dist().get_backend() == 'nccl' else None)
         return BatchData(states=ro.obs[:T].reshape(T * N, -1), actions=ro.act.reshape(T * N, -1),
                          rewards=ro.rew.reshape(T * N, 1), values=ro.val.reshape(T * N, 1), returns=ret.reshape(T * N, 1),

@@ -1,13 +1,13 @@
 #!/bin/bash
 # scripts/build_variant.sh NAME [-D...]: liblhw.so with extra compile flags -> learninghumanoidwalking_amd/variants/liblhw_NAME.so
-# (kernel experiments: run with LHW_LIB=<that file>).  HFLAGS: flags for lhw_humanoid.hip only (default: the product's).
+# (kernel experiments: run with LHW_LIB=<that file>).  HFLAGS: flags for lhw_humanoid.hip / lhw_humanoid_rollout.hip only (default: the product's).
 set -e
 cd "$(dirname "$0")/.."
 NAME=$1; shift
 D=learninghumanoidwalking_amd/variants; mkdir -p $D/obj_$NAME
 C="/opt/rocm/bin/hipcc --offload-arch=gfx950 ${OPT:--O3} -std=c++17 -fPIC -w"
 for f in learninghumanoidwalking_amd/csrc/*.hip; do
-  X=""; [ "$(basename $f)" = lhw_humanoid.hip ] && X="${HFLAGS--mllvm -disable-machine-licm}"
+  X=""; case "$(basename $f)" in lhw_humanoid*.hip) X="${HFLAGS--mllvm -disable-machine-licm}";; esac
   $C $X "$@" -c $f -o $D/obj_$NAME/$(basename $f).o &
 done
 wait

@@ -43,5 +43,12 @@ for r in range(R):
             prior_done = bool((done[:t0, e0] != 0).any()) or r > 0
             print(f"rollout {r} {n}: {int(d.sum())} differ, first at t={t0} env={e0} ({x[tuple(idx[0])]} vs {y[tuple(idx[0])]}), envs {sorted(set(idx[:, 1].tolist()))[:12]}, "
                   f"an episode of that env ended before: {prior_done}; max |diff| {np.nanmax(np.abs(x.astype(np.float64) - y.astype(np.float64)))}")
+            if n == "obs":
+                e = idx[0][1]
+                cols = sorted(set(idx[(idx[:, 0] == t0) & (idx[:, 1] == e)][:, 2].tolist()))
+                print("   columns", cols)
+                print("   steps   ", x[t0, e, cols])
+                print("   resident", y[t0, e, cols])
+                print("   full row steps   ", np.array2string(x[t0, e], precision=4, max_line_width=250))
         else:
             print(f"rollout {r} {n}: equal")
