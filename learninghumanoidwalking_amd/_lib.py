@@ -59,12 +59,19 @@ def sources():
     return sorted(glob.glob(os.path.join(_HERE, "csrc", "*.hip")))
 
 
-# Per-source compile flags.  lhw_humanoid.hip: -disable-machine-licm -- LLVM's machine LICM hoists the materialisation of
-# 64-bit constants (1.0, polynomial coefficients) and of lane-derived addresses out of the 25-sub-step loop, the register
-# allocator then parks them in scratch and every use becomes a scratch reload (one slot holding the constant 1.0 was reloaded
-# 42 times in the round-3 ISA).  Without it: scratch 480 -> 352 B per lane, SGPR spills 438 -> 206, VGPR spills 154 -> 100,
-# control step -5 %.  The GEMM / strip kernels keep the default pipeline.
-EXTRA_FLAGS = {"lhw_humanoid.hip": ["-mllvm", "-disable-machine-licm"], "lhw_humanoid_rollout.hip": ["-mllvm", "-disable-machine-licm"]}
+# Per-source compile flags of the stepper's translation units.
+# -disable-machine-licm: LLVM's machine LICM hoists the materialisation of 64-bit constants (1.0, polynomial coefficients) and of
+# lane-derived addresses out of the 25-sub-step loop, the register allocator then parks them in scratch and every use becomes a
+# scratch reload (one slot holding the constant 1.0 was reloaded 42 times in the round-3 ISA).  Without it: scratch 480 -> 352 B
+# per lane, SGPR spills 438 -> 206, VGPR spills 154 -> 100, control step -5 %.
+# -ffp-contract=on (round 5): hipcc's default, fast, lets the BACKEND fuse a multiply with an add wherever the two end up in one
+# basic block with the right use counts -- a decision that depends on the code around them, so the same control_step source
+# compiled into two kernels (the launch-per-step kernel and the resident rollout kernel) rounded a handful of box-contact
+# expressions differently and the two rollouts differed by 1e-15 in the state after a reset.  With `on` the FRONT END fuses, within a
+# source expression only: the same source gives the same arithmetic in every kernel (measured: same speed, both kernels bitwise
+# equal on all four humanoid tasks).  The GEMM / strip / cartpole kernels keep the default pipeline.
+_STEPPER_FLAGS = ["-mllvm", "-disable-machine-licm", "-ffp-contract=on"]
+EXTRA_FLAGS = {"lhw_humanoid.hip": _STEPPER_FLAGS, "lhw_humanoid_rollout.hip": _STEPPER_FLAGS}
 
 
 def _stale(deps) -> bool:

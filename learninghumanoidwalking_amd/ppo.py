@@ -215,9 +215,16 @@ class Rollout:
     def _collect_resident(self, deterministic) -> bool:
         """All T control steps in one launch per rollout group, the actor evaluated inside the stepper's wavefronts
         (BatchedEnv.rollout): bitwise the values of the launch-per-step loop below, without its per-control-step barrier across
-        the envs of a group.  LHW_ROLLOUT_MODE=steps keeps the launch-per-step pipeline."""
+        the envs of a group.  LHW_ROLLOUT_MODE = auto (default) | resident | steps (the launch-per-step pipeline)."""
         env, k, T = self.env, self.k, self.T
-        if os.environ.get("LHW_ROLLOUT_MODE", "resident") != "resident" or not hasattr(env, "rollout") or not hasattr(k, "rollout_policy"):
+        mode = os.environ.get("LHW_ROLLOUT_MODE", "auto")
+        if mode not in ("auto", "resident") or not hasattr(env, "rollout") or not hasattr(k, "rollout_policy"):
+            return False
+        # Measured, same box, interleaved (profiles/r05_rollout_modes.txt): resident over launch-per-step with two groups --
+        # jvrc_walk @ 4096 +19 % env-steps/s (rollout 0.534 -> 0.430 s), jvrc_step @ 4096 +25 %, h1_walk @ 8192 +4 %, and h1 @ 8192
+        # -4 %: twice as many wavefronts as the chip holds, hardly a re-run, a narrow spread of wave times -- there two whole-chip
+        # launches in flight already backfill each other's tails and the in-wave policy step is the only difference left.
+        if mode == "auto" and getattr(env, "task", None) == 2 and self.N > 4096:      # LHW_TASK_H1_STAND
             return False
         pol = k.rollout_policy(seed=self.seed, counter=self.counter, deterministic=deterministic)
         if pol is None:
