@@ -70,6 +70,40 @@ def static_pmc_executed_fp64(kernel_substr):
     return None
 
 
+def static_pmc_rollout(kernel_substr="humanoid_rollout"):
+    """Per env-step figures of the RESIDENT rollout kernel from the committed rocprofv3 --pmc passes of this round
+    (profiles/r05_jvrc_walk_rollout_pmc_*.csv: jvrc_walk @ 4096 envs, T = 400, one dispatch = one rollout): executed fp64 FLOPs
+    ((2 FMA + MUL + ADD) wave-instructions x active lanes per VALU instruction), VALU instructions, and HBM bytes (2 x FETCH_SIZE +
+    WRITE_SIZE, KB counters; the factor 2 is the gfx950 correction of MI355X_MICROARCH.md for coalesced reads).  Static: the
+    counters need their own rocprofv3 runs (scripts/gpu_r5_profiles.sh), this run does not collect them."""
+    import csv
+    env_steps = 4096 * 400
+    v = {}
+    for name in ("sq", "fetch_size", "write_size"):
+        path = os.path.join(ROOT, "profiles", f"r05_jvrc_walk_rollout_pmc_{name}.csv")
+        if not os.path.exists(path):
+            return None
+        for row in csv.reader(open(path)):
+            if len(row) >= 4 and kernel_substr in row[0]:
+                try:
+                    v[row[1]] = float(row[3])
+                except ValueError:
+                    pass
+    need = ("SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_ADD_F64", "SQ_THREAD_CYCLES_VALU", "SQ_INSTS_VALU", "FETCH_SIZE", "WRITE_SIZE")
+    if not all(k in v for k in need):
+        return None
+    lanes = v["SQ_THREAD_CYCLES_VALU"] / v["SQ_INSTS_VALU"] / 4.0
+    flops = (2 * v["SQ_INSTS_VALU_FMA_F64"] + v["SQ_INSTS_VALU_MUL_F64"] + v["SQ_INSTS_VALU_ADD_F64"]) * lanes
+    out = dict(executed_flops_per_env_step=flops / env_steps, active_lanes_per_valu_instruction=lanes,
+               valu_instructions_per_env_substep=v["SQ_INSTS_VALU"] / env_steps / 25.0,   # (wave-instructions / 2: a wave's instruction serves its two envs)
+               hbm_bytes_per_env_step=(2.0 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024.0 / env_steps,
+               source="profiles/r05_jvrc_walk_rollout_pmc_{sq,fetch_size,write_size}.csv (jvrc_walk @ 4096, T = 400; per dispatch means / 1 638 400 env-steps)")
+    if "SQ_WAVE_CYCLES" in v and "SQ_ACTIVE_INST_VALU" in v and "SQ_WAIT_ANY" in v:
+        out["wave_cycles_issuing_valu"] = v["SQ_ACTIVE_INST_VALU"] / v["SQ_WAVE_CYCLES"]
+        out["wave_cycles_waiting"] = v["SQ_WAIT_ANY"] / v["SQ_WAVE_CYCLES"]
+    return out
+
+
 def update_flops_per_sample_epoch(D, H, A, mirror):
     """Multiply-add FLOPs the update performs per sample and epoch: actor forward + backward on the row (and on its mirrored twin),
     critic forward + backward.  forward = 2 (D H + H H + H O); backward = the weight gradients (the same count) + the activation
@@ -318,6 +352,10 @@ def main():
             frac=(iso_tf if iso_tf is not None else overlapped_tf) / FP64_VALU_PEAK_TFLOPS, traffic=None,
             traffic_note="HBM bytes are not measured by this run (PMC counters need separate rocprofv3 passes); see traffic_static",
             traffic_static=static, executed_static=executed,
+            step_kernel_isolated=dict(kernel=spec.step_kernel_name, avg_launch_ms=isolated_ms, envs_per_launch=N,
+                                      algorithmic_fp64_tflops=iso_tf, algorithmic_fp64_frac=None if iso_tf is None else iso_tf / FP64_VALU_PEAK_TFLOPS,
+                                      note="one control step of the whole batch as ONE launch of the launch-per-step kernel, median of 20 issued one at a "
+                                           "time after the timed region (HIP events on the launch stream)"),
             algorithmic_flops_per_launch=flops_per_env_step * N, algorithmic_bytes_per_launch=bytes_per_env_step * N,
             algorithmic_flops_per_env_step=flops_per_env_step, algorithmic_bytes_per_env_step=bytes_per_env_step,
             avg_launch_ms=isolated_ms if isolated_ms is not None else avg_step_ms, envs_per_launch=N if isolated_ms is not None else NL,
@@ -339,6 +377,36 @@ def main():
                            note="whole batch's algorithmic FLOPs / wall time per control step of the rollout (policy inference included)"),
             hbm=dict(bound="hbm", achieved=achieved_gbs, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved_gbs / HBM_PEAK_GBS,
                      note="secondary: algorithmic bytes / launch span; ~3e-4 of peak by construction"))
+        if resident:
+            # The dominant kernel of the resident mode is the rollout kernel itself: ONE launch = T control steps of all N envs.
+            # Primary figure = what the hardware EXECUTED (fp64 FLOPs by the committed SQ counter pass, scaled by this run's env-steps)
+            # over the launch's measured duration; SURVEY.md 8(d)'s algorithmic estimate (75 kFLOP per env-sub-step, a dense 18 x 18
+            # solver with four Newton iterations: 2.6x what is executed) is reported beside it, not instead of it.
+            launch_ms = float(np.mean(resident_ms))
+            pmc = static_pmc_rollout() if env_name == "jvrc_walk" else None
+            alg_tf = flops_per_env_step * N * T / (launch_ms * 1e-3) / 1e12
+            roofline["kernel"] = spec.step_kernel_name.replace("humanoid_kernel<0, ", "humanoid_rollout_kernel<")
+            roofline["avg_launch_ms"] = launch_ms
+            roofline["envs_per_launch"] = N
+            roofline["control_steps_per_launch"] = T
+            roofline["launch_note"] = ("mean span of lhw_env_rollout (one launch = T control steps of all N envs, policy steps included) over the timed "
+                                       "region, HIP events on its stream: the duration rocprofv3 --kernel-trace reports for humanoid_rollout_kernel "
+                                       "(profiles/r05_jvrc_walk_kernel_stats.csv)")
+            roofline["algorithmic_estimate"] = dict(flops_per_launch=flops_per_env_step * N * T, tflops=alg_tf, frac=alg_tf / FP64_VALU_PEAK_TFLOPS,
+                                                    note="SURVEY.md 8(d): 75 kFLOP per env-sub-step x 25 sub-steps x N x T")
+            roofline["algorithmic_flops_per_launch"] = flops_per_env_step * N * T
+            roofline["algorithmic_bytes_per_launch"] = bytes_per_env_step * N * T
+            if pmc is not None:
+                ex_tf = pmc["executed_flops_per_env_step"] * N * T / (launch_ms * 1e-3) / 1e12
+                roofline["achieved"], roofline["frac"] = ex_tf, ex_tf / FP64_VALU_PEAK_TFLOPS
+                roofline["achieved_note"] = "EXECUTED fp64 FLOPs (committed SQ counters, per env-step x this run's N x T) / measured launch duration"
+                roofline["traffic"] = pmc["hbm_bytes_per_env_step"] * N * T
+                roofline["traffic_note"] = ("HBM bytes per launch from the COMMITTED PMC passes of this round (2 x FETCH_SIZE + WRITE_SIZE per env-step x this run's "
+                                            "N x T), not collected by this run; vs algorithmic_bytes_per_launch: the excess is register-spill write-back")
+                roofline["executed_static"] = pmc
+            else:
+                roofline["achieved"], roofline["frac"] = alg_tf, alg_tf / FP64_VALU_PEAK_TFLOPS
+                roofline["achieved_note"] = "algorithmic estimate (no committed counter pass for this env)"
         L = algo.last_losses
         kk = algo.kernels
         use_mirror = bool(getattr(kk, "use_mirror", False))

@@ -196,6 +196,10 @@ __global__ void __launch_bounds__(64, LHW_WAVES_PER_SIMD) humanoid_rollout_kerne
     float* act_t = ro.act + (size_t)t * N * m.nu;
     policy_step<G>(ro.pol, reinterpret_cast<float*>(SG[0].U), obs_t, act_t, ro.logp + (size_t)t * N, env0, nlive, p.env_id_base + (unsigned)env0,
                    ro.pol.counter + (unsigned)t);
+#ifdef LHW_RO_POLICY2X   // (analysis builds: the policy step twice -- the difference in rollout time is its cost)
+    policy_step<G>(ro.pol, reinterpret_cast<float*>(SG[0].U), obs_t, act_t, ro.logp + (size_t)t * N, env0, nlive, p.env_id_base + (unsigned)env0,
+                   ro.pol.counter + (unsigned)t);
+#endif
     __threadfence();   // the action rows are read back by the lanes of their env's group
     const int wl = fresh_wave_lane();
     const int g = W == 32 ? (wl >> 5) : 0, lane = wl & (W - 1);
