@@ -1672,7 +1672,22 @@ __device__ void fwd_collision(const HModel& m, const HParams& p, L& S, int lane,
       far = dot3(dif, nn) - rb2 > margin + 1e-9;
     } else {
       const double lim = rb1 + rb2 + margin + 1e-9;
-      far = lim > 0 && dot3(dif, dif) > lim * lim;
+      const double dd = dot3(dif, dif);
+      far = lim > 0 && dd > lim * lim;
+      // Spheres and capsules are segments with a radius (a sphere: of length 0): the distance of two segments is at least their
+      // separation along the line of centres, |d| - h1 |a1 . d^| - h2 |a2 . d^|, whatever points the narrow phase ends up with
+      // (they lie on the segments).  The bounding spheres of the leg capsules -- thigh beside thigh, shank under the hip -- always
+      // overlap, so without this the capsule-capsule and sphere-capsule narrow phases (divisions, square roots) ran in both passes
+      // of every sub-step of an upright robot; the separation test is three dot products.  Conservative like the test above
+      // (same slack), so the contacts are the same.  (multiplied through by |d|: far <=> A > 0 and A^2 > R^2 |d|^2, no root)
+      if (!far && (ty1 == G_SPHERE || ty1 == G_CAPSULE) && (ty2 == G_SPHERE || ty2 == G_CAPSULE)) {
+        const double h1 = ty1 == G_CAPSULE ? m.pair_d[PDS * lane + PD_SIZE1 + 1] : 0.0, h2 = ty2 == G_CAPSULE ? m.pair_d[PDS * lane + PD_SIZE2 + 1] : 0.0;
+        const double a1d = S.U[U_GMAT + 9 * g1 + 2] * dif[0] + S.U[U_GMAT + 9 * g1 + 5] * dif[1] + S.U[U_GMAT + 9 * g1 + 8] * dif[2];
+        const double a2d = S.U[U_GMAT + 9 * g2 + 2] * dif[0] + S.U[U_GMAT + 9 * g2 + 5] * dif[1] + S.U[U_GMAT + 9 * g2 + 8] * dif[2];
+        const double A = dd - h1 * fabs(a1d) - h2 * fabs(a2d);
+        const double R = m.pair_d[PDS * lane + PD_SIZE1] + m.pair_d[PDS * lane + PD_SIZE2] + margin + 1e-9;
+        far = A > 0 && (R <= 0 || A * A > R * R * dd);
+      }
     }
     have = !far;
   }
