@@ -2823,6 +2823,25 @@ __device__ __forceinline__ void solve_tail(const HModel& m, const HParams& p, L&
 template <bool BOXBOX, class L>
 __device__ __forceinline__ void substep(const HModel& m, const HParams& p, L* SG0, int flags, long long* st_prof, gtab_d ter, gws_d bd, gws_i bi) {
   constexpr int W = L::W_;
+#if defined(__HIP_DEVICE_COMPILE__) && defined(LHW_SUBSTEP_PRIO)
+  // (Resident rollout kernels only -- lhw_humanoid_rollout.hip defines LHW_SUBSTEP_PRIO.  In the launch-per-step pipeline the
+  // policy launch of one rollout group runs beside the other group's stepper waves and must not queue behind waves that hold a
+  // raised priority: measured there, rollout +6 %.)
+  // The two wavefronts of a SIMD do not share its issue slots evenly: at equal priority the older one wins every arbitration tie.
+  // Over a resident rollout it ran ~12 % ahead of its partner (wave totals clustered at 0.885 and 1.115 of the mean) and left it
+  // to finish alone, with nobody to fill its stalls; within a control-step launch it is the spread between the fast low block
+  // indices and the slow high ones.  The issue priority therefore alternates between the two on a clock BOTH read: bit
+  // LHW_PRIO_SHIFT of the shader clock (a period of a few sub-steps) xor the parity of the wave's slot id in its SIMD
+  // (HW_ID[3:0]), re-evaluated at every sub-step -- at any time one of the two is ahead in line, each for half the time.
+  {
+#ifndef LHW_PRIO_SHIFT
+#define LHW_PRIO_SHIFT 18
+#endif
+    const unsigned hw = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4);   // HW_REG_HW_ID, bits [3:0]: wave slot within the SIMD
+    const unsigned ph = (unsigned)((unsigned long long)clock64() >> LHW_PRIO_SHIFT);
+    if ((hw ^ ph) & 1u) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+  }
+#endif
   long long prof_t;
   { FRESH_GROUP(W, SG0); prof_t = (st_prof && lane == 0) ? (long long)clock64() : 0; fwd_kinematics<BOXBOX>(m, S, lane); PROF_MARK(0); }
   { FRESH_GROUP(W, SG0); fwd_collision<BOXBOX>(m, p, S, lane, ter, bd, bi); PROF_MARK(3); }   // stage A temporaries (geom frames) die with fwd_com

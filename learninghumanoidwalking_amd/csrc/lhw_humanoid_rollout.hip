@@ -24,6 +24,7 @@
 // Here the wave does that itself, at once: both envs have left the LDS working set by then (everything persistent is in the HBM
 // record between control steps), so the wave re-interprets its LDS allocation as the W = 64 layout and runs
 // control_step<0, TASK, 64> for the flagged env with all 64 lanes -- same code, same bits as the second launch.
+#define LHW_SUBSTEP_PRIO 1   // the sub-steps of these kernels alternate the wave's issue priority with its SIMD partner's (substep(), lhw_humanoid_dev.h)
 #include "lhw_humanoid_dev.h"
 #include "lhw_policy.h"
 
@@ -187,6 +188,7 @@ __global__ void __launch_bounds__(64, LHW_WAVES_PER_SIMD) humanoid_rollout_kerne
   const int env0 = lz.env_first + eidx0;
   const int OBS = TASK == TASK_WALK ? 37 : (TASK == TASK_STEP ? 39 : (TASK == TASK_H1WALK ? 43 : 35));
   const size_t N = (size_t)ro.n_total;
+  const long long t_begin = st.wave_cyc ? (long long)clock64() : 0;   // (diagnostic, lhw_env_debug_wave_cycles: the wave's whole rollout)
   for (int t = 0; t < ro.T; t++) {
     GROUP_SYNC(64);
     // what this wave wrote in the previous control step (the observation rows it now reads; after a W = 64 re-run, by other
@@ -224,6 +226,10 @@ __global__ void __launch_bounds__(64, LHW_WAVES_PER_SIMD) humanoid_rollout_kerne
           }
       }
     }
+  }
+  if (st.wave_cyc) {   // overwrites the per-control-step figure control_step left: cycles from this wave's first to its last control step
+    const int wl = fresh_wave_lane();
+    if ((wl & (W - 1)) == 0 && (W == 32 ? (wl >> 5) : 0) < nlive) st.wave_cyc[env0 + (W == 32 ? (wl >> 5) : 0)] = (long long)clock64() - t_begin;
   }
 }
 

@@ -220,12 +220,10 @@ class Rollout:
         mode = os.environ.get("LHW_ROLLOUT_MODE", "auto")
         if mode not in ("auto", "resident") or not hasattr(env, "rollout") or not hasattr(k, "rollout_policy"):
             return False
-        # Measured, same box, interleaved (profiles/r05_rollout_modes.txt): resident over launch-per-step with two groups --
-        # jvrc_walk @ 4096 +19 % env-steps/s (rollout 0.534 -> 0.430 s), jvrc_step @ 4096 +25 %, h1_walk @ 8192 +4 %, and h1 @ 8192
-        # -4 %: twice as many wavefronts as the chip holds, hardly a re-run, a narrow spread of wave times -- there two whole-chip
-        # launches in flight already backfill each other's tails and the in-wave policy step is the only difference left.
-        if mode == "auto" and getattr(env, "task", None) == 2 and self.N > 4096:      # LHW_TASK_H1_STAND
-            return False
+        # Measured, same box, interleaved (profiles/r05_rollout_modes.txt, final kernels): resident over launch-per-step with two groups --
+        # jvrc_walk @ 4096 +25 % env-steps/s (rollout 0.524 -> 0.397 s), jvrc_step @ 4096 +26 %, h1_walk @ 8192 +9 %, h1 @ 8192 +2 %
+        # (twice as many wavefronts as the chip holds and a narrow spread of wave times: there two whole-chip launches in flight
+        # already backfill each other's tails).  So `auto` is resident wherever the library has the kernel.
         pol = k.rollout_policy(seed=self.seed, counter=self.counter, deterministic=deterministic)
         if pol is None:
             return False
