@@ -2831,11 +2831,13 @@ __device__ __forceinline__ void substep(const HModel& m, const HParams& p, L* SG
   // Over a resident rollout it ran ~12 % ahead of its partner (wave totals clustered at 0.885 and 1.115 of the mean) and left it
   // to finish alone, with nobody to fill its stalls; within a control-step launch it is the spread between the fast low block
   // indices and the slow high ones.  The issue priority therefore alternates between the two on a clock BOTH read: bit
-  // LHW_PRIO_SHIFT of the shader clock (a period of a few sub-steps) xor the parity of the wave's slot id in its SIMD
-  // (HW_ID[3:0]), re-evaluated at every sub-step -- at any time one of the two is ahead in line, each for half the time.
+  // LHW_PRIO_SHIFT of the shader clock xor the parity of the wave's slot id in its SIMD (HW_ID[3:0]), re-evaluated at every
+  // sub-step -- at any time one of the two is ahead in line, each for half the time.  Period (profiles/r05_wave_priority.txt,
+  // rollout of jvrc_walk @ 4096): 2^15 / 2^16 ticks (under a sub-step) 0.412 / 0.410 s, 2^18 0.3975, 2^20 0.394, 2^22 .. 2^26
+  // 0.392, 2^28 (a third of the rollout) 0.398; equal priorities 0.425.  2^24 ticks = about eight control steps.
   {
 #ifndef LHW_PRIO_SHIFT
-#define LHW_PRIO_SHIFT 18
+#define LHW_PRIO_SHIFT 24
 #endif
     const unsigned hw = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4);   // HW_REG_HW_ID, bits [3:0]: wave slot within the SIMD
     const unsigned ph = (unsigned)((unsigned long long)clock64() >> LHW_PRIO_SHIFT);
