@@ -9,7 +9,12 @@ For every model (default: the reference's cartpole.xml copy and the two stand-in
   1. compiles the XML with MuJoCo, converts the MjModel with `model_from_mjmodel` (so the oracle runs on MuJoCo's own
      compiled constants: inertias, invweight0, meaninertia, ...) and ALSO compiles it with this repository's MJCF compiler,
      reporting field-by-field differences between the two compiled models;
-  2. resets both sides to a perturbed pose, applies the same random control tape, and steps `mj_step` next to the oracle's
+  2. runs ONE forward pass on both sides from the same state -- the perturbed start pose, and MuJoCo's state at the first step
+     with contacts -- and compares them STAGE BY STAGE in pipeline order (kinematics -> com / cvel -> qM -> bias / passive /
+     actuator forces -> qacc_smooth -> contacts -> efc_J / efc_D / efc_R / efc_aref -> efc_force / qacc): the first stage that
+     differs names the routine to re-check, with the field, index and both values (`stage_report`; self-tested without MuJoCo
+     by tests/test_pin_stage_report.py);
+  2b. resets both sides to a perturbed pose, applies the same random control tape, and steps `mj_step` next to the oracle's
      `orc_step`, reporting the largest |dqpos|, |dqvel|, the first step at which contact counts differ, and the worst
      difference in efc_force / qacc / contact frames on the first step with contacts (where states are still identical);
   3. with --hip, also advances the HIP stepper's state through the C ABI (`lhw_env_set_state` / `lhw_env_step`).
@@ -44,6 +49,100 @@ def compare_models(a, b, rtol=1e-9):
     return bad
 
 
+# ---- per-stage first-difference report -------------------------------------------------------------------------------------
+# The pipeline stages of one mj_forward, in the order MuJoCo runs them, with the mjData fields each one produces.  Both sides are
+# put into the same state, run one forward pass, and are compared stage by stage: the FIRST stage that differs names the routine
+# to re-check (mjc_oracle.c marks the candidates [MJ-recall]); everything downstream of it differs as a consequence.
+STAGES = (
+    ("kinematics (mj_kinematics)", ("xpos", "xmat", "xipos", "ximat", "geom_xpos", "geom_xmat")),
+    ("centre of mass, spatial velocities (mj_comPos, mj_comVel)", ("subtree_com", "cvel")),
+    ("inertia matrix (mj_crb -> qM)", ("M",)),
+    ("bias / passive / actuator forces (mj_rne, mj_passive, mj_fwdActuation)", ("qfrc_bias", "qfrc_passive", "qfrc_actuator")),
+    ("unconstrained acceleration (mj_fwdAcceleration)", ("qacc_smooth",)),
+    ("collision detection (mj_collision): contact count, geoms, dist, pos, frame", ("contacts",)),
+    ("constraint rows (mj_makeConstraint, mj_makeImpedance): efc_J, efc_pos, efc_D / efc_R, efc_aref", ("efc_J", "efc_pos", "efc_D", "efc_R", "efc_aref")),
+    ("constraint solver (mj_solNewton): efc_force, qacc", ("efc_force", "qacc")),
+)
+
+
+class OracleSide:
+    """the float64 oracle (oracle/physics.py: OracleSim) behind the field names of the report"""
+
+    def __init__(self, sim):
+        self.sim = sim
+
+    def field(self, name):
+        sim = self.sim
+        if name == "contacts":
+            return [sim.contact(i) for i in range(sim.ncon)]
+        if name.startswith("efc_"):
+            return sim.efc(name)
+        return np.array(getattr(sim, name), dtype=np.float64)
+
+
+class MujocoSide:
+    """a real mujoco (MjModel, MjData) pair behind the same names"""
+
+    def __init__(self, mjm, mjd):
+        self.m, self.d = mjm, mjd
+
+    def field(self, name):
+        import mujoco
+        m, d = self.m, self.d
+        if name == "contacts":
+            return [dict(dist=float(c.dist), pos=np.array(c.pos), frame=np.array(c.frame).reshape(3, 3), geom1=int(c.geom1), geom2=int(c.geom2))
+                    for c in d.contact[:d.ncon]]
+        if name == "M":
+            M = np.zeros((m.nv, m.nv))
+            mujoco.mj_fullM(m, M, d.qM)
+            return M
+        if name == "efc_J":
+            J = np.array(d.efc_J, dtype=np.float64)
+            return J.reshape(d.nefc, m.nv) if J.size == d.nefc * m.nv else J     # (dense Jacobian; a sparse model needs mj_sparse2dense here)
+        if name in ("xmat", "ximat", "geom_xmat"):
+            return np.array(getattr(d, name), dtype=np.float64).reshape(-1, 9)
+        if name.startswith("efc_"):
+            return np.array(getattr(d, name), dtype=np.float64)[:d.nefc]
+        return np.array(getattr(d, name), dtype=np.float64)
+
+
+def stage_report(a, b, tol=1e-9, names=("mujoco", "oracle")):
+    """Compare two sides stage by stage after a forward pass on the same state.  Returns (first differing stage or None, lines)."""
+    lines, first = [], None
+    for stage, fields in STAGES:
+        worst, detail = 0.0, ""
+        for f in fields:
+            x, y = a.field(f), b.field(f)
+            if f == "contacts":
+                if len(x) != len(y):
+                    worst, detail = float("inf"), f"contact count {len(x)} ({names[0]}) vs {len(y)} ({names[1]})"
+                    break
+                for i, (cx, cy) in enumerate(zip(x, y)):
+                    if (cx["geom1"], cx["geom2"]) != (cy["geom1"], cy["geom2"]):
+                        worst, detail = float("inf"), f"contact {i}: geoms {cx['geom1'], cx['geom2']} vs {cy['geom1'], cy['geom2']} (ordering)"
+                        break
+                    for k in ("dist", "pos", "frame"):
+                        e = float(np.abs(np.asarray(cx[k]) - np.asarray(cy[k])).max())
+                        if e > worst:
+                            worst, detail = e, f"contact {i} (geoms {cx['geom1']}, {cx['geom2']}) {k}"
+                continue
+            x, y = np.asarray(x, dtype=np.float64), np.asarray(y, dtype=np.float64)
+            if x.shape != y.shape:
+                worst, detail = float("inf"), f"{f}: shape {x.shape} vs {y.shape}"
+                break
+            if x.size:
+                scale = 1.0 + float(np.abs(x).max())
+                e = float(np.abs(x - y).max()) / scale
+                if e > worst:
+                    idx = np.unravel_index(int(np.abs(x - y).argmax()), x.shape)
+                    worst, detail = e, f"{f}{list(int(i) for i in idx)}: {x[idx]!r} vs {y[idx]!r}"
+        ok = worst <= tol
+        lines.append(f"   {'ok  ' if ok else 'DIFF'} {stage}: max rel |diff| {worst:.3e}" + ("" if ok else f"  <- {detail}"))
+        if not ok and first is None:
+            first = stage
+    return first, lines
+
+
 def pin_model(xml, steps, tol, seed=0, verbose=True):
     import mujoco
     from learninghumanoidwalking_amd import mjcf
@@ -68,6 +167,14 @@ def pin_model(xml, steps, tol, seed=0, verbose=True):
     worst_q = worst_v = 0.0
     first_ncon_diff = None
     solver_report = None
+    # stage by stage on the start pose (no contacts yet on most models) ...
+    mujoco.mj_forward(mjm, mjd)
+    sim.forward()
+    first_stage, lines = stage_report(MujocoSide(mjm, mjd), OracleSide(sim), tol)
+    if verbose:
+        print("   forward pass on the perturbed start pose, stage by stage:")
+        print("\n".join(lines))
+    staged_contact = False
     for t in range(steps):
         ctrl = rs.normal(size=mjm.nu) * 0.3
         mjd.ctrl[:] = ctrl
@@ -81,6 +188,21 @@ def pin_model(xml, steps, tol, seed=0, verbose=True):
                                  d_efc_aref=float(np.abs(mjd.efc_aref - sim.efc("efc_aref")).max()),
                                  d_efc_D=float(np.abs(mjd.efc_D - sim.efc("efc_D")).max() / (1 + np.abs(mjd.efc_D).max())),
                                  d_qacc=float(np.abs(mjd.qacc - sim.qacc).max()))
+        if not staged_contact and mjd.ncon > 0:
+            # ... and on the first state with contacts: MuJoCo's state copied into the oracle, one forward pass on each side
+            staged_contact = True
+            q, v, w = mjd.qpos.copy(), mjd.qvel.copy(), mjd.qacc_warmstart.copy()
+            keep = (sim.qpos.copy(), sim.qvel.copy(), sim.qacc_warmstart.copy())
+            sim.qpos[:], sim.qvel[:], sim.qacc_warmstart[:] = q, v, w
+            mujoco.mj_forward(mjm, mjd)
+            sim.forward()
+            fs, lines = stage_report(MujocoSide(mjm, mjd), OracleSide(sim), tol)
+            first_stage = first_stage or fs
+            if verbose:
+                print(f"   forward pass on MuJoCo's state after step {t} ({mjd.ncon} contacts), stage by stage:")
+                print("\n".join(lines))
+            sim.qpos[:], sim.qvel[:], sim.qacc_warmstart[:] = keep
+            sim.forward()
         eq, ev = float(np.abs(mjd.qpos - sim.qpos).max()), float(np.abs(mjd.qvel - sim.qvel).max())
         worst_q, worst_v = max(worst_q, eq), max(worst_v, ev)
         if t == 99:
@@ -90,7 +212,8 @@ def pin_model(xml, steps, tol, seed=0, verbose=True):
     if verbose:
         print(f"   {steps} steps: worst |dqpos| {worst_q:.3e} |dqvel| {worst_v:.3e}; first 100 steps {first100[0]:.3e} / {first100[1]:.3e}"
               f"; first contact-count difference {first_ncon_diff}; first constrained step {solver_report}  ->  {'PINNED' if ok else 'DIFFERS'}")
-    return ok, dict(worst_q=worst_q, worst_v=worst_v, first100=first100, ncon_diff=first_ncon_diff, solver=solver_report, model_diffs=diffs)
+    return ok, dict(worst_q=worst_q, worst_v=worst_v, first100=first100, ncon_diff=first_ncon_diff, solver=solver_report, model_diffs=diffs,
+                    first_differing_stage=first_stage)
 
 
 def main():
