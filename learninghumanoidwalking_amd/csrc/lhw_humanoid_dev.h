@@ -2841,7 +2841,10 @@ __device__ __forceinline__ void substep(const HModel& m, const HParams& p, L* SG
 #endif
     const unsigned hw = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4);   // HW_REG_HW_ID, bits [3:0]: wave slot within the SIMD
     const unsigned ph = (unsigned)((unsigned long long)clock64() >> LHW_PRIO_SHIFT);
-    if ((hw ^ ph) & 1u) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+#ifndef LHW_PRIO_LEVEL
+#define LHW_PRIO_LEVEL 1
+#endif
+    if ((hw ^ ph) & 1u) __builtin_amdgcn_s_setprio(LHW_PRIO_LEVEL); else __builtin_amdgcn_s_setprio(0);
   }
 #endif
   long long prof_t;

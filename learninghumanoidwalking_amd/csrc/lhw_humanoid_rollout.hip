@@ -212,6 +212,7 @@ __global__ void __launch_bounds__(64, LHW_WAVES_PER_SIMD) humanoid_rollout_kerne
     bool ovf = false;
     if (g < nlive)
       ovf = control_step<0, TASK, W>(m, p, lz, st, SG, SG[g], env0 + g, lane, act_t, obs_n, tob_t, rew_t, done_t, ro.rew_terms, nullptr, nullptr);
+#ifndef LHW_RO_NO_RERUN   // (analysis builds: without the in-wave re-run, to see what its code costs the hot path -- nothing measurable)
     if constexpr (W == 32) {
       GROUP_SYNC(64);
       const unsigned long long ob = __ballot(ovf);
@@ -226,6 +227,7 @@ __global__ void __launch_bounds__(64, LHW_WAVES_PER_SIMD) humanoid_rollout_kerne
           }
       }
     }
+#endif
   }
   if (st.wave_cyc) {   // overwrites the per-control-step figure control_step left: cycles from this wave's first to its last control step
     const int wl = fresh_wave_lane();
