@@ -1,19 +1,21 @@
 #!/bin/bash
-# Run on the GPU box (via gpurun): bench lines, kernel-trace stats, HBM traffic counters (separate --pmc passes), SQ
-# instruction-mix counters, per-phase cycle breakdown and a training log.  Outputs under gpurun_out/profiles_raw/ (copy the
-# summaries into profiles/ with the round prefix afterwards).  QUICK=1 skips the SQ counter passes and the training run.
+# Run on the GPU box (via gpurun): bench lines of every env, kernel-trace stats of the default bench command, HBM traffic and SQ
+# counter passes of the resident rollout kernel (each --pmc set in its own run), per-phase cycle breakdown, wave-time spread, the
+# update's GEMM / strip micro-benchmarks and a training log.  Outputs under gpurun_out/profiles_raw/ (copy the summaries into
+# profiles/ with the round prefix afterwards).  QUICK=1 skips the counter passes and the training run.
 set -u
 OUT=/root/repo/gpurun_out/profiles_raw
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 B=/root/repo/bench.py
-timeout 300 python $B 2>/dev/null | tail -1 > $OUT/bench_jvrc_walk_1gpu.json
-timeout 200 python $B --env h1 --num-envs 8192 --steps 2 --warmup 1 2>/dev/null | tail -1 > $OUT/bench_h1_8192_1gpu.json
+timeout 300 python $B --steps 20 --warmup 5 2>/dev/null | tail -1 > $OUT/bench_jvrc_walk_1gpu.json
+timeout 200 python $B --env h1 --num-envs 8192 --steps 3 --warmup 1 2>/dev/null | tail -1 > $OUT/bench_h1_8192_1gpu.json
 timeout 100 python $B --env cartpole --steps 3 --warmup 1 2>/dev/null | tail -1 > $OUT/bench_cartpole_1gpu.json
-timeout 200 python $B --env jvrc_step --steps 2 --warmup 1 2>/dev/null | tail -1 > $OUT/bench_jvrc_step_1gpu.json
-timeout 200 python $B --env h1_walk --num-envs 8192 --steps 2 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/bench_h1_walk_8192_1gpu.json
-timeout 200 python $B --env h1 --num-envs 8192 --fp16 --steps 2 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/bench_h1_8192_fp16_1gpu.json
-# per-kernel durations of the default bench command (the control-step kernel's average must agree with the bench line's HIP events)
+timeout 200 python $B --env jvrc_step --steps 3 --warmup 1 2>/dev/null | tail -1 > $OUT/bench_jvrc_step_1gpu.json
+timeout 200 python $B --env h1_walk --num-envs 8192 --steps 3 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/bench_h1_walk_8192_1gpu.json
+timeout 200 python $B --env h1 --num-envs 8192 --fp16 --steps 3 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/bench_h1_8192_fp16_1gpu.json
+LHW_ROLLOUT_MODE=steps timeout 200 python $B --steps 5 --warmup 2 --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/bench_jvrc_walk_1gpu_launch_per_step.json
+# per-kernel durations of the default bench command (the rollout kernel's average must agree with the bench line's HIP events)
 rm -rf /tmp/kt; timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -- python $B --no-cpu-baseline > $OUT/kt.log 2>&1
 cp /tmp/kt/*/*kernel_stats.csv $OUT/jvrc_walk_kernel_stats.csv
 grep '^{' $OUT/kt.log | tail -1 > $OUT/bench_jvrc_walk_under_rocprof.json
@@ -22,22 +24,18 @@ for E in h1 jvrc_step h1_walk; do
   rm -rf /tmp/kt; timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -- python $B --env $E --num-envs $NE --steps 2 --warmup 1 --no-cpu-baseline > /tmp/kt.log 2>&1
   cp /tmp/kt/*/*kernel_stats.csv $OUT/${E}_kernel_stats.csv
 done
-for C in FETCH_SIZE WRITE_SIZE; do
-  rm -rf /tmp/pm; timeout 300 rocprofv3 --pmc $C --output-format csv -d /tmp/pm -- python /root/repo/scripts/step_only.py 4096 6 > /tmp/pm.log 2>&1
-  python /root/repo/scripts/pmc_summary.py /tmp/pm > $OUT/jvrc_walk_step_pmc_$C.csv
-done
 timeout 120 python /root/repo/scripts/jvrc_phase_profile.py 4096 > $OUT/jvrc_walk_phase_cycles.txt 2>/dev/null
+( timeout 100 python /root/repo/scripts/rollout_wave_spread.py jvrc_walk 4096 3; timeout 100 python /root/repo/scripts/rollout_wave_spread.py jvrc_step 4096 1; timeout 100 python /root/repo/scripts/rollout_wave_spread.py h1 8192 1; timeout 100 python /root/repo/scripts/rollout_wave_spread.py h1_walk 8192 1 ) 2>/dev/null | grep -v "^Using" > $OUT/rollout_wave_spread.txt
 timeout 200 python /root/repo/scripts/gemm_bench.py 32768 > $OUT/ppo_gemm_shapes.txt 2>/dev/null
-# MLP strip kernels vs the per-layer GEMM sequence, isolated (one actor minibatch with its mirrored rows; one critic minibatch)
 ( timeout 100 python /root/repo/scripts/strip_bench.py 65536; timeout 100 python /root/repo/scripts/strip_bench.py 32768 ) 2>/dev/null | grep rows > $OUT/ppo_strip_bench.txt
-for C in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_LDS" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_VALU SQ_INSTS_SALU"; do
-  rm -rf /tmp/pm; timeout 200 rocprofv3 --pmc $C --output-format csv -d /tmp/pm -- python /root/repo/scripts/strip_bench.py 65536 > /tmp/pm.log 2>&1
-  python /root/repo/scripts/pmc_summary.py /tmp/pm | grep -E "kernel,|strip" >> $OUT/ppo_strip_pmc.csv
-done
 if [ "${QUICK:-0}" != 1 ]; then
-for C in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_SALU SQ_IFETCH SQ_INSTS_SMEM" "SQC_ICACHE_REQ SQC_ICACHE_MISSES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_FLAT" "SQ_INSTS_VALU SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_INT32 SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU"; do
-  rm -rf /tmp/pm; timeout 300 rocprofv3 --pmc $C --output-format csv -d /tmp/pm -- python /root/repo/scripts/step_only.py 4096 4 > /tmp/pm.log 2>&1
-  python /root/repo/scripts/pmc_summary.py /tmp/pm | grep -E "kernel,|humanoid_kernel<0" >> $OUT/jvrc_walk_step_pmc_sq.csv
+for C in FETCH_SIZE WRITE_SIZE; do
+  rm -rf /tmp/pm; timeout 300 rocprofv3 --pmc $C --output-format csv -d /tmp/pm -- python $B --steps 2 --warmup 1 --no-cpu-baseline > /tmp/pm.log 2>&1
+  python /root/repo/scripts/pmc_summary.py /tmp/pm | grep -E "kernel,|humanoid_rollout" > $OUT/jvrc_walk_rollout_pmc_$C.csv
+done
+for C in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_SALU SQ_IFETCH SQ_INSTS_SMEM" "SQ_INSTS_VALU SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_INT32 SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU"; do
+  rm -rf /tmp/pm; timeout 300 rocprofv3 --pmc $C --output-format csv -d /tmp/pm -- python $B --steps 2 --warmup 1 --no-cpu-baseline > /tmp/pm.log 2>&1
+  python /root/repo/scripts/pmc_summary.py /tmp/pm | grep -E "kernel,|humanoid_rollout" >> $OUT/jvrc_walk_rollout_pmc_sq.csv
 done
 # end-to-end sanity: 100 PPO iterations of jvrc_walk on the stand-in robot (reward / episode length trend)
 rm -rf /tmp/train_log; timeout 600 python /root/repo/run_experiment.py train --env jvrc_walk --num-envs 4096 --minibatch-size 32768 --n-itr 100 --eval-freq 1000 --logdir /tmp/train_log --seed 0 2>&1 | grep -E "Iteration|Mean Eprew|Mean Eplen|fps=|Sampling took|Optimizer took" > $OUT/train_jvrc_walk_100iters.log
