@@ -157,6 +157,8 @@ typedef struct {
   const float *obs_mean, *obs_std;             /* [obs_dim] observation normalisation (actor.obs_mean / obs_std) */
   int32_t obs_dim, obs_pad, act_dim, act_pad, hidden;
   int32_t deterministic;                       /* != 0: act = mean (evaluation) */
+  int32_t fp16_operands;                       /* != 0: weights and activations rounded to fp16 per product, float32 accumulation
+                                                  (lhw_ppo_set_inference_dtype; BASELINE config 5 "fp16 actor / critic") */
   uint64_t seed;                               /* policy-noise key, as lhw_ppo_forward's */
   uint32_t counter;                            /* policy-stream counter of the FIRST control step; step t uses counter + t */
 } LhwRolloutPolicy;
@@ -314,7 +316,10 @@ int lhw_ppo_begin_rollout(LhwPpo* ppo, const float* theta, void* stream);
 int lhw_ppo_end_rollout(LhwPpo* ppo);
 /* Inside a rollout bracket opened with this theta: the actor of theta as lhw_env_rollout reads it (the bracket's [in][out]
  * weight copies, biases and stds inside theta, the caller's normalisation vectors).  Valid until lhw_ppo_end_rollout /
- * lhw_ppo_apply.  LHW_ERR_UNSUPPORTED outside a bracket, with fp16 inference, or for shapes the strip kernels do not cover. */
+ * lhw_ppo_apply.  LHW_ERR_UNSUPPORTED outside a bracket or for shapes the strip kernels do not cover.  With fp16 inference selected
+ * (lhw_ppo_set_inference_dtype) the view asks for fp16 operands: the in-wave policy step then rounds weights and activations to fp16 and
+ * accumulates in float32 over ascending k -- the fp16 MFMA of the launch-per-step path adds its 16 products per instruction in its own
+ * order, so in THAT mode the two rollouts agree to float32 rounding (1e-6), not bitwise. */
 int lhw_ppo_rollout_policy(LhwPpo* ppo, const float* theta, const float* obs_mean, const float* obs_std, uint64_t seed,
                            uint32_t counter, int deterministic, LhwRolloutPolicy* out);
 /* lhw_ppo_forward on workspace rows [ws_row, ws_row + N): calls issued on different streams for disjoint env groups may run

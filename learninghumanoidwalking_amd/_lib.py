@@ -33,7 +33,7 @@ class LhwEnvConfig(ctypes.Structure):
 
 class LhwRolloutPolicy(ctypes.Structure):      # include/lhw.h: the frozen actor as lhw_env_rollout reads it
     _fields_ = [(n, ctypes.c_void_p) for n in ("w1t", "b1", "w2t", "b2", "w3t", "b3", "stdv", "obs_mean", "obs_std")] + [
-        (n, ctypes.c_int32) for n in ("obs_dim", "obs_pad", "act_dim", "act_pad", "hidden", "deterministic")] + [
+        (n, ctypes.c_int32) for n in ("obs_dim", "obs_pad", "act_dim", "act_pad", "hidden", "deterministic", "fp16_operands")] + [
         ("seed", ctypes.c_uint64), ("counter", ctypes.c_uint32)]
 
 

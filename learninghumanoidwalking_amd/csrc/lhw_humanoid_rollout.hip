@@ -53,7 +53,14 @@ struct HRollout {
 // k >= K are clamped copies of row K - 1 multiplied by the zeros xin holds there (K is padded to a multiple of 2 PU by the caller's
 // buffer: the observation row is zero beyond its width up to PXK), so the prefetches run past the end unconditionally.
 #define PU 8
-template <int G>
+// HALF: fp16 operands (BASELINE config 5) -- every weight and every activation is rounded to fp16 before it is multiplied (the product of
+// two fp16 values is exact in float32), the sums stay float32 over ascending k; biases, the ReLU and the read-out's final sum are float32.
+#if defined(__HIP_EMU__)
+__device__ __forceinline__ float r16(float x) { return emu_f16_round(x); }
+#else
+__device__ __forceinline__ float r16(float x) { return (float)(_Float16)x; }
+#endif
+template <int G, bool HALF>
 __device__ __forceinline__ void policy_hidden(const float* __restrict__ wt, const float* __restrict__ bias, const float* xin, const int ldx, const int K,
                                               float* hout, const int wl) {
   float acc[G][4];
@@ -72,9 +79,10 @@ __device__ __forceinline__ void policy_hidden(const float* __restrict__ wt, cons
     for (int j = 0; j < PU; j++)
 #pragma unroll
       for (int r = 0; r < G; r++) {
-        const float x = xin[r * ldx + k0 + j];
-        acc[r][0] = fmaf(w[j].x, x, acc[r][0]); acc[r][1] = fmaf(w[j].y, x, acc[r][1]);
-        acc[r][2] = fmaf(w[j].z, x, acc[r][2]); acc[r][3] = fmaf(w[j].w, x, acc[r][3]);
+        const float x = xin[r * ldx + k0 + j];   // (HALF: rounded when it was stored)
+        const float w0 = HALF ? r16(w[j].x) : w[j].x, w1 = HALF ? r16(w[j].y) : w[j].y, w2 = HALF ? r16(w[j].z) : w[j].z, w3 = HALF ? r16(w[j].w) : w[j].w;
+        acc[r][0] = fmaf(w0, x, acc[r][0]); acc[r][1] = fmaf(w1, x, acc[r][1]);
+        acc[r][2] = fmaf(w2, x, acc[r][2]); acc[r][3] = fmaf(w3, x, acc[r][3]);
       }
   };
   load(wa, 0);
@@ -92,6 +100,7 @@ __device__ __forceinline__ void policy_hidden(const float* __restrict__ wt, cons
 #pragma unroll
   for (int r = 0; r < G; r++) {
     float4 v = make_float4(fmaxf(acc[r][0] + b.x, 0.f), fmaxf(acc[r][1] + b.y, 0.f), fmaxf(acc[r][2] + b.z, 0.f), fmaxf(acc[r][3] + b.w, 0.f));
+    if (HALF) v = make_float4(r16(v.x), r16(v.y), r16(v.z), r16(v.w));   // the next layer's operand
     *reinterpret_cast<float4*>(hout + r * PH + 4 * wl) = v;
   }
 }
@@ -100,7 +109,7 @@ __device__ __forceinline__ void policy_hidden(const float* __restrict__ wt, cons
 template <int G> struct PolicyLds { static constexpr int XS = 0, H1 = XS + G * PXK, H2 = H1 + G * PH, PP = H2 + G * PH, TM = PP + 8 * G * 16, FLOATS = TM + G * 16; };
 
 // Actor forward + Gaussian head for the wave's rows (envs env0 .. env0 + nlive - 1 of this time slice); all 64 lanes take part.
-template <int G>
+template <int G, bool HALF>
 __device__ __forceinline__ void policy_step(const LhwRolloutPolicy& q, float* sc, const float* __restrict__ obs_t, float* __restrict__ act_t,
                                             float* __restrict__ logp_t, const int env0, const int nlive, const unsigned genv0, const unsigned counter) {
   typedef PolicyLds<G> PL;
@@ -112,15 +121,15 @@ __device__ __forceinline__ void policy_step(const LhwRolloutPolicy& q, float* sc
     const int r = i / PXK, k = i - r * PXK;
     float v = 0.f;
     if (k < D && r < nlive) v = (obs_t[(size_t)(env0 + r) * D + k] - q.obs_mean[k]) / q.obs_std[k];
-    xs[i] = v;
+    xs[i] = HALF ? r16(v) : v;
   }
   SYNC();
-  policy_hidden<G>(q.w1t, q.b1, xs, PXK, q.obs_pad, h1, wl);
+  policy_hidden<G, HALF>(q.w1t, q.b1, xs, PXK, q.obs_pad, h1, wl);
   SYNC();
 #ifdef LHW_DBG_POL
   if (wl == 0 && env0 == 0) printf("dbg counter %u xs %g %g %g %g h1 %g %g %g %g w1t %g %g b1 %g\n", counter, xs[0], xs[1], xs[36], xs[37], h1[0], h1[1], h1[2], h1[255], q.w1t[0], q.w1t[1], q.b1[0]);
 #endif
-  policy_hidden<G>(q.w2t, q.b2, h1, PH, PH, h2, wl);
+  policy_hidden<G, HALF>(q.w2t, q.b2, h1, PH, PH, h2, wl);
   SYNC();
   // read-out: lane = (partial q8 of 8, row r, column group cg of four output units); with one row per wave the r = 1 lanes repeat
   // the r = 0 lanes' work and keep it to themselves.  One 16-byte weight load per lane and k (W3^T rows are act_pad floats), PU of
@@ -137,8 +146,9 @@ __device__ __forceinline__ void policy_step(const LhwRolloutPolicy& q, float* sc
 #pragma unroll
     for (int j = 0; j < PU; j++) {
       const float h = h2[rr_ * PH + q8 * PKQ + kk0 + j];
-      pacc[0] = fmaf(h, 4 * cg + 0 < O ? w[j].x : 0.f, pacc[0]); pacc[1] = fmaf(h, 4 * cg + 1 < O ? w[j].y : 0.f, pacc[1]);
-      pacc[2] = fmaf(h, 4 * cg + 2 < O ? w[j].z : 0.f, pacc[2]); pacc[3] = fmaf(h, 4 * cg + 3 < O ? w[j].w : 0.f, pacc[3]);
+      const float w0 = HALF ? r16(w[j].x) : w[j].x, w1 = HALF ? r16(w[j].y) : w[j].y, w2 = HALF ? r16(w[j].z) : w[j].z, w3 = HALF ? r16(w[j].w) : w[j].w;
+      pacc[0] = fmaf(h, 4 * cg + 0 < O ? w0 : 0.f, pacc[0]); pacc[1] = fmaf(h, 4 * cg + 1 < O ? w1 : 0.f, pacc[1]);
+      pacc[2] = fmaf(h, 4 * cg + 2 < O ? w2 : 0.f, pacc[2]); pacc[3] = fmaf(h, 4 * cg + 3 < O ? w3 : 0.f, pacc[3]);
     }
     __builtin_amdgcn_sched_barrier(0);
   }
@@ -196,11 +206,15 @@ __global__ void __launch_bounds__(64, LHW_WAVES_PER_SIMD) humanoid_rollout_kerne
     __threadfence();
     const float* obs_t = ro.obs + (size_t)t * N * OBS;
     float* act_t = ro.act + (size_t)t * N * m.nu;
-    policy_step<G>(ro.pol, reinterpret_cast<float*>(SG[0].U), obs_t, act_t, ro.logp + (size_t)t * N, env0, nlive, p.env_id_base + (unsigned)env0,
-                   ro.pol.counter + (unsigned)t);
+    if (ro.pol.fp16_operands)
+      policy_step<G, true>(ro.pol, reinterpret_cast<float*>(SG[0].U), obs_t, act_t, ro.logp + (size_t)t * N, env0, nlive, p.env_id_base + (unsigned)env0,
+                           ro.pol.counter + (unsigned)t);
+    else
+      policy_step<G, false>(ro.pol, reinterpret_cast<float*>(SG[0].U), obs_t, act_t, ro.logp + (size_t)t * N, env0, nlive, p.env_id_base + (unsigned)env0,
+                            ro.pol.counter + (unsigned)t);
 #ifdef LHW_RO_POLICY2X   // (analysis builds: the policy step twice -- the difference in rollout time is its cost)
-    policy_step<G>(ro.pol, reinterpret_cast<float*>(SG[0].U), obs_t, act_t, ro.logp + (size_t)t * N, env0, nlive, p.env_id_base + (unsigned)env0,
-                   ro.pol.counter + (unsigned)t);
+    policy_step<G, false>(ro.pol, reinterpret_cast<float*>(SG[0].U), obs_t, act_t, ro.logp + (size_t)t * N, env0, nlive, p.env_id_base + (unsigned)env0,
+                          ro.pol.counter + (unsigned)t);
 #endif
     __threadfence();   // the action rows are read back by the lanes of their env's group
     const int wl = fresh_wave_lane();

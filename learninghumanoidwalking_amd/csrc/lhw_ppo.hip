@@ -199,12 +199,14 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(GemmArgs g) {
 
 // Half-precision GEMM (BASELINE config "fp16 actor/critic"): the same tiling, block order, epilogues, split-K and fused column
 // sums as gemm_f32_kernel, with both operands read as float32, rounded to fp16 while they are staged into LDS ([row][k] tiles,
-// k contiguous) and multiplied on the fp16 MFMA (v_mfma_f32_32x32x8_f16) with float32 accumulation; bias / ReLU / mask / outputs
+// k contiguous) and multiplied on the fp16 MFMA (gfx950: v_mfma_f32_32x32x16_f16) with float32 accumulation; bias / ReLU / mask / outputs
 // and the split-K partials stay float32.  Used by the rollout inference (lhw_ppo_set_inference_dtype) and, with
 // lhw_ppo_set_update_dtype, by every GEMM of the update (weights, activations and back-propagated gradients rounded to fp16
 // per GEMM; float32 master weights, loss, Adam).
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 #define HLD (BK + 4)
+static_assert(BK % 16 == 0, "the fp16 GEMM multiplies 16 k per MFMA");
 template <bool A_KC, bool B_KC>
 __global__ void __launch_bounds__(256) gemm_f16_kernel(GemmArgs g) {
   __shared__ _Float16 Ah[2][BM][HLD];
@@ -270,11 +272,15 @@ __global__ void __launch_bounds__(256) gemm_f16_kernel(GemmArgs g) {
       load_tile(rb, g.B, g.ldb, B_KC, n0, g.N, k0 + BK);
     }
     const int am = wm * 32 + (lane & 31), bn = wn * 32 + (lane & 31), kh = lane >> 5;
+    // gfx950's v_mfma_f32_32x32x16_f16: 16 k per instruction (lane l supplies k = 8 (l / 32) .. + 7 of its row / column), twice the
+    // rate of the 32x32x8 form this kernel used through round 4.  (Two 8-byte LDS reads per operand: the tile rows are 40 bytes apart.)
 #pragma unroll
-    for (int kk = 0; kk < BK / 8; kk++) {
-      const f16x4 a = *reinterpret_cast<const f16x4*>(&Ah[cur][am][kk * 8 + kh * 4]);
-      const f16x4 b = *reinterpret_cast<const f16x4*>(&Bh[cur][bn][kk * 8 + kh * 4]);
-      acc = __builtin_amdgcn_mfma_f32_32x32x8f16(a, b, acc, 0, 0, 0);
+    for (int kk = 0; kk < BK / 16; kk++) {
+      const f16x4 a0 = *reinterpret_cast<const f16x4*>(&Ah[cur][am][kk * 16 + kh * 8]), a1 = *reinterpret_cast<const f16x4*>(&Ah[cur][am][kk * 16 + kh * 8 + 4]);
+      const f16x4 b0 = *reinterpret_cast<const f16x4*>(&Bh[cur][bn][kk * 16 + kh * 8]), b1 = *reinterpret_cast<const f16x4*>(&Bh[cur][bn][kk * 16 + kh * 8 + 4]);
+      const f16x8 a = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+      const f16x8 b = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc, 0, 0, 0);
     }
     if (want_colsum) {   // thread (m = tid % 64, k group = tid / 64): the rounded entries it would also have multiplied
       const int m = tid & 63, kg = tid >> 6;
@@ -1100,8 +1106,8 @@ extern "C" int lhw_ppo_rollout_policy(LhwPpo* p, const float* theta, const float
   const MlpLayout& La = p->la;
   if (p->roll_theta == nullptr || p->roll_theta != theta || !p->wt_roll)
     return lhw_fail(LHW_ERR_UNSUPPORTED, "lhw_ppo_rollout_policy: no rollout bracket open for this theta (lhw_ppo_begin_rollout)");
-  if (p->infer_half || !mlp_strip_supported(La.H, La.Dp, La.O, La.Op))
-    return lhw_fail(LHW_ERR_UNSUPPORTED, "lhw_ppo_rollout_policy: float32 actor with hidden width 256 only");
+  if (!mlp_strip_supported(La.H, La.Dp, La.O, La.Op))
+    return lhw_fail(LHW_ERR_UNSUPPORTED, "lhw_ppo_rollout_policy: actor with hidden width 256 only");
   const float* th = theta + p->off_actor;
   const float* wt = p->wt_roll;
   out->w1t = wt; out->b1 = th + La.b1;
@@ -1110,6 +1116,7 @@ extern "C" int lhw_ppo_rollout_policy(LhwPpo* p, const float* theta, const float
   out->stdv = theta + p->off_std; out->obs_mean = obs_mean; out->obs_std = obs_std;
   out->obs_dim = p->D; out->obs_pad = La.Dp; out->act_dim = La.O; out->act_pad = La.Op; out->hidden = La.H;
   out->deterministic = deterministic; out->seed = seed; out->counter = counter;
+  out->fp16_operands = p->infer_half ? 1 : 0;
   return LHW_OK;
 }
 

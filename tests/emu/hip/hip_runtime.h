@@ -236,6 +236,29 @@ static inline int __any(int p) { return emu_ballot(p) != 0; }
 static inline int __all(int p) { return emu_ballot(!p) == 0; }
 static inline unsigned long long __ballot(int p) { return emu_ballot(p); }
 
+// float32 -> fp16 -> float32 (round to nearest even), for sources that round operands to fp16 (g++ 11 has no _Float16 on x86-64)
+static inline float emu_f16_round(float x) {
+  uint32_t u;
+  memcpy(&u, &x, 4);
+  const uint32_t sign = u & 0x80000000u;
+  uint32_t a = u & 0x7fffffffu;
+  if (a >= 0x7f800000u) return x;                                   // inf / NaN
+  if (a >= 0x477ff000u) a = 0x7f800000u;                            // >= 65520: rounds to infinity (largest fp16: 65504)
+  else if (a < 0x38800000u) {                                       // below 2^-14: fp16 subnormals, quantum 2^-24
+    float ax;
+    memcpy(&ax, &a, 4);
+    const float y = nearbyintf(ax * 16777216.0f) * (1.0f / 16777216.0f);
+    memcpy(&a, &y, 4);
+  } else {
+    a += 0xfffu + ((a >> 13) & 1u);                                 // 10 mantissa bits survive
+    a &= ~0x1fffu;
+  }
+  a |= sign;
+  float r;
+  memcpy(&r, &a, 4);
+  return r;
+}
+
 // ---- scalar device functions
 static inline int __clz(int v) { return v ? __builtin_clz((unsigned)v) : 32; }
 static inline int __ffs(unsigned v) { return __builtin_ffs((int)v); }

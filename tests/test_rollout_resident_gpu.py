@@ -97,3 +97,24 @@ def test_training_with_the_resident_rollout_ends_with_the_same_weights(monkeypat
         return algo.kernels.theta.clone()
 
     assert torch.equal(run("steps"), run("resident"))
+
+
+def test_fp16_operand_policy_in_the_resident_rollout_matches_the_fp16_mfma_forward(monkeypatch):
+    """BASELINE config 5 (fp16 actor): with fp16 inference selected the in-wave policy step rounds weights and activations to fp16 and
+    accumulates in float32 -- what the launch-per-step path's fp16 MFMA GEMMs do, up to the order in which an MFMA adds its 16
+    products: the means agree to float32 rounding, and the rollout runs resident."""
+    from learninghumanoidwalking_amd.envs import ENVIRONMENTS
+    from learninghumanoidwalking_amd.ppo import PPO
+    monkeypatch.setenv("LHW_ROLLOUT_MODE", "auto")
+    a = _args(64, 8, std=0.3)
+    a.infer_fp16 = True
+    algo = PPO(ENVIRONMENTS["h1"], a, seed=4)
+    algo.sample_parallel_with_workers(deterministic=True)
+    ro = algo.rollout
+    assert ro.last_mode == "resident"
+    mu, _, _, _ = algo.kernels.forward(ro.obs[0], deterministic=True, want_value=False)       # fp16-operand MFMA GEMMs
+    assert torch.isfinite(ro.act).all()
+    np.testing.assert_allclose(ro.act[0].cpu().numpy(), mu.cpu().numpy(), rtol=0, atol=2e-5)
+    algo.kernels.set_inference_fp16(False)
+    mu32, _, _, _ = algo.kernels.forward(ro.obs[0], deterministic=True, want_value=False)
+    assert (ro.act[0] - mu32).abs().max() > 1e-6          # and they are not the float32 means
