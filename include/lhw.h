@@ -246,6 +246,12 @@ int lhw_env_pop_rerun_count(LhwEnv* env, int64_t* reruns);
 int lhw_debug_gemm(int32_t a_kc, int32_t b_kc, int32_t wt, int32_t M, int32_t N, int32_t K, const float* A, int32_t lda, const float* B,
                    int32_t ldb, float* C, int32_t ldc, const float* bias, int32_t relu, const float* mask, int32_t ldmask,
                    int32_t k_chunk, float* part, float* colsum, float* colsum_out, void* stream);
+/* Test hook for the fused skinny weight gradients of the update (csrc/lhw_ppo.hip: wgrad_skinny_kernel; reference
+ * /root/reference/rl/algos/ppo.py:387-396, the first- and last-layer parts of loss.backward()): dW1 [H][Dp] += dh1^T x, db1 += colsum(dh1),
+ * dW3 [O][H] += dy^T h2, db3 += colsum(dy) over R rows in one launch.  H = 256, Dp <= 64 (multiple of 4), O <= Op <= 32; device buffers;
+ * scratch: ceil(R / max(128, ceil(R / 256))) x (256 Dp + 256 + 256 O + O) floats. */
+int lhw_debug_wgrad_skinny(int32_t H, int32_t Dp, int32_t O, int32_t Op, const float* dh1, const float* x, int32_t ldx, const float* dy,
+                           const float* h2, int32_t R, float* dW1, float* db1, float* dW3, float* db3, float* scratch, void* stream);
 /* Test hooks for the LDS-resident strip kernels of the update's MLPs (csrc/lhw_mlp_strip.hip; reference:
  * /root/reference/rl/algos/ppo.py:299-406, the actor / critic forward and the activation gradients of loss.backward()):
  * forward  h1 = relu(x W1^T + b1), h2 = relu(h1 W2^T + b2), y = h2 W3^T + b3 for R rows in one launch;

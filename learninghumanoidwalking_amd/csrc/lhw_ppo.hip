@@ -389,6 +389,129 @@ static void launch_reduce_segments(const SegList& L, hipStream_t s) {
   hipLaunchKernelGGL(reduce_segments_kernel, dim3(L.first[L.n] / 64), dim3(256), 0, s, L);
 }
 
+// The two SKINNY weight gradients of one network in one K-streaming launch (round 5):
+//   dW1 [H][Dp] = dh1^T x,  db1 = colsum(dh1),   dW3 [O][H] = dy^T h2,  db3 = colsum(dy)        (H = 256, Dp <= 64, O <= 32)
+// Both contract over the minibatch rows and are bound by streaming one [R][256] activation array each (dh1, h2); as two 64 x 64-tile
+// split-K GEMMs with 128-row slices they ran at 1.3 TB/s (23 + 26 us per 32768 rows: a thousand short blocks, prologue and epilogue
+// per 128 rows).  Here a block of 8 waves takes `kc` consecutive rows and keeps BOTH products' whole outputs in registers -- wave w
+// owns rows 32 w .. 32 w + 31 of dW1 (two 32 x 32 MFMA tiles across the padded Dp) and columns 32 w .. + 31 of dW3 (one tile) --
+// while the rows stream through double-buffered LDS tiles in their row-major order ([r][256]: lane = column, the MFMA's operand
+// layout for a product that contracts over r).  Partials per block: 256 x Dp + O x 256 + 256 + O floats, reduced in slice order by
+// reduce_segments like every other weight gradient (same seed -> same bits).
+struct WgradSkinnyArgs {
+  const float *dh1, *x, *dy, *h2;   // [R][256], [R][ldx], [R][Op], [R][256]
+  int ldx, Dp, O, Op, R, kc;
+  float *pw1, *pb1, *pw3, *pb3;     // slice z: pw1 + z * 256 * Dp, pb1 + z * 256, pw3 + z * O * 256, pb3 + z * O
+};
+#define WS_KS 16
+#define WS_H 256
+__global__ void __launch_bounds__(512) wgrad_skinny_kernel(WgradSkinnyArgs g) {
+  __shared__ float Dh[2][WS_KS][WS_H + 4];
+  LHW_LDS_POISON(Dh);
+  __shared__ float Hs[2][WS_KS][WS_H + 4];
+  LHW_LDS_POISON(Hs);
+  __shared__ float Xs[2][WS_KS][64 + 4];
+  LHW_LDS_POISON(Xs);
+  __shared__ float Ys[2][WS_KS][32 + 4];
+  LHW_LDS_POISON(Ys);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, kh = lane >> 5;
+  const int bz = (int)blockIdx.x, kbeg = bz * g.kc, kend = min(g.R, kbeg + g.kc);
+  f32x16 a1[2], a3;
+  for (int r = 0; r < 16; r++) { a1[0][r] = 0.f; a1[1][r] = 0.f; a3[r] = 0.f; }
+  float4 rd[2], rh[2], rx, ry;
+  auto load = [&](int k0) {
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+      const int idx = tid + 512 * q, row = idx >> 6, c4 = idx & 63, k = k0 + row;
+      rd[q] = rh[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (k < kend) {
+        rd[q] = *reinterpret_cast<const float4*>(g.dh1 + (size_t)k * WS_H + 4 * c4);
+        rh[q] = *reinterpret_cast<const float4*>(g.h2 + (size_t)k * WS_H + 4 * c4);
+      }
+    }
+    rx = ry = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (tid < 256) {
+      const int row = tid >> 4, c4 = tid & 15, k = k0 + row;
+      if (k < kend && 4 * c4 < g.Dp) rx = *reinterpret_cast<const float4*>(g.x + (size_t)k * g.ldx + 4 * c4);   // (Dp is a multiple of 4)
+    } else if (tid < 384) {
+      const int row = (tid - 256) >> 3, c4 = (tid - 256) & 7, k = k0 + row;
+      if (k < kend && 4 * c4 < g.Op) {
+        ry = *reinterpret_cast<const float4*>(g.dy + (size_t)k * g.Op + 4 * c4);
+        if (4 * c4 + 1 >= g.O) ry.y = 0.f;
+        if (4 * c4 + 2 >= g.O) ry.z = 0.f;
+        if (4 * c4 + 3 >= g.O) ry.w = 0.f;
+        if (4 * c4 >= g.O) ry.x = 0.f;
+      }
+    }
+  };
+  auto store = [&](int buf) {
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+      const int idx = tid + 512 * q, row = idx >> 6, c4 = idx & 63;
+      *reinterpret_cast<float4*>(&Dh[buf][row][4 * c4]) = rd[q];
+      *reinterpret_cast<float4*>(&Hs[buf][row][4 * c4]) = rh[q];
+    }
+    if (tid < 256) *reinterpret_cast<float4*>(&Xs[buf][tid >> 4][4 * (tid & 15)]) = rx;
+    else if (tid < 384) *reinterpret_cast<float4*>(&Ys[buf][(tid - 256) >> 3][4 * ((tid - 256) & 7)]) = ry;
+  };
+  float cs1 = 0.f, cs3 = 0.f;   // thread (m = tid % 256, k group = tid / 256): column sum of dh1; thread t < 32: column sum of dy
+  int cur = 0;
+  if (kbeg < kend) { load(kbeg); store(0); }
+  __syncthreads();
+  for (int k0 = kbeg; k0 < kend; k0 += WS_KS) {
+    const bool more = k0 + WS_KS < kend;
+    if (more) load(k0 + WS_KS);
+#pragma unroll
+    for (int kk = 0; kk < WS_KS / 2; kk++) {
+      const int k = kk * 2 + kh;
+      const float ad = Dh[cur][k][32 * wave + l31], bx0 = Xs[cur][k][l31], bx1 = Xs[cur][k][32 + l31];
+      const float ay = Ys[cur][k][l31], bh = Hs[cur][k][32 * wave + l31];
+      a1[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ad, bx0, a1[0], 0, 0, 0);
+      a1[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ad, bx1, a1[1], 0, 0, 0);
+      a3 = __builtin_amdgcn_mfma_f32_32x32x2f32(ay, bh, a3, 0, 0, 0);
+    }
+    {
+      const int m = tid & 255, kg = tid >> 8;
+#pragma unroll
+      for (int q = 0; q < WS_KS / 2; q++) cs1 += Dh[cur][kg * (WS_KS / 2) + q][m];
+      if (tid < 32) {
+#pragma unroll
+        for (int q = 0; q < WS_KS; q++) cs3 += Ys[cur][q][tid];
+      }
+    }
+    if (more) store(cur ^ 1);
+    __syncthreads();
+    cur ^= 1;
+  }
+  // epilogue; C/D map of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+  float* pw1 = g.pw1 + (size_t)bz * WS_H * g.Dp;
+  float* pw3 = g.pw3 + (size_t)bz * g.O * WS_H;
+#pragma unroll
+  for (int r = 0; r < 16; r++) {
+    const int rr = (r & 3) + 8 * (r >> 2) + 4 * kh;
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      const int col = 32 * j + l31;
+      if (col < g.Dp) pw1[(size_t)(32 * wave + rr) * g.Dp + col] = a1[j][r];
+    }
+    if (rr < g.O) pw3[(size_t)rr * WS_H + 32 * wave + l31] = a3[r];
+  }
+  float* red = &Dh[0][0][0];   // (the tiles are idle: the loop ended with a barrier)
+  red[tid] = cs1;
+  __syncthreads();
+  if (tid < 256) g.pb1[(size_t)bz * WS_H + tid] = red[tid] + red[256 + tid];
+  if (tid < g.O) g.pb3[(size_t)bz * g.O + tid] = cs3;
+}
+static bool fused_skinny_on() {   // LHW_WGRAD_FUSED=0: the two split-K GEMMs instead (A/B measurements)
+  static const bool on = !(getenv("LHW_WGRAD_FUSED") && atoi(getenv("LHW_WGRAD_FUSED")) == 0);
+  return on;
+}
+static inline int wgrad_skinny_chunk(int R) {   // rows per block: about 256 blocks per launch, at least the slice length the partial regions are sized for
+  const int kc = ((R + 255) / 256 + WS_KS - 1) / WS_KS * WS_KS;
+  return kc < 128 ? 128 : kc;
+}
+static bool wgrad_skinny_supported(int H, int Dp, int O, int Op) { return H == WS_H && Dp > 0 && Dp <= 64 && (Dp & 3) == 0 && O > 0 && O <= 32 && Op >= O && Op <= 32 && (Op & 3) == 0; }
+
 // defer != 0: split-K partials (and the fused column sums) stay in g.part / g.colsum for a later reduce_segments launch
 template <bool A_KC, bool B_KC>
 static void launch_gemm(const GemmArgs& g, hipStream_t s, int defer = 0, int wt = 0, int half = 0) {
@@ -555,10 +678,13 @@ static void mlp_backward(const MlpLayout& L, const float* theta, const float* x,
     MlpStripBwd a{theta + L.w2, theta + L.w3, dy, h1, h2, L.O, L.Op, R, dh2, dh1};
     mlp_strip_backward(a, s);
   }
+  // The skinny weight gradients dW1 / db1 / dW3 / db3: one K-streaming launch behind the activation gradients (wgrad_skinny_kernel; its
+  // slices are at least KC_SKINNY rows, so they fit the partial regions), or two split-K GEMMs (other widths, fp16 operands)
+  const bool fused_skinny = strip && z.w1 == z.w3 && wgrad_skinny_supported(L.H, L.Dp, L.O, L.Op) && ldx >= L.Dp && !(ldx & 3) && fused_skinny_on();
   // dW3 [O][H] = dy^T h2 ; db3 = colsum(dy)
   g.A = dy; g.lda = L.Op; g.B = h2; g.ldb = L.H; g.M = L.O; g.N = L.H; g.K = R;
   g.part = P.w3 + (size_t)z.w3 * L.O * L.H; g.colsum = P.b3 + (size_t)z.w3 * L.O; g.k_chunk = KC_SKINNY;
-  launch_gemm<false, false>(g, s, 1, 0, half);
+  if (!fused_skinny) launch_gemm<false, false>(g, s, 1, 0, half);
   // dh2 = (dy W3) * (h2 > 0)
   if (!strip) {
     g = GemmArgs{};
@@ -579,6 +705,14 @@ static void mlp_backward(const MlpLayout& L, const float* theta, const float* x,
     launch_gemm<true, false>(g, s, 0, 0, half);
   }
   // dW1 [H][Dp] = dh1^T x ; db1 = colsum(dh1)
+  if (fused_skinny) {
+    const int kc = wgrad_skinny_chunk(R), ns = nsl(R, kc);
+    WgradSkinnyArgs a{dh1, x, dy, h2, ldx, L.Dp, L.O, L.Op, R, kc, P.w1 + (size_t)z.w1 * L.H * L.Dp, P.b1 + (size_t)z.w1 * L.H,
+                      P.w3 + (size_t)z.w3 * L.O * L.H, P.b3 + (size_t)z.w3 * L.O};
+    hipLaunchKernelGGL(wgrad_skinny_kernel, dim3(ns), dim3(512), 0, s, a);
+    z.w3 += ns; z.w2 += nsl(R, KC_WIDE); z.w1 += ns;
+    return;
+  }
   g = GemmArgs{};
   g.A = dh1; g.lda = L.H; g.B = x; g.ldb = ldx; g.M = L.H; g.N = L.Dp; g.K = R;
   g.part = P.w1 + (size_t)z.w1 * L.H * L.Dp; g.colsum = P.b1 + (size_t)z.w1 * L.H; g.k_chunk = KC_SKINNY;
@@ -899,6 +1033,26 @@ extern "C" int lhw_debug_gemm(int32_t a_kc, int32_t b_kc, int32_t wt, int32_t M,
     if (colsum) seg_add(S, colsum, colsum_out, (K + kc - 1) / kc, M, 1, 1);
     launch_reduce_segments(S, s);
   }
+  HIPCHK(hipGetLastError());
+  return LHW_OK;
+}
+
+// Test hook: dW1 / db1 / dW3 / db3 of one network by the fused K-streaming kernel, ADDED to the outputs (scratch: slices x (256 Dp + 256 + 256 O + O) floats)
+extern "C" int lhw_debug_wgrad_skinny(int32_t H, int32_t Dp, int32_t O, int32_t Op, const float* dh1, const float* x, int32_t ldx, const float* dy,
+                                      const float* h2, int32_t R, float* dW1, float* db1, float* dW3, float* db3, float* scratch, void* stream) {
+  if (!dh1 || !x || !dy || !h2 || !dW1 || !db1 || !dW3 || !db3 || !scratch || R <= 0) return lhw_fail(LHW_ERR_ARG, "lhw_debug_wgrad_skinny: bad argument");
+  if (!wgrad_skinny_supported(H, Dp, O, Op) || ldx < Dp || (ldx & 3)) return lhw_fail(LHW_ERR_UNSUPPORTED, "fused skinny weight gradients: hidden 256, Dp <= 64, O <= 32");
+  hipStream_t s = (hipStream_t)stream;
+  const int kc = wgrad_skinny_chunk(R), ns = (R + kc - 1) / kc;
+  WgradSkinnyArgs g{dh1, x, dy, h2, ldx, Dp, O, Op, R, kc, scratch, scratch + (size_t)ns * H * Dp, scratch + (size_t)ns * (H * Dp + H), scratch + (size_t)ns * (H * Dp + H + O * H)};
+  hipLaunchKernelGGL(wgrad_skinny_kernel, dim3(ns), dim3(512), 0, s, g);
+  SegList S;
+  S.n = 0; S.scale = 1.f;
+  seg_add(S, g.pw1, dW1, ns, H, Dp, Dp);
+  seg_add(S, g.pb1, db1, ns, H, 1, 1);
+  seg_add(S, g.pw3, dW3, ns, O, H, H);
+  seg_add(S, g.pb3, db3, ns, O, 1, 1);
+  launch_reduce_segments(S, s);
   HIPCHK(hipGetLastError());
   return LHW_OK;
 }

@@ -47,3 +47,20 @@ for name, flops, fn in cases:
         us = e0.elapsed_time(e1) / 20 * 1e3
         line += f"  wt{wt}: {us:7.1f} us {flops / us / 1e6:6.1f} TF/s"
     print(line)
+
+# the fused skinny weight gradients (dW1 + db1 + dW3 + db3 in one K-streaming launch) against the two split-K GEMMs above
+kc = max(128, (((B + 255) // 256) + 15) // 16 * 16)
+ns = (B + kc - 1) // kc
+scr = torch.zeros(ns * (H * Dp + H + Op * H + Op), device=dev); db3 = torch.zeros(Op, device=dev)
+fn = lambda: L.lhw_debug_wgrad_skinny(H, Dp, Op, Op, p(h), p(x), Dp, p(y), p(h2), B, p(dW1), p(db), p(dW3), p(db3), p(scr), None)
+for _ in range(3):
+    _lib.check(fn())
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(20):
+    fn()
+e1.record()
+torch.cuda.synchronize()
+us = e0.elapsed_time(e1) / 20 * 1e3
+print(f"{'dW1 + dW3 fused (wgrad_skinny) +colsums':40s}  {us:7.1f} us {2.0 * B * H * (Dp + Op) / us / 1e6:6.1f} TF/s   ({2 * B * H * 4 / us / 1e6:.2f} TB/s of activations)")

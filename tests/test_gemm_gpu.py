@@ -115,3 +115,39 @@ def test_fp16_operand_mode_equals_half_rounded_operands(layout, M, N, K):
         ref = h(dY[:, :M]).t() @ h(X)
         assert (C.double() - ref).abs().max().item() < 2e-5 * K ** 0.5 * 4
         assert (bsum.double() - h(dY[:, :M]).sum(0)).abs().max().item() < 2e-5 * K ** 0.5 * 4
+
+
+@pytest.mark.parametrize("R,Dp,O,Op", [(1000, 40, 12, 12), (32768, 40, 12, 12), (4099, 36, 10, 12), (300, 44, 1, 4), (65536, 40, 12, 12)])
+def test_fused_skinny_weight_gradients_match_float64(R, Dp, O, Op):
+    """wgrad_skinny_kernel (csrc/lhw_ppo.hip): dW1 = dh1^T x, db1, dW3 = dy^T h2, db3 of one network in one K-streaming launch
+    (reference rl/algos/ppo.py:387-396: the first / last layer's share of loss.backward()), against float64; ragged row counts,
+    the critic's single output, accumulation into the outputs, run-to-run bitwise determinism."""
+    import torch
+    from learninghumanoidwalking_amd import _lib
+    L = _lib.lib()
+    H = 256
+    g = torch.Generator(device="cuda").manual_seed(R)
+    dh1 = torch.randn(R, H, device="cuda", generator=g) * 0.1
+    h2 = torch.relu(torch.randn(R, H, device="cuda", generator=g))
+    x = torch.randn(R, Dp, device="cuda", generator=g)
+    dy = torch.zeros(R, Op, device="cuda")
+    dy[:, :O] = torch.randn(R, O, device="cuda", generator=g) * 0.01
+    kc = max(128, (((R + 255) // 256) + 15) // 16 * 16)
+    ns = (R + kc - 1) // kc
+    scratch = torch.empty(ns * (H * Dp + H + O * H + O), device="cuda")
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+
+    def run():
+        out = [torch.full((H, Dp), 0.5, device="cuda"), torch.zeros(H, device="cuda"), torch.zeros(O, H, device="cuda"), torch.full((O,), -1.0, device="cuda")]
+        _lib.check(L.lhw_debug_wgrad_skinny(H, Dp, O, Op, p(dh1), p(x), Dp, p(dy), p(h2), R, p(out[0]), p(out[1]), p(out[2]), p(out[3]), p(scratch), None))
+        torch.cuda.synchronize()
+        return out
+
+    a, b = run(), run()
+    for u, v in zip(a, b):
+        assert torch.equal(u, v)
+    d64, x64, y64, h64 = dh1.double(), x.double(), dy[:, :O].double(), h2.double()
+    ref = [d64.t() @ x64 + 0.5, d64.sum(0), y64.t() @ h64, y64.sum(0) - 1.0]
+    for u, r in zip(a, ref):
+        scale = float(r.abs().max()) + 1.0
+        assert float((u.double() - r).abs().max()) < 2e-5 * scale * max(1.0, (R / 32768) ** 0.5)
