@@ -129,7 +129,7 @@ class Rollout:
         # Number of independent env groups pipelined on separate streams (wave-per-env steppers; LHW_ROLLOUT_GROUPS overrides).
         # Two groups: one group's policy launch and the tail of its control-step kernel -- a launch ends with its slowest wave,
         # the chip draining meanwhile -- hide behind the other group's kernel.  Measured on the round-4 kernels
-        # (scripts/gpu_r4_groups.sh, profiles/r04_rollout_groups.txt): jvrc_walk @ 4096 +11-12 % env-steps/s over one group
+        # (profiles/r04_rollout_groups.txt): jvrc_walk @ 4096 +11-12 % env-steps/s over one group
         # (rollout 0.608 -> 0.538 s), h1 @ 4096 +11 %, jvrc_walk @ 2048 / 1024 +4 / +3 %; three or four groups lose badly
         # (jvrc_walk @ 4096: 1.07 s).  (An earlier round had measured one group ahead at 4096 envs, 2.07 vs 1.99 M, on a
         # slower control step and an unfused policy step.)  Small batches keep one group: their launches are latency-bound.

@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 5: resident rollout (lhw_env_rollout) vs the launch-per-step pipeline -- parity tests, then same-box interleaved A/B benches.
+# resident rollout (lhw_env_rollout) vs the launch-per-step pipeline -- parity tests, then same-box interleaved A/B benches.
 # $1 = output tag
 TAG=${1:-r5_resident}; OUT=/root/repo/gpurun_out/$TAG; mkdir -p $OUT
 cd /root/repo
