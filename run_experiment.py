@@ -67,10 +67,16 @@ def run_experiment(args):
         raise SystemExit("this trainer runs on MI355X only: there is no CPU path (use the reference for --device cpu)")
     world = int(os.environ.get("WORLD_SIZE", 1))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    share = os.environ.get("LHW_SHARE_GPU") == "1"     # (tests only: every rank on GPU 0 over gloo, to run the N > 1 path on a 1-GPU box)
+    if share:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if share:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     rank = dist.get_rank() if world > 1 else 0
     if args.env not in ENVIRONMENTS:
         raise SystemExit(f"unknown --env {args.env!r}; available: {sorted(ENVIRONMENTS)}")

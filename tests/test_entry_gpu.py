@@ -171,6 +171,22 @@ def test_bench_gpus_2_as_a_plain_command_launches_its_own_ranks():
     assert dp["allreduce_calls_per_iter"] == d["optimizer_steps_per_iter"] and dp["allreduce_ms_per_step"] > 0
 
 
+def test_run_experiment_gpus_2_launches_its_own_ranks(tmp_path):
+    """`python run_experiment.py train --gpus 2 ...` as a plain command: two ranks (sharing the test box's GPU over gloo), envs sharded
+    by global env id, gradients all-reduced, rank 0 logs and checkpoints -- the reference's entry point starts its own workers too
+    (run_experiment.py:132-133 ray.init, rl/algos/ppo.py:184-193)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env["LHW_SHARE_GPU"] = "1"
+    cmd = [sys.executable, os.path.join(ROOT, "run_experiment.py"), "train", "--env", "jvrc_walk", "--gpus", "2", "--num-envs", "32", "--max-traj-len", "8",
+           "--minibatch-size", "128", "--n-itr", "2", "--eval-freq", "100", "--logdir", str(tmp_path), "--seed", "3"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    assert out.stdout.count("********** Iteration 1 ************") == 1          # rank 0 only
+    assert "Sampling took" in out.stdout and "for 512 steps." in out.stdout      # 2 ranks x 32 envs x 8 control steps
+    runs = [d for d in os.listdir(tmp_path) if d.endswith("_jvrc_walk")]
+    assert len(runs) == 1 and os.path.exists(os.path.join(tmp_path, runs[0], "actor_0.pt"))
+
+
 def test_ppo_imitate_wiring(tmp_path):
     """--imitate: expert checkpoint + env projector are picked up, the imitation loss is reported, and an env without a
     projector raises the reference's error (reference tests/test_imitation.py)."""
