@@ -46,8 +46,8 @@ def static_pmc_traffic(kernel_substr, stem="step"):
 
 def static_pmc_executed_fp64(kernel_substr):
     """fp64 FLOPs one launch of the dominant kernel EXECUTES, from the committed SQ counter pass (profiles/): (2 FMA + MUL + ADD)
-    wave-instructions x the average number of active lanes per VALU instruction (SQ_THREAD_CYCLES_VALU / SQ_INSTS_VALU / 4: the
-    counter advances 4 per lane and instruction).  Static, like the traffic figure; it is what the hardware did, where
+    wave-instructions x the average number of active lanes per VALU instruction (SQ_THREAD_CYCLES_VALU / SQ_INSTS_VALU: the counter
+    advances by the active lanes of each instruction -- profiles/r05_pmc_lane_calibration.txt).  Static, like the traffic figure; it is what the hardware did, where
     `algorithmic_flops_per_env_step` is SURVEY.md 8(d)'s estimate for a dense 18 x 18 solver with four Newton iterations."""
     import csv
     for rnd in ("r04", "r03"):
@@ -63,7 +63,7 @@ def static_pmc_executed_fp64(kernel_substr):
                     pass
         need = ("SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_ADD_F64", "SQ_THREAD_CYCLES_VALU", "SQ_INSTS_VALU")
         if all(k in v for k in need):
-            lanes = v["SQ_THREAD_CYCLES_VALU"] / v["SQ_INSTS_VALU"] / 4.0
+            lanes = v["SQ_THREAD_CYCLES_VALU"] / v["SQ_INSTS_VALU"]      # active lanes per instruction (see static_pmc_rollout: no further / 4)
             return dict(flops_per_launch=(2 * v["SQ_INSTS_VALU_FMA_F64"] + v["SQ_INSTS_VALU_MUL_F64"] + v["SQ_INSTS_VALU_ADD_F64"]) * lanes,
                         active_lanes_per_valu_instruction=lanes, valu_instructions_per_launch=v["SQ_INSTS_VALU"], envs_per_launch=4096,
                         source=f"profiles/{rnd}_jvrc_walk_step_pmc_sq.csv")
@@ -92,7 +92,9 @@ def static_pmc_rollout(kernel_substr="humanoid_rollout"):
     need = ("SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_ADD_F64", "SQ_THREAD_CYCLES_VALU", "SQ_INSTS_VALU", "FETCH_SIZE", "WRITE_SIZE")
     if not all(k in v for k in need):
         return None
-    lanes = v["SQ_THREAD_CYCLES_VALU"] / v["SQ_INSTS_VALU"] / 4.0
+    # SQ_THREAD_CYCLES_VALU advances by the number of ACTIVE LANES per VALU instruction (calibrated on fully active kernels, which read
+    # 64.0: profiles/r05_pmc_lane_calibration.txt) -- rounds 3-4 divided by another 4 and under-reported lanes and executed FLOPs 4x
+    lanes = v["SQ_THREAD_CYCLES_VALU"] / v["SQ_INSTS_VALU"]
     flops = (2 * v["SQ_INSTS_VALU_FMA_F64"] + v["SQ_INSTS_VALU_MUL_F64"] + v["SQ_INSTS_VALU_ADD_F64"]) * lanes
     out = dict(executed_flops_per_env_step=flops / env_steps, active_lanes_per_valu_instruction=lanes,
                valu_instructions_per_env_substep=v["SQ_INSTS_VALU"] / env_steps / 25.0,   # (wave-instructions / 2: a wave's instruction serves its two envs)
@@ -381,7 +383,7 @@ def main():
             # The dominant kernel of the resident mode is the rollout kernel itself: ONE launch = T control steps of all N envs.
             # Primary figure = what the hardware EXECUTED (fp64 FLOPs by the committed SQ counter pass, scaled by this run's env-steps)
             # over the launch's measured duration; SURVEY.md 8(d)'s algorithmic estimate (75 kFLOP per env-sub-step, a dense 18 x 18
-            # solver with four Newton iterations: 2.6x what is executed) is reported beside it, not instead of it.
+            # solver with four Newton iterations: two thirds of what is executed) is reported beside it, not instead of it.
             launch_ms = float(np.mean(resident_ms))
             pmc = static_pmc_rollout() if env_name == "jvrc_walk" else None
             alg_tf = flops_per_env_step * N * T / (launch_ms * 1e-3) / 1e12
