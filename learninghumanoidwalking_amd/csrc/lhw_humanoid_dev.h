@@ -367,6 +367,7 @@ struct HumanoidEnv {
   std::vector<void*> dev_allocs;
   int device;
   bool fast;   // the model fits the two-envs-per-wave kernels (W = 32)
+  unsigned* ro_queue = nullptr;   // job counter + per-group progress words of the resident rollout's queue mode (lhw_humanoid_rollout.hip)
 };
 
 // ------------------------------------------------------------------------------------------------ LDS working set

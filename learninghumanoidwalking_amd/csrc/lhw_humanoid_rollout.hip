@@ -33,6 +33,15 @@
 #define PXK 64      // capacity of the padded observation row
 #define PO_MAX 16   // action dims the read-out's lane mapping covers (JVRC 12, H1 10): four column groups of four
 
+// agent-scope loads / stores of the job queue's progress words (a wave on another XCD wrote them: not through this XCD's L2)
+#if defined(__HIP_EMU__)
+__device__ __forceinline__ unsigned lhw_load_agent(const unsigned* p) { return *p; }
+__device__ __forceinline__ void lhw_store_agent(unsigned* p, unsigned v) { *p = v; }
+#else
+__device__ __forceinline__ unsigned lhw_load_agent(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void lhw_store_agent(unsigned* p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
+#endif
+
 struct HRollout {
   int T;                 // control steps of this launch
   int n_total;           // envs of the batch: row count of one time slice of the buffers below
@@ -43,6 +52,11 @@ struct HRollout {
   float* rew;            // [T][n_total]
   unsigned char* done;   // [T][n_total] LHW_DONE_* flags
   float* rew_terms;      // [n_total][n_terms] of the last control step, nullable
+  // Job queue (nullable = off: wave b of the grid keeps env group b for all T steps).  When the range has more env groups than the
+  // chip has wave slots, a group's rollout is cut into jobs of `chunk` control steps; the resident waves pop jobs from queue[0]
+  // in the order (chunk 0 of every group, chunk 1 of every group, ...), queue[1 + group] counts the group's finished chunks.
+  unsigned* queue;
+  int chunk;
   LhwRolloutPolicy pol;
 };
 
@@ -179,27 +193,28 @@ __device__ __forceinline__ void policy_step(const LhwRolloutPolicy& q, float* sc
   SYNC();
 }
 
+// Control steps [t0, t1) of env group `grp` of the range (the G envs one wave advances together).
 template <int TASK, int W>
-__global__ void __launch_bounds__(64, LHW_WAVES_PER_SIMD) humanoid_rollout_kernel(const HModel* __restrict__ mp, const HParams* __restrict__ pp, HLaunch lz, HState st, HRollout ro) {
+__device__ __forceinline__ void rollout_steps(const HModel& m, const HParams& p, const HLaunch& lz, const HState& st, const HRollout& ro, unsigned char* SGraw, int grp,
+                                              int t0, int t1) {
   using L = typename LayoutOf<TASK, W>::type;
   using L1 = typename LayoutOf<TASK, 64>::type;
   constexpr int G = 64 / W;   // envs per wavefront
-  constexpr size_t LDS_BYTES = sizeof(L) * G > sizeof(L1) ? sizeof(L) * G : sizeof(L1);
-  static_assert(W == 64 || sizeof(L1) <= sizeof(L) * G, "the one-env-per-wave layout must fit the wave's two-env allocation (8 workgroups per CU)");
-  static_assert(L::USIZE_ * 2 - 48 >= PolicyLds<G>::FLOATS, "the policy step's activations must fit the stage region in front of the observation staging");
-  __shared__ __attribute__((aligned(16))) unsigned char SGraw[LDS_BYTES];
-  LHW_LDS_POISON(SGraw);
   L* SG = reinterpret_cast<L*>(SGraw);
-  const HParams& p = *pp;
-  const HModel& m = *mp;
-  const int eidx0 = (int)blockIdx.x * G;
-  if (eidx0 >= lz.env_count) return;
+  const int eidx0 = grp * G;
   const int nlive = min(G, lz.env_count - eidx0);
   const int env0 = lz.env_first + eidx0;
   const int OBS = TASK == TASK_WALK ? 37 : (TASK == TASK_STEP ? 39 : (TASK == TASK_H1WALK ? 43 : 35));
   const size_t N = (size_t)ro.n_total;
-  const long long t_begin = st.wave_cyc ? (long long)clock64() : 0;   // (diagnostic, lhw_env_debug_wave_cycles: the wave's whole rollout)
-  for (int t = 0; t < ro.T; t++) {
+  // (diagnostic, lhw_env_debug_wave_cycles: shader-clock cycles the group's control steps took, summed over the rollout's chunks;
+  //  control_step leaves the last step's own figure in the same word, so the running sum is picked up before the chunk's first step)
+  long long cyc_before = 0;
+  if (st.wave_cyc && t0 > 0) {
+    const int wl = fresh_wave_lane();
+    if ((wl & (W - 1)) == 0 && (W == 32 ? (wl >> 5) : 0) < nlive) cyc_before = st.wave_cyc[env0 + (W == 32 ? (wl >> 5) : 0)];
+  }
+  const long long t_begin = st.wave_cyc ? (long long)clock64() : 0;
+  for (int t = t0; t < t1; t++) {
     GROUP_SYNC(64);
     // what this wave wrote in the previous control step (the observation rows it now reads; after a W = 64 re-run, by other
     // lanes than the ones that read them) is visible
@@ -243,9 +258,52 @@ __global__ void __launch_bounds__(64, LHW_WAVES_PER_SIMD) humanoid_rollout_kerne
     }
 #endif
   }
-  if (st.wave_cyc) {   // overwrites the per-control-step figure control_step left: cycles from this wave's first to its last control step
+  if (st.wave_cyc) {
     const int wl = fresh_wave_lane();
-    if ((wl & (W - 1)) == 0 && (W == 32 ? (wl >> 5) : 0) < nlive) st.wave_cyc[env0 + (W == 32 ? (wl >> 5) : 0)] = (long long)clock64() - t_begin;
+    const int g = W == 32 ? (wl >> 5) : 0;
+    if ((wl & (W - 1)) == 0 && g < nlive) st.wave_cyc[env0 + g] = cyc_before + ((long long)clock64() - t_begin);
+  }
+}
+
+// QUEUE = false: wave b of the grid keeps env group b for all T control steps.
+// QUEUE = true: the grid is the chip's resident set of waves and drains a job list (HRollout::queue) -- a group whose envs are slow
+// (stepping task: the walking mode and the terrain under the feet set the contact count for a whole episode; the waves of one
+// launch spread +-20 % around their mean, and with two groups per wave slot the launch ends 22 % after the mean slot) no longer
+// decides when its slot's NEXT group can start: the slot takes whatever job is next.  Nothing of an env lives in the wave between
+// control steps (control_step reads the HBM record and writes it back), so which wave runs a job does not matter to the bits.
+// A separate instantiation: wrapped into the job loop, the two-envs-per-wave kernels spill 25 more VGPRs and lose 2.8 % (round 5,
+// same box, jvrc_walk @ 4096), and at 8192 envs their waves are within +-2 % of each other anyway (queue +0.1 %).
+template <int TASK, int W, bool QUEUE>
+__global__ void __launch_bounds__(64, LHW_WAVES_PER_SIMD) humanoid_rollout_kernel(const HModel* __restrict__ mp, const HParams* __restrict__ pp, HLaunch lz, HState st, HRollout ro) {
+  using L = typename LayoutOf<TASK, W>::type;
+  using L1 = typename LayoutOf<TASK, 64>::type;
+  constexpr int G = 64 / W;
+  constexpr size_t LDS_BYTES = sizeof(L) * G > sizeof(L1) ? sizeof(L) * G : sizeof(L1);
+  static_assert(W == 64 || sizeof(L1) <= sizeof(L) * G, "the one-env-per-wave layout must fit the wave's two-env allocation (8 workgroups per CU)");
+  static_assert(L::USIZE_ * 2 - 48 >= PolicyLds<G>::FLOATS, "the policy step's activations must fit the stage region in front of the observation staging");
+  __shared__ __attribute__((aligned(16))) unsigned char SGraw[LDS_BYTES];
+  LHW_LDS_POISON(SGraw);
+  const HParams& p = *pp;
+  const HModel& m = *mp;
+  const int n_groups = (lz.env_count + G - 1) / G;
+  if constexpr (!QUEUE) {
+    if ((int)blockIdx.x >= n_groups) return;
+    rollout_steps<TASK, W>(m, p, lz, st, ro, SGraw, (int)blockIdx.x, 0, ro.T);
+  } else {
+    const int n_chunks = (ro.T + ro.chunk - 1) / ro.chunk;
+    for (;;) {
+      unsigned j = 0;
+      if (fresh_wave_lane() == 0) j = atomicAdd(ro.queue, 1u);
+      j = (unsigned)__builtin_amdgcn_readlane((int)j, 0);
+      if (j >= (unsigned)n_groups * (unsigned)n_chunks) break;
+      const int c = (int)(j / (unsigned)n_groups), grp = (int)(j % (unsigned)n_groups);
+      const int t0 = c * ro.chunk, t1 = min(ro.T, t0 + ro.chunk);
+      // the group's previous chunk was popped n_groups - 1 jobs ago by a wave that is running: it ends without waiting for anyone
+      while (lhw_load_agent(ro.queue + 1 + grp) < (unsigned)c) __builtin_amdgcn_s_sleep(32);
+      rollout_steps<TASK, W>(m, p, lz, st, ro, SGraw, grp, t0, t1);
+      __threadfence();   // the group's records, observations and flags of this chunk, before the chunk counts as done
+      if (fresh_wave_lane() == 0) lhw_store_agent(ro.queue + 1 + grp, (unsigned)(c + 1));
+    }
   }
 }
 
@@ -254,8 +312,8 @@ __global__ void __launch_bounds__(64, LHW_WAVES_PER_SIMD) humanoid_rollout_kerne
 #define ROLLOUT_OTHER_TASKS(WIDTH)
 #else
 #define ROLLOUT_OTHER_TASKS(WIDTH)                                                                                                                              \
-  else if (h->p.task == TASK_H1WALK) hipLaunchKernelGGL((humanoid_rollout_kernel<TASK_H1WALK, WIDTH>), grid, dim3(64), 0, s, (const HModel*)h->m_dev, (const HParams*)h->p_dev, lz, h->st, ro); \
-  else hipLaunchKernelGGL((humanoid_rollout_kernel<TASK_STAND, WIDTH>), grid, dim3(64), 0, s, (const HModel*)h->m_dev, (const HParams*)h->p_dev, lz, h->st, ro);
+  else if (h->p.task == TASK_H1WALK) hipLaunchKernelGGL((humanoid_rollout_kernel<TASK_H1WALK, WIDTH, false>), grid, dim3(64), 0, s, (const HModel*)h->m_dev, (const HParams*)h->p_dev, lz, h->st, ro); \
+  else hipLaunchKernelGGL((humanoid_rollout_kernel<TASK_STAND, WIDTH, false>), grid, dim3(64), 0, s, (const HModel*)h->m_dev, (const HParams*)h->p_dev, lz, h->st, ro);
 #endif
 
 int humanoid_rollout(HumanoidEnv* h, int first, int count, int T, const LhwRolloutPolicy* pol, float* obs, float* act, float* logp, float* term_obs,
@@ -269,17 +327,50 @@ int humanoid_rollout(HumanoidEnv* h, int first, int count, int T, const LhwRollo
   ro.T = T; ro.n_total = h->p.n_envs;
   ro.obs = obs; ro.act = act; ro.logp = logp; ro.tob = term_obs; ro.rew = rew; ro.done = done; ro.rew_terms = rew_terms;
   ro.pol = *pol;
+  ro.queue = nullptr; ro.chunk = 0;
   const HLaunch lz{first, count, 0, h->iteration};
+  if (!h->fast && h->p.task != TASK_STEP) return -3;   // a walking / standing model that does not fit the two-envs-per-wave layout (or LHW_ONE_ENV_PER_WAVE): launch-per-step only
+  // Stepping task with more env groups than wave slots: the resident waves share a job queue of `chunk`-step pieces instead of a
+  // group each (humanoid_rollout_kernel<.., QUEUE = true>).  LHW_ROLLOUT_CHUNK: control steps per job (default 10; 0 = one wave per
+  // group whatever the batch).  LHW_ROLLOUT_SLOTS: tests only,
+  // the number of wave slots to assume (so that a small batch takes the queue path).
+  const int n_groups = h->fast ? (count + 1) / 2 : count;
+  int grid_n = n_groups;
+  {
+    const int chunk_env = getenv("LHW_ROLLOUT_CHUNK") ? atoi(getenv("LHW_ROLLOUT_CHUNK")) : 10;
+    int slots = getenv("LHW_ROLLOUT_SLOTS") ? atoi(getenv("LHW_ROLLOUT_SLOTS")) : 0;
+    if (slots <= 0) {
+      static int chip_slots = 0;
+      if (!chip_slots) {
+        int nb = humanoid_occupancy(), dev = 0;
+        hipDeviceProp_t prop;
+        if (nb <= 0 || hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return -4;
+        chip_slots = nb * prop.multiProcessorCount;
+      }
+      slots = chip_slots;
+    }
+    if (!h->fast && chunk_env > 0 && n_groups > slots && T > chunk_env) {
+      if (!h->ro_queue) {   // two words per env: the ranges of concurrent launches (disjoint by contract) get disjoint pieces
+        void* d = nullptr;
+        if (lhw_malloc(&d, ((size_t)h->p.n_envs * 2 + 2) * sizeof(unsigned)) != hipSuccess) return -4;
+        h->dev_allocs.push_back(d);
+        h->ro_queue = (unsigned*)d;
+      }
+      ro.queue = h->ro_queue + 2 * (size_t)first;
+      ro.chunk = chunk_env;
+      if (hipMemsetAsync(ro.queue, 0, ((size_t)n_groups + 1) * sizeof(unsigned), s) != hipSuccess) return -4;
+      grid_n = slots;
+    }
+  }
+  const dim3 grid(grid_n);
   if (h->fast) {
-    const dim3 grid((count + 1) / 2);
-    if (h->p.task == TASK_WALK) hipLaunchKernelGGL((humanoid_rollout_kernel<TASK_WALK, 32>), grid, dim3(64), 0, s, (const HModel*)h->m_dev, (const HParams*)h->p_dev, lz, h->st, ro);
+    if (h->p.task == TASK_WALK) hipLaunchKernelGGL((humanoid_rollout_kernel<TASK_WALK, 32, false>), grid, dim3(64), 0, s, (const HModel*)h->m_dev, (const HParams*)h->p_dev, lz, h->st, ro);
     ROLLOUT_OTHER_TASKS(32)
-  } else if (h->p.task == TASK_STEP) {
-#ifndef LHW_ONLY_WALK
-    hipLaunchKernelGGL((humanoid_rollout_kernel<TASK_STEP, 64>), dim3(count), dim3(64), 0, s, (const HModel*)h->m_dev, (const HParams*)h->p_dev, lz, h->st, ro);
-#endif
   } else {
-    return -3;   // a walking / standing model that does not fit the two-envs-per-wave layout (or LHW_ONE_ENV_PER_WAVE): launch-per-step only
+#ifndef LHW_ONLY_WALK
+    if (ro.queue) hipLaunchKernelGGL((humanoid_rollout_kernel<TASK_STEP, 64, true>), grid, dim3(64), 0, s, (const HModel*)h->m_dev, (const HParams*)h->p_dev, lz, h->st, ro);
+    else hipLaunchKernelGGL((humanoid_rollout_kernel<TASK_STEP, 64, false>), grid, dim3(64), 0, s, (const HModel*)h->m_dev, (const HParams*)h->p_dev, lz, h->st, ro);
+#endif
   }
   return 0;
 }

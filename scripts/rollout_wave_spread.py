@@ -1,6 +1,7 @@
 """Spread of the wavefronts' total times over a resident rollout (lhw_env_rollout): a wave that finishes early leaves its slot idle
 until the launch ends.  usage: rollout_wave_spread.py ENV [N] [ITERS]   (PPO iterations first, so that the policy is not the initial one)"""
 import os, sys
+os.environ.setdefault("LHW_ROLLOUT_CHUNK", "0")   # one wave per env group for the whole rollout: the job queue of the stepping task would hide the spread it exists for
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from types import SimpleNamespace
 import numpy as np, torch

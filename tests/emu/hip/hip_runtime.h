@@ -227,6 +227,7 @@ static inline void __syncthreads() {
 #define __builtin_amdgcn_wave_barrier emu_wave_barrier
 #define __builtin_amdgcn_fence(order, scope) ((void)0)
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
+#define __builtin_amdgcn_s_sleep(x) ((void)0)
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
 #define __builtin_amdgcn_rsq(x) (1.0 / sqrt((double)(x)))
 #define __builtin_amdgcn_rcp(x) (1.0 / (double)(x))

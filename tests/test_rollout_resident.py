@@ -167,6 +167,33 @@ def test_resident_rollout_other_tasks(name):
         np.testing.assert_array_equal(x, y)
 
 
+def test_resident_rollout_through_the_job_queue_is_bitwise_the_same(monkeypatch):
+    """Stepping task with more env groups than wave slots (jvrc_step @ 4096 on the chip; forced here by LHW_ROLLOUT_SLOTS): the
+    resident waves pop (group, chunk of control steps) jobs from a queue, so a group's chunks run on whichever wave is free and a
+    wave advances one group after the other.  Nothing of an env lives in a wave between control steps: every buffer and the state
+    afterwards must be bitwise those of the one-wave-per-group launch, including across resets, for a chunk that does not divide T,
+    and for a sub-range whose queue words sit elsewhere."""
+    from learninghumanoidwalking_amd.envs.jvrc_step import JvrcStepSpec
+    spec = JvrcStepSpec()
+    N, T = 4, 7
+    envs = [emu.make_emulated(spec, N, seed=3, max_traj_len=4) for _ in range(3)]
+    pol = NumpyActor(spec.obs_dim, spec.act_dim, seed=5, scale=2.0)
+    obs0 = [e.reset().copy() for e in envs]
+    monkeypatch.setenv("LHW_ROLLOUT_CHUNK", "0")
+    a = _resident(envs[0], pol, T, obs0[0])
+    monkeypatch.setenv("LHW_ROLLOUT_CHUNK", "3")
+    monkeypatch.setenv("LHW_ROLLOUT_SLOTS", "1")
+    b = _resident(envs[1], pol, T, obs0[1])
+    _same(a, b)
+    assert (a["done"] & 2).any()
+    for x, y in zip(envs[0].get_state(), envs[1].get_state()):
+        np.testing.assert_array_equal(x, y)
+    assert envs[0].pop_episode_stats() == envs[1].pop_episode_stats()
+    c = _resident(envs[2], pol, T, obs0[2], first=1, count=N - 1)
+    _same(a, c, rows=slice(1, N))
+    assert not c["act"][:, 0].any()
+
+
 def test_fp16_operand_policy_step_rounds_every_operand_and_accumulates_in_float32():
     """BASELINE config 5 in the resident rollout: with `fp16_operands` the in-wave policy step rounds weights and activations to fp16
     before each product and sums in float32 over ascending k (read-out: eight 32-k partials, then the bias).  The product of two

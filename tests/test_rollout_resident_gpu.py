@@ -83,6 +83,39 @@ def test_resident_rollout_repeats_overflowing_envs_inside_the_wave(monkeypatch):
     assert fa == fb == (0, 0)
 
 
+def test_resident_rollout_through_the_job_queue_is_bitwise_the_same(monkeypatch):
+    """Stepping task with more env groups than wave slots (jvrc_step @ 4096; forced here with LHW_ROLLOUT_SLOTS = 48): the resident
+    waves pop (group, chunk of control steps) jobs from a device queue, a group's chunks run on whichever wave is free -- on other
+    CUs and XCDs than the chunk before (the HBM record and the rollout rows travel under agent-scope fences).  Bitwise the
+    one-wave-per-group rollout, twice in a row, resets and in-wave re-runs included."""
+    from learninghumanoidwalking_amd.envs import ENVIRONMENTS
+    from learninghumanoidwalking_amd.ppo import PPO
+    monkeypatch.setenv("LHW_ROLLOUT_MODE", "resident")
+    env_name, N = "jvrc_step", 301
+
+    def run(chunk):
+        monkeypatch.setenv("LHW_ROLLOUT_CHUNK", str(chunk))
+        algo = PPO(ENVIRONMENTS[env_name], _args(N, 14), seed=4)
+        out = []
+        for _ in range(2):
+            algo.sample_parallel_with_workers()
+            assert algo.rollout.last_mode == "resident"
+            out.append(_buffers(algo.rollout))
+        q, v = algo.env.get_state()
+        return out, q, v, algo.env.pop_fault_stats(), algo.env.pop_episode_stats()
+
+    monkeypatch.setenv("LHW_ROLLOUT_SLOTS", "48")
+    (a, qa, va, fa, ea), (b, qb, vb, fb, eb), (c, qc, vc, fc, ec) = run(0), run(3), run(5)
+    for other in (b, c):
+        for ra, rb in zip(a, other):
+            for x, y in zip(ra, rb):
+                assert torch.equal(x, y)
+    np.testing.assert_array_equal(qa, qb)
+    np.testing.assert_array_equal(va, vc)
+    assert fa == fb == fc == (0, 0) and ea == eb == ec
+    assert (a[0][5] != 0).any()
+
+
 def test_training_with_the_resident_rollout_ends_with_the_same_weights(monkeypatch):
     from learninghumanoidwalking_amd.envs import ENVIRONMENTS
     from learninghumanoidwalking_amd.ppo import PPO
