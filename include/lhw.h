@@ -173,7 +173,9 @@ typedef struct {
  *   term_obs_dev [T][N][obs_dim], rew_dev [T][N], done_dev [T][N] (LHW_DONE_*): as lhw_env_step, per control step, out
  *   rew_terms_dev [N][num_reward_terms] of the LAST control step, nullable
  * Humanoid tasks only, feed-forward float32 actor with hidden width 256 and act_dim <= 12 (LHW_ERR_UNSUPPORTED otherwise: the
- * caller keeps the launch-per-step pipeline). */
+ * caller keeps the launch-per-step pipeline).  Ranges of concurrent calls on different streams must be disjoint.  Stepping task
+ * with more envs than the chip has wave slots: the resident wavefronts drain a device queue of (env, LHW_ROLLOUT_CHUNK = 10 control
+ * steps) jobs instead of keeping one env each (the cost of an env follows its walking mode; same values either way). */
 int lhw_env_rollout(LhwEnv* env, const LhwRolloutPolicy* policy, int32_t first, int32_t count, int32_t T, float* obs_dev, float* act_dev,
                     float* logp_dev, float* term_obs_dev, float* rew_dev, uint8_t* done_dev, float* rew_terms_dev, void* stream);
 /* Parity hooks; HOST pointers, synchronous.  qpos [N][nq], qvel [N][nv] float64. */
