@@ -1623,8 +1623,11 @@ __device__ void collide_pair(ConSink<L>& k, const HModel& m, const L& S, int q, 
   }
 }
 
+// (forced inline: left to itself the compiler inlines the walking kernels' instance and makes the stepping task's -- 9.6 k instructions --
+// a call, whose prologue and epilogue save and restore 42 callee-saved VGPRs through scratch in every sub-step, besides what the
+// caller spills around the call; round 5, same box, jvrc_step @ 4096: rollout 1.228 -> 1.169 s.  col_box_box inlined as well: 1.249 s.)
 template <bool BOXBOX, class L>
-__device__ void fwd_collision(const HModel& m, const HParams& p, L& S, int lane, gtab_d ter, gws_d bd, gws_i bi) {
+__device__ __forceinline__ void fwd_collision(const HModel& m, const HParams& p, L& S, int lane, gtab_d ter, gws_d bd, gws_i bi) {
   FINE_BEGIN(3);
   if (lane < m.ngeom) {
     const int g = lane, b = m.geom_i[GIS * (g) + GI_BODY];
@@ -2574,7 +2577,21 @@ __device__ __forceinline__ void solve_tail(const HModel& m, const HParams& p, L&
   if constexpr (L::STEP_ && W == 64) bigpath = bd != nullptr && S.nbig > 0;
   if (bigpath) {
     // more contacts than row lanes (fwd_collision left them in the HBM workspace; S.ncon is 0, the in-LDS row code above idled)
-    if constexpr (L::STEP_ && W == 64) newton_big<L>(m, p, S, lane, bd, bi, dof, prim, Mrow, mdiag, marm, fs, as, uon, uD, uaref, ufl, anyunit, qacc, fcon);
+    if constexpr (L::STEP_ && W == 64) {
+      // The callee is not inlined and takes its arrays by reference: it gets COPIES.  Handed the originals, they escape and every
+      // access to them in this function -- Mrow in the Hessian / M-product loops, the unit-row parameters in each cost evaluation
+      // of the ordinary Newton path -- is a scratch access (2048 waves x 50 KB of scratch do not fit the L2: 25 KB per sub-step
+      // came back from beyond it).  Round 5, same box, jvrc_step @ 4096: rollout 1.336 -> 1.225 s (unit-row arrays alone 1.253 s;
+      // the callee inlined instead 1.59 s).  Round 4 measured the same copies +3 % in the launch-per-step kernel of the time.
+      double qo = as, fo = 0;
+      bool uon_c[3] = {uon[0], uon[1], uon[2]};
+      double uD_c[3] = {uD[0], uD[1], uD[2]}, uaref_c[3] = {uaref[0], uaref[1], uaref[2]};
+      double Mrow_c[NR];
+#pragma unroll
+      for (int k = 0; k < NR; k++) Mrow_c[k] = Mrow[k];
+      newton_big<L>(m, p, S, lane, bd, bi, dof, prim, Mrow_c, mdiag, marm, fs, as, uon_c, uD_c, uaref_c, ufl, anyunit, qo, fo);
+      qacc = qo; fcon = fo;
+    }
     S.efc_force[lane] = 0;
   } else if (anyrow) {
     // ------------------------------------------------------------ primal Newton (engine_solver.c)
