@@ -49,12 +49,13 @@ def test_full_batch_equals_small_batch_and_is_deterministic(name, N):
     assert count >= N * (T // 12) * 0.9 and 1 <= length / count <= 12
 
 
-@pytest.mark.parametrize("name,N", [("jvrc_walk", 4096), ("h1", 8192), ("jvrc_step", 2048)])
+@pytest.mark.parametrize("name,N", [("jvrc_walk", 4096), ("h1", 8192), ("jvrc_step", 2048), ("jvrc_step", 4096)])
 def test_full_size_resident_rollout_equals_small_batch_and_is_deterministic(name, N, monkeypatch):
     """The resident rollout (lhw_env_rollout: one launch, policy step inside the stepper's wavefronts) at the BASELINE batch: env i
     of the full batch stores bit-identical observations / actions / log-densities / rewards / flags to env i of a 32-env batch
     (env ids, hence every random draw, are global; a wavefront owns its envs for the whole rollout), twice the same bits, all
-    finite, nothing diverged, no contact dropped."""
+    finite, nothing diverged, no contact dropped.  (jvrc_step @ 4096: more envs than wave slots -- the resident waves drain the job
+    queue, three chunks per env; the 32-env batch runs one wave per env.)"""
     from types import SimpleNamespace
     from learninghumanoidwalking_amd.envs import ENVIRONMENTS
     from learninghumanoidwalking_amd.ppo import PPO
