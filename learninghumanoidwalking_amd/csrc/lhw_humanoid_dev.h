@@ -849,8 +849,11 @@ __device__ __forceinline__ void affine_scan_round(double (&R)[9], double (&pw)[3
 #pragma unroll
   for (int k = 0; k < 3; k++) pw[k] = pa[k] + t[k];
 }
+// (fwd_kinematics / fwd_com forced inline: with fwd_collision inlined the compiler had made THESE two calls in the stepping-task
+// kernel instead -- generic-pointer loads of the model tables, callee-saved registers through scratch, every sub-step; round 5, same
+// box, jvrc_step @ 4096: 1.287 -> 1.320 M env-steps/s.  The walking kernels inline them either way.)
 template <bool STEPT, class L>
-__device__ void fwd_kinematics(const HModel& m, L& S, int lane) {
+__device__ __forceinline__ void fwd_kinematics(const HModel& m, L& S, int lane) {
   double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, pw[3] = {0, 0, 0}, jax[3] = {0, 0, 0}, jps[3] = {0, 0, 0};
   int kb = -1, jt = -1, jid = 0;
   if (lane < 32) {
@@ -971,7 +974,7 @@ __device__ void fwd_kinematics(const HModel& m, L& S, int lane) {
 
 // subtree com of the (single) dynamic tree rooted at body 1, cinert, cdof  (mj_comPos)
 template <class L>
-__device__ void fwd_com(const HModel& m, const HParams& p, L& S, int lane) {
+__device__ __forceinline__ void fwd_com(const HModel& m, const HParams& p, L& S, int lane) {
   double ms = 0, mx = 0, my = 0, mz = 0;
   if (lane >= 1 && lane < m.nbody && m.body_i[BIS * (lane) + BI_ROOT] == 1) {
     ms = prm_mass(m, S, lane);
@@ -2914,8 +2917,11 @@ __device__ __forceinline__ void quat_roll_pitch(const double* q, double* roll, d
   else { *roll = atan2(-M12, M11); *pitch = atan2(-M20, cy); }
 }
 
+// (forced inline: as a call -- the compiler's choice -- it cost the walking kernel 36 B of scratch per lane and its mode_ref argument a
+// home in memory; round 5, same box, jvrc_walk @ 4096: rollout 0.3931 -> 0.3862 s.  The H1 tasks' write_obs_h1 / randomize_dynamics
+// inlined the same way LOSE 1.5 % on h1 @ 8192 and stay calls.)
 template <class L>
-__device__ void write_obs(const HModel& m, const HParams& p, L& S, int lane, int phase, int mode, const double* mode_ref,
+__device__ __forceinline__ void write_obs(const HModel& m, const HParams& p, L& S, int lane, int phase, int mode, const double* mode_ref,
                           float* o) {
   // get_obs (base_humanoid_env.py:177-197): fresh root quaternion / angular velocity, stale motor pos/vel
   if (lane == 0) {
