@@ -159,9 +159,28 @@ class Rollout:
             self.tob_all = torch.zeros(T, self.N, self.obs.shape[2], dtype=torch.float32, device=self.obs.device)
         k.begin_rollout()      # theta is frozen for the whole rollout (policy steps and the batched critic passes behind them)
         try:
+            if not getattr(self, "_rare_path_warm", False):
+                self._warm_rare_path()
             self._collect_steps(deterministic)
         finally:
             k.end_rollout()
+
+    def _warm_rare_path(self):
+        """Runs the truncated-trajectory branch of _collect_steps once on eight dummy rows.  An untrained policy falls long before
+        max_traj_len, so that branch is first taken some ten iterations into a run -- and the first call of its torch ops
+        (index_select, index_copy_) loads their code objects: 0.1-0.2 s in the middle of that iteration (bench.py's iter_s showed
+        it at iteration 10 of every run).  A process start-up cost, paid here before the first rollout instead."""
+        self._rare_path_warm = True
+        if self.obs.device.type != "cuda" or self.tob_all is None:
+            return
+        T = self.T
+        need = torch.zeros(T * self.N, dtype=torch.bool, device=self.obs.device)
+        need[:8] = True
+        idx = torch.nonzero(need).reshape(-1)
+        vals = _lib.empty(idx.numel(), dtype=torch.float32, device=self.obs.device)
+        self._batched_values(self.tob_all.reshape(T * self.N, -1).index_select(0, idx), vals)
+        self.vterm.reshape(-1).index_copy_(0, idx, vals)
+        self.vterm.zero_()
 
     def _collect_hooked(self, deterministic):
         """Launch-per-step rollout with the TASK outside the kernels (task_hook.py): after each control step the env's exported
