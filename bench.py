@@ -387,7 +387,9 @@ def main():
             launch_ms = float(np.mean(resident_ms))
             pmc = static_pmc_rollout() if env_name == "jvrc_walk" else None
             alg_tf = flops_per_env_step * N * T / (launch_ms * 1e-3) / 1e12
-            roofline["kernel"] = spec.step_kernel_name.replace("humanoid_kernel<0, ", "humanoid_rollout_kernel<")
+            # (rocprof name: humanoid_rollout_kernel<TASK, W, QUEUE>; QUEUE = the stepping task's job queue, csrc/lhw_humanoid_rollout.hip)
+            queued = env_name == "jvrc_step" and N > 2048 and os.environ.get("LHW_ROLLOUT_CHUNK", "10") != "0"
+            roofline["kernel"] = spec.step_kernel_name.replace("humanoid_kernel<0, ", "humanoid_rollout_kernel<").replace(">", ", true>" if queued else ", false>")
             roofline["avg_launch_ms"] = launch_ms
             roofline["envs_per_launch"] = N
             roofline["control_steps_per_launch"] = T
