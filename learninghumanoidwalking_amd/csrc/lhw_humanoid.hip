@@ -13,8 +13,8 @@ __global__ void __launch_bounds__(64, LHW_WAVES_PER_SIMD) humanoid_kernel(const 
   __shared__ L SG[G];
   LHW_LDS_POISON(SG);
   const int lane = threadIdx.x & (W - 1);   // lane within the env's group
-  const HParams& p = *pp;
-  const HModel& m = *mp;   // (a register copy of the whole record was measured: +3.5 %, its ~100 scalars crowd the SGPR file)
+  HParamsRef p = *(const HParams LHW_GLOBAL_AS*)pp;
+  HModelRef m = *(const HModel LHW_GLOBAL_AS*)mp;   // (a register copy of the whole record was measured: +3.5 %, its ~100 scalars crowd the SGPR file)
   if constexpr (MODE == 0 && W == 64) {
     // One call site for both uses of the one-env-per-wave step kernel.  As the re-run behind the two-envs-per-wave kernel
     // (only_flagged) it is launched with FEW workgroups, each scanning the flags of `chunk` <= 64 consecutive envs and stepping
@@ -436,14 +436,16 @@ int humanoid_create(HumanoidEnv** out, const std::vector<int32_t>& mi, const std
   }
   auto BID = [&](int f) { const int b = cfg->task_iparams[f]; return (b >= 0 && b < nbm) ? bmap[b] : -1; };
   m.track_body[0] = BID(LHW_TI_ROOT_BODY); m.track_body[1] = BID(LHW_TI_RFOOT_BODY); m.track_body[2] = BID(LHW_TI_LFOOT_BODY);
-  ok = ok && (m.body_d = to_dev<double>(h, body_d.data(), body_d.size())) && (m.jnt_d = to_dev<double>(h, jnt_d.data(), jnt_d.size())) &&
-       (m.dof_d = to_dev<double>(h, dof_d.data(), dof_d.size())) && (m.geom_d = to_dev<double>(h, geom_d.data(), geom_d.size())) &&
-       (m.act_d = to_dev<double>(h, act_d.data(), act_d.size())) && (m.body_i = to_dev<int>(h, body_i.data(), body_i.size())) &&
-       (m.jnt_i = to_dev<int>(h, jnt_i.data(), jnt_i.size())) && (m.dof_i = to_dev<int>(h, dof_i.data(), dof_i.size())) &&
-       (m.geom_i = to_dev<int>(h, geom_i.data(), geom_i.size())) && (m.act_i = to_dev<int>(h, act_i.data(), act_i.size())) &&
-       (m.pair_i = to_dev<int>(h, pair_i.data(), pair_i.size())) && (m.pair_d = to_dev<double>(h, pair_d.data(), pair_d.size())) && (m.own_tab = to_dev<int>(h, own_tab.data(), own_tab.size())) &&
-       (m.kin_i = to_dev<int>(h, kin_i.data(), kin_i.size())) && (m.kin_d = to_dev<double>(h, kin_d.data(), kin_d.size())) &&
-       (m.fix_i = to_dev<int>(h, fix_i.data(), fix_i.size())) && (m.fix_d = to_dev<double>(h, fix_d.data(), fix_d.size()));
+  if (max_owned > MAX_OWNED) { humanoid_destroy(h); return lhw_fail(LHW_ERR_UNSUPPORTED, "more than %d bodies move with one dof (%d): fold welded links first (Model.fuse_static)", MAX_OWNED, (int)max_owned); }
+  // the tables are members of HModel (fixed capacities; the limits were checked above)
+  std::copy(body_d.begin(), body_d.end(), m.body_d); std::copy(jnt_d.begin(), jnt_d.end(), m.jnt_d); std::copy(dof_d.begin(), dof_d.end(), m.dof_d);
+  std::copy(geom_d.begin(), geom_d.end(), m.geom_d); std::copy(act_d.begin(), act_d.end(), m.act_d); std::copy(pair_d.begin(), pair_d.end(), m.pair_d);
+  std::copy(kin_d.begin(), kin_d.end(), m.kin_d); std::copy(fix_d.begin(), fix_d.end(), m.fix_d);
+  std::copy(body_i.begin(), body_i.end(), m.body_i); std::copy(jnt_i.begin(), jnt_i.end(), m.jnt_i); std::copy(dof_i.begin(), dof_i.end(), m.dof_i);
+  std::copy(geom_i.begin(), geom_i.end(), m.geom_i); std::copy(act_i.begin(), act_i.end(), m.act_i); std::copy(pair_i.begin(), pair_i.end(), m.pair_i);
+  std::copy(kin_i.begin(), kin_i.end(), m.kin_i); std::copy(fix_i.begin(), fix_i.end(), m.fix_i);
+  for (int a = 0; a < 32 * MAX_OWNED; a++) m.own_tab[a] = -1;
+  std::copy(own_tab.begin(), own_tab.end(), m.own_tab);
   HParams& p = h->p;
   memset(&p, 0, sizeof p);
   p.n_envs = cfg->n_envs; p.frame_skip = cfg->frame_skip; p.max_traj_len = cfg->max_traj_len; p.period = cfg->period;
@@ -481,10 +483,10 @@ int humanoid_create(HumanoidEnv** out, const std::vector<int32_t>& mi, const std
   std::vector<double> nominal(nq), neutral(nu);
   for (int k = 0; k < nq; k++) nominal[k] = cfg->nominal_qpos ? cfg->nominal_qpos[k] : DF(LHW_DF_QPOS0)[k];
   for (int u = 0; u < nu; u++) neutral[u] = cfg->action_offset[u];  // task._neutral_pose == half-sitting pose == offsets (jvrc_walk.py:33)
-  ok = ok && (p.kp = to_dev<double>(h, cfg->kp, nu)) && (p.kd = to_dev<double>(h, cfg->kd, nu)) &&
-       (p.nominal_qpos = to_dev<double>(h, nominal.data(), nq)) && (p.action_offset = to_dev<double>(h, cfg->action_offset, nu)) &&
-       (p.clock_lut = to_dev<double>(h, cfg->clock_lut, (walk || h1walk) ? (size_t)4 * cfg->period : 0)) &&
-       (p.neutral_pose = to_dev<double>(h, neutral.data(), nu)) && (p.obs_noise = to_dev<double>(h, obs_noise.data(), 35));
+  for (int u = 0; u < nu; u++) { p.kp[u] = cfg->kp[u]; p.kd[u] = cfg->kd[u]; p.action_offset[u] = cfg->action_offset[u]; p.neutral_pose[u] = neutral[u]; }
+  for (int k = 0; k < nq; k++) p.nominal_qpos[k] = nominal[k];
+  for (int k = 0; k < 35; k++) p.obs_noise[k] = obs_noise[k];
+  ok = ok && (p.clock_lut = to_dev<double>(h, cfg->clock_lut, (walk || h1walk) ? (size_t)4 * cfg->period : 0));
   const size_t N = cfg->n_envs;
   h->st.prm = nullptr;
   if (ok && p.env_params) {
@@ -680,10 +682,10 @@ void humanoid_set_iteration(HumanoidEnv* h, int64_t it) { h->iteration = (int)st
 int humanoid_actuator_state(HumanoidEnv* h, double* pos, double* vel, double* tq) {
   const size_t N = h->p.n_envs;
   const int nu = h->m.nu;
-  std::vector<double> rec(N * REC_D), act_d((size_t)nu * ADS);
+  std::vector<double> rec(N * REC_D);
+  const double* act_d = h->m.act_d;   // (host copy of the model record)
   if (hipDeviceSynchronize() != hipSuccess) return -1;
   if (hipMemcpy(rec.data(), h->st.rec, rec.size() * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) return -1;
-  if (hipMemcpy(act_d.data(), h->m.act_d, act_d.size() * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) return -1;
   for (size_t n = 0; n < N; n++)
     for (int u = 0; u < nu; u++) {
       if (pos) pos[n * nu + u] = rec[n * REC_D + R_SQ + u];

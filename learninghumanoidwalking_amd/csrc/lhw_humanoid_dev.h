@@ -223,23 +223,31 @@ struct DevTab {   // what to_dev returns: converts to the table pointer type of 
 #endif
 };
 
+#define KIS 4    // kin_i: body jnt_type qposadr joint
+#define KDS 20   // kin_d: R0[9] p0[3] jnt_axis[3] jnt_pos[3] qpos0 pad   (R0, p0: frame relative to the previous jointed body)
+#define MAX_OWNED 8   // bodies per lane of the chain layout (chain_dynamics' per-body loop; checked at create)
+// Round 6: the model tables are MEMBERS of HModel (fixed capacities), not pointers to seventeen separate allocations: every table
+// read of the kernels is a global load off ONE base -- the kernel's HModel argument -- plus a compile-time offset.  Before, each
+// table access first fetched the table's own pointer from HModel with an s_load (about sixty scalar loads per wave and sub-step,
+// each answered on the counter the LDS reads use), and the pointers that stayed live crowded the SGPR file (SGPR spills of the
+// walking rollout kernel: 499 -> see DESIGN.md section 4).  The struct is 45 KB; the kernels see it through an address-space-1 reference
+// (HModelRef) so that also the functions that are not inlined read it with global / scalar loads instead of flat ones.
 struct HModel {
   int nq, nv, nu, nbody, njnt, ngeom, npair, nlevel, iterations, disableflags;
   double timestep, gravity[3], tolerance, meaninertia, totalmass;
-  gtab_d body_d, jnt_d, dof_d, geom_d, act_d;
-  gtab_i body_i, jnt_i, dof_i, geom_i, act_i, pair_i;   // pair_i / pair_d: one record per candidate pair (mj_contactParam is a function of the pair)
-  gtab_d pair_d;
   int has_primbox;     // some collision pair is sphere-box or capsule-box (collide_primbox)
   int npb, pb_pair[4]; // plane-box pairs (floor against a foot box), in pair order, if there are at most four of them (else npb = 0):
                        // their eight corners are tested on eight lanes each instead of one after the other on the pair's lane
-  gtab_i kin_i;          // [32][KIS], kin_d [32][KDS]: per lane of the chain layout, its jointed body and that body's frame relative to the
-  gtab_d kin_d;          //   previous jointed body (fwd_kinematics)
-  gtab_i fix_i;          // [nbody]: jointed body a welded body moves with (-1 for jointed bodies), fix_d [nbody][12]: its frame in that body's
-  gtab_d fix_d;
-  int max_owned;         // bodies per lane in chain_dynamics' per-body loop
-  gtab_i own_tab;        // [32][max_owned]: bodies whose force / inertia the lane of the chain layout contributes (-1: none)
+  int max_owned;         // bodies per lane in chain_dynamics' per-body loop (<= MAX_OWNED)
   int track_body[3];  // bodies whose spatial velocity must survive the sub-step (the task reads them afterwards)
   double track_off[9];  // local offset of the tracked point on each of them (foot force sites for the stepping task)
+  double body_d[NB * BDS], jnt_d[NJ * JDS], dof_d[NVMAX * DDS], geom_d[NG * GDS], act_d[NU * ADS];
+  double pair_d[NP * PDS];   // pair_i / pair_d: one record per candidate pair (mj_contactParam is a function of the pair)
+  double kin_d[32 * KDS];    // kin_i [32][KIS], kin_d [32][KDS]: per lane of the chain layout, its jointed body and that body's frame relative
+                             //   to the previous jointed body (fwd_kinematics)
+  double fix_d[NB * 12];     // fix_i [nbody]: jointed body a welded body moves with (-1 for jointed bodies), fix_d [nbody][12]: its frame in that body's
+  int body_i[NB * BIS], jnt_i[NJ * JIS], dof_i[NVMAX * DIS], geom_i[NG * GIS], act_i[NU * AIS], pair_i[NP * PIS], kin_i[32 * KIS], fix_i[NB];
+  int own_tab[32 * MAX_OWNED];   // [32][max_owned]: bodies whose force / inertia the lane of the chain layout contributes (-1: none)
 };
 
 struct HParams {
@@ -255,8 +263,16 @@ struct HParams {
   unsigned env_id_base;
   unsigned long long seed;
   double action_smoothing, goal_height, init_noise, force_mag, torque_mag;
-  gtab_d kp, kd, nominal_qpos, action_offset, clock_lut, neutral_pose, obs_noise;
+  gtab_d clock_lut;
+  double kp[NU], kd[NU], nominal_qpos[NQ], action_offset[NU], neutral_pose[NU], obs_noise[36];   // (members, like the model tables)
 };
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef const HModel LHW_GLOBAL_AS& HModelRef;
+typedef const HParams LHW_GLOBAL_AS& HParamsRef;
+#else
+typedef const HModel& HModelRef;
+typedef const HParams& HParamsRef;
+#endif
 
 // what changes from launch to launch (everything else of the task configuration sits in device memory: HumanoidEnv::p_dev)
 struct HLaunch {
@@ -526,16 +542,16 @@ __host__ __device__ __forceinline__ int opaque_zero() {
 #else
 #define GROUP_SYNC(W) ((void)0)
 #endif
-template <class L> __device__ __forceinline__ double prm_damp(const HModel& m, const L& S, int d) {
+template <class L> __device__ __forceinline__ double prm_damp(HModelRef m, const L& S, int d) {
   if constexpr (L::PRM_) return S.damp[d]; else return m.dof_d[DDS * d + DD_DAMPING];
 }
-template <class L> __device__ __forceinline__ double prm_floss(const HModel& m, const L& S, int d) {
+template <class L> __device__ __forceinline__ double prm_floss(HModelRef m, const L& S, int d) {
   if constexpr (L::PRM_) return S.floss[d]; else return m.dof_d[DDS * d + DD_FLOSS];
 }
-template <class L> __device__ __forceinline__ double prm_mass(const HModel& m, const L& S, int b) {
+template <class L> __device__ __forceinline__ double prm_mass(HModelRef m, const L& S, int b) {
   if constexpr (L::PRM_) return S.bmass[b]; else return m.body_d[BDS * b + BD_MASS];
 }
-template <class L> __device__ __forceinline__ double prm_ipos(const HModel& m, const L& S, int b, int a) {
+template <class L> __device__ __forceinline__ double prm_ipos(HModelRef m, const L& S, int b, int a) {
   if constexpr (L::PRM_) return S.bipos[3 * b + a]; else return m.body_d[BDS * b + BD_IPOS + a];
 }
 
@@ -598,6 +614,91 @@ template <int SRC>
 __device__ __forceinline__ double rbc(double v) {
   const long long lv = __double_as_longlong(v);
   return __longlong_as_double(__builtin_amdgcn_update_dpp(lv, lv, 0x150 + SRC, 0xf, 0xf, false));
+}
+// ---- v_fmac_f64 with a DPP source (round 6).  gfx90a+ encode v_fmac_f64 as VOP2, and a VOP2 instruction can take its first source
+// through DPP; for 64-bit operands the one control available is row_newbcast -- exactly the chain layout's "value held by the lane of
+// row position e".  acc += bcast_e(v) * c is then ONE instruction instead of v_mov_b64_dpp + v_fma_f64 (the compiler does not form it:
+// its DPP combiner skips 64-bit operations, so it is written out; the product is the same single-rounding fma, bit for bit).  A DPP
+// instruction must not read a VGPR that a VALU instruction wrote in the two issue slots before it -- the compiler inserts s_nop for its
+// own DPP instructions but cannot see into an asm statement, so every statement starts with `s_nop 1`; inside a statement the DPP
+// sources are never written (fmac_col: each accumulator is read, through DPP, by its own instruction only -- reads of a row happen
+// before its writes, as in any in-place DPP reduction).  Checked on the hardware by scripts/dpp_probe.hip before any kernel used it;
+// the host pass / SIMT emulator and LHW_FMAC_DPP=0 builds take the two-instruction form.
+#ifndef LHW_FMAC_DPP
+#define LHW_FMAC_DPP 1
+#endif
+#if defined(__HIP_DEVICE_COMPILE__) && LHW_FMAC_DPP
+#define LHW_FMAC_ASM 1
+#else
+#define LHW_FMAC_ASM 0
+#endif
+#define LHW_FD(a) "v_fmac_f64_dpp %[" #a "], %[" #a "], %[c] row_newbcast:%[k] row_mask:0xf bank_mask:0xf\n\t"
+#define LHW_FA(e) "v_fmac_f64_dpp %[acc], %[x], %[m" #e "] row_newbcast:" #e " row_mask:0xf bank_mask:0xf\n\t"
+#define LHW_FB(e) "v_fmac_f64_dpp %[acc], %[c" #e "], %[b" #e "] row_newbcast:%[k] row_mask:0xf bank_mask:0xf\n\t"
+// acc += (v held by the lane of row position SRC) * c
+template <int SRC>
+__device__ __forceinline__ double fma_rbc(double v, double c, double acc) {
+#if LHW_FMAC_ASM
+  asm("s_nop 1\n\tv_fmac_f64_dpp %[acc], %[v], %[c] row_newbcast:%[k] row_mask:0xf bank_mask:0xf" : [acc] "+v"(acc) : [v] "v"(v), [c] "v"(c), [k] "n"(SRC));
+  return acc;
+#else
+  return fma(rbc<SRC>(v), c, acc);
+#endif
+}
+// column step K of the chain factorisation: x += bcast_K(x) nf, R[e] += bcast_K(R[e]) nf for e < K
+template <int K, int NRR>
+__device__ __forceinline__ void fmac_col(double (&R)[NRR], double& x, const double nf) {
+#if LHW_FMAC_ASM
+  static_assert(K < 12, "fmac_col: column index");
+  if constexpr (K == 0) asm("s_nop 1\n\t" LHW_FD(x) : [x] "+v"(x) : [c] "v"(nf), [k] "n"(K));
+  else if constexpr (K == 1) asm("s_nop 1\n\t" LHW_FD(x) LHW_FD(a0) : [x] "+v"(x), [a0] "+v"(R[0]) : [c] "v"(nf), [k] "n"(K));
+  else if constexpr (K == 2) asm("s_nop 1\n\t" LHW_FD(x) LHW_FD(a0) LHW_FD(a1) : [x] "+v"(x), [a0] "+v"(R[0]), [a1] "+v"(R[1]) : [c] "v"(nf), [k] "n"(K));
+  else if constexpr (K == 3) asm("s_nop 1\n\t" LHW_FD(x) LHW_FD(a0) LHW_FD(a1) LHW_FD(a2) : [x] "+v"(x), [a0] "+v"(R[0]), [a1] "+v"(R[1]), [a2] "+v"(R[2]) : [c] "v"(nf), [k] "n"(K));
+  else if constexpr (K == 4) asm("s_nop 1\n\t" LHW_FD(x) LHW_FD(a0) LHW_FD(a1) LHW_FD(a2) LHW_FD(a3) : [x] "+v"(x), [a0] "+v"(R[0]), [a1] "+v"(R[1]), [a2] "+v"(R[2]), [a3] "+v"(R[3]) : [c] "v"(nf), [k] "n"(K));
+  else if constexpr (K == 5) asm("s_nop 1\n\t" LHW_FD(x) LHW_FD(a0) LHW_FD(a1) LHW_FD(a2) LHW_FD(a3) LHW_FD(a4) : [x] "+v"(x), [a0] "+v"(R[0]), [a1] "+v"(R[1]), [a2] "+v"(R[2]), [a3] "+v"(R[3]), [a4] "+v"(R[4]) : [c] "v"(nf), [k] "n"(K));
+  else if constexpr (K == 6) asm("s_nop 1\n\t" LHW_FD(x) LHW_FD(a0) LHW_FD(a1) LHW_FD(a2) LHW_FD(a3) LHW_FD(a4) LHW_FD(a5) : [x] "+v"(x), [a0] "+v"(R[0]), [a1] "+v"(R[1]), [a2] "+v"(R[2]), [a3] "+v"(R[3]), [a4] "+v"(R[4]), [a5] "+v"(R[5]) : [c] "v"(nf), [k] "n"(K));
+  else if constexpr (K == 7) asm("s_nop 1\n\t" LHW_FD(x) LHW_FD(a0) LHW_FD(a1) LHW_FD(a2) LHW_FD(a3) LHW_FD(a4) LHW_FD(a5) LHW_FD(a6) : [x] "+v"(x), [a0] "+v"(R[0]), [a1] "+v"(R[1]), [a2] "+v"(R[2]), [a3] "+v"(R[3]), [a4] "+v"(R[4]), [a5] "+v"(R[5]), [a6] "+v"(R[6]) : [c] "v"(nf), [k] "n"(K));
+  else if constexpr (K == 8) asm("s_nop 1\n\t" LHW_FD(x) LHW_FD(a0) LHW_FD(a1) LHW_FD(a2) LHW_FD(a3) LHW_FD(a4) LHW_FD(a5) LHW_FD(a6) LHW_FD(a7) : [x] "+v"(x), [a0] "+v"(R[0]), [a1] "+v"(R[1]), [a2] "+v"(R[2]), [a3] "+v"(R[3]), [a4] "+v"(R[4]), [a5] "+v"(R[5]), [a6] "+v"(R[6]), [a7] "+v"(R[7]) : [c] "v"(nf), [k] "n"(K));
+  else if constexpr (K == 9) asm("s_nop 1\n\t" LHW_FD(x) LHW_FD(a0) LHW_FD(a1) LHW_FD(a2) LHW_FD(a3) LHW_FD(a4) LHW_FD(a5) LHW_FD(a6) LHW_FD(a7) LHW_FD(a8) : [x] "+v"(x), [a0] "+v"(R[0]), [a1] "+v"(R[1]), [a2] "+v"(R[2]), [a3] "+v"(R[3]), [a4] "+v"(R[4]), [a5] "+v"(R[5]), [a6] "+v"(R[6]), [a7] "+v"(R[7]), [a8] "+v"(R[8]) : [c] "v"(nf), [k] "n"(K));
+  else if constexpr (K == 10) asm("s_nop 1\n\t" LHW_FD(x) LHW_FD(a0) LHW_FD(a1) LHW_FD(a2) LHW_FD(a3) LHW_FD(a4) LHW_FD(a5) LHW_FD(a6) LHW_FD(a7) LHW_FD(a8) LHW_FD(a9) : [x] "+v"(x), [a0] "+v"(R[0]), [a1] "+v"(R[1]), [a2] "+v"(R[2]), [a3] "+v"(R[3]), [a4] "+v"(R[4]), [a5] "+v"(R[5]), [a6] "+v"(R[6]), [a7] "+v"(R[7]), [a8] "+v"(R[8]), [a9] "+v"(R[9]) : [c] "v"(nf), [k] "n"(K));
+  else if constexpr (K == 11) asm("s_nop 1\n\t" LHW_FD(x) LHW_FD(a0) LHW_FD(a1) LHW_FD(a2) LHW_FD(a3) LHW_FD(a4) LHW_FD(a5) LHW_FD(a6) LHW_FD(a7) LHW_FD(a8) LHW_FD(a9) LHW_FD(a10) : [x] "+v"(x), [a0] "+v"(R[0]), [a1] "+v"(R[1]), [a2] "+v"(R[2]), [a3] "+v"(R[3]), [a4] "+v"(R[4]), [a5] "+v"(R[5]), [a6] "+v"(R[6]), [a7] "+v"(R[7]), [a8] "+v"(R[8]), [a9] "+v"(R[9]), [a10] "+v"(R[10]) : [c] "v"(nf), [k] "n"(K));
+#else
+  x = fma(rbc<K>(x), nf, x);
+#pragma unroll
+  for (int e = 0; e < K; e++) R[e] = fma(rbc<K>(R[e]), nf, R[e]);
+#endif
+}
+template <int NRR, int E>
+__device__ __forceinline__ void fmac_mrow_ref(const double (&Mr)[NRR], double x, double& acc) {
+  if constexpr (E < NRR) {
+    acc = fma(Mr[E], rbc<E>(x), acc);
+    fmac_mrow_ref<NRR, E + 1>(Mr, x, acc);
+  }
+}
+// acc += sum_e Mr[e] * bcast_e(x)
+template <int NRR>
+__device__ __forceinline__ void fmac_mrow(const double (&Mr)[NRR], double x, double& acc) {
+#if LHW_FMAC_ASM
+  static_assert(NRR == 11 || NRR == 12, "fmac_mrow: row length");
+  if constexpr (NRR == 12) asm("s_nop 1\n\t" LHW_FA(0) LHW_FA(1) LHW_FA(2) LHW_FA(3) LHW_FA(4) LHW_FA(5) LHW_FA(6) LHW_FA(7) LHW_FA(8) LHW_FA(9) LHW_FA(10) LHW_FA(11) : [acc] "+v"(acc) : [x] "v"(x), [m0] "v"(Mr[0]), [m1] "v"(Mr[1]), [m2] "v"(Mr[2]), [m3] "v"(Mr[3]), [m4] "v"(Mr[4]), [m5] "v"(Mr[5]), [m6] "v"(Mr[6]), [m7] "v"(Mr[7]), [m8] "v"(Mr[8]), [m9] "v"(Mr[9]), [m10] "v"(Mr[10]), [m11] "v"(Mr[11]));
+  else asm("s_nop 1\n\t" LHW_FA(0) LHW_FA(1) LHW_FA(2) LHW_FA(3) LHW_FA(4) LHW_FA(5) LHW_FA(6) LHW_FA(7) LHW_FA(8) LHW_FA(9) LHW_FA(10) : [acc] "+v"(acc) : [x] "v"(x), [m0] "v"(Mr[0]), [m1] "v"(Mr[1]), [m2] "v"(Mr[2]), [m3] "v"(Mr[3]), [m4] "v"(Mr[4]), [m5] "v"(Mr[5]), [m6] "v"(Mr[6]), [m7] "v"(Mr[7]), [m8] "v"(Mr[8]), [m9] "v"(Mr[9]), [m10] "v"(Mr[10]));
+#else
+  fmac_mrow_ref<NRR, 0>(Mr, x, acc);
+#endif
+}
+// sum_k b[k] * bcast_E(c[k]), k = 0..5
+template <int E>
+__device__ __forceinline__ double fmac_dot6(const double (&b)[6], const double (&c)[6]) {
+#if LHW_FMAC_ASM
+  double acc = 0.0;
+  asm("s_nop 1\n\t" LHW_FB(0) LHW_FB(1) LHW_FB(2) LHW_FB(3) LHW_FB(4) LHW_FB(5)
+      : [acc] "+v"(acc)
+      : [c0] "v"(c[0]), [c1] "v"(c[1]), [c2] "v"(c[2]), [c3] "v"(c[3]), [c4] "v"(c[4]), [c5] "v"(c[5]),
+        [b0] "v"(b[0]), [b1] "v"(b[1]), [b2] "v"(b[2]), [b3] "v"(b[3]), [b4] "v"(b[4]), [b5] "v"(b[5]), [k] "n"(E));
+  return acc;
+#else
+  return b[0] * rbc<E>(c[0]) + b[1] * rbc<E>(c[1]) + b[2] * rbc<E>(c[2]) + b[3] * rbc<E>(c[3]) + b[4] * rbc<E>(c[4]) + b[5] * rbc<E>(c[5]);
+#endif
 }
 // The values of this lane and of lane ^ 16 (v_permlane16_swap, gfx950), as (value of the even row, value of the odd row) of the
 // row pair -- the same ordered pair in both lanes, so a reduction over it is bit-identical in the two rows.
@@ -673,22 +774,65 @@ __device__ __forceinline__ bool gany(bool pred) {
   if constexpr (W == 64) return b != 0;
   else return ((b >> (32 * group_id<W>())) & 0xffffffffull) != 0;
 }
+// ---- fp64 reciprocal, division, square root without the IEEE expansions (round 6).  The compiler expands `a / b` into v_div_scale x2,
+// v_rcp_f64, eight FMAs, v_div_fmas, v_div_fixup (13 instructions) and sqrt() into v_rsq_f64 plus a scaled Goldschmidt iteration with class
+// tests (17); the operands of the sub-step are lengths, masses, pivots and regularisers -- normal numbers far from the ends of the
+// exponent range -- so the seed instruction plus two Newton steps (error about one ulp, not correctly rounded) is enough: the float64
+// oracle keeps IEEE division and the parity tolerance (1e-12 per five-control-step segment) has four decades of room.
+// LHW_FASTDIV=0 compiles the IEEE forms back in (A/B, scripts/build_variant.sh).
+#ifndef LHW_FASTDIV
+#define LHW_FASTDIV 1
+#endif
+__device__ __forceinline__ double rcp_f64(double d) {
+  double x = __builtin_amdgcn_rcp(d);
+  x = fma(fma(-d, x, 1.0), x, x);
+  x = fma(fma(-d, x, 1.0), x, x);
+  return x;
+}
+__device__ __forceinline__ double qdiv(double a, double b) {
+#if LHW_FASTDIV
+  return a * rcp_f64(b);
+#else
+  return a / b;
+#endif
+}
+// 1 / sqrt(x) for x > 0 (v_rsq_f64 + two Newton steps); x = 0 gives +inf like the instruction
+__device__ __forceinline__ double rsqrt_f64(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+  const double hx = 0.5 * x;
+  y = fma(fma(-hx * y, y, 0.5), y, y);
+  y = fma(fma(-hx * y, y, 0.5), y, y);
+  return y;
+}
+// sqrt(x) for x >= 0: x * rsqrt(x) with the residual of the product folded back in; 0 for x = 0
+__device__ __forceinline__ double qsqrt(double x) {
+#if LHW_FASTDIV
+  double y = __builtin_amdgcn_rsq(x);
+  double g = x * y, h = 0.5 * y;
+  double r = fma(-h, g, 0.5);
+  g = fma(g, r, g); h = fma(h, r, h);
+  g = fma(fma(-g, g, x), h, g);
+  return x == 0.0 ? 0.0 : g;
+#else
+  return sqrt(x);
+#endif
+}
 __device__ __forceinline__ double dot3(const double* a, const double* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
 __device__ __forceinline__ void cross3(double* r, const double* a, const double* b) {
   double x = a[1] * b[2] - a[2] * b[1], y = a[2] * b[0] - a[0] * b[2], z = a[0] * b[1] - a[1] * b[0];
   r[0] = x; r[1] = y; r[2] = z;
 }
 __device__ __forceinline__ double normalize3(double* a) {
-  double n = sqrt(dot3(a, a));
+  double n = qsqrt(dot3(a, a));
   if (n < HMINVAL) { a[0] = 1; a[1] = 0; a[2] = 0; return n; }
-  double inv = 1.0 / n;
+  double inv = qdiv(1.0, n);
   a[0] *= inv; a[1] *= inv; a[2] *= inv;
   return n;
 }
 __device__ __forceinline__ void normalize4(double* q) {
-  double n = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  double n = qsqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
   if (n < HMINVAL) { q[0] = 1; q[1] = q[2] = q[3] = 0; return; }
-  double inv = 1.0 / n;
+  double inv = qdiv(1.0, n);
   q[0] *= inv; q[1] *= inv; q[2] *= inv; q[3] *= inv;
 }
 __device__ __forceinline__ void mul_quat(double* r, const double* a, const double* b) {
@@ -722,8 +866,9 @@ __device__ __forceinline__ void mat_mul(double* C, const double* A, const double
     for (int j = 0; j < 3; j++) C[3 * i + j] = A[3 * i] * B[j] + A[3 * i + 1] * B[3 + j] + A[3 * i + 2] * B[6 + j];
 }
 __device__ __forceinline__ void axis_angle_quat(double* q, const double* ax, double ang) {
-  double s = sin(0.5 * ang);
-  q[0] = cos(0.5 * ang); q[1] = ax[0] * s; q[2] = ax[1] * s; q[3] = ax[2] * s;
+  double s, c;
+  sincos(0.5 * ang, &s, &c);
+  q[0] = c; q[1] = ax[0] * s; q[2] = ax[1] * s; q[3] = ax[2] * s;
 }
 // 10-number com-based inertia times spatial motion vector [rot; lin]
 __device__ __forceinline__ void inert_vec(double* r, const double* i, const double* v) {
@@ -762,21 +907,13 @@ __device__ __forceinline__ double row_dot(const double (&row)[NV], const double*
 // two copies (their Schur complements add up: one v_permlane16_swap exchange per value after the chain columns).
 // Lane p holds row p of its half's matrix [[Krr_h, C_h^T], [C_h, T_h]] as R[0 .. NR) (full symmetric row; R[p] itself is
 // never read), its diagonal entry in dg, and element p of the right-hand side.
-__device__ __forceinline__ double rcp_f64(double d) {
-  double x = __builtin_amdgcn_rcp(d);
-  x = fma(fma(-d, x, 1.0), x, x);
-  x = fma(fma(-d, x, 1.0), x, x);
-  return x;
-}
 // column step K of the factorisation with the right-hand side carried along (x <- L^-T x on the fly)
 template <class L, int K>
 __device__ __forceinline__ void chain_col(double (&R)[NR], double& dg, double& x, int p) {
   const double inv = rcp_f64(rbc<K>(dg));
-  const double f = (p < K) ? R[K] * inv : 0.0;   // L[K][p]
-  dg = fma(-f, R[K], dg);
-  x = fma(-f, rbc<K>(x), x);
-#pragma unroll
-  for (int e = 0; e < K; e++) R[e] = fma(-f, rbc<K>(R[e]), R[e]);
+  const double nf = (p < K) ? -(R[K] * inv) : 0.0;   // -L[K][p]
+  dg = fma(nf, R[K], dg);
+  fmac_col<K>(R, x, nf);
 }
 template <class L, int K, int KEND>
 __device__ __forceinline__ void chain_cols(double (&R)[NR], double& dg, double& x, int p) {
@@ -788,17 +925,15 @@ __device__ __forceinline__ void chain_cols(double (&R)[NR], double& dg, double& 
 template <class L, int E>
 __device__ __forceinline__ void chain_fwd(const double (&Lr)[NR], double& x) {
   if constexpr (E < NR) {
-    x = fma(-Lr[E], rbc<E>(x), x);
+    x = fma_rbc<E>(x, Lr[E], x);
     chain_fwd<L, E + 1>(Lr, x);
   }
 }
 // acc += sum_e Mrow[e] * (x held by the lane of row position e)
 template <class L, int E>
 __device__ __forceinline__ void chain_mrow(const double (&Mr)[NR], double x, double& acc) {
-  if constexpr (E < NR) {
-    acc = fma(Mr[E], rbc<E>(x), acc);
-    chain_mrow<L, E + 1>(Mr, x, acc);
-  }
+  static_assert(E == 0, "chain_mrow: whole rows only");
+  fmac_mrow<NR>(Mr, x, acc);
 }
 // x <- K^-1 x.  R, dg: this lane's row / diagonal (copy B of the root: zero; destroyed); rootb: this lane is a root dof's copy B.
 // Root elements of x must be identical in the two copies on entry, and are on return.
@@ -818,7 +953,7 @@ __device__ __forceinline__ double chain_solve(double (&R)[NR], double dg, double
   x *= myinv;
   double Lr[NR];
 #pragma unroll
-  for (int e = 0; e < NR; e++) Lr[e] = (e < p) ? R[e] * myinv : 0.0;   // row p of the unit factor
+  for (int e = 0; e < NR; e++) Lr[e] = (e < p) ? -(R[e] * myinv) : 0.0;   // row p of the unit factor, negated
   chain_fwd<L, 0>(Lr, x);
   return x;
 }
@@ -830,8 +965,6 @@ __device__ __forceinline__ double chain_solve(double (&R)[NR], double dg, double
 // Hillis-Steele scan of map compositions along the row (row_shr 1, 2, 4 [, 8]; identity where a lane has no source) gives every
 // world frame in log2 depth: three rounds of 24 DPP moves + a 3x3 product instead of seven dependent tree levels with an LDS
 // hand-off each.  Bodies without a joint (welded upper body ...) are then one product with the frame of the body they move with.
-#define KIS 4    // kin_i: body jnt_type qposadr joint
-#define KDS 20   // kin_d: R0[9] p0[3] jnt_axis[3] jnt_pos[3] qpos0 pad   (R0, p0: frame relative to the previous jointed body)
 template <int CTRL>
 __device__ __forceinline__ double dpp_row_id(double v, double ident) { return dpp_d<CTRL, 0xf>(v, ident); }
 template <int CTRL>
@@ -853,7 +986,7 @@ __device__ __forceinline__ void affine_scan_round(double (&R)[9], double (&pw)[3
 // kernel instead -- generic-pointer loads of the model tables, callee-saved registers through scratch, every sub-step; round 5, same
 // box, jvrc_step @ 4096: 1.287 -> 1.320 M env-steps/s.  The walking kernels inline them either way.)
 template <bool STEPT, class L>
-__device__ __forceinline__ void fwd_kinematics(const HModel& m, L& S, int lane) {
+__device__ __forceinline__ void fwd_kinematics(HModelRef m, L& S, int lane) {
   double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, pw[3] = {0, 0, 0}, jax[3] = {0, 0, 0}, jps[3] = {0, 0, 0};
   int kb = -1, jt = -1, jid = 0;
   if (lane < 32) {
@@ -974,14 +1107,14 @@ __device__ __forceinline__ void fwd_kinematics(const HModel& m, L& S, int lane) 
 
 // subtree com of the (single) dynamic tree rooted at body 1, cinert, cdof  (mj_comPos)
 template <class L>
-__device__ __forceinline__ void fwd_com(const HModel& m, const HParams& p, L& S, int lane) {
+__device__ __forceinline__ void fwd_com(HModelRef m, HParamsRef p, L& S, int lane) {
   double ms = 0, mx = 0, my = 0, mz = 0;
   if (lane >= 1 && lane < m.nbody && m.body_i[BIS * (lane) + BI_ROOT] == 1) {
     ms = prm_mass(m, S, lane);
     mx = ms * S.U[U_XIPOS + 3 * lane]; my = ms * S.U[U_XIPOS + 3 * lane + 1]; mz = ms * S.U[U_XIPOS + 3 * lane + 2];
   }
   ms = gsum<L::W_>(ms); mx = gsum<L::W_>(mx); my = gsum<L::W_>(my); mz = gsum<L::W_>(mz);
-  const double com[3] = {mx / ms, my / ms, mz / ms};
+  const double com[3] = {qdiv(mx, ms), qdiv(my, ms), qdiv(mz, ms)};
   if (lane == 0) { S.com[0] = com[0]; S.com[1] = com[1]; S.com[2] = com[2]; }
   if (lane >= 1 && lane < m.nbody) {
     const int b = lane;
@@ -1047,13 +1180,13 @@ __device__ __forceinline__ void row_suffix(double (&v)[N]) {   // inclusive suff
 template <class L, int E>
 __device__ __forceinline__ void chain_mlow(const double (&buf)[6], const double (&cd)[6], double (&t)[NR]) {
   if constexpr (E < NR) {
-    t[E] = buf[0] * rbc<E>(cd[0]) + buf[1] * rbc<E>(cd[1]) + buf[2] * rbc<E>(cd[2]) + buf[3] * rbc<E>(cd[3]) + buf[4] * rbc<E>(cd[4]) + buf[5] * rbc<E>(cd[5]);
+    t[E] = fmac_dot6<E>(buf, cd);
     chain_mlow<L, E + 1>(buf, cd, t);
   }
 }
 #define U_TB (L::X_)   // transposition buffer [2][NR][NR] (stage B region; dead before and after)
 template <class L>
-__device__ __forceinline__ void chain_dynamics(const HModel& m, const HParams& p, L& S, const int lane, const int dof, const bool prim,
+__device__ __forceinline__ void chain_dynamics(HModelRef m, HParamsRef p, L& S, const int lane, const int dof, const bool prim,
                                                double (&Mrow)[NR], double& mdiag, double& marm, double& bias, double& qapp) {
   const int cp = lane & 15, hh = (lane >> 4) & 1, dd = dof >= 0 ? dof : 0;
   const bool isdof = dof >= 0, rootb = isdof && !prim;
@@ -1204,7 +1337,7 @@ struct ConSink {
         else { Z.U[U_CDIST + c] = dist; for (int a = 0; a < 3; a++) Z.con_pos[3 * c + a] = pos[a]; }
         // mju_makeFrame
         normalize3(f);
-        if (sqrt(dot3(f + 3, f + 3)) < 0.5) {
+        if (dot3(f + 3, f + 3) < 0.25) {
           f[3] = f[4] = f[5] = 0;
           if (f[1] < 0.5 && f[1] > -0.5) f[4] = 1; else f[5] = 1;
         }
@@ -1243,9 +1376,9 @@ __device__ __forceinline__ void col_plane_sphere(ConSink<L>& k, const double* p1
 template <class L>
 __device__ __forceinline__ void col_sphere_sphere(ConSink<L>& k, const double* p1, double r1, const double* p2, double r2, double margin) {
   double dif[3] = {p2[0] - p1[0], p2[1] - p1[1], p2[2] - p1[2]};
-  const double cd = sqrt(dot3(dif, dif)), dist = cd - r1 - r2;
+  const double cd = qsqrt(dot3(dif, dif)), dist = cd - r1 - r2;
   if (dist > margin) return;
-  if (cd < HMINVAL) { dif[0] = 1; dif[1] = dif[2] = 0; } else { dif[0] /= cd; dif[1] /= cd; dif[2] /= cd; }
+  if (cd < HMINVAL) { dif[0] = 1; dif[1] = dif[2] = 0; } else { dif[0] = qdiv(dif[0], cd); dif[1] = qdiv(dif[1], cd); dif[2] = qdiv(dif[2], cd); }
   double pos[3];
   const double zero[3] = {0, 0, 0};
   for (int a = 0; a < 3; a++) pos[a] = p1[a] + dif[a] * (r1 + 0.5 * dist);
@@ -1277,7 +1410,7 @@ __device__ __forceinline__ double sel3(int i, double a0, double a1, double a2) {
 // whole narrow phase lives in registers: the first version kept the clipped polygon in scratch memory and cost ~58 k
 // cycles per sub-step for a wave with feet on boxes.
 template <class L>
-__device__ __noinline__ void col_box_box(BoxRec& k, const HModel& m, const L& S, int q, int g1, int g2, double margin) {
+__device__ __noinline__ void col_box_box(BoxRec& k, HModelRef m, const L& S, int q, int g1, int g2, double margin) {
   double p1[3], p2[3], R1[9], R2[9], s1[3], s2[3];
 #pragma unroll
   for (int a = 0; a < 3; a++) { p1[a] = S.U[U_GPOS + 3 * g1 + a]; p2[a] = S.U[U_GPOS + 3 * g2 + a]; s1[a] = m.pair_d[PDS * q + PD_SIZE1 + a]; s2[a] = m.pair_d[PDS * q + PD_SIZE2 + a]; }
@@ -1322,7 +1455,7 @@ __device__ __noinline__ void col_box_box(BoxRec& k, const HModel& m, const L& S,
       const double tl = ta[i2] * R[i1][j] - ta[i1] * R[i2][j];
       const double ra = s1[i1] * AR[i2][j] + s1[i2] * AR[i1][j], rb = s2[j1] * AR[i][j2] + s2[j2] * AR[i][j1];
       if (len2 >= 1e-12) {
-        const double s = (fabs(tl) - ra - rb) / sqrt(len2);
+        const double s = (fabs(tl) - ra - rb) * rsqrt_f64(len2);
         sep = sep || s > margin;
         if (s > ebest) { ebest = s; ecode = 6 + 3 * i + j; }
       }
@@ -1461,12 +1594,12 @@ __device__ __forceinline__ bool sphere_box_raw(const double* p1, double r, const
   double ctr[3], cl[3], v[3], nl[3], pl[3];
   for (int a = 0; a < 3; a++) ctr[a] = R2[a] * d[0] + R2[3 + a] * d[1] + R2[6 + a] * d[2];   // R2^T d
   for (int a = 0; a < 3; a++) { cl[a] = ctr[a] > size[a] ? size[a] : (ctr[a] < -size[a] ? -size[a] : ctr[a]); v[a] = ctr[a] - cl[a]; }
-  const double dist = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+  const double dist = qsqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
   double pen;
   if (dist > HMINVAL) {
     pen = dist - r;
     if (pen > margin) return false;
-    for (int a = 0; a < 3; a++) { nl[a] = v[a] / dist; pl[a] = cl[a] + nl[a] * (0.5 * pen); }
+    for (int a = 0; a < 3; a++) { nl[a] = qdiv(v[a], dist); pl[a] = cl[a] + nl[a] * (0.5 * pen); }
   } else {
     int kf = 0;
     double depth = size[0] - fabs(ctr[0]);
@@ -1500,7 +1633,7 @@ __device__ __forceinline__ double seg_box_slope(const double* c0, const double* 
 // scalar branch): models without such pairs -- the stand-ins -- must not pay for this code (inside collide_pair's dispatch
 // chain the compiler speculated parts of it for every pair: +8 % VALU instructions per sub-step).
 template <class L>
-__device__ void collide_primbox(ConSink<L>& k, const HModel& m, const L& S, int q, int g1, int g2, double margin) {
+__device__ void collide_primbox(ConSink<L>& k, HModelRef m, const L& S, int q, int g1, int g2, double margin) {
   const double zero[3] = {0, 0, 0};
   const int t1 = m.pair_i[PIS * q + PI_TYPE1];
   double p1[3], p2[3], R1[9], R2[9], s1[3], s2[3];
@@ -1557,7 +1690,7 @@ __device__ void collide_primbox(ConSink<L>& k, const HModel& m, const L& S, int 
 }
 
 template <class L>
-__device__ void collide_pair(ConSink<L>& k, const HModel& m, const L& S, int q, int g1, int g2, double margin) {
+__device__ void collide_pair(ConSink<L>& k, HModelRef m, const L& S, int q, int g1, int g2, double margin) {
   const double zero[3] = {0, 0, 0};
   const int t1 = m.pair_i[PIS * q + PI_TYPE1], t2 = m.pair_i[PIS * q + PI_TYPE2];
   double p1[3], p2[3], R1[9], R2[9], s1[3], s2[3];
@@ -1593,11 +1726,11 @@ __device__ void collide_pair(ConSink<L>& k, const HModel& m, const L& S, int q, 
     const double ma = dot3(a1, a1), mb = -dot3(a1, a2), mc = dot3(a2, a2), u = -dot3(a1, dif), v = dot3(a2, dif);
     const double det = ma * mc - mb * mb;
     if (fabs(det) >= HMINVAL) {
-      double x1 = (mc * u - mb * v) / det, x2 = (ma * v - mb * u) / det;
-      if (x1 > s1[1]) { x1 = s1[1]; x2 = (v - mb * s1[1]) / mc; }
-      else if (x1 < -s1[1]) { x1 = -s1[1]; x2 = (v + mb * s1[1]) / mc; }
-      if (x2 > s2[1]) { x2 = s2[1]; x1 = fmin(s1[1], fmax(-s1[1], (u - mb * s2[1]) / ma)); }
-      else if (x2 < -s2[1]) { x2 = -s2[1]; x1 = fmin(s1[1], fmax(-s1[1], (u + mb * s2[1]) / ma)); }
+      double x1 = qdiv(mc * u - mb * v, det), x2 = qdiv(ma * v - mb * u, det);
+      if (x1 > s1[1]) { x1 = s1[1]; x2 = qdiv(v - mb * s1[1], mc); }
+      else if (x1 < -s1[1]) { x1 = -s1[1]; x2 = qdiv(v + mb * s1[1], mc); }
+      if (x2 > s2[1]) { x2 = s2[1]; x1 = fmin(s1[1], fmax(-s1[1], qdiv(u - mb * s2[1], ma))); }
+      else if (x2 < -s2[1]) { x2 = -s2[1]; x1 = fmin(s1[1], fmax(-s1[1], qdiv(u + mb * s2[1], ma))); }
       double q1[3], q2[3];
       for (int a = 0; a < 3; a++) { q1[a] = p1[a] + a1[a] * x1; q2[a] = p2[a] + a2[a] * x2; }
       col_sphere_sphere(k, q1, s1[0], q2, s2[0], margin);
@@ -1630,7 +1763,7 @@ __device__ void collide_pair(ConSink<L>& k, const HModel& m, const L& S, int q, 
 // a call, whose prologue and epilogue save and restore 42 callee-saved VGPRs through scratch in every sub-step, besides what the
 // caller spills around the call; round 5, same box, jvrc_step @ 4096: rollout 1.228 -> 1.169 s.  col_box_box inlined as well: 1.249 s.)
 template <bool BOXBOX, class L>
-__device__ __forceinline__ void fwd_collision(const HModel& m, const HParams& p, L& S, int lane, gtab_d ter, gws_d bd, gws_i bi) {
+__device__ __forceinline__ void fwd_collision(HModelRef m, HParamsRef p, L& S, int lane, gtab_d ter, gws_d bd, gws_i bi) {
   FINE_BEGIN(3);
   if (lane < m.ngeom) {
     const int g = lane, b = m.geom_i[GIS * (g) + GI_BODY];
@@ -1975,7 +2108,7 @@ __device__ __forceinline__ void fwd_collision(const HModel& m, const HParams& p,
 }
 
 // getsolparam + getimpedance + KBIP + R for one row
-__device__ __forceinline__ void row_params(const HModel& m, const double* sr_in, const double* si_in, double pos, double margin,
+__device__ __forceinline__ void row_params(HModelRef m, const double* sr_in, const double* si_in, double pos, double margin,
                                            double diagApprox, double* K, double* B, double* imp, double* R) {
   double sr0 = sr_in[0], sr1 = sr_in[1];
   if (!(m.disableflags & (1 << 11)) && sr0 > 0 && sr0 < 2 * m.timestep) sr0 = 2 * m.timestep;
@@ -1984,26 +2117,26 @@ __device__ __forceinline__ void row_params(const HModel& m, const double* sr_in,
   double im;
   if (s0 == s1 || s2 <= HMINVAL) im = 0.5 * (s0 + s1);
   else {
-    double x = fabs((pos - margin) / s2);
+    double x = fabs(qdiv(pos - margin, s2));
     if (x >= 1) im = s1;
     else if (x <= 0) im = s0;
     else {
       double y;
       if (s4 == 1) y = x;
-      else if (s4 == 2) y = (x <= s3) ? x * x / s3 : 1 - (1 - x) * (1 - x) / (1 - s3);  // default solimp power, no pow()
+      else if (s4 == 2) y = (x <= s3) ? qdiv(x * x, s3) : 1 - qdiv((1 - x) * (1 - x), 1 - s3);  // default solimp power, no pow()
       else if (x <= s3) y = pow(x, s4) / pow(s3, s4 - 1);
       else y = 1 - pow(1 - x, s4) / pow(1 - s3, s4 - 1);
       im = s0 + y * (s1 - s0);
     }
   }
   *imp = im;
-  *R = fmax(HMINVAL, (1 - im) / im * diagApprox);
+  *R = fmax(HMINVAL, qdiv(1 - im, im) * diagApprox);
   if (sr0 > 0) {
-    *K = 1 / fmax(HMINVAL, s1 * s1 * sr0 * sr0 * sr1 * sr1);
-    *B = 2 / fmax(HMINVAL, s1 * sr0);
+    *K = qdiv(1, fmax(HMINVAL, s1 * s1 * sr0 * sr0 * sr1 * sr1));
+    *B = qdiv(2, fmax(HMINVAL, s1 * sr0));
   } else {
-    *K = -sr0 / fmax(HMINVAL, s1 * s1);
-    *B = -sr1 / fmax(HMINVAL, s1);
+    *K = qdiv(-sr0, fmax(HMINVAL, s1 * s1));
+    *B = qdiv(-sr1, fmax(HMINVAL, s1));
   }
 }
 // mj_constraintUpdate for one row at residual x = J a - aref: limit / contact rows are one-sided quadratics, frictionloss
@@ -2012,7 +2145,7 @@ __device__ __forceinline__ void row_eval(bool valid, double fl, double D, double
   double c = 0, f = 0, da = 0;
   if (valid) {
     if (fl > 0) {
-      const double Rf = fl / D;
+      const double Rf = qdiv(fl, D);
       if (x <= -Rf) { f = fl; c = -0.5 * Rf * fl - fl * x; }
       else if (x >= Rf) { f = -fl; c = -0.5 * Rf * fl + fl * x; }
       else { f = -D * x; c = 0.5 * D * x * x; da = D; }
@@ -2025,7 +2158,7 @@ __device__ __forceinline__ void row_deriv(bool valid, double fl, double D, doubl
   double a = 0, b = 0;
   if (valid) {
     if (fl > 0) {
-      const double Rf = fl / D;
+      const double Rf = qdiv(fl, D);
       if (x <= -Rf) a = -fl * jv;
       else if (x >= Rf) a = fl * jv;
       else { a = D * x * jv; b = D * jv * jv; }
@@ -2056,14 +2189,14 @@ __device__ __forceinline__ double dense_factor_solve(L& S, double (&row)[NV], co
       t -= row[k] * xs[k];
     }
     if (prim && d == j) {
-      const double piv = sqrt(fmax(s, HMINVAL));
+      const double piv = qsqrt(fmax(s, HMINVAL));
       A[TRI(j, j)] = piv;
-      y = t / piv;
+      y = qdiv(t, piv);
       xs[j] = y;
     }
     SYNC();
     if (prim && d > j) {
-      row[j] = s / A[TRI(j, j)];
+      row[j] = qdiv(s, A[TRI(j, j)]);
       A[TRI(d, j)] = row[j];
     }
     SYNC();
@@ -2072,7 +2205,7 @@ __device__ __forceinline__ double dense_factor_solve(L& S, double (&row)[NV], co
   double xd = 0.0;
 #pragma unroll
   for (int j = NV - 1; j >= 0; j--) {
-    if (prim && d == j) { xd = y / A[TRI(j, j)]; xs[j] = xd; }
+    if (prim && d == j) { xd = qdiv(y, A[TRI(j, j)]); xs[j] = xd; }
     SYNC();
     if (prim && d < j) y -= A[TRI(j, d)] * xs[j];
   }
@@ -2130,7 +2263,7 @@ __device__ __forceinline__ double dense_lds_solve(L& S, const double (&Hrow)[NR]
 // Slow by construction (~100 contacts = ~400 rows = seven chunks per sweep, five to six sweeps per sub-step): it exists so that the
 // terrain of the reference is the terrain of the kernel, not to be fast.
 template <class L>
-__device__ __noinline__ void newton_big(const HModel& m, const HParams& p, L& S, const int lane, gws_d __restrict__ bd, gws_i __restrict__ bi,
+__device__ __noinline__ void newton_big(HModelRef m, HParamsRef p, L& S, const int lane, gws_d __restrict__ bd, gws_i __restrict__ bi,
                                         const int dof, const bool prim, const double (&Mrow)[NR], const double mdiag, const double marm,
                                         const double fs, const double as, const bool (&uon)[3], const double (&uD)[3],
                                         const double (&uaref)[3], const double ufl, const bool anyunit, double& qacc_out, double& fcon_out) {
@@ -2226,7 +2359,7 @@ __device__ __noinline__ void newton_big(const HModel& m, const HParams& p, L& S,
         const double diag = dim == 1 ? tran : tran + mu * mu * tran;
         row_params(m, &bd[BW_SOLREF + 2 * c], &bd[BW_SOLIMP + 5 * c], bd[BW_DIST + c], bd[BW_MARGIN + c], diag, &K, &B, &imp, &R);
         if (dim == 3) R = fmax(HMINVAL, 2 * mu * mu * R);
-        D = (1 / R) * bd[BW_MULT + c];   // (k identical contacts merged by the collision stage: one row with k times the D)
+        D = qdiv(1, R) * bd[BW_MULT + c];   // (k identical contacts merged by the collision stage: one row with k times the D)
         aref = -B * jv0 - K * imp * (bd[BW_DIST + c] - bd[BW_MARGIN + c]);
       }
       bd[BW_D + r] = D; bd[BW_AREF + r] = aref;   // D == 0: not a row (its cost, force and derivatives are zero)
@@ -2330,7 +2463,7 @@ __device__ __noinline__ void newton_big(const HModel& m, const HParams& p, L& S,
     if (dof >= 0) { fcon = ((f0 + f1) + (f2 + f3)) + ufrc; grad = Ma - fs - fcon; }
     double gn;
     gsum2<W>(c, prim ? grad * grad : 0.0, cost, gn);
-    gn = sqrt(gn);
+    gn = qsqrt(gn);
     if (iter > 0) { if (scale * (oldcost - cost) < m.tolerance || scale * gn < m.tolerance) break; }
     else if (scale * gn < m.tolerance) break;
     if (iter == m.iterations) break;
@@ -2380,7 +2513,7 @@ __device__ __noinline__ void newton_big(const HModel& m, const HParams& p, L& S,
         const double d0 = fabs(d1);
         double lo = 0, hi = -1;
         for (int it = 0; it < 40; it++) {
-          double a = alpha - d1 / d2;
+          double a = alpha - qdiv(d1, d2);
           if (hi >= 0 && (a <= lo || a >= hi)) a = 0.5 * (lo + hi);
           deriv_all(a, &d1, &d2);
           d1 += 2 * a * qg2 + qg1;
@@ -2430,7 +2563,7 @@ __device__ __noinline__ void newton_big(const HModel& m, const HParams& p, L& S,
 // Dofs sit in the half-env-per-DPP-row layout of the chain solver: a root dof is held by two lanes, `prim` marks the one that
 // counts in sums over dofs and writes the dof's results.  `cross`: some contact couples the two chains (group-uniform).
 template <class L>
-__device__ __forceinline__ void solve_tail(const HModel& m, const HParams& p, L& S, const int lane, const int flags, long long* st_prof,
+__device__ __forceinline__ void solve_tail(HModelRef m, HParamsRef p, L& S, const int lane, const int flags, long long* st_prof,
                                            const int dof, const bool prim, const bool cross, const double (&Mrow)[NR], const double mdiag,
                                            const double marm, const double qapp, const double bias, gws_d bd, gws_i bi) {
   constexpr int W = L::W_;
@@ -2501,7 +2634,7 @@ __device__ __forceinline__ void solve_tail(const HModel& m, const HParams& p, L&
       const double diag = dim == 1 ? tran : tran + mu * mu * tran;
       row_params(m, &S.U[U_CSOLREF + 2 * c], &S.U[U_CSOLIMP + 5 * c], S.U[U_CDIST + c], S.U[U_CMARGIN + c], diag, &K, &B, &imp, &R);
       if (dim == 3) R = fmax(HMINVAL, 2 * mu * mu * R);  // every pyramid edge shares 2 mu^2 R(first edge)
-      D = 1 / R;
+      D = qdiv(1, R);
       if constexpr (L::STEP_) D *= S.con_mult[c];   // k identical contacts merged by the collision stage: one row with k times the D
       aref = -B * jv0 - K * imp * (S.U[U_CDIST + c] - S.U[U_CMARGIN + c]);
     }
@@ -2517,7 +2650,7 @@ __device__ __forceinline__ void solve_tail(const HModel& m, const HParams& p, L&
       double sr[2] = {m.dof_d[DDS * d + DD_SOLREF], m.dof_d[DDS * d + DD_SOLREF + 1]}, si[5], K, B, imp, R;
       for (int a = 0; a < 5; a++) si[a] = m.dof_d[DDS * d + DD_SOLIMP + a];
       row_params(m, sr, si, 0.0, 0.0, m.dof_d[DDS * d + DD_INVW], &K, &B, &imp, &R);
-      uon[0] = true; uD[0] = 1 / R; uaref[0] = -B * qv; ufl = fl;
+      uon[0] = true; uD[0] = qdiv(1, R); uaref[0] = -B * qv; ufl = fl;
     }
     const int j = m.dof_i[DIS * d + DI_JNT];
     if (m.dof_i[DIS * d + DI_KIND] >= 2 && m.dof_i[DIS * d + DI_LIMITED]) {
@@ -2528,11 +2661,11 @@ __device__ __forceinline__ void solve_tail(const HModel& m, const HParams& p, L&
         for (int a = 0; a < 5; a++) si[a] = m.jnt_d[JDS * j + JD_SOLIMP + a];
         if (dlo < mg) {
           row_params(m, sr, si, dlo, mg, m.dof_d[DDS * d + DD_INVW], &K, &B, &imp, &R);
-          uon[1] = true; uD[1] = 1 / R; uaref[1] = -B * qv - K * imp * (dlo - mg);
+          uon[1] = true; uD[1] = qdiv(1, R); uaref[1] = -B * qv - K * imp * (dlo - mg);
         }
         if (dhi < mg) {
           row_params(m, sr, si, dhi, mg, m.dof_d[DDS * d + DD_INVW], &K, &B, &imp, &R);
-          uon[2] = true; uD[2] = 1 / R; uaref[2] = B * qv - K * imp * (dhi - mg);
+          uon[2] = true; uD[2] = qdiv(1, R); uaref[2] = B * qv - K * imp * (dhi - mg);
         }
       }
     }
@@ -2545,8 +2678,8 @@ __device__ __forceinline__ void solve_tail(const HModel& m, const HParams& p, L&
   // transmission + actuation (lane = actuator)
   if (lane < m.nu) {
     const double gear = m.act_d[ADS * (lane) + AD_GEAR];
-    S.sq[lane] = (gear * S.qpos[m.act_i[AIS * lane + AI_QADR]]) / gear;  // actuator_length / gear, as the reference computes it
-    S.sv[lane] = (gear * S.qvel[m.act_i[AIS * lane + AI_DADR]]) / gear;
+    S.sq[lane] = qdiv(gear * S.qpos[m.act_i[AIS * lane + AI_QADR]], gear);  // actuator_length / gear, as the reference computes it
+    S.sv[lane] = qdiv(gear * S.qvel[m.act_i[AIS * lane + AI_DADR]], gear);
     double f = 0;
     if (flags & 1) {
       double c = S.ctrl[lane];
@@ -2683,7 +2816,7 @@ __device__ __forceinline__ void solve_tail(const HModel& m, const HParams& p, L&
       FINE_MARK(7, 2);
       double gn;
       gsum2<W>(c, prim ? grad * grad : 0.0, cost, gn);   // the cost of this iterate and the squared gradient norm in one reduction
-      gn = sqrt(gn);
+      gn = qsqrt(gn);
       if (iter > 0) { if (scale * (oldcost - cost) < m.tolerance || scale * gn < m.tolerance) break; }
       else if (scale * gn < m.tolerance) break;
       if (iter == m.iterations) break;
@@ -2771,7 +2904,7 @@ __device__ __forceinline__ void solve_tail(const HModel& m, const HParams& p, L&
           double lo = 0, hi = -1;
           for (int it = 0; it < 40; it++) {
             if (st_prof && lane == 0) st_prof[14] += 1;   // diagnostic: line-search passes of env 0
-            double a = alpha - d1 / d2;
+            double a = alpha - qdiv(d1, d2);
             if (hi >= 0 && (a <= lo || a >= hi)) a = 0.5 * (lo + hi);
             deriv_rows(a, &r1, &r2);
             gsum2<W>(r1, r2, d1, d2);
@@ -2842,7 +2975,7 @@ __device__ __forceinline__ void solve_tail(const HModel& m, const HParams& p, L&
 // J x is the lane's own element, J^T f lands on the lane's own dof, J^T D J on its own diagonal entry.  Only the summation
 // order differs from the row order of the reference; every row is there.
 template <bool BOXBOX, class L>
-__device__ __forceinline__ void substep(const HModel& m, const HParams& p, L* SG0, int flags, long long* st_prof, gtab_d ter, gws_d bd, gws_i bi) {
+__device__ __forceinline__ void substep(HModelRef m, HParamsRef p, L* SG0, int flags, long long* st_prof, gtab_d ter, gws_d bd, gws_i bi) {
   constexpr int W = L::W_;
 #if defined(__HIP_DEVICE_COMPILE__) && defined(LHW_SUBSTEP_PRIO)
   // (Resident rollout kernels only -- lhw_humanoid_rollout.hip defines LHW_SUBSTEP_PRIO.  In the launch-per-step pipeline the
@@ -2893,7 +3026,7 @@ __device__ __forceinline__ void substep(const HModel& m, const HParams& p, L* SG
   solve_tail(m, p, S, lane, flags, st_prof, dof, prim, cross, Mrow, mdiag, marm, qapp, bias, bd, bi);
 }
 // ------------------------------------------------------------------------------------------------ task layer
-__device__ __forceinline__ void sample_ref(const HParams& p, unsigned genv, unsigned stream, unsigned counter, unsigned slot0,
+__device__ __forceinline__ void sample_ref(HParamsRef p, unsigned genv, unsigned stream, unsigned counter, unsigned slot0,
                                            int mode, double* ref) {
   if (mode == MODE_STANDING) {
     for (int k = 0; k < 3; k++) ref[k] = lhw_rng_uniform(p.seed, genv, stream, counter, slot0 + k, -1.0, 1.0);
@@ -2921,7 +3054,7 @@ __device__ __forceinline__ void quat_roll_pitch(const double* q, double* roll, d
 // home in memory; round 5, same box, jvrc_walk @ 4096: rollout 0.3931 -> 0.3862 s.  The H1 tasks' write_obs_h1 / randomize_dynamics
 // inlined the same way LOSE 1.5 % on h1 @ 8192 and stay calls.)
 template <class L>
-__device__ __forceinline__ void write_obs(const HModel& m, const HParams& p, L& S, int lane, int phase, int mode, const double* mode_ref,
+__device__ __forceinline__ void write_obs(HModelRef m, HParamsRef p, L& S, int lane, int phase, int mode, const double* mode_ref,
                           float* o) {
   // get_obs (base_humanoid_env.py:177-197): fresh root quaternion / angular velocity, stale motor pos/vel
   if (lane == 0) {
@@ -2939,7 +3072,7 @@ __device__ __forceinline__ void write_obs(const HModel& m, const HParams& p, L& 
 
 // jvrc_step observation (jvrc_step.py:66-77): robot state, clock, goal steps x[2] y[2] z[2] theta[2]
 template <class L>
-__device__ void write_obs_step(const HModel& m, const HParams& p, L& S, int lane, int phase, const double* goal, float* o) {
+__device__ void write_obs_step(HModelRef m, HParamsRef p, L& S, int lane, int phase, const double* goal, float* o) {
   if (lane == 0) {
     double r, pt;
     quat_roll_pitch(&S.qpos[3], &r, &pt);
@@ -2953,7 +3086,7 @@ __device__ void write_obs_step(const HModel& m, const HParams& p, L& S, int lane
 }
 
 // external state of the walking envs (jvrc_walk.py:65-67, h1_walk.py:118-123): clock, mode one-hot, mode reference
-__device__ __forceinline__ void write_obs_walk_ext(const HParams& p, int lane, int phase, int mode, const double* mode_ref, float* o) {
+__device__ __forceinline__ void write_obs_walk_ext(HParamsRef p, int lane, int phase, int mode, const double* mode_ref, float* o) {
   if (lane == 0) {
     const double ang = 2 * 3.141592653589793 * (double)phase / (double)p.period;
     o[0] = (float)sin(ang); o[1] = (float)cos(ang);
@@ -2965,7 +3098,7 @@ __device__ __forceinline__ void write_obs_walk_ext(const HParams& p, int lane, i
 // H1 robot state (h1_base.py:95-119): [roll, pitch, ang vel 3, motor pos 10, motor vel 10, motor torque 10] plus uniform
 // observation noise drawn per entry on every get_obs (base_humanoid_env.py:307-338); lane = observation entry
 template <class L>
-__device__ void write_obs_h1(const HModel& m, const HParams& p, L& S, int lane, unsigned genv, unsigned obs_count, float* o,
+__device__ void write_obs_h1(HModelRef m, HParamsRef p, L& S, int lane, unsigned genv, unsigned obs_count, float* o,
                              float* o2) {
   for (int e = lane; e < 35; e += L::W_) {   // e = observation entry (35 > 32: the two-envs-per-wave groups take two passes)
     double v;
@@ -2994,7 +3127,7 @@ __device__ void write_obs_h1(const HModel& m, const HParams& p, L& S, int lane, 
 // offset of pelvis + leg bodies relative to the DEFAULT model.  Writes the LDS copies (used immediately on reset) and
 // the per-env record.  slot0 = first RNG slot (0 on reset, 1 in step).
 template <class L>
-__device__ void randomize_dynamics(const HModel& m, const HParams& p, L& S, double* prm, int lane, unsigned genv,
+__device__ void randomize_dynamics(HModelRef m, HParamsRef p, L& S, double* prm, int lane, unsigned genv,
                                    unsigned stream, unsigned counter, unsigned slot0) {
   if (lane < p.n_rand_dof) {
     const int d = p.rand_dof[lane];
@@ -3034,14 +3167,14 @@ struct LayoutOf {
 };
 
 template <int MODE, int TASK, int W>
-__device__ __forceinline__ bool store_record(const HModel& m, const HLaunch& lz, const HState& st, typename LayoutOf<TASK, W>::type* SG0, const int env,
+__device__ __forceinline__ bool store_record(HModelRef m, const HLaunch& lz, const HState& st, typename LayoutOf<TASK, W>::type* SG0, const int env,
                                              const long long t_launch);
 
 // One control step (MODE 0), reset (1), set_state (2) or get_state (3) of env `env` by the group of W lanes that calls it
 // (`lane` = lane within the group, S = the group's LDS working set).  Returns true iff the env exceeded the contact capacity
 // of the two-envs-per-wave layout before anything of this control step was written: the caller repeats the step with W = 64.
 template <int MODE, int TASK, int W>
-__device__ __forceinline__ bool control_step(const HModel& m, const HParams& p, const HLaunch& lz, const HState& st, typename LayoutOf<TASK, W>::type* SG0,
+__device__ __forceinline__ bool control_step(HModelRef m, HParamsRef p, const HLaunch& lz, const HState& st, typename LayoutOf<TASK, W>::type* SG0,
                                              typename LayoutOf<TASK, W>::type& S, const int env,
                                              const int lane, const float* __restrict__ act, float* __restrict__ obs, float* __restrict__ term_obs,
                                              float* __restrict__ rew, unsigned char* __restrict__ done_out, float* __restrict__ rew_terms,
@@ -3125,7 +3258,7 @@ __device__ __forceinline__ bool control_step(const HModel& m, const HParams& p, 
         if (lane < m.nu) {
           // step_pd on the transmission fields of the previous forward pass (note S); ctrl = tau / gear
           const double tau = p.kp[lane] * (target - S.sq[lane]) + p.kd[lane] * (0.0 - S.sv[lane]);
-          S.ctrl[lane] = tau / m.act_d[ADS * (lane) + AD_GEAR];
+          S.ctrl[lane] = qdiv(tau, m.act_d[ADS * (lane) + AD_GEAR]);
         }
         SYNC();
         kstep++;
@@ -3623,7 +3756,7 @@ __device__ __forceinline__ bool control_step(const HModel& m, const HParams& p, 
 
 // The persistent record goes back to HBM (lane-strided); everything it needs is re-derived from the env index and a fresh lane.
 template <int MODE, int TASK, int W>
-__device__ __forceinline__ bool store_record(const HModel& m, const HLaunch& lz, const HState& st, typename LayoutOf<TASK, W>::type* SG0, const int env,
+__device__ __forceinline__ bool store_record(HModelRef m, const HLaunch& lz, const HState& st, typename LayoutOf<TASK, W>::type* SG0, const int env,
                                              const long long t_launch) {
   using L = typename LayoutOf<TASK, W>::type;
   FRESH_GROUP(W, SG0);

@@ -195,7 +195,7 @@ __device__ __forceinline__ void policy_step(const LhwRolloutPolicy& q, float* sc
 
 // Control steps [t0, t1) of env group `grp` of the range (the G envs one wave advances together).
 template <int TASK, int W>
-__device__ __forceinline__ void rollout_steps(const HModel& m, const HParams& p, const HLaunch& lz, const HState& st, const HRollout& ro, unsigned char* SGraw, int grp,
+__device__ __forceinline__ void rollout_steps(HModelRef m, HParamsRef p, const HLaunch& lz, const HState& st, const HRollout& ro, unsigned char* SGraw, int grp,
                                               int t0, int t1) {
   using L = typename LayoutOf<TASK, W>::type;
   using L1 = typename LayoutOf<TASK, 64>::type;
@@ -284,8 +284,8 @@ __global__ void __launch_bounds__(64, LHW_WAVES_PER_SIMD) humanoid_rollout_kerne
   static_assert(L::USIZE_ * 2 - 48 >= PolicyLds<G>::FLOATS, "the policy step's activations must fit the stage region in front of the observation staging");
   __shared__ __attribute__((aligned(16))) unsigned char SGraw[LDS_BYTES];
   LHW_LDS_POISON(SGraw);
-  const HParams& p = *pp;
-  const HModel& m = *mp;
+  HParamsRef p = *(const HParams LHW_GLOBAL_AS*)pp;
+  HModelRef m = *(const HModel LHW_GLOBAL_AS*)mp;
   const int n_groups = (lz.env_count + G - 1) / G;
   if constexpr (!QUEUE) {
     if ((int)blockIdx.x >= n_groups) return;
