@@ -524,6 +524,16 @@ __host__ __device__ __forceinline__ int opaque_zero() {
 #endif
 }
 
+// A value the optimiser must take as it finds it HERE: everything computed from it stays behind this point.  Used at the entry of
+// rarely executed code (the dense fallback solve) so that its lane predicates -- dozens of 64-bit masks -- are formed inside the
+// branch instead of being hoisted above it, held in SGPRs across the common path and spilled there (round 6: 136 v_writelane per
+// sub-step in front of the Newton loop were the masks of a solve that runs in one sub-step of a thousand).
+__host__ __device__ __forceinline__ int opaque_int(int v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("" : "+v"(v));
+#endif
+  return v;
+}
 // The lanes of a group belong to one wavefront, and a wave's LDS instructions execute in issue order, so cross-lane
 // hand-offs through LDS need no hardware barrier and no s_waitcnt: __syncthreads() would add a workgroup-scope fence, i.e.
 // s_waitcnt vmcnt(0) lgkmcnt(0) -- a full drain of outstanding global loads -- ~60 times per sub-step.  A wavefront-scope
@@ -2172,9 +2182,11 @@ __device__ __forceinline__ void row_deriv(bool valid, double fl, double D, doubl
 // row stays in registers (statically indexed: the column loops are fully unrolled), the pivot row is read as LDS broadcasts off the
 // dependency chain, the right-hand side is carried through the factorisation.  Packed lower triangle of the factor in the U_L region.
 template <class L>
-__device__ __forceinline__ double dense_factor_solve(L& S, double (&row)[NV], const double hd, const double x, const int dof, const bool prim) {
+__device__ __forceinline__ double dense_factor_solve(L& S, double (&row)[NV], const double hd, const double x, const int dof_in, const bool prim_in) {
   double* A = S.U + U_L;
   double* xs = S.U + U_DG;
+  const int dof = opaque_int(dof_in);
+  const bool prim = opaque_int(prim_in ? 1 : 0) != 0;
   const int d = dof >= 0 ? dof : 0;
   SYNC();
   double y = x;   // right-hand side element, then y = L^-1 b
