@@ -172,6 +172,10 @@ def main():
     ap.add_argument("--no-mirror", action="store_true")
     ap.add_argument("--infer-fp16", action="store_true", help="rollout inference with fp16 operands; update stays f32")
     ap.add_argument("--fp16", action="store_true", help="BASELINE config 5: fp16 actor / critic (inference and every GEMM of the update with fp16 operands, f32 accumulation / master weights / Adam)")
+    ap.add_argument("--task-hook", choices=["none", "walking", "walking-own-done"], default="none",
+                    help="measurement of the BaseTask seam (task_hook.py; walking envs): the reference's WalkingTask as a PLUG-IN instead of "
+                         "the fused task -- 'walking': reward-only (resident rollout + one batched evaluation), 'walking-own-done': the task "
+                         "also decides terminations (launch-per-step, host-side resets)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -217,7 +221,12 @@ def main():
         mirror_coeff=0.4, eval_freq=10**9, recurrent=False, imitate=None, imitate_coeff=0.3, learn_std=False,
         std_dev=0.223, no_mirror=args.no_mirror, infer_fp16=args.infer_fp16, fp16=args.fp16, continued=None, logdir=os.path.join("/tmp", f"lhw_bench_{os.getpid()}"),
         device_index=local_rank)
-    algo = PPO(spec_cls, ppo_args, seed=0)
+    hook = None
+    if args.task_hook != "none":
+        from learninghumanoidwalking_amd.task_hook import VectorWalkingTask
+        own = args.task_hook == "walking-own-done"
+        hook = (lambda spec, dev: VectorWalkingTask(spec, dev, height_limits=(0.6, 1.4000001))) if own else (lambda spec, dev: VectorWalkingTask(spec, dev))
+    algo = PPO(spec_cls, ppo_args, seed=0, task=hook)
     if algo.obs_rms is not None:  # cartpole path: frozen running normalisation after a short warm-up (ppo.py:442-457)
         b = algo.sample_parallel_with_workers()
         algo.obs_rms.update(b.states.cpu().numpy())

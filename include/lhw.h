@@ -178,6 +178,14 @@ typedef struct {
  * steps) jobs instead of keeping one env each (the cost of an env follows its walking mode; same values either way). */
 int lhw_env_rollout(LhwEnv* env, const LhwRolloutPolicy* policy, int32_t first, int32_t count, int32_t T, float* obs_dev, float* act_dev,
                     float* logp_dev, float* term_obs_dev, float* rew_dev, uint8_t* done_dev, float* rew_terms_dev, void* stream);
+/* lhw_env_rollout that also exports the batched sim facade (below) of EVERY control step: tin_dev [T][N][LHW_TASK_INPUT_DIM] float64
+ * receives, per control step and env, the record lhw_env_get_task_inputs would return after that step -- what the reference's robot
+ * hands its exchangeable task once per control step (robots/robot_base.py:88-96: task.step / calc_reward / done reading RobotInterface).
+ * For task code that only changes the REWARD (an edited tasks/rewards.py): the rollout runs resident with the fused termination and
+ * resets, and the plug-in evaluates the whole [T * N] batch once after the launch (task_hook.py).  Everything else as lhw_env_rollout. */
+int lhw_env_rollout_task_inputs(LhwEnv* env, const LhwRolloutPolicy* policy, int32_t first, int32_t count, int32_t T, float* obs_dev,
+                                float* act_dev, float* logp_dev, float* term_obs_dev, float* rew_dev, uint8_t* done_dev, float* rew_terms_dev,
+                                double* tin_dev, void* stream);
 /* Parity hooks; HOST pointers, synchronous.  qpos [N][nq], qvel [N][nv] float64. */
 int lhw_env_get_state(LhwEnv* env, double* qpos_host, double* qvel_host);
 int lhw_env_set_state(LhwEnv* env, const double* qpos_host, const double* qvel_host);

@@ -174,12 +174,14 @@ class BatchedEnv:
                                               _ptr(done), _ptr(self.rew_terms), _stream_ptr(self.device)))
 
     def rollout(self, policy, T: int, obs: torch.Tensor, act: torch.Tensor, logp: torch.Tensor, term_obs: torch.Tensor, rew: torch.Tensor,
-                done: torch.Tensor, first: int = 0, count: int | None = None) -> bool:
+                done: torch.Tensor, first: int = 0, count: int | None = None, task_inputs: torch.Tensor | None = None) -> bool:
         """The resident rollout (lhw_env_rollout): T control steps of envs [first, first + count) in ONE launch on the current
         stream, the actor (`policy`: PpoKernels.rollout_policy()) evaluated inside the stepper's wavefronts -- the body of
         RolloutWorker.sample's loop (reference rl/workers/rollout_worker.py:142-181) with no wavefront waiting for another env.
         Buffers are time-major over the full batch: obs [T + 1, N, D] (slice 0 in), act [T, N, A], logp / rew / done [T, N],
-        term_obs [T, N, D].  Returns False (nothing launched) where the library has no resident kernel for this env / policy."""
+        term_obs [T, N, D].  `task_inputs` [T, N, TASK_INPUT_DIM] float64 (optional): the sim-facade record of EVERY control step
+        (lhw_env_rollout_task_inputs), for reward-only task plug-ins.  Returns False (nothing launched) where the library has no
+        resident kernel for this env / policy; a HIP failure raises."""
         N = self.n_envs
         if self.history_len > 1 or policy is None or not hasattr(self._L, "lhw_env_rollout"):
             return False
@@ -187,9 +189,14 @@ class BatchedEnv:
         assert logp.shape == (T, N) and rew.shape == (T, N) and done.shape == (T, N) and done.dtype == torch.uint8
         for x in (obs, act, logp, term_obs, rew, done):
             assert x.is_cuda and x.is_contiguous()
-        rc = self._L.lhw_env_rollout(self._h, ctypes.byref(policy), int(first), int(N - first if count is None else count), int(T), _ptr(obs),
-                                     _ptr(act), _ptr(logp), _ptr(term_obs), _ptr(rew), _ptr(done), _ptr(self.rew_terms), _stream_ptr(self.device))
-        if rc == -4:      # LHW_ERR_UNSUPPORTED
+        args = (self._h, ctypes.byref(policy), int(first), int(N - first if count is None else count), int(T), _ptr(obs),
+                _ptr(act), _ptr(logp), _ptr(term_obs), _ptr(rew), _ptr(done), _ptr(self.rew_terms))
+        if task_inputs is not None:
+            assert task_inputs.shape == (T, N, _lib.TASK_INPUT_DIM) and task_inputs.dtype == torch.float64 and task_inputs.is_cuda and task_inputs.is_contiguous()
+            rc = self._L.lhw_env_rollout_task_inputs(*args, _ptr(task_inputs), _stream_ptr(self.device))
+        else:
+            rc = self._L.lhw_env_rollout(*args, _stream_ptr(self.device))
+        if rc == -4:      # LHW_ERR_UNSUPPORTED: the caller keeps the launch-per-step pipeline (anything else -- LHW_ERR_HIP ... -- raises)
             return False
         _lib.check(rc)
         return True

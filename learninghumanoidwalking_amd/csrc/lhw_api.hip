@@ -225,17 +225,28 @@ extern "C" int lhw_env_step_range(LhwEnv* e, int32_t first, int32_t count, const
   return LHW_OK;
 }
 
-extern "C" int lhw_env_rollout(LhwEnv* e, const LhwRolloutPolicy* policy, int32_t first, int32_t count, int32_t T, float* obs_dev, float* act_dev,
-                               float* logp_dev, float* term_obs_dev, float* rew_dev, uint8_t* done_dev, float* rew_terms_dev, void* stream) {
+static int env_rollout_impl(LhwEnv* e, const LhwRolloutPolicy* policy, int32_t first, int32_t count, int32_t T, float* obs_dev, float* act_dev,
+                            float* logp_dev, float* term_obs_dev, float* rew_dev, uint8_t* done_dev, float* rew_terms_dev, double* tin_dev, void* stream) {
   if (!e || !policy || !obs_dev || !act_dev || !logp_dev || !term_obs_dev || !rew_dev || !done_dev) return lhw_fail(LHW_ERR_ARG, "null argument");
   if (e->task == LHW_TASK_CARTPOLE) return lhw_fail(LHW_ERR_UNSUPPORTED, "lhw_env_rollout: wave-per-env (humanoid) steppers only");
   HIPCHK(hipSetDevice(e->device));
-  const int rc = humanoid_rollout(e->hum, first, count, T, policy, obs_dev, act_dev, logp_dev, term_obs_dev, rew_dev, done_dev, rew_terms_dev, (hipStream_t)stream);
+  const int rc = humanoid_rollout(e->hum, first, count, T, policy, obs_dev, act_dev, logp_dev, term_obs_dev, rew_dev, done_dev, rew_terms_dev, tin_dev, (hipStream_t)stream);
   if (rc == -1) return lhw_fail(LHW_ERR_ARG, "env range [%d, %d) outside the batch, or T = %d", first, first + count, T);
+  if (rc == -4) return lhw_fail(LHW_ERR_HIP, "lhw_env_rollout: a HIP call failed while preparing the launch (%s)", hipGetErrorString(hipGetLastError()));
   if (rc) return lhw_fail(LHW_ERR_UNSUPPORTED, "lhw_env_rollout: needs a float32 actor obs %d -> 256 -> 256 -> act %d (<= 12) and a model that fits the task's resident kernel",
                           e->obs_dim, e->act_dim);
   HIPCHK(hipGetLastError());
   return LHW_OK;
+}
+extern "C" int lhw_env_rollout(LhwEnv* e, const LhwRolloutPolicy* policy, int32_t first, int32_t count, int32_t T, float* obs_dev, float* act_dev,
+                               float* logp_dev, float* term_obs_dev, float* rew_dev, uint8_t* done_dev, float* rew_terms_dev, void* stream) {
+  return env_rollout_impl(e, policy, first, count, T, obs_dev, act_dev, logp_dev, term_obs_dev, rew_dev, done_dev, rew_terms_dev, nullptr, stream);
+}
+extern "C" int lhw_env_rollout_task_inputs(LhwEnv* e, const LhwRolloutPolicy* policy, int32_t first, int32_t count, int32_t T, float* obs_dev, float* act_dev,
+                                           float* logp_dev, float* term_obs_dev, float* rew_dev, uint8_t* done_dev, float* rew_terms_dev, double* tin_dev,
+                                           void* stream) {
+  if (!tin_dev) return lhw_fail(LHW_ERR_ARG, "lhw_env_rollout_task_inputs: null task-input buffer");
+  return env_rollout_impl(e, policy, first, count, T, obs_dev, act_dev, logp_dev, term_obs_dev, rew_dev, done_dev, rew_terms_dev, tin_dev, stream);
 }
 
 extern "C" int lhw_env_get_state(LhwEnv* e, double* qpos_host, double* qvel_host) {

@@ -541,7 +541,7 @@ int humanoid_create(HumanoidEnv** out, const std::vector<int32_t>& mi, const std
   if (p.task == TASK_WALK && !getenv("LHW_NO_RESET_TEMPLATE")) {
     // reset the template record (index N) once with the ordinary reset kernel; auto-resets copy its state from then on
     if (!humanoid_upload_params(h)) { humanoid_destroy(h); return lhw_fail(LHW_ERR_HIP, "humanoid_create: parameter upload failed"); }
-    const HLaunch lz{(int)N, 1, 0, 0};
+    const HLaunch lz{(int)N, 1, 0, 0, 0};
     hipLaunchKernelGGL((humanoid_kernel<1, TASK_WALK, 64>), dim3(1), dim3(64), 0, 0, (const HModel*)h->m_dev, (const HParams*)h->p_dev, lz, h->st, (const float*)nullptr, (float*)nullptr,
                        (float*)nullptr, (float*)nullptr, (unsigned char*)nullptr, (float*)nullptr, (const unsigned char*)nullptr, (double*)nullptr,
                        (double*)nullptr);
@@ -571,7 +571,7 @@ void humanoid_destroy(HumanoidEnv* h) {
 #define LAUNCH_RANGE(MODE, WIDTH, FLAGGED, FIRST, COUNT, ...)                                                       \
   do {                                                                                                             \
     const HParams& pp_ = h->p;                                                                                     \
-    const HLaunch lz_{(FIRST), (COUNT), (FLAGGED), h->iteration};                                                  \
+    const HLaunch lz_{(FIRST), (COUNT), (FLAGGED), h->iteration, 0};                                                \
     /* the re-run launch scans the flags with few workgroups (at most 64 envs each): see humanoid_kernel */           \
     const int full_ = (lz_.env_count + (64 / WIDTH) - 1) / (64 / WIDTH);                                            \
     const dim3 grid_((FLAGGED) ? std::min(full_, std::max(256, (lz_.env_count + 63) / 64)) : full_);                \

@@ -279,6 +279,8 @@ struct HLaunch {
   int env_first, env_count;             // sub-range of envs this launch advances (lhw_env_step_range); blockIdx.x is relative to it
   int only_flagged;                     // 1: advance only the envs whose st.slow flag is set (re-run of fast-path overflows), clearing it
   int iteration;                        // training iteration (stepping-task curriculum)
+  long long tin_off;                    // offset (doubles) of this control step's slice of st.tin: 0 for the per-launch record; t * N * LHW_TASK_INPUT_DIM
+                                        // when a resident rollout exports the record of EVERY control step (lhw_env_rollout_task_inputs)
 };
 
 struct HState {
@@ -2622,6 +2624,8 @@ __device__ __forceinline__ void solve_tail(HModelRef m, HParamsRef p, L& S, cons
   // ---- contact rows (lane = row): Jacobian row -> registers, impedance / regulariser / reference acceleration
   // (the row is re-read from LDS for each product instead of being held across the factorisations: 36 VGPRs that the
   // Cholesky needs more)
+  // (round 6, measured and not adopted: the row held in registers across the products -- it fits since the v_fmac_f64_dpp change, 0.3213-0.3221 s
+  // against 0.3218-0.3219 s per rollout, same box: profiles/r06_stepper_ab_jrow_other_envs.txt)
   auto jrow_dot = [&](const double* v) {
     double Jrow[NV];
 #pragma unroll
@@ -2632,6 +2636,7 @@ __device__ __forceinline__ void solve_tail(HModelRef m, HParamsRef p, L& S, cons
     const double d = row_dot<L>(Jrow, v);
     return lane < nrow ? d : 0.0;   // rows beyond the last contact are not initialised
   };
+
   bool isrow = false;
   double D = 0, aref = 0;
   {
@@ -3492,7 +3497,7 @@ __device__ __forceinline__ bool control_step(HModelRef m, HParamsRef p, const HL
           terminated = z < 0.9 || z > 1.4 || self_collision;  // standing_task.py:111-131
         }
         if (st.tin) {   // the batched sim facade (include/lhw.h: LhwTaskInput)
-          double* ti = st.tin + (size_t)env * LHW_TASK_INPUT_DIM;
+          double* ti = st.tin + lz.tin_off + (size_t)env * LHW_TASK_INPUT_DIM;
           double rv3[3], lv3[3], rl3[3], vl3[3];
           body_linvel(S, 1, p.rfoot_body, rv3); body_linvel(S, 2, p.lfoot_body, lv3); body_linvel(S, 0, p.root_body, rl3);
           matT_vec(vl3, S.rootmat, rl3);

@@ -57,6 +57,7 @@ struct HRollout {
   // in the order (chunk 0 of every group, chunk 1 of every group, ...), queue[1 + group] counts the group's finished chunks.
   unsigned* queue;
   int chunk;
+  long long tin_step;    // doubles per control step of the task-input export (n_total * LHW_TASK_INPUT_DIM), 0: the per-launch record (or none)
   LhwRolloutPolicy pol;
 };
 
@@ -239,14 +240,16 @@ __device__ __forceinline__ void rollout_steps(HModelRef m, HParamsRef p, const H
     float* rew_t = ro.rew + (size_t)t * N;
     unsigned char* done_t = ro.done + (size_t)t * N;
     bool ovf = false;
+    HLaunch lzt = lz;
+    lzt.tin_off = (long long)t * ro.tin_step;   // (the batched sim facade of EVERY control step, for reward-only task plug-ins: lhw_env_rollout_task_inputs)
     if (g < nlive)
-      ovf = control_step<0, TASK, W>(m, p, lz, st, SG, SG[g], env0 + g, lane, act_t, obs_n, tob_t, rew_t, done_t, ro.rew_terms, nullptr, nullptr);
+      ovf = control_step<0, TASK, W>(m, p, lzt, st, SG, SG[g], env0 + g, lane, act_t, obs_n, tob_t, rew_t, done_t, ro.rew_terms, nullptr, nullptr);
 #ifndef LHW_RO_NO_RERUN   // (analysis builds: without the in-wave re-run, to see what its code costs the hot path -- nothing measurable)
     if constexpr (W == 32) {
       GROUP_SYNC(64);
       const unsigned long long ob = __ballot(ovf);
       if (ob) {
-        HLaunch lz1 = lz;
+        HLaunch lz1 = lzt;
         lz1.only_flagged = 1;   // (store_record clears the env's flag and counts the re-run)
         L1* S1 = reinterpret_cast<L1*>(SGraw);
         for (int gg = 0; gg < 2; gg++)
@@ -313,12 +316,12 @@ __global__ void __launch_bounds__(64, LHW_WAVES_PER_SIMD) humanoid_rollout_kerne
 #define ROLLOUT_OTHER_TASKS(WIDTH)
 #else
 #define ROLLOUT_OTHER_TASKS(WIDTH)                                                                                                                              \
-  else if (h->p.task == TASK_H1WALK) hipLaunchKernelGGL((humanoid_rollout_kernel<TASK_H1WALK, WIDTH, false>), grid, dim3(64), 0, s, (const HModel*)h->m_dev, (const HParams*)h->p_dev, lz, h->st, ro); \
-  else hipLaunchKernelGGL((humanoid_rollout_kernel<TASK_STAND, WIDTH, false>), grid, dim3(64), 0, s, (const HModel*)h->m_dev, (const HParams*)h->p_dev, lz, h->st, ro);
+  else if (h->p.task == TASK_H1WALK) hipLaunchKernelGGL((humanoid_rollout_kernel<TASK_H1WALK, WIDTH, false>), grid, dim3(64), 0, s, (const HModel*)h->m_dev, (const HParams*)h->p_dev, lz, st, ro); \
+  else hipLaunchKernelGGL((humanoid_rollout_kernel<TASK_STAND, WIDTH, false>), grid, dim3(64), 0, s, (const HModel*)h->m_dev, (const HParams*)h->p_dev, lz, st, ro);
 #endif
 
 int humanoid_rollout(HumanoidEnv* h, int first, int count, int T, const LhwRolloutPolicy* pol, float* obs, float* act, float* logp, float* term_obs,
-                     float* rew, uint8_t* done, float* rew_terms, hipStream_t s) {
+                     float* rew, uint8_t* done, float* rew_terms, double* tin_all, hipStream_t s) {
   if (first < 0 || count <= 0 || first + count > h->p.n_envs || T <= 0) return -1;
   const int obs_dim = h->p.task == TASK_STEP ? 39 : (h->p.task == TASK_WALK ? 37 : (h->p.task == TASK_H1WALK ? 43 : 35));
   if (pol->hidden != PH || pol->obs_dim != obs_dim || pol->act_dim != h->m.nu || pol->act_pad > PO_MAX || (pol->act_pad & 3) || pol->act_pad < pol->act_dim ||
@@ -329,7 +332,10 @@ int humanoid_rollout(HumanoidEnv* h, int first, int count, int T, const LhwRollo
   ro.obs = obs; ro.act = act; ro.logp = logp; ro.tob = term_obs; ro.rew = rew; ro.done = done; ro.rew_terms = rew_terms;
   ro.pol = *pol;
   ro.queue = nullptr; ro.chunk = 0;
-  const HLaunch lz{first, count, 0, h->iteration};
+  ro.tin_step = tin_all ? (long long)h->p.n_envs * LHW_TASK_INPUT_DIM : 0;
+  HState st = h->st;
+  if (tin_all) st.tin = tin_all;   // [T][n_envs][LHW_TASK_INPUT_DIM]: every control step's record instead of the last one's
+  const HLaunch lz{first, count, 0, h->iteration, 0};
   if (!h->fast && h->p.task != TASK_STEP) return -3;   // a walking / standing model that does not fit the two-envs-per-wave layout (or LHW_ONE_ENV_PER_WAVE): launch-per-step only
   // Stepping task with more env groups than wave slots: the resident waves share a job queue of `chunk`-step pieces instead of a
   // group each (humanoid_rollout_kernel<.., QUEUE = true>).  LHW_ROLLOUT_CHUNK: control steps per job (default 10; 0 = one wave per
@@ -365,12 +371,12 @@ int humanoid_rollout(HumanoidEnv* h, int first, int count, int T, const LhwRollo
   }
   const dim3 grid(grid_n);
   if (h->fast) {
-    if (h->p.task == TASK_WALK) hipLaunchKernelGGL((humanoid_rollout_kernel<TASK_WALK, 32, false>), grid, dim3(64), 0, s, (const HModel*)h->m_dev, (const HParams*)h->p_dev, lz, h->st, ro);
+    if (h->p.task == TASK_WALK) hipLaunchKernelGGL((humanoid_rollout_kernel<TASK_WALK, 32, false>), grid, dim3(64), 0, s, (const HModel*)h->m_dev, (const HParams*)h->p_dev, lz, st, ro);
     ROLLOUT_OTHER_TASKS(32)
   } else {
 #ifndef LHW_ONLY_WALK
-    if (ro.queue) hipLaunchKernelGGL((humanoid_rollout_kernel<TASK_STEP, 64, true>), grid, dim3(64), 0, s, (const HModel*)h->m_dev, (const HParams*)h->p_dev, lz, h->st, ro);
-    else hipLaunchKernelGGL((humanoid_rollout_kernel<TASK_STEP, 64, false>), grid, dim3(64), 0, s, (const HModel*)h->m_dev, (const HParams*)h->p_dev, lz, h->st, ro);
+    if (ro.queue) hipLaunchKernelGGL((humanoid_rollout_kernel<TASK_STEP, 64, true>), grid, dim3(64), 0, s, (const HModel*)h->m_dev, (const HParams*)h->p_dev, lz, st, ro);
+    else hipLaunchKernelGGL((humanoid_rollout_kernel<TASK_STEP, 64, false>), grid, dim3(64), 0, s, (const HModel*)h->m_dev, (const HParams*)h->p_dev, lz, st, ro);
 #endif
   }
   return 0;

@@ -113,6 +113,11 @@ class Rollout:
         # task: a task_hook.VectorTask evaluated OUTSIDE the kernels after every control step; its reward / termination replace
         # the fused ones and the rollout, not the env, truncates at max_traj_len and resets (see _collect_hooked)
         self.task, self.max_traj_len = task, int(max_traj_len if max_traj_len is not None else T)
+        if task is not None and getattr(env, "history_len", 1) > 1:
+            # (the hooked paths write the reset observation / history rows themselves and know nothing of the env-side history deque)
+            raise NotImplementedError("a plugged-in task with obs_history_len > 1 is not supported")
+        self.reward_only = bool(task is not None and getattr(task, "reward_only", False))
+        self._tin_all = None
         N, D, A, dev = env.n_envs, env.obs_dim, env.act_dim, env.device
         self.N = N
         self.obs = torch.zeros(T + 1, N, D, dtype=torch.float32, device=dev)
@@ -202,7 +207,9 @@ class Rollout:
                       want_value=False, want_mu=False, act=self.act[t], logp=self.logp[t])
             env.step(self.act[t], obs_out=self.obs[t + 1], term_obs_out=self.tob_all[t], rew_out=self._scratch_rew, done_out=self._scratch_done)
             rew, term = self.task.evaluate(ti)
-            bad = ~torch.isfinite(rew)                 # a diverged env (the kernel has sanitised its state): the episode ends
+            # a diverged env (the kernel has sanitised its state, the record is exported before that): the episode ends -- whatever
+            # the plugged task's reward looks at
+            bad = ~torch.isfinite(rew) | ~torch.isfinite(ti.qpos).all(1) | ~torch.isfinite(ti.qvel).all(1) | ~torch.isfinite(ti.qacc).all(1)
             rew = torch.where(bad, torch.zeros_like(rew), rew)
             term = term.bool() | bad
             self.rew[t].copy_(rew)
@@ -211,14 +218,96 @@ class Rollout:
             trunc = self._traj_len >= self.max_traj_len
             self.done[t].copy_(term.to(torch.uint8) | (trunc.to(torch.uint8) << 1))
             ended = term | trunc
-            if bool(ended.any()):
-                self._stats += torch.stack([(self._ep_ret * ended).sum(), (self._traj_len * ended).sum().double(), ended.sum().double()])
-                self.task.reset(ended)
-                env.reset(ended.to(torch.uint8), obs_out=self.obs[t + 1])      # rows of the other envs are left untouched
-                self._traj_len[ended] = 0
-                self._ep_ret[ended] = 0
+            # (no host round trip per control step: the statistics are masked sums and the reset launch takes the mask as it is --
+            # an all-zero mask is a launch whose waves return at once)
+            self._stats += torch.stack([(self._ep_ret * ended).sum(), (self._traj_len * ended).sum().double(), ended.sum().double()])
+            self.task.reset(ended)
+            env.reset(ended.to(torch.uint8), obs_out=self.obs[t + 1])      # rows of the other envs are left untouched
+            self._traj_len.masked_fill_(ended, 0)
+            self._ep_ret.masked_fill_(ended, 0)
             self.counter += 1
         self.last_mode = "hooked"
+
+    # ---- reward-only plug-ins: the kernel keeps its own termination / truncation / resets, the task supplies the reward
+    def _hook_state(self):
+        dev = self.obs.device
+        if not hasattr(self, "_traj_len"):
+            self._traj_len = torch.zeros(self.N, dtype=torch.int32, device=dev)
+            self._ep_ret = torch.zeros(self.N, dtype=torch.float64, device=dev)
+            self._stats = torch.zeros(3, dtype=torch.float64, device=dev)      # sum of returns, sum of lengths, episodes
+
+    def _episode_stats_from_buffers(self):
+        """Finished-episode returns / lengths of this rollout from self.rew (the plugged task's rewards) and self.done (the kernel's
+        flags), vectorised over [T, N]; episodes carried in from / out to the neighbouring rollouts through _ep_ret / _traj_len."""
+        self._hook_state()
+        T, N, dev = self.T, self.N, self.obs.device
+        ended = self.done != 0
+        cc = torch.cumsum(self.rew.double(), dim=0)
+        tt = torch.arange(T, device=dev, dtype=torch.int64).unsqueeze(1).expand(T, N)
+        last = torch.cummax(torch.where(ended, tt, torch.full_like(tt, -1)), dim=0).values          # last end at or before t
+        prev = torch.cat([torch.full((1, N), -1, dtype=torch.int64, device=dev), last[:-1]], dim=0)  # last end strictly before t
+        has_prev = prev >= 0
+        base = torch.where(has_prev, cc.gather(0, prev.clamp(min=0)), torch.zeros_like(cc))
+        ret = cc - base + torch.where(has_prev, torch.zeros_like(cc), self._ep_ret.unsqueeze(0).expand(T, N))
+        length = torch.where(has_prev, tt - prev, tt + 1 + self._traj_len.unsqueeze(0).to(torch.int64))
+        e = ended.double()
+        self._stats += torch.stack([(ret * e).sum(), (length.double() * e).sum(), e.sum()])
+        fin = last[-1]                                                                                # last end of the column (-1: none)
+        none = fin < 0
+        tail = cc[-1] - torch.where(none, torch.zeros_like(cc[-1]), cc.gather(0, fin.clamp(min=0).unsqueeze(0)).squeeze(0))
+        self._ep_ret = torch.where(none, self._ep_ret + cc[-1], tail)
+        self._traj_len = torch.where(none, self._traj_len.to(torch.int64) + T, (T - 1) - fin).to(torch.int32)
+
+    def _evaluate_reward_batch(self, rec):
+        """The plugged task's reward for [M, TASK_INPUT_DIM] records (non-finite -> 0: the kernel ended that episode itself)."""
+        from .task_hook import TaskInputs
+        env = self.env
+        rew, _ = self.task.evaluate(TaskInputs(rec, env.nq, env.nv, env.act_dim))
+        return torch.where(torch.isfinite(rew), rew, torch.zeros_like(rew)).float()
+
+    def _collect_resident_hooked(self, deterministic) -> bool:
+        """Reward-only task plug-ins at the resident rollout's speed: one lhw_env_rollout_task_inputs launch (fused termination,
+        truncation and resets; the sim-facade record of every control step exported, [T][N][160] float64), then ONE evaluation of
+        the task over the whole batch -- RobotBase.step's `task.calc_reward` (robots/robot_base.py:88-96) moved behind the rollout,
+        which it may be because a reward does not feed back into the simulation."""
+        env, k, T = self.env, self.k, self.T
+        mode = os.environ.get("LHW_ROLLOUT_MODE", "auto")
+        if mode not in ("auto", "resident") or not hasattr(env, "rollout") or not hasattr(k, "rollout_policy"):
+            return False
+        if not hasattr(env._L, "lhw_env_rollout_task_inputs") or getattr(env, "env_id_base", 0) != self.env_base:
+            return False
+        pol = k.rollout_policy(seed=self.seed, counter=self.counter, deterministic=deterministic)
+        if pol is None:
+            return False
+        self._pol_keep = pol
+        if self._tin_all is None:
+            self._tin_all = _lib.empty(T, self.N, _lib.TASK_INPUT_DIM, dtype=torch.float64, device=self.obs.device)
+        if not env.rollout(pol, T, self.obs, self.act, self.logp, self.tob_all, self.rew, self.done, task_inputs=self._tin_all):
+            return False
+        self.counter += T
+        rec = self._tin_all.reshape(T * self.N, -1)
+        rew = self.rew.reshape(-1)
+        chunk = max(self.N, (1 << 19) // self.N * self.N)      # whole time slices, about half a million rows per evaluation
+        for a in range(0, rec.shape[0], chunk):
+            rew[a:a + chunk] = self._evaluate_reward_batch(rec[a:a + chunk])
+        self._episode_stats_from_buffers()
+        return True
+
+    def _collect_reward_only_steps(self, deterministic):
+        """The same plug-in on the launch-per-step pipeline (LHW_ROLLOUT_MODE=steps, or no resident kernel for this env / policy):
+        the kernel's own flags and resets, the task's reward per control step, no host round trip."""
+        from .task_hook import device_task_inputs
+        env, k, T = self.env, self.k, self.T
+        ti = device_task_inputs(env)
+        if not hasattr(self, "_scratch_rew"):
+            self._scratch_rew = torch.zeros(self.N, dtype=torch.float32, device=self.obs.device)
+        for t in range(T):
+            k.forward(self.obs[t], seed=self.seed, env_id_base=self.env_base, counter=self.counter, deterministic=deterministic,
+                      want_value=False, want_mu=False, act=self.act[t], logp=self.logp[t])
+            env.step(self.act[t], obs_out=self.obs[t + 1], term_obs_out=self.tob_all[t], rew_out=self._scratch_rew, done_out=self.done[t])
+            self.rew[t].copy_(self._evaluate_reward_batch(ti.rec))
+            self.counter += 1
+        self._episode_stats_from_buffers()
 
     def pop_episode_stats(self):
         """(sum of finished-episode returns, sum of their lengths, their number) since the last call -- the env's own counters, or,
@@ -251,6 +340,8 @@ class Rollout:
         if getattr(env, "env_id_base", 0) != self.env_base:
             return False
         if not env.rollout(pol, T, self.obs, self.act, self.logp, self.tob_all, self.rew, self.done):
+            if mode == "resident":
+                raise _lib.LhwError(-4, "LHW_ROLLOUT_MODE=resident, but the library has no resident rollout kernel for this env / policy")
             return False
         self.counter += T
         return True
@@ -259,7 +350,13 @@ class Rollout:
         env, k, T = self.env, self.k, self.T
         G = self.groups
         self.last_mode = "steps"      # which path collected the last rollout (tests, bench line)
-        if self.task is not None:
+        if self.task is not None and self.reward_only:
+            if self._collect_resident_hooked(deterministic):
+                self.last_mode = "resident"
+            else:
+                self._collect_reward_only_steps(deterministic)
+                self.last_mode = "hooked"
+        elif self.task is not None:
             self._collect_hooked(deterministic)
         elif self._collect_resident(deterministic):
             self.last_mode = "resident"
@@ -450,11 +547,13 @@ class PPO:
         self.env_seed = env_seed
         if task is not None and self.recurrent:
             raise NotImplementedError("a plugged-in task needs the feed-forward policies")
-        # (with a task plugged in the env never ends an episode by itself: the rollout truncates and resets, Rollout._collect_hooked)
-        self.env = spec.make_batched(self.n_proc, seed=env_seed, device=self.device, max_traj_len=0 if task is not None else self.max_traj_len,
+        self.task = task(spec, self.device) if task is not None else None
+        # A task that decides terminations itself is consulted after every control step and the env never ends an episode by itself:
+        # the rollout truncates and resets (Rollout._collect_hooked).  A reward-only task leaves all that to the kernel.
+        own_done = self.task is not None and not getattr(self.task, "reward_only", False)
+        self.env = spec.make_batched(self.n_proc, seed=env_seed, device=self.device, max_traj_len=0 if own_done else self.max_traj_len,
                                      env_id_base=dist_utils.shard_env_ids(self.n_proc, self.rank))
         self.env.env_id_base = dist_utils.shard_env_ids(self.n_proc, self.rank)
-        self.task = task(spec, self.device) if task is not None else None
         self.rollout = Rollout(self.env, self.kernels, self.max_traj_len, seed=env_seed ^ 0x5DEECE66D, task=self.task, max_traj_len=self.max_traj_len)
         # --imitate: frozen expert + the env's projector (reference rl/algos/ppo.py:111-122)
         self.base_policy, self.imitation_projector = None, None

@@ -73,7 +73,14 @@ def device_task_inputs(env) -> TaskInputs:
 
 
 class VectorTask:
-    """Batched counterpart of the reference's BaseTask (tasks/base_task.py:12-83) for one control step of N envs."""
+    """Batched counterpart of the reference's BaseTask (tasks/base_task.py:12-83) for one control step of N envs.
+
+    `reward_only = True` declares that the task changes the REWARD only -- its termination rule is the fused task's (the common
+    case: an edited tasks/rewards.py, other term weights).  The rollout then stays resident (one launch per rollout, the kernel's
+    own termination / truncation / resets), exports the record of every control step, and `evaluate` is called ONCE over the whole
+    [T * N] batch after the launch; the `done` it returns is ignored (Rollout._collect_resident_hooked).  With False (default)
+    the task is consulted after every control step and decides terminations itself (Rollout._collect_hooked)."""
+    reward_only = False
 
     def evaluate(self, ti: TaskInputs):
         """-> (reward [N] float tensor, done [N] bool tensor); called once per control step, after the env step"""
@@ -87,6 +94,7 @@ class VectorWalkingTask(VectorTask):
     """WalkingTask.calc_reward + done (reference tasks/walking_task.py:85-147, 184-192; tasks/rewards.py:9-194) on the exported
     inputs, vectorised over the batch in float64 torch.  `weights` overrides the reference's term weights by name."""
 
+    reward_only = True      # done() below IS the fused WalkingTask.done: the resident rollout may keep the kernel's own flags
     TERMS = ("foot_frc_score", "foot_vel_score", "root_accel", "height_error", "com_vel_error", "yaw_vel_error", "upper_body_reward",
              "posture_error", "torque_penalty", "action_penalty")
     WEIGHTS = dict(foot_frc_score=0.225, foot_vel_score=0.225, root_accel=0.050, height_error=0.050, com_vel_error=0.150,
@@ -94,6 +102,8 @@ class VectorWalkingTask(VectorTask):
     STANDING, INPLACE, FORWARD = 0, 1, 2      # the kernels' mode codes (tasks/walking_task.py: WalkModes)
 
     def __init__(self, spec, device, weights: dict | None = None, height_limits=(0.6, 1.4)):
+        if tuple(height_limits) != (0.6, 1.4):
+            self.reward_only = False      # another termination rule than the fused one: consulted step by step
         self.w = dict(self.WEIGHTS, **(weights or {}))
         unknown = set(self.w) - set(self.TERMS)
         if unknown:

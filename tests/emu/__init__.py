@@ -127,14 +127,19 @@ class EmuBatchedEnv:
                                          self.rew.ctypes.data, self.done.ctypes.data, self.rew_terms.ctypes.data, None))
         return self.obs, self.rew, self.done, self.term_obs
 
-    def rollout(self, policy, T, obs, act, logp, tob, rew, done, first=0, count=None):
-        """lhw_env_rollout on numpy buffers (time-major over the full batch; obs[0] is the input)."""
+    def rollout(self, policy, T, obs, act, logp, tob, rew, done, first=0, count=None, task_inputs=None):
+        """lhw_env_rollout on numpy buffers (time-major over the full batch; obs[0] is the input); task_inputs [T][N][TASK_INPUT_DIM]
+        float64: lhw_env_rollout_task_inputs (the sim-facade record of every control step)."""
         N = self.n_envs
         assert obs.shape == (T + 1, N, self.obs_dim) and act.shape == (T, N, self.act_dim) and tob.shape == (T, N, self.obs_dim)
         assert all(a.flags.c_contiguous for a in (obs, act, logp, tob, rew, done))
-        self._check(self._L.lhw_env_rollout(self._h, ctypes.byref(policy), int(first), int(N - first if count is None else count), int(T),
-                                            obs.ctypes.data, act.ctypes.data, logp.ctypes.data, tob.ctypes.data, rew.ctypes.data,
-                                            done.ctypes.data, self.rew_terms.ctypes.data, None))
+        args = (self._h, ctypes.byref(policy), int(first), int(N - first if count is None else count), int(T),
+                obs.ctypes.data, act.ctypes.data, logp.ctypes.data, tob.ctypes.data, rew.ctypes.data, done.ctypes.data, self.rew_terms.ctypes.data)
+        if task_inputs is not None:
+            assert task_inputs.dtype == np.float64 and task_inputs.shape[:2] == (T, N) and task_inputs.flags.c_contiguous
+            self._check(self._L.lhw_env_rollout_task_inputs(*args, task_inputs.ctypes.data, None))
+        else:
+            self._check(self._L.lhw_env_rollout(*args, None))
 
     def get_state(self):
         q, v = np.zeros((self.n_envs, self.nq)), np.zeros((self.n_envs, self.nv))

@@ -236,3 +236,47 @@ def test_fp16_operand_policy_step_rounds_every_operand_and_accumulates_in_float3
     env2 = emu.make_emulated(spec, N, seed=6, max_traj_len=0)
     c = _resident(env2, pol, 1, env2.reset().copy())
     assert not np.array_equal(b["act"], c["act"]) and np.abs(b["act"] - c["act"]).max() < 2e-2
+
+
+def test_resident_rollout_exports_the_task_inputs_of_every_control_step():
+    """lhw_env_rollout_task_inputs: the [T][N][160] record a reward-only task plug-in evaluates after the launch equals, step by step,
+    what lhw_env_get_task_inputs returns behind each control step of the launch-per-step pipeline (robots/robot_base.py:88-96: what
+    the robot hands its task once per control step) -- with a truncation / auto-reset and a two-envs-per-wave overflow re-run inside."""
+    from learninghumanoidwalking_amd import _lib as product
+    from learninghumanoidwalking_amd.envs.jvrc_walk import JvrcWalkSpec
+    spec = JvrcWalkSpec()
+    N, T = 5, 6
+    envs = [emu.make_emulated(spec, N, seed=3, max_traj_len=4) for _ in range(2)]
+    pol = NumpyActor(37, 12, seed=5, scale=2.0)
+    q, v = _fallen_states(spec, N, seed=21)
+    for e in envs:
+        e.reset()
+        e.set_state(q, v)
+    obs0 = np.zeros((N, 37), np.float32)
+    L = emu.lib()
+    # launch per step, the record read back after every control step
+    envs[0].enable_task_inputs(True)
+    a = _buffers(T, N, 37, 12)
+    a["obs"][0] = obs0
+    want = np.zeros((T, N, product.TASK_INPUT_DIM))
+    y = np.zeros((N, pol.view.act_pad), np.float32)
+    for t in range(T):
+        assert L.lhw_debug_policy_step(ctypes.byref(pol.view), a["obs"][t].ctypes.data, N, 0, pol.view.counter + t, y.ctypes.data,
+                                       a["act"][t].ctypes.data, a["logp"][t].ctypes.data, None) == 0
+        obs, rew, done, tob = envs[0].step(a["act"][t])
+        a["obs"][t + 1], a["rew"][t], a["done"][t], a["tob"][t] = obs, rew, done, tob
+        rec = np.zeros((N, product.TASK_INPUT_DIM))
+        envs[0]._check(L.lhw_env_get_task_inputs(envs[0]._h, rec.ctypes.data))
+        want[t] = rec
+    # one launch, every record
+    b = _buffers(T, N, 37, 12)
+    b["obs"][0] = obs0
+    got = np.full((T, N, product.TASK_INPUT_DIM), np.nan)
+    envs[1].rollout(pol.view, T, b["obs"], b["act"], b["logp"], b["tob"], b["rew"], b["done"], task_inputs=got)
+    _same(a, b)
+    used = np.zeros(product.TASK_INPUT_DIM, bool)
+    for name, (o, n) in product.TASK_INPUT_FIELDS.items():
+        n = dict(qpos=19, qvel=18, qacc=18).get(name, n)
+        used[o:o + n] = True
+    np.testing.assert_array_equal(got[:, :, used], want[:, :, used])
+    assert (a["done"] & 2).any() and envs[0].pop_rerun_count() == envs[1].pop_rerun_count() > 0

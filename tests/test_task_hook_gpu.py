@@ -48,14 +48,22 @@ def _train(task, iters=2, N=24, T=10, env="jvrc_walk"):
     return algo, rews, dones, stats
 
 
-def test_training_through_the_task_hook_reproduces_the_fused_task():
+def test_training_through_the_task_hook_reproduces_the_fused_task(monkeypatch):
+    """(the rewards module is the reference's own file where /root/reference exists -- the build container -- and the restatement
+    tests/test_specs.py pins to it on the GPU box)"""
     from learninghumanoidwalking_amd.task_hook import PerEnvRewards, VectorWalkingTask
     fused, rf, df, sf = _train(None)
     assert fused.rollout.last_mode in ("resident", "steps")
     slow, rs, ds, ss = _train(lambda spec, dev: PerEnvRewards(_rewards_module(), spec))          # tasks/rewards.py, env by env
-    vect, rv, dv, sv = _train(lambda spec, dev: VectorWalkingTask(spec, dev))                   # the same task, torch-vectorised
-    assert slow.rollout.last_mode == vect.rollout.last_mode == "hooked"
-    for other_r, other_d, other_s, other in ((rs, ds, ss, slow), (rv, dv, sv, vect)):
+    vect, rv, dv, sv = _train(lambda spec, dev: VectorWalkingTask(spec, dev))                   # the same task, torch-vectorised, reward-only
+    own, ro, do, so = _train(lambda spec, dev: VectorWalkingTask(spec, dev, height_limits=(0.6, 1.4000001)))   # ... deciding terminations itself
+    monkeypatch.setenv("LHW_ROLLOUT_MODE", "steps")
+    stp, rp, dp, sp = _train(lambda spec, dev: VectorWalkingTask(spec, dev))                    # reward-only on the launch-per-step pipeline
+    monkeypatch.delenv("LHW_ROLLOUT_MODE")
+    assert slow.rollout.last_mode == own.rollout.last_mode == stp.rollout.last_mode == "hooked"
+    # a reward-only task keeps the resident rollout: one launch, the record of every control step, one evaluation behind it
+    assert vect.rollout.last_mode == fused.rollout.last_mode and vect.rollout.reward_only and not own.rollout.reward_only
+    for other_r, other_d, other_s, other in ((rs, ds, ss, slow), (rv, dv, sv, vect), (ro, do, so, own), (rp, dp, sp, stp)):
         for a, b in zip(rf, other_r):
             np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=0, atol=1e-6)
         for a, b in zip(df, other_d):
