@@ -223,7 +223,8 @@ enum LhwTaskInput {
   LHW_TIN_PREV_TORQUE = 123,  /* calc_reward(prev_torque, prev_action, action) */
   LHW_TIN_PREV_ACTION = 135,
   LHW_TIN_ACTION = 147,
-  LHW_TASK_INPUT_DIM = 160
+  LHW_TIN_ROOT_XMAT = 160,    /* 9: get_object_affine_by_name(root body)'s rotation, row-major (standing_task.py:76-85: the torso in the pelvis frame) */
+  LHW_TASK_INPUT_DIM = 176
 };
 int lhw_env_enable_task_inputs(LhwEnv* env, int enable);
 /* HOST pointer [N][LHW_TASK_INPUT_DIM] float64, synchronous; humanoid tasks only, after lhw_env_enable_task_inputs(env, 1). */

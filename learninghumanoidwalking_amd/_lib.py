@@ -38,11 +38,11 @@ class LhwRolloutPolicy(ctypes.Structure):      # include/lhw.h: the frozen actor
 
 
 # include/lhw.h: enum LhwTaskInput (offsets into one env's record, length)
-TASK_INPUT_DIM = 160
+TASK_INPUT_DIM = 176
 TASK_INPUT_FIELDS = dict(grf_r=(0, 1), grf_l=(1, 1), contact_z=(2, 1), foot_contact=(3, 1), self_collision=(4, 1), phase=(5, 1), mode=(6, 1),
                          mode_ref=(7, 3), rfoot_vel=(10, 3), lfoot_vel=(13, 3), root_vel_local=(16, 3), root_xpos=(19, 3), head_xpos=(22, 3),
                          rfoot_xpos=(25, 3), lfoot_xpos=(28, 3), qpos=(32, 19), qvel=(51, 18), qacc=(69, 18), act_pos=(87, 12), act_vel=(99, 12),
-                         act_tau=(111, 12), prev_torque=(123, 12), prev_action=(135, 12), action=(147, 12))
+                         act_tau=(111, 12), prev_torque=(123, 12), prev_action=(135, 12), action=(147, 12), root_xmat=(160, 9))
 
 
 def split_task_inputs(rec, nq, nv, nu):

@@ -3519,6 +3519,7 @@ __device__ __forceinline__ bool control_step(HModelRef m, HParamsRef p, const HL
               ti[LHW_TIN_RFOOT_XPOS + a] = S.xpos[3 * p.rfoot_body + a]; ti[LHW_TIN_LFOOT_XPOS + a] = S.xpos[3 * p.lfoot_body + a];
             }
           }
+          if (lane < 9) ti[LHW_TIN_ROOT_XMAT + lane] = S.rootmat[lane];
           if (lane < m.nq) ti[LHW_TIN_QPOS + lane] = S.qpos[lane];
           if (lane < NV) { ti[LHW_TIN_QVEL + lane] = S.qvel[lane]; ti[LHW_TIN_QACC + lane] = S.qacc[lane]; }
           if (lane < m.nu) {

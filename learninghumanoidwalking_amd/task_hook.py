@@ -38,7 +38,7 @@ class _DevArray:
 class TaskInputs:
     """Named views of the [N, LHW_TASK_INPUT_DIM] float64 record the last control step exported (include/lhw.h: enum LhwTaskInput):
     grf_r grf_l contact_z foot_contact self_collision phase mode mode_ref rfoot_vel lfoot_vel root_vel_local root_xpos head_xpos
-    rfoot_xpos lfoot_xpos qpos qvel qacc act_pos act_vel act_tau prev_torque prev_action action."""
+    rfoot_xpos lfoot_xpos qpos qvel qacc act_pos act_vel act_tau prev_torque prev_action action root_xmat."""
 
     def __init__(self, rec: torch.Tensor, nq: int, nv: int, nu: int):
         self.rec, self.n_envs = rec, rec.shape[0]
@@ -152,6 +152,44 @@ class VectorWalkingTask(VectorTask):
         reward = sum(self.last_terms[k] for k in self.TERMS)      # python sum() over the dict, left to right
         z = ti.qpos[:, 2]
         done = (z < self.zlim[0]) | (z > self.zlim[1]) | (ti.self_collision != 0)     # walking_task.py:184-192
+        return reward, done
+
+
+class VectorStandingTask(VectorTask):
+    """StandingTask.calc_reward + done (reference tasks/standing_task.py:49-131) on the exported inputs -- the H1 standing env's task as a
+    plug-in (`head_xpos` of that env is the torso link, `root_xmat` the pelvis frame).  `weights` overrides term weights by name."""
+
+    reward_only = True
+    TERMS = ("com_vel_error", "yaw_vel_error", "height", "upperbody", "joint_torque_reward", "posture")
+    WEIGHTS = dict(com_vel_error=0.3, yaw_vel_error=0.3, height=0.1, upperbody=0.1, joint_torque_reward=0.1, posture=0.1)
+
+    def __init__(self, spec, device, weights: dict | None = None, height_limits=(0.9, 1.4)):
+        if tuple(height_limits) != (0.9, 1.4):
+            self.reward_only = False
+        self.w = dict(self.WEIGHTS, **(weights or {}))
+        unknown = set(self.w) - set(self.TERMS)
+        if unknown:
+            raise KeyError(f"unknown reward terms {sorted(unknown)}")
+        self.goal_height = float(getattr(spec, "goal_height", 0.98))          # standing_task.py:78 target_root_h
+        self.neutral = torch.as_tensor(np.asarray(spec.action_offset(), dtype=np.float64), device=device)   # standing_task.py:33 (the nominal leg pose)
+        self.zlim = height_limits
+        self.last_terms = None
+
+    def evaluate(self, ti: TaskInputs):
+        R = ti.root_xmat.reshape(-1, 3, 3)
+        dh = ti.head_xpos - ti.root_xpos
+        hloc = torch.einsum("nji,nj->ni", R, dh)            # inv(root_pose) . head_pose: R^T (head - root)
+        t = {}
+        t["com_vel_error"] = torch.exp(-4 * (ti.root_vel_local[:, 0] ** 2 + ti.root_vel_local[:, 1] ** 2))
+        t["yaw_vel_error"] = torch.exp(-4 * ti.qvel[:, 5] ** 2)
+        t["height"] = torch.exp(-0.5 * (ti.root_xpos[:, 2] - self.goal_height) ** 2)
+        t["upperbody"] = torch.exp(-40 * (hloc[:, 0] ** 2 + hloc[:, 1] ** 2))
+        t["joint_torque_reward"] = torch.exp(-5e-5 * (ti.act_tau ** 2).sum(1))
+        t["posture"] = torch.exp(-((ti.act_pos - self.neutral) ** 2).sum(1))
+        self.last_terms = {k: self.w[k] * t[k] for k in self.TERMS}
+        reward = sum(self.last_terms[k] for k in self.TERMS)
+        z = ti.qpos[:, 2]
+        done = (z < self.zlim[0]) | (z > self.zlim[1]) | (ti.self_collision != 0)     # standing_task.py:111-131
         return reward, done
 
 

@@ -74,6 +74,22 @@ def test_training_through_the_task_hook_reproduces_the_fused_task(monkeypatch):
     assert any((d != 0).any() for d in df), "no episode ended: the host-side truncation / reset path was not exercised"
 
 
+def test_standing_task_as_a_plug_in_reproduces_the_fused_h1_task():
+    """VectorStandingTask (tasks/standing_task.py:49-131 on the exported record, incl. the pelvis frame root_xmat) on the H1 env with
+    its observation noise, dynamics randomisation and perturbations on: rewards 1e-6, the kernel's own flags, weights 3e-6."""
+    from learninghumanoidwalking_amd.task_hook import VectorStandingTask
+    fused, rf, df, sf = _train(None, env="h1", N=16, T=12)
+    vect, rv, dv, sv = _train(lambda spec, dev: VectorStandingTask(spec, dev), env="h1", N=16, T=12)
+    assert vect.rollout.last_mode == fused.rollout.last_mode and vect.rollout.reward_only
+    for a, b in zip(rf, rv):
+        np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=0, atol=1e-6)
+    for a, b in zip(df, dv):
+        assert torch.equal(a, b)
+    for a, b in zip(sf, sv):
+        np.testing.assert_allclose(a, b, rtol=1e-6, atol=1e-5)
+    np.testing.assert_allclose(vect.kernels.theta.cpu().numpy(), fused.kernels.theta.cpu().numpy(), rtol=0, atol=3e-6)
+
+
 def test_a_changed_task_changes_what_the_policy_is_trained_on():
     from learninghumanoidwalking_amd.task_hook import VectorTask, VectorWalkingTask
     base, rb, _, _ = _train(lambda spec, dev: VectorWalkingTask(spec, dev), iters=1)
