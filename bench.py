@@ -24,82 +24,37 @@ MFMA_F32_PEAK_TFLOPS = 157.3  # f32-input MFMA peak (= f32 vector peak)
 FP64_VALU_PEAK_TFLOPS = 78.6
 
 
-def static_pmc_traffic(kernel_substr, stem="step"):
-    """HBM bytes per launch of the dominant kernel from the COMMITTED rocprofv3 --pmc summaries (profiles/), with the gfx950
-    correction of MI355X_MICROARCH.md (FETCH_SIZE under-reports coalesced reads by 2x; WRITE_SIZE uncalibrated).  Static: it
-    is NOT measured by this run (the counters need their own rocprofv3 passes, scripts/collect_profiles.sh)."""
+def committed_pmc(env_name, kernel_substr="humanoid_rollout"):
+    """Counter digest of the RESIDENT rollout kernel from the rocprofv3 --pmc passes COMMITTED under profiles/ this round
+    (profiles/r06_<env>_rollout_pmc.csv, written by scripts/gpu_pmc.sh traffic <env>: one dispatch = one rollout of N envs x T = 400
+    control steps; FETCH_SIZE / WRITE_SIZE in their own passes).  Per env-step: executed fp64 FLOPs ((2 FMA + MUL + ADD)
+    wave-instructions x active lanes per VALU instruction -- SQ_THREAD_CYCLES_VALU / SQ_INSTS_VALU, calibrated on fully active kernels:
+    profiles/r05_pmc_lane_calibration.txt), VALU instructions, HBM bytes (2 x FETCH_SIZE + WRITE_SIZE, KB counters; the factor 2 is the
+    gfx950 correction of MI355X_MICROARCH.md for coalesced reads).  NOT measured by this run: the counters need their own rocprofv3 runs."""
     import csv
-    for rnd in ("r04", "r03", "r02"):          # newest committed round first
-        vals = {}
-        for name in ("fetch_size", "write_size"):
-            path = os.path.join(ROOT, "profiles", f"{rnd}_jvrc_walk_{stem}_pmc_{name}.csv")
-            if not os.path.exists(path):
-                break
-            for row in csv.DictReader(open(path)):
-                if kernel_substr in row["kernel"]:
-                    vals[name] = float(row["mean"]) * 1024.0
-        if len(vals) == 2:
-            return dict(bytes_per_launch=2.0 * vals["fetch_size"] + vals["write_size"], envs_per_launch=4096, control_steps_per_launch=1,
-                        source=f"profiles/{rnd}_jvrc_walk_{stem}_pmc_{{fetch,write}}_size.csv: 2*FETCH_SIZE + WRITE_SIZE, whole-batch launches")
-    return None
-
-
-def static_pmc_executed_fp64(kernel_substr):
-    """fp64 FLOPs one launch of the dominant kernel EXECUTES, from the committed SQ counter pass (profiles/): (2 FMA + MUL + ADD)
-    wave-instructions x the average number of active lanes per VALU instruction (SQ_THREAD_CYCLES_VALU / SQ_INSTS_VALU: the counter
-    advances by the active lanes of each instruction -- profiles/r05_pmc_lane_calibration.txt).  Static, like the traffic figure; it is what the hardware did, where
-    `algorithmic_flops_per_env_step` is SURVEY.md 8(d)'s estimate for a dense 18 x 18 solver with four Newton iterations."""
-    import csv
-    for rnd in ("r04", "r03"):
-        path = os.path.join(ROOT, "profiles", f"{rnd}_jvrc_walk_step_pmc_sq.csv")
-        if not os.path.exists(path):
-            continue
-        v = {}
-        for row in csv.reader(open(path)):
-            if len(row) >= 4 and kernel_substr in row[0]:
-                try:
-                    v[row[1]] = float(row[3])
-                except ValueError:
-                    pass
-        need = ("SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_ADD_F64", "SQ_THREAD_CYCLES_VALU", "SQ_INSTS_VALU")
-        if all(k in v for k in need):
-            lanes = v["SQ_THREAD_CYCLES_VALU"] / v["SQ_INSTS_VALU"]      # active lanes per instruction (see static_pmc_rollout: no further / 4)
-            return dict(flops_per_launch=(2 * v["SQ_INSTS_VALU_FMA_F64"] + v["SQ_INSTS_VALU_MUL_F64"] + v["SQ_INSTS_VALU_ADD_F64"]) * lanes,
-                        active_lanes_per_valu_instruction=lanes, valu_instructions_per_launch=v["SQ_INSTS_VALU"], envs_per_launch=4096,
-                        source=f"profiles/{rnd}_jvrc_walk_step_pmc_sq.csv")
-    return None
-
-
-def static_pmc_rollout(kernel_substr="humanoid_rollout"):
-    """Per env-step figures of the RESIDENT rollout kernel from the committed rocprofv3 --pmc passes of this round
-    (profiles/r05_jvrc_walk_rollout_pmc_*.csv: jvrc_walk @ 4096 envs, T = 400, one dispatch = one rollout): executed fp64 FLOPs
-    ((2 FMA + MUL + ADD) wave-instructions x active lanes per VALU instruction), VALU instructions, and HBM bytes (2 x FETCH_SIZE +
-    WRITE_SIZE, KB counters; the factor 2 is the gfx950 correction of MI355X_MICROARCH.md for coalesced reads).  Static: the
-    counters need their own rocprofv3 runs (scripts/gpu_r5_profiles.sh), this run does not collect them."""
-    import csv
-    env_steps = 4096 * 400
+    path = os.path.join(ROOT, "profiles", f"r06_{env_name}_rollout_pmc.csv")
+    if not os.path.exists(path):
+        return None
+    n_envs = 8192 if env_name in ("h1", "h1_walk") else 4096      # what scripts/gpu_pmc.sh runs
+    env_steps = n_envs * 400
     v = {}
-    for name in ("sq", "fetch_size", "write_size"):
-        path = os.path.join(ROOT, "profiles", f"r05_jvrc_walk_rollout_pmc_{name}.csv")
-        if not os.path.exists(path):
-            return None
-        for row in csv.reader(open(path)):
-            if len(row) >= 4 and kernel_substr in row[0]:
-                try:
-                    v[row[1]] = float(row[3])
-                except ValueError:
-                    pass
+    for row in csv.reader(open(path)):
+        if len(row) >= 4 and kernel_substr in row[0]:
+            try:
+                v[row[1]] = float(row[3])
+            except ValueError:
+                pass
     need = ("SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_ADD_F64", "SQ_THREAD_CYCLES_VALU", "SQ_INSTS_VALU", "FETCH_SIZE", "WRITE_SIZE")
     if not all(k in v for k in need):
         return None
-    # SQ_THREAD_CYCLES_VALU advances by the number of ACTIVE LANES per VALU instruction (calibrated on fully active kernels, which read
-    # 64.0: profiles/r05_pmc_lane_calibration.txt) -- rounds 3-4 divided by another 4 and under-reported lanes and executed FLOPs 4x
     lanes = v["SQ_THREAD_CYCLES_VALU"] / v["SQ_INSTS_VALU"]
     flops = (2 * v["SQ_INSTS_VALU_FMA_F64"] + v["SQ_INSTS_VALU_MUL_F64"] + v["SQ_INSTS_VALU_ADD_F64"]) * lanes
+    envs_per_wave = 1 if env_name == "jvrc_step" else 2
     out = dict(executed_flops_per_env_step=flops / env_steps, active_lanes_per_valu_instruction=lanes,
-               valu_instructions_per_env_substep=v["SQ_INSTS_VALU"] / env_steps / 25.0,   # (wave-instructions / 2: a wave's instruction serves its two envs)
+               valu_instructions_per_env_substep=v["SQ_INSTS_VALU"] / env_steps / 25.0,
                hbm_bytes_per_env_step=(2.0 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024.0 / env_steps,
-               source="profiles/r05_jvrc_walk_rollout_pmc_{sq,fetch_size,write_size}.csv (jvrc_walk @ 4096, T = 400; per dispatch means / 1 638 400 env-steps)")
+               source=f"profiles/r06_{env_name}_rollout_pmc.csv ({env_name} @ {n_envs}, T = 400; per-dispatch means / {env_steps} env-steps; "
+                      f"{envs_per_wave} env(s) per wavefront: a wave's instruction counts once per env it serves)")
     if "SQ_WAVE_CYCLES" in v and "SQ_ACTIVE_INST_VALU" in v and "SQ_WAIT_ANY" in v:
         out["wave_cycles_issuing_valu"] = v["SQ_ACTIVE_INST_VALU"] / v["SQ_WAVE_CYCLES"]
         out["wave_cycles_waiting"] = v["SQ_WAIT_ANY"] / v["SQ_WAVE_CYCLES"]
@@ -347,22 +302,16 @@ def main():
         achieved_gbs = bytes_per_env_step * NL / (avg_step_ms * 1e-3) / 1e9
         overlapped_tf = flops_per_env_step * NL / (avg_step_ms * 1e-3) / 1e12
         wall_step_ms = sample_t / K / T * 1e3     # wall time per control step of all N envs, policy inference included
-        static = static_pmc_traffic(spec.step_kernel_name) if env_name == "jvrc_walk" else None
-        # The fused control-step kernel touches each env's state once per control step (3 KB): by design it is not HBM-bound
+        # The fused control-step code touches each env's state once per control step (3 KB): by design it is not HBM-bound
         #  but bound by fp64 vector issue + on-chip latency, so the primary roofline is the fp64 VALU one.
-        # `achieved` / `frac` are those of an ISOLATED whole-batch launch (what an isolated rocprofv3 dispatch shows); the
-        # rollout itself runs `concurrent_launches` half-batch launches side by side, whose per-launch spans are in `overlapped`.
+        # `achieved` = SURVEY.md 8(d)'s ALGORITHMIC FLOPs of one launch / that launch's duration, measured live with HIP events.
         iso_tf = None if isolated_ms is None else flops_per_env_step * N / (isolated_ms * 1e-3) / 1e12
-        executed = static_pmc_executed_fp64(spec.step_kernel_name) if env_name == "jvrc_walk" else None
-        if executed is not None and isolated_ms is not None and N == executed["envs_per_launch"]:
-            executed["tflops"] = executed["flops_per_launch"] / (isolated_ms * 1e-3) / 1e12
-            executed["frac_of_fp64_peak"] = executed["tflops"] / FP64_VALU_PEAK_TFLOPS
+        mode = getattr(algo.rollout, "last_mode", "steps")
         roofline = dict(
             bound="valu_fp64", kernel=spec.step_kernel_name, achieved=iso_tf if iso_tf is not None else overlapped_tf,
             peak=FP64_VALU_PEAK_TFLOPS, unit="TFLOP/s",
             frac=(iso_tf if iso_tf is not None else overlapped_tf) / FP64_VALU_PEAK_TFLOPS, traffic=None,
-            traffic_note="HBM bytes are not measured by this run (PMC counters need separate rocprofv3 passes); see traffic_static",
-            traffic_static=static, executed_static=executed,
+            traffic_note="HBM bytes are not measured by this run (PMC counters need separate rocprofv3 passes)",
             step_kernel_isolated=dict(kernel=spec.step_kernel_name, avg_launch_ms=isolated_ms, envs_per_launch=N,
                                       algorithmic_fp64_tflops=iso_tf, algorithmic_fp64_frac=None if iso_tf is None else iso_tf / FP64_VALU_PEAK_TFLOPS,
                                       note="one control step of the whole batch as ONE launch of the launch-per-step kernel, median of 20 issued one at a "
@@ -372,16 +321,12 @@ def main():
             avg_launch_ms=isolated_ms if isolated_ms is not None else avg_step_ms, envs_per_launch=N if isolated_ms is not None else NL,
             launch_note="median of 20 whole-batch control-step launches issued one at a time after the timed region, HIP events on the "
                         "launch stream (no overlap): the duration rocprofv3 --kernel-trace reports for an isolated dispatch",
-            rollout_mode=getattr(algo.rollout, "last_mode", "steps"),
-            resident=(dict(kernel="humanoid_rollout_kernel", launches=len(resident_ms), avg_launch_ms=float(np.mean(resident_ms)), control_steps_per_launch=T,
-                           envs_per_launch=N, ms_per_control_step=avg_step_ms, fp64_tflops=overlapped_tf, fp64_frac=overlapped_tf / FP64_VALU_PEAK_TFLOPS,
-                           note="HIP events around lhw_env_rollout on its stream over the timed region: one launch = T control steps of all N envs, "
-                                "policy steps included; algorithmic FLOPs of N x T env-steps / that span") if resident else None),
-            overlapped=dict(avg_launch_ms=avg_step_ms, launches=len(step_ms), envs_per_launch=NL, concurrent_launches=groups,
+            rollout_mode=mode,
+            overlapped=(None if resident else dict(avg_launch_ms=avg_step_ms, launches=len(step_ms), envs_per_launch=NL, concurrent_launches=groups,
                             fp64_tflops=overlapped_tf, fp64_frac=overlapped_tf / FP64_VALU_PEAK_TFLOPS,
                             note="HIP events on the launch stream around lhw_env_step_range over the timed region: the two-envs-per-wave "
                                  "kernel plus the (normally empty) one-env-per-wave re-run launch behind it; with concurrent_launches > 1 "
-                                 "the groups' kernels overlap, so a launch's span includes the share of the GPU it cedes to the other group"),
+                                 "the groups' kernels overlap, so a launch's span includes the share of the GPU it cedes to the other group")),
             aggregate=dict(wall_ms_per_control_step=wall_step_ms,
                            fp64_tflops=flops_per_env_step * N / (wall_step_ms * 1e-3) / 1e12,
                            fp64_frac=flops_per_env_step * N / (wall_step_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS,
@@ -389,37 +334,34 @@ def main():
             hbm=dict(bound="hbm", achieved=achieved_gbs, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved_gbs / HBM_PEAK_GBS,
                      note="secondary: algorithmic bytes / launch span; ~3e-4 of peak by construction"))
         if resident:
-            # The dominant kernel of the resident mode is the rollout kernel itself: ONE launch = T control steps of all N envs.
-            # Primary figure = what the hardware EXECUTED (fp64 FLOPs by the committed SQ counter pass, scaled by this run's env-steps)
-            # over the launch's measured duration; SURVEY.md 8(d)'s algorithmic estimate (75 kFLOP per env-sub-step, a dense 18 x 18
-            # solver with four Newton iterations: two thirds of what is executed) is reported beside it, not instead of it.
+            # The dominant kernel of the resident mode is the rollout kernel itself: ONE launch = T control steps of all N envs,
+            # policy steps included.  achieved / frac: SURVEY.md 8(d)'s 75 kFLOP per env-sub-step x 25 x N x T over the launch's
+            # duration (HIP events on its stream, this run).  What the hardware EXECUTED -- more, because every lane in EXEC counts --
+            # and the HBM traffic come from the committed counter passes of this round and are labelled as such.
             launch_ms = float(np.mean(resident_ms))
-            pmc = static_pmc_rollout() if env_name == "jvrc_walk" else None
             alg_tf = flops_per_env_step * N * T / (launch_ms * 1e-3) / 1e12
-            # (rocprof name: humanoid_rollout_kernel<TASK, W, QUEUE>; QUEUE = the stepping task's job queue, csrc/lhw_humanoid_rollout.hip)
-            queued = env_name == "jvrc_step" and N > 2048 and os.environ.get("LHW_ROLLOUT_CHUNK", "10") != "0"
+            queued = bool(env.last_rollout_queued()) if hasattr(env, "last_rollout_queued") else False
             roofline["kernel"] = spec.step_kernel_name.replace("humanoid_kernel<0, ", "humanoid_rollout_kernel<").replace(">", ", true>" if queued else ", false>")
+            roofline["achieved"], roofline["frac"] = alg_tf, alg_tf / FP64_VALU_PEAK_TFLOPS
+            roofline["achieved_note"] = "ALGORITHMIC fp64 FLOPs of one launch (SURVEY.md 8(d): 75 kFLOP per env-sub-step x 25 sub-steps x N x T) / its measured duration"
             roofline["avg_launch_ms"] = launch_ms
+            roofline["launches_timed"] = len(resident_ms)
             roofline["envs_per_launch"] = N
             roofline["control_steps_per_launch"] = T
             roofline["launch_note"] = ("mean span of lhw_env_rollout (one launch = T control steps of all N envs, policy steps included) over the timed "
                                        "region, HIP events on its stream: the duration rocprofv3 --kernel-trace reports for humanoid_rollout_kernel "
-                                       "(profiles/r05_jvrc_walk_kernel_stats.csv)")
-            roofline["algorithmic_estimate"] = dict(flops_per_launch=flops_per_env_step * N * T, tflops=alg_tf, frac=alg_tf / FP64_VALU_PEAK_TFLOPS,
-                                                    note="SURVEY.md 8(d): 75 kFLOP per env-sub-step x 25 sub-steps x N x T")
+                                       "(profiles/r06_jvrc_walk_kernel_stats.csv)")
             roofline["algorithmic_flops_per_launch"] = flops_per_env_step * N * T
             roofline["algorithmic_bytes_per_launch"] = bytes_per_env_step * N * T
+            pmc = committed_pmc(env_name)
             if pmc is not None:
                 ex_tf = pmc["executed_flops_per_env_step"] * N * T / (launch_ms * 1e-3) / 1e12
-                roofline["achieved"], roofline["frac"] = ex_tf, ex_tf / FP64_VALU_PEAK_TFLOPS
-                roofline["achieved_note"] = "EXECUTED fp64 FLOPs (committed SQ counters, per env-step x this run's N x T) / measured launch duration"
+                roofline["executed"] = dict(tflops=ex_tf, frac_of_fp64_peak=ex_tf / FP64_VALU_PEAK_TFLOPS, **pmc,
+                                            note="fp64 FLOPs the hardware executed per env-step by the COMMITTED SQ counter pass x this run's N x T, over this "
+                                                 "run's launch duration; counts every lane in EXEC, useful or not -- context for `frac`, not a replacement")
                 roofline["traffic"] = pmc["hbm_bytes_per_env_step"] * N * T
-                roofline["traffic_note"] = ("HBM bytes per launch from the COMMITTED PMC passes of this round (2 x FETCH_SIZE + WRITE_SIZE per env-step x this run's "
-                                            "N x T), not collected by this run; vs algorithmic_bytes_per_launch: the excess is register-spill write-back")
-                roofline["executed_static"] = pmc
-            else:
-                roofline["achieved"], roofline["frac"] = alg_tf, alg_tf / FP64_VALU_PEAK_TFLOPS
-                roofline["achieved_note"] = "algorithmic estimate (no committed counter pass for this env)"
+                roofline["traffic_note"] = ("HBM bytes per launch from the COMMITTED FETCH_SIZE / WRITE_SIZE passes of this round (2 x FETCH + WRITE per env-step "
+                                            "x this run's N x T), not collected by this run; compare algorithmic_bytes_per_launch")
         L = algo.last_losses
         kk = algo.kernels
         use_mirror = bool(getattr(kk, "use_mirror", False))
@@ -437,7 +379,9 @@ def main():
             n_gpus=world, steps=K, warmup=args.warmup, ms_per_step=elapsed / K * 1e3, higher_is_better=True, scaling="weak",
             vs_baseline=None, dtype="f64 physics / " + ("fp16-operand networks, f32 accumulate + master weights" if args.fp16 else "f32 networks" + (" (fp16-operand rollout inference)" if args.infer_fp16 else "")), data="synthetic",
             config=dict(workload=f"{env_name} @ {N} envs/GPU, T={T} control steps/iter, {args.epochs} epochs, "
-                                 f"minibatch {args.minibatch_size}/GPU" + (" (JVRC stand-in model)" if env_name.startswith("jvrc") else " (H1 stand-in model)" if env_name.startswith("h1") else ""),
+                                 f"minibatch {args.minibatch_size}/GPU" + (" (JVRC stand-in model)" if env_name.startswith("jvrc") else " (H1 stand-in model)" if env_name.startswith("h1") else "")
+                                 + (", flat ground (the reference's uneven-terrain hook is dead code: tasks/walking_task.py:173-179)" if env_name.startswith("h1") else "")
+                                 + (f", task plug-in: {args.task_hook}" if args.task_hook != "none" else ""),
                         envs_per_gpu=N, traj_len=T, epochs=args.epochs, minibatch_per_gpu=args.minibatch_size,
                         mirror=not args.no_mirror and spec.mirror_tables() is not None,
                         frame_skip=spec.frame_skip, sim_dt=spec.sim_dt, control_dt=spec.control_dt),

@@ -186,6 +186,9 @@ int lhw_env_rollout(LhwEnv* env, const LhwRolloutPolicy* policy, int32_t first, 
 int lhw_env_rollout_task_inputs(LhwEnv* env, const LhwRolloutPolicy* policy, int32_t first, int32_t count, int32_t T, float* obs_dev,
                                 float* act_dev, float* logp_dev, float* term_obs_dev, float* rew_dev, uint8_t* done_dev, float* rew_terms_dev,
                                 double* tin_dev, void* stream);
+/* 1 if the most recent lhw_env_rollout of this env drained the job queue (rocprof name humanoid_rollout_kernel<TASK, 64, true>), 0 if
+ * every wavefront kept its env group (<.., false>); what bench.py names as the dominant kernel. */
+int lhw_env_last_rollout_queued(LhwEnv* env);
 /* Parity hooks; HOST pointers, synchronous.  qpos [N][nq], qvel [N][nv] float64. */
 int lhw_env_get_state(LhwEnv* env, double* qpos_host, double* qvel_host);
 int lhw_env_set_state(LhwEnv* env, const double* qpos_host, const double* qvel_host);

@@ -177,6 +177,7 @@ def declare(L):
     sig("lhw_ppo_set_imitation", [vp, vp, vp, ctypes.c_float, i64])
     sig("lhw_env_debug_step_record", [vp, vp, vp, vp])
     sig("lhw_env_rollout", [vp, ctypes.POINTER(LhwRolloutPolicy), i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp])
+    sig("lhw_env_last_rollout_queued", [vp])
     sig("lhw_env_rollout_task_inputs", [vp, ctypes.POINTER(LhwRolloutPolicy), i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp])
     sig("lhw_ppo_rollout_policy", [vp, vp, vp, vp, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_int, ctypes.POINTER(LhwRolloutPolicy)])
     sig("lhw_debug_policy_step", [ctypes.POINTER(LhwRolloutPolicy), vp, i32, ctypes.c_uint32, ctypes.c_uint32, vp, vp, vp, vp])

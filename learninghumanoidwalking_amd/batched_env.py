@@ -201,6 +201,10 @@ class BatchedEnv:
         _lib.check(rc)
         return True
 
+    def last_rollout_queued(self) -> bool:
+        """the most recent resident rollout drained the job queue (stepping task with more envs than wave slots)"""
+        return bool(getattr(self._L, "lhw_env_last_rollout_queued", lambda h: 0)(self._h) == 1)
+
     def get_state(self):
         qpos = np.zeros((self.n_envs, self.nq))
         qvel = np.zeros((self.n_envs, self.nv))

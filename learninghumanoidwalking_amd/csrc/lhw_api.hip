@@ -249,6 +249,11 @@ extern "C" int lhw_env_rollout_task_inputs(LhwEnv* e, const LhwRolloutPolicy* po
   return env_rollout_impl(e, policy, first, count, T, obs_dev, act_dev, logp_dev, term_obs_dev, rew_dev, done_dev, rew_terms_dev, tin_dev, stream);
 }
 
+extern "C" int lhw_env_last_rollout_queued(LhwEnv* e) {
+  if (!e) return lhw_fail(LHW_ERR_ARG, "null env");
+  return e->task == LHW_TASK_CARTPOLE ? 0 : humanoid_last_rollout_queued(e->hum);
+}
+
 extern "C" int lhw_env_get_state(LhwEnv* e, double* qpos_host, double* qvel_host) {
   if (!e || !qpos_host || !qvel_host) return lhw_fail(LHW_ERR_ARG, "null argument");
   HIPCHK(hipSetDevice(e->device));

@@ -386,6 +386,7 @@ struct HumanoidEnv {
   int device;
   bool fast;   // the model fits the two-envs-per-wave kernels (W = 32)
   unsigned* ro_queue = nullptr;   // job counter + per-group progress words of the resident rollout's queue mode (lhw_humanoid_rollout.hip)
+  int last_rollout_queued = 0;    // the most recent resident rollout drained the job queue (humanoid_rollout_kernel<.., QUEUE = true>)
 };
 
 // ------------------------------------------------------------------------------------------------ LDS working set

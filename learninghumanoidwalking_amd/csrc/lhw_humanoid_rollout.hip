@@ -320,6 +320,8 @@ __global__ void __launch_bounds__(64, LHW_WAVES_PER_SIMD) humanoid_rollout_kerne
   else hipLaunchKernelGGL((humanoid_rollout_kernel<TASK_STAND, WIDTH, false>), grid, dim3(64), 0, s, (const HModel*)h->m_dev, (const HParams*)h->p_dev, lz, st, ro);
 #endif
 
+int humanoid_last_rollout_queued(const HumanoidEnv* h) { return h->last_rollout_queued; }
+
 int humanoid_rollout(HumanoidEnv* h, int first, int count, int T, const LhwRolloutPolicy* pol, float* obs, float* act, float* logp, float* term_obs,
                      float* rew, uint8_t* done, float* rew_terms, double* tin_all, hipStream_t s) {
   if (first < 0 || count <= 0 || first + count > h->p.n_envs || T <= 0) return -1;
@@ -370,6 +372,7 @@ int humanoid_rollout(HumanoidEnv* h, int first, int count, int T, const LhwRollo
     }
   }
   const dim3 grid(grid_n);
+  h->last_rollout_queued = ro.queue != nullptr;
   if (h->fast) {
     if (h->p.task == TASK_WALK) hipLaunchKernelGGL((humanoid_rollout_kernel<TASK_WALK, 32, false>), grid, dim3(64), 0, s, (const HModel*)h->m_dev, (const HParams*)h->p_dev, lz, st, ro);
     ROLLOUT_OTHER_TASKS(32)

@@ -39,6 +39,7 @@ void humanoid_step(HumanoidEnv* h, const float* act, float* obs, float* term_obs
                    hipStream_t s);
 int humanoid_step_range(HumanoidEnv* h, int first, int count, const float* act, float* obs, float* term_obs, float* rew, uint8_t* done,
                         float* rew_terms, hipStream_t s);
+int humanoid_last_rollout_queued(const HumanoidEnv* h);
 int humanoid_rollout(HumanoidEnv* h, int first, int count, int T, const LhwRolloutPolicy* pol, float* obs, float* act, float* logp, float* term_obs,
                      float* rew, uint8_t* done, float* rew_terms, double* tin_all, hipStream_t s);   // lhw_humanoid_rollout.hip; -1 bad range, -2 / -3 unsupported, -4 HIP error
 void humanoid_get_state(HumanoidEnv* h, double* qpos, double* qvel, hipStream_t s);

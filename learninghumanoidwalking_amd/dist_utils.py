@@ -87,15 +87,12 @@ def allreduce_grad_(flat_grad: torch.Tensor) -> float:
 def relaunch_under_torchrun(n_procs: int, script: str, argv: list) -> int:
     """Fan-out is the entry point's job (the reference's PPO starts its own Ray workers, rl/algos/ppo.py:215-297): a plain
     `python <script> --gpus N` with N > 1 and no launcher environment re-executes itself as N ranks on this node under
-    torch.distributed.run (one process per GPU, rendezvous on 127.0.0.1 at a free port) and returns the launcher's exit code."""
-    import socket
+    torch.distributed.run (one process per GPU) and returns the launcher's exit code.  `--standalone`: the launcher itself opens the
+    rendezvous store on a free port of 127.0.0.1 and hands the ranks MASTER_ADDR / MASTER_PORT (no bind-then-close port guess here)."""
     import subprocess
     import sys
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={int(n_procs)}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), script] + list(argv)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
+           f"--nproc-per-node={int(n_procs)}", script] + list(argv)
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     return subprocess.call(cmd, env=env)

@@ -76,13 +76,21 @@ class JvrcWalkSpec:
         self.history_len = int(c.get("obs_history_len", 1))     # base_humanoid_env.py:53,177-197 (kept above the kernels: BatchedEnv)
         if self.history_len < 1:
             raise ValueError("obs_history_len must be >= 1")
-        # BaseHumanoidEnv.reset_model / step apply these for ANY env that configures them (base_humanoid_env.py:76-92,247-305); the
-        # JVRC kernels implement none of them (and copy a precomputed post-reset state into every auto-reset): refuse, do not ignore
-        for key in ("init_noise", "dynamics_randomization", "perturbation", "observation_noise"):
+        # BaseHumanoidEnv applies these keys to any env that configures them (base_humanoid_env.py:76-92,221-225,247-305) -- but what
+        # the reference DOES with them on a JVRC env differs by key (round 6, read off the reference's code):
+        #   observation_noise        ignored: only H1BaseEnv._get_robot_state calls _apply_observation_noise (h1_base.py:107-115);
+        #                            JvrcBaseEnv._get_robot_state (jvrc_base.py:133-138) never does -> accepted and ignored here too
+        #   dynamics_randomization   raises: randomize_dynamics looks up the body "pelvis" (domain_randomization.py:44), which a JVRC
+        #                            model does not have (its root is "PELVIS_S", jvrc_base.py:32) -> KeyError in the reference, refused here
+        #   perturbation, init_noise would run in the reference; the JVRC kernels do not implement them (the H1 kernels do, and the
+        #                            JVRC auto-reset copies a precomputed post-reset state): refused, not silently ignored
+        for key in ("init_noise", "dynamics_randomization", "perturbation"):
             v = c.get(key)
             on = (v.get("enable", v.get("enabled", False)) if isinstance(v, dict) else bool(v))
             if on:
-                raise NotImplementedError(f"{key} is configured in {self.yaml_path}: the JVRC tasks do not implement it (the H1 tasks do)")
+                why = ("the reference itself fails on it for a JVRC model (randomize_dynamics needs a body named 'pelvis')" if key == "dynamics_randomization"
+                       else "the JVRC kernels do not implement it (the H1 kernels do)")
+                raise NotImplementedError(f"{key} is configured in {self.yaml_path}: {why}")
         self.action_smoothing = float(c["action_smoothing"])
         self.kp, self.kd = np.array(c["kp"], dtype=float), np.array(c["kd"], dtype=float)
         self.half_sitting_pose = np.deg2rad(np.array(c["half_sitting_pose"], dtype=float))

@@ -9,6 +9,7 @@ rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 B=/root/repo/bench.py
 timeout 300 python $B --steps 20 --warmup 5 2>/dev/null | tail -1 > $OUT/bench_jvrc_walk_1gpu.json
+timeout 200 python $B --steps 5 --warmup 2 --no-cpu-baseline --task-hook walking 2>/dev/null | tail -1 > $OUT/bench_jvrc_walk_1gpu_task_plugin.json
 timeout 200 python $B --env h1 --num-envs 8192 --steps 3 --warmup 1 2>/dev/null | tail -1 > $OUT/bench_h1_8192_1gpu.json
 timeout 100 python $B --env cartpole --steps 3 --warmup 1 2>/dev/null | tail -1 > $OUT/bench_cartpole_1gpu.json
 timeout 200 python $B --env jvrc_step --steps 3 --warmup 1 2>/dev/null | tail -1 > $OUT/bench_jvrc_step_1gpu.json
@@ -29,13 +30,11 @@ timeout 120 python /root/repo/scripts/jvrc_phase_profile.py 4096 > $OUT/jvrc_wal
 timeout 200 python /root/repo/scripts/gemm_bench.py 32768 > $OUT/ppo_gemm_shapes.txt 2>/dev/null
 ( timeout 100 python /root/repo/scripts/strip_bench.py 65536; timeout 100 python /root/repo/scripts/strip_bench.py 32768 ) 2>/dev/null | grep rows > $OUT/ppo_strip_bench.txt
 if [ "${QUICK:-0}" != 1 ]; then
-for C in FETCH_SIZE WRITE_SIZE; do
-  rm -rf /tmp/pm; timeout 300 rocprofv3 --pmc $C --output-format csv -d /tmp/pm -- python $B --steps 2 --warmup 1 --no-cpu-baseline > /tmp/pm.log 2>&1
-  python /root/repo/scripts/pmc_summary.py /tmp/pm | grep -E "kernel,|humanoid_rollout" > $OUT/jvrc_walk_rollout_pmc_$C.csv
-done
-for C in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_SALU SQ_IFETCH SQ_INSTS_SMEM" "SQ_INSTS_VALU SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_INT32 SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU"; do
-  rm -rf /tmp/pm; timeout 300 rocprofv3 --pmc $C --output-format csv -d /tmp/pm -- python $B --steps 2 --warmup 1 --no-cpu-baseline > /tmp/pm.log 2>&1
-  python /root/repo/scripts/pmc_summary.py /tmp/pm | grep -E "kernel,|humanoid_rollout" >> $OUT/jvrc_walk_rollout_pmc_sq.csv
+# counter passes of the resident rollout kernels (scripts/gpu_pmc.sh: every --pmc set in its own rocprofv3 run; bench.py reads
+# profiles/r06_<env>_rollout_pmc.csv): the headline env, config 5's stepper (h1 @ 8192) and the stepping task
+for E in jvrc_walk h1 jvrc_step; do
+  bash /root/repo/scripts/gpu_pmc.sh traffic $E > /tmp/pmc_$E.log 2>&1
+  cp /root/repo/gpurun_out/pmc/${E}_traffic.csv $OUT/${E}_rollout_pmc.csv
 done
 # end-to-end sanity: 100 PPO iterations of jvrc_walk on the stand-in robot (reward / episode length trend)
 rm -rf /tmp/train_log; timeout 600 python /root/repo/run_experiment.py train --env jvrc_walk --num-envs 4096 --minibatch-size 32768 --n-itr 100 --eval-freq 1000 --logdir /tmp/train_log --seed 0 2>&1 | grep -E "Iteration|Mean Eprew|Mean Eplen|fps=|Sampling took|Optimizer took" > $OUT/train_jvrc_walk_100iters.log

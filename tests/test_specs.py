@@ -103,3 +103,27 @@ def test_device_rng_header_matches_python_restatement(tmp_path):
                 assert float(u) == rng.uniform(12345, e, 1, c, s, -0.5, 0.5)
                 assert int(r) == rng.randint(99, e, 2, c, s, 88)
                 k += 1
+
+
+def test_jvrc_yaml_keys_of_base_humanoid_env_follow_the_reference_key_by_key(tmp_path):
+    """BaseHumanoidEnv's generic hooks on a JVRC env, as the reference's code treats them (envs/common/base_humanoid_env.py:76-92,
+    247-338; envs/jvrc/jvrc_base.py:133-138; envs/common/domain_randomization.py:44): observation_noise is never applied by the JVRC
+    robot state -> accepted and ignored; dynamics_randomization fails there (no body named 'pelvis') -> refused; perturbation / init_noise
+    would run there and are not in the JVRC kernels -> refused, not silently dropped."""
+    import pytest
+    import yaml
+    from learninghumanoidwalking_amd.envs.jvrc_walk import JVRC_BASE_YAML
+    base = yaml.safe_load(open(JVRC_BASE_YAML))
+
+    def spec_with(**extra):
+        p = tmp_path / ("cfg_" + "_".join(extra) + ".yaml")
+        p.write_text(yaml.safe_dump(dict(base, **extra)))
+        return JvrcWalkSpec(yaml_path=str(p))
+
+    s = spec_with(observation_noise=dict(enabled=True, type="uniform", multiplier=1.0, scales=dict(root_orient=0.05)))
+    assert s.obs_dim == 37
+    for extra in (dict(dynamics_randomization=dict(enable=True, interval=0.5)), dict(perturbation=dict(enable=True, interval=5.0, bodies=["PELVIS_S"])),
+                  dict(init_noise=3)):
+        with pytest.raises(NotImplementedError):
+            spec_with(**extra)
+    spec_with(dynamics_randomization=dict(enable=False, interval=0.5), init_noise=0)      # configured but off: fine
