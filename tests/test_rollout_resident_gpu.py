@@ -151,3 +151,66 @@ def test_fp16_operand_policy_in_the_resident_rollout_matches_the_fp16_mfma_forwa
     algo.kernels.set_inference_fp16(False)
     mu32, _, _, _ = algo.kernels.forward(ro.obs[0], deterministic=True, want_value=False)
     assert not torch.equal(ro.act[0], mu32)               # and they are not the float32 means
+
+
+def test_resident_rollout_against_the_oracle_directly(monkeypatch):
+    """The resident rollout held to the float64 ORACLE without the launch-per-step pipeline in between: 288 jvrc_walk envs, one
+    launch of T = 48 control steps with the trained-size actor sampling in the wavefronts, episodes truncated at 12 (so every env
+    is reset three times inside the launch), three envs started lying on the floor (the in-wave one-env-per-wave re-run).  The oracle
+    envs replay the actions the launch stored (an action tape: the policy's float32 arithmetic is not the subject here -- its bits
+    are held to the strip kernel by the tests above) and must reproduce every stored observation (2e-5: float32 rows), reward (2e-6),
+    flag (exactly) and the final state (1e-9 / 1e-7 after 1200 free-running sub-steps with resets).  Reference:
+    rl/workers/rollout_worker.py:142-181 over robots/robot_base.py:64-98.  Physics parity is UNPINNED against MuJoCo."""
+    from learninghumanoidwalking_amd.envs import ENVIRONMENTS
+    from learninghumanoidwalking_amd.envs.jvrc_walk import JvrcWalkSpec
+    from learninghumanoidwalking_amd.ppo import PPO
+    from oracle.env_jvrc_walk import OracleJvrcWalkEnv
+    monkeypatch.setenv("LHW_ROLLOUT_MODE", "resident")
+    N, T, L = 288, 48, 12
+    a = _args(N, T, std=0.223)
+    a.max_traj_len = L
+    algo = PPO(ENVIRONMENTS["jvrc_walk"], a, seed=6)
+    env, spec = algo.env, JvrcWalkSpec()
+    # a rollout of T control steps with episodes of L: Rollout is built with T = max_traj_len, so lhw_env_rollout is driven directly
+    obs0 = env.reset()
+    orc = [OracleJvrcWalkEnv(spec, seed=algo.env_seed, env_id=i, max_traj_len=L) for i in range(N)]
+    ref0 = np.array([o.reset() for o in orc])
+    np.testing.assert_allclose(obs0.cpu().numpy(), ref0, rtol=1e-6, atol=2e-6)
+    poses = ([0.0, 0.0, 0.2571, -0.7309, -0.1371, 0.232, 0.627, -0.9859, -0.3243, -0.4729, 0.119, 0.609, 0.1118, -1.4146, 0.1458, 0.4932, 2.1903, 0.42, -0.5225],
+             [0.0, 0.0, 0.1223, -0.4502, 0.0287, 0.3794, 0.8078, -1.2999, -0.2333, 0.4393, 0.4916, 0.2839, -0.8672, -1.533, 0.0192, -0.4235, 2.2823, -0.1645, -1.051],
+             [0.0, 0.0, 0.142, -0.7055, -0.3568, 0.5444, 0.2804, 0.2372, -0.0299, -0.0106, 1.5965, -0.2912, -0.7387, -0.6059, -0.272, 0.0915, 0.445, -0.3003, 0.7158])
+    q, v = env.get_state()
+    for i, pose in zip((0, 5, 287), poses):
+        q[i] = pose
+        q[i, 3:7] /= np.linalg.norm(q[i, 3:7])
+        v[i] = 0
+    env.set_state(q, v)
+    for i, o in enumerate(orc):      # (set_state re-runs the forward pass: on both sides, for every env)
+        o.set_state(q[i], v[i])
+    env.pop_rerun_count()
+    dev = obs0.device
+    D, A = env.obs_dim, env.act_dim
+    obs = torch.zeros(T + 1, N, D, device=dev); act = torch.zeros(T, N, A, device=dev); logp = torch.zeros(T, N, device=dev)
+    tob = torch.zeros(T, N, D, device=dev); rew = torch.zeros(T, N, device=dev); done = torch.zeros(T, N, dtype=torch.uint8, device=dev)
+    obs[0].copy_(obs0)
+    k = algo.kernels
+    k.begin_rollout()
+    try:
+        pol = k.rollout_policy(seed=123, counter=0, deterministic=False)
+        assert pol is not None and env.rollout(pol, T, obs, act, logp, tob, rew, done)
+    finally:
+        k.end_rollout()
+    torch.cuda.synchronize()
+    A_, O_, R_, F_, TB_ = (x.cpu().numpy() for x in (act, obs, rew, done, tob))
+    for t in range(T):
+        res = [o.step_auto(A_[t, i]) for i, o in enumerate(orc)]
+        np.testing.assert_array_equal(F_[t], np.array([r[2] for r in res], dtype=np.uint8), err_msg=f"flags t={t}")
+        np.testing.assert_allclose(R_[t], np.array([r[1] for r in res]), rtol=0, atol=2e-6, err_msg=f"rew t={t}")
+        np.testing.assert_allclose(O_[t + 1], np.array([r[0] for r in res]), rtol=1e-5, atol=2e-5, err_msg=f"obs t={t}")
+        np.testing.assert_allclose(TB_[t], np.array([r[3] for r in res]), rtol=1e-5, atol=2e-5, err_msg=f"terminal obs t={t}")
+    qg, vg = env.get_state()
+    np.testing.assert_allclose(qg, np.array([o.sim.qpos for o in orc]), rtol=0, atol=1e-9)
+    np.testing.assert_allclose(vg, np.array([o.sim.qvel for o in orc]), rtol=0, atol=1e-7)
+    assert (F_ & 2).sum() >= 3 * N * 0.8 and (F_ & 1).any(), "truncations / falls missing"
+    assert env.pop_rerun_count() > 0, "no env took the in-wave one-env-per-wave re-run"
+    assert env.pop_fault_stats() == (0, 0)
