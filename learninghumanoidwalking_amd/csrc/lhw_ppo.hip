@@ -47,6 +47,9 @@ struct GemmArgs {
   int k_chunk;              // K range per blockIdx.z
   float* colsum;            // (A stored [K][M] only) slice z also stores sum_k A[k][m] at colsum + z*M: the bias gradient of a dW GEMM
   int tiles_m, tiles_n, slices;   // filled in by launch_gemm
+  // fp16 GEMM only (gemm_h_kernel): which of the buffers hold _Float16 instead of float (the pointers above are then reinterpreted;
+  // leading dimensions count elements of the buffer's own type).  Operands stored as float are rounded to fp16 while they are staged.
+  int a_half, b_half, c_half, mask_half;
 };
 
 // C = op(A) op(B) on v_mfma_f32_32x32x2_f32.  Block = 4 waves (2 x 2), each wave owns WT x WT MFMA tiles of 32 x 32:
@@ -197,21 +200,22 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(GemmArgs g) {
   }
 }
 
-// Half-precision GEMM (BASELINE config "fp16 actor/critic"): the same tiling, block order, epilogues, split-K and fused column
-// sums as gemm_f32_kernel, with both operands read as float32, rounded to fp16 while they are staged into LDS ([row][k] tiles,
-// k contiguous) and multiplied on the fp16 MFMA (gfx950: v_mfma_f32_32x32x16_f16) with float32 accumulation; bias / ReLU / mask / outputs
-// and the split-K partials stay float32.  Used by the rollout inference (lhw_ppo_set_inference_dtype) and, with
-// lhw_ppo_set_update_dtype, by every GEMM of the update (weights, activations and back-propagated gradients rounded to fp16
-// per GEMM; float32 master weights, loss, Adam).
+// Half-precision GEMM (BASELINE config 5, "fp16 actor/critic on CDNA4"): the block order, epilogues, split-K and fused column sums of
+// gemm_f32_kernel on gfx950's v_mfma_f32_32x32x16_f16 with float32 accumulation.  Round 6: the operands may LIVE in fp16 in HBM
+// (a_half / b_half: the update's activations x, h1, h2 and back-propagated gradients dh2, dh1 -- written as fp16 by the GEMM that
+// produces them, c_half) and are then loaded as 16-byte f16x8 vectors with no conversion; operands stored as float32 (the master weights,
+// the loss gradients) are rounded while they are staged, as every operand was through round 5.  K advances 32 per step (two MFMAs per
+// wave and barrier instead of one per 16-k step).  Bias / ReLU / mask in float32; outputs float32 or fp16; split-K partials float32.
+// Used by the rollout inference with fp16 operands (lhw_ppo_set_inference_dtype) and by every GEMM of the --fp16 update.
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-#define HLD (BK + 4)
-static_assert(BK % 16 == 0, "the fp16 GEMM multiplies 16 k per MFMA");
+#define HBK 32
+#define HLD (HBK + 8)      // tile rows 80 bytes apart: 16-byte aligned operand reads, conflict-free across the 32 rows of a wave's read
 template <bool A_KC, bool B_KC>
-__global__ void __launch_bounds__(256) gemm_f16_kernel(GemmArgs g) {
-  __shared__ _Float16 Ah[2][BM][HLD];
+__global__ void __launch_bounds__(256) gemm_h_kernel(GemmArgs g) {
+  __shared__ __attribute__((aligned(16))) _Float16 Ah[2][BM][HLD];
   LHW_LDS_POISON(Ah);
-  __shared__ _Float16 Bh[2][BN][HLD];
+  __shared__ __attribute__((aligned(16))) _Float16 Bh[2][BN][HLD];
   LHW_LDS_POISON(Bh);
   __shared__ float red[256];
   LHW_LDS_POISON(red);
@@ -225,67 +229,65 @@ __global__ void __launch_bounds__(256) gemm_f16_kernel(GemmArgs g) {
   const int kend = min(g.K, kbeg + g.k_chunk);
   f32x16 acc;
   for (int r = 0; r < 16; r++) acc[r] = 0.f;
-  float4 ra, rb;
-  auto load_tile = [&](float4& r, const float* __restrict__ P, int ld, bool kc, int x0, int X, int k0) {
-    r = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (kc) {
-      const int row = x0 + (tid >> 2), k = k0 + (tid & 3) * 4;
-      if (row < X && k < kend) {
-        r = *reinterpret_cast<const float4*>(P + (size_t)row * ld + k);
-        if (k + 1 >= kend) r.y = 0.f;
-        if (k + 2 >= kend) r.z = 0.f;
-        if (k + 3 >= kend) r.w = 0.f;
-      }
-    } else {
-      const int k = k0 + (tid >> 4), x = x0 + (tid & 15) * 4;
-      if (k < kend && x < X) {
-        r = *reinterpret_cast<const float4*>(P + (size_t)k * ld + x);
-        if (x + 1 >= X) r.y = 0.f;
-        if (x + 2 >= X) r.z = 0.f;
-        if (x + 3 >= X) r.w = 0.f;
+  // staging: 8 elements per thread and operand.  KC layout ([X][K]): 4 threads per row, 8 consecutive k each; else ([K][X]): 8 threads
+  // per k, 8 consecutive x each.  Elements beyond the matrix / the slice are zero.
+  auto load_tile = [&](const float* __restrict__ P, int ld, bool kc, bool is_half, int x0, int X, int k0) -> f16x8 {
+    f16x8 r = {0, 0, 0, 0, 0, 0, 0, 0};
+    const int row = kc ? x0 + (tid >> 2) : k0 + (tid >> 3);        // index along the leading dimension
+    const int col = kc ? k0 + (tid & 3) * 8 : x0 + (tid & 7) * 8;  // first of the 8 contiguous elements
+    const int rlim = kc ? X : kend, clim = kc ? kend : X;
+    if (row < rlim && col < clim) {
+      if (is_half) {
+        const _Float16* Ph = reinterpret_cast<const _Float16*>(P) + (size_t)row * ld + col;
+        if (col + 8 <= clim && !(((size_t)row * ld + col) & 7)) r = *reinterpret_cast<const f16x8*>(Ph);
+        else for (int j = 0; j < 8; j++) if (col + j < clim) r[j] = Ph[j];
+      } else {
+        const float* Pf = P + (size_t)row * ld + col;
+        if (col + 8 <= clim) {
+          const float4 u = *reinterpret_cast<const float4*>(Pf), w = *reinterpret_cast<const float4*>(Pf + 4);
+          r = f16x8{(_Float16)u.x, (_Float16)u.y, (_Float16)u.z, (_Float16)u.w, (_Float16)w.x, (_Float16)w.y, (_Float16)w.z, (_Float16)w.w};
+        } else for (int j = 0; j < 8; j++) if (col + j < clim) r[j] = (_Float16)Pf[j];
       }
     }
+    return r;
   };
-  auto store_tile = [&](_Float16 (&T)[BM][HLD], const float4& r, bool kc) {
-    if (kc) {
-      const f16x4 hv = {(_Float16)r.x, (_Float16)r.y, (_Float16)r.z, (_Float16)r.w};
-      *reinterpret_cast<f16x4*>(&T[tid >> 2][(tid & 3) * 4]) = hv;
-    } else {
-      const int k = tid >> 4, xq = (tid & 15) * 4;
-      T[xq + 0][k] = (_Float16)r.x; T[xq + 1][k] = (_Float16)r.y; T[xq + 2][k] = (_Float16)r.z; T[xq + 3][k] = (_Float16)r.w;
+  auto store_tile = [&](_Float16 (&T)[BM][HLD], const f16x8& r, bool kc) {
+    if (kc) *reinterpret_cast<f16x8*>(&T[tid >> 2][(tid & 3) * 8]) = r;
+    else {
+      const int k = tid >> 3, xq = (tid & 7) * 8;
+#pragma unroll
+      for (int j = 0; j < 8; j++) T[xq + j][k] = r[j];
     }
   };
   const bool want_colsum = !A_KC && g.colsum != nullptr && tn == 0;
   float cs = 0.f;
   int cur = 0;
+  f16x8 ra, rb;
   if (kbeg < kend) {
-    load_tile(ra, g.A, g.lda, A_KC, m0, g.M, kbeg);
-    load_tile(rb, g.B, g.ldb, B_KC, n0, g.N, kbeg);
+    ra = load_tile(g.A, g.lda, A_KC, g.a_half != 0, m0, g.M, kbeg);
+    rb = load_tile(g.B, g.ldb, B_KC, g.b_half != 0, n0, g.N, kbeg);
     store_tile(Ah[0], ra, A_KC);
     store_tile(Bh[0], rb, B_KC);
   }
   __syncthreads();
-  for (int k0 = kbeg; k0 < kend; k0 += BK) {
-    const bool more = k0 + BK < kend;
+  for (int k0 = kbeg; k0 < kend; k0 += HBK) {
+    const bool more = k0 + HBK < kend;
     if (more) {
-      load_tile(ra, g.A, g.lda, A_KC, m0, g.M, k0 + BK);
-      load_tile(rb, g.B, g.ldb, B_KC, n0, g.N, k0 + BK);
+      ra = load_tile(g.A, g.lda, A_KC, g.a_half != 0, m0, g.M, k0 + HBK);
+      rb = load_tile(g.B, g.ldb, B_KC, g.b_half != 0, n0, g.N, k0 + HBK);
     }
     const int am = wm * 32 + (lane & 31), bn = wn * 32 + (lane & 31), kh = lane >> 5;
-    // gfx950's v_mfma_f32_32x32x16_f16: 16 k per instruction (lane l supplies k = 8 (l / 32) .. + 7 of its row / column), twice the
-    // rate of the 32x32x8 form this kernel used through round 4.  (Two 8-byte LDS reads per operand: the tile rows are 40 bytes apart.)
+    // v_mfma_f32_32x32x16_f16: lane l supplies k = 8 (l / 32) .. + 7 of its row / column: one 16-byte LDS read per operand
 #pragma unroll
-    for (int kk = 0; kk < BK / 16; kk++) {
-      const f16x4 a0 = *reinterpret_cast<const f16x4*>(&Ah[cur][am][kk * 16 + kh * 8]), a1 = *reinterpret_cast<const f16x4*>(&Ah[cur][am][kk * 16 + kh * 8 + 4]);
-      const f16x4 b0 = *reinterpret_cast<const f16x4*>(&Bh[cur][bn][kk * 16 + kh * 8]), b1 = *reinterpret_cast<const f16x4*>(&Bh[cur][bn][kk * 16 + kh * 8 + 4]);
-      const f16x8 a = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
-      const f16x8 b = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+    for (int kk = 0; kk < HBK / 16; kk++) {
+      const f16x8 a = *reinterpret_cast<const f16x8*>(&Ah[cur][am][kk * 16 + kh * 8]);
+      const f16x8 b = *reinterpret_cast<const f16x8*>(&Bh[cur][bn][kk * 16 + kh * 8]);
       acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc, 0, 0, 0);
     }
     if (want_colsum) {   // thread (m = tid % 64, k group = tid / 64): the rounded entries it would also have multiplied
       const int m = tid & 63, kg = tid >> 6;
 #pragma unroll
-      for (int q = 0; q < 4; q++) cs += (float)Ah[cur][m][kg * 4 + q];
+      for (int q = 0; q < 8; q++) cs += (float)Ah[cur][m][kg * 8 + q];
     }
     if (more) {
       store_tile(Ah[cur ^ 1], ra, A_KC);
@@ -297,14 +299,20 @@ __global__ void __launch_bounds__(256) gemm_f16_kernel(GemmArgs g) {
   const int col = n0 + wn * 32 + (lane & 31);
   const float bias = (g.bias && col < g.N) ? g.bias[col] : 0.f;
   float* part = g.part ? g.part + (size_t)bz * g.M * g.N : nullptr;
+  const _Float16* maskh = reinterpret_cast<const _Float16*>(g.mask);
+  _Float16* Ch = reinterpret_cast<_Float16*>(g.C);
 #pragma unroll
   for (int r = 0; r < 16; r++) {
     const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
     if (row < g.M && col < g.N) {
       float v2 = acc[r] + bias;
       if (g.relu) v2 = fmaxf(v2, 0.f);
-      if (g.mask) v2 = g.mask[(size_t)row * g.ldmask + col] > 0.f ? v2 : 0.f;
+      if (g.mask) {
+        const bool on = g.mask_half ? (float)maskh[(size_t)row * g.ldmask + col] > 0.f : g.mask[(size_t)row * g.ldmask + col] > 0.f;
+        v2 = on ? v2 : 0.f;
+      }
       if (part) part[(size_t)row * g.N + col] = v2;
+      else if (g.c_half) Ch[(size_t)row * g.ldc + col] = (_Float16)v2;
       else g.C[(size_t)row * g.ldc + col] = v2;
     }
   }
@@ -517,7 +525,8 @@ template <bool A_KC, bool B_KC>
 static void launch_gemm(const GemmArgs& g, hipStream_t s, int defer = 0, int wt = 0, int half = 0) {
   GemmArgs a = g;
   if (a.k_chunk <= 0) a.k_chunk = a.K;
-  a.k_chunk = ((a.k_chunk + BK - 1) / BK) * BK;
+  const int kstep = half ? HBK : BK;
+  a.k_chunk = ((a.k_chunk + kstep - 1) / kstep) * kstep;
   const int nz = (a.K + a.k_chunk - 1) / a.k_chunk;
   static const int env_wt = getenv("LHW_GEMM_WT") ? atoi(getenv("LHW_GEMM_WT")) : 0;   // tuning aid: 1 / 2 forces the tile size
   const int force_wt = wt ? wt : env_wt;
@@ -528,7 +537,7 @@ static void launch_gemm(const GemmArgs& g, hipStream_t s, int defer = 0, int wt 
   const int tile = (big && !half) ? 128 : 64;
   a.tiles_m = (a.M + tile - 1) / tile; a.tiles_n = (a.N + tile - 1) / tile; a.slices = nz;
   const dim3 grid(8 * (((size_t)a.tiles_m * a.tiles_n * nz + 7) / 8));
-  if (half) hipLaunchKernelGGL((gemm_f16_kernel<A_KC, B_KC>), grid, dim3(256), 0, s, a);
+  if (half) hipLaunchKernelGGL((gemm_h_kernel<A_KC, B_KC>), grid, dim3(256), 0, s, a);
   else if (big) hipLaunchKernelGGL((gemm_f32_kernel<A_KC, B_KC, 2>), grid, dim3(256), 0, s, a);
   else hipLaunchKernelGGL((gemm_f32_kernel<A_KC, B_KC, 1>), grid, dim3(256), 0, s, a);
   if (a.part && !defer) {  // ordered reduction of the split-K slices into the (accumulating) destination
@@ -560,8 +569,16 @@ static MlpLayout mlp_layout(int D, int H, int O) {
   return L;
 }
 
+// fp16 copies of one network's minibatch activations (the --fp16 update keeps them in HBM as fp16: gemm_h_kernel)
+struct HalfBufs {
+  const _Float16* x; int ldx;          // gathered inputs [rows][ldx], ldx = Dp rounded up to 8 (16-byte rows), pad columns zero
+  _Float16 *h1, *h2, *dh2, *dh1;       // [rows][H]
+};
 struct LhwPpo {
   int device, D, A, H, learn_std, max_rows;  // max_rows: capacity of the minibatch workspace (rows per net)
+  _Float16 *xb_h = nullptr, *h1a_h = nullptr, *h2a_h = nullptr, *dh2a_h = nullptr, *dh1a_h = nullptr;   // --fp16 update: fp16 storage (actor: 2R rows)
+  _Float16 *h1c_h = nullptr, *h2c_h = nullptr, *dh2c_h = nullptr, *dh1c_h = nullptr;                    // critic: R rows
+  int ldxh = 0;
   float clip, ent_coeff, mirror_coeff, grad_clip, lr, adam_eps, beta1, beta2;
   int use_mirror;
   int infer_half = 0;     // rollout inference with fp16 operands (lhw_ppo_set_inference_dtype)
@@ -616,7 +633,23 @@ static int strip_mode() {
   return m;
 }
 static void mlp_forward(const MlpLayout& L, const float* theta, const float* x, int ldx, int R, float* h1, float* h2,
-                        float* y, hipStream_t s, int half = 0, float* strip_wt = nullptr, bool wt_ready = false, bool keep_hidden = true) {
+                        float* y, hipStream_t s, int half = 0, float* strip_wt = nullptr, bool wt_ready = false, bool keep_hidden = true,
+                        const HalfBufs* hb = nullptr) {
+  if (hb && half) {   // --fp16 update: x / h1 / h2 live in fp16 (hb), the weights are rounded while staged, y stays float32 for the loss
+    GemmArgs g{};
+    g.A = reinterpret_cast<const float*>(hb->x); g.lda = hb->ldx; g.a_half = 1; g.B = theta + L.w1; g.ldb = L.Dp;
+    g.C = reinterpret_cast<float*>(hb->h1); g.ldc = L.H; g.c_half = 1; g.M = R; g.N = L.H; g.K = L.Dp; g.bias = theta + L.b1; g.relu = 1;
+    launch_gemm<true, true>(g, s, 0, 0, 1);
+    g = GemmArgs{};
+    g.A = reinterpret_cast<const float*>(hb->h1); g.lda = L.H; g.a_half = 1; g.B = theta + L.w2; g.ldb = L.H;
+    g.C = reinterpret_cast<float*>(hb->h2); g.ldc = L.H; g.c_half = 1; g.M = R; g.N = L.H; g.K = L.H; g.bias = theta + L.b2; g.relu = 1;
+    launch_gemm<true, true>(g, s, 0, 0, 1);
+    g = GemmArgs{};
+    g.A = reinterpret_cast<const float*>(hb->h2); g.lda = L.H; g.a_half = 1; g.B = theta + L.w3; g.ldb = L.H; g.C = y; g.ldc = L.Op;
+    g.M = R; g.N = L.O; g.K = L.H; g.bias = theta + L.b3;
+    launch_gemm<true, true>(g, s, 0, 0, 1);
+    return;
+  }
   if (strip_wt && !half && mlp_strip_supported(L.H, L.Dp, L.O, L.Op)) {   // one launch, h1 / h2 stay in LDS between the layers
     if (!wt_ready) mlp_strip_prepare(theta + L.w1, theta + L.w2, theta + L.w3, L.Dp, L.O, L.Op, strip_wt, s);   // [in][out] copies of the weights
     MlpStripFwd a{strip_wt, theta + L.b1, strip_wt + (size_t)L.Dp * L.H, theta + L.b2, strip_wt + (size_t)L.Dp * L.H + (size_t)L.H * L.H,
@@ -671,8 +704,38 @@ static BwdParts bwd_parts_carve(const MlpLayout& L, size_t rows, int passes, flo
 // wrote; mlp_backward_segments then lists them for the ordered reduction into grad.  Every reduction runs in a fixed order
 // (same seed -> bitwise identical weights, the property the reference's tests/test_determinism.py checks).
 static void mlp_backward(const MlpLayout& L, const float* theta, const float* x, int ldx, int R, const float* h1, const float* h2,
-                         const float* dy, float* dh2, float* dh1, const BwdParts& P, BwdSlices& z, hipStream_t s, int half = 0) {
+                         const float* dy, float* dh2, float* dh1, const BwdParts& P, BwdSlices& z, hipStream_t s, int half = 0,
+                         const HalfBufs* hb = nullptr) {
   GemmArgs g{};
+  if (hb && half) {   // --fp16 update with fp16 storage: the same five GEMMs on the fp16 copies (dy and the weights are float32)
+    auto H16 = [](const _Float16* q) { return reinterpret_cast<const float*>(q); };
+    // dW3 [O][H] = dy^T h2 ; db3 = colsum(dy)
+    g.A = dy; g.lda = L.Op; g.B = H16(hb->h2); g.ldb = L.H; g.b_half = 1; g.M = L.O; g.N = L.H; g.K = R;
+    g.part = P.w3 + (size_t)z.w3 * L.O * L.H; g.colsum = P.b3 + (size_t)z.w3 * L.O; g.k_chunk = KC_SKINNY;
+    launch_gemm<false, false>(g, s, 1, 0, 1);
+    // dh2 = (dy W3) * (h2 > 0)
+    g = GemmArgs{};
+    g.A = dy; g.lda = L.Op; g.B = theta + L.w3; g.ldb = L.H; g.C = reinterpret_cast<float*>(hb->dh2); g.ldc = L.H; g.c_half = 1;
+    g.M = R; g.N = L.H; g.K = L.O; g.mask = H16(hb->h2); g.ldmask = L.H; g.mask_half = 1;
+    launch_gemm<true, false>(g, s, 0, 0, 1);
+    // dW2 = dh2^T h1 ; db2 = colsum(dh2)
+    g = GemmArgs{};
+    g.A = H16(hb->dh2); g.lda = L.H; g.a_half = 1; g.B = H16(hb->h1); g.ldb = L.H; g.b_half = 1; g.M = L.H; g.N = L.H; g.K = R;
+    g.part = P.w2 + (size_t)z.w2 * L.H * L.H; g.colsum = P.b2 + (size_t)z.w2 * L.H; g.k_chunk = KC_WIDE;
+    launch_gemm<false, false>(g, s, 1, 0, 1);
+    // dh1 = (dh2 W2) * (h1 > 0)
+    g = GemmArgs{};
+    g.A = H16(hb->dh2); g.lda = L.H; g.a_half = 1; g.B = theta + L.w2; g.ldb = L.H; g.C = reinterpret_cast<float*>(hb->dh1); g.ldc = L.H; g.c_half = 1;
+    g.M = R; g.N = L.H; g.K = L.H; g.mask = H16(hb->h1); g.ldmask = L.H; g.mask_half = 1;
+    launch_gemm<true, false>(g, s, 0, 0, 1);
+    // dW1 [H][Dp] = dh1^T x ; db1 = colsum(dh1)
+    g = GemmArgs{};
+    g.A = H16(hb->dh1); g.lda = L.H; g.a_half = 1; g.B = H16(hb->x); g.ldb = hb->ldx; g.b_half = 1; g.M = L.H; g.N = L.Dp; g.K = R;
+    g.part = P.w1 + (size_t)z.w1 * L.H * L.Dp; g.colsum = P.b1 + (size_t)z.w1 * L.H; g.k_chunk = KC_SKINNY;
+    launch_gemm<false, false>(g, s, 1, 0, 1);
+    z.w3 += nsl(R, KC_SKINNY); z.w2 += nsl(R, KC_WIDE); z.w1 += nsl(R, KC_SKINNY);
+    return;
+  }
   const bool strip = strip_mode() >= 1 && !half && mlp_strip_supported(L.H, L.Dp, L.O, L.Op);
   if (strip) {   // dh2 = (dy W3) * (h2 > 0) and dh1 = (dh2 W2) * (h1 > 0) in one launch, the dh2 slab staying in LDS
     MlpStripBwd a{theta + L.w2, theta + L.w3, dy, h1, h2, L.O, L.Op, R, dh2, dh1};
@@ -729,6 +792,14 @@ static void mlp_backward_segments(SegList& S, const MlpLayout& L, float* grad, c
 }
 
 // ------------------------------------------------------------------------------------------- elementwise kernels
+// float32 rows [rows][ld] -> fp16 rows [rows][ldh] (ldh >= cols, pad columns zero): the gathered minibatch inputs of the --fp16 update
+__global__ void __launch_bounds__(256) rows_to_half_kernel(const float* __restrict__ src, int ld, int cols, size_t rows, _Float16* __restrict__ dst, int ldh) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * (size_t)ldh) return;
+  const size_t r = i / ldh;
+  const int c = (int)(i - r * ldh);
+  dst[i] = c < cols ? (_Float16)src[r * ld + c] : (_Float16)0.f;
+}
 // (x - mean)/std into a [R][Dp] buffer (pad columns zero); optional mirrored copy
 // mirror: out[j] = sign[j] * obs[src[j]]  == obs @ M with the clock sign flip folded in
 // (reference rl/envs/wrappers.py:53-85: sin(arcsin(c)+pi) == -c)
@@ -1019,14 +1090,16 @@ extern "C" int lhw_debug_gemm(int32_t a_kc, int32_t b_kc, int32_t wt, int32_t M,
   GemmArgs g{};
   g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.bias = bias; g.relu = relu;
   g.mask = mask; g.ldmask = ldmask; g.part = part; g.k_chunk = k_chunk; g.colsum = colsum;
-  const int defer = part != nullptr, half = wt == 16;   // wt = 16: fp16 operands on the fp16 MFMA
-  if (half) wt = 1;
+  // wt = 16 .. 31: the fp16 GEMM; bits 0..3 of (wt - 16): A / B / C / mask are STORED as fp16 (else float32, rounded while staged)
+  const int defer = part != nullptr, half = wt >= 16 && wt < 32;
+  if (half) { g.a_half = (wt - 16) & 1; g.b_half = ((wt - 16) >> 1) & 1; g.c_half = ((wt - 16) >> 2) & 1; g.mask_half = ((wt - 16) >> 3) & 1; wt = 1; }
   if (a_kc && b_kc) launch_gemm<true, true>(g, s, defer, wt, half);
   else if (a_kc && !b_kc) launch_gemm<true, false>(g, s, defer, wt, half);
   else if (!a_kc && !b_kc) launch_gemm<false, false>(g, s, defer, wt, half);
   else return lhw_fail(LHW_ERR_UNSUPPORTED, "lhw_debug_gemm: A [K][M] with B [N][K] is not used by the update");
   if (part) {   // the deferred path of the update: partials (and column sums) reduced by one launch, accumulating into C / colsum_out
-    const int kc = ((std::max(1, k_chunk > 0 ? k_chunk : K) + BK - 1) / BK) * BK;
+    const int kstep = half ? HBK : BK;
+    const int kc = ((std::max(1, k_chunk > 0 ? k_chunk : K) + kstep - 1) / kstep) * kstep;
     SegList S;
     S.n = 0; S.scale = 1.f;
     seg_add(S, part, C, (K + kc - 1) / kc, M, N, ldc);
@@ -1127,6 +1200,8 @@ extern "C" int lhw_ppo_destroy(LhwPpo* p) {
                    p->mb_act, p->mb_logp, p->mb_adv, p->mb_ret, p->stats, p->d_obs_sign, p->d_act_sign, p->part, p->dstd, p->stats_part,
                    p->norm_part, p->bwd_part, p->wt_a, p->wt_c, p->wt_inf, p->wt_roll};
   for (float* b : bufs) if (b) (void)hipFree(b);
+  _Float16* hbufs[] = {p->xb_h, p->h1a_h, p->h2a_h, p->dh2a_h, p->dh1a_h, p->h1c_h, p->h2c_h, p->dh2c_h, p->dh1c_h};
+  for (_Float16* b : hbufs) if (b) (void)hipFree(b);
   if (p->d_obs_src) (void)hipFree(p->d_obs_src);
   if (p->d_act_src) (void)hipFree(p->d_act_src);
   if (p->side) { (void)hipStreamSynchronize(p->side); (void)hipStreamDestroy(p->side); }
@@ -1144,6 +1219,16 @@ extern "C" int lhw_ppo_set_inference_dtype(LhwPpo* p, int fp16) {
 
 extern "C" int lhw_ppo_set_update_dtype(LhwPpo* p, int fp16) {
   if (!p) return lhw_fail(LHW_ERR_ARG, "null ppo");
+  if (fp16 && !p->xb_h && !(getenv("LHW_FP16_STORAGE") && atoi(getenv("LHW_FP16_STORAGE")) == 0)) {
+    // fp16 HBM storage of the minibatch activations (round 6; LHW_FP16_STORAGE=0: float32 storage rounded per GEMM, as through round 5)
+    HIPCHK(hipSetDevice(p->device));
+    const size_t R = p->max_rows, H = p->H;
+    p->ldxh = (p->la.Dp + 7) & ~7;
+    auto alloch = [&](_Float16** ptr, size_t n) { return lhw_malloc(ptr, sizeof(_Float16) * n) == hipSuccess && hipMemset(*ptr, 0, sizeof(_Float16) * n) == hipSuccess; };
+    const bool ok = alloch(&p->xb_h, 2 * R * p->ldxh) && alloch(&p->h1a_h, 2 * R * H) && alloch(&p->h2a_h, 2 * R * H) && alloch(&p->dh2a_h, 2 * R * H) &&
+                    alloch(&p->dh1a_h, 2 * R * H) && alloch(&p->h1c_h, R * H) && alloch(&p->h2c_h, R * H) && alloch(&p->dh2c_h, R * H) && alloch(&p->dh1c_h, R * H);
+    if (!ok) return lhw_fail(LHW_ERR_HIP, "fp16 workspace allocation failed (max_rows=%d)", p->max_rows);
+  }
   p->update_half = fp16 ? 1 : 0;
   return LHW_OK;
 }
@@ -1376,15 +1461,33 @@ extern "C" int lhw_ppo_grad(LhwPpo* p, const float* theta, float* grad, const fl
   hipStream_t sc = p->two_streams ? p->side : s;   // the critic's chain
   auto fork = [&]() { if (sc != s) { (void)hipEventRecord(p->ev_fork, s); (void)hipStreamWaitEvent(sc, p->ev_fork, 0); } };
   auto join = [&]() { if (sc != s) { (void)hipEventRecord(p->ev_join, sc); (void)hipStreamWaitEvent(s, p->ev_join, 0); } };
+  // --fp16 update with fp16 storage: fp16 copies of the gathered rows; every activation the GEMMs exchange stays fp16 in HBM
+  const bool hstore = p->update_half && p->xb_h != nullptr;
+  HalfBufs ha{}, hc{}, ham{};
+  if (hstore) {
+    const int ldh = p->ldxh;
+    if (mir && B == R) {
+      const size_t nn = (size_t)2 * B * ldh;
+      hipLaunchKernelGGL(rows_to_half_kernel, dim3((nn + 255) / 256), dim3(256), 0, s, p->xb, Dp, Dp, (size_t)2 * B, p->xb_h, ldh);
+    } else {
+      const size_t nn = (size_t)B * ldh;
+      hipLaunchKernelGGL(rows_to_half_kernel, dim3((nn + 255) / 256), dim3(256), 0, s, p->xb, Dp, Dp, (size_t)B, p->xb_h, ldh);
+      if (mir) hipLaunchKernelGGL(rows_to_half_kernel, dim3((nn + 255) / 256), dim3(256), 0, s, p->xb + (size_t)R * Dp, Dp, Dp, (size_t)B, p->xb_h + (size_t)R * ldh, ldh);
+    }
+    ha = HalfBufs{p->xb_h, ldh, p->h1a_h, p->h2a_h, p->dh2a_h, p->dh1a_h};
+    hc = HalfBufs{p->xb_h, ldh, p->h1c_h, p->h2c_h, p->dh2c_h, p->dh1c_h};
+    ham = HalfBufs{p->xb_h + (size_t)R * ldh, ldh, p->h1a_h + (size_t)R * p->H, p->h2a_h + (size_t)R * p->H, p->dh2a_h + (size_t)R * p->H, p->dh1a_h + (size_t)R * p->H};
+  }
+  const HalfBufs *pha = hstore ? &ha : nullptr, *phc = hstore ? &hc : nullptr, *pham = hstore ? &ham : nullptr;
   // forward: rows [0,B) and, if mirroring, rows [R, R+B)
   fork();
-  mlp_forward(p->lc, th_c, p->xb, Dp, B, p->h1c, p->h2c, p->yc, sc, p->update_half, strip_mode() >= 1 ? p->wt_c : nullptr);
+  mlp_forward(p->lc, th_c, p->xb, Dp, B, p->h1c, p->h2c, p->yc, sc, p->update_half, strip_mode() >= 1 ? p->wt_c : nullptr, false, true, phc);
   if (mir && B == R) {
-    mlp_forward(p->la, th_a, p->xb, Dp, 2 * B, p->h1a, p->h2a, p->ya, s, p->update_half, strip_mode() >= 1 ? p->wt_a : nullptr);   // mirrored rows follow without a gap
+    mlp_forward(p->la, th_a, p->xb, Dp, 2 * B, p->h1a, p->h2a, p->ya, s, p->update_half, strip_mode() >= 1 ? p->wt_a : nullptr, false, true, pha);   // mirrored rows follow without a gap
   } else {
-    mlp_forward(p->la, th_a, p->xb, Dp, B, p->h1a, p->h2a, p->ya, s, p->update_half, strip_mode() >= 1 ? p->wt_a : nullptr);
+    mlp_forward(p->la, th_a, p->xb, Dp, B, p->h1a, p->h2a, p->ya, s, p->update_half, strip_mode() >= 1 ? p->wt_a : nullptr, false, true, pha);
     if (mir)
-      mlp_forward(p->la, th_a, p->xb + (size_t)R * Dp, Dp, B, p->h1a + (size_t)R * p->H, p->h2a + (size_t)R * p->H, p->ya + (size_t)R * Op, s, p->update_half, strip_mode() >= 1 ? p->wt_a : nullptr);
+      mlp_forward(p->la, th_a, p->xb + (size_t)R * Dp, Dp, B, p->h1a + (size_t)R * p->H, p->h2a + (size_t)R * p->H, p->ya + (size_t)R * Op, s, p->update_half, strip_mode() >= 1 ? p->wt_a : nullptr, false, true, pham);
   }
   join();
   const int nblk = (B + 255) / 256;
@@ -1406,15 +1509,15 @@ extern "C" int lhw_ppo_grad(LhwPpo* p, const float* theta, float* grad, const fl
   const BwdParts Pc = bwd_parts_carve(p->lc, R, 1, p->bwd_part + bwd_parts_floats(p->la, R, 2));
   BwdSlices za, zc;
   fork();
-  mlp_backward(p->lc, th_c, p->xb, Dp, B, p->h1c, p->h2c, p->dyc, p->dh2c, p->dh1c, Pc, zc, sc, p->update_half);
+  mlp_backward(p->lc, th_c, p->xb, Dp, B, p->h1c, p->h2c, p->dyc, p->dh2c, p->dh1c, Pc, zc, sc, p->update_half, phc);
   if (mir && B == R) {
     // the mirrored rows follow the normal ones without a gap: one pass over 2B rows
-    mlp_backward(p->la, th_a, p->xb, Dp, 2 * B, p->h1a, p->h2a, p->dya, p->dh2a, p->dh1a, Pa, za, s, p->update_half);
+    mlp_backward(p->la, th_a, p->xb, Dp, 2 * B, p->h1a, p->h2a, p->dya, p->dh2a, p->dh1a, Pa, za, s, p->update_half, pha);
   } else {
-    mlp_backward(p->la, th_a, p->xb, Dp, B, p->h1a, p->h2a, p->dya, p->dh2a, p->dh1a, Pa, za, s, p->update_half);
+    mlp_backward(p->la, th_a, p->xb, Dp, B, p->h1a, p->h2a, p->dya, p->dh2a, p->dh1a, Pa, za, s, p->update_half, pha);
     if (mir)
       mlp_backward(p->la, th_a, p->xb + (size_t)R * Dp, Dp, B, p->h1a + (size_t)R * p->H, p->h2a + (size_t)R * p->H,
-                   p->dya + (size_t)R * Op, p->dh2a + (size_t)R * p->H, p->dh1a + (size_t)R * p->H, Pa, za, s, p->update_half);
+                   p->dya + (size_t)R * Op, p->dh2a + (size_t)R * p->H, p->dh1a + (size_t)R * p->H, Pa, za, s, p->update_half, pham);
   }
   join();
   SegList S;

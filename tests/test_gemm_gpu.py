@@ -151,3 +151,54 @@ def test_fused_skinny_weight_gradients_match_float64(R, Dp, O, Op):
     for u, r in zip(a, ref):
         scale = float(r.abs().max()) + 1.0
         assert float((u.double() - r).abs().max()) < 2e-5 * scale * max(1.0, (R / 32768) ** 0.5)
+
+
+@pytest.mark.parametrize("layout,M,N,K", [("fwd", 1000, 256, 40), ("fwd", 777, 12, 256), ("fwd", 515, 256, 36), ("bwd", 2049, 256, 256), ("bwd", 3000, 256, 12),
+                                          ("dw", 256, 256, 5000), ("dw", 12, 256, 4097), ("dw", 256, 40, 3000)])
+def test_fp16_storage_mode_loads_and_stores_fp16(layout, M, N, K):
+    """Round 6 (BASELINE config 5 as an fp16 pipeline): gemm_h_kernel with operands that LIVE in fp16 in HBM (wt = 16 + bits: A / B / C /
+    mask stored as fp16) -- the update's activations and back-propagated gradients -- against the same half-rounded reference as the
+    float32-storage mode: loading an fp16 buffer is loading the rounded value."""
+    import torch
+    g = torch.Generator(device="cuda").manual_seed(7 * M + 3 * N + K)
+    h = lambda x: x.half().double()
+    if layout == "fwd":          # x / h (fp16, row stride padded to 8) times float32 weights -> fp16 activations
+        Kp = (K + 7) // 8 * 8
+        A = torch.zeros(M, Kp, device="cuda", dtype=torch.float16)
+        A[:, :K] = torch.randn(M, K, device="cuda", generator=g).half()
+        W = torch.zeros(N, (K + 3) // 4 * 4, device="cuda")
+        W[:, :K] = torch.randn(N, K, device="cuda", generator=g) / K ** 0.5
+        b = torch.randn(N, device="cuda", generator=g)
+        Np = (N + 3) // 4 * 4
+        C = torch.full((M, Np), 7.0, device="cuda", dtype=torch.float16)
+        _gemm(True, True, 16 + 1 + 4, M, N, K, A, W, C, bias=b, relu=1)
+        ref = torch.relu(A[:, :K].double() @ h(W[:, :K]).t() + b.double())
+        assert (C[:, :N].double() - ref).abs().max().item() < 1e-4 + ref.abs().max().item() * 2 ** -10      # the output is rounded to fp16
+        assert (C[:, N:] == 7.0).all()
+        C32 = torch.zeros(M, Np, device="cuda")
+        _gemm(True, True, 16 + 1, M, N, K, A, W, C32, bias=b, relu=1)                                           # float32 output (the read-out layer)
+        assert (C32[:, :N].double() - ref).abs().max().item() < 1e-4
+    elif layout == "bwd":        # dh = (dy W) * (h > 0): fp16 dy / mask / output, float32 weights
+        Kp = (K + 7) // 8 * 8
+        dY = torch.zeros(M, Kp, device="cuda", dtype=torch.float16)
+        dY[:, :K] = torch.randn(M, K, device="cuda", generator=g).half()
+        W = torch.randn(K, N, device="cuda", generator=g) / K ** 0.5
+        msk = torch.randn(M, N, device="cuda", generator=g).half()
+        C = torch.zeros(M, N, device="cuda", dtype=torch.float16)
+        _gemm(True, False, 16 + 1 + 4 + 8, M, N, K, dY, W, C, mask=msk)
+        ref = (dY[:, :K].double() @ h(W)) * (msk > 0)
+        assert (C.double() - ref).abs().max().item() < 1e-4 + ref.abs().max().item() * 2 ** -10
+    else:                        # dW = dh^T h, db = colsum(dh): both operands fp16, float32 split-K partials
+        Mp = (M + 7) // 8 * 8
+        dY = torch.zeros(K, Mp, device="cuda", dtype=torch.float16)
+        dY[:, :M] = torch.randn(K, M, device="cuda", generator=g).half()
+        X = torch.randn(K, N, device="cuda", generator=g).half()
+        kc = 512
+        nz = (K + kc - 1) // kc
+        part = torch.full((nz, M * N), float("nan"), device="cuda")
+        cpart = torch.full((nz, M), float("nan"), device="cuda")
+        C = torch.zeros(M, N, device="cuda"); bsum = torch.zeros(M, device="cuda")
+        _gemm(False, False, 16 + 1 + 2, M, N, K, dY, X, C, k_chunk=kc, part=part, colsum=cpart, colsum_out=bsum)
+        ref = dY[:, :M].double().t() @ X.double()
+        assert (C.double() - ref).abs().max().item() < 2e-5 * K ** 0.5 * 4
+        assert (bsum.double() - dY[:, :M].double().sum(0)).abs().max().item() < 2e-5 * K ** 0.5 * 4
