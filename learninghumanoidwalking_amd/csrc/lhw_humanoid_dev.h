@@ -1491,7 +1491,7 @@ __device__ __noinline__ void col_box_box(BoxRec& k, HModelRef m, const L& S, int
     const double w[3] = {pa[0] - pb[0], pa[1] - pb[1], pa[2] - pb[2]};
     const double bq = sel3(i, sel3(j, R[0][0], R[0][1], R[0][2]), sel3(j, R[1][0], R[1][1], R[1][2]), sel3(j, R[2][0], R[2][1], R[2][2]));
     const double dd = dot3(Ai, w), ee = dot3(Bj, w), den = 1.0 - bq * bq;
-    const double al = (bq * ee - dd) / den, be = (ee - bq * dd) / den;
+    const double rden = rcp_f64(den), al = (bq * ee - dd) * rden, be = (ee - bq * dd) * rden;
     double pos[3];
     for (int a = 0; a < 3; a++) pos[a] = 0.5 * ((pa[a] + al * Ai[a]) + (pb[a] + be * Bj[a]));
     k.emit(ebest, pos, n, nullptr);
@@ -1559,10 +1559,11 @@ __device__ __noinline__ void col_box_box(BoxRec& k, HModelRef m, const L& S, int
     const double e1x = px[1] - px[0], e1y = py[1] - py[0], e2x = px[3] - px[0], e2y = py[3] - py[0];
     const double det = e1x * e2y - e1y * e2x;
     if (fabs(det) > 1e-14) {
+      const double rdet = rcp_f64(det);
 #pragma unroll
       for (int c = 0; c < 4; c++) {
         const double cx = (c == 0 || c == 3) ? ha : -ha, cy = (c < 2) ? hb : -hb;
-        const double al = ((cx - px[0]) * e2y - (cy - py[0]) * e2x) / det, be = (e1x * (cy - py[0]) - e1y * (cx - px[0])) / det;
+        const double al = ((cx - px[0]) * e2y - (cy - py[0]) * e2x) * rdet, be = (e1x * (cy - py[0]) - e1y * (cx - px[0])) * rdet;
         if (al >= 0 && al <= 1 && be >= 0 && be <= 1) {
           const double dep = pd[0] + al * (pd[1] - pd[0]) + be * (pd[3] - pd[0]);
           push(dep, fc[0] + cx * u[0] + cy * v[0] + dep * nr[0], fc[1] + cx * u[1] + cy * v[1] + dep * nr[1],
@@ -1575,16 +1576,17 @@ __device__ __noinline__ void col_box_box(BoxRec& k, HModelRef m, const L& S, int
   for (int q = 0; q < 4; q++) {
     const int q1 = (q + 1) & 3;
     const double dx = px[q1] - px[q], dy = py[q1] - py[q], dd = pd[q1] - pd[q];
+    const double rdx = rcp_f64(dx), rdy = rcp_f64(dy);   // (one reciprocal per edge direction instead of two divisions per side; dx == 0 / dy == 0 edges are masked by `ok`)
 #pragma unroll
     for (int sd = 0; sd < 4; sd++) {
       double tt = 0, other = 0, lim = 0;
       bool ok;
       if (sd < 2) {
         ok = dx != 0;
-        tt = ((sd == 0 ? ha : -ha) - px[q]) / dx; other = py[q] + tt * dy; lim = hb;
+        tt = ((sd == 0 ? ha : -ha) - px[q]) * rdx; other = py[q] + tt * dy; lim = hb;
       } else {
         ok = dy != 0;
-        tt = ((sd == 2 ? hb : -hb) - py[q]) / dy; other = px[q] + tt * dx; lim = ha;
+        tt = ((sd == 2 ? hb : -hb) - py[q]) * rdy; other = px[q] + tt * dx; lim = ha;
       }
       if (ok && tt > 0 && tt < 1 && fabs(other) < lim)
         push(pd[q] + tt * dd, P[q][0] + tt * (P[q1][0] - P[q][0]), P[q][1] + tt * (P[q1][1] - P[q][1]), P[q][2] + tt * (P[q1][2] - P[q][2]));
