@@ -89,6 +89,9 @@ typedef struct {
   const double* clock_lut;       /* walking: [4][period] r_frc, r_vel, l_frc, l_vel at integer phases
                                     (tasks/rewards.py:196-300 evaluated on 0..period-1) */
   int32_t period;
+  double init_noise;             /* BaseHumanoidEnv._apply_init_noise (envs/common/base_humanoid_env.py:278-305) for ANY humanoid task: half-width in
+                                    radians of the uniform noise on root roll / pitch and every joint at reset (root z += U(0, 0.02)); 0 = off.
+                                    (H1 tasks may also give it as task_params[LHW_TP_H1_INIT_NOISE]; this field wins when > 0.) */
 } LhwEnvConfig;
 
 /* task_params indices: [0] target root height (walking goal_height / standing 0.98); H1 standing adds the

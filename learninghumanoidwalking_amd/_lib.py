@@ -27,7 +27,7 @@ class LhwEnvConfig(ctypes.Structure):
         ("kp", ctypes.c_void_p), ("kd", ctypes.c_void_p), ("nominal_qpos", ctypes.c_void_p),
         ("action_offset", ctypes.c_void_p), ("task_params", ctypes.c_void_p), ("n_task_params", ctypes.c_int32),
         ("task_iparams", ctypes.c_void_p), ("n_task_iparams", ctypes.c_int32),
-        ("clock_lut", ctypes.c_void_p), ("period", ctypes.c_int32),
+        ("clock_lut", ctypes.c_void_p), ("period", ctypes.c_int32), ("init_noise", ctypes.c_double),
     ]
 
 

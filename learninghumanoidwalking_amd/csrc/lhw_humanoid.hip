@@ -480,6 +480,7 @@ int humanoid_create(HumanoidEnv** out, const std::vector<int32_t>& mi, const std
     for (int k = 0; k < 11; k++) if (p.rand_body[k] <= 0 || p.rand_body[k] >= nb) ok = false;
     p.env_params = 1;
   }
+  if (cfg->init_noise > 0) p.init_noise = cfg->init_noise;   // any humanoid task (base_humanoid_env.py:260-263)
   std::vector<double> nominal(nq), neutral(nu);
   for (int k = 0; k < nq; k++) nominal[k] = cfg->nominal_qpos ? cfg->nominal_qpos[k] : DF(LHW_DF_QPOS0)[k];
   for (int u = 0; u < nu; u++) neutral[u] = cfg->action_offset[u];  // task._neutral_pose == half-sitting pose == offsets (jvrc_walk.py:33)
@@ -538,7 +539,7 @@ int humanoid_create(HumanoidEnv** out, const std::vector<int32_t>& mi, const std
   if (!ok) { humanoid_destroy(h); return lhw_fail(LHW_ERR_HIP, "humanoid_create: device allocation failed or bad body ids"); }
   *obs_dim = stepping ? 39 : (walk ? 37 : (h1walk ? 43 : 35)); *act_dim = nu; *n_terms = ((walk && !stepping) || h1walk) ? 10 : 6;
   p.reset_template = -1;
-  if (p.task == TASK_WALK && !getenv("LHW_NO_RESET_TEMPLATE")) {
+  if (p.task == TASK_WALK && !(p.init_noise > 0) && !getenv("LHW_NO_RESET_TEMPLATE")) {   // (with init noise every reset has its own state: computed)
     // reset the template record (index N) once with the ordinary reset kernel; auto-resets copy its state from then on
     if (!humanoid_upload_params(h)) { humanoid_destroy(h); return lhw_fail(LHW_ERR_HIP, "humanoid_create: parameter upload failed"); }
     const HLaunch lz{(int)N, 1, 0, 0, 0};

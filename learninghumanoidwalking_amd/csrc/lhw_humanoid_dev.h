@@ -3733,19 +3733,19 @@ __device__ __forceinline__ bool control_step(HModelRef m, HParamsRef p, const HL
         // mj_resetData clears xfrc_applied; dynamics randomisation on reset (base_humanoid_env.py:254-255), slots 0..63
         if (lane < 12) { S.xfrc[lane] = 0; prm[P_XFRC + lane] = 0; }
         if (p.dynrand_interval > 0) randomize_dynamics(m, p, S, prm, lane, genv, LHW_STREAM_RESET, reset_count, 0);
-        SYNC();
-        if (p.init_noise > 0) {  // _apply_init_noise (base_humanoid_env.py:278-305): slot 64 root z, 65/66 roll/pitch, 67.. joints
-          const double cn = p.init_noise;
-          if (lane == 0) {
-            const double z0 = p.nominal_qpos[2];
-            S.qpos[2] = lhw_rng_uniform(p.seed, genv, LHW_STREAM_RESET, reset_count, 64, z0, z0 + 0.02);
-            const double ai = 0.5 * lhw_rng_uniform(p.seed, genv, LHW_STREAM_RESET, reset_count, 65, -cn, cn);
-            const double aj = 0.5 * lhw_rng_uniform(p.seed, genv, LHW_STREAM_RESET, reset_count, 66, -cn, cn);
-            const double ci = cos(ai), si = sin(ai), cj = cos(aj), sj = sin(aj);   // euler2quat(ai, aj, 0), static xyz
-            S.qpos[3] = cj * ci; S.qpos[4] = cj * si; S.qpos[5] = sj * ci; S.qpos[6] = -sj * si;
-          }
-          if (lane >= 7 && lane < m.nq) S.qpos[lane] += lhw_rng_uniform(p.seed, genv, LHW_STREAM_RESET, reset_count, 67 + (lane - 7), -cn, cn);
+      }
+      SYNC();   // (the nominal pose is in place before lane 0 overwrites the root's part of it)
+      if (p.init_noise > 0) {  // _apply_init_noise (base_humanoid_env.py:278-305), any task: slot 64 root z, 65/66 roll/pitch, 67.. joints
+        const double cn = p.init_noise;
+        if (lane == 0) {
+          const double z0 = p.nominal_qpos[2];
+          S.qpos[2] = lhw_rng_uniform(p.seed, genv, LHW_STREAM_RESET, reset_count, 64, z0, z0 + 0.02);
+          const double ai = 0.5 * lhw_rng_uniform(p.seed, genv, LHW_STREAM_RESET, reset_count, 65, -cn, cn);
+          const double aj = 0.5 * lhw_rng_uniform(p.seed, genv, LHW_STREAM_RESET, reset_count, 66, -cn, cn);
+          const double ci = cos(ai), si = sin(ai), cj = cos(aj), sj = sin(aj);   // euler2quat(ai, aj, 0), static xyz
+          S.qpos[3] = cj * ci; S.qpos[4] = cj * si; S.qpos[5] = sj * ci; S.qpos[6] = -sj * si;
         }
+        if (lane >= 7 && lane < m.nq) S.qpos[lane] += lhw_rng_uniform(p.seed, genv, LHW_STREAM_RESET, reset_count, 67 + (lane - 7), -cn, cn);
       }
       SYNC();
       flags = 0;   // set_state: forward pass with actuation disabled

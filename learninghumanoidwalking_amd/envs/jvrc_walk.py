@@ -82,9 +82,12 @@ class JvrcWalkSpec:
         #                            JvrcBaseEnv._get_robot_state (jvrc_base.py:133-138) never does -> accepted and ignored here too
         #   dynamics_randomization   raises: randomize_dynamics looks up the body "pelvis" (domain_randomization.py:44), which a JVRC
         #                            model does not have (its root is "PELVIS_S", jvrc_base.py:32) -> KeyError in the reference, refused here
-        #   perturbation, init_noise would run in the reference; the JVRC kernels do not implement them (the H1 kernels do, and the
-        #                            JVRC auto-reset copies a precomputed post-reset state): refused, not silently ignored
-        for key in ("init_noise", "dynamics_randomization", "perturbation"):
+        #   init_noise               runs there (base_humanoid_env.py:260-263, 278-305) and here: root z / roll / pitch / joint noise at every
+        #                            reset, in every humanoid kernel (the JVRC auto-reset then computes the reset instead of copying a template)
+        #   perturbation             would run in the reference; the JVRC kernels do not implement it (per-env applied wrenches need the
+        #                            H1 layouts' per-env parameter block, which does not fit the JVRC two-envs-per-wave LDS budget): refused
+        self.init_noise_deg = float(c.get("init_noise") or 0.0)
+        for key in ("dynamics_randomization", "perturbation"):
             v = c.get(key)
             on = (v.get("enable", v.get("enabled", False)) if isinstance(v, dict) else bool(v))
             if on:
@@ -178,7 +181,8 @@ class JvrcWalkSpec:
                           device=device, max_traj_len=max_traj_len, env_id_base=env_id_base,
                           action_smoothing=self.action_smoothing, nominal_qpos=self.nominal_pose,
                           action_offset=self.action_offset(), task_params=[self.goal_height],
-                          task_iparams=self.body_ids(), clock_lut=self.clock_lut(), history_len=self.history_len)
+                          task_iparams=self.body_ids(), clock_lut=self.clock_lut(), history_len=self.history_len,
+                          init_noise=np.deg2rad(self.init_noise_deg))
 
     def algorithmic_bytes_per_env_step(self) -> int:
         """Persistent state record read + written once per control step (168 f64 words) plus

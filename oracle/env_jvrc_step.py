@@ -138,7 +138,7 @@ class OracleJvrcStepEnv(OracleJvrcWalkEnv):
     def reset(self):
         c = self.reset_count
         self.sim.reset_data()
-        self.set_state(self.spec.nominal_pose, np.zeros(self.m.nv))
+        self.set_state(self._reset_pose(c), np.zeros(self.m.nv))
         for _ in range(3):
             self.sim.step()
         self._task_reset(c)

@@ -144,10 +144,24 @@ class OracleJvrcWalkEnv:
         self.sim.qvel[:] = qvel
         self.sim.forward(actuation=False)
 
+    def _reset_pose(self, c):
+        """nominal pose, with BaseHumanoidEnv._apply_init_noise when the YAML sets init_noise (envs/common/base_humanoid_env.py:
+        260-263, 278-305): RESET-stream slots 64 root z, 65 / 66 roll / pitch, 67.. joints (the slots the H1 envs use)"""
+        qpos = np.array(self.spec.nominal_pose, dtype=float).copy()
+        cn = np.deg2rad(getattr(self.spec, "init_noise_deg", 0.0))
+        if cn > 0:
+            from .env_h1 import euler2quat_sxyz
+            s, e = self.seed, self.env_id
+            qpos[2] = rng.uniform(s, e, rng.STREAM_RESET, c, 64, qpos[2], qpos[2] + 0.02)
+            qpos[3:7] = euler2quat_sxyz(rng.uniform(s, e, rng.STREAM_RESET, c, 65, -cn, cn), rng.uniform(s, e, rng.STREAM_RESET, c, 66, -cn, cn), 0)
+            for k in range(len(qpos) - 7):
+                qpos[7 + k] += rng.uniform(s, e, rng.STREAM_RESET, c, 67 + k, -cn, cn)
+        return qpos
+
     def reset(self):
         s, e, c = self.seed, self.env_id, self.reset_count
         self.sim.reset_data()
-        self.set_state(self.spec.nominal_pose, np.zeros(self.m.nv))
+        self.set_state(self._reset_pose(c), np.zeros(self.m.nv))
         for _ in range(3):      # base_humanoid_env.py:268-269, ctrl is zero after mj_resetData
             self.sim.step()
         self._walk_task_reset(c)

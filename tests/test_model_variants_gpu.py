@@ -93,3 +93,40 @@ def test_h1_gaussian_observation_noise(tmp_path):
     np.testing.assert_allclose(obs, ref, rtol=1e-6, atol=2e-5)
     tape = (np.random.default_rng(1).normal(size=(3, n, 10)) * 0.05).astype(np.float32)
     _run_tape(env, orc, tape, otol=2e-4)
+
+
+@pytest.mark.parametrize("task", ["jvrc_walk", "jvrc_step"])
+def test_jvrc_init_noise(tmp_path, task):
+    """init_noise in a JVRC YAML (base_humanoid_env.py:260-263, 278-305): the explicit reset and the auto-resets inside the control steps
+    (two envs per wave: computed in the wave, no template copy) draw their own poses -- kernel == oracle draw for draw, 67 envs so that
+    every position of a wavefront meets a reset.  GPU twin of tests/test_emu_stepper.py::test_emulated_jvrc_init_noise."""
+    import yaml
+    from learninghumanoidwalking_amd.envs.jvrc_step import JvrcStepSpec
+    from learninghumanoidwalking_amd.envs.jvrc_walk import JVRC_BASE_YAML, JvrcWalkSpec
+    from oracle.env_jvrc_step import OracleJvrcStepEnv
+    from oracle.env_jvrc_walk import OracleJvrcWalkEnv
+    cfg = yaml.safe_load(open(JVRC_BASE_YAML))
+    cfg["init_noise"] = 3
+    path = tmp_path / "jvrc_noise.yaml"
+    path.write_text(yaml.safe_dump(cfg))
+    S, O = (JvrcWalkSpec, OracleJvrcWalkEnv) if task == "jvrc_walk" else (JvrcStepSpec, OracleJvrcStepEnv)
+    spec = S(yaml_path=str(path))
+    n, L = 67, 2
+    env = _Numpy(spec.make_batched(n, seed=13, device=0, max_traj_len=L))
+    orc = [O(spec, seed=13, env_id=i, max_traj_len=L) for i in range(n)]
+    obs = env.reset()
+    ref = np.array([o.reset() for o in orc])
+    np.testing.assert_allclose(obs, ref, rtol=1e-6, atol=2e-6)
+    q, _ = env.get_state()
+    assert np.abs(q[:, 7:] - np.asarray(spec.nominal_pose)[7:]).max(axis=1).min() > 1e-3
+    tape = (np.random.default_rng(2).normal(size=(5, n, 12)) * 0.1).astype(np.float32)
+    for t in range(tape.shape[0]):
+        o_dev, rew, done, tob = env.step(tape[t])
+        res = [o.step_auto(tape[t, i]) for i, o in enumerate(orc)]
+        q, v = env.get_state()
+        np.testing.assert_array_equal(done, np.array([r[2] for r in res], dtype=np.uint8), err_msg=f"flags t={t}")
+        np.testing.assert_allclose(q, np.array([o.sim.qpos for o in orc]), rtol=0, atol=1e-11, err_msg=f"qpos t={t}")
+        np.testing.assert_allclose(v, np.array([o.sim.qvel for o in orc]), rtol=0, atol=1e-9, err_msg=f"qvel t={t}")
+        np.testing.assert_allclose(o_dev, np.array([r[0] for r in res]), rtol=1e-5, atol=2e-5, err_msg=f"obs t={t}")
+        np.testing.assert_allclose(rew, np.array([r[1] for r in res]), rtol=0, atol=2e-6, err_msg=f"rew t={t}")
+    assert env.pop_fault_stats() == (0, 0)
