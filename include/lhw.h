@@ -92,6 +92,14 @@ typedef struct {
   double init_noise;             /* BaseHumanoidEnv._apply_init_noise (envs/common/base_humanoid_env.py:278-305) for ANY humanoid task: half-width in
                                     radians of the uniform noise on root roll / pitch and every joint at reset (root z += U(0, 0.02)); 0 = off.
                                     (H1 tasks may also give it as task_params[LHW_TP_H1_INIT_NOISE]; this field wins when > 0.) */
+  /* apply_perturbation for the JVRC tasks (envs/common/domain_randomization.py:10-26 behind base_humanoid_env.py:86-92, 224-225; the H1 tasks
+   * carry theirs in task_params / task_iparams): after the observation of a control step, with probability 1 / interval, every listed body
+   * receives a world-frame force U(+-force)^3 and torque U(+-torque)^3 at its centre of mass, each body followed by a coin flip that clears ALL
+   * applied wrenches; they act until the next draw or reset.  interval = int(cfg.interval / control_dt) control steps, 0 = off. */
+  int32_t perturb_interval;
+  int32_t n_perturb_bodies;      /* <= 2 */
+  int32_t perturb_bodies[2];     /* body ids of the packed model */
+  double perturb_force, perturb_torque;
 } LhwEnvConfig;
 
 /* task_params indices: [0] target root height (walking goal_height / standing 0.98); H1 standing adds the

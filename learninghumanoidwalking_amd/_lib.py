@@ -28,6 +28,8 @@ class LhwEnvConfig(ctypes.Structure):
         ("action_offset", ctypes.c_void_p), ("task_params", ctypes.c_void_p), ("n_task_params", ctypes.c_int32),
         ("task_iparams", ctypes.c_void_p), ("n_task_iparams", ctypes.c_int32),
         ("clock_lut", ctypes.c_void_p), ("period", ctypes.c_int32), ("init_noise", ctypes.c_double),
+        ("perturb_interval", ctypes.c_int32), ("n_perturb_bodies", ctypes.c_int32), ("perturb_bodies", ctypes.c_int32 * 2),
+        ("perturb_force", ctypes.c_double), ("perturb_torque", ctypes.c_double),
     ]
 
 

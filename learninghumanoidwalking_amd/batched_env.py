@@ -49,7 +49,7 @@ class BatchedEnv:
     def __init__(self, model: Model, task: int, n_envs: int, *, frame_skip: int, kp, kd, seed: int = 0,
                  device: int | torch.device = 0, max_traj_len: int = 0, env_id_base: int = 0,
                  action_smoothing: float = 1.0, nominal_qpos=None, action_offset=None, task_params=None,
-                 task_iparams=None, clock_lut=None, history_len: int = 1, init_noise: float = 0.0):
+                 task_iparams=None, clock_lut=None, history_len: int = 1, init_noise: float = 0.0, perturbation: dict | None = None):
         if not torch.cuda.is_available():
             raise _lib.LhwError(-5, "no GPU visible: BatchedEnv has no CPU fallback")
         self.device = torch.device("cuda", device) if isinstance(device, int) else device
@@ -81,6 +81,14 @@ class BatchedEnv:
         cfg.clock_lut = lut
         cfg.period = 0 if clock_lut is None else int(np.asarray(clock_lut).shape[-1])
         cfg.init_noise = float(init_noise)      # radians (base_humanoid_env.py:287: cfg.init_noise degrees * pi / 180)
+        if perturbation:                        # JVRC tasks: dict(interval=<control steps>, bodies=[ids], force=, torque=)
+            bodies = [int(b) for b in perturbation.get("bodies", [])]
+            if len(bodies) > 2:
+                raise ValueError("perturbation: at most two bodies")
+            cfg.perturb_interval, cfg.n_perturb_bodies = int(perturbation["interval"]), len(bodies)
+            for i, b in enumerate(bodies):
+                cfg.perturb_bodies[i] = b
+            cfg.perturb_force, cfg.perturb_torque = float(perturbation.get("force", 0.0)), float(perturbation.get("torque", 0.0))
         self._h = ctypes.c_void_p()
         L = _lib.lib()
         _lib.check(L.lhw_env_create(self._ib.ctypes.data, self._ib.size, self._db.ctypes.data, self._db.size,

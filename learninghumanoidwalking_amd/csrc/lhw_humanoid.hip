@@ -481,6 +481,18 @@ int humanoid_create(HumanoidEnv** out, const std::vector<int32_t>& mi, const std
     p.env_params = 1;
   }
   if (cfg->init_noise > 0) p.init_noise = cfg->init_noise;   // any humanoid task (base_humanoid_env.py:260-263)
+  bool jvrc_perturb = false;
+  if (walk && cfg->perturb_interval > 0) {   // apply_perturbation on a JVRC task: wrenches live in the per-env record (no LDS copy: see chain_dynamics)
+    if (cfg->n_perturb_bodies < 1 || cfg->n_perturb_bodies > 2) ok = false;
+    p.perturb_interval = cfg->perturb_interval; p.n_pbody = cfg->n_perturb_bodies;
+    p.force_mag = cfg->perturb_force; p.torque_mag = cfg->perturb_torque;
+    for (int k = 0; ok && k < p.n_pbody; k++) {
+      const int b = cfg->perturb_bodies[k];
+      p.pbody[k] = (b > 0 && b < nbm) ? bmap[b] : -1;
+      if (p.pbody[k] <= 0 || p.pbody[k] >= nb) ok = false;
+    }
+    jvrc_perturb = ok;
+  }
   std::vector<double> nominal(nq), neutral(nu);
   for (int k = 0; k < nq; k++) nominal[k] = cfg->nominal_qpos ? cfg->nominal_qpos[k] : DF(LHW_DF_QPOS0)[k];
   for (int u = 0; u < nu; u++) neutral[u] = cfg->action_offset[u];  // task._neutral_pose == half-sitting pose == offsets (jvrc_walk.py:33)
@@ -490,7 +502,7 @@ int humanoid_create(HumanoidEnv** out, const std::vector<int32_t>& mi, const std
   ok = ok && (p.clock_lut = to_dev<double>(h, cfg->clock_lut, (walk || h1walk) ? (size_t)4 * cfg->period : 0));
   const size_t N = cfg->n_envs;
   h->st.prm = nullptr;
-  if (ok && p.env_params) {
+  if (ok && (p.env_params || jvrc_perturb)) {
     // per-env parameter records start from the model's defaults
     std::vector<double> one(PRM_D, 0.0), all((size_t)PRM_D * N);
     for (int d = 0; d < nv; d++) { one[P_DAMP + d] = DF(LHW_DF_DOF_DAMPING)[d]; one[P_FLOSS + d] = DF(LHW_DF_DOF_FRICTIONLOSS)[d]; }
@@ -501,6 +513,7 @@ int humanoid_create(HumanoidEnv** out, const std::vector<int32_t>& mi, const std
     for (size_t n = 0; n < N; n++) std::copy(one.begin(), one.end(), all.begin() + n * PRM_D);
     h->st.prm = const_cast<double*>(to_dev<double>(h, all.data(), all.size()).p);
     ok = ok && h->st.prm != nullptr;
+    if (jvrc_perturb) p.xfrc_base = DevTab<double>{h->st.prm};
   }
   h->st.ter = nullptr;
   if (ok && stepping) {
@@ -539,7 +552,7 @@ int humanoid_create(HumanoidEnv** out, const std::vector<int32_t>& mi, const std
   if (!ok) { humanoid_destroy(h); return lhw_fail(LHW_ERR_HIP, "humanoid_create: device allocation failed or bad body ids"); }
   *obs_dim = stepping ? 39 : (walk ? 37 : (h1walk ? 43 : 35)); *act_dim = nu; *n_terms = ((walk && !stepping) || h1walk) ? 10 : 6;
   p.reset_template = -1;
-  if (p.task == TASK_WALK && !(p.init_noise > 0) && !getenv("LHW_NO_RESET_TEMPLATE")) {   // (with init noise every reset has its own state: computed)
+  if (p.task == TASK_WALK && !(p.init_noise > 0) && !jvrc_perturb && !getenv("LHW_NO_RESET_TEMPLATE")) {   // (with init noise every reset has its own state: computed)
     // reset the template record (index N) once with the ordinary reset kernel; auto-resets copy its state from then on
     if (!humanoid_upload_params(h)) { humanoid_destroy(h); return lhw_fail(LHW_ERR_HIP, "humanoid_create: parameter upload failed"); }
     const HLaunch lz{(int)N, 1, 0, 0, 0};

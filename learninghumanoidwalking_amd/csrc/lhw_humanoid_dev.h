@@ -264,6 +264,7 @@ struct HParams {
   unsigned long long seed;
   double action_smoothing, goal_height, init_noise, force_mag, torque_mag;
   gtab_d clock_lut;
+  gtab_d xfrc_base;                     // JVRC tasks with perturbations: the per-env parameter records [N][PRM_D] (chain_dynamics reads P_XFRC of its env); else NULL
   double kp[NU], kd[NU], nominal_qpos[NQ], action_offset[NU], neutral_pose[NU], obs_noise[36];   // (members, like the model tables)
 };
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -494,6 +495,7 @@ struct LdsT : StepLds<STEP_T, W_T / 4> {
   static constexpr int OBSF_ = USIZE_ - 24;
   __device__ __forceinline__ float* obsf() { return reinterpret_cast<float*>(U + OBSF_); }
   int ncon, overflow;
+  int env_id;   // index of the env this group advances (what chain_dynamics needs to find the env's applied wrenches in HBM: JVRC perturbations)
 };
 enum { CI_PHASE = 0, CI_MODE, CI_TRAJ, CI_STARTED, CI_STEPCNT, CI_RESETCNT, CI_OBSCNT, CI_T1, CI_T2, CI_REACHED, CI_FRAMES, CI_NSEQ };
 #define CTX_LOAD()                                                                                                     \
@@ -1211,15 +1213,34 @@ __device__ __forceinline__ void chain_dynamics(HModelRef m, HParamsRef p, L& S, 
     qv = S.qvel[dd];
   }
   // ---- mj_xfrcAccumulate: Cartesian force / torque applied at the com of the perturbed bodies -> joint space
+  // (H1 layouts: the wrenches sit in LDS with the env's other per-env parameters.  JVRC tasks with `perturbation` configured read them from
+  // the env's HBM record -- p.xfrc_base + the env index parked in LDS -- because their two-envs-per-wave layout has no LDS left for twelve
+  // more doubles per env, and nothing of it may ride through the sub-step in registers: the branch is a uniform scalar test when it is off)
   qapp = 0;
-  if (L::PRM_ && p.env_params && isdof) {
-    for (int k = 0; k < p.n_pbody; k++) {
-      const int pb = p.pbody[k];
-      if (!(((unsigned)m.body_i[BIS * pb + BI_DOFMASK] >> dd) & 1u)) continue;
-      double off[3], t[3];
-      for (int a = 0; a < 3; a++) off[a] = S.U[U_XIPOS + 3 * pb + a] - S.com[a];
-      cross3(t, cd, off);
-      for (int a = 0; a < 3; a++) qapp += (cd[3 + a] + t[a]) * S.xfrc[6 * k + a] + cd[a] * S.xfrc[6 * k + 3 + a];
+  if constexpr (L::PRM_) {
+    if (p.env_params && isdof) {
+      for (int k = 0; k < p.n_pbody; k++) {
+        const int pb = p.pbody[k];
+        if (!(((unsigned)m.body_i[BIS * pb + BI_DOFMASK] >> dd) & 1u)) continue;
+        double off[3], t[3];
+        for (int a = 0; a < 3; a++) off[a] = S.U[U_XIPOS + 3 * pb + a] - S.com[a];
+        cross3(t, cd, off);
+        for (int a = 0; a < 3; a++) qapp += (cd[3 + a] + t[a]) * S.xfrc[6 * k + a] + cd[a] * S.xfrc[6 * k + 3 + a];
+      }
+    }
+  } else if (p.perturb_interval > 0) {
+    if (isdof) {
+      gtab_d xr = p.xfrc_base + (size_t)S.env_id * PRM_D + P_XFRC;
+#pragma unroll
+      for (int k = 0; k < 2; k++) {
+        if (k >= p.n_pbody) break;
+        const int pb = p.pbody[k];
+        if (!(((unsigned)m.body_i[BIS * pb + BI_DOFMASK] >> dd) & 1u)) continue;
+        double off[3], t[3];
+        for (int a = 0; a < 3; a++) off[a] = S.U[U_XIPOS + 3 * pb + a] - S.com[a];
+        cross3(t, cd, off);
+        for (int a = 0; a < 3; a++) qapp += (cd[3 + a] + t[a]) * xr[6 * k + a] + cd[a] * xr[6 * k + 3 + a];
+      }
     }
   }
   // ---- velocities (mj_comVel): cvel of the body behind each dof, cdof_dot
@@ -3250,7 +3271,7 @@ __device__ __forceinline__ bool control_step(HModelRef m, HParamsRef p, const HL
     if (lane < 12) S.xfrc[lane] = prm ? prm[P_XFRC + lane] : 0.0;
   }
   SYNC();
-  if (lane == 0) { S.overflow = 0; if constexpr (L::STEP_) S.nbig = 0; }
+  if (lane == 0) { S.overflow = 0; S.env_id = env; if constexpr (L::STEP_) S.nbig = 0; }
   SYNC();
 
   // One loop, one sub-step call site.  Each env walks through its stages -- the frame_skip control sub-steps, then (if
@@ -3591,6 +3612,30 @@ __device__ __forceinline__ bool control_step(HModelRef m, HParamsRef p, const HL
           }
           step_count++;
         }
+        if constexpr (TASK == TASK_WALK || TASK == TASK_STEP) {
+          // apply_perturbation on a JVRC task (LhwEnvConfig.perturb_*; base_humanoid_env.py:224-225 behind get_obs): the draws of the H1 tasks
+          // -- STEP stream, slot 70 the trigger, 71.. per body force / torque / coin -- under the counter this control step's task draws used.
+          // (the record's address is re-derived here from an opaque copy of the env index: nothing of this block is live in the sub-steps)
+          if (p.perturb_interval > 0) {
+            const unsigned pc = step_count - 1u;
+            if (lhw_rng_randint(p.seed, genv, LHW_STREAM_STEP, pc, 70, p.perturb_interval) == 0) {
+              double* xr = st.prm + (size_t)opaque_int(env) * PRM_D + P_XFRC;
+              double v = lane < 12 ? xr[lane] : 0.0;      // lane = component: body lane / 6, axis lane % 6
+#pragma unroll
+              for (int k = 0; k < 2; k++) {
+                if (k < p.n_pbody) {
+                  if (lane >= 6 * k && lane < 6 * k + 6) {
+                    const int a = lane - 6 * k;
+                    v = a < 3 ? lhw_rng_uniform(p.seed, genv, LHW_STREAM_STEP, pc, 71 + 7 * k + a, -p.force_mag, p.force_mag)
+                              : lhw_rng_uniform(p.seed, genv, LHW_STREAM_STEP, pc, 74 + 7 * k + (a - 3), -p.torque_mag, p.torque_mag);
+                  }
+                  if (lhw_rng_randint(p.seed, genv, LHW_STREAM_STEP, pc, 77 + 7 * k, 2) == 0) v = 0.0;   // the coin clears ALL applied wrenches
+                }
+              }
+              if (lane < 12) xr[lane] = v;
+            }
+          }
+        }
         if (lane == 0) {
           rew[env] = (float)r_sum;
           done_out[env] = (terminated ? 1 : 0) | (truncated ? 2 : 0);
@@ -3733,6 +3778,8 @@ __device__ __forceinline__ bool control_step(HModelRef m, HParamsRef p, const HL
         // mj_resetData clears xfrc_applied; dynamics randomisation on reset (base_humanoid_env.py:254-255), slots 0..63
         if (lane < 12) { S.xfrc[lane] = 0; prm[P_XFRC + lane] = 0; }
         if (p.dynrand_interval > 0) randomize_dynamics(m, p, S, prm, lane, genv, LHW_STREAM_RESET, reset_count, 0);
+      } else if (p.perturb_interval > 0) {   // JVRC task with perturbations: mj_resetData clears xfrc_applied
+        if (lane < 12) st.prm[(size_t)opaque_int(env) * PRM_D + P_XFRC + lane] = 0;
       }
       SYNC();   // (the nominal pose is in place before lane 0 overwrites the root's part of it)
       if (p.init_noise > 0) {  // _apply_init_noise (base_humanoid_env.py:278-305), any task: slot 64 root z, 65/66 roll/pitch, 67.. joints

@@ -84,16 +84,19 @@ class JvrcWalkSpec:
         #                            model does not have (its root is "PELVIS_S", jvrc_base.py:32) -> KeyError in the reference, refused here
         #   init_noise               runs there (base_humanoid_env.py:260-263, 278-305) and here: root z / roll / pitch / joint noise at every
         #                            reset, in every humanoid kernel (the JVRC auto-reset then computes the reset instead of copying a template)
-        #   perturbation             would run in the reference; the JVRC kernels do not implement it (per-env applied wrenches need the
-        #                            H1 layouts' per-env parameter block, which does not fit the JVRC two-envs-per-wave LDS budget): refused
+        #   perturbation             runs there (base_humanoid_env.py:86-92, 224-225; domain_randomization.py:10-26) and here: the wrenches live
+        #                            in the per-env HBM record (LhwEnvConfig.perturb_*; at most two bodies, as the H1 kernels)
         self.init_noise_deg = float(c.get("init_noise") or 0.0)
-        for key in ("dynamics_randomization", "perturbation"):
-            v = c.get(key)
-            on = (v.get("enable", v.get("enabled", False)) if isinstance(v, dict) else bool(v))
-            if on:
-                why = ("the reference itself fails on it for a JVRC model (randomize_dynamics needs a body named 'pelvis')" if key == "dynamics_randomization"
-                       else "the JVRC kernels do not implement it (the H1 kernels do)")
-                raise NotImplementedError(f"{key} is configured in {self.yaml_path}: {why}")
+        pc = c.get("perturbation") or {}
+        self.perturb_interval = int(pc["interval"] / self.control_dt) if pc.get("enable") else 0
+        self.perturb_bodies = list(pc.get("bodies", [])) if self.perturb_interval > 0 else []
+        self.force_magnitude, self.torque_magnitude = float(pc.get("force_magnitude", 0)), float(pc.get("torque_magnitude", 0))
+        if len(self.perturb_bodies) > 2:
+            raise NotImplementedError(f"perturbation of more than two bodies ({self.perturb_bodies}) in {self.yaml_path}")
+        v = c.get("dynamics_randomization")
+        if isinstance(v, dict) and v.get("enable", v.get("enabled", False)):
+            raise NotImplementedError(f"dynamics_randomization is configured in {self.yaml_path}: the reference itself fails on it for a JVRC model "
+                                      "(randomize_dynamics needs a body named 'pelvis', envs/common/domain_randomization.py:44)")
         self.action_smoothing = float(c["action_smoothing"])
         self.kp, self.kd = np.array(c["kp"], dtype=float), np.array(c["kd"], dtype=float)
         self.half_sitting_pose = np.deg2rad(np.array(c["half_sitting_pose"], dtype=float))
@@ -137,7 +140,7 @@ class JvrcWalkSpec:
                 raise ValueError("model does not have the JVRC leg actuator layout (free root + 12 leg hinges)")
             # a real JVRC export keeps ~30 arm / head / finger links welded to the torso after gen_xml.py:84-87 deleted their
             # joints: they are folded into the bodies they move with (exact; the head stays a body, the task reads its position)
-            self._model = fit_stepper_limits(m, 18, keep=("NECK_P_S",))
+            self._model = fit_stepper_limits(m, 18, keep=("NECK_P_S",) + tuple(getattr(self, "perturb_bodies", ())))
         return self._model
 
     def clock_lut(self):
@@ -182,7 +185,14 @@ class JvrcWalkSpec:
                           action_smoothing=self.action_smoothing, nominal_qpos=self.nominal_pose,
                           action_offset=self.action_offset(), task_params=[self.goal_height],
                           task_iparams=self.body_ids(), clock_lut=self.clock_lut(), history_len=self.history_len,
-                          init_noise=np.deg2rad(self.init_noise_deg))
+                          init_noise=np.deg2rad(self.init_noise_deg), perturbation=self.perturbation_config())
+
+    def perturbation_config(self):
+        """BatchedEnv(perturbation=...) for this YAML (None: off): interval in control steps, packed-model body ids, magnitudes"""
+        if self.perturb_interval <= 0:
+            return None
+        m = self.model()
+        return dict(interval=self.perturb_interval, bodies=[m.body_id(b) for b in self.perturb_bodies], force=self.force_magnitude, torque=self.torque_magnitude)
 
     def algorithmic_bytes_per_env_step(self) -> int:
         """Persistent state record read + written once per control step (168 f64 words) plus

@@ -264,8 +264,29 @@ class OracleJvrcWalkEnv:
         self.prev_torque = np.asarray(self._act_torque()).copy()
         obs = self.get_obs()
         self.prev_prediction = action
+        self._post_obs_perturbation()
         self.traj_len += 1
         return obs, sum(terms.values()), done, terms
+
+    def _post_obs_perturbation(self):
+        """apply_perturbation behind get_obs when the YAML configures it (base_humanoid_env.py:224-225; domain_randomization.py:10-26): the H1
+        envs' draws -- STEP stream, slot 70 the trigger, 71.. per body three forces, three torques, a coin that clears ALL wrenches -- under
+        the counter this control step's task draws used"""
+        sp = self.spec
+        n = getattr(sp, "perturb_interval", 0)
+        if n <= 0:
+            return
+        s, e, c = self.seed, self.env_id, self.step_count - 1
+        if rng.randint(s, e, rng.STREAM_STEP, c, 70, n) != 0:
+            return
+        for k, name in enumerate(sp.perturb_bodies):
+            b, base = self.m.body_id(name), 71 + 7 * k
+            for ax in range(3):
+                self.sim.xfrc_applied[b, ax] = rng.uniform(s, e, rng.STREAM_STEP, c, base + ax, -sp.force_magnitude, sp.force_magnitude)
+            for ax in range(3):
+                self.sim.xfrc_applied[b, 3 + ax] = rng.uniform(s, e, rng.STREAM_STEP, c, base + 3 + ax, -sp.torque_magnitude, sp.torque_magnitude)
+            if rng.randint(s, e, rng.STREAM_STEP, c, base + 6, 2) == 0:
+                self.sim.xfrc_applied[:] = 0
 
     def step_auto(self, action):
         obs, r, done, terms = self.step(action)

@@ -130,3 +130,38 @@ def test_jvrc_init_noise(tmp_path, task):
         np.testing.assert_allclose(o_dev, np.array([r[0] for r in res]), rtol=1e-5, atol=2e-5, err_msg=f"obs t={t}")
         np.testing.assert_allclose(rew, np.array([r[1] for r in res]), rtol=0, atol=2e-6, err_msg=f"rew t={t}")
     assert env.pop_fault_stats() == (0, 0)
+
+
+@pytest.mark.parametrize("task", ["jvrc_walk", "jvrc_step"])
+def test_jvrc_perturbation(tmp_path, task):
+    """perturbation in a JVRC YAML (domain_randomization.py:10-26 behind base_humanoid_env.py:86-92, 224-225): applied wrenches on two bodies
+    from the env's HBM record, drawn after the observation, cleared by the coin and by resets -- 67 envs against the oracle, draw for draw.
+    GPU twin of tests/test_emu_stepper.py::test_emulated_jvrc_perturbation."""
+    import yaml
+    from learninghumanoidwalking_amd.envs.jvrc_step import JvrcStepSpec
+    from learninghumanoidwalking_amd.envs.jvrc_walk import JVRC_BASE_YAML, JvrcWalkSpec
+    from oracle.env_jvrc_step import OracleJvrcStepEnv
+    from oracle.env_jvrc_walk import OracleJvrcWalkEnv
+    cfg = yaml.safe_load(open(JVRC_BASE_YAML))
+    cfg["perturbation"] = dict(enable=True, interval=2 * cfg["control_dt"], bodies=["PELVIS_S", "R_KNEE_S"], force_magnitude=60.0, torque_magnitude=8.0)
+    path = tmp_path / "jvrc_perturb.yaml"
+    path.write_text(yaml.safe_dump(cfg))
+    S, O = (JvrcWalkSpec, OracleJvrcWalkEnv) if task == "jvrc_walk" else (JvrcStepSpec, OracleJvrcStepEnv)
+    spec = S(yaml_path=str(path))
+    n, L = 67, 4
+    env = _Numpy(spec.make_batched(n, seed=17, device=0, max_traj_len=L))
+    orc = [O(spec, seed=17, env_id=i, max_traj_len=L) for i in range(n)]
+    np.testing.assert_allclose(env.reset(), np.array([o.reset() for o in orc]), rtol=1e-6, atol=2e-6)
+    tape = (np.random.default_rng(4).normal(size=(9, n, 12)) * 0.1).astype(np.float32)
+    pushed = 0
+    for t in range(tape.shape[0]):
+        o_dev, rew, done, tob = env.step(tape[t])
+        res = [o.step_auto(tape[t, i]) for i, o in enumerate(orc)]
+        pushed += sum(bool(np.abs(o.sim.xfrc_applied).max() > 0) for o in orc)
+        q, v = env.get_state()
+        np.testing.assert_array_equal(done, np.array([r[2] for r in res], dtype=np.uint8), err_msg=f"flags t={t}")
+        np.testing.assert_allclose(q, np.array([o.sim.qpos for o in orc]), rtol=0, atol=1e-11, err_msg=f"qpos t={t}")
+        np.testing.assert_allclose(v, np.array([o.sim.qvel for o in orc]), rtol=0, atol=1e-9, err_msg=f"qvel t={t}")
+        np.testing.assert_allclose(o_dev, np.array([r[0] for r in res]), rtol=1e-5, atol=2e-5, err_msg=f"obs t={t}")
+        np.testing.assert_allclose(rew, np.array([r[1] for r in res]), rtol=0, atol=2e-6, err_msg=f"rew t={t}")
+    assert pushed >= n and env.pop_fault_stats() == (0, 0)
