@@ -389,6 +389,13 @@ int lhw_ppo_grad(LhwPpo* ppo, const float* theta, float* grad, const float* xn, 
 /* dual clip_grad_norm_ + Adam; zeroes grad */
 int lhw_ppo_apply(LhwPpo* ppo, float* theta, float* grad, float* adam_m, float* adam_v, int64_t step, float grad_scale,
                   void* stream);
+/* lhw_ppo_grad followed by lhw_ppo_apply as ONE launch: the optimiser step of rl/algos/ppo.py:387-396 (zero_grad, backward, two
+ * clip_grad_norm_, two Adam steps) captured once as a hipGraph per (buffers, minibatch size) and replayed, the minibatch's index pointer
+ * and Adam's bias corrections patched into the graph's kernel nodes.  Bitwise the result of the two calls.  Single process only: with data
+ * parallelism the gradient all-reduce belongs between lhw_ppo_grad and lhw_ppo_apply. */
+int lhw_ppo_step(LhwPpo* ppo, float* theta, float* grad, float* adam_m, float* adam_v, const float* xn, const float* xm, const float* act,
+                 const float* old_logp, const float* adv, const float* ret, const int32_t* idx, int32_t B, float* stats_dev, int64_t step,
+                 float grad_scale, void* stream);
 
 /* ------------------------------------------------------------------ recurrent PPO (LSTM actor / critic)
  * Gaussian_LSTM_Actor / LSTM_V: two stacked LSTMCells (hidden) + linear read-out (reference rl/policies/actor.py:191-286,

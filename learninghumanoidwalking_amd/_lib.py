@@ -177,6 +177,7 @@ def declare(L):
     sig("lhw_env_phase_cycles", [vp, ctypes.c_int, vp])
     sig("lhw_env_step_range", [vp, i32, i32, vp, vp, vp, vp, vp, vp, vp])
     sig("lhw_ppo_set_imitation", [vp, vp, vp, ctypes.c_float, i64])
+    sig("lhw_ppo_step", [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, i64, ctypes.c_float, vp])
     sig("lhw_env_debug_step_record", [vp, vp, vp, vp])
     sig("lhw_env_rollout", [vp, ctypes.POINTER(LhwRolloutPolicy), i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp])
     sig("lhw_env_last_rollout_queued", [vp])

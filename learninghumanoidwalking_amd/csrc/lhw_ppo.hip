@@ -615,6 +615,14 @@ struct LhwPpo {
   hipStream_t side = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   int two_streams = 1;
+  // lhw_ppo_step: one optimiser step (lhw_ppo_grad + lhw_ppo_apply) captured once as a hipGraph and replayed; the two things that change
+  // from step to step -- the minibatch's index pointer (gather_kernel) and Adam's bias corrections (adam2_kernel) -- are patched into
+  // the executable graph's kernel nodes before each launch
+  hipGraph_t step_graph = nullptr;
+  hipGraphExec_t step_exec = nullptr;
+  hipGraphNode_t node_gather = nullptr, node_adam = nullptr;
+  const void* step_key[14] = {nullptr};
+  int step_key_b = 0, step_key_half = 0;
 };
 
 #define HIPCHK(x)                                                                                   \
@@ -1204,6 +1212,8 @@ extern "C" int lhw_ppo_destroy(LhwPpo* p) {
   for (_Float16* b : hbufs) if (b) (void)hipFree(b);
   if (p->d_obs_src) (void)hipFree(p->d_obs_src);
   if (p->d_act_src) (void)hipFree(p->d_act_src);
+  if (p->step_exec) (void)hipGraphExecDestroy(p->step_exec);
+  if (p->step_graph) (void)hipGraphDestroy(p->step_graph);
   if (p->side) { (void)hipStreamSynchronize(p->side); (void)hipStreamDestroy(p->side); }
   if (p->ev_fork) (void)hipEventDestroy(p->ev_fork);
   if (p->ev_join) (void)hipEventDestroy(p->ev_join);
@@ -1553,6 +1563,93 @@ extern "C" int lhw_ppo_apply(LhwPpo* p, float* theta, float* grad, float* adam_m
                 p->lr, p->beta1, p->beta2, p->adam_eps, s);
   if (!p->learn_std) HIPCHK(hipMemsetAsync(grad + p->off_std, 0, sizeof(float) * pad4(p->A), s));
   HIPCHK(hipGetLastError());
+  return LHW_OK;
+}
+
+// One optimiser step as ONE graph launch (round 6).  lhw_ppo_grad + lhw_ppo_apply are some forty launches on two streams, a dozen of
+// them small (gather, loss, ordered reductions, transposes, clip, Adam: 5-20 us of work each behind a launch gap of the same order);
+// captured once per (buffers, minibatch size) as a hipGraph they replay with one host call and the runtime's graph scheduling between the
+// nodes.  Same kernels, same order, same arithmetic: bitwise the weights of the two-call path (tests/test_ppo_gpu.py).  What changes from
+// step to step is patched into the executable graph: the minibatch's index pointer (gather_kernel's first argument) and Adam's bias
+// corrections (adam2_kernel's last two).  Single process only -- with data parallelism the gradient all-reduce sits between the two halves
+// (the Python layer then keeps lhw_ppo_grad / all-reduce / lhw_ppo_apply).  LHW_PPO_GRAPH=0 turns it off (the two calls, eagerly).
+static bool ppo_graph_on() {
+  static const bool on = !(getenv("LHW_PPO_GRAPH") && atoi(getenv("LHW_PPO_GRAPH")) == 0);
+  return on;
+}
+extern "C" int lhw_ppo_step(LhwPpo* p, float* theta, float* grad, float* adam_m, float* adam_v, const float* xn, const float* xm, const float* act,
+                            const float* old_logp, const float* adv, const float* ret, const int32_t* idx, int32_t B, float* stats_dev,
+                            int64_t step, float grad_scale, void* stream) {
+  if (!p || !theta || !grad || !adam_m || !adam_v || !idx || step <= 0) return lhw_fail(LHW_ERR_ARG, "bad argument");
+  hipStream_t s = (hipStream_t)stream;
+  // (an armed imitation term is a one-shot argument of the next lhw_ppo_grad: not captured; the legacy default stream cannot be captured)
+  if (!ppo_graph_on() || p->imit_target != nullptr || s == nullptr) {
+    const int rc = lhw_ppo_grad(p, theta, grad, xn, xm, act, old_logp, adv, ret, idx, B, stats_dev, stream);
+    return rc ? rc : lhw_ppo_apply(p, theta, grad, adam_m, adam_v, step, grad_scale, stream);
+  }
+  HIPCHK(hipSetDevice(p->device));
+  const void* key[14] = {theta, grad, adam_m, adam_v, xn, xm, act, old_logp, adv, ret, stats_dev, stream, nullptr, nullptr};
+  float gs_key; memcpy(&gs_key, &grad_scale, sizeof gs_key);
+  bool same = p->step_exec != nullptr && p->step_key_b == B && p->step_key_half == p->update_half;
+  for (int i = 0; same && i < 12; i++) same = p->step_key[i] == key[i];
+  const size_t na = p->learn_std ? p->off_std + p->A : p->off_std;
+  const float bc1 = 1.f - powf(p->beta1, (float)step), bc2s = sqrtf(1.f - powf(p->beta2, (float)step));
+  if (!same) {
+    if (p->step_exec) { (void)hipGraphExecDestroy(p->step_exec); p->step_exec = nullptr; }
+    if (p->step_graph) { (void)hipGraphDestroy(p->step_graph); p->step_graph = nullptr; }
+    p->node_gather = p->node_adam = nullptr;
+    HIPCHK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+    int rc = lhw_ppo_grad(p, theta, grad, xn, xm, act, old_logp, adv, ret, idx, B, stats_dev, stream);
+    if (!rc) rc = lhw_ppo_apply(p, theta, grad, adam_m, adam_v, step, grad_scale, stream);
+    hipGraph_t g = nullptr;
+    const hipError_t ec = hipStreamEndCapture(s, &g);
+    if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }
+    if (ec != hipSuccess || !g) return lhw_fail(LHW_ERR_HIP, "lhw_ppo_step: stream capture failed: %s", hipGetErrorString(ec));
+    p->step_graph = g;
+    size_t nn = 0;
+    HIPCHK(hipGraphGetNodes(g, nullptr, &nn));
+    std::vector<hipGraphNode_t> nodes(nn);
+    HIPCHK(hipGraphGetNodes(g, nodes.data(), &nn));
+    for (hipGraphNode_t nd : nodes) {
+      hipGraphNodeType ty;
+      if (hipGraphNodeGetType(nd, &ty) != hipSuccess || ty != hipGraphNodeTypeKernel) continue;
+      hipKernelNodeParams kp;
+      if (hipGraphKernelNodeGetParams(nd, &kp) != hipSuccess) continue;
+      if (kp.func == (void*)gather_kernel) p->node_gather = nd;
+      else if (kp.func == (void*)adam2_kernel) p->node_adam = nd;
+    }
+    if (!p->node_gather || !p->node_adam) return lhw_fail(LHW_ERR_HIP, "lhw_ppo_step: gather / Adam nodes not found in the captured graph (%zu nodes)", nn);
+    HIPCHK(hipGraphInstantiate(&p->step_exec, g, nullptr, nullptr, 0));
+    for (int i = 0; i < 12; i++) p->step_key[i] = key[i];
+    p->step_key_b = B; p->step_key_half = p->update_half;
+  }
+  // patch the two nodes: the kernels' full argument lists, as lhw_ppo_grad / clip_and_adam pass them
+  {
+    const int mir = p->use_mirror && xm != nullptr;
+    const int* a_idx = idx; int a_B = B, a_R = p->max_rows, a_Dp = p->la.Dp, a_A = p->A;
+    const float *a_xn = xn, *a_xm = mir ? xm : nullptr, *a_act = act, *a_lp = old_logp, *a_adv = adv, *a_ret = ret;
+    float *a_xb = p->xb, *a_ma = p->mb_act, *a_ml = p->mb_logp, *a_mv = p->mb_adv, *a_mr = p->mb_ret;
+    void* args[16] = {&a_idx, &a_B, &a_R, &a_Dp, &a_A, &a_xn, &a_xm, &a_act, &a_lp, &a_adv, &a_ret, &a_xb, &a_ma, &a_ml, &a_mv, &a_mr};
+    hipKernelNodeParams kp;
+    HIPCHK(hipGraphKernelNodeGetParams(p->node_gather, &kp));
+    kp.kernelParams = args; kp.extra = nullptr;
+    HIPCHK(hipGraphExecKernelNodeSetParams(p->step_exec, p->node_gather, &kp));
+  }
+  {
+    float *a_th = theta, *a_g = grad, *a_m = adam_m, *a_v = adam_v;
+    size_t a_n0 = na, a_off1 = p->off_critic, a_n1 = p->lc.total;
+    int a_b0 = (int)((na + 255) / 256);
+    float a_gs = grad_scale, a_clip = p->grad_clip, a_lr = p->lr, a_b1 = p->beta1, a_b2 = p->beta2, a_eps = p->adam_eps, a_bc1 = bc1, a_bc2 = bc2s;
+    const float* a_part = p->norm_part;
+    float* a_nout = p->stats + 8;
+    void* args[18] = {&a_th, &a_g, &a_m, &a_v, &a_n0, &a_off1, &a_n1, &a_b0, &a_gs, &a_part, &a_nout, &a_clip, &a_lr, &a_b1, &a_b2, &a_eps, &a_bc1, &a_bc2};
+    hipKernelNodeParams kp;
+    HIPCHK(hipGraphKernelNodeGetParams(p->node_adam, &kp));
+    kp.kernelParams = args; kp.extra = nullptr;
+    HIPCHK(hipGraphExecKernelNodeSetParams(p->step_exec, p->node_adam, &kp));
+  }
+  p->roll_theta = nullptr;
+  HIPCHK(hipGraphLaunch(p->step_exec, s));
   return LHW_OK;
 }
 

@@ -713,14 +713,30 @@ class PPO:
         mb = min(mb, n_samples)
         k.stats.zero_()
         n_updates = 0
-        for epoch in range(self.epochs):
-            perm = self._minibatch_perm(itr, epoch, n_samples)
-            for start in range(0, n_samples - mb + 1, mb):
-                mb_idx = perm[start:start + mb]
-                imit = self._imitation_term(raw_obs.index_select(0, mb_idx.long())) if self.imitation_projector is not None else None
-                k.grad_minibatch(xn, xm, act, logp, adv, ret, mb_idx, imitation=imit)
-                self._allreduce_and_apply()
-                n_updates += 1
+        # Single process, no imitation term: an optimiser step is ONE graph launch (lhw_ppo_step) on a stream of its own -- a hipGraph is
+        # captured from a stream, and torch's default stream is the legacy one, which cannot be captured.  With data parallelism the
+        # gradient all-reduce sits between the two halves: lhw_ppo_grad, all-reduce, lhw_ppo_apply, eagerly.
+        fused = (self.imitation_projector is None and not dist_utils._active(dist_utils.dist()) and hasattr(k._L, "lhw_ppo_step")
+                 and os.environ.get("LHW_PPO_GRAPH", "1") != "0")
+        cur = torch.cuda.current_stream(self.device)
+        if fused:
+            if getattr(self, "_update_stream", None) is None:
+                self._update_stream = torch.cuda.Stream(device=self.device)
+            self._update_stream.wait_stream(cur)
+        with torch.cuda.stream(self._update_stream if fused else cur):
+            for epoch in range(self.epochs):
+                perm = self._minibatch_perm(itr, epoch, n_samples)
+                for start in range(0, n_samples - mb + 1, mb):
+                    mb_idx = perm[start:start + mb]
+                    if fused:
+                        k.step_minibatch(xn, xm, act, logp, adv, ret, mb_idx)
+                    else:
+                        imit = self._imitation_term(raw_obs.index_select(0, mb_idx.long())) if self.imitation_projector is not None else None
+                        k.grad_minibatch(xn, xm, act, logp, adv, ret, mb_idx, imitation=imit)
+                        self._allreduce_and_apply()
+                    n_updates += 1
+        if fused:
+            cur.wait_stream(self._update_stream)
         s = (k.stats / max(1, n_updates)).cpu().numpy()
         self.last_losses = dict(actor=float(s[0]), critic=float(s[1]), mirror=float(s[2]), kl=float(s[3]),
                                 clip_fraction=float(s[4]), imitation=float(s[5]), entropy=self._entropy_penalty(), n_updates=n_updates)

@@ -240,6 +240,13 @@ class PpoKernels:
         _lib.check(self._L.lhw_ppo_grad(self._h, _p(self.theta), _p(self.grad), _p(xn), _p(xm), _p(act), _p(old_logp),
                                         _p(adv), _p(ret), _p(idx), B, _p(self.stats), self._stream()))
 
+    def step_minibatch(self, xn, xm, act, old_logp, adv, ret, idx):
+        """grad_minibatch + apply as ONE hipGraph launch (lhw_ppo_step: single process, no imitation term).  Must run on a torch stream
+        other than the default one (a legacy default stream cannot be captured: the library then makes the two calls eagerly)."""
+        self.adam_step += 1
+        _lib.check(self._L.lhw_ppo_step(self._h, _p(self.theta), _p(self.grad), _p(self.adam_m), _p(self.adam_v), _p(xn), _p(xm), _p(act),
+                                        _p(old_logp), _p(adv), _p(ret), _p(idx), idx.numel(), _p(self.stats), self.adam_step, 1.0, self._stream()))
+
     def apply(self, grad_scale=1.0):
         self.adam_step += 1
         _lib.check(self._L.lhw_ppo_apply(self._h, _p(self.theta), _p(self.grad), _p(self.adam_m), _p(self.adam_v),

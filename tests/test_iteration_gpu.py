@@ -137,3 +137,34 @@ def test_grouped_rollout_is_bitwise_identical_to_single_stream(env_name, monkeyp
     a, b, c = run(1), run(2), run(3)
     for x, y, z in zip(a, b, c):
         assert torch.equal(x, y) and torch.equal(x, z)
+
+
+@pytest.mark.parametrize("variant", ["mirror", "learn_std", "fp16"])
+def test_the_optimiser_step_as_one_graph_launch_is_bitwise_the_two_call_path(variant, monkeypatch):
+    """lhw_ppo_step (round 6): lhw_ppo_grad + lhw_ppo_apply captured once as a hipGraph and replayed, the minibatch's index pointer and
+    Adam's bias corrections patched into its kernel nodes per step -- the same kernels in the same order: after two iterations (2 epochs x
+    2 minibatches each, so the graph is replayed with four different index pointers and eight Adam steps) the weights, the Adam state and
+    the loss statistics equal those of the eager two-call path bit for bit.  Reference: rl/algos/ppo.py:387-396."""
+    from types import SimpleNamespace
+    from learninghumanoidwalking_amd.envs import ENVIRONMENTS
+    from learninghumanoidwalking_amd.ppo import PPO
+
+    def run(graph):
+        monkeypatch.setenv("LHW_PPO_GRAPH", "1" if graph else "0")
+        args = SimpleNamespace(gamma=0.99, lam=0.95, lr=3e-4, eps=1e-5, entropy_coeff=0.01 if variant == "learn_std" else 0.0, clip=0.2, minibatch_size=512,
+                               epochs=2, max_traj_len=16, num_procs=64, num_envs=64, max_grad_norm=0.5, mirror_coeff=0.4, eval_freq=10**9,
+                               recurrent=False, imitate=None, learn_std=variant == "learn_std", std_dev=0.223, no_mirror=variant != "mirror",
+                               fp16=variant == "fp16", continued=None, logdir="/tmp/lhw_test_graph", device_index=0)
+        algo = PPO(ENVIRONMENTS["jvrc_walk"], args, seed=11)
+        losses = []
+        for itr in range(2):
+            algo.iterate(itr)
+            losses.append(dict(algo.last_losses))
+        k = algo.kernels
+        return k.theta.clone(), k.adam_m.clone(), k.adam_v.clone(), losses, getattr(algo, "_update_stream", None) is not None
+
+    ta, ma, va, la, used_a = run(True)
+    tb, mb, vb, lb, used_b = run(False)
+    assert used_a and not used_b
+    assert torch.equal(ta, tb) and torch.equal(ma, mb) and torch.equal(va, vb)
+    assert la == lb and la[0]["n_updates"] == 4
