@@ -138,18 +138,22 @@ int humanoid_create(HumanoidEnv** out, const std::vector<int32_t>& mi, const std
     if (cd != 1 && cd != 3) return lhw_fail(LHW_ERR_UNSUPPORTED, "condim %d", cd);
   }
   if (mi[LHW_IH_CONE] != 0) return lhw_fail(LHW_ERR_UNSUPPORTED, "only the pyramidal cone is implemented");
-  int primbox_pairs = 0;
+  int primbox_pairs = 0, cyl_pairs = 0;
   for (int q = 0; q < np; q++) {
     const int t1 = IF(LHW_IF_GEOM_TYPE)[IF(LHW_IF_PAIR_GEOM1)[q]], t2 = IF(LHW_IF_GEOM_TYPE)[IF(LHW_IF_PAIR_GEOM2)[q]];
     if (!stepping && t1 == G_BOX && t2 == G_BOX)
       return lhw_fail(LHW_ERR_UNSUPPORTED, "box-box pairs are only compiled into the stepping-task kernels");
     // narrow phases that exist (geom1 type <= geom2 type, as MuJoCo orders a pair): a model packed straight from an mjModel
     // (pack_from_mjmodel) does not pass through mjcf.build_pairs, which refuses the others
-    const bool ok = (t1 == G_PLANE && (t2 == G_SPHERE || t2 == G_CAPSULE || t2 == G_BOX)) ||
-                    (t1 == G_SPHERE && (t2 == G_SPHERE || t2 == G_CAPSULE || t2 == G_BOX)) ||
+    const bool ok = (t1 == G_PLANE && (t2 == G_SPHERE || t2 == G_CAPSULE || t2 == G_BOX || t2 == G_CYLINDER)) ||
+                    (t1 == G_SPHERE && (t2 == G_SPHERE || t2 == G_CAPSULE || t2 == G_BOX || t2 == G_CYLINDER)) ||
                     (t1 == G_CAPSULE && (t2 == G_CAPSULE || t2 == G_BOX)) || (t1 == G_BOX && t2 == G_BOX);
     if (t2 == G_BOX && (t1 == G_SPHERE || t1 == G_CAPSULE)) primbox_pairs++;
-    if (!ok) return lhw_fail(LHW_ERR_UNSUPPORTED, "collision pair %d: no narrow phase for geom types %d / %d (plane, sphere, capsule, box only)", q, t1, t2);
+    if (t2 == G_CYLINDER) cyl_pairs++;
+    if (!ok) return lhw_fail(LHW_ERR_UNSUPPORTED, "collision pair %d (geoms %d / %d): no narrow phase for geom types %d / %d -- plane, sphere, capsule, box among "
+                             "themselves, cylinders against planes and spheres (MuJoCo resolves the other cylinder pairs, ellipsoids and meshes through its general "
+                             "convex collider): mask the pair with contype / conaffinity or replace the geom by an enclosing capsule / box",
+                             q, IF(LHW_IF_PAIR_GEOM1)[q], IF(LHW_IF_PAIR_GEOM2)[q], t1, t2);
   }
 
   int ndev = 0;
@@ -287,6 +291,7 @@ int humanoid_create(HumanoidEnv** out, const std::vector<int32_t>& mi, const std
         if (type == G_SPHERE) return sz[0];
         if (type == G_CAPSULE) return sz[0] + sz[1];
         if (type == G_BOX) return std::sqrt(sz[0] * sz[0] + sz[1] * sz[1] + sz[2] * sz[2]);
+        if (type == G_CYLINDER) return std::sqrt(sz[0] * sz[0] + sz[1] * sz[1]);
         return 0.0;
       };
       pd[PD_RBOUND1] = rbound(I1[GI_TYPE], G1 + GD_SIZE); pd[PD_RBOUND2] = rbound(I2[GI_TYPE], G2 + GD_SIZE);
@@ -427,6 +432,7 @@ int humanoid_create(HumanoidEnv** out, const std::vector<int32_t>& mi, const std
   for (int l = 0; l < 32; l++) for (size_t q = 0; q < owned[l].size(); q++) own_tab[l * max_owned + q] = owned[l][q];
   m.max_owned = (int)max_owned;
   m.has_primbox = primbox_pairs > 0;
+  m.has_cyl = cyl_pairs > 0;
   {
     int cnt = 0, idx[4] = {0, 0, 0, 0};
     for (int q = 0; q < np; q++)

@@ -58,7 +58,7 @@
 #define HMINVAL 1e-15
 
 enum { JT_FREE = 0, JT_SLIDE = 2, JT_HINGE = 3 };
-enum { G_PLANE = 0, G_SPHERE = 2, G_CAPSULE = 3, G_BOX = 6 };
+enum { G_PLANE = 0, G_SPHERE = 2, G_CAPSULE = 3, G_CYLINDER = 5, G_BOX = 6 };
 enum { MODE_STANDING = 0, MODE_INPLACE = 1, MODE_FORWARD = 2 };
 enum { WALK_CURVED = 0, WALK_STANDING = 1, WALK_BACKWARD = 2, WALK_LATERAL = 3, WALK_FORWARD = 4 };  // stepping_task.py:282-285
 
@@ -236,6 +236,7 @@ struct HModel {
   int nq, nv, nu, nbody, njnt, ngeom, npair, nlevel, iterations, disableflags;
   double timestep, gravity[3], tolerance, meaninertia, totalmass;
   int has_primbox;     // some collision pair is sphere-box or capsule-box (collide_primbox)
+  int has_cyl;         // some collision pair is plane-cylinder or sphere-cylinder (collide_cyl)
   int npb, pb_pair[4]; // plane-box pairs (floor against a foot box), in pair order, if there are at most four of them (else npb = 0):
                        // their eight corners are tested on eight lanes each instead of one after the other on the pair's lane
   int max_owned;         // bodies per lane in chain_dynamics' per-body loop (<= MAX_OWNED)
@@ -1725,6 +1726,83 @@ __device__ void collide_primbox(ConSink<L>& k, HModelRef m, const L& S, int q, i
   }
 }
 
+// Plane-cylinder and sphere-cylinder pairs (round 6): the two cylinder narrow phases MuJoCo resolves analytically (mjc_PlaneCylinder,
+// mjc_SphereCylinder [MJ-recall]; the other cylinder pairs go through its general convex collider and are refused at create).  Kept out of
+// collide_pair and called only under the model-wide flag m.has_cyl, like collide_primbox: models without cylinders do not pay for it.
+// (same operation order as planeCylinder / sphereCylinder in the CPU checker, mjc_oracle.c)
+template <class L>
+__device__ void collide_cyl(ConSink<L>& k, HModelRef m, const L& S, int q, int g1, int g2, double margin) {
+  const double zero[3] = {0, 0, 0};
+  const int t1 = m.pair_i[PIS * q + PI_TYPE1];
+  double p1[3], p2[3], R1[9], R2[9];
+  for (int a = 0; a < 3; a++) { p1[a] = S.U[U_GPOS + 3 * g1 + a]; p2[a] = S.U[U_GPOS + 3 * g2 + a]; }
+  for (int a = 0; a < 9; a++) { R1[a] = S.U[U_GMAT + 9 * g1 + a]; R2[a] = S.U[U_GMAT + 9 * g2 + a]; }
+  const double r1 = m.pair_d[PDS * q + PD_SIZE1], rad = m.pair_d[PDS * q + PD_SIZE2], hl = m.pair_d[PDS * q + PD_SIZE2 + 1];
+  if (t1 == G_PLANE) {
+    const double n[3] = {R1[2], R1[5], R1[8]}, dif[3] = {p2[0] - p1[0], p2[1] - p1[1], p2[2] - p1[2]};
+    double axis[3] = {R2[2], R2[5], R2[8]}, vec[3];
+    double prjaxis = dot3(n, axis);
+    if (prjaxis > 0) { for (int a = 0; a < 3; a++) axis[a] = -axis[a]; prjaxis = -prjaxis; }
+    const double dist0 = dot3(dif, n);
+    for (int a = 0; a < 3; a++) vec[a] = axis[a] * prjaxis - n[a];
+    const double len_sqr = dot3(vec, vec);
+    if (len_sqr >= HMINVAL * HMINVAL) { const double scl = rad / sqrt(len_sqr); for (int a = 0; a < 3; a++) vec[a] *= scl; }
+    else { vec[0] = R2[0] * rad; vec[1] = R2[3] * rad; vec[2] = R2[6] * rad; }
+    const double prjvec = dot3(vec, n);
+    for (int a = 0; a < 3; a++) axis[a] *= hl;
+    prjaxis *= hl;
+    double pos[3];
+    if (!(dist0 + prjaxis + prjvec <= margin)) return;
+    {
+      const double d = dist0 + prjaxis + prjvec;
+      for (int a = 0; a < 3; a++) pos[a] = p2[a] + vec[a] + axis[a] - n[a] * d * 0.5;
+      k.emit(d, pos, n, zero);
+    }
+    if (dist0 - prjaxis + prjvec <= margin) {
+      const double d = dist0 - prjaxis + prjvec;
+      for (int a = 0; a < 3; a++) pos[a] = p2[a] + vec[a] - axis[a] - n[a] * d * 0.5;
+      k.emit(d, pos, n, zero);
+    }
+    const double prjvec1 = -prjvec * 0.5;
+    if (dist0 + prjaxis + prjvec1 <= margin) {
+      double vec1[3];
+      cross3(vec1, vec, axis);
+      normalize3(vec1);
+      const double sc = rad * sqrt(3.0) / 2;
+      for (int a = 0; a < 3; a++) vec1[a] *= sc;
+      const double d = dist0 + prjaxis + prjvec1;
+      for (int sgn = 1; sgn >= -1; sgn -= 2) {
+        for (int a = 0; a < 3; a++) pos[a] = p2[a] + sgn * vec1[a] + axis[a] - 0.5 * vec[a] - n[a] * d * 0.5;
+        k.emit(d, pos, n, zero);
+      }
+    }
+  } else {   // sphere (geom1) against the cylinder: beside the lateral surface, over a cap, or off the rim
+    const double axis[3] = {R2[2], R2[5], R2[8]}, vec[3] = {p1[0] - p2[0], p1[1] - p2[1], p1[2] - p2[2]};
+    const double x = dot3(vec, axis);
+    double a3[3];
+    for (int a = 0; a < 3; a++) a3[a] = vec[a] - axis[a] * x;
+    const double a_sqr = dot3(a3, a3);
+    if (x >= -hl && x <= hl) {
+      const double q3[3] = {p2[0] + axis[0] * x, p2[1] + axis[1] * x, p2[2] + axis[2] * x};
+      col_sphere_sphere(k, p1, r1, q3, rad, margin);
+    } else {
+      const double sg = x > 0 ? 1.0 : -1.0;
+      if (a_sqr <= rad * rad) {
+        const double dist = fabs(x) - hl - r1;
+        if (dist > margin) return;
+        double nrm[3], pos[3];
+        for (int a = 0; a < 3; a++) { nrm[a] = -sg * axis[a]; pos[a] = p1[a] - sg * axis[a] * (r1 + 0.5 * dist); }
+        k.emit(dist, pos, nrm, zero);
+      } else {
+        const double sc = rad / sqrt(a_sqr);
+        double q3[3];
+        for (int a = 0; a < 3; a++) q3[a] = p2[a] + axis[a] * sg * hl + a3[a] * sc;
+        col_sphere_sphere(k, p1, r1, q3, 0.0, margin);
+      }
+    }
+  }
+}
+
 template <class L>
 __device__ void collide_pair(ConSink<L>& k, HModelRef m, const L& S, int q, int g1, int g2, double margin) {
   const double zero[3] = {0, 0, 0};
@@ -1879,6 +1957,8 @@ __device__ __forceinline__ void fwd_collision(HModelRef m, HParamsRef p, L& S, i
     const int ta = ty1, tb = ty2;
     primbox = tb == G_BOX && (ta == G_SPHERE || ta == G_CAPSULE);
   }
+  bool cylpair = false;
+  if (m.has_cyl && have) cylpair = ty2 == G_CYLINDER;
   // Plane-box pairs (the floor against a foot box; kernels without box-box pairs): lane 8 j + i tests corner i of the j-th such
   // pair -- the same expressions, corner by corner, as collide_pair's loop, which walks the eight corners one after the other on the
   // pair's own lane, twice (counting, writing).  A ballot gives every corner its rank among the corners in contact (the first four
@@ -1923,8 +2003,9 @@ __device__ __forceinline__ void fwd_collision(HModelRef m, HParamsRef p, L& S, i
       }
     }
   }
-  if (have && !boxpair && !primbox && !pbpair) collide_pair(k, m, S, lane, g1, g2, margin);
+  if (have && !boxpair && !primbox && !pbpair && !cylpair) collide_pair(k, m, S, lane, g1, g2, margin);
   if (m.has_primbox) { if (primbox) collide_primbox(k, m, S, lane, g1, g2, margin); }
+  if (m.has_cyl) { if (cylpair) collide_cyl(k, m, S, lane, g1, g2, margin); }
   if constexpr (BOXBOX) {
     if (gany<L::W_>(boxpair)) {
       if (boxpair) { col_box_box(br, m, S, lane, g1, g2, margin); k.n = br.cnt; }
@@ -1960,8 +2041,9 @@ __device__ __forceinline__ void fwd_collision(HModelRef m, HParamsRef p, L& S, i
       }
     }
   }
-  if (have && !boxpair && !primbox && !pbpair && mine > 0 && base < cap) collide_pair(k, m, S, lane, g1, g2, margin);
+  if (have && !boxpair && !primbox && !pbpair && !cylpair && mine > 0 && base < cap) collide_pair(k, m, S, lane, g1, g2, margin);
   if (m.has_primbox) { if (primbox && mine > 0 && base < cap) collide_primbox(k, m, S, lane, g1, g2, margin); }
+  if (m.has_cyl) { if (cylpair && mine > 0 && base < cap) collide_cyl(k, m, S, lane, g1, g2, margin); }
   if constexpr (BOXBOX) {
     if (boxpair && base < cap) {
       const double zero[3] = {0, 0, 0};

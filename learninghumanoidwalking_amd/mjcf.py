@@ -20,14 +20,14 @@ import xml.etree.ElementTree as ET
 
 import numpy as np
 
-from .model import (GEOM_BOX, GEOM_CAPSULE, GEOM_PLANE, GEOM_SPHERE, JNT_FREE, JNT_HINGE, JNT_SLIDE, Model)
+from .model import (GEOM_BOX, GEOM_CAPSULE, GEOM_CYLINDER, GEOM_PLANE, GEOM_SPHERE, JNT_FREE, JNT_HINGE, JNT_SLIDE, Model)
 
 
 class MjcfError(ValueError):
     pass
 
 
-_GEOM_TYPES = {"plane": GEOM_PLANE, "sphere": GEOM_SPHERE, "capsule": GEOM_CAPSULE, "box": GEOM_BOX}
+_GEOM_TYPES = {"plane": GEOM_PLANE, "sphere": GEOM_SPHERE, "capsule": GEOM_CAPSULE, "cylinder": GEOM_CYLINDER, "box": GEOM_BOX}
 _JNT_TYPES = {"free": JNT_FREE, "slide": JNT_SLIDE, "hinge": JNT_HINGE}
 _INERT_TAGS = {"camera", "light", "sensor", "keyframe", "custom", "visual", "asset", "size", "statistic"}
 
@@ -36,7 +36,11 @@ SUPPORTED_PAIRS = {
     (GEOM_PLANE, GEOM_SPHERE), (GEOM_PLANE, GEOM_CAPSULE), (GEOM_PLANE, GEOM_BOX),
     (GEOM_SPHERE, GEOM_SPHERE), (GEOM_SPHERE, GEOM_CAPSULE), (GEOM_CAPSULE, GEOM_CAPSULE), (GEOM_BOX, GEOM_BOX),
     (GEOM_SPHERE, GEOM_BOX), (GEOM_CAPSULE, GEOM_BOX),
+    # round 6: the two cylinder pairs MuJoCo resolves analytically (mjc_PlaneCylinder, mjc_SphereCylinder); capsule- / cylinder- / box-cylinder go
+    # through its general convex collider there and are refused here
+    (GEOM_PLANE, GEOM_CYLINDER), (GEOM_SPHERE, GEOM_CYLINDER),
 }
+_TYPE_NAMES = {GEOM_PLANE: "plane", 1: "hfield", GEOM_SPHERE: "sphere", GEOM_CAPSULE: "capsule", 4: "ellipsoid", GEOM_CYLINDER: "cylinder", GEOM_BOX: "box", 7: "mesh"}
 
 _DEF_SOLREF = (0.02, 1.0)
 _DEF_SOLIMP = (0.9, 0.95, 0.001, 0.5, 2.0)
@@ -288,17 +292,20 @@ class _Compiler:
     def _add_geom(self, a, bid):
         tname = a.get("type", "sphere")
         if tname not in _GEOM_TYPES:
+            name = a.get("name", f"geom{len(self.geoms)}")
             if tname == "mesh":
-                raise MjcfError("mesh geoms are not supported (reduce the model to primitives)")
-            raise MjcfError(f"unsupported geom type {tname!r}")
+                raise MjcfError(f"geom {name!r}: mesh geoms are not supported (replace it by the primitive that encloses it: box, capsule, sphere or cylinder)")
+            if tname == "ellipsoid":
+                raise MjcfError(f"geom {name!r}: ellipsoid geoms are not supported (MuJoCo collides them through its general convex collider; use a capsule or a sphere)")
+            raise MjcfError(f"geom {name!r}: unsupported geom type {tname!r}")
         gt = _GEOM_TYPES[tname]
         size = _floats(a.get("size", "0 0 0"))
         size = (size + [0.0, 0.0, 0.0])[:3]
         pos = np.array(_floats(a.get("pos", "0 0 0"), 3))
         quat = self._orientation(a)
         if "fromto" in a:
-            if gt != GEOM_CAPSULE:
-                raise MjcfError("fromto only supported for capsules")
+            if gt not in (GEOM_CAPSULE, GEOM_CYLINDER):
+                raise MjcfError("fromto only supported for capsules and cylinders")
             ft = np.array(_floats(a["fromto"], 6))
             p0, p1 = ft[:3], ft[3:]
             pos = 0.5 * (p0 + p1)
@@ -342,6 +349,12 @@ class _Compiler:
             izz = mc * r * r / 2 + ms * 0.4 * r * r
             ixx = mc * (r * r / 4 + l * l / 3) + ms * (0.4 * r * r + l * l + 0.75 * r * l)
             return m, np.array([ixx, ixx, izz])
+        if t == GEOM_CYLINDER:      # radius s[0], half length s[1] along z
+            r, l = s[0], s[1]
+            vol = math.pi * r * r * 2 * l
+            m = g["mass"] if g["mass"] is not None else vol * g["density"]
+            ixx = m * (3 * r * r + (2 * l) ** 2) / 12.0
+            return m, np.array([ixx, ixx, m * r * r / 2])
         return 0.0, np.zeros(3)
 
     def _body_inertial(self, b):
@@ -640,9 +653,11 @@ def build_pairs(m: Model, excludes: set) -> tuple[np.ndarray, np.ndarray]:
                     if gt[x] == GEOM_PLANE and gt[y] == GEOM_PLANE:
                         continue
                     if (int(gt[x]), int(gt[y])) not in SUPPORTED_PAIRS:
+                        tn = lambda t: _TYPE_NAMES.get(int(t), str(int(t)))
                         raise MjcfError(
-                            f"collision pair {m.geom_names[x]}/{m.geom_names[y]} needs an unimplemented "
-                            f"narrow phase (types {gt[x]},{gt[y]}); mask it with contype/conaffinity")
+                            f"collision pair {m.geom_names[x]} ({tn(gt[x])}) / {m.geom_names[y]} ({tn(gt[y])}) needs a narrow phase that is not "
+                            f"implemented (cylinders collide with planes and spheres only: MuJoCo resolves the other cylinder pairs through its "
+                            f"general convex collider); mask the pair with contype / conaffinity or <exclude>, or replace the cylinder by a capsule")
                     p1.append(x)
                     p2.append(y)
     return np.array(p1, dtype=np.int32), np.array(p2, dtype=np.int32)

@@ -33,7 +33,7 @@
 #define MAXIMP 0.9999
 
 enum { JNT_FREE = 0, JNT_BALL = 1, JNT_SLIDE = 2, JNT_HINGE = 3 };
-enum { GEOM_PLANE = 0, GEOM_SPHERE = 2, GEOM_CAPSULE = 3, GEOM_BOX = 6 };
+enum { GEOM_PLANE = 0, GEOM_SPHERE = 2, GEOM_CAPSULE = 3, GEOM_CYLINDER = 5, GEOM_BOX = 6 };
 enum { EFC_FRICTION = 0, EFC_LIMIT = 1, EFC_CONTACT = 2 };
 #define DSBL_WARMSTART (1 << 7)
 #define DSBL_REFSAFE (1 << 11)
@@ -507,6 +507,75 @@ static int sphereCapsule(RawCon* c, const double* p1, double r1, const double* p
   double q[3] = {p2[0] + axis[0] * x, p2[1] + axis[1] * x, p2[2] + axis[2] * x};
   return sphereSphereRaw(c, p1, r1, q, size2[0], margin);
 }
+/* mjc_PlaneCylinder [MJ-recall]: the rim point of the cap nearer the plane that lies deepest (along the plane normal with its axial part
+ * removed), the corresponding rim point of the other cap, and -- when the near cap is (nearly) flat on the plane -- two more points of the
+ * near rim at +-120 degrees from the first; up to four contacts, all with the plane's normal.  size2 = (radius, half length). */
+static int planeCylinder(RawCon* c, const double* p1, const double* R1, const double* p2, const double* R2, const double* size2, double margin) {
+  double n[3] = {R1[2], R1[5], R1[8]}, axis[3] = {R2[2], R2[5], R2[8]}, vec[3], dif[3] = {p2[0] - p1[0], p2[1] - p1[1], p2[2] - p1[2]};
+  double prjaxis = dot3(n, axis);
+  if (prjaxis > 0) { for (int k = 0; k < 3; k++) axis[k] = -axis[k]; prjaxis = -prjaxis; }   /* the axis points towards the plane */
+  const double dist0 = dot3(dif, n);
+  for (int k = 0; k < 3; k++) vec[k] = axis[k] * prjaxis - n[k];                              /* -normal with its axial component removed */
+  const double len_sqr = dot3(vec, vec);
+  if (len_sqr >= MINVAL * MINVAL) { const double scl = size2[0] / sqrt(len_sqr); for (int k = 0; k < 3; k++) vec[k] *= scl; }
+  else { vec[0] = R2[0] * size2[0]; vec[1] = R2[3] * size2[0]; vec[2] = R2[6] * size2[0]; }     /* disk parallel to the plane: the cylinder's x axis */
+  const double prjvec = dot3(vec, n);
+  for (int k = 0; k < 3; k++) axis[k] *= size2[1];
+  prjaxis *= size2[1];
+  int cnt = 0;
+  if (dist0 + prjaxis + prjvec <= margin) {
+    c[cnt].dist = dist0 + prjaxis + prjvec;
+    for (int k = 0; k < 3; k++) { c[cnt].pos[k] = p2[k] + vec[k] + axis[k] - n[k] * c[cnt].dist * 0.5; c[cnt].frame[k] = n[k]; c[cnt].frame[3 + k] = 0; }
+    cnt++;
+  } else return 0;                                                                            /* the nearest point is beyond the margin */
+  if (dist0 - prjaxis + prjvec <= margin) {
+    c[cnt].dist = dist0 - prjaxis + prjvec;
+    for (int k = 0; k < 3; k++) { c[cnt].pos[k] = p2[k] + vec[k] - axis[k] - n[k] * c[cnt].dist * 0.5; c[cnt].frame[k] = n[k]; c[cnt].frame[3 + k] = 0; }
+    cnt++;
+  }
+  const double prjvec1 = -prjvec * 0.5;
+  if (dist0 + prjaxis + prjvec1 <= margin) {                                                    /* triangle points on the near cap */
+    double vec1[3];
+    cross3(vec1, vec, axis);
+    normalize3(vec1);
+    for (int k = 0; k < 3; k++) vec1[k] *= size2[0] * sqrt(3.0) / 2;
+    for (int sgn = 1; sgn >= -1; sgn -= 2) {
+      c[cnt].dist = dist0 + prjaxis + prjvec1;
+      for (int k = 0; k < 3; k++) {
+        c[cnt].pos[k] = p2[k] + sgn * vec1[k] + axis[k] - 0.5 * vec[k] - n[k] * c[cnt].dist * 0.5;
+        c[cnt].frame[k] = n[k]; c[cnt].frame[3 + k] = 0;
+      }
+      cnt++;
+    }
+  }
+  return cnt;
+}
+/* mjc_SphereCylinder [MJ-recall]: the sphere's centre relative to the cylinder decides the case -- beside the lateral surface (a sphere
+ * against the axis point at its height, radius = the cylinder's), over a cap (a sphere against the cap's plane), or off the rim (a sphere
+ * against the nearest rim point).  One contact, normal from the sphere (geom1) to the cylinder. */
+static int sphereCylinder(RawCon* c, const double* p1, double r1, const double* p2, const double* R2, const double* size2, double margin) {
+  const double axis[3] = {R2[2], R2[5], R2[8]}, vec[3] = {p1[0] - p2[0], p1[1] - p2[1], p1[2] - p2[2]};
+  const double x = dot3(vec, axis), rad = size2[0], hl = size2[1];
+  double a[3];
+  for (int k = 0; k < 3; k++) a[k] = vec[k] - axis[k] * x;
+  const double a_sqr = dot3(a, a);
+  if (x >= -hl && x <= hl) {                                    /* side */
+    double q[3] = {p2[0] + axis[0] * x, p2[1] + axis[1] * x, p2[2] + axis[2] * x};
+    return sphereSphereRaw(c, p1, r1, q, rad, margin);
+  }
+  const double sg = x > 0 ? 1.0 : -1.0;
+  if (a_sqr <= rad * rad) {                                     /* cap: the plane of the nearer flat face */
+    const double dist = fabs(x) - hl - r1;
+    if (dist > margin) return 0;
+    c->dist = dist;
+    for (int k = 0; k < 3; k++) { c->frame[k] = -sg * axis[k]; c->frame[3 + k] = 0; c->pos[k] = p1[k] - sg * axis[k] * (r1 + 0.5 * dist); }
+    return 1;
+  }
+  const double sc = rad / sqrt(a_sqr);                          /* rim */
+  double q[3];
+  for (int k = 0; k < 3; k++) q[k] = p2[k] + axis[k] * sg * hl + a[k] * sc;
+  return sphereSphereRaw(c, p1, r1, q, 0.0, margin);
+}
 /* mjc_CapsuleCapsule: closest points of two segments; parallel case gives up to two contacts [MJ-recall] */
 static int capsuleCapsule(RawCon* c, const double* p1, const double* R1, const double* s1, const double* p2, const double* R2, const double* s2, double margin) {
   double a1[3] = {R1[2], R1[5], R1[8]}, a2[3] = {R2[2], R2[5], R2[8]};
@@ -813,6 +882,8 @@ static void collision(OData* d) {
     else if (t1 == GEOM_SPHERE && t2 == GEOM_SPHERE) n = sphereSphereRaw(rc, p1, s1[0], p2, s2[0], margin);
     else if (t1 == GEOM_SPHERE && t2 == GEOM_CAPSULE) n = sphereCapsule(rc, p1, s1[0], p2, R2, s2, margin);
     else if (t1 == GEOM_CAPSULE && t2 == GEOM_CAPSULE) n = capsuleCapsule(rc, p1, R1, s1, p2, R2, s2, margin);
+    else if (t1 == GEOM_PLANE && t2 == GEOM_CYLINDER) n = planeCylinder(rc, p1, R1, p2, R2, s2, margin);
+    else if (t1 == GEOM_SPHERE && t2 == GEOM_CYLINDER) n = sphereCylinder(rc, p1, s1[0], p2, R2, s2, margin);
     else if (t1 == GEOM_SPHERE && t2 == GEOM_BOX) n = sphereBox(rc, p1, s1[0], p2, R2, s2, margin);
     else if (t1 == GEOM_CAPSULE && t2 == GEOM_BOX) n = capsuleBox(rc, p1, R1, s1, p2, R2, s2, margin);
     else if (t1 == GEOM_BOX && t2 == GEOM_BOX) n = boxBox(rc, p1, R1, s1, p2, R2, s2, margin);

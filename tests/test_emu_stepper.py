@@ -466,3 +466,47 @@ def test_emulated_jvrc_perturbation(tmp_path, task):
         np.testing.assert_allclose(rew, np.array([r[1] for r in res]), rtol=0, atol=2e-6, err_msg=f"rew t={t}")
     assert pushed >= 3, "no env carried an applied wrench through a control step"
     assert env.pop_fault_stats() == (0, 0)
+
+
+def _cylinder_case(spec, env, orc):
+    """shared with tests/test_model_variants_gpu.py: fallen poses on cylinder shanks, two control steps each against the oracle"""
+    from tests.cyl_variant import contact_kinds, cylinder_poses
+    m = spec.model()
+    N = len(orc)
+    env.reset()
+    for o in orc:
+        o.reset()
+    q = cylinder_poses(spec, orc[0], N)
+    v = np.random.default_rng(4).normal(size=(N, m.nv)) * 0.2
+    env.set_state(q, v)
+    for i, o in enumerate(orc):
+        o.set_state(q[i], v[i])
+    act = (np.random.default_rng(6).normal(size=(2, N, 12)) * 0.2).astype(np.float32)
+    kinds = set()
+    for t in range(2):
+        obs, rew, done, _ = env.step(act[t])
+        res = [o.step(act[t, i]) for i, o in enumerate(orc)]
+        for o in orc:
+            kinds |= contact_kinds(m, o.sim)
+        gq, gv = env.get_state()
+        oq, ov = _states(orc)
+        np.testing.assert_allclose(gq, oq, rtol=0, atol=1e-11, err_msg=f"qpos t={t}")
+        np.testing.assert_allclose(gv, ov, rtol=0, atol=1e-8, err_msg=f"qvel t={t}")
+        np.testing.assert_allclose(obs, np.array([r[0] for r in res]), rtol=1e-5, atol=2e-5, err_msg=f"obs t={t}")
+        np.testing.assert_array_equal(done & 1, np.array([int(r[2]) for r in res], dtype=np.uint8))
+        env.set_state(oq, ov)
+        for o in orc:
+            o.set_state(o.sim.qpos.copy(), o.sim.qvel.copy())
+    assert {(0, 5), (2, 5)} <= kinds, kinds
+    assert env.pop_fault_stats() == (0, 0)
+
+
+def test_emulated_cylinder_geoms(tmp_path):
+    """cylinder shanks: the plane-cylinder and sphere-cylinder narrow phases of the kernels against the oracle's"""
+    from oracle.env_jvrc_walk import OracleJvrcWalkEnv
+    from tests.cyl_variant import cylinder_spec
+    spec = cylinder_spec(tmp_path)
+    n = 4
+    env = emu.make_emulated(spec, n, seed=3)
+    orc = [OracleJvrcWalkEnv(spec, seed=3, env_id=i) for i in range(n)]
+    _cylinder_case(spec, env, orc)

@@ -81,12 +81,24 @@ def test_unsupported_features_raise():
         mjcf.compile_string(base % ("ball", "sphere"))
     with pytest.raises(mjcf.MjcfError):
         mjcf.compile_string(base % ("hinge", "mesh"))
-    with pytest.raises(mjcf.MjcfError):   # cylinders have no narrow phase (box-capsule / box-sphere do since round 2)
+    with pytest.raises(mjcf.MjcfError):   # box-cylinder has no analytic narrow phase (plane- / sphere-cylinder do since round 6)
         mjcf.compile_string("<mujoco><worldbody><body><freejoint/><geom type='box' size='.1 .1 .1'/></body>"
                             "<body pos='1 0 0'><freejoint/><geom type='cylinder' size='.1 .1'/></body></worldbody></mujoco>")
     m = mjcf.compile_string("<mujoco><worldbody><body><freejoint/><geom type='box' size='.1 .1 .1'/></body>"
                             "<body pos='1 0 0'><freejoint/><geom type='capsule' size='.1 .1'/></body></worldbody></mujoco>")
     assert m.npair == 1 and m.geom_type[m.pair_geom1[0]] == 3 and m.geom_type[m.pair_geom2[0]] == 6   # capsule before box
+
+
+def test_cylinder_geoms_compile():
+    """plane-cylinder and sphere-cylinder pairs are accepted; a cylinder's default inertia is the solid cylinder's"""
+    m = mjcf.compile_string("<mujoco><worldbody><geom type='plane' size='0 0 1'/>"
+                            "<body pos='0 0 1'><freejoint/><geom type='cylinder' size='.1 .3' density='500'/></body>"
+                            "<body pos='1 0 1'><freejoint/><geom type='sphere' size='.2'/></body></worldbody></mujoco>")
+    kinds = sorted((int(m.geom_type[a]), int(m.geom_type[b])) for a, b in zip(m.pair_geom1, m.pair_geom2))
+    assert kinds == [(0, 2), (0, 5), (2, 5)]
+    r, h, mass = 0.1, 0.6, 500 * np.pi * 0.1 ** 2 * 0.6
+    assert abs(m.body_mass[1] - mass) < 1e-12
+    np.testing.assert_allclose(sorted(m.body_inertia[1]), sorted([mass * (3 * r * r + h * h) / 12] * 2 + [mass * r * r / 2]), rtol=1e-12)
 
 
 def test_euler_and_fromto_orientation():

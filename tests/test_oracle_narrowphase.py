@@ -97,3 +97,67 @@ def test_capsule_capsule_crossed_and_parallel():
     assert xs[0] >= -0.3 - 1e-9 and xs[1] <= 0.35 + 1e-9 and xs[1] - xs[0] > 0.4
     _set(s, [0, 0, 0.2], Y90, adr=7)                                              # apart: nothing
     assert _cons(s) == []
+
+
+def test_plane_cylinder_and_sphere_cylinder():
+    """round 6: the two cylinder pairs MuJoCo resolves analytically (mjc_PlaneCylinder, mjc_SphereCylinder; the restatement is from recall --
+    what is held here is the documented contact convention on configurations with closed-form answers)."""
+    r, hl = 0.1, 0.25
+    m, s = _plane(f'type="cylinder" size="{r} {hl}"')
+    # upright on the plane, 2 mm deep: the near cap is flat on it -> the deepest rim point plus the two triangle points, all at the same depth;
+    # the far cap is out of range
+    _set(s, [0.3, -0.2, hl - 0.002])
+    cs = _cons(s)
+    assert len(cs) == 3 and all(abs(c["dist"] + 0.002) < 1e-12 and c["geom1"] == m.geom_id("floor") for c in cs)
+    for c in cs:
+        np.testing.assert_allclose(c["frame"][0], [0, 0, 1], atol=1e-15)
+        assert abs(np.hypot(c["pos"][0] - 0.3, c["pos"][1] + 0.2) - r) < 1e-12 and abs(c["pos"][2] + 0.001) < 1e-12      # on the rim, midway in depth
+    ang = [np.arctan2(c["pos"][1] + 0.2, c["pos"][0] - 0.3) for c in cs]
+    d = sorted((np.diff(sorted(ang)) % (2 * np.pi)).tolist())
+    np.testing.assert_allclose(d, [2 * np.pi / 3, 2 * np.pi / 3], atol=1e-9)                                            # an equilateral triangle
+    # lying on its side along x, 3 mm deep: one contact under each cap's lowest rim point
+    _set(s, [0, 0, r - 0.003], Y90)
+    cs = _cons(s)
+    assert len(cs) == 2 and all(abs(c["dist"] + 0.003) < 1e-12 for c in cs)
+    np.testing.assert_allclose(sorted(c["pos"][0] for c in cs), [-hl, hl], atol=1e-12)
+    for c in cs:
+        assert abs(c["pos"][1]) < 1e-12 and abs(c["pos"][2] + 0.0015) < 1e-12
+    # tilted by 0.3 rad about y: the lowest point of the lower rim only
+    t = 0.3
+    zc = hl * np.cos(t) + r * np.sin(t) - 0.001
+    _set(s, [0, 0, zc], [np.cos(t / 2), 0, np.sin(t / 2), 0])
+    (c,) = _cons(s)
+    assert abs(c["dist"] + 0.001) < 1e-12
+    assert abs(abs(c["pos"][0]) - abs(-hl * np.sin(t) + r * np.cos(t))) < 1e-12
+    _set(s, [0, 0, zc + 0.0011], [np.cos(t / 2), 0, np.sin(t / 2), 0])
+    assert _cons(s) == []
+    # sphere against the cylinder: beside the lateral surface, over a cap, off the rim -- the sphere is geom1 (lower type id)
+    m, s = _two(f'type="cylinder" size="{r} {hl}"', 'type="sphere" size="0.05"')
+    _set(s, [0, 0, 0]); _set(s, [r + 0.05 - 0.004, 0, 0.1], adr=7)                      # side
+    (c,) = _cons(s)
+    assert c["geom1"] == m.geom_id("b") and abs(c["dist"] + 0.004) < 1e-12
+    np.testing.assert_allclose(c["frame"][0], [-1, 0, 0], atol=1e-12)                   # from the sphere towards the axis
+    np.testing.assert_allclose(c["pos"], [r - 0.002, 0, 0.1], atol=1e-12)
+    _set(s, [0.03, -0.02, hl + 0.05 - 0.003], adr=7)                                    # over the upper cap
+    (c,) = _cons(s)
+    assert abs(c["dist"] + 0.003) < 1e-12
+    np.testing.assert_allclose(c["frame"][0], [0, 0, -1], atol=1e-12)
+    np.testing.assert_allclose(c["pos"], [0.03, -0.02, hl - 0.0015], atol=1e-12)
+    dx, dz = 0.03, 0.03                                                                 # off the rim: nearest point = the rim circle
+    _set(s, [r + dx, 0, -(hl + dz)], adr=7)
+    (c,) = _cons(s)
+    gap = np.hypot(dx, dz) - 0.05
+    assert abs(c["dist"] - gap) < 1e-12
+    np.testing.assert_allclose(c["frame"][0], [-dx / np.hypot(dx, dz), 0, dz / np.hypot(dx, dz)], atol=1e-12)
+    # the pairs MuJoCo sends through its general convex collider are refused with a message that names the geoms
+    import pytest
+    with pytest.raises(mjcf.MjcfError, match="cylinder"):
+        _two(f'type="cylinder" size="{r} {hl}"', f'type="capsule" size="0.05 0.2"')
+    with pytest.raises(mjcf.MjcfError, match="ellipsoid"):
+        _plane('type="ellipsoid" size="0.1 0.2 0.3"')
+    # inertia of a cylinder from its geom (user_objects.cc: m = rho pi r^2 2 l; I_zz = m r^2 / 2, I_xx = m (3 r^2 + (2 l)^2) / 12)
+    m2 = mjcf.compile_string(f'<mujoco><compiler inertiafromgeom="true"/><worldbody><body name="c"><freejoint/><geom type="cylinder" size="{r} {hl}" density="1000"/></body></worldbody></mujoco>')
+    mass = 1000 * np.pi * r * r * 2 * hl
+    b = m2.body_id("c")
+    assert abs(m2.arrays["body_mass"][b] - mass) < 1e-9
+    np.testing.assert_allclose(sorted(m2.arrays["body_inertia"][b]), sorted([mass * r * r / 2, mass * (3 * r * r + 4 * hl * hl) / 12, mass * (3 * r * r + 4 * hl * hl) / 12]), rtol=1e-12)
