@@ -271,6 +271,10 @@ int lhw_env_pop_rerun_count(LhwEnv* env, int64_t* reruns);
 int lhw_debug_gemm(int32_t a_kc, int32_t b_kc, int32_t wt, int32_t M, int32_t N, int32_t K, const float* A, int32_t lda, const float* B,
                    int32_t ldb, float* C, int32_t ldc, const float* bias, int32_t relu, const float* mask, int32_t ldmask,
                    int32_t k_chunk, float* part, float* colsum, float* colsum_out, void* stream);
+/* Test hook for the wide weight gradient of the update (csrc/lhw_ppo.hip: wgrad_wide_kernel; reference /root/reference/rl/algos/ppo.py:387-396,
+ * the hidden layer's part of loss.backward()): per k slice z of k_chunk rows, part[z] [256][256] = A[rows of z]^T B[rows of z] and
+ * colsum[z] [256] = column sums of A's rows (A, B: [K][256] device buffers, dh2 and h1; colsum may be NULL).  The caller reduces the slices. */
+int lhw_debug_wgrad_wide(const float* A, const float* B, int32_t K, int32_t k_chunk, float* part, float* colsum, void* stream);
 /* Test hook for the fused skinny weight gradients of the update (csrc/lhw_ppo.hip: wgrad_skinny_kernel; reference
  * /root/reference/rl/algos/ppo.py:387-396, the first- and last-layer parts of loss.backward()): dW1 [H][Dp] += dh1^T x, db1 += colsum(dh1),
  * dW3 [O][H] += dy^T h2, db3 += colsum(dy) over R rows in one launch.  H = 256, Dp <= 64 (multiple of 4), O <= Op <= 32; device buffers;
@@ -288,6 +292,15 @@ int lhw_debug_mlp_strip_forward(int32_t H, int32_t Dp, int32_t O, int32_t Op, co
                                 float* h1, float* h2, float* y, float* wt_scratch, void* stream);
 int lhw_debug_mlp_strip_backward(int32_t H, int32_t O, int32_t Op, const float* w2, const float* w3, const float* dy, int32_t R,
                                  const float* h1, const float* h2, float* dh2, float* dh1, void* stream);
+/* The same two launches with the ReLU masks handed over as BITS (round 6): the forward launch also writes, per hidden layer,
+ * ceil(R / 64) * 512 words (bit set = activation positive, in the kernels' own thread-to-element order); a backward launch over the same
+ * R rows given those words does not read h1 / h2 (which may then be NULL).  64-row slabs whatever the row count. */
+int lhw_debug_mlp_strip_forward_bits(int32_t H, int32_t Dp, int32_t O, int32_t Op, const float* w1, const float* b1, const float* w2,
+                                     const float* b2, const float* w3, const float* b3, const float* x, int32_t ldx, int32_t R, float* h1,
+                                     float* h2, float* y, float* wt_scratch, uint32_t* bits1, uint32_t* bits2, void* stream);
+int lhw_debug_mlp_strip_backward_bits(int32_t H, int32_t O, int32_t Op, const float* w2, const float* w3, const float* dy, int32_t R,
+                                      const float* h1, const float* h2, float* dh2, float* dh1, const uint32_t* bits1, const uint32_t* bits2,
+                                      void* stream);
 /* Test hook: the rollout's per-control-step policy launch (observation normalisation -> actor -> Gaussian head, one strip launch;
  * what lhw_ppo_forward_at runs when only act / logp are requested) on R raw observation rows [R][obs_dim], from an actor view.
  * y [R][act_pad] receives the means.  The reference of lhw_env_rollout's in-wave policy step (bitwise). */

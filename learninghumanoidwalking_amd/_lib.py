@@ -173,6 +173,9 @@ def declare(L):
     sig("lhw_debug_gemm", [i32, i32, i32, i32, i32, i32, vp, i32, vp, i32, vp, i32, vp, i32, vp, i32, i32, vp, vp, vp, vp])
     sig("lhw_debug_mlp_strip_forward", [i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, vp, vp])
     sig("lhw_debug_mlp_strip_backward", [i32, i32, i32, vp, vp, vp, i32, vp, vp, vp, vp, vp])
+    sig("lhw_debug_mlp_strip_forward_bits", [i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, vp, vp, vp, vp])
+    sig("lhw_debug_mlp_strip_backward_bits", [i32, i32, i32, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp])
+    sig("lhw_debug_wgrad_wide", [vp, vp, i32, i32, vp, vp, vp])
     sig("lhw_debug_wgrad_skinny", [i32, i32, i32, i32, vp, vp, i32, vp, vp, i32, vp, vp, vp, vp, vp, vp])
     sig("lhw_env_phase_cycles", [vp, ctypes.c_int, vp])
     sig("lhw_env_step_range", [vp, i32, i32, vp, vp, vp, vp, vp, vp, vp])

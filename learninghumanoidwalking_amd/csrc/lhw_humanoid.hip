@@ -150,6 +150,7 @@ int humanoid_create(HumanoidEnv** out, const std::vector<int32_t>& mi, const std
                     (t1 == G_CAPSULE && (t2 == G_CAPSULE || t2 == G_BOX)) || (t1 == G_BOX && t2 == G_BOX);
     if (t2 == G_BOX && (t1 == G_SPHERE || t1 == G_CAPSULE)) primbox_pairs++;
     if (t2 == G_CYLINDER) cyl_pairs++;
+    if (stepping && t2 == G_CYLINDER) return lhw_fail(LHW_ERR_UNSUPPORTED, "cylinder geoms are not compiled into the stepping-task kernels");
     if (!ok) return lhw_fail(LHW_ERR_UNSUPPORTED, "collision pair %d (geoms %d / %d): no narrow phase for geom types %d / %d -- plane, sphere, capsule, box among "
                              "themselves, cylinders against planes and spheres (MuJoCo resolves the other cylinder pairs, ellipsoids and meshes through its general "
                              "convex collider): mask the pair with contype / conaffinity or replace the geom by an enclosing capsule / box",

@@ -1957,8 +1957,10 @@ __device__ __forceinline__ void fwd_collision(HModelRef m, HParamsRef p, L& S, i
     const int ta = ty1, tb = ty2;
     primbox = tb == G_BOX && (ta == G_SPHERE || ta == G_CAPSULE);
   }
+  // (cylinders are compiled into the walking / standing kernels only: in the stepping kernels the extra live state cost 6.5 % of
+  // jvrc_step's rate with no cylinder in the model, profiles/r06_jvrc_step_cylinder_ab.txt; humanoid_create refuses them there)
   bool cylpair = false;
-  if (m.has_cyl && have) cylpair = ty2 == G_CYLINDER;
+  if constexpr (!BOXBOX) { if (m.has_cyl && have) cylpair = ty2 == G_CYLINDER; }
   // Plane-box pairs (the floor against a foot box; kernels without box-box pairs): lane 8 j + i tests corner i of the j-th such
   // pair -- the same expressions, corner by corner, as collide_pair's loop, which walks the eight corners one after the other on the
   // pair's own lane, twice (counting, writing).  A ballot gives every corner its rank among the corners in contact (the first four
@@ -2005,7 +2007,7 @@ __device__ __forceinline__ void fwd_collision(HModelRef m, HParamsRef p, L& S, i
   }
   if (have && !boxpair && !primbox && !pbpair && !cylpair) collide_pair(k, m, S, lane, g1, g2, margin);
   if (m.has_primbox) { if (primbox) collide_primbox(k, m, S, lane, g1, g2, margin); }
-  if (m.has_cyl) { if (cylpair) collide_cyl(k, m, S, lane, g1, g2, margin); }
+  if constexpr (!BOXBOX) { if (m.has_cyl) { if (cylpair) collide_cyl(k, m, S, lane, g1, g2, margin); } }
   if constexpr (BOXBOX) {
     if (gany<L::W_>(boxpair)) {
       if (boxpair) { col_box_box(br, m, S, lane, g1, g2, margin); k.n = br.cnt; }
@@ -2043,7 +2045,7 @@ __device__ __forceinline__ void fwd_collision(HModelRef m, HParamsRef p, L& S, i
   }
   if (have && !boxpair && !primbox && !pbpair && !cylpair && mine > 0 && base < cap) collide_pair(k, m, S, lane, g1, g2, margin);
   if (m.has_primbox) { if (primbox && mine > 0 && base < cap) collide_primbox(k, m, S, lane, g1, g2, margin); }
-  if (m.has_cyl) { if (cylpair && mine > 0 && base < cap) collide_cyl(k, m, S, lane, g1, g2, margin); }
+  if constexpr (!BOXBOX) { if (m.has_cyl) { if (cylpair && mine > 0 && base < cap) collide_cyl(k, m, S, lane, g1, g2, margin); } }
   if constexpr (BOXBOX) {
     if (boxpair && base < cap) {
       const double zero[3] = {0, 0, 0};

@@ -66,12 +66,17 @@ struct MlpStripFwd {
   const float* stdv = nullptr;               // Gaussian head on the read-out (lhw_policy.h): act [R][O] = sample(y, stdv), logp [R]
   float *act = nullptr, *logp = nullptr;
   unsigned long long seed = 0; unsigned env_base = 0, counter = 0; int deterministic = 0;
+  // optional (the update, 64-row slabs only): the ReLU masks of h1 / h2 as bits, mlp_strip_bits_words(R) words each, for the backward launch
+  // over the SAME rows (same first row, same R): see store_act_t
+  unsigned *bits1 = nullptr, *bits2 = nullptr;
 };
 struct MlpStripBwd {
   const float *w2, *w3, *dy, *h1, *h2;       // torch Linear layout [out][in]: W2 [256][256], W3 [Op][256]; dy [R][Op]
   int O, Op, R;
   float *dh2, *dh1;                          // [R][256] each
+  const unsigned *bits1 = nullptr, *bits2 = nullptr;   // the forward launch's mask bits: h1 / h2 are then not read
 };
+size_t mlp_strip_bits_words(size_t rows);    // words per layer of the mask bits of a launch over `rows` rows (64-row slabs)
 bool mlp_strip_supported(int H, int Dp, int O, int Op);
 size_t mlp_strip_wt_floats(int Dp, int Op);
 void mlp_strip_prepare(const float* w1, const float* w2, const float* w3, int Dp, int O, int Op, float* wt, hipStream_t s);

@@ -53,6 +53,19 @@ struct StripShape {
 typedef StripShape<2, 2, 4> StripBig;
 typedef StripShape<1, 1, 8> StripSmall;
 
+// -DLHW_STRIP_CLOCK (analysis builds, scripts/strip_clock.py): every wave of the first 2048 workgroups stamps the 100 MHz wall clock at
+// the phase boundaries of the strip kernels; lhw_debug_strip_clock_read copies the stamps out.
+#ifdef LHW_STRIP_CLOCK
+#define SCLK_N 16
+__device__ unsigned long long g_strip_clk[2048 * 4 * SCLK_N];
+#define SCLK(k) do { if ((threadIdx.x & 63) == 0 && blockIdx.x < 2048 && (threadIdx.x >> 6) < 4) g_strip_clk[((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * SCLK_N + (k)] = wall_clock64(); } while (0)
+extern "C" int lhw_debug_strip_clock_read(unsigned long long* host) {
+  return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_strip_clk), sizeof(g_strip_clk)) == hipSuccess ? LHW_OK : LHW_ERR_HIP;
+}
+#else
+#define SCLK(k) do { } while (0)
+#endif
+
 template <class C>
 struct StripLds {
   float S[SH][C::LD];       // activation slab, k-major (Big: 69 632 B).  The input slab (x / dy, at most SXK columns) occupies
@@ -134,9 +147,16 @@ __device__ __forceinline__ void slab_mma(const float (*A)[C::LD], const int K, c
 // from zero inputs) but never stored to HBM.
 template <class C, bool TO_SLAB, bool FULL>
 __device__ __forceinline__ void store_act_t(StripLds<C>& L, const f32x16 (&acc)[C::RT][C::CT], const float* __restrict__ bias, const bool relu,
-                                            const float* __restrict__ mask, float* __restrict__ out, const int row0, const int R) {
+                                            const float* __restrict__ mask, float* __restrict__ out, const int row0, const int R,
+                                            unsigned* __restrict__ bits_out, const unsigned* __restrict__ bits_in) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, kh = lane >> 5;
+  // ReLU masks as BITS (round 6): the forward pass leaves, per thread and column tile, one word with bit (g RT + i) 4 + c set where its
+  // output is positive; the backward pass -- same workgroup shape, same thread-to-element map -- reads that word instead of sixteen
+  // 16-byte loads of the activations themselves (2 MB instead of 33.5 MB per layer and 32768 rows)
+  unsigned wbits[C::CT];
+#pragma unroll
+  for (int j = 0; j < C::CT; j++) wbits[j] = bits_in ? bits_in[((size_t)blockIdx.x * C::THR + tid) * C::CT + j] : 0u;
 #pragma unroll
   for (int j = 0; j < C::CT; j++) {
     const int nb = wave * 32 * C::CT + 32 * j + 4 * kh;
@@ -149,8 +169,9 @@ __device__ __forceinline__ void store_act_t(StripLds<C>& L, const f32x16 (&acc)[
       for (int g = 0; g < 4; g++) {
         const int row = 32 * i + l31;
         mk[i][g] = make_float4(1.f, 1.f, 1.f, 1.f);
-        if (mask && (FULL || row0 + row < R)) mk[i][g] = *reinterpret_cast<const float4*>(mask + (size_t)(row0 + row) * SH + nb + 8 * g);
+        if (mask && !bits_in && (FULL || row0 + row < R)) mk[i][g] = *reinterpret_cast<const float4*>(mask + (size_t)(row0 + row) * SH + nb + 8 * g);
       }
+    unsigned ob = 0u;
 #pragma unroll
     for (int g = 0; g < 4; g++) {
       const int n = nb + 8 * g;
@@ -162,21 +183,29 @@ __device__ __forceinline__ void store_act_t(StripLds<C>& L, const f32x16 (&acc)[
         const bool live = FULL || row0 + row < R;
         float4 v = make_float4(acc[i][j][4 * g] + bv.x, acc[i][j][4 * g + 1] + bv.y, acc[i][j][4 * g + 2] + bv.z, acc[i][j][4 * g + 3] + bv.w);
         if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-        if (mask) {
+        const int b0 = (g * C::RT + i) * 4;
+        if (bits_in) {
+          const unsigned w = wbits[j] >> b0;
+          v.x = (live && (w & 1u)) ? v.x : 0.f; v.y = (live && (w & 2u)) ? v.y : 0.f;
+          v.z = (live && (w & 4u)) ? v.z : 0.f; v.w = (live && (w & 8u)) ? v.w : 0.f;
+        } else if (mask) {
           v.x = (live && mk[i][g].x > 0.f) ? v.x : 0.f; v.y = (live && mk[i][g].y > 0.f) ? v.y : 0.f;
           v.z = (live && mk[i][g].z > 0.f) ? v.z : 0.f; v.w = (live && mk[i][g].w > 0.f) ? v.w : 0.f;
         }
+        if (bits_out) ob |= ((v.x > 0.f ? 1u : 0u) | (v.y > 0.f ? 2u : 0u) | (v.z > 0.f ? 4u : 0u) | (v.w > 0.f ? 8u : 0u)) << b0;
         if (TO_SLAB) { L.S[n][row] = v.x; L.S[n + 1][row] = v.y; L.S[n + 2][row] = v.z; L.S[n + 3][row] = v.w; }
         if (live && out) *reinterpret_cast<float4*>(out + (size_t)(row0 + row) * SH + n) = v;   // (out == NULL: inference, the hidden layers stay in LDS)
       }
     }
+    if (bits_out) bits_out[((size_t)blockIdx.x * C::THR + tid) * C::CT + j] = ob;
   }
 }
 template <class C, bool TO_SLAB>
 __device__ __forceinline__ void store_act(StripLds<C>& L, const f32x16 (&acc)[C::RT][C::CT], const float* __restrict__ bias, const bool relu,
-                                          const float* __restrict__ mask, float* __restrict__ out, const int row0, const int R) {
-  if (row0 + C::ROWS <= R) store_act_t<C, TO_SLAB, true>(L, acc, bias, relu, mask, out, row0, R);   // (all but the last slab: no per-row tests)
-  else store_act_t<C, TO_SLAB, false>(L, acc, bias, relu, mask, out, row0, R);
+                                          const float* __restrict__ mask, float* __restrict__ out, const int row0, const int R,
+                                          unsigned* __restrict__ bits_out = nullptr, const unsigned* __restrict__ bits_in = nullptr) {
+  if (row0 + C::ROWS <= R) store_act_t<C, TO_SLAB, true>(L, acc, bias, relu, mask, out, row0, R, bits_out, bits_in);   // (all but the last slab: no per-row tests)
+  else store_act_t<C, TO_SLAB, false>(L, acc, bias, relu, mask, out, row0, R, bits_out, bits_in);
 }
 
 // stage a [rows][K] row-major slab (row stride ld) k-major into X, zero-padded to a multiple of SBK in k and beyond R in rows
@@ -186,6 +215,32 @@ template <class C>
 __device__ __forceinline__ void stage_input(float (*X)[C::LD], const float* __restrict__ x, const int ld, const int K, const int row0, const int R,
                                             const float* __restrict__ mean = nullptr, const float* __restrict__ stdv = nullptr, const int in_dim = 0) {
   const int Kp = (K + SBK - 1) & ~(SBK - 1);
+  if (!mean && !(ld & 3) && !(reinterpret_cast<size_t>(x) & 15)) {
+    // 16-byte rows (the update's minibatches: x [R][Dp], dy [R][Op]): every thread issues ALL its 16-byte loads before the first LDS write
+    // -- as a loop of load -> write round trips (twelve of them, dependent) this stage took 5.4 us of a 64 us forward pass
+    // (profiles/r06_strip_clock.txt)
+    const int k4 = Kp >> 2;
+    constexpr int NQ = (C::ROWS * (SXK / 4) + C::THR - 1) / C::THR;
+    const float rk4 = 1.f / (float)k4;
+    float4 v[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; q++) {
+      const int idx = (int)threadIdx.x + q * C::THR, r = (int)(((float)idx + 0.5f) * rk4), k = 4 * (idx - r * k4);
+      v[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (idx < C::ROWS * k4 && k < K && row0 + r < R) {
+        v[q] = *reinterpret_cast<const float4*>(x + (size_t)(row0 + r) * ld + k);
+        if (k + 1 >= K) v[q].y = 0.f;
+        if (k + 2 >= K) v[q].z = 0.f;
+        if (k + 3 >= K) v[q].w = 0.f;
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < NQ; q++) {
+      const int idx = (int)threadIdx.x + q * C::THR, r = (int)(((float)idx + 0.5f) * rk4), k = 4 * (idx - r * k4);
+      if (idx < C::ROWS * k4) { X[k][r] = v[q].x; X[k + 1][r] = v[q].y; X[k + 2][r] = v[q].z; X[k + 3][r] = v[q].w; }
+    }
+    return;
+  }
   for (int i = threadIdx.x; i < C::ROWS * Kp; i += C::THR) {
     const int r = i / Kp, k = i - r * Kp;
     float v = 0.f;
@@ -205,21 +260,31 @@ __global__ void __launch_bounds__(C::THR, 2) mlp_fwd_strip_kernel(MlpStripFwd a)
   const int row0 = (int)blockIdx.x * C::ROWS;
   float (*X)[C::LD] = &L.S[SH - SXK];
   WOp<C> w;
+  SCLK(0);
   wload<C>(w, a.w1t, SH, a.Dp, 0);   // (the first weights of a layer are in flight while the slab is staged / the previous epilogue runs)
   stage_input<C>(X, a.x, a.ldx, a.Dp, row0, a.R, a.in_mean, a.in_std, a.in_dim);
   __syncthreads();
+  SCLK(1);
   f32x16 acc[C::RT][C::CT];
   zero_acc<C>(acc);
   slab_mma<C>(X, a.Dp, a.w1t, SH, w, acc);
   wload<C>(w, a.w2t, SH, SH, 0);
+  SCLK(2);
   __syncthreads();   // every wave is done with the input slab
-  store_act<C, true>(L, acc, a.b1, true, nullptr, a.h1, row0, a.R);
+  SCLK(3);
+  store_act<C, true>(L, acc, a.b1, true, nullptr, a.h1, row0, a.R, a.bits1);
+  SCLK(4);
   __syncthreads();
+  SCLK(5);
   zero_acc<C>(acc);
   slab_mma<C>(L.S, SH, a.w2t, SH, w, acc);
+  SCLK(6);
   __syncthreads();
-  store_act<C, true>(L, acc, a.b2, true, nullptr, a.h2, row0, a.R);
+  SCLK(7);
+  store_act<C, true>(L, acc, a.b2, true, nullptr, a.h2, row0, a.R, a.bits2);
+  SCLK(8);
   __syncthreads();
+  SCLK(9);
   // read-out: y = h2 W3^T + b3, N = O <= 32: one column tile.  The K range is cut into SH / SKQ partial products of SKQ k each
   // (the same cut for every workgroup shape, so every shape returns the same bits); a wave takes QW consecutive ones for all
   // row tiles, and the partials are summed in ascending k order afterwards.
@@ -241,7 +306,9 @@ __global__ void __launch_bounds__(C::THR, 2) mlp_fwd_strip_kernel(MlpStripFwd a)
       for (int i = 0; i < C::RT; i++) p[q][i] = __builtin_amdgcn_mfma_f32_32x32x2f32(L.S[k][32 * i + l31], b, p[q][i], 0, 0, 0);
     }
   }
+  SCLK(10);
   __syncthreads();   // all waves are done with the slab: it now holds the partial products
+  SCLK(11);
   float (*P)[C::ROWS][32] = reinterpret_cast<float (*)[C::ROWS][32]>(&L.S[0][0]);     // [NQ][ROWS][32]: NQ * ROWS * 128 B <= the slab
 #pragma unroll
   for (int q = 0; q < QW; q++)
@@ -265,6 +332,7 @@ __global__ void __launch_bounds__(C::THR, 2) mlp_fwd_strip_kernel(MlpStripFwd a)
       }
     }
   }
+  SCLK(12);
   if (a.act) {
     __syncthreads();
     for (int row = tid; row < C::ROWS; row += C::THR)
@@ -283,19 +351,27 @@ __global__ void __launch_bounds__(C::THR, 2) mlp_bwd_strip_kernel(MlpStripBwd a)
   const int row0 = (int)blockIdx.x * C::ROWS;
   float (*X)[C::LD] = &L.S[SH - SXK];
   WOp<C> w;
+  SCLK(0);
   wload<C>(w, a.w3, SH, a.O, 0);
   stage_input<C>(X, a.dy, a.Op, a.O, row0, a.R);
   __syncthreads();
+  SCLK(1);
   f32x16 acc[C::RT][C::CT];
   zero_acc<C>(acc);
   slab_mma<C>(X, a.O, a.w3, SH, w, acc);                                    // dy W3: B[k = o][n] = W3[o][n]
   wload<C>(w, a.w2, SH, SH, 0);
+  SCLK(2);
   __syncthreads();
-  store_act<C, true>(L, acc, nullptr, false, a.h2, a.dh2, row0, a.R);
+  SCLK(3);
+  store_act<C, true>(L, acc, nullptr, false, a.h2, a.dh2, row0, a.R, nullptr, a.bits2);
+  SCLK(4);
   __syncthreads();
+  SCLK(5);
   zero_acc<C>(acc);
   slab_mma<C>(L.S, SH, a.w2, SH, w, acc);                                   // dh2 W2: B[k = o][n = i] = W2[o][i]
-  store_act<C, false>(L, acc, nullptr, false, a.h1, a.dh1, row0, a.R);
+  SCLK(6);
+  store_act<C, false>(L, acc, nullptr, false, a.h1, a.dh1, row0, a.R, nullptr, a.bits1);
+  SCLK(7);
 }
 
 // WT [cols][rows] <- W [rows][ld] for three matrices in one launch (the forward pass multiplies by W^T: its weight operand must
@@ -328,6 +404,8 @@ void mlp_strip_prepare(const float* w1, const float* w2, const float* w3, int Dp
   hipLaunchKernelGGL(transpose3_kernel, dim3(J.j[2].first + tiles(O, SH)), dim3(256), 0, s, J);
 }
 
+size_t mlp_strip_bits_words(size_t rows) { return (rows + StripBig::ROWS - 1) / StripBig::ROWS * StripBig::THR * StripBig::CT; }
+
 bool mlp_strip_supported(int H, int Dp, int O, int Op) { return H == SH && Dp > 0 && Dp <= SXK && (Dp & 3) == 0 && O > 0 && O <= 32 && Op >= O; }
 
 // Rows up to which the small shape is used: below it the slabs of the big shape would not even fill the CUs once, and the call
@@ -335,7 +413,7 @@ bool mlp_strip_supported(int H, int Dp, int O, int Op) { return H == SH && Dp > 
 #define STRIP_SMALL_ROWS 16384
 void mlp_strip_forward(const MlpStripFwd& a, hipStream_t s, int shape /* 0: by row count, 1: small, 2: big */) {
   if (a.R <= 0) return;
-  if (shape == 1 || (shape == 0 && a.R <= STRIP_SMALL_ROWS))
+  if ((shape == 1 || (shape == 0 && a.R <= STRIP_SMALL_ROWS)) && !a.bits1 && !a.bits2)   // (mask bits: the backward kernel's shape)
     hipLaunchKernelGGL((mlp_fwd_strip_kernel<StripSmall>), dim3((a.R + StripSmall::ROWS - 1) / StripSmall::ROWS), dim3(StripSmall::THR), 0, s, a);
   else
     hipLaunchKernelGGL((mlp_fwd_strip_kernel<StripBig>), dim3((a.R + StripBig::ROWS - 1) / StripBig::ROWS), dim3(StripBig::THR), 0, s, a);
@@ -346,25 +424,37 @@ void mlp_strip_backward(const MlpStripBwd& a, hipStream_t s) {
   hipLaunchKernelGGL((mlp_bwd_strip_kernel<StripBig>), dim3((a.R + StripBig::ROWS - 1) / StripBig::ROWS), dim3(StripBig::THR), 0, s, a);
 }
 
-extern "C" int lhw_debug_mlp_strip_forward(int32_t H, int32_t Dp, int32_t O, int32_t Op, const float* w1, const float* b1, const float* w2,
-                                           const float* b2, const float* w3, const float* b3, const float* x, int32_t ldx, int32_t R,
-                                           float* h1, float* h2, float* y, float* wt_scratch, void* stream) {
+extern "C" int lhw_debug_mlp_strip_forward_bits(int32_t H, int32_t Dp, int32_t O, int32_t Op, const float* w1, const float* b1, const float* w2,
+                                                const float* b2, const float* w3, const float* b3, const float* x, int32_t ldx, int32_t R,
+                                                float* h1, float* h2, float* y, float* wt_scratch, uint32_t* bits1, uint32_t* bits2, void* stream) {
   if (!wt_scratch || !w1 || !b1 || !w2 || !b2 || !w3 || !b3 || !x || !h1 || !h2 || !y) return lhw_fail(LHW_ERR_ARG, "null argument");
   if (!mlp_strip_supported(H, Dp, O, Op) || ldx < Dp) return lhw_fail(LHW_ERR_UNSUPPORTED, "strip kernels: hidden width 256, padded input width <= 64, outputs <= 32");
   mlp_strip_prepare(w1, w2, w3, Dp, O, Op, wt_scratch, (hipStream_t)stream);
   MlpStripFwd a{wt_scratch, b1, wt_scratch + (size_t)Dp * SH, b2, wt_scratch + (size_t)Dp * SH + (size_t)SH * SH, b3, x, ldx, Dp, O, Op, R, h1, h2, y};
+  a.bits1 = bits1; a.bits2 = bits2;
   const char* sh = getenv("LHW_DEBUG_STRIP_SHAPE");     // (tests: "small" / "big" force the workgroup shape; default by row count)
   mlp_strip_forward(a, (hipStream_t)stream, sh ? (sh[0] == 's' ? 1 : 2) : 0);
   return hipGetLastError() == hipSuccess ? LHW_OK : lhw_fail(LHW_ERR_HIP, "mlp_fwd_strip_kernel launch failed");
 }
+extern "C" int lhw_debug_mlp_strip_forward(int32_t H, int32_t Dp, int32_t O, int32_t Op, const float* w1, const float* b1, const float* w2,
+                                           const float* b2, const float* w3, const float* b3, const float* x, int32_t ldx, int32_t R,
+                                           float* h1, float* h2, float* y, float* wt_scratch, void* stream) {
+  return lhw_debug_mlp_strip_forward_bits(H, Dp, O, Op, w1, b1, w2, b2, w3, b3, x, ldx, R, h1, h2, y, wt_scratch, nullptr, nullptr, stream);
+}
 
-extern "C" int lhw_debug_mlp_strip_backward(int32_t H, int32_t O, int32_t Op, const float* w2, const float* w3, const float* dy, int32_t R,
-                                            const float* h1, const float* h2, float* dh2, float* dh1, void* stream) {
-  if (!w2 || !w3 || !dy || !h1 || !h2 || !dh2 || !dh1) return lhw_fail(LHW_ERR_ARG, "null argument");
+extern "C" int lhw_debug_mlp_strip_backward_bits(int32_t H, int32_t O, int32_t Op, const float* w2, const float* w3, const float* dy, int32_t R,
+                                                 const float* h1, const float* h2, float* dh2, float* dh1, const uint32_t* bits1, const uint32_t* bits2,
+                                                 void* stream) {
+  if (!w2 || !w3 || !dy || !dh2 || !dh1 || (!h1 && !bits1) || (!h2 && !bits2)) return lhw_fail(LHW_ERR_ARG, "null argument");
   if (!mlp_strip_supported(H, 4, O, Op)) return lhw_fail(LHW_ERR_UNSUPPORTED, "strip kernels: hidden width 256, outputs <= 32");
   MlpStripBwd a{w2, w3, dy, h1, h2, O, Op, R, dh2, dh1};
+  a.bits1 = bits1; a.bits2 = bits2;
   mlp_strip_backward(a, (hipStream_t)stream);
   return hipGetLastError() == hipSuccess ? LHW_OK : lhw_fail(LHW_ERR_HIP, "mlp_bwd_strip_kernel launch failed");
+}
+extern "C" int lhw_debug_mlp_strip_backward(int32_t H, int32_t O, int32_t Op, const float* w2, const float* w3, const float* dy, int32_t R,
+                                            const float* h1, const float* h2, float* dh2, float* dh1, void* stream) {
+  return lhw_debug_mlp_strip_backward_bits(H, O, Op, w2, w3, dy, R, h1, h2, dh2, dh1, nullptr, nullptr, stream);
 }
 
 // the rollout's fused policy step (normalisation -> three layers -> Gaussian head) on R observation rows, from the actor view the

@@ -520,6 +520,109 @@ static inline int wgrad_skinny_chunk(int R) {   // rows per block: about 256 blo
 }
 static bool wgrad_skinny_supported(int H, int Dp, int O, int Op) { return H == WS_H && Dp > 0 && Dp <= 64 && (Dp & 3) == 0 && O > 0 && O <= 32 && Op >= O && Op <= 32 && (Op & 3) == 0; }
 
+// The WIDE weight gradient dW2 [256][256] = dh2^T h1 (and db2 = colsum(dh2)) without LDS and without barriers (round 6).  Both operands
+// are stored [row][256] and the product contracts over the rows, so row k of either IS the MFMA's operand layout (lane l: unit l % 32
+// of row k + l / 32): a wave's load instruction fetches two 128-byte segments straight from HBM / L2, as the strip kernels load their
+// weights.  Block tile 128 x 128 (four per k slice), wave tile 64 x 64 = 2 x 2 MFMA tiles: one operand load per MFMA (the LDS-staged
+// 64 x 64-tile GEMM: two LDS reads per MFMA and a barrier every 16 rows, 65 us per 32768 rows = 42 % of the f32 MFMA peak).  The rows
+// of chunk s + 1 are in flight while chunk s is multiplied.  XCD-aware block order: the four tiles of a k slice run on one L2.
+// The bias gradient comes from the same operand registers: waves with tn == wn == 0 keep a running sum of their dh2 entries (per
+// lane ascending k of one parity, the two parities added at the end: a fixed order).
+struct WgradWideArgs {
+  const float *A, *B;      // [K][256] each: dh2, h1
+  int K, k_chunk, slices;
+  float *part, *colsum;    // slice z: part + z * 256 * 256 (row-major [m][n]), colsum + z * 256
+};
+#define WW_H 256
+// KS: rows per register buffer.  Two buffers: the loads of chunk s + 1 are issued before chunk s is multiplied, i.e. KS / 2 x 4 MFMAs
+// (KS x 128 cycles when the wave has its SIMD's MFMA pipe to itself) ahead of their use.  In the update the operands come from HBM (the
+// forward pass wrote h1 a few hundred MB of traffic earlier): KS = 32 (1.7 us ahead); with KS = 16 the kernel was faster than the
+// LDS-staged GEMM alone on cache-warm operands and slower inside the update (profiles/r06_wgrad_wide.txt).
+template <int KS>
+struct WwOp { float a[KS / 2][2], b[KS / 2][2]; };
+template <int KS>
+__device__ __forceinline__ void ww_load(WwOp<KS>& w, const float* __restrict__ A, const float* __restrict__ B, const int k0, const int kend, const int am, const int bn) {
+  const int kh = (threadIdx.x & 63) >> 5;
+#pragma unroll
+  for (int kk = 0; kk < KS / 2; kk++) {
+    const int k = k0 + 2 * kk + kh, kc = min(k, kend - 1);
+    const bool live = k < kend;
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      const float av = A[(size_t)kc * WW_H + am + 32 * i];
+      w.a[kk][i] = live ? av : 0.f;                       // (rows beyond the slice: a zero dh2 entry, times a valid row of h1)
+      w.b[kk][i] = B[(size_t)kc * WW_H + bn + 32 * i];
+    }
+  }
+}
+template <int KS>
+__global__ void __launch_bounds__(256, 2) wgrad_wide_kernel(WgradWideArgs g) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, kh = lane >> 5;
+  const int per = (int)gridDim.x >> 3, v = ((int)blockIdx.x & 7) * per + ((int)blockIdx.x >> 3);
+  if (v >= 4 * g.slices) return;
+  const int t = v & 3, tm = t >> 1, tn = t & 1, bz = v >> 2, wm = wave & 1, wn = wave >> 1;
+  const int m0 = tm * 128 + wm * 64, n0 = tn * 128 + wn * 64;
+  const int kbeg = bz * g.k_chunk, kend = min(g.K, kbeg + g.k_chunk);
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+  float cs[2] = {0.f, 0.f};
+  WwOp<KS> w0, w1;
+  auto mul = [&](const WwOp<KS>& w) {
+#pragma unroll
+    for (int kk = 0; kk < KS / 2; kk++) {
+#pragma unroll
+      for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(w.a[kk][i], w.b[kk][j], acc[i][j], 0, 0, 0);
+      cs[0] += w.a[kk][0]; cs[1] += w.a[kk][1];
+    }
+  };
+  if (kbeg < kend) {
+    ww_load<KS>(w0, g.A, g.B, kbeg, kend, m0 + l31, n0 + l31);
+    for (int k0 = kbeg; k0 < kend; k0 += 2 * KS) {
+      ww_load<KS>(w1, g.A, g.B, k0 + KS, kend, m0 + l31, n0 + l31);      // (unconditional: clamped past the end)
+      __builtin_amdgcn_sched_barrier(0);
+      mul(w0);
+      __builtin_amdgcn_sched_barrier(0);
+      ww_load<KS>(w0, g.A, g.B, k0 + 2 * KS, kend, m0 + l31, n0 + l31);
+      __builtin_amdgcn_sched_barrier(0);
+      if (k0 + KS < kend) mul(w1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  // epilogue; C/D map of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+  float* part = g.part + (size_t)bz * WW_H * WW_H;
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) part[(size_t)(m0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * kh) * WW_H + n0 + 32 * j + l31] = acc[i][j][r];
+  if (g.colsum && tn == 0 && wn == 0) {
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      const float o = __shfl_down(cs[i], 32);
+      if (kh == 0) g.colsum[(size_t)bz * WW_H + m0 + 32 * i + l31] = cs[i] + o;
+    }
+  }
+}
+static bool wgrad_wide_on() {   // LHW_WGRAD_WIDE=0: the LDS-staged split-K GEMM instead (A/B measurements)
+  static const bool on = !(getenv("LHW_WGRAD_WIDE") && atoi(getenv("LHW_WGRAD_WIDE")) == 0);
+  return on;
+}
+static void launch_wgrad_wide(const float* A, const float* B, int K, int k_chunk, float* part, float* colsum, hipStream_t s) {
+  WgradWideArgs a{A, B, K, k_chunk, (K + k_chunk - 1) / k_chunk, part, colsum};
+  static const int ks = getenv("LHW_WGRAD_WIDE_KS") ? atoi(getenv("LHW_WGRAD_WIDE_KS")) : 32;   // (tuning aid)
+  const dim3 grid(8 * ((4 * (size_t)a.slices + 7) / 8));
+  if (ks == 16) hipLaunchKernelGGL(wgrad_wide_kernel<16>, grid, dim3(256), 0, s, a);
+  else hipLaunchKernelGGL(wgrad_wide_kernel<32>, grid, dim3(256), 0, s, a);
+}
+
 // defer != 0: split-K partials (and the fused column sums) stay in g.part / g.colsum for a later reduce_segments launch
 template <bool A_KC, bool B_KC>
 static void launch_gemm(const GemmArgs& g, hipStream_t s, int defer = 0, int wt = 0, int half = 0) {
@@ -598,6 +701,7 @@ struct LhwPpo {
   float *stats = nullptr;  // [16] loss scalars; [8],[9] grad norm^2 actor/critic
   float *part = nullptr;       // split-K partial tiles [max slices][H*H]
   float *dstd = nullptr;       // per-row d loss / d std [R][Op]
+  unsigned *bits_a = nullptr, *bits_c = nullptr;   // ReLU masks of h1 / h2 as bits, forward strip -> backward strip (2 layers x words(2R) / words(R)); NULL: max_rows % 64 != 0
   float *wt_a = nullptr, *wt_c = nullptr;   // [in][out] weight copies for the strip kernels (hidden width 256 only): the update's
   float *wt_inf = nullptr;                  // ... and WT_SLOTS pairs (actor, critic) for rollout inference, one per eighth of the
                                             // forward workspace, so that concurrent calls (disjoint row ranges, different streams) do not share one
@@ -642,7 +746,7 @@ static int strip_mode() {
 }
 static void mlp_forward(const MlpLayout& L, const float* theta, const float* x, int ldx, int R, float* h1, float* h2,
                         float* y, hipStream_t s, int half = 0, float* strip_wt = nullptr, bool wt_ready = false, bool keep_hidden = true,
-                        const HalfBufs* hb = nullptr) {
+                        const HalfBufs* hb = nullptr, unsigned* bits1 = nullptr, unsigned* bits2 = nullptr) {
   if (hb && half) {   // --fp16 update: x / h1 / h2 live in fp16 (hb), the weights are rounded while staged, y stays float32 for the loss
     GemmArgs g{};
     g.A = reinterpret_cast<const float*>(hb->x); g.lda = hb->ldx; g.a_half = 1; g.B = theta + L.w1; g.ldb = L.Dp;
@@ -662,6 +766,7 @@ static void mlp_forward(const MlpLayout& L, const float* theta, const float* x, 
     if (!wt_ready) mlp_strip_prepare(theta + L.w1, theta + L.w2, theta + L.w3, L.Dp, L.O, L.Op, strip_wt, s);   // [in][out] copies of the weights
     MlpStripFwd a{strip_wt, theta + L.b1, strip_wt + (size_t)L.Dp * L.H, theta + L.b2, strip_wt + (size_t)L.Dp * L.H + (size_t)L.H * L.H,
                   theta + L.b3, x, ldx, L.Dp, L.O, L.Op, R, keep_hidden ? h1 : nullptr, keep_hidden ? h2 : nullptr, y};   // (inference: h1 / h2 never leave LDS)
+    if (keep_hidden) { a.bits1 = bits1; a.bits2 = bits2; }
     mlp_strip_forward(a, s);
     return;
   }
@@ -713,7 +818,7 @@ static BwdParts bwd_parts_carve(const MlpLayout& L, size_t rows, int passes, flo
 // (same seed -> bitwise identical weights, the property the reference's tests/test_determinism.py checks).
 static void mlp_backward(const MlpLayout& L, const float* theta, const float* x, int ldx, int R, const float* h1, const float* h2,
                          const float* dy, float* dh2, float* dh1, const BwdParts& P, BwdSlices& z, hipStream_t s, int half = 0,
-                         const HalfBufs* hb = nullptr) {
+                         const HalfBufs* hb = nullptr, const unsigned* bits1 = nullptr, const unsigned* bits2 = nullptr) {
   GemmArgs g{};
   if (hb && half) {   // --fp16 update with fp16 storage: the same five GEMMs on the fp16 copies (dy and the weights are float32)
     auto H16 = [](const _Float16* q) { return reinterpret_cast<const float*>(q); };
@@ -747,6 +852,7 @@ static void mlp_backward(const MlpLayout& L, const float* theta, const float* x,
   const bool strip = strip_mode() >= 1 && !half && mlp_strip_supported(L.H, L.Dp, L.O, L.Op);
   if (strip) {   // dh2 = (dy W3) * (h2 > 0) and dh1 = (dh2 W2) * (h1 > 0) in one launch, the dh2 slab staying in LDS
     MlpStripBwd a{theta + L.w2, theta + L.w3, dy, h1, h2, L.O, L.Op, R, dh2, dh1};
+    a.bits1 = bits1; a.bits2 = bits2;
     mlp_strip_backward(a, s);
   }
   // The skinny weight gradients dW1 / db1 / dW3 / db3: one K-streaming launch behind the activation gradients (wgrad_skinny_kernel; its
@@ -767,7 +873,8 @@ static void mlp_backward(const MlpLayout& L, const float* theta, const float* x,
   g = GemmArgs{};
   g.A = dh2; g.lda = L.H; g.B = h1; g.ldb = L.H; g.M = L.H; g.N = L.H; g.K = R;
   g.part = P.w2 + (size_t)z.w2 * L.H * L.H; g.colsum = P.b2 + (size_t)z.w2 * L.H; g.k_chunk = KC_WIDE;
-  launch_gemm<false, false>(g, s, 1, 0, half);
+  if (!half && L.H == WW_H && wgrad_wide_on()) launch_wgrad_wide(dh2, h1, R, KC_WIDE, g.part, g.colsum, s);
+  else launch_gemm<false, false>(g, s, 1, 0, half);
   // dh1 = (dh2 W2) * (h1 > 0)
   if (!strip) {
     g = GemmArgs{};
@@ -1119,6 +1226,11 @@ extern "C" int lhw_debug_gemm(int32_t a_kc, int32_t b_kc, int32_t wt, int32_t M,
 }
 
 // Test hook: dW1 / db1 / dW3 / db3 of one network by the fused K-streaming kernel, ADDED to the outputs (scratch: slices x (256 Dp + 256 + 256 O + O) floats)
+extern "C" int lhw_debug_wgrad_wide(const float* A, const float* B, int32_t K, int32_t k_chunk, float* part, float* colsum, void* stream) {
+  if (!A || !B || !part || K <= 0 || k_chunk <= 0) return lhw_fail(LHW_ERR_ARG, "bad argument");
+  launch_wgrad_wide(A, B, K, k_chunk, part, colsum, (hipStream_t)stream);
+  return hipGetLastError() == hipSuccess ? LHW_OK : lhw_fail(LHW_ERR_HIP, "wgrad_wide_kernel launch failed");
+}
 extern "C" int lhw_debug_wgrad_skinny(int32_t H, int32_t Dp, int32_t O, int32_t Op, const float* dh1, const float* x, int32_t ldx, const float* dy,
                                       const float* h2, int32_t R, float* dW1, float* db1, float* dW3, float* db3, float* scratch, void* stream) {
   if (!dh1 || !x || !dy || !h2 || !dW1 || !db1 || !dW3 || !db3 || !scratch || R <= 0) return lhw_fail(LHW_ERR_ARG, "lhw_debug_wgrad_skinny: bad argument");
@@ -1171,6 +1283,8 @@ extern "C" int lhw_ppo_create(const LhwPpoConfig* c, LhwPpo** out) {
   ok = ok && alloc(&p->bwd_part, bwd_parts_floats(p->la, R, 2) + bwd_parts_floats(p->lc, R, 1));
   if (mlp_strip_supported(p->la.H, p->la.Dp, p->la.O, p->la.Op)) ok = ok && alloc(&p->wt_a, mlp_strip_wt_floats(p->la.Dp, p->la.Op));
   if (mlp_strip_supported(p->lc.H, p->lc.Dp, p->lc.O, p->lc.Op)) ok = ok && alloc(&p->wt_c, mlp_strip_wt_floats(p->lc.Dp, p->lc.Op));
+  if (p->wt_a && p->wt_c && R % 64 == 0 && !(getenv("LHW_STRIP_BITS") && atoi(getenv("LHW_STRIP_BITS")) == 0))
+    ok = ok && alloc(reinterpret_cast<float**>(&p->bits_a), 4 * mlp_strip_bits_words(R)) && alloc(reinterpret_cast<float**>(&p->bits_c), 2 * mlp_strip_bits_words(R));
   if (p->wt_a && p->wt_c) ok = ok && alloc(&p->wt_inf, WT_SLOTS * (mlp_strip_wt_floats(p->la.Dp, p->la.Op) + mlp_strip_wt_floats(p->lc.Dp, p->lc.Op))) &&
                                alloc(&p->wt_roll, mlp_strip_wt_floats(p->la.Dp, p->la.Op) + mlp_strip_wt_floats(p->lc.Dp, p->lc.Op));
   if (ok && p->use_mirror) {
@@ -1206,7 +1320,7 @@ extern "C" int lhw_ppo_destroy(LhwPpo* p) {
   (void)hipSetDevice(p->device);
   float* bufs[] = {p->xb, p->h1a, p->h2a, p->ya, p->h1c, p->h2c, p->yc, p->dya, p->dh2a, p->dh1a, p->dyc, p->dh2c, p->dh1c,
                    p->mb_act, p->mb_logp, p->mb_adv, p->mb_ret, p->stats, p->d_obs_sign, p->d_act_sign, p->part, p->dstd, p->stats_part,
-                   p->norm_part, p->bwd_part, p->wt_a, p->wt_c, p->wt_inf, p->wt_roll};
+                   p->norm_part, p->bwd_part, p->wt_a, p->wt_c, p->wt_inf, p->wt_roll, reinterpret_cast<float*>(p->bits_a), reinterpret_cast<float*>(p->bits_c)};
   for (float* b : bufs) if (b) (void)hipFree(b);
   _Float16* hbufs[] = {p->xb_h, p->h1a_h, p->h2a_h, p->dh2a_h, p->dh1a_h, p->h1c_h, p->h2c_h, p->dh2c_h, p->dh1c_h};
   for (_Float16* b : hbufs) if (b) (void)hipFree(b);
@@ -1490,14 +1604,18 @@ extern "C" int lhw_ppo_grad(LhwPpo* p, const float* theta, float* grad, const fl
   }
   const HalfBufs *pha = hstore ? &ha : nullptr, *phc = hstore ? &hc : nullptr, *pham = hstore ? &ham : nullptr;
   // forward: rows [0,B) and, if mirroring, rows [R, R+B)
+  // ReLU masks as bits from the forward strips to the backward strips (per layer: normal rows, then the mirrored rows' launch)
+  const size_t bw = mlp_strip_bits_words(R);
+  unsigned *ba1 = p->bits_a, *ba2 = p->bits_a ? p->bits_a + 2 * bw : nullptr, *bc1 = p->bits_c, *bc2 = p->bits_c ? p->bits_c + bw : nullptr;
   fork();
-  mlp_forward(p->lc, th_c, p->xb, Dp, B, p->h1c, p->h2c, p->yc, sc, p->update_half, strip_mode() >= 1 ? p->wt_c : nullptr, false, true, phc);
+  mlp_forward(p->lc, th_c, p->xb, Dp, B, p->h1c, p->h2c, p->yc, sc, p->update_half, strip_mode() >= 1 ? p->wt_c : nullptr, false, true, phc, bc1, bc2);
   if (mir && B == R) {
-    mlp_forward(p->la, th_a, p->xb, Dp, 2 * B, p->h1a, p->h2a, p->ya, s, p->update_half, strip_mode() >= 1 ? p->wt_a : nullptr, false, true, pha);   // mirrored rows follow without a gap
+    mlp_forward(p->la, th_a, p->xb, Dp, 2 * B, p->h1a, p->h2a, p->ya, s, p->update_half, strip_mode() >= 1 ? p->wt_a : nullptr, false, true, pha, ba1, ba2);   // mirrored rows follow without a gap
   } else {
-    mlp_forward(p->la, th_a, p->xb, Dp, B, p->h1a, p->h2a, p->ya, s, p->update_half, strip_mode() >= 1 ? p->wt_a : nullptr, false, true, pha);
+    mlp_forward(p->la, th_a, p->xb, Dp, B, p->h1a, p->h2a, p->ya, s, p->update_half, strip_mode() >= 1 ? p->wt_a : nullptr, false, true, pha, ba1, ba2);
     if (mir)
-      mlp_forward(p->la, th_a, p->xb + (size_t)R * Dp, Dp, B, p->h1a + (size_t)R * p->H, p->h2a + (size_t)R * p->H, p->ya + (size_t)R * Op, s, p->update_half, strip_mode() >= 1 ? p->wt_a : nullptr, false, true, pham);
+      mlp_forward(p->la, th_a, p->xb + (size_t)R * Dp, Dp, B, p->h1a + (size_t)R * p->H, p->h2a + (size_t)R * p->H, p->ya + (size_t)R * Op, s, p->update_half, strip_mode() >= 1 ? p->wt_a : nullptr, false, true, pham,
+                  ba1 ? ba1 + bw : nullptr, ba2 ? ba2 + bw : nullptr);
   }
   join();
   const int nblk = (B + 255) / 256;
@@ -1519,15 +1637,16 @@ extern "C" int lhw_ppo_grad(LhwPpo* p, const float* theta, float* grad, const fl
   const BwdParts Pc = bwd_parts_carve(p->lc, R, 1, p->bwd_part + bwd_parts_floats(p->la, R, 2));
   BwdSlices za, zc;
   fork();
-  mlp_backward(p->lc, th_c, p->xb, Dp, B, p->h1c, p->h2c, p->dyc, p->dh2c, p->dh1c, Pc, zc, sc, p->update_half, phc);
+  mlp_backward(p->lc, th_c, p->xb, Dp, B, p->h1c, p->h2c, p->dyc, p->dh2c, p->dh1c, Pc, zc, sc, p->update_half, phc, bc1, bc2);
   if (mir && B == R) {
     // the mirrored rows follow the normal ones without a gap: one pass over 2B rows
-    mlp_backward(p->la, th_a, p->xb, Dp, 2 * B, p->h1a, p->h2a, p->dya, p->dh2a, p->dh1a, Pa, za, s, p->update_half, pha);
+    mlp_backward(p->la, th_a, p->xb, Dp, 2 * B, p->h1a, p->h2a, p->dya, p->dh2a, p->dh1a, Pa, za, s, p->update_half, pha, ba1, ba2);
   } else {
-    mlp_backward(p->la, th_a, p->xb, Dp, B, p->h1a, p->h2a, p->dya, p->dh2a, p->dh1a, Pa, za, s, p->update_half, pha);
+    mlp_backward(p->la, th_a, p->xb, Dp, B, p->h1a, p->h2a, p->dya, p->dh2a, p->dh1a, Pa, za, s, p->update_half, pha, ba1, ba2);
     if (mir)
       mlp_backward(p->la, th_a, p->xb + (size_t)R * Dp, Dp, B, p->h1a + (size_t)R * p->H, p->h2a + (size_t)R * p->H,
-                   p->dya + (size_t)R * Op, p->dh2a + (size_t)R * p->H, p->dh1a + (size_t)R * p->H, Pa, za, s, p->update_half, pham);
+                   p->dya + (size_t)R * Op, p->dh2a + (size_t)R * p->H, p->dh1a + (size_t)R * p->H, Pa, za, s, p->update_half, pham,
+                   ba1 ? ba1 + bw : nullptr, ba2 ? ba2 + bw : nullptr);
   }
   join();
   SegList S;

@@ -48,6 +48,33 @@ for name, flops, fn in cases:
         line += f"  wt{wt}: {us:7.1f} us {flops / us / 1e6:6.1f} TF/s"
     print(line)
 
+# the wide weight gradient without LDS (wgrad_wide_kernel): dW2 + db2 partials of 512-row slices, against the LDS-staged GEMM (partials
+# + reduction); warm = the operands stay in the caches between launches, cold = 1 GB written between launches (as in the update, where the
+# forward pass wrote h1 several hundred MB of traffic before the weight gradients read it)
+nsw = (B + 511) // 512
+pw = torch.zeros(nsw * H * H, device=dev); cw = torch.zeros(nsw * H, device=dev)
+fnw = lambda: L.lhw_debug_wgrad_wide(p(h), p(h2), B, 512, p(pw), p(cw), None)
+fng = lambda: L.lhw_debug_gemm(0, 0, 1, H, H, B, p(h), H, p(h2), H, p(dW), H, None, 0, None, 0, 512, p(part), p(cpart), p(db), None)
+flush = torch.empty(256 * 1024 * 1024, device=dev)
+
+
+def timed(fn, cold, n=20):
+    ts = []
+    for _ in range(n + 3):
+        if cold:
+            flush.fill_(1.0)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); _lib.check(fn()); e1.record()
+        torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1) * 1e3)
+    return sorted(ts[3:])[n // 2]
+
+
+import os
+for nm, fn in (("dW2 LDS-staged GEMM 64x64 (+ reduction)", fng), (f"dW2 wide, KS={os.environ.get('LHW_WGRAD_WIDE_KS', '32')} (partials only)", fnw)):
+    tw, tc = timed(fn, False), timed(fn, True)
+    print(f"{nm:44s} warm {tw:7.1f} us {2.0 * B * H * H / tw / 1e6:6.1f} TF/s   cold {tc:7.1f} us {2.0 * B * H * H / tc / 1e6:6.1f} TF/s")
+
 # the fused skinny weight gradients (dW1 + db1 + dW3 + db3 in one K-streaming launch) against the two split-K GEMMs above
 kc = max(128, (((B + 255) // 256) + 15) // 16 * 16)
 ns = (B + kc - 1) // kc

@@ -101,3 +101,51 @@ def test_strip_refuses_other_widths():
     z = np.zeros(4, np.float32)
     rc = L.lhw_debug_mlp_strip_forward(128, 40, 12, 12, _ptr(z), _ptr(z), _ptr(z), _ptr(z), _ptr(z), _ptr(z), _ptr(z), 40, 1, _ptr(z), _ptr(z), _ptr(z), _ptr(z), None)
     assert rc != 0
+
+
+def run_bits_round_trip(L, c, ptr=_ptr, alloc=None):
+    """forward with mask bits, then backward (a) from the bits alone and (b) from the activations: (a) == (b) bit for bit, and the forward
+    outputs equal the launch without bits.  `alloc(shape, dtype, fill)` / `ptr` let the GPU twin run the same steps on device buffers."""
+    R, H, Op = c["R"], c["H"], c["Op"]
+    alloc = alloc or (lambda shape, dt, fill: np.full(shape, fill, dt))
+    nw = (R + 63) // 64 * 512
+    wt = alloc(((c["Dp"] + 256 + Op) * 256,), np.float32, 0)
+    outs = []
+    for with_bits in (False, True):
+        h1, h2, y = alloc((R, H), np.float32, 7.0), alloc((R, H), np.float32, 7.0), alloc((R, Op), np.float32, 7.0)
+        b1, b2 = alloc((nw,), np.uint32, 0xFFFFFFFF), alloc((nw,), np.uint32, 0xFFFFFFFF)
+        rc = L.lhw_debug_mlp_strip_forward_bits(H, c["Dp"], c["O"], Op, ptr(c["w1"]), ptr(c["b1"]), ptr(c["w2"]), ptr(c["b2"]), ptr(c["w3"]), ptr(c["b3"]),
+                                                ptr(c["x"]), c["Dp"], R, ptr(h1), ptr(h2), ptr(y), ptr(wt), ptr(b1) if with_bits else None,
+                                                ptr(b2) if with_bits else None, None)
+        assert rc == 0
+        outs.append((h1, h2, y, b1, b2))
+    grads = []
+    for mode in ("acts", "bits"):
+        h1, h2, y, b1, b2 = outs[1]
+        dh2, dh1 = alloc((R, H), np.float32, 7.0), alloc((R, H), np.float32, 7.0)
+        rc = L.lhw_debug_mlp_strip_backward_bits(H, c["O"], Op, ptr(c["w2"]), ptr(c["w3"]), ptr(c["dy"]), R, ptr(h1) if mode == "acts" else None,
+                                                 ptr(h2) if mode == "acts" else None, ptr(dh2), ptr(dh1), ptr(b1) if mode == "bits" else None,
+                                                 ptr(b2) if mode == "bits" else None, None)
+        assert rc == 0
+        grads.append((dh2, dh1))
+    return outs, grads
+
+
+@pytest.mark.parametrize("R,Dp,O,Op", [(100, 40, 12, 12), (64, 36, 1, 4)])
+def test_relu_mask_bits_round_trip_on_the_emulator(R, Dp, O, Op):
+    from tests import emu
+    L = emu.lib()
+    c = make_case(R=R, Dp=Dp, O=O, Op=Op, seed=5)
+    outs, grads = run_bits_round_trip(L, c)
+    for a, b in zip(outs[0][:3], outs[1][:3]):
+        np.testing.assert_array_equal(a, b)
+    np.testing.assert_array_equal(grads[0][0], grads[1][0])
+    np.testing.assert_array_equal(grads[0][1], grads[1][1])
+    g2, g1 = reference_backward(c, outs[1][0].astype(np.float64), outs[1][1].astype(np.float64))
+    np.testing.assert_allclose(grads[1][0], g2, rtol=0, atol=5e-5)
+    np.testing.assert_allclose(grads[1][1], g1, rtol=0, atol=1e-4)
+    # one bit per positive activation (rows beyond R of a ragged last slab are computed from zero inputs and carry bits too)
+    for layer in (0, 1):
+        pop = int(np.unpackbits(np.asarray(outs[1][3 + layer]).view(np.uint8)).sum())
+        pos = int((np.asarray(outs[1][layer]) > 0).sum())
+        assert pop == pos if R % 64 == 0 else pop >= pos

@@ -76,6 +76,37 @@ def test_weight_gradient_split_k_with_fused_bias_gradient(wt, M, N, K, kc):
     assert torch.equal(C, C2) and torch.equal(bsum, b2)
 
 
+@pytest.mark.parametrize("K,kc", [(32768, 512), (1000, 512), (4099, 128), (37, 512), (65536, 512)])
+def test_wide_weight_gradient_matches_float64(K, kc):
+    """wgrad_wide_kernel (csrc/lhw_ppo.hip): dW2 = dh2^T h1 and db2 = colsum(dh2) per k slice, operands straight from global memory
+    (reference rl/algos/ppo.py:387-396: the hidden layer's share of loss.backward()), against float64 slice by slice; ragged row
+    counts (a last chunk shorter than the 16-row register buffer), run-to-run bitwise determinism."""
+    import torch
+    from learninghumanoidwalking_amd import _lib
+    L = _lib.lib()
+    H = 256
+    g = torch.Generator(device="cuda").manual_seed(K)
+    dh2 = torch.randn(K, H, device="cuda", generator=g) * 0.1
+    h1 = torch.relu(torch.randn(K, H, device="cuda", generator=g))
+    ns = (K + kc - 1) // kc
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+
+    def run():
+        part = torch.full((ns, H, H), 7.0, device="cuda")
+        cs = torch.full((ns, H), 7.0, device="cuda")
+        _lib.check(L.lhw_debug_wgrad_wide(p(dh2), p(h1), K, kc, p(part), p(cs), None))
+        torch.cuda.synchronize()
+        return part, cs
+
+    (pa, ca), (pb, cb) = run(), run()
+    assert torch.equal(pa, pb) and torch.equal(ca, cb)
+    for z in range(ns):
+        a64, b64 = dh2[z * kc:(z + 1) * kc].double(), h1[z * kc:(z + 1) * kc].double()
+        ref = a64.t() @ b64
+        assert float((pa[z].double() - ref).abs().max()) < 2e-5 * (float(ref.abs().max()) + 1.0)
+        assert float((ca[z].double() - a64.sum(0)).abs().max()) < 2e-5 * (float(a64.sum(0).abs().max()) + 1.0)
+
+
 @pytest.mark.parametrize("layout,M,N,K", [("fwd", 1000, 256, 40), ("fwd", 777, 12, 256), ("bwd", 2049, 256, 256), ("bwd", 3000, 256, 12),
                                           ("dw", 256, 256, 5000), ("dw", 12, 256, 4097), ("dw", 256, 40, 3000)])
 def test_fp16_operand_mode_equals_half_rounded_operands(layout, M, N, K):

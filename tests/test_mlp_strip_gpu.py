@@ -40,6 +40,29 @@ def test_strip_kernels_match_float64_reference(R, Dp, O, Op):
     np.testing.assert_allclose(dh1[:R].cpu().numpy(), g1, rtol=0, atol=1e-4)
 
 
+@pytest.mark.parametrize("R,Dp,O,Op", [(64 * 37 + 5, 40, 12, 12), (32768, 40, 12, 12), (4096, 36, 1, 4)])
+def test_relu_mask_bits_round_trip(R, Dp, O, Op):
+    """the forward strip's mask bits drive the backward strip to the same dh2 / dh1, bit for bit, as the activations themselves"""
+    import torch
+    from learninghumanoidwalking_amd import _lib
+    from tests.test_emu_mlp_strip import make_case, run_bits_round_trip
+    L = _lib.lib()
+    c = make_case(R=R, Dp=Dp, O=O, Op=Op, seed=R + 1)
+    d = _dev(c)
+
+    def alloc(shape, dt, fill):
+        if dt == np.uint32:
+            return torch.full(shape, -1, dtype=torch.int32, device="cuda")
+        return torch.full(shape, float(fill), dtype=torch.float32, device="cuda")
+
+    outs, grads = run_bits_round_trip(L, d, ptr=lambda t: t.data_ptr(), alloc=alloc)
+    torch.cuda.synchronize()
+    for a, b in zip(outs[0][:3], outs[1][:3]):
+        assert torch.equal(a, b)
+    assert torch.equal(grads[0][0], grads[1][0]) and torch.equal(grads[0][1], grads[1][1])
+    assert not (grads[1][0] == 7.0).all()
+
+
 def test_strip_hidden_layers_are_bit_identical_to_the_gemm_path():
     """h1 / h2 / dh2 / dh1 are the same fmaf chains over ascending k in both paths (only the K-split read-out sums in another order)."""
     import torch
