@@ -2098,21 +2098,19 @@ __device__ __forceinline__ void fwd_collision(HModelRef m, HParamsRef p, L& S, i
             const int cle = ml.k16[e];
             if ((cle >> 1) != (key >> 1)) continue;
             if (fabsf(ml.d32[e] - dc32) > tol32 + rel32 * fabsf(dc32) || fabsf(ml.y32[e] - yc32) > tol32 + rel32 * fabsf(yc32)) continue;
+            // the candidate's whole record in ONE round trip to the workspace (round 6: distance first, then position and frame, were
+            // two dependent ones per verified copy -- and nearly every candidate that passes the float32 filters is a copy)
             const double dex = bd[AR_DIST + e];
-            if (fabs(dex - dc) > dtol) continue;
+            double pe[3], fe[9];
+            for (int a = 0; a < 3; a++) pe[a] = bd[AR_POS + 3 * e + a];
+            for (int a = 0; a < 9; a++) fe[a] = bd[AR_FRAME + 9 * e + a];
             const bool mirror = ((cle ^ key) & 1) != 0;
-            bool same = mirror || dex == dc;
-            for (int a = 0; a < 3; a++) {
-              const double pe = bd[AR_POS + 3 * e + a];
-              // (the two narrow phases agree to 1-2 ulp of the coordinate: an absolute floor for coordinates near zero, which are sums
-              // of terms of order 0.1, and a relative part so that the copies still merge metres away from the origin -- one ulp
-              // at |x| >= 4 m is 0.9e-15)
-              same = same && (mirror ? fabs(pe - pc[a]) <= 1e-15 + 4e-16 * fabs(pc[a]) : pe == pc[a]);
-            }
-            for (int a = 0; a < 9; a++) {
-              const double fe = bd[AR_FRAME + 9 * e + a];
-              same = same && (mirror ? fabs(((a < 3 || a >= 6) ? -fe : fe) - fc[a]) <= 1e-15 : fe == fc[a]);
-            }
+            bool same = fabs(dex - dc) <= dtol && (mirror || dex == dc);
+            // (the two narrow phases agree to 1-2 ulp of the coordinate: an absolute floor for coordinates near zero, which are sums
+            // of terms of order 0.1, and a relative part so that the copies still merge metres away from the origin -- one ulp
+            // at |x| >= 4 m is 0.9e-15)
+            for (int a = 0; a < 3; a++) same = same && (mirror ? fabs(pe[a] - pc[a]) <= 1e-15 + 4e-16 * fabs(pc[a]) : pe[a] == pc[a]);
+            for (int a = 0; a < 9; a++) same = same && (mirror ? fabs(((a < 3 || a >= 6) ? -fe[a] : fe[a]) - fc[a]) <= 1e-15 : fe[a] == fc[a]);
             if (same) f = e;
           }
         }
