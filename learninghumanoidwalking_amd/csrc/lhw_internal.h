@@ -69,14 +69,12 @@ struct MlpStripFwd {
   // optional (the update, 64-row slabs only): the ReLU masks of h1 / h2 as bits, mlp_strip_bits_words(R) words each, for the backward launch
   // over the SAME rows (same first row, same R): see store_act_t
   unsigned *bits1 = nullptr, *bits2 = nullptr;
-  int stagger = 0;                           // (set by mlp_strip_forward for the four-workgroups-per-CU shape)
 };
 struct MlpStripBwd {
   const float *w2, *w3, *dy, *h1, *h2;       // torch Linear layout [out][in]: W2 [256][256], W3 [Op][256]; dy [R][Op]
   int O, Op, R;
   float *dh2, *dh1;                          // [R][256] each
   const unsigned *bits1 = nullptr, *bits2 = nullptr;   // the forward launch's mask bits: h1 / h2 are then not read
-  int stagger = 0;
 };
 size_t mlp_strip_bits_words(size_t rows);    // words per layer of the mask bits of a launch over `rows` rows (64-row slabs)
 bool mlp_strip_supported(int H, int Dp, int O, int Op);

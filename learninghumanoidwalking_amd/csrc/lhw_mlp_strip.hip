@@ -45,28 +45,13 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // MFMA chain per wave: the shape of rollout inference, where a few thousand rows put fewer slabs on the chip than it has CUs
 // and the latency of one slab is the latency of the policy step (41 -> ~15 us).  Results are identical between the shapes (the
 // hidden layers are the same fmaf chains, the read-out has the same partial sums).
-template <int RT_, int CT_, int NW_, int MINW_ = 2>
+template <int RT_, int CT_, int NW_>
 struct StripShape {
-  static constexpr int RT = RT_, CT = CT_, NW = NW_, ROWS = 32 * RT_, LD = ROWS + 4, THR = 64 * NW_, MINW = MINW_;
+  static constexpr int RT = RT_, CT = CT_, NW = NW_, ROWS = 32 * RT_, LD = ROWS + 4, THR = 64 * NW_;
   static_assert(NW_ * CT_ * 32 == SH, "the waves' column tiles must cover the hidden width");
 };
 typedef StripShape<2, 2, 4> StripBig;
 typedef StripShape<1, 1, 8> StripSmall;
-// Mid (round 6, LHW_STRIP_UPDATE_SHAPE=mid): 32-row slabs, 4 waves x 64 columns -- 37 KB of LDS, FOUR workgroups per CU.  With two (Big) the
-// workgroups of a CU move in lock-step and the MFMA pipes idle through every epilogue; four waves per SIMD at staggered issue priorities
-// (strip_stagger) keep two of them in products while the others store.  Twice the weight loads per MFMA of Big.
-typedef StripShape<1, 2, 4, 4> StripMid;
-__device__ __forceinline__ void strip_stagger() {
-#if defined(__HIP_DEVICE_COMPILE__)
-  // the dispatcher deals workgroups 256 s .. 256 s + 255 to slot s of the CUs: slot 0 issues first, slot 3 last
-  switch (((int)blockIdx.x >> 8) & 3) {
-    case 0: __builtin_amdgcn_s_setprio(3); break;
-    case 1: __builtin_amdgcn_s_setprio(2); break;
-    case 2: __builtin_amdgcn_s_setprio(1); break;
-    default: __builtin_amdgcn_s_setprio(0); break;
-  }
-#endif
-}
 
 // -DLHW_STRIP_CLOCK (analysis builds, scripts/strip_clock.py): every wave of the first 2048 workgroups stamps the 100 MHz wall clock at
 // the phase boundaries of the strip kernels; lhw_debug_strip_clock_read copies the stamps out.
@@ -267,10 +252,9 @@ __device__ __forceinline__ void stage_input(float (*X)[C::LD], const float* __re
 }
 
 template <class C>
-__global__ void __launch_bounds__(C::THR, C::MINW) mlp_fwd_strip_kernel(MlpStripFwd a) {
+__global__ void __launch_bounds__(C::THR, 2) mlp_fwd_strip_kernel(MlpStripFwd a) {
   __shared__ StripLds<C> L;
   LHW_LDS_POISON(L);
-  if constexpr (C::MINW == 4) { if (a.stagger) strip_stagger(); }
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, kh = lane >> 5;
   const int row0 = (int)blockIdx.x * C::ROWS;
@@ -361,10 +345,9 @@ __global__ void __launch_bounds__(C::THR, C::MINW) mlp_fwd_strip_kernel(MlpStrip
 }
 
 template <class C>
-__global__ void __launch_bounds__(C::THR, C::MINW) mlp_bwd_strip_kernel(MlpStripBwd a) {
+__global__ void __launch_bounds__(C::THR, 2) mlp_bwd_strip_kernel(MlpStripBwd a) {
   __shared__ StripLds<C> L;
   LHW_LDS_POISON(L);
-  if constexpr (C::MINW == 4) { if (a.stagger) strip_stagger(); }
   const int row0 = (int)blockIdx.x * C::ROWS;
   float (*X)[C::LD] = &L.S[SH - SXK];
   WOp<C> w;
@@ -421,12 +404,7 @@ void mlp_strip_prepare(const float* w1, const float* w2, const float* w3, int Dp
   hipLaunchKernelGGL(transpose3_kernel, dim3(J.j[2].first + tiles(O, SH)), dim3(256), 0, s, J);
 }
 
-// shape of the update's launches (forward and backward must agree: the mask bits are in the shape's own thread-to-element order)
-static int strip_update_shape() {   // 2: big (64-row slabs), 3: mid (32-row slabs, four workgroups per CU); LHW_STRIP_UPDATE_SHAPE=big|mid|mid-flat
-  static const int v = [] { const char* e = getenv("LHW_STRIP_UPDATE_SHAPE"); return (e && e[0] == 'm') ? ((e[1] && e[2] && e[3] == '-') ? 4 : 3) : 2; }();
-  return v;
-}
-size_t mlp_strip_bits_words(size_t rows) { return (rows + StripMid::ROWS - 1) / StripMid::ROWS * StripMid::THR * StripMid::CT; }   // (the larger of the two shapes')
+size_t mlp_strip_bits_words(size_t rows) { return (rows + StripBig::ROWS - 1) / StripBig::ROWS * StripBig::THR * StripBig::CT; }
 
 bool mlp_strip_supported(int H, int Dp, int O, int Op) { return H == SH && Dp > 0 && Dp <= SXK && (Dp & 3) == 0 && O > 0 && O <= 32 && Op >= O; }
 
@@ -437,22 +415,12 @@ void mlp_strip_forward(const MlpStripFwd& a, hipStream_t s, int shape /* 0: by r
   if (a.R <= 0) return;
   if ((shape == 1 || (shape == 0 && a.R <= STRIP_SMALL_ROWS)) && !a.bits1 && !a.bits2)   // (mask bits: the backward kernel's shape)
     hipLaunchKernelGGL((mlp_fwd_strip_kernel<StripSmall>), dim3((a.R + StripSmall::ROWS - 1) / StripSmall::ROWS), dim3(StripSmall::THR), 0, s, a);
-  else if (shape == 0 && strip_update_shape() >= 3) {
-    MlpStripFwd b = a;
-    b.stagger = strip_update_shape() == 3;
-    hipLaunchKernelGGL((mlp_fwd_strip_kernel<StripMid>), dim3((a.R + StripMid::ROWS - 1) / StripMid::ROWS), dim3(StripMid::THR), 0, s, b);
-  } else
+  else
     hipLaunchKernelGGL((mlp_fwd_strip_kernel<StripBig>), dim3((a.R + StripBig::ROWS - 1) / StripBig::ROWS), dim3(StripBig::THR), 0, s, a);
 }
 
 void mlp_strip_backward(const MlpStripBwd& a, hipStream_t s) {
   if (a.R <= 0) return;
-  if (strip_update_shape() >= 3) {
-    MlpStripBwd b = a;
-    b.stagger = strip_update_shape() == 3;
-    hipLaunchKernelGGL((mlp_bwd_strip_kernel<StripMid>), dim3((a.R + StripMid::ROWS - 1) / StripMid::ROWS), dim3(StripMid::THR), 0, s, b);
-    return;
-  }
   hipLaunchKernelGGL((mlp_bwd_strip_kernel<StripBig>), dim3((a.R + StripBig::ROWS - 1) / StripBig::ROWS), dim3(StripBig::THR), 0, s, a);
 }
 

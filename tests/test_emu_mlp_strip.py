@@ -3,7 +3,6 @@ the f32 MFMA emulated as its fmaf chain, against a float64 numpy evaluation of t
 k-major LDS hand-off between the layers, the MFMA operand / accumulator lane maps, the K-split read-out, partial last slab.
 tests/test_mlp_strip_gpu.py is the GPU twin (and compares with the per-layer GEMM path)."""
 import ctypes
-import os
 
 import numpy as np
 import pytest
@@ -109,7 +108,7 @@ def run_bits_round_trip(L, c, ptr=_ptr, alloc=None):
     outputs equal the launch without bits.  `alloc(shape, dtype, fill)` / `ptr` let the GPU twin run the same steps on device buffers."""
     R, H, Op = c["R"], c["H"], c["Op"]
     alloc = alloc or (lambda shape, dt, fill: np.full(shape, fill, dt))
-    nw = (R + 31) // 32 * 512          # (enough for either slab shape of the update: 64-row slabs use half)
+    nw = (R + 63) // 64 * 512
     wt = alloc(((c["Dp"] + 256 + Op) * 256,), np.float32, 0)
     outs = []
     for with_bits in (False, True):
@@ -146,7 +145,7 @@ def test_relu_mask_bits_round_trip_on_the_emulator(R, Dp, O, Op):
     np.testing.assert_allclose(grads[1][0], g2, rtol=0, atol=5e-5)
     np.testing.assert_allclose(grads[1][1], g1, rtol=0, atol=1e-4)
     # one bit per positive activation (rows beyond R of a ragged last slab are computed from zero inputs and carry bits too)
-    used = (R + 63) // 64 * 512 if not os.environ.get("LHW_STRIP_UPDATE_SHAPE", "").startswith("m") else (R + 31) // 32 * 512
+    used = (R + 63) // 64 * 512
     for layer in (0, 1):
         pop = int(np.unpackbits(np.asarray(outs[1][3 + layer]).view(np.uint8)).sum())
         pos = int((np.asarray(outs[1][layer]) > 0).sum())
