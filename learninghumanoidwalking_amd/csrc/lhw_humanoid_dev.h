@@ -2956,8 +2956,21 @@ __device__ __forceinline__ void solve_tail(HModelRef m, HParamsRef p, L& S, cons
       // 4 ncon -- those are never written in a sub-step and hold whatever the LDS held before (round 4: the union loop of
       // round 3 multiplied them by D = 0, which a NaN bit pattern left by another kernel survives).
       const typename RowMask<W>::type mm_all = group_rows<W>(__ballot(dactive != 0.0));
+      // Round 6: each HALF of the env walks the rows of its own chain only.  Without a leg-leg contact (`cross`) every row touches one
+      // chain at most (root-only rows: counted with chain A), and the columns of the other chain are zeros: the rows of foot B used to
+      // pass through the lanes of chain A (and the reverse) multiplied by 0 -- two feet on the ground = 32 trips' worth of rows where each
+      // half needs 16.  The root-root block is then the sum of what the two copies of the root rows collect, which is exactly how
+      // chain_solve merges the copies (xhalf_sum of the Schur complements): copy B keeps its share instead of being cleared.
+      typename RowMask<W>::type mm_mine = mm_all;
+      if (!cross) {
+        const unsigned cbm = (((1u << NCH) - 1u) << 6) << NCH;     // dofs of chain B
+        const bool rowB = lane < nrow && ((unsigned)S.con_xm[lane >> 2] & cbm) != 0;
+        const typename RowMask<W>::type rowsB = group_rows<W>(__ballot(rowB));
+        mm_mine = ((lane >> 4) & 1) ? (mm_all & rowsB) : (mm_all & ~rowsB);
+      }
+      if (rootb) hd = 0.0;   // (copy B of a root dof: M's diagonal and the unit rows live in copy A)
       {
-        typename RowMask<W>::type mm = mm_all;
+        typename RowMask<W>::type mm = mm_mine;
         while (mm) {      // two active rows per trip: their LDS reads are in flight together, the sums keep the row order
                           // (round 4, same box: -1.9 %; four rows per trip: +1 %; round 3's `#pragma unroll` of the one-row loop had lost)
           const int r = first_row(mm);
@@ -2989,13 +3002,13 @@ __device__ __forceinline__ void solve_tail(HModelRef m, HParamsRef p, L& S, cons
             for (int k = 0; k < NCH; k++) { Hrow[6 + k] += cj * S.U[U_J + r * NV + coff + k]; Hrow[6 + k] += cj2 * S.U[U_J + r2 * NV + coff + k]; }
           }
         }
-        if (rootb) {   // the root-root block lives in copy A
+        if (rootb && cross) {   // (dense fallback: the root-root block lives in copy A)
 #pragma unroll
           for (int k = 0; k < 6; k++) Hrow[k] = 0.0;
         }
       }
       FINE_MARK(2, 0);
-      const double search = cross ? -dense_lds_solve<L>(S, Hrow, hd, grad, dof, prim, coff, mm_all) : -spd_solve(Hrow, hd, grad);
+      const double search = cross ? -dense_lds_solve<L>(S, Hrow, hd, grad, dof, prim, coff, mm_all) : -chain_solve<L>(Hrow, hd, grad, cp, rootb);
       FINE_MARK(2, 1);
       PROF_MARK(2);
       if (prim) S.U[U_VEC2 + dd] = search;
