@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 6: Newton Hessian rows walked per chain half (in-tree) vs all rows by every lane (head)
+# round 6: same-box A/B of the in-tree stepper against learninghumanoidwalking_amd/variants/liblhw_head.so on three envs
 cd /root/repo; mkdir -p gpurun_out/r6w
 timeout 1200 python -m pytest tests/test_jvrc_gpu.py tests/test_h1_gpu.py tests/test_h1_walk_gpu.py tests/test_jvrc_step_gpu.py tests/test_wide_batch_gpu.py tests/test_rollout_resident_gpu.py -m gpu -x -q 2>&1 | tail -2
 bash scripts/gpu_ab.sh r6w/ab --steps 8 --warmup 3 | tee gpurun_out/r6w/ab.txt
