@@ -2703,9 +2703,21 @@ __device__ __forceinline__ void solve_tail(HModelRef m, HParamsRef p, L& S, cons
   // K^-1 x for K = M + diag(extra) (+ J^T D J accumulated by the caller into Krow / kd)
   auto spd_solve = [&](double (&Krow)[NR], double kd, double x) { return chain_solve<L>(Krow, rootb ? 0.0 : kd, x, cp, rootb); };
   // ---- contact Jacobian, item = (contact, dof): rows 4c .. 4c+3 = Jn +- mu Jt1, Jn +- mu Jt2 (condim 1: row 4c = Jn)
+  FINE_BEGIN(4);
   const int ncon = S.ncon, nrow = 4 * ncon;
-  for (int it = lane; it < ncon * NV; it += W) {
-    const int c = it / NV, k = it - c * NV;
+  // Round 6: without a leg-leg contact a contact's rows are non-zero in the root's columns and in ONE chain's: the items are (contact, one of
+  // those 6 + NCH columns) -- 8 x 12 = three trips for a JVRC env instead of the five of 8 x 18 -- and the lane of a chain column also
+  // clears the same column of the other chain (the row loops of the solver read whole columns).  `cross`: every column is an item.
+  const int ncol = cross ? NV : 6 + NCH;
+  for (int it = lane; it < ncon * ncol; it += W) {
+    const int c = cross ? it / NV : it / (6 + NCH), j = it - c * ncol;   // (two divisions by constants, not one by a variable)
+    int k = j, kz = -1;
+    if (!cross && j >= 6) {
+      const unsigned cbm = (((1u << NCH) - 1u) << 6) << NCH;     // dofs of chain B
+      const bool onB = ((unsigned)S.con_xm[c] & cbm) != 0;
+      k = j + (onB ? NCH : 0);
+      kz = j + (onB ? 0 : NCH);
+    }
     const unsigned bit = 1u << k;
     const bool in2 = ((unsigned)S.con_m2[c] & bit) != 0;
     double d[3] = {0, 0, 0};
@@ -2725,8 +2737,13 @@ __device__ __forceinline__ void solve_tail(HModelRef m, HParamsRef p, L& S, cons
     Jc[NV] = pyr ? jn - t1 : 0.0;
     Jc[2 * NV] = pyr ? jn + t2 : 0.0;
     Jc[3 * NV] = pyr ? jn - t2 : 0.0;
+    if (kz >= 0) {
+      double* Jz = &S.U[U_J + 4 * c * NV + kz];
+      Jz[0] = 0.0; Jz[NV] = 0.0; Jz[2 * NV] = 0.0; Jz[3 * NV] = 0.0;
+    }
   }
   SYNC();
+  FINE_MARK(4, 0);
   // ---- contact rows (lane = row): Jacobian row -> registers, impedance / regulariser / reference acceleration
   // (the row is re-read from LDS for each product instead of being held across the factorisations: 36 VGPRs that the
   // Cholesky needs more)
@@ -2762,6 +2779,7 @@ __device__ __forceinline__ void solve_tail(HModelRef m, HParamsRef p, L& S, cons
       aref = -B * jv0 - K * imp * (S.U[U_CDIST + c] - S.U[U_CMARGIN + c]);
     }
   }
+  FINE_MARK(4, 1);
   // ---- unit rows of this lane's dof: slot 0 frictionloss (Huber), 1 lower limit (J = +1), 2 upper limit (J = -1)
   bool uon[3] = {false, false, false};
   double uD[3] = {0, 0, 0}, uaref[3] = {0, 0, 0}, ufl = 0;
@@ -2797,6 +2815,7 @@ __device__ __forceinline__ void solve_tail(HModelRef m, HParamsRef p, L& S, cons
   // a whole in every cost / derivative evaluation of the solver)
   const bool anyunit = gany<W>(uon[0] || uon[1] || uon[2]);
   const bool anyrow = gany<W>(isrow) || anyunit;
+  FINE_MARK(4, 2);
   PROF_MARK(4);
   // transmission + actuation (lane = actuator)
   if (lane < m.nu) {
