@@ -684,6 +684,26 @@ __device__ __forceinline__ void fmac_col(double (&R)[NRR], double& x, const doub
   for (int e = 0; e < K; e++) R[e] = fma(rbc<K>(R[e]), nf, R[e]);
 #endif
 }
+// H[e] += bcast_e(x) * c for every row position e: the rank-1 update of a lane's Hessian row by one constraint row whose Jacobian entries
+// are held one per lane (x = the entry of this lane's own dof) -- the entries of the other columns come through DPP, not from LDS
+#define LHW_FO(e) "v_fmac_f64_dpp %[h" #e "], %[x], %[c] row_newbcast:" #e " row_mask:0xf bank_mask:0xf\n\t"
+template <int NRR, int E>
+__device__ __forceinline__ void fmac_outer_ref(double (&H)[NRR], double x, double c) {
+  if constexpr (E < NRR) {
+    H[E] = fma(rbc<E>(x), c, H[E]);
+    fmac_outer_ref<NRR, E + 1>(H, x, c);
+  }
+}
+template <int NRR>
+__device__ __forceinline__ void fmac_outer(double (&H)[NRR], double x, double c) {
+#if LHW_FMAC_ASM
+  static_assert(NRR == 11 || NRR == 12, "fmac_outer: row length");
+  if constexpr (NRR == 12) asm("s_nop 1\n\t" LHW_FO(0) LHW_FO(1) LHW_FO(2) LHW_FO(3) LHW_FO(4) LHW_FO(5) LHW_FO(6) LHW_FO(7) LHW_FO(8) LHW_FO(9) LHW_FO(10) LHW_FO(11) : [h0] "+v"(H[0]), [h1] "+v"(H[1]), [h2] "+v"(H[2]), [h3] "+v"(H[3]), [h4] "+v"(H[4]), [h5] "+v"(H[5]), [h6] "+v"(H[6]), [h7] "+v"(H[7]), [h8] "+v"(H[8]), [h9] "+v"(H[9]), [h10] "+v"(H[10]), [h11] "+v"(H[11]) : [x] "v"(x), [c] "v"(c));
+  else asm("s_nop 1\n\t" LHW_FO(0) LHW_FO(1) LHW_FO(2) LHW_FO(3) LHW_FO(4) LHW_FO(5) LHW_FO(6) LHW_FO(7) LHW_FO(8) LHW_FO(9) LHW_FO(10) : [h0] "+v"(H[0]), [h1] "+v"(H[1]), [h2] "+v"(H[2]), [h3] "+v"(H[3]), [h4] "+v"(H[4]), [h5] "+v"(H[5]), [h6] "+v"(H[6]), [h7] "+v"(H[7]), [h8] "+v"(H[8]), [h9] "+v"(H[9]), [h10] "+v"(H[10]) : [x] "v"(x), [c] "v"(c));
+#else
+  fmac_outer_ref<NRR, 0>(H, x, c);
+#endif
+}
 template <int NRR, int E>
 __device__ __forceinline__ void fmac_mrow_ref(const double (&Mr)[NRR], double x, double& acc) {
   if constexpr (E < NRR) {
@@ -3001,26 +3021,12 @@ __device__ __forceinline__ void solve_tail(HModelRef m, HParamsRef p, L& S, cons
           const double cj = S.U[U_DACT + r] * jl, cj2 = two ? S.U[U_DACT + r2] * jl2 : 0.0;
           hd += cj * jl;
           hd += cj2 * jl2;
-#pragma unroll
-          for (int k = 0; k < 6; k += 2) {
-            const double2 ab = *reinterpret_cast<const double2*>(&S.U[U_J + r * NV + k]);
-            const double2 cd = *reinterpret_cast<const double2*>(&S.U[U_J + r2 * NV + k]);
-            Hrow[k] += cj * ab.x; Hrow[k + 1] += cj * ab.y;
-            Hrow[k] += cj2 * cd.x; Hrow[k + 1] += cj2 * cd.y;
-          }
-          if constexpr (NCH % 2 == 0) {
-#pragma unroll
-            for (int k = 0; k < NCH; k += 2) {
-              const double2 ab = *reinterpret_cast<const double2*>(&S.U[U_J + r * NV + coff + k]);
-              const double2 cd = *reinterpret_cast<const double2*>(&S.U[U_J + r2 * NV + coff + k]);
-              Hrow[6 + k] += cj * ab.x; Hrow[6 + k + 1] += cj * ab.y;
-              Hrow[6 + k] += cj2 * cd.x; Hrow[6 + k + 1] += cj2 * cd.y;
-            }
-          } else {
-#pragma unroll
-            for (int k = 0; k < NCH; k++) { Hrow[6 + k] += cj * S.U[U_J + r * NV + coff + k]; Hrow[6 + k] += cj2 * S.U[U_J + r2 * NV + coff + k]; }
-          }
+          // (round 6: the row's other entries are the `jl` of the other lanes of this half -- row position e holds the dof of column e of
+          // Hrow -- and come through DPP inside the multiply-add: six 16-byte LDS reads per row and their addresses are gone)
+          fmac_outer<NR>(Hrow, jl, cj);
+          fmac_outer<NR>(Hrow, jl2, cj2);
         }
+        GROUP_SYNC(W);   // (the halves leave the loop after different trip counts, and it holds cross-lane operations)
         if (rootb && cross) {   // (dense fallback: the root-root block lives in copy A)
 #pragma unroll
           for (int k = 0; k < 6; k++) Hrow[k] = 0.0;
