@@ -145,14 +145,14 @@ int humanoid_create(HumanoidEnv** out, const std::vector<int32_t>& mi, const std
       return lhw_fail(LHW_ERR_UNSUPPORTED, "box-box pairs are only compiled into the stepping-task kernels");
     // narrow phases that exist (geom1 type <= geom2 type, as MuJoCo orders a pair): a model packed straight from an mjModel
     // (pack_from_mjmodel) does not pass through mjcf.build_pairs, which refuses the others
-    const bool ok = (t1 == G_PLANE && (t2 == G_SPHERE || t2 == G_CAPSULE || t2 == G_BOX || t2 == G_CYLINDER)) ||
+    const bool ok = (t1 == G_PLANE && (t2 == G_SPHERE || t2 == G_CAPSULE || t2 == G_BOX || t2 == G_CYLINDER || t2 == G_ELLIPSOID)) ||
                     (t1 == G_SPHERE && (t2 == G_SPHERE || t2 == G_CAPSULE || t2 == G_BOX || t2 == G_CYLINDER)) ||
                     (t1 == G_CAPSULE && (t2 == G_CAPSULE || t2 == G_BOX)) || (t1 == G_BOX && t2 == G_BOX);
     if (t2 == G_BOX && (t1 == G_SPHERE || t1 == G_CAPSULE)) primbox_pairs++;
-    if (t2 == G_CYLINDER) cyl_pairs++;
-    if (stepping && t2 == G_CYLINDER) return lhw_fail(LHW_ERR_UNSUPPORTED, "cylinder geoms are not compiled into the stepping-task kernels");
+    if (t2 == G_CYLINDER || t2 == G_ELLIPSOID) cyl_pairs++;
+    if (stepping && (t2 == G_CYLINDER || t2 == G_ELLIPSOID)) return lhw_fail(LHW_ERR_UNSUPPORTED, "cylinder / ellipsoid geoms are not compiled into the stepping-task kernels");
     if (!ok) return lhw_fail(LHW_ERR_UNSUPPORTED, "collision pair %d (geoms %d / %d): no narrow phase for geom types %d / %d -- plane, sphere, capsule, box among "
-                             "themselves, cylinders against planes and spheres (MuJoCo resolves the other cylinder pairs, ellipsoids and meshes through its general "
+                             "themselves, cylinders against planes and spheres, ellipsoids against planes (MuJoCo resolves the other cylinder / ellipsoid pairs and meshes through its general "
                              "convex collider): mask the pair with contype / conaffinity or replace the geom by an enclosing capsule / box",
                              q, IF(LHW_IF_PAIR_GEOM1)[q], IF(LHW_IF_PAIR_GEOM2)[q], t1, t2);
   }
@@ -293,6 +293,7 @@ int humanoid_create(HumanoidEnv** out, const std::vector<int32_t>& mi, const std
         if (type == G_CAPSULE) return sz[0] + sz[1];
         if (type == G_BOX) return std::sqrt(sz[0] * sz[0] + sz[1] * sz[1] + sz[2] * sz[2]);
         if (type == G_CYLINDER) return std::sqrt(sz[0] * sz[0] + sz[1] * sz[1]);
+        if (type == G_ELLIPSOID) return std::max(sz[0], std::max(sz[1], sz[2]));
         return 0.0;
       };
       pd[PD_RBOUND1] = rbound(I1[GI_TYPE], G1 + GD_SIZE); pd[PD_RBOUND2] = rbound(I2[GI_TYPE], G2 + GD_SIZE);

@@ -58,7 +58,7 @@
 #define HMINVAL 1e-15
 
 enum { JT_FREE = 0, JT_SLIDE = 2, JT_HINGE = 3 };
-enum { G_PLANE = 0, G_SPHERE = 2, G_CAPSULE = 3, G_CYLINDER = 5, G_BOX = 6 };
+enum { G_PLANE = 0, G_SPHERE = 2, G_CAPSULE = 3, G_ELLIPSOID = 4, G_CYLINDER = 5, G_BOX = 6 };
 enum { MODE_STANDING = 0, MODE_INPLACE = 1, MODE_FORWARD = 2 };
 enum { WALK_CURVED = 0, WALK_STANDING = 1, WALK_BACKWARD = 2, WALK_LATERAL = 3, WALK_FORWARD = 4 };  // stepping_task.py:282-285
 
@@ -1758,7 +1758,19 @@ __device__ void collide_cyl(ConSink<L>& k, HModelRef m, const L& S, int q, int g
   for (int a = 0; a < 3; a++) { p1[a] = S.U[U_GPOS + 3 * g1 + a]; p2[a] = S.U[U_GPOS + 3 * g2 + a]; }
   for (int a = 0; a < 9; a++) { R1[a] = S.U[U_GMAT + 9 * g1 + a]; R2[a] = S.U[U_GMAT + 9 * g2 + a]; }
   const double r1 = m.pair_d[PDS * q + PD_SIZE1], rad = m.pair_d[PDS * q + PD_SIZE2], hl = m.pair_d[PDS * q + PD_SIZE2 + 1];
-  if (t1 == G_PLANE) {
+  if (m.pair_i[PIS * q + PI_TYPE2] == G_ELLIPSOID) {   // plane-ellipsoid (mjc_PlaneConvex on a smooth geom): the support point towards the plane
+    const double n[3] = {R1[2], R1[5], R1[8]}, sz[3] = {rad, hl, m.pair_d[PDS * q + PD_SIZE2 + 2]};
+    double dl[3], v[3], sup[3], pos[3];
+    for (int a = 0; a < 3; a++) dl[a] = -(R2[a] * n[0] + R2[3 + a] * n[1] + R2[6 + a] * n[2]);
+    for (int a = 0; a < 3; a++) v[a] = sz[a] * dl[a];
+    const double len = sqrt(dot3(v, v));
+    for (int a = 0; a < 3; a++) v[a] = sz[a] * v[a] / len;
+    for (int a = 0; a < 3; a++) sup[a] = p2[a] + R2[3 * a] * v[0] + R2[3 * a + 1] * v[1] + R2[3 * a + 2] * v[2];
+    const double dist = (sup[0] - p1[0]) * n[0] + (sup[1] - p1[1]) * n[1] + (sup[2] - p1[2]) * n[2];
+    if (dist > margin) return;
+    for (int a = 0; a < 3; a++) pos[a] = sup[a] - n[a] * dist * 0.5;
+    k.emit(dist, pos, n, zero);
+  } else if (t1 == G_PLANE) {
     const double n[3] = {R1[2], R1[5], R1[8]}, dif[3] = {p2[0] - p1[0], p2[1] - p1[1], p2[2] - p1[2]};
     double axis[3] = {R2[2], R2[5], R2[8]}, vec[3];
     double prjaxis = dot3(n, axis);
@@ -1980,7 +1992,7 @@ __device__ __forceinline__ void fwd_collision(HModelRef m, HParamsRef p, L& S, i
   // (cylinders are compiled into the walking / standing kernels only: in the stepping kernels the extra live state cost 6.5 % of
   // jvrc_step's rate with no cylinder in the model, profiles/r06_jvrc_step_cylinder_ab.txt; humanoid_create refuses them there)
   bool cylpair = false;
-  if constexpr (!BOXBOX) { if (m.has_cyl && have) cylpair = ty2 == G_CYLINDER; }
+  if constexpr (!BOXBOX) { if (m.has_cyl && have) cylpair = ty2 == G_CYLINDER || ty2 == G_ELLIPSOID; }
   // Plane-box pairs (the floor against a foot box; kernels without box-box pairs): lane 8 j + i tests corner i of the j-th such
   // pair -- the same expressions, corner by corner, as collide_pair's loop, which walks the eight corners one after the other on the
   // pair's own lane, twice (counting, writing).  A ballot gives every corner its rank among the corners in contact (the first four

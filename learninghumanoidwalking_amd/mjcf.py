@@ -20,14 +20,15 @@ import xml.etree.ElementTree as ET
 
 import numpy as np
 
-from .model import (GEOM_BOX, GEOM_CAPSULE, GEOM_CYLINDER, GEOM_PLANE, GEOM_SPHERE, JNT_FREE, JNT_HINGE, JNT_SLIDE, Model)
+from .model import (GEOM_BOX, GEOM_CAPSULE, GEOM_CYLINDER, GEOM_ELLIPSOID, GEOM_PLANE, GEOM_SPHERE, JNT_FREE, JNT_HINGE, JNT_SLIDE, Model)
 
 
 class MjcfError(ValueError):
     pass
 
 
-_GEOM_TYPES = {"plane": GEOM_PLANE, "sphere": GEOM_SPHERE, "capsule": GEOM_CAPSULE, "cylinder": GEOM_CYLINDER, "box": GEOM_BOX}
+_GEOM_TYPES = {"plane": GEOM_PLANE, "sphere": GEOM_SPHERE, "capsule": GEOM_CAPSULE, "ellipsoid": GEOM_ELLIPSOID, "cylinder": GEOM_CYLINDER,
+               "box": GEOM_BOX}
 _JNT_TYPES = {"free": JNT_FREE, "slide": JNT_SLIDE, "hinge": JNT_HINGE}
 _INERT_TAGS = {"camera", "light", "sensor", "keyframe", "custom", "visual", "asset", "size", "statistic"}
 
@@ -39,6 +40,7 @@ SUPPORTED_PAIRS = {
     # round 6: the two cylinder pairs MuJoCo resolves analytically (mjc_PlaneCylinder, mjc_SphereCylinder); capsule- / cylinder- / box-cylinder go
     # through its general convex collider there and are refused here
     (GEOM_PLANE, GEOM_CYLINDER), (GEOM_SPHERE, GEOM_CYLINDER),
+    (GEOM_PLANE, GEOM_ELLIPSOID),     # mjc_PlaneConvex on a smooth geom: one contact at the support point
 }
 _TYPE_NAMES = {GEOM_PLANE: "plane", 1: "hfield", GEOM_SPHERE: "sphere", GEOM_CAPSULE: "capsule", 4: "ellipsoid", GEOM_CYLINDER: "cylinder", GEOM_BOX: "box", 7: "mesh"}
 
@@ -295,8 +297,6 @@ class _Compiler:
             name = a.get("name", f"geom{len(self.geoms)}")
             if tname == "mesh":
                 raise MjcfError(f"geom {name!r}: mesh geoms are not supported (replace it by the primitive that encloses it: box, capsule, sphere or cylinder)")
-            if tname == "ellipsoid":
-                raise MjcfError(f"geom {name!r}: ellipsoid geoms are not supported (MuJoCo collides them through its general convex collider; use a capsule or a sphere)")
             raise MjcfError(f"geom {name!r}: unsupported geom type {tname!r}")
         gt = _GEOM_TYPES[tname]
         size = _floats(a.get("size", "0 0 0"))
@@ -349,6 +349,10 @@ class _Compiler:
             izz = mc * r * r / 2 + ms * 0.4 * r * r
             ixx = mc * (r * r / 4 + l * l / 3) + ms * (0.4 * r * r + l * l + 0.75 * r * l)
             return m, np.array([ixx, ixx, izz])
+        if t == GEOM_ELLIPSOID:     # semi-axes s
+            vol = 4.0 / 3.0 * math.pi * s[0] * s[1] * s[2]
+            m = g["mass"] if g["mass"] is not None else vol * g["density"]
+            return m, m / 5.0 * np.array([s[1] ** 2 + s[2] ** 2, s[0] ** 2 + s[2] ** 2, s[0] ** 2 + s[1] ** 2])
         if t == GEOM_CYLINDER:      # radius s[0], half length s[1] along z
             r, l = s[0], s[1]
             vol = math.pi * r * r * 2 * l
@@ -656,8 +660,8 @@ def build_pairs(m: Model, excludes: set) -> tuple[np.ndarray, np.ndarray]:
                         tn = lambda t: _TYPE_NAMES.get(int(t), str(int(t)))
                         raise MjcfError(
                             f"collision pair {m.geom_names[x]} ({tn(gt[x])}) / {m.geom_names[y]} ({tn(gt[y])}) needs a narrow phase that is not "
-                            f"implemented (cylinders collide with planes and spheres only: MuJoCo resolves the other cylinder pairs through its "
-                            f"general convex collider); mask the pair with contype / conaffinity or <exclude>, or replace the cylinder by a capsule")
+                            f"implemented (cylinders collide with planes and spheres, ellipsoids with planes only: MuJoCo resolves their other pairs "
+                            f"through its general convex collider); mask the pair with contype / conaffinity or <exclude>, or replace the geom by a capsule")
                     p1.append(x)
                     p2.append(y)
     return np.array(p1, dtype=np.int32), np.array(p2, dtype=np.int32)

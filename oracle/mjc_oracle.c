@@ -33,7 +33,7 @@
 #define MAXIMP 0.9999
 
 enum { JNT_FREE = 0, JNT_BALL = 1, JNT_SLIDE = 2, JNT_HINGE = 3 };
-enum { GEOM_PLANE = 0, GEOM_SPHERE = 2, GEOM_CAPSULE = 3, GEOM_CYLINDER = 5, GEOM_BOX = 6 };
+enum { GEOM_PLANE = 0, GEOM_SPHERE = 2, GEOM_CAPSULE = 3, GEOM_ELLIPSOID = 4, GEOM_CYLINDER = 5, GEOM_BOX = 6 };
 enum { EFC_FRICTION = 0, EFC_LIMIT = 1, EFC_CONTACT = 2 };
 #define DSBL_WARMSTART (1 << 7)
 #define DSBL_REFSAFE (1 << 11)
@@ -510,6 +510,22 @@ static int sphereCapsule(RawCon* c, const double* p1, double r1, const double* p
 /* mjc_PlaneCylinder [MJ-recall]: the rim point of the cap nearer the plane that lies deepest (along the plane normal with its axial part
  * removed), the corresponding rim point of the other cap, and -- when the near cap is (nearly) flat on the plane -- two more points of the
  * near rim at +-120 degrees from the first; up to four contacts, all with the plane's normal.  size2 = (radius, half length). */
+/* mjc_PlaneConvex for an ellipsoid [MJ-recall]: the support point of the ellipsoid in the direction -normal (analytic: in the geom frame
+ * s_i^2 d_i / |s . d| for semi-axes s and direction d), its signed distance to the plane, one contact half way between the point and the plane. */
+static int planeEllipsoid(RawCon* c, const double* p1, const double* R1, const double* p2, const double* R2, const double* size2, double margin) {
+  const double n[3] = {R1[2], R1[5], R1[8]};
+  double dl[3], v[3], sup[3];
+  for (int k = 0; k < 3; k++) dl[k] = -(R2[k] * n[0] + R2[3 + k] * n[1] + R2[6 + k] * n[2]);        /* R2^T (-n) */
+  for (int k = 0; k < 3; k++) v[k] = size2[k] * dl[k];
+  const double len = sqrt(dot3(v, v));
+  for (int k = 0; k < 3; k++) v[k] = size2[k] * v[k] / len;                                         /* support point, geom frame */
+  for (int k = 0; k < 3; k++) sup[k] = p2[k] + R2[3 * k] * v[0] + R2[3 * k + 1] * v[1] + R2[3 * k + 2] * v[2];
+  const double dist = (sup[0] - p1[0]) * n[0] + (sup[1] - p1[1]) * n[1] + (sup[2] - p1[2]) * n[2];
+  if (dist > margin) return 0;
+  c->dist = dist;
+  for (int k = 0; k < 3; k++) { c->pos[k] = sup[k] - n[k] * dist * 0.5; c->frame[k] = n[k]; c->frame[3 + k] = 0; }
+  return 1;
+}
 static int planeCylinder(RawCon* c, const double* p1, const double* R1, const double* p2, const double* R2, const double* size2, double margin) {
   double n[3] = {R1[2], R1[5], R1[8]}, axis[3] = {R2[2], R2[5], R2[8]}, vec[3], dif[3] = {p2[0] - p1[0], p2[1] - p1[1], p2[2] - p1[2]};
   double prjaxis = dot3(n, axis);
@@ -883,6 +899,7 @@ static void collision(OData* d) {
     else if (t1 == GEOM_SPHERE && t2 == GEOM_CAPSULE) n = sphereCapsule(rc, p1, s1[0], p2, R2, s2, margin);
     else if (t1 == GEOM_CAPSULE && t2 == GEOM_CAPSULE) n = capsuleCapsule(rc, p1, R1, s1, p2, R2, s2, margin);
     else if (t1 == GEOM_PLANE && t2 == GEOM_CYLINDER) n = planeCylinder(rc, p1, R1, p2, R2, s2, margin);
+    else if (t1 == GEOM_PLANE && t2 == GEOM_ELLIPSOID) n = planeEllipsoid(rc, p1, R1, p2, R2, s2, margin);
     else if (t1 == GEOM_SPHERE && t2 == GEOM_CYLINDER) n = sphereCylinder(rc, p1, s1[0], p2, R2, s2, margin);
     else if (t1 == GEOM_SPHERE && t2 == GEOM_BOX) n = sphereBox(rc, p1, s1[0], p2, R2, s2, margin);
     else if (t1 == GEOM_CAPSULE && t2 == GEOM_BOX) n = capsuleBox(rc, p1, R1, s1, p2, R2, s2, margin);

@@ -497,16 +497,17 @@ def _cylinder_case(spec, env, orc):
         env.set_state(oq, ov)
         for o in orc:
             o.set_state(o.sim.qpos.copy(), o.sim.qvel.copy())
-    assert {(0, 5), (2, 5)} <= kinds, kinds
+    assert {(0, 5), (2, 5), (0, 4)} <= kinds, kinds
     assert env.pop_fault_stats() == (0, 0)
 
 
 def test_emulated_cylinder_geoms(tmp_path):
-    """cylinder shanks: the plane-cylinder and sphere-cylinder narrow phases of the kernels against the oracle's"""
+    """cylinder shanks and ellipsoid thighs: the plane-cylinder, sphere-cylinder and plane-ellipsoid narrow phases of the kernels against the
+    oracle's"""
     from oracle.env_jvrc_walk import OracleJvrcWalkEnv
     from tests.cyl_variant import cylinder_spec
     spec = cylinder_spec(tmp_path)
-    n = 4
+    n = 6
     env = emu.make_emulated(spec, n, seed=3)
     orc = [OracleJvrcWalkEnv(spec, seed=3, env_id=i) for i in range(n)]
     _cylinder_case(spec, env, orc)

@@ -76,12 +76,12 @@ def test_jvrc_model_variants(name, tmp_path):
 
 
 def test_cylinder_geoms(tmp_path):
-    """plane-cylinder and sphere-cylinder contacts (tests/cyl_variant.py) through the compiled kernels"""
+    """plane-cylinder, sphere-cylinder and plane-ellipsoid contacts (tests/cyl_variant.py) through the compiled kernels"""
     from oracle.env_jvrc_walk import OracleJvrcWalkEnv
     from tests.cyl_variant import cylinder_spec
     from tests.test_emu_stepper import _cylinder_case
     spec = cylinder_spec(tmp_path)
-    n = 8
+    n = 9
     env = _Numpy(spec.make_batched(n, seed=3, device=0))
     orc = [OracleJvrcWalkEnv(spec, seed=3, env_id=i) for i in range(n)]
     _cylinder_case(spec, env, orc)

@@ -154,10 +154,42 @@ def test_plane_cylinder_and_sphere_cylinder():
     with pytest.raises(mjcf.MjcfError, match="cylinder"):
         _two(f'type="cylinder" size="{r} {hl}"', f'type="capsule" size="0.05 0.2"')
     with pytest.raises(mjcf.MjcfError, match="ellipsoid"):
-        _plane('type="ellipsoid" size="0.1 0.2 0.3"')
+        _two('type="ellipsoid" size="0.1 0.2 0.3"', 'type="sphere" size="0.05"')
     # inertia of a cylinder from its geom (user_objects.cc: m = rho pi r^2 2 l; I_zz = m r^2 / 2, I_xx = m (3 r^2 + (2 l)^2) / 12)
     m2 = mjcf.compile_string(f'<mujoco><compiler inertiafromgeom="true"/><worldbody><body name="c"><freejoint/><geom type="cylinder" size="{r} {hl}" density="1000"/></body></worldbody></mujoco>')
     mass = 1000 * np.pi * r * r * 2 * hl
     b = m2.body_id("c")
     assert abs(m2.arrays["body_mass"][b] - mass) < 1e-9
     np.testing.assert_allclose(sorted(m2.arrays["body_inertia"][b]), sorted([mass * r * r / 2, mass * (3 * r * r + 4 * hl * hl) / 12, mass * (3 * r * r + 4 * hl * hl) / 12]), rtol=1e-12)
+
+
+def test_plane_ellipsoid():
+    """round 6: plane-ellipsoid (mjc_PlaneConvex on a smooth geom, from recall): one contact at the ellipsoid's support point towards the plane.
+    Closed forms: axis-aligned, the support point is the end of the semi-axis along the normal; rotated, the height of the lowest point of an
+    ellipsoid is sqrt(sum_i (s_i R_zi)^2) below its centre."""
+    sz = np.array([0.1, 0.2, 0.3])
+    m, s = _plane('type="ellipsoid" size="0.1 0.2 0.3"')
+    _set(s, [0.4, -0.1, sz[2] - 0.002])
+    (c,) = _cons(s)
+    assert c["geom1"] == m.geom_id("floor") and abs(c["dist"] + 0.002) < 1e-12
+    np.testing.assert_allclose(c["frame"][0], [0, 0, 1], atol=1e-15)
+    np.testing.assert_allclose(c["pos"], [0.4, -0.1, -0.001], atol=1e-12)
+    _set(s, [0, 0, sz[2] + 1e-3])
+    assert _cons(s) == []
+    rs = np.random.default_rng(0)
+    for _ in range(20):
+        q = rs.normal(size=4); q /= np.linalg.norm(q)
+        R = mjcf.quat2mat(q)
+        h = float(np.sqrt(((sz * R[2, :]) ** 2).sum()))            # centre height at which the ellipsoid touches z = 0
+        _set(s, [0.1, 0.2, h - 0.003], q)
+        (c,) = _cons(s)
+        assert abs(c["dist"] + 0.003) < 1e-12
+        # the support point: the surface point whose outward normal is -z, i.e. x_local = -S^2 R^T z / |S R^T z|
+        sup = np.array([0.1, 0.2, h - 0.003]) + R @ (-(sz ** 2) * R[2, :] / h)
+        np.testing.assert_allclose(c["pos"], sup + np.array([0, 0, 0.0015]), atol=1e-12)
+    # inertia of an ellipsoid from its geom: m = rho 4/3 pi a b c, I = m / 5 (b^2 + c^2, a^2 + c^2, a^2 + b^2)
+    m2 = mjcf.compile_string('<mujoco><compiler inertiafromgeom="true"/><worldbody><body name="e"><freejoint/><geom type="ellipsoid" size="0.1 0.2 0.3" density="800"/></body></worldbody></mujoco>')
+    mass = 800 * 4 / 3 * np.pi * 0.1 * 0.2 * 0.3
+    b = m2.body_id("e")
+    assert abs(m2.arrays["body_mass"][b] - mass) < 1e-9
+    np.testing.assert_allclose(sorted(m2.arrays["body_inertia"][b]), sorted(mass / 5 * np.array([0.13, 0.10, 0.05])), rtol=1e-12)
