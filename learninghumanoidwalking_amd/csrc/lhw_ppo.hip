@@ -1578,13 +1578,23 @@ extern "C" int lhw_ppo_grad(LhwPpo* p, const float* theta, float* grad, const fl
   hipStream_t s = (hipStream_t)stream;
   const int R = p->max_rows, Dp = p->la.Dp, Op = p->la.Op;
   size_t n = (size_t)B * Dp;
-  hipLaunchKernelGGL(gather_kernel, dim3((n + 255) / 256), dim3(256), 0, s, idx, B, R, Dp, p->A, xn, mir ? xm : nullptr, act, old_logp,
-                     adv, ret, p->xb, p->mb_act, p->mb_logp, p->mb_adv, p->mb_ret);
   const float* th_a = theta + p->off_actor;
   const float* th_c = theta + p->off_critic;
   hipStream_t sc = p->two_streams ? p->side : s;   // the critic's chain
   auto fork = [&]() { if (sc != s) { (void)hipEventRecord(p->ev_fork, s); (void)hipStreamWaitEvent(sc, p->ev_fork, 0); } };
   auto join = [&]() { if (sc != s) { (void)hipEventRecord(p->ev_join, sc); (void)hipStreamWaitEvent(s, p->ev_join, 0); } };
+  // the [in][out] weight copies of the forward strips are made on the side stream while the minibatch is gathered (round 6: the two
+  // 9 us transposes were the first links of the step's chain)
+  const bool strips = strip_mode() >= 1 && !p->update_half && p->wt_a && p->wt_c && mlp_strip_supported(p->la.H, p->la.Dp, p->la.O, p->la.Op) &&
+                      mlp_strip_supported(p->lc.H, p->lc.Dp, p->lc.O, p->lc.Op);
+  if (strips) {
+    fork();
+    mlp_strip_prepare(th_a + p->la.w1, th_a + p->la.w2, th_a + p->la.w3, p->la.Dp, p->la.O, p->la.Op, p->wt_a, sc);
+    mlp_strip_prepare(th_c + p->lc.w1, th_c + p->lc.w2, th_c + p->lc.w3, p->lc.Dp, p->lc.O, p->lc.Op, p->wt_c, sc);
+  }
+  hipLaunchKernelGGL(gather_kernel, dim3((n + 255) / 256), dim3(256), 0, s, idx, B, R, Dp, p->A, xn, mir ? xm : nullptr, act, old_logp,
+                     adv, ret, p->xb, p->mb_act, p->mb_logp, p->mb_adv, p->mb_ret);
+  if (strips) join();
   // --fp16 update with fp16 storage: fp16 copies of the gathered rows; every activation the GEMMs exchange stays fp16 in HBM
   const bool hstore = p->update_half && p->xb_h != nullptr;
   HalfBufs ha{}, hc{}, ham{};
@@ -1608,13 +1618,13 @@ extern "C" int lhw_ppo_grad(LhwPpo* p, const float* theta, float* grad, const fl
   const size_t bw = mlp_strip_bits_words(R);
   unsigned *ba1 = p->bits_a, *ba2 = p->bits_a ? p->bits_a + 2 * bw : nullptr, *bc1 = p->bits_c, *bc2 = p->bits_c ? p->bits_c + bw : nullptr;
   fork();
-  mlp_forward(p->lc, th_c, p->xb, Dp, B, p->h1c, p->h2c, p->yc, sc, p->update_half, strip_mode() >= 1 ? p->wt_c : nullptr, false, true, phc, bc1, bc2);
+  mlp_forward(p->lc, th_c, p->xb, Dp, B, p->h1c, p->h2c, p->yc, sc, p->update_half, strip_mode() >= 1 ? p->wt_c : nullptr, strips, true, phc, bc1, bc2);
   if (mir && B == R) {
-    mlp_forward(p->la, th_a, p->xb, Dp, 2 * B, p->h1a, p->h2a, p->ya, s, p->update_half, strip_mode() >= 1 ? p->wt_a : nullptr, false, true, pha, ba1, ba2);   // mirrored rows follow without a gap
+    mlp_forward(p->la, th_a, p->xb, Dp, 2 * B, p->h1a, p->h2a, p->ya, s, p->update_half, strip_mode() >= 1 ? p->wt_a : nullptr, strips, true, pha, ba1, ba2);   // mirrored rows follow without a gap
   } else {
-    mlp_forward(p->la, th_a, p->xb, Dp, B, p->h1a, p->h2a, p->ya, s, p->update_half, strip_mode() >= 1 ? p->wt_a : nullptr, false, true, pha, ba1, ba2);
+    mlp_forward(p->la, th_a, p->xb, Dp, B, p->h1a, p->h2a, p->ya, s, p->update_half, strip_mode() >= 1 ? p->wt_a : nullptr, strips, true, pha, ba1, ba2);
     if (mir)
-      mlp_forward(p->la, th_a, p->xb + (size_t)R * Dp, Dp, B, p->h1a + (size_t)R * p->H, p->h2a + (size_t)R * p->H, p->ya + (size_t)R * Op, s, p->update_half, strip_mode() >= 1 ? p->wt_a : nullptr, false, true, pham,
+      mlp_forward(p->la, th_a, p->xb + (size_t)R * Dp, Dp, B, p->h1a + (size_t)R * p->H, p->h2a + (size_t)R * p->H, p->ya + (size_t)R * Op, s, p->update_half, strip_mode() >= 1 ? p->wt_a : nullptr, strips, true, pham,
                   ba1 ? ba1 + bw : nullptr, ba2 ? ba2 + bw : nullptr);
   }
   join();
@@ -1628,7 +1638,6 @@ extern "C" int lhw_ppo_grad(LhwPpo* p, const float* theta, float* grad, const fl
                      p->dyc, p->learn_std ? p->dstd : (float*)nullptr, p->stats_part, p->imit_target, p->imit_mask, p->imit_coeff,
                      p->imit_inv_count, 0, lscale);
   p->imit_target = nullptr; p->imit_mask = nullptr;   // armed for one call only
-  hipLaunchKernelGGL(reduce_rows_kernel, dim3(1), dim3(64), 0, s, p->stats_part, nblk, NSTAT, stats_dev);
   if (p->learn_std) {
     colsum_det(p->dstd, B, Op, p->A, grad + p->off_std, p->part, s);
     hipLaunchKernelGGL(entropy_grad_kernel, dim3(1), dim3(64), 0, s, theta + p->off_std, p->A, p->ent_coeff, grad + p->off_std);
@@ -1637,6 +1646,8 @@ extern "C" int lhw_ppo_grad(LhwPpo* p, const float* theta, float* grad, const fl
   const BwdParts Pc = bwd_parts_carve(p->lc, R, 1, p->bwd_part + bwd_parts_floats(p->la, R, 2));
   BwdSlices za, zc;
   fork();
+  // (the step's loss statistics -- logging only -- are summed at the head of the side stream, off the actor's chain)
+  hipLaunchKernelGGL(reduce_rows_kernel, dim3(1), dim3(64), 0, sc, p->stats_part, nblk, NSTAT, stats_dev);
   mlp_backward(p->lc, th_c, p->xb, Dp, B, p->h1c, p->h2c, p->dyc, p->dh2c, p->dh1c, Pc, zc, sc, p->update_half, phc, bc1, bc2);
   if (mir && B == R) {
     // the mirrored rows follow the normal ones without a gap: one pass over 2B rows
