@@ -322,7 +322,8 @@ class Rollout:
 
     def _collect_resident(self, deterministic) -> bool:
         """All T control steps in one launch per rollout group, the actor evaluated inside the stepper's wavefronts
-        (BatchedEnv.rollout): bitwise the values of the launch-per-step loop below, without its per-control-step barrier across
+        (BatchedEnv.rollout): bitwise the values of the launch-per-step loop below (float32 inference; with fp16 inference float32-rounding-close),
+        without its per-control-step barrier across
         the envs of a group.  LHW_ROLLOUT_MODE = auto (default) | resident | steps (the launch-per-step pipeline)."""
         env, k, T = self.env, self.k, self.T
         mode = os.environ.get("LHW_ROLLOUT_MODE", "auto")

@@ -189,8 +189,10 @@ class PpoKernels:
 
     def rollout_policy(self, *, seed=0, counter=0, deterministic=False):
         """The frozen actor as the resident rollout (BatchedEnv.rollout -> lhw_env_rollout) evaluates it inside the stepper's
-        wavefronts; valid inside a begin_rollout() bracket.  Returns None where the in-wave policy step does not apply (fp16
-        inference, shapes outside the strip kernels): the caller keeps the launch-per-step pipeline."""
+        wavefronts; valid inside a begin_rollout() bracket.  Returns None where the in-wave policy step does not apply (shapes outside
+        the strip kernels): the caller keeps the launch-per-step pipeline.  With fp16 inference the view carries fp16_operands = 1: the
+        in-wave policy step then rounds its operands to fp16 like the launch-per-step fp16 GEMMs do, but sums in another order -- that
+        resident rollout is float32-rounding-close (~1e-6) to the launch-per-step one, not bitwise (the float32 policy step is bitwise)."""
         view = _lib.LhwRolloutPolicy()
         rc = self._L.lhw_ppo_rollout_policy(self._h, _p(self.theta), _p(self.obs_mean), _p(self.obs_std), int(seed) & (2**64 - 1),
                                             int(counter) & 0xFFFFFFFF, int(bool(deterministic)), ctypes.byref(view))
