@@ -2818,7 +2818,11 @@ __device__ __forceinline__ void solve_tail(HModelRef m, HParamsRef p, L& S, cons
   const double qv = dof >= 0 ? S.qvel[dd] : 0.0;
   if (dof >= 0) {
     const int d = dof;
+    // (every model constant the tests below read is requested here, in ONE batch of loads: inside their branches the limit test was a second,
+    // dependent round trip to the tables behind the first -- kind / limited, then address / margin / range)
     const double fl = prm_floss(m, S, d);
+    const int u_kind = m.dof_i[DIS * d + DI_KIND], u_limited = m.dof_i[DIS * d + DI_LIMITED], u_qadr = m.dof_i[DIS * d + DI_QADR];
+    const double u_mg = m.dof_d[DDS * d + DD_MARGIN], u_lo = m.dof_d[DDS * d + DD_RANGE], u_hi = m.dof_d[DDS * d + DD_RANGE + 1];
     if (fl > 0) {
       double sr[2] = {m.dof_d[DDS * d + DD_SOLREF], m.dof_d[DDS * d + DD_SOLREF + 1]}, si[5], K, B, imp, R;
       for (int a = 0; a < 5; a++) si[a] = m.dof_d[DDS * d + DD_SOLIMP + a];
@@ -2826,9 +2830,9 @@ __device__ __forceinline__ void solve_tail(HModelRef m, HParamsRef p, L& S, cons
       uon[0] = true; uD[0] = qdiv(1, R); uaref[0] = -B * qv; ufl = fl;
     }
     const int j = m.dof_i[DIS * d + DI_JNT];
-    if (m.dof_i[DIS * d + DI_KIND] >= 2 && m.dof_i[DIS * d + DI_LIMITED]) {
-      const double q = S.qpos[m.dof_i[DIS * d + DI_QADR]], mg = m.dof_d[DDS * d + DD_MARGIN];
-      const double dlo = q - m.dof_d[DDS * d + DD_RANGE], dhi = m.dof_d[DDS * d + DD_RANGE + 1] - q;
+    if (u_kind >= 2 && u_limited) {
+      const double q = S.qpos[u_qadr], mg = u_mg;
+      const double dlo = q - u_lo, dhi = u_hi - q;
       if (dlo < mg || dhi < mg) {
         double sr[2] = {m.jnt_d[JDS * j + JD_SOLREF], m.jnt_d[JDS * j + JD_SOLREF + 1]}, si[5], K, B, imp, R;
         for (int a = 0; a < 5; a++) si[a] = m.jnt_d[JDS * j + JD_SOLIMP + a];
