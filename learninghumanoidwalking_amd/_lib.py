@@ -73,7 +73,11 @@ def sources():
 # source expression only: the same source gives the same arithmetic in every kernel (measured: same speed, both kernels bitwise
 # equal on all four humanoid tasks).  The GEMM / strip / cartpole kernels keep the default pipeline.
 _STEPPER_FLAGS = ["-mllvm", "-disable-machine-licm", "-ffp-contract=on"]
-EXTRA_FLAGS = {"lhw_humanoid.hip": _STEPPER_FLAGS, "lhw_humanoid_rollout.hip": _STEPPER_FLAGS}
+# -amdgpu-sched-strategy=max-ilp (round 6, the stepping task's rollout kernels only -- a translation unit of their own): one env per wave
+# leaves a third of the lanes idle and the instruction stream latency-bound; scheduling for ILP instead of register pressure makes
+# jvrc_step's rollout 1.7 % faster (the two-envs-per-wave kernels lose 2.6 % under it, and with machine LICM back on the stepping kernels lose 50 %).
+EXTRA_FLAGS = {"lhw_humanoid.hip": _STEPPER_FLAGS, "lhw_humanoid_rollout.hip": _STEPPER_FLAGS,
+               "lhw_humanoid_rollout_step.hip": _STEPPER_FLAGS + ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]}
 
 
 def _stale(deps) -> bool:

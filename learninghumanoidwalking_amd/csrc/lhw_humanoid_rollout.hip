@@ -312,6 +312,16 @@ __global__ void __launch_bounds__(64, LHW_WAVES_PER_SIMD) humanoid_rollout_kerne
 }
 
 // ------------------------------------------------------------------------------------------------ host side
+// The stepping task's two instantiations live in a translation unit of their own, lhw_humanoid_rollout_step.hip (this file included with
+// LHW_ROLLOUT_STEP_TU defined): it is compiled with LLVM's max-ILP scheduling strategy, which makes the one-env-per-wave kernels 1.7 % faster and
+// the two-envs-per-wave kernels 2.6 % slower (profiles/r06_stepper_compiler_flags.txt) -- and the two halves compile in parallel.
+void humanoid_rollout_launch_step(bool queued, dim3 grid, hipStream_t s, const HModel* m_dev, const HParams* p_dev, HLaunch lz, HState st, HRollout ro);
+#ifdef LHW_ROLLOUT_STEP_TU
+void humanoid_rollout_launch_step(bool queued, dim3 grid, hipStream_t s, const HModel* m_dev, const HParams* p_dev, HLaunch lz, HState st, HRollout ro) {
+  if (queued) hipLaunchKernelGGL((humanoid_rollout_kernel<TASK_STEP, 64, true>), grid, dim3(64), 0, s, m_dev, p_dev, lz, st, ro);
+  else hipLaunchKernelGGL((humanoid_rollout_kernel<TASK_STEP, 64, false>), grid, dim3(64), 0, s, m_dev, p_dev, lz, st, ro);
+}
+#else
 #ifdef LHW_ONLY_WALK
 #define ROLLOUT_OTHER_TASKS(WIDTH)
 #else
@@ -378,9 +388,9 @@ int humanoid_rollout(HumanoidEnv* h, int first, int count, int T, const LhwRollo
     ROLLOUT_OTHER_TASKS(32)
   } else {
 #ifndef LHW_ONLY_WALK
-    if (ro.queue) hipLaunchKernelGGL((humanoid_rollout_kernel<TASK_STEP, 64, true>), grid, dim3(64), 0, s, (const HModel*)h->m_dev, (const HParams*)h->p_dev, lz, st, ro);
-    else hipLaunchKernelGGL((humanoid_rollout_kernel<TASK_STEP, 64, false>), grid, dim3(64), 0, s, (const HModel*)h->m_dev, (const HParams*)h->p_dev, lz, st, ro);
+    humanoid_rollout_launch_step(ro.queue != nullptr, grid, s, (const HModel*)h->m_dev, (const HParams*)h->p_dev, lz, st, ro);
 #endif
   }
   return 0;
 }
+#endif   // LHW_ROLLOUT_STEP_TU

@@ -7,7 +7,9 @@ NAME=$1; shift
 D=learninghumanoidwalking_amd/variants; mkdir -p $D/obj_$NAME
 C="/opt/rocm/bin/hipcc --offload-arch=gfx950 ${OPT:--O3} -std=c++17 -fPIC -w"
 for f in learninghumanoidwalking_amd/csrc/*.hip; do
-  X=""; case "$(basename $f)" in lhw_humanoid*.hip) X="${HFLAGS--mllvm -disable-machine-licm -ffp-contract=on}";; esac
+  X=""; case "$(basename $f)" in
+    lhw_humanoid_rollout_step.hip) X="${HFLAGS--mllvm -disable-machine-licm -ffp-contract=on} ${STEPFLAGS--mllvm -amdgpu-sched-strategy=max-ilp}";;
+    lhw_humanoid*.hip) X="${HFLAGS--mllvm -disable-machine-licm -ffp-contract=on}";; esac
   $C $X "$@" -c $f -o $D/obj_$NAME/$(basename $f).o &
 done
 wait

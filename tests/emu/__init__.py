@@ -21,7 +21,7 @@ _ROOT = os.path.dirname(os.path.dirname(_HERE))
 _CSRC = os.path.join(_ROOT, "learninghumanoidwalking_amd", "csrc")
 _BUILD = os.path.join(_HERE, "_build")
 LIB_PATH = os.path.join(_BUILD, "liblhw_emu.so")
-SOURCES = ["lhw_humanoid.hip", "lhw_humanoid_rollout.hip", "lhw_cartpole.hip", "lhw_api.hip", "lhw_mlp_strip.hip"]
+SOURCES = ["lhw_humanoid.hip", "lhw_humanoid_rollout.hip", "lhw_humanoid_rollout_step.hip", "lhw_cartpole.hip", "lhw_api.hip", "lhw_mlp_strip.hip"]
 _LIB = None
 
 
