@@ -73,11 +73,16 @@ def sources():
 # source expression only: the same source gives the same arithmetic in every kernel (measured: same speed, both kernels bitwise
 # equal on all four humanoid tasks).  The GEMM / strip / cartpole kernels keep the default pipeline.
 _STEPPER_FLAGS = ["-mllvm", "-disable-machine-licm", "-ffp-contract=on"]
-# -amdgpu-sched-strategy=max-ilp (round 6, the stepping task's rollout kernels only -- a translation unit of their own): one env per wave
-# leaves a third of the lanes idle and the instruction stream latency-bound; scheduling for ILP instead of register pressure makes
-# jvrc_step's rollout 1.7 % faster (the two-envs-per-wave kernels lose 2.6 % under it, and with machine LICM back on the stepping kernels lose 50 %).
-EXTRA_FLAGS = {"lhw_humanoid.hip": _STEPPER_FLAGS, "lhw_humanoid_rollout.hip": _STEPPER_FLAGS,
-               "lhw_humanoid_rollout_step.hip": _STEPPER_FLAGS + ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]}
+# -amdgpu-sched-strategy=iterative-ilp (round 6, the stepping task's rollout kernels only -- a translation unit of their own): one env per
+# wave leaves a third of the lanes idle and the instruction stream latency-bound; LLVM's iterative ILP scheduler makes jvrc_step's rollout
+# 3 % faster than the default strategy (max-ilp: 1 %, iterative-maxocc: 2 %, iterative-minreg: 4 % slower).  The two-envs-per-wave kernels
+# lose 2.6 % under max-ilp, and this ROCm's clang crashes on their translation unit under iterative-ilp, so they keep the default;
+# with machine LICM back on the stepping kernels lose 50 % (profiles/r06_stepper_compiler_flags.txt).
+# -amdgpu-sched-strategy=iterative-maxocc (round 6, the other stepper translation units): LLVM's iterative scheduler aiming at the kernel's
+# occupancy target -- the same 254 VGPRs and no spills, jvrc_walk's rollout 1.8 % faster than under the default strategy.
+_MAXOCC = ["-mllvm", "-amdgpu-sched-strategy=iterative-maxocc"]
+EXTRA_FLAGS = {"lhw_humanoid.hip": _STEPPER_FLAGS + _MAXOCC, "lhw_humanoid_rollout.hip": _STEPPER_FLAGS + _MAXOCC,
+               "lhw_humanoid_rollout_step.hip": _STEPPER_FLAGS + ["-mllvm", "-amdgpu-sched-strategy=iterative-ilp"]}
 
 
 def _stale(deps) -> bool:

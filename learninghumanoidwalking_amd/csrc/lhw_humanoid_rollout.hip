@@ -313,8 +313,8 @@ __global__ void __launch_bounds__(64, LHW_WAVES_PER_SIMD) humanoid_rollout_kerne
 
 // ------------------------------------------------------------------------------------------------ host side
 // The stepping task's two instantiations live in a translation unit of their own, lhw_humanoid_rollout_step.hip (this file included with
-// LHW_ROLLOUT_STEP_TU defined): it is compiled with LLVM's max-ILP scheduling strategy, which makes the one-env-per-wave kernels 1.7 % faster and
-// the two-envs-per-wave kernels 2.6 % slower (profiles/r06_stepper_compiler_flags.txt) -- and the two halves compile in parallel.
+// LHW_ROLLOUT_STEP_TU defined): it is compiled with LLVM's iterative ILP scheduling strategy, which makes the one-env-per-wave kernels 3 % faster
+// (the two-envs-per-wave kernels keep the default strategy: profiles/r06_stepper_compiler_flags.txt) -- and the two halves compile in parallel.
 void humanoid_rollout_launch_step(bool queued, dim3 grid, hipStream_t s, const HModel* m_dev, const HParams* p_dev, HLaunch lz, HState st, HRollout ro);
 #ifdef LHW_ROLLOUT_STEP_TU
 void humanoid_rollout_launch_step(bool queued, dim3 grid, hipStream_t s, const HModel* m_dev, const HParams* p_dev, HLaunch lz, HState st, HRollout ro) {
